@@ -1,0 +1,173 @@
+/*
+ * said_hip.h — C ABI of the MI355X (gfx950) engine behind said_amd.
+ *
+ * The reference (yunik1004/SAiD) has no FFI/plugin interface: its boundary for
+ * the denoising path is the Python class surface of said/model/diffusion.py.
+ * This header is the C-ABI seam the build's own `said_amd.model.*` classes bind
+ * with ctypes; every entry point names the reference
+ * method/lines whose device work it replaces.  All paths are relative to
+ * /root/reference.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error;
+ *     said_last_error(ctx) (or said_last_error(NULL) for create failures) gives
+ *     the message.  Nothing here ever falls back to a CPU path.
+ *   - `*_dev` pointers are device pointers (e.g. torch.Tensor.data_ptr()) owned
+ *     by the caller; `*_host` pointers are host memory.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream()
+ *     .cuda_stream); all work is enqueued on it, no call synchronises the
+ *     device unless documented.
+ *   - tensors crossing the ABI use the reference's layouts: coefficients
+ *     (B, T, 32) fp32 row-major, audio features (B, S, D) fp32 row-major,
+ *     waveforms (B, Ta) fp32.
+ */
+#ifndef SAID_HIP_H
+#define SAID_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct said_ctx said_ctx;
+
+/* prediction_type of the noise scheduler (diffusion.py:100-104) */
+enum { SAID_PRED_EPSILON = 0, SAID_PRED_SAMPLE = 1, SAID_PRED_V = 2 };
+
+/* ---- lifecycle ---------------------------------------------------------- */
+
+/* Replaces the device-side part of SAID_UNet1D.__init__ (diffusion.py:478-527):
+ * allocates every activation/workspace buffer once, sized for `max_batch_eff`
+ * samples through the UNet at a time (= 2*B under classifier-free guidance) of
+ * at most `max_frames` frames.  `ctx_dim` is the cross-attention feature size
+ * (768, or feature_dim when > 0); `in_channels` the coefficient width (32). */
+int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, int in_channels, int ctx_dim);
+int said_destroy(said_ctx* ctx);
+const char* said_last_error(const said_ctx* ctx);
+/* ABI version of this library (bumped on any signature change). */
+int said_abi_version(void);
+
+/* ---- weights ------------------------------------------------------------ */
+
+/* Replaces `.load_state_dict(...)` + `.to(device)` (script/inference.py:157-158).
+ * `name` is the reference state-dict key: "null_cond_emb",
+ * "denoiser.model.*", "audio_encoder.*" (transformers-4.30.2 naming, i.e.
+ * "...pos_conv_embed.conv.weight_g/weight_v"), optional "audio_proj_layer.*".
+ * Data is copied; fp32, C-contiguous. */
+int said_set_weight(said_ctx* ctx, const char* name, const float* data_host, const int64_t* shape, int ndim);
+/* Validates the key set strictly (like load_state_dict(strict=True)), packs
+ * every GEMM weight into MFMA fragment order and uploads.  Must be called once
+ * after the last said_set_weight and before any compute call. */
+int said_finalize_weights(said_ctx* ctx, void* stream);
+
+/* Optional: the sinusoid frequency table of ldm/util.py:78-82
+ * (exp(-ln(10000) * arange(half) / half), fp32) as computed by the host in the
+ * reference's own op order.  If never called the engine derives it from a
+ * double-precision exp rounded to fp32. */
+int said_set_timestep_freqs(said_ctx* ctx, const float* freqs_host, int n);
+
+/* ---- audio path (once per clip) ----------------------------------------- */
+
+/* Replaces SAID.get_audio_embedding (diffusion.py:209-230) →
+ * ModifiedWav2Vec2Model.forward (said/model/wav2vec2.py:13-82): conv feature
+ * extractor, linear interpolation to `num_frames` (<=0: none), projection,
+ * positional conv, transformer encoder; with apply_proj != 0 also the
+ * audio_proj_layer Linear(768, feature_dim) of diffusion.py:228-229.
+ * waveform_dev (B, Ta) → out_dev (B, F, D), D = 768 or feature_dim.  *out_frames receives F. */
+int said_audio_encode(said_ctx* ctx, const float* waveform_dev, int batch, int num_samples, int num_frames,
+                      int apply_proj, float* out_dev, int* out_frames, void* stream);
+
+/* ---- denoiser: one evaluation ------------------------------------------- */
+
+/* Replaces SAID.forward (diffusion.py:127-155) → UNet1DConditionModel.forward
+ * (said/model/unet_1d_condition.py:51-77) → UNetModel.forward
+ * (said/model/ldm/openaimodel.py:677-709).  sample_dev (Be, T, C_in),
+ * timesteps_host (Be) int64, context_dev (Be, S, ctx_dim) → out_dev (Be, T, C_in). */
+int said_unet_forward(said_ctx* ctx, const float* sample_dev, const int64_t* timesteps_host, const float* context_dev,
+                      int batch_eff, int frames, int ctx_len, float* out_dev, void* stream);
+
+/* ---- denoising loop (diffusion.py:354-472) ------------------------------ */
+
+typedef struct said_loop_params {
+    int batch;               /* B clips (UNet batch is 2*B when guidance_scale > 1) */
+    int frames;              /* T = window_size */
+    int num_steps;           /* number of scheduler steps actually run (len(timesteps[t_start:])) */
+    int prediction_type;     /* SAID_PRED_* */
+    float guidance_scale;    /* CFG active iff > 1.0 (diffusion.py:358) */
+    float guidance_rescale;  /* rescale_noise_cfg phi, active iff > 0 (diffusion.py:436-439) */
+    float latent_scale;      /* diffusion.py:370, 470 */
+    int use_step_noise;      /* eta > 0: add sigma_t * step_noise[k] (scheduler.step) */
+    int use_mask;            /* editing: blend with re-noised init each step (diffusion.py:446-456) */
+    int save_intermediate;   /* write pre-step latents / latent_scale per step (diffusion.py:417-419) */
+    /* host tables, num_steps entries each, produced by the host scheduler in fp32 */
+    const int64_t* timesteps_host;   /* scheduler.timesteps[t_start:] */
+    const float* coef_host;          /* [num_steps][SAID_NCOEF], see SAID_COEF_* */
+    /* device tensors, reference layouts */
+    const float* context_dev;        /* (B, S=T, ctx_dim) conditional audio embedding */
+    float* latents_dev;              /* (B, T, C) in: start latents (already noised/scaled); out: final latents */
+    const float* step_noise_dev;     /* (num_steps, B, T, C) or NULL */
+    const float* init_latents_dev;   /* (B, T, C) clean init (editing) or NULL */
+    const float* edit_noise_dev;     /* (B, T, C) noise drawn by add_noise (diffusion.py:383-385) or NULL */
+    const float* mask_dev;           /* (B, T, C) or NULL */
+    float* intermediates_dev;        /* (num_steps, B, T, C) or NULL */
+    float* result_dev;               /* (B, T, C): clamp(latents / latent_scale, 0, 1) (diffusion.py:470) */
+} said_loop_params;
+
+/* columns of coef_host (all fp32, computed on the host in the scheduler's op order) */
+enum {
+    SAID_COEF_SQRT_ALPHA_T = 0,   /* alpha_prod_t ** 0.5                       */
+    SAID_COEF_SQRT_BETA_T = 1,    /* (1 - alpha_prod_t) ** 0.5                 */
+    SAID_COEF_SQRT_ALPHA_PREV = 2,/* alpha_prod_t_prev ** 0.5                  */
+    SAID_COEF_DIR = 3,            /* (1 - alpha_prod_t_prev - sigma**2) ** 0.5 */
+    SAID_COEF_SIGMA = 4,          /* eta * variance ** 0.5                     */
+    SAID_COEF_NEXT_SQRT_ALPHA = 5,/* add_noise coefficient at t_next (mask blend), 1 on the last step */
+    SAID_COEF_NEXT_SQRT_BETA = 6, /* add_noise coefficient at t_next, 0 on the last step               */
+    SAID_NCOEF = 8
+};
+
+/* Runs the whole loop: per step one hipGraph replay covering the UNet, the CFG
+ * combine, the scheduler update and the mask blend.  Asynchronous on `stream`. */
+int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream);
+
+/* ---- scheduler arithmetic on its own (bit-exactness tests) -------------- */
+
+/* One DDIMScheduler.step (+ optional CFG combine and mask blend) as a plain
+ * elementwise kernel over n = B*T*C values, using the same device function the
+ * loop uses.  eps_uncond_dev may be NULL (no guidance).  coef = one row of
+ * coef_host.  Replaces diffusers' DDIMScheduler.step / add_noise as called at
+ * diffusion.py:441-443, 451-454. */
+int said_ddim_step(said_ctx* ctx, const float* eps_dev, const float* eps_uncond_dev, float guidance_scale,
+                   const float* sample_dev, const float* coef_host, int prediction_type,
+                   const float* step_noise_dev, const float* init_latents_dev, const float* edit_noise_dev,
+                   const float* mask_dev, float* prev_sample_dev, int64_t n, void* stream);
+
+/* out[b, i] = a[b] * x[b, i] + c[b] * y[b, i] with each product and the sum rounded
+ * separately (no FMA): DDIMScheduler.add_noise / get_velocity as called at
+ * diffusion.py:271-272, 383-385 (velocity: a = sqrt_alpha, x = noise, c = -sqrt_beta,
+ * y = sample).  a_host/c_host have `batch` entries; y_dev may be NULL (c ignored). */
+int said_axpby(said_ctx* ctx, const float* a_host, const float* x_dev, const float* c_host, const float* y_dev,
+               float* out_dev, int batch, int64_t n_per_batch, void* stream);
+
+/* ---- introspection ------------------------------------------------------- */
+
+/* Number of kernel launches captured in the current per-step graph (0 if none). */
+int said_graph_num_nodes(const said_ctx* ctx);
+/* Algorithmic bytes / flops of one UNet evaluation for (batch_eff, frames),
+ * SURVEY.md §8(d) formulas; used by bench.py's roofline block. */
+double said_unet_algorithmic_bytes(int batch_eff, int frames, int bytes_per_elem);
+double said_unet_algorithmic_flops(int batch_eff, int frames);
+
+/* ---- debugging aids (used by tests/ only) ---------------------------------- */
+
+/* Stop the UNet schedule after `n_launches` kernel launches (< 0: run everything). */
+int said_debug_stop_after(said_ctx* ctx, int n_launches);
+/* Synchronously copy `n` floats from the start of the named internal buffer
+ * ("H0","H1","P","Q","M","X1","X2","X3","O","QK","VT","F","KV","CTX","EO","E0","E1","E2",
+ *  "x","eps","stH0","stP","stM", ...) to host memory. */
+int said_debug_read(said_ctx* ctx, const char* name, float* out_host, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAID_HIP_H */

@@ -18,6 +18,15 @@ MODEL_CH = 192
 HEADS = 6
 HEAD_DIM = 32
 
+# Optional stage trace for kernel bring-up (tests/debug_stages.py): when set to a list, every
+# tensor that one HIP kernel launch materialises is appended as (name, tensor), in launch order.
+TRACE = None
+
+
+def _t(name: str, x: torch.Tensor) -> None:
+    if TRACE is not None:
+        TRACE.append((name, x.detach().clone()))
+
 
 def timestep_embedding(timesteps: torch.Tensor, dim: int, max_period: int = 10000) -> torch.Tensor:
     """ldm/util.py:66-90 — ``[cos(t·f), sin(t·f)]``, cos half first."""
@@ -45,11 +54,13 @@ def res_block(sd: SD, p: str, x: torch.Tensor, emb: torch.Tensor) -> torch.Tenso
     h = F.conv1d(h, sd[p + ".in_layers.2.weight"], sd[p + ".in_layers.2.bias"], padding=1)
     e = F.linear(F.silu(emb), sd[p + ".emb_layers.1.weight"], sd[p + ".emb_layers.1.bias"])
     h = h + e[..., None]
+    _t(p + ":mid", h)
     h = F.group_norm(h.float(), 32, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], eps=1e-5)
     h = F.silu(h)
     h = F.conv1d(h, sd[p + ".out_layers.3.weight"], sd[p + ".out_layers.3.bias"], padding=1)
     if (p + ".skip_connection.weight") in sd:
         x = F.conv1d(x, sd[p + ".skip_connection.weight"], sd[p + ".skip_connection.bias"])
+    _t(p + ":out", x + h)
     return x + h
 
 
@@ -79,6 +90,8 @@ def cross_attention(sd: SD, p: str, x: torch.Tensor, context: Optional[torch.Ten
     def split(t: torch.Tensor) -> torch.Tensor:  # b n (h d) -> (b h) n d
         return t.reshape(b, t.shape[1], h, -1).permute(0, 2, 1, 3).reshape(b * h, t.shape[1], -1)
 
+    if context is None:
+        _t(p + ":q", q); _t(p + ":k", k); _t(p + ":v", v)
     q, k, v = split(q), split(k), split(v)
     sim = torch.einsum("bid,bjd->bij", q, k) * (HEAD_DIM ** -0.5)
     if mask is not None:
@@ -87,6 +100,7 @@ def cross_attention(sd: SD, p: str, x: torch.Tensor, context: Optional[torch.Ten
     attn = sim.softmax(dim=-1)
     out = torch.einsum("bij,bjd->bid", attn, v)
     out = out.reshape(b, h, n, -1).permute(0, 2, 1, 3).reshape(b, n, -1)
+    _t(p + ":attn", out)
     return F.linear(out, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
 
 
@@ -95,6 +109,7 @@ def feed_forward(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     y = F.linear(x, sd[p + ".net.0.proj.weight"], sd[p + ".net.0.proj.bias"])
     a, gate = y.chunk(2, dim=-1)
     y = a * F.gelu(gate)
+    _t(p + ":geglu", y)
     return F.linear(y, sd[p + ".net.2.weight"], sd[p + ".net.2.bias"])
 
 
@@ -103,12 +118,15 @@ def transformer_block(sd: SD, p: str, x: torch.Tensor, context: Optional[torch.T
     C = x.shape[-1]
     x = cross_attention(sd, p + ".attn1", F.layer_norm(x, (C,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"]),
                         None, None) + x
+    _t(p + ":x1", x)
     mask = None
     if context is not None:
         mask = alignment_mask(x.shape[0], x.shape[1], context.shape[1])
     x = cross_attention(sd, p + ".attn2", F.layer_norm(x, (C,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"]),
                         context, mask) + x
+    _t(p + ":x2", x)
     x = feed_forward(sd, p + ".ff", F.layer_norm(x, (C,), sd[p + ".norm3.weight"], sd[p + ".norm3.bias"])) + x
+    _t(p + ":x3", x)
     return x
 
 
@@ -120,6 +138,7 @@ def spatial_transformer(sd: SD, p: str, x: torch.Tensor, context: Optional[torch
     h = transformer_block(sd, p + ".transformer_blocks.0", h, context)
     h = h.transpose(1, 2)
     h = F.conv1d(h, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
+    _t(p + ":out", h + x_in)
     return h + x_in
 
 
@@ -129,6 +148,7 @@ def unet_model_forward(sd: SD, x: torch.Tensor, timesteps: torch.Tensor, context
     emb = time_embed(sd, timesteps)
     hs = []
     h = F.conv1d(x.float(), sd["model.input_blocks.0.0.weight"], sd["model.input_blocks.0.0.bias"], padding=1)
+    _t("conv_in", h)
     hs.append(h)
     h = res_block(sd, "model.input_blocks.1.0", h, emb)
     h = spatial_transformer(sd, "model.input_blocks.1.1", h, context)

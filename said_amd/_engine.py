@@ -1,0 +1,274 @@
+"""ctypes binding of libsaid_hip.so (C ABI: include/said_hip.h).
+
+There is deliberately no fallback: if the library is missing, cannot be loaded,
+or no gfx950 device is visible, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsaid_hip.so")
+_lib = None
+
+PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
+NCOEF = 8
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class LoopParams(ctypes.Structure):
+    _fields_ = [
+        ("batch", c_int), ("frames", c_int), ("num_steps", c_int), ("prediction_type", c_int),
+        ("guidance_scale", c_float), ("guidance_rescale", c_float), ("latent_scale", c_float),
+        ("use_step_noise", c_int), ("use_mask", c_int), ("save_intermediate", c_int),
+        ("timesteps_host", POINTER(c_int64)), ("coef_host", POINTER(c_float)),
+        ("context_dev", c_void_p), ("latents_dev", c_void_p), ("step_noise_dev", c_void_p),
+        ("init_latents_dev", c_void_p), ("edit_noise_dev", c_void_p), ("mask_dev", c_void_p),
+        ("intermediates_dev", c_void_p), ("result_dev", c_void_p),
+    ]
+
+
+EXPORTS = {
+    "said_abi_version": (c_int, []),
+    "said_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int]),
+    "said_destroy": (c_int, [c_void_p]),
+    "said_last_error": (c_char_p, [c_void_p]),
+    "said_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
+    "said_finalize_weights": (c_int, [c_void_p, c_void_p]),
+    "said_set_timestep_freqs": (c_int, [c_void_p, c_void_p, c_int]),
+    "said_audio_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, POINTER(c_int), c_void_p]),
+    "said_unet_forward": (c_int, [c_void_p, c_void_p, POINTER(c_int64), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "said_denoise_loop": (c_int, [c_void_p, POINTER(LoopParams), c_void_p]),
+    "said_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, POINTER(c_float), c_int, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "said_axpby": (c_int, [c_void_p, POINTER(c_float), c_void_p, POINTER(c_float), c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "said_graph_num_nodes": (c_int, [c_void_p]),
+    "said_debug_stop_after": (c_int, [c_void_p, c_int]),
+    "said_debug_read": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
+    "said_unet_algorithmic_bytes": (c_double, [c_int, c_int, c_int]),
+    "said_unet_algorithmic_flops": (c_double, [c_int, c_int]),
+}
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen the engine and bind every symbol of include/said_hip.h (no compute)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise EngineError(
+            f"{_LIB_PATH} not found: build it with `python -m said_amd.build` (hipcc, gfx950). "
+            "said_amd has no CPU fallback.")
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _check_dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise EngineError(f"{name} must live on the MI355X (got device {t.device}); said_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise EngineError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """One engine context on one GPU (one process per GPU)."""
+
+    def __init__(self, device: torch.device, max_batch_eff: int, max_frames: int, in_channels: int = 32, ctx_dim: int = 768):
+        self.lib = load_library()
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise EngineError(f"said_amd runs on MI355X only (device={device}); there is no CPU fallback")
+        self.device = device
+        self.index = device.index if device.index is not None else torch.cuda.current_device()
+        self.max_batch_eff, self.max_frames = int(max_batch_eff), int(max_frames)
+        self.in_channels, self.ctx_dim = in_channels, ctx_dim
+        h = c_void_p()
+        rc = self.lib.said_create(ctypes.byref(h), self.index, self.max_batch_eff, self.max_frames, in_channels, ctx_dim)
+        if rc != 0:
+            raise EngineError("said_create: " + (self.lib.said_last_error(None) or b"?").decode())
+        self.h = h
+        self.has_audio = False
+        self._keep = []  # host buffers referenced by in-flight async copies
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.said_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int, what: str):
+        if rc != 0:
+            raise EngineError(f"{what}: " + (self.lib.said_last_error(self.h) or b"?").decode())
+
+    # ---- weights ----
+    def load_weights(self, state_dict: Dict[str, torch.Tensor]):
+        """`state_dict` uses the reference's SAID key layout."""
+        with torch.cuda.device(self.index):
+            half = 96
+            freqs = torch.exp(-np.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+            fr = np.ascontiguousarray(freqs.numpy())
+            self._chk(self.lib.said_set_timestep_freqs(self.h, fr.ctypes.data_as(c_void_p), half), "said_set_timestep_freqs")
+            for k, v in state_dict.items():
+                a = np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy())
+                shape = (c_int64 * a.ndim)(*a.shape)
+                self._chk(self.lib.said_set_weight(self.h, k.encode(), a.ctypes.data_as(c_void_p), shape, a.ndim), f"said_set_weight({k})")
+            self._chk(self.lib.said_finalize_weights(self.h, _stream()), "said_finalize_weights")
+        self.has_audio = any(k.startswith("audio_encoder.") for k in state_dict)
+
+    # ---- compute ----
+    def audio_encode(self, waveform: torch.Tensor, num_frames: Optional[int], apply_proj: bool = False) -> torch.Tensor:
+        waveform = _check_dev(waveform, "waveform")
+        B, Ta = waveform.shape
+        out_dim = self.ctx_dim if apply_proj else 768
+        with torch.cuda.device(self.index):
+            # frame count without interpolation is decided by the library
+            nf = int(num_frames) if num_frames is not None else 0
+            if nf > 0:
+                out = torch.empty(B, nf, out_dim, device=waveform.device, dtype=torch.float32)
+            else:
+                L = Ta
+                for k, s in zip((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)):
+                    L = (L - k) // s + 1
+                out = torch.empty(B, max(L, 1), out_dim, device=waveform.device, dtype=torch.float32)
+            got = c_int(0)
+            self._chk(self.lib.said_audio_encode(self.h, _ptr(waveform), B, Ta, nf, int(apply_proj), _ptr(out), ctypes.byref(got), _stream()), "said_audio_encode")
+            assert got.value == out.shape[1], (got.value, out.shape)
+        return out
+
+    def unet_forward(self, sample: torch.Tensor, timesteps: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+        sample = _check_dev(sample, "sample")
+        context = _check_dev(context, "encoder_hidden_states")
+        Be, T, C = sample.shape
+        if context.shape[0] != Be or context.shape[2] != self.ctx_dim:
+            raise EngineError(f"context shape {tuple(context.shape)} does not match batch {Be} / ctx_dim {self.ctx_dim}")
+        ts = np.ascontiguousarray(timesteps.detach().to("cpu", torch.int64).reshape(-1).numpy())
+        if ts.shape[0] != Be:
+            raise EngineError(f"timesteps must have {Be} entries, got {ts.shape[0]}")
+        out = torch.empty_like(sample)
+        with torch.cuda.device(self.index):
+            self._chk(self.lib.said_unet_forward(self.h, _ptr(sample), ts.ctypes.data_as(POINTER(c_int64)), _ptr(context), Be, T,
+                                                 context.shape[1], _ptr(out), _stream()), "said_unet_forward")
+        return out
+
+    def denoise_loop(self, *, latents: torch.Tensor, context: torch.Tensor, timesteps: np.ndarray, coef: np.ndarray,
+                     prediction_type: str, guidance_scale: float, guidance_rescale: float, latent_scale: float,
+                     step_noise: Optional[torch.Tensor] = None, init_latents: Optional[torch.Tensor] = None,
+                     edit_noise: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                     save_intermediate: bool = False):
+        """Returns (result, final_latents, intermediates or None)."""
+        latents = _check_dev(latents, "latents").clone()
+        context = _check_dev(context, "audio_embedding")
+        B, T, C = latents.shape
+        N = int(len(timesteps))
+        ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int64))
+        cf = np.ascontiguousarray(np.asarray(coef, dtype=np.float32).reshape(N, NCOEF))
+        result = torch.empty_like(latents)
+        inter = torch.empty(N, B, T, C, device=latents.device, dtype=torch.float32) if save_intermediate else None
+        use_mask = mask is not None and init_latents is not None
+        keep = [ts, cf, latents, context, result, inter]
+        p = LoopParams()
+        p.batch, p.frames, p.num_steps, p.prediction_type = B, T, N, PRED[prediction_type]
+        p.guidance_scale, p.guidance_rescale, p.latent_scale = float(guidance_scale), float(guidance_rescale), float(latent_scale)
+        p.use_step_noise = int(step_noise is not None)
+        p.use_mask = int(use_mask)
+        p.save_intermediate = int(save_intermediate)
+        p.timesteps_host = ts.ctypes.data_as(POINTER(c_int64))
+        p.coef_host = cf.ctypes.data_as(POINTER(c_float))
+        p.context_dev = context.data_ptr()
+        p.latents_dev = latents.data_ptr()
+        if step_noise is not None:
+            step_noise = _check_dev(step_noise, "step_noise")
+            assert tuple(step_noise.shape) == (N, B, T, C), step_noise.shape
+            p.step_noise_dev = step_noise.data_ptr()
+            keep.append(step_noise)
+        if use_mask:
+            init_latents = _check_dev(init_latents, "init_latents")
+            edit_noise = _check_dev(edit_noise, "edit_noise")
+            mask = _check_dev(mask.expand_as(latents) if mask.shape != latents.shape else mask, "mask")
+            p.init_latents_dev, p.edit_noise_dev, p.mask_dev = init_latents.data_ptr(), edit_noise.data_ptr(), mask.data_ptr()
+            keep += [init_latents, edit_noise, mask]
+        if inter is not None:
+            p.intermediates_dev = inter.data_ptr()
+        p.result_dev = result.data_ptr()
+        with torch.cuda.device(self.index):
+            self._chk(self.lib.said_denoise_loop(self.h, ctypes.byref(p), _stream()), "said_denoise_loop")
+        self._keep = keep  # alive until the next call (async copies / kernels may still reference them)
+        return result, latents, inter
+
+    def ddim_step(self, eps: torch.Tensor, sample: torch.Tensor, coef_row: np.ndarray, prediction_type: str,
+                  eps_uncond: Optional[torch.Tensor] = None, guidance_scale: float = 1.0,
+                  step_noise: Optional[torch.Tensor] = None, init_latents: Optional[torch.Tensor] = None,
+                  edit_noise: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        eps, sample = _check_dev(eps, "model_output"), _check_dev(sample, "sample")
+        out = torch.empty_like(sample)
+        cf = np.ascontiguousarray(np.asarray(coef_row, dtype=np.float32).reshape(NCOEF))
+        opt = [None if t is None else _check_dev(t, "tensor") for t in (eps_uncond, step_noise, init_latents, edit_noise, mask)]
+        with torch.cuda.device(self.index):
+            self._chk(self.lib.said_ddim_step(self.h, _ptr(eps), _ptr(opt[0]), float(guidance_scale), _ptr(sample),
+                                              cf.ctypes.data_as(POINTER(c_float)), PRED[prediction_type], _ptr(opt[1]), _ptr(opt[2]),
+                                              _ptr(opt[3]), _ptr(opt[4]), _ptr(out), sample.numel(), _stream()), "said_ddim_step")
+            torch.cuda.current_stream().synchronize()  # cf is a temporary
+        return out
+
+    def axpby(self, a: Sequence[float], x: torch.Tensor, c: Optional[Sequence[float]] = None, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = _check_dev(x, "x")
+        B = x.shape[0]
+        av = (c_float * B)(*[float(v) for v in a])
+        cv = (c_float * B)(*[float(v) for v in (c if c is not None else [0.0] * B)])
+        if y is not None:
+            y = _check_dev(y, "y")
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.index):
+            self._chk(self.lib.said_axpby(self.h, av, _ptr(x), cv, _ptr(y), _ptr(out), B, x.numel() // B, _stream()), "said_axpby")
+        return out
+
+    # ---- debugging aids (tests only) ----
+    def debug_stop_after(self, n: int):
+        self._chk(self.lib.said_debug_stop_after(self.h, int(n)), "said_debug_stop_after")
+
+    def debug_read(self, name: str, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=np.float32)
+        self._chk(self.lib.said_debug_read(self.h, name.encode(), out.ctypes.data_as(c_void_p), out.size), "said_debug_read")
+        return out
+
+    def graph_num_nodes(self) -> int:
+        return int(self.lib.said_graph_num_nodes(self.h))
+
+
+def unet_algorithmic_bytes(batch_eff: int, frames: int, bytes_per_elem: int = 4) -> float:
+    return float(load_library().said_unet_algorithmic_bytes(batch_eff, frames, bytes_per_elem))
+
+
+def unet_algorithmic_flops(batch_eff: int, frames: int) -> float:
+    return float(load_library().said_unet_algorithmic_flops(batch_eff, frames))

@@ -1,0 +1,157 @@
+// attn.hip — fp32 self-attention for channel-major activations on gfx950.
+//
+// One workgroup = one (batch, head, 32-query tile); its KS waves split the key tiles
+// (flash-decoding style) and merge their online-softmax states through LDS in a fixed order.
+// Everything stays in registers between the two MFMAs:
+//   S^T[j][i] = sum_d K[d][j] Q[d][i]      A = K fragment (coalesced row of K[d][.]), B = Q fragment
+//   O^T[d][i] = sum_j V[j][d] P^T[j][i]    A = V fragment (coalesced row of Vt[j][.]), B = p[r] as-is
+// Computing S transposed leaves each lane with one query column (i = lane & 31), so the row max /
+// row sum are in-lane reductions plus one exchange with lane^32, the rescale factor is a per-lane
+// scalar, and — because v_mfma_f32_32x32x2_f32 consumes exactly the two keys (j, j+4) that lanes
+// l and l+32 already hold in accumulator register r — P feeds the second MFMA without any
+// cross-lane movement or LDS round trip.
+// Reference semantics: ldm/attention.py:86-128 (scale after QK^T, softmax over all keys).
+#include <cstdio>
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace said {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int ND, int KS>
+__global__ __launch_bounds__(64 * KS) void attn_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int D = 32 * ND;
+    const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+    const int T = a.T, pitch = a.pitch;
+    const float* qb = a.q + (long long)b * a.qkv_bstride + (long long)(h * D) * pitch;
+    const float* kb = a.k + (long long)b * a.qkv_bstride + (long long)(h * D) * pitch;
+    const float* vb = a.vt + ((long long)b * a.heads + h) * (long long)a.vt_rows * D;
+
+    float qf[ND * 16];
+#pragma unroll
+    for (int dp = 0; dp < ND * 16; ++dp) qf[dp] = qb[(long long)(2 * dp + lh) * pitch + i0 + lt];
+
+    float m = -1.0e30f, lsum = 0.f;
+    f32x16 o[ND];
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nd][r] = 0.f;
+
+    const int nkt = (T + 31) >> 5;
+    for (int kt = w; kt < nkt; kt += KS) {
+        const int j0 = kt * 32;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int dp = 0; dp < ND * 16; ++dp) {
+            const float kf = kb[(long long)(2 * dp + lh) * pitch + j0 + lt];
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, qf[dp], s, 0, 0, 0);
+        }
+        float mx = -1.0e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            s[r] = (j < T) ? s[r] * a.scale : -1.0e30f;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __expf(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - mn);
+            ps += s[r];
+        }
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[nd][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) {
+                const float vf = vb[(long long)j * D + nd * 32 + lt];
+                o[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], o[nd], 0, 0, 0);
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 32);
+
+    // ---- merge the KS partial states ----
+    float* ml = smem;                 // [KS][2][32]
+    float* ob = smem + KS * 64;       // [KS][ND][16][64]
+    if (lh == 0) {
+        ml[(w * 2 + 0) * 32 + lt] = m;
+        ml[(w * 2 + 1) * 32 + lt] = lsum;
+    }
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[((w * ND + nd) * 16 + r) * 64 + l] = o[nd][r];
+    __syncthreads();
+    float M = -1.0e30f;
+#pragma unroll
+    for (int w2 = 0; w2 < KS; ++w2) M = fmaxf(M, ml[(w2 * 2) * 32 + lt]);
+    float f[KS];
+    float L = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < KS; ++w2) {
+        f[w2] = __expf(ml[(w2 * 2) * 32 + lt] - M);
+        L += ml[(w2 * 2 + 1) * 32 + lt] * f[w2];
+    }
+    const float invL = 1.0f / L;
+    constexpr int NV = ND * 16;
+    static_assert(NV % KS == 0, "");
+    float* ob_out = a.o + (long long)b * a.qkv_bstride + (long long)(h * D) * pitch;
+#pragma unroll
+    for (int jv = 0; jv < NV / KS; ++jv) {
+        const int v = w + jv * KS;
+        const int nd = v >> 4, r = v & 15;
+        float acc = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < KS; ++w2) acc += ob[((w2 * ND + nd) * 16 + r) * 64 + l] * f[w2];
+        const int d = nd * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int i = i0 + lt;
+        if (i < T) ob_out[(long long)d * pitch + i] = acc * invL;
+    }
+}
+
+template <int ND, int KS>
+static void launch_attn_one(const AttnArgs& a, int batch, hipStream_t s) {
+    const int smem = (KS * 64 + KS * ND * 16 * 64) * (int)sizeof(float);
+    dim3 grid((a.T + 31) / 32, a.heads, batch);
+    hipLaunchKernelGGL((attn_kernel<ND, KS>), grid, dim3(64 * KS), smem, s, a);
+}
+template <int ND, int KS>
+static void configure_attn_one() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<ND, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+}
+void configure_attn_kernels() {
+    configure_attn_one<1, 8>(); configure_attn_one<1, 4>(); configure_attn_one<1, 1>();
+    configure_attn_one<2, 8>(); configure_attn_one<2, 4>(); configure_attn_one<2, 1>();
+}
+
+void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s) {
+    if (head_dim == 32 && KS == 8) return launch_attn_one<1, 8>(a, batch, s);
+    if (head_dim == 32 && KS == 4) return launch_attn_one<1, 4>(a, batch, s);
+    if (head_dim == 32 && KS == 1) return launch_attn_one<1, 1>(a, batch, s);
+    if (head_dim == 64 && KS == 8) return launch_attn_one<2, 8>(a, batch, s);
+    if (head_dim == 64 && KS == 4) return launch_attn_one<2, 4>(a, batch, s);
+    if (head_dim == 64 && KS == 1) return launch_attn_one<2, 1>(a, batch, s);
+    fprintf(stderr, "said: unsupported attention config D=%d KS=%d\n", head_dim, KS);
+    abort();
+}
+
+}  // namespace said

@@ -1,0 +1,1120 @@
+// engine.cpp — host side of libsaid_hip.so: context, weight packing, the UNet1D / Wav2Vec2
+// kernel schedules, the hipGraph-replayed denoising loop and the C ABI of include/said_hip.h.
+// No math happens here: every tensor op is one of the gfx950 kernels in gemm/attn/misc.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/said_hip.h"
+#include "kernels.h"
+
+using namespace said;
+
+namespace {
+
+constexpr int MC = 192;       // model_channels (unet_1d_condition.py:40)
+constexpr int TE = 768;       // time_embed_dim = 4 * model_channels
+constexpr int HEADS = 6;      // 192 / num_head_channels(32)
+constexpr int HD = 32;
+constexpr int FFI = 768;      // GEGLU inner dim (4 * 192)
+constexpr int NRES = 5, NST = 4;
+constexpr int W2V_H = 768, W2V_HEADS = 12, W2V_HD = 64, W2V_FFN = 3072, W2V_CONV = 512;
+
+std::string g_create_err;
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    int64_t numel() const { int64_t n = 1; for (auto d : shape) n *= d; return n; }
+};
+
+struct PW {  // packed GEMM weight (up to 2 K-segments) + bias
+    float* w[2] = {nullptr, nullptr};
+    float* bias = nullptr;
+    int N = 0, C[2] = {0, 0}, taps = 1, nseg = 1;
+};
+struct ResW { float *g1, *b1, *g2, *b2; PW conv1, conv2, skip; int cin; bool has_skip; float* bias2; };
+struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj; };
+struct W2VLayer { PW qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln2g, *ln2b; };
+
+struct ActBuf {  // channel-major activation + its GroupNorm partial statistics
+    float* p = nullptr;
+    float* st = nullptr;
+};
+
+}  // namespace
+
+struct said_ctx {
+    int device = 0, maxBe = 0, maxT = 0, cin = 32, ctx_dim = 768;
+    int maxTp = 0, maxNp = 0;
+    std::string err;
+    std::map<std::string, HostTensor> host_w;
+    std::vector<void*> allocs;
+    bool finalized = false, has_audio = false, has_audio_proj = false;
+    int w2v_layers = 0;
+    int w2v_kernel[7] = {0}, w2v_stride[7] = {5, 2, 2, 2, 2, 2, 2};
+
+    // ---- UNet weights ----
+    PW conv_in, conv_out, te1, te2, emb_all, kv_all;
+    float *out_g = nullptr, *out_b = nullptr;
+    ResW res[NRES];
+    STW st[NST];
+    float* null_cond = nullptr;
+    float* freqs = nullptr;
+    bool freqs_set = false;
+
+    // ---- audio encoder weights ----
+    float *c0_w = nullptr, *c0_g = nullptr, *c0_b = nullptr;
+    PW aconv[7];
+    float *fp_lng = nullptr, *fp_lnb = nullptr, *enc_lng = nullptr, *enc_lnb = nullptr;
+    PW fproj, posconv, aproj;
+    std::vector<W2VLayer> layers;
+
+    // ---- UNet workspace ----
+    float *x_cm = nullptr, *eps_cm = nullptr;
+    ActBuf H0, H1, P, Q, M;
+    float *X1 = nullptr, *X2 = nullptr, *X3 = nullptr, *O = nullptr, *QK = nullptr, *VT = nullptr, *F = nullptr;
+    float *KV = nullptr, *CTX = nullptr;
+    float *E0 = nullptr, *E1 = nullptr, *E2 = nullptr, *EO = nullptr;
+    long long* ts_dev = nullptr;
+    float* coef_dev = nullptr;
+    int* step_dev = nullptr;
+    int *band_lo = nullptr, *band_hi = nullptr;
+    int band_T = -1, band_S = -1, band_wmax = 0;
+    float *init_cm = nullptr, *enoise_cm = nullptr, *mask_cm = nullptr, *rescale_part = nullptr;
+    float* noise_cm = nullptr; size_t noise_cm_elems = 0;
+    float* coef1_dev = nullptr;  // one row for said_ddim_step
+    float* axpby_coef = nullptr;
+
+    // ---- audio workspace (lazily sized) ----
+    float *abufA = nullptr, *abufB = nullptr; size_t abuf_elems[2] = {0, 0};
+    float *aH = nullptr, *aT = nullptr, *aO = nullptr, *aQK = nullptr, *aVT = nullptr, *aF = nullptr, *aPOS = nullptr, *aX = nullptr;
+    size_t a_tok_elems = 0; int a_chunk = 0;
+
+    // ---- per-step graph ----
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    std::vector<long long> gkey;
+    int gnodes = 0;
+    int dbg_stop = -1, dbg_count = 0;
+};
+
+namespace {
+
+int fail(said_ctx* c, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return -1;
+}
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return fail(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+template <typename T>
+int dalloc(said_ctx* ctx, T** out, size_t n, bool zero = true) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+    if (zero) HIPCHK(hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    ctx->allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    return 0;
+}
+int upload(said_ctx* ctx, float** out, const float* h, size_t n) {
+    if (dalloc(ctx, out, n, false)) return -1;
+    HIPCHK(hipMemcpy(*out, h, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+const HostTensor* getw(said_ctx* ctx, const std::string& name, std::initializer_list<int64_t> shape) {
+    auto it = ctx->host_w.find(name);
+    if (it == ctx->host_w.end()) { fail(ctx, "missing key in state dict: %s", name.c_str()); return nullptr; }
+    if (it->second.shape != std::vector<int64_t>(shape)) {
+        std::string got;
+        for (auto d : it->second.shape) got += std::to_string(d) + ",";
+        fail(ctx, "size mismatch for %s: got (%s)", name.c_str(), got.c_str());
+        return nullptr;
+    }
+    return &it->second;
+}
+int upvec(said_ctx* ctx, float** out, const std::string& name, int64_t n) {
+    const HostTensor* t = getw(ctx, name, {n});
+    if (!t) return -1;
+    return upload(ctx, out, t->data.data(), (size_t)n);
+}
+
+// Pack W[Ntot][Ctot][taps] into MFMA A-fragment order: Wp[group][tile][tap][cpair][lane],
+// lane l <-> (n = tile*32 + (l & 31), c = c_begin + 2*cpair + (l >> 5)); rows beyond N are zero.
+std::vector<float> pack_rows(const float* W, int Ctot, int taps, const std::vector<int>& row_of /* per (group,tile,r): row or -1 */,
+                             int ntiles_total, int c_begin, int C) {
+    std::vector<float> out((size_t)ntiles_total * taps * (C / 2) * 64);
+    size_t o = 0;
+    for (int tile = 0; tile < ntiles_total; ++tile)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int cp = 0; cp < C / 2; ++cp)
+                for (int l = 0; l < 64; ++l) {
+                    const int row = row_of[tile * 32 + (l & 31)];
+                    const int c = c_begin + 2 * cp + (l >> 5);
+                    out[o++] = row < 0 ? 0.f : W[((size_t)row * Ctot + c) * taps + tap];
+                }
+    return out;
+}
+std::vector<int> rows_dense(int N, int row0 = 0) {
+    const int nt = (N + 31) / 32;
+    std::vector<int> r(nt * 32, -1);
+    for (int i = 0; i < N; ++i) r[i] = row0 + i;
+    return r;
+}
+
+// Linear/conv weight `name` (N, Ctot[, taps]) -> PW with the K range split into `nseg` equal segments.
+int make_pw(said_ctx* ctx, PW* pw, const std::string& wname, const std::string& bname, int N, int Ctot, int taps, int nseg = 1) {
+    const HostTensor* t = taps > 0 && ctx->host_w.count(wname) && ctx->host_w[wname].shape.size() == 3
+                              ? getw(ctx, wname, {N, Ctot, taps})
+                              : getw(ctx, wname, {N, Ctot});
+    if (!t) return -1;
+    const int tp = t->shape.size() == 3 ? taps : 1;
+    pw->N = N; pw->taps = tp; pw->nseg = nseg;
+    const auto rows = rows_dense(N);
+    for (int s = 0; s < nseg; ++s) {
+        const int C = Ctot / nseg;
+        pw->C[s] = C;
+        auto packed = pack_rows(t->data.data(), Ctot, tp, rows, (N + 31) / 32, s * C, C);
+        if (upload(ctx, &pw->w[s], packed.data(), packed.size())) return -1;
+    }
+    if (!bname.empty()) { if (upvec(ctx, &pw->bias, bname, N)) return -1; }
+    return 0;
+}
+
+struct LaunchCfg { int NB, KS; };
+LaunchCfg pick_cfg(long long t_tiles_total, int ntiles, bool allow6 = true) {
+    // small problems: maximise workgroups (split K over 8 waves, one tile each);
+    // large problems: amortise the operand transform over more tiles per workgroup.
+    if (t_tiles_total * ntiles <= 1536 || ntiles % 2) return {1, 8};
+    if (t_tiles_total * ntiles <= 4096) return {2, 8};
+    if (allow6 && ntiles % 6 == 0) return {6, 4};
+    if (ntiles % 4 == 0) return {4, 4};
+    if (ntiles % 3 == 0) return {3, 4};
+    return {2, 8};
+}
+
+Seg mkseg(const float* x, long long bstride, int pitch, int C, int taps, int pad, int stride, int Tin, int xform, const float* w) {
+    Seg s;
+    memset(&s, 0, sizeof s);
+    s.x = x; s.w = w; s.x_bstride = bstride; s.x_pitch = pitch; s.C = C; s.taps = taps; s.pad = pad; s.stride = stride;
+    s.Tin = Tin; s.xform = xform; s.gn_cpg = 1; s.gn_nparts = 1;
+    return s;
+}
+void seg_gn(Seg& s, const float* part, long long part_bstride, int cpg, int nparts, float eps, const float* g, const float* b) {
+    s.gn_part = part; s.gn_part_bstride = part_bstride; s.gn_cpg = cpg; s.gn_nparts = nparts; s.gn_eps = eps; s.gn_gamma = g; s.gn_beta = b;
+}
+GemmArgs mkargs(int T, int N) {
+    GemmArgs a;
+    memset(&a, 0, sizeof a);
+    a.T = T; a.N = N; a.groups = 1; a.ntiles_per_group = (N + 31) / 32;
+    return a;
+}
+
+// geometry of one UNet evaluation
+struct UGeo {
+    int Be, B_lat /* latents batch (b_mod) */, T, Tp, np /* GN partials per channel */, S, Sp;
+    long long hs;      // batch stride of a 192-channel activation
+    long long sts;     // batch stride of its stats
+    const int* step_ptr;
+    int emb_b_stride;
+};
+
+inline bool dbg_go(said_ctx* c) { return c->dbg_stop < 0 || c->dbg_count++ < c->dbg_stop; }
+
+void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, const ActBuf& in0, const ActBuf* in1, const ActBuf& out, hipStream_t s) {
+    const int cpg = rw.cin / 32;
+    const long long tt = (long long)g.Be * ((g.T + 31) / 32);
+    {   // in_layers: GN -> SiLU -> conv3 ; + emb_layers(emb)   (openaimodel.py:205-225)
+        GemmArgs a = mkargs(g.T, MC);
+        a.nseg = in1 ? 2 : 1;
+        a.seg[0] = mkseg(in0.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[0]);
+        seg_gn(a.seg[0], in0.st, g.sts, cpg, g.np, 1e-5f, rw.g1, rw.b1);
+        if (in1) {
+            a.seg[1] = mkseg(in1->p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[1]);
+            seg_gn(a.seg[1], in1->st, g.sts, cpg, g.np, 1e-5f, rw.g1 + MC, rw.b1 + MC);
+        }
+        a.bias = rw.conv1.bias;
+        a.emb = c->EO + (long long)rb_index * MC * c->maxNp; a.emb_pitch = c->maxNp; a.step_ptr = g.step_ptr; a.emb_b_stride = g.emb_b_stride;
+        a.y = c->M.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
+        a.stats_out = c->M.st; a.stats_bstride = g.sts;
+        const LaunchCfg lc = pick_cfg(tt, 6);
+        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+    }
+    {   // out_layers: GN -> SiLU -> conv3 ; + skip(x)   (openaimodel.py:226-227)
+        GemmArgs a = mkargs(g.T, MC);
+        a.nseg = 1;
+        a.seg[0] = mkseg(c->M.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv2.w[0]);
+        seg_gn(a.seg[0], c->M.st, g.sts, 6, g.np, 1e-5f, rw.g2, rw.b2);
+        if (rw.has_skip) {  // 1x1 conv over the concatenated input folded in as two extra K segments
+            a.seg[1] = mkseg(in0.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, rw.skip.w[0]);
+            a.seg[2] = mkseg(in1->p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, rw.skip.w[1]);
+            a.nseg = 3;
+            a.bias = rw.bias2;
+        } else {
+            a.bias = rw.conv2.bias;
+            a.res_kind = RES_PLAIN; a.res = in0.p; a.res_bstride = g.hs; a.res_pitch = g.Tp;
+        }
+        a.y = out.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
+        a.stats_out = out.st; a.stats_bstride = g.sts;
+        const LaunchCfg lc = pick_cfg(tt, 6);
+        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+    }
+}
+
+void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const ActBuf& in, const ActBuf& out, hipStream_t s) {
+    const long long tt = (long long)g.Be * ((g.T + 31) / 32);
+    const bool big = tt * 6 > 1536;
+    const int vt_rows = rup(g.T, 32);
+    {   // x = norm(x) (GroupNorm eps 1e-6); q,k,v = to_{q,k,v}(norm1(x))   (attention.py:227, 168, 93-97)
+        GemmArgs a = mkargs(g.T, 3 * MC);
+        a.nseg = 1;
+        a.seg[0] = mkseg(in.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_GN_LN, sw.qkv.w[0]);
+        seg_gn(a.seg[0], in.st, g.sts, 6, g.np, 1e-6f, sw.gn_g, sw.gn_b);
+        a.seg[0].ln_gamma = sw.l1g; a.seg[0].ln_beta = sw.l1b; a.seg[0].ln_eps = 1e-5f;
+        a.y = c->QK; a.y_bstride = 2LL * MC * g.Tp; a.y_pitch = g.Tp;
+        a.vt = c->VT; a.vt_first_tile = 12; a.vt_heads = HEADS; a.vt_dim = HD; a.vt_rows = vt_rows;
+        const LaunchCfg lc = big ? LaunchCfg{6, 4} : LaunchCfg{1, 8};
+        if (dbg_go(c)) launch_gemm(a, EPI_QKV, g.Be, lc.NB, lc.KS, s);
+    }
+    {   // softmax(q k^T * scale) v   (attention.py:99-126)
+        AttnArgs a;
+        a.q = c->QK; a.k = c->QK + (long long)MC * g.Tp; a.vt = c->VT; a.o = c->O;
+        a.qkv_bstride = 2LL * MC * g.Tp; a.pitch = g.Tp; a.T = g.T; a.heads = HEADS; a.vt_rows = vt_rows;
+        a.scale = 0.17677669529663687f;  // 32 ** -0.5
+        // q/k/o share a batch stride only if O is laid out like QK; O has its own stride -> separate launch arg
+        AttnArgs b = a;
+        (void)b;
+        if (dbg_go(c)) launch_attn(a, g.Be, HD, tt * HEADS <= 2048 ? 8 : (tt * HEADS <= 8192 ? 4 : 1), s);
+    }
+    {   // x1 = to_out(attn) + x, with x = GroupNorm(in) recomputed on the fly   (attention.py:127, 168)
+        GemmArgs a = mkargs(g.T, MC);
+        a.nseg = 1;
+        a.seg[0] = mkseg(c->O, 2LL * MC * g.Tp, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out1.w[0]);
+        a.bias = sw.out1.bias;
+        a.res_kind = RES_GN; a.res = in.p; a.res_bstride = g.hs; a.res_pitch = g.Tp;
+        a.res_gn_part = in.st; a.res_gn_part_bstride = g.sts; a.res_gn_cpg = 6; a.res_gn_nparts = g.np; a.res_gn_eps = 1e-6f;
+        a.res_gn_gamma = sw.gn_g; a.res_gn_beta = sw.gn_b;
+        a.y = c->X1; a.y_bstride = g.hs; a.y_pitch = g.Tp;
+        const LaunchCfg lc = pick_cfg(tt, 6);
+        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+    }
+    {   // attn2: q = to_q(norm2(x1)); banded softmax over the precomputed audio K/V   (attention.py:170-191)
+        GemmArgs a = mkargs(g.T, MC);
+        a.nseg = 1;
+        a.seg[0] = mkseg(c->X1, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.q2.w[0]);
+        a.seg[0].ln_gamma = sw.l2g; a.seg[0].ln_beta = sw.l2b; a.seg[0].ln_eps = 1e-5f;
+        a.y = c->O; a.y_bstride = 2LL * MC * g.Tp; a.y_pitch = g.Tp;
+        a.band.k = c->KV + (long long)(blk * 2 * MC) * g.Sp;
+        a.band.v = c->KV + (long long)(blk * 2 * MC + MC) * g.Sp;
+        a.band.kv_bstride = (long long)NST * 2 * MC * g.Sp; a.band.kv_pitch = g.Sp;
+        a.band.lo = c->band_lo; a.band.hi = c->band_hi; a.band.wmax = c->band_wmax; a.band.scale = 0.17677669529663687f;
+        if (dbg_go(c)) launch_gemm(a, EPI_BAND, g.Be, 1, big ? 4 : 8, s);
+    }
+    {   // x2 = to_out(attn2) + x1
+        GemmArgs a = mkargs(g.T, MC);
+        a.nseg = 1;
+        a.seg[0] = mkseg(c->O, 2LL * MC * g.Tp, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out2.w[0]);
+        a.bias = sw.out2.bias;
+        a.res_kind = RES_PLAIN; a.res = c->X1; a.res_bstride = g.hs; a.res_pitch = g.Tp;
+        a.y = c->X2; a.y_bstride = g.hs; a.y_pitch = g.Tp;
+        const LaunchCfg lc = pick_cfg(tt, 6);
+        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+    }
+    {   // GEGLU: proj(norm3(x2)) -> a * gelu(gate)   (attention.py:25-32)
+        GemmArgs a = mkargs(g.T, FFI);
+        a.nseg = 1;
+        a.seg[0] = mkseg(c->X2, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.ff1.w[0]);
+        a.seg[0].ln_gamma = sw.l3g; a.seg[0].ln_beta = sw.l3b; a.seg[0].ln_eps = 1e-5f;
+        a.bias = sw.ff1.bias; a.geglu_gate_tiles = FFI / 32;
+        a.y = c->F; a.y_bstride = (long long)FFI * g.Tp; a.y_pitch = g.Tp;
+        if (dbg_go(c)) launch_gemm(a, EPI_GEGLU, g.Be, big ? 3 : 1, big ? 4 : 8, s);
+    }
+    {   // x3 = net.2(h) + x2
+        GemmArgs a = mkargs(g.T, MC);
+        a.nseg = 1;
+        a.seg[0] = mkseg(c->F, (long long)FFI * g.Tp, g.Tp, FFI, 1, 0, 1, g.T, XF_NONE, sw.ff2.w[0]);
+        a.bias = sw.ff2.bias;
+        a.res_kind = RES_PLAIN; a.res = c->X2; a.res_bstride = g.hs; a.res_pitch = g.Tp;
+        a.y = c->X3; a.y_bstride = g.hs; a.y_pitch = g.Tp;
+        const LaunchCfg lc = pick_cfg(tt, 6);
+        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+    }
+    {   // proj_out (1x1 conv) + x_in   (attention.py:232-234)
+        GemmArgs a = mkargs(g.T, MC);
+        a.nseg = 1;
+        a.seg[0] = mkseg(c->X3, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.proj.w[0]);
+        a.bias = sw.proj.bias;
+        a.res_kind = RES_PLAIN; a.res = in.p; a.res_bstride = g.hs; a.res_pitch = g.Tp;
+        a.y = out.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
+        a.stats_out = out.st; a.stats_bstride = g.sts;
+        const LaunchCfg lc = pick_cfg(tt, 6);
+        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+    }
+}
+
+// UNetModel.forward (openaimodel.py:677-709): x_cm (latents) -> eps_cm.  Needs KV, band tables and EO ready.
+void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
+    const long long tt = (long long)g.Be * ((g.T + 31) / 32);
+    {   // input_blocks.0: Conv1d(32 -> 192, k3)
+        GemmArgs a = mkargs(g.T, MC);
+        a.nseg = 1;
+        a.seg[0] = mkseg(c->x_cm, (long long)c->cin * g.Tp, g.Tp, c->cin, 3, 1, 1, g.T, XF_NONE, c->conv_in.w[0]);
+        a.seg[0].b_mod = g.B_lat;
+        a.bias = c->conv_in.bias;
+        a.y = c->H0.p; a.y_bstride = g.hs; a.y_pitch = g.Tp; a.stats_out = c->H0.st; a.stats_bstride = g.sts;
+        const LaunchCfg lc = pick_cfg(tt, 6);
+        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+    }
+    run_resblock(c, g, c->res[0], 0, c->H0, nullptr, c->P, s);       // input_blocks.1.0
+    run_transformer(c, g, c->st[0], 0, c->P, c->H1, s);              // input_blocks.1.1   (hs: H0, H1)
+    run_resblock(c, g, c->res[1], 1, c->H1, nullptr, c->P, s);       // middle_block.0
+    run_transformer(c, g, c->st[1], 1, c->P, c->Q, s);               // middle_block.1
+    run_resblock(c, g, c->res[2], 2, c->Q, nullptr, c->P, s);        // middle_block.2
+    run_resblock(c, g, c->res[3], 3, c->P, &c->H1, c->Q, s);         // output_blocks.0.0  cat([h, H1])
+    run_transformer(c, g, c->st[2], 2, c->Q, c->P, s);               // output_blocks.0.1
+    run_resblock(c, g, c->res[4], 4, c->P, &c->H0, c->Q, s);         // output_blocks.1.0  cat([h, H0])
+    run_transformer(c, g, c->st[3], 3, c->Q, c->P, s);               // output_blocks.1.1
+    {   // out: GN -> SiLU -> Conv1d(192 -> 32, k3)
+        GemmArgs a = mkargs(g.T, c->cin);
+        a.nseg = 1;
+        a.seg[0] = mkseg(c->P.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, c->conv_out.w[0]);
+        seg_gn(a.seg[0], c->P.st, g.sts, 6, g.np, 1e-5f, c->out_g, c->out_b);
+        a.bias = c->conv_out.bias;
+        a.y = c->eps_cm; a.y_bstride = (long long)c->cin * g.Tp; a.y_pitch = g.Tp;
+        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, 1, 8, s);
+    }
+}
+
+// time_embed + the five emb_layers for `n` timesteps already in ts_dev -> EO [5*192][Np]
+void run_time_embed(said_ctx* c, int n, hipStream_t s) {
+    const int Np = c->maxNp;
+    launch_timestep_embedding(c->ts_dev, c->E0, n, MC, Np, s);
+    const long long tt = (n + 31) / 32;
+    {
+        GemmArgs a = mkargs(n, TE);
+        a.nseg = 1;
+        a.seg[0] = mkseg(c->E0, 0, Np, MC, 1, 0, 1, n, XF_NONE, c->te1.w[0]);
+        a.bias = c->te1.bias; a.act = ACT_SILU;
+        a.y = c->E1; a.y_pitch = Np;
+        const LaunchCfg lc = pick_cfg(tt, TE / 32);
+        launch_gemm(a, EPI_STORE, 1, lc.NB, lc.KS, s);
+    }
+    {
+        GemmArgs a = mkargs(n, TE);
+        a.nseg = 1;
+        a.seg[0] = mkseg(c->E1, 0, Np, TE, 1, 0, 1, n, XF_NONE, c->te2.w[0]);
+        a.bias = c->te2.bias;
+        a.y = c->E2; a.y_pitch = Np;
+        const LaunchCfg lc = pick_cfg(tt, TE / 32);
+        launch_gemm(a, EPI_STORE, 1, lc.NB, lc.KS, s);
+    }
+    {
+        GemmArgs a = mkargs(n, NRES * MC);
+        a.nseg = 1;
+        a.seg[0] = mkseg(c->E2, 0, Np, TE, 1, 0, 1, n, XF_SILU, c->emb_all.w[0]);
+        a.bias = c->emb_all.bias;
+        a.y = c->EO; a.y_pitch = Np;
+        const LaunchCfg lc = pick_cfg(tt, NRES * MC / 32);
+        launch_gemm(a, EPI_STORE, 1, lc.NB, lc.KS, s);
+    }
+}
+
+// cross-attention K/V of all four transformer blocks from the channel-major context (step-invariant)
+void run_kv(said_ctx* c, int Be, int S, int Sp, hipStream_t s) {
+    GemmArgs a = mkargs(S, NST * 2 * MC);
+    a.nseg = 1;
+    a.seg[0] = mkseg(c->CTX, (long long)c->ctx_dim * Sp, Sp, c->ctx_dim, 1, 0, 1, S, XF_NONE, c->kv_all.w[0]);
+    a.y = c->KV; a.y_bstride = (long long)NST * 2 * MC * Sp; a.y_pitch = Sp;
+    const LaunchCfg lc = pick_cfg((long long)Be * ((S + 31) / 32), NST * 2 * MC / 32);
+    launch_gemm(a, EPI_STORE, Be, lc.NB, lc.KS, s);
+}
+
+// alignment band of ldm/attention.py:170-189 with Python's banker's rounding on doubles
+int set_band(said_ctx* ctx, int T, int S) {
+    if (ctx->band_T == T && ctx->band_S == S) return 0;
+    std::vector<int> lo(T), hi(T);
+    const double ratio = (double)S / (double)T, kh = ratio / 2 + 1;
+    int wmax = 0;
+    for (int i = 0; i < T; ++i) {
+        const double mid = (i + 0.5) * ratio;
+        const int a = std::max((int)std::nearbyint(mid - kh), 0);
+        const int b = std::min((int)std::nearbyint(mid + kh), S);
+        lo[i] = a; hi[i] = b;
+        wmax = std::max(wmax, b - a);
+        if (b <= a) return fail(ctx, "empty alignment window at query %d (T=%d, S=%d)", i, T, S);
+    }
+    if (wmax > 8) return fail(ctx, "alignment window of %d keys exceeds the kernel limit of 8 (T=%d, S=%d)", wmax, T, S);
+    HIPCHK(hipMemcpy(ctx->band_lo, lo.data(), T * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->band_hi, hi.data(), T * sizeof(int), hipMemcpyHostToDevice));
+    ctx->band_T = T; ctx->band_S = S; ctx->band_wmax = wmax;
+    return 0;
+}
+
+UGeo make_geo(said_ctx* c, int Be, int B_lat, int T, int S) {
+    UGeo g;
+    g.Be = Be; g.B_lat = B_lat; g.T = T; g.Tp = rup(T, 32); g.np = (T + 31) / 32; g.S = S; g.Sp = rup(S, 32);
+    g.hs = (long long)MC * g.Tp; g.sts = (long long)MC * g.np * 2;
+    g.step_ptr = nullptr; g.emb_b_stride = 0;
+    return g;
+}
+
+int check_ready(said_ctx* ctx) {
+    if (!ctx) return -1;
+    if (!ctx->finalized) return fail(ctx, "weights not finalized: call said_finalize_weights first");
+    return 0;
+}
+
+}  // namespace
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+extern "C" {
+
+int said_abi_version(void) { return 1; }
+
+const char* said_last_error(const said_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, int in_channels, int ctx_dim) {
+    said_ctx* ctx = nullptr;
+    if (!out) return fail(nullptr, "said_create: out is null");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, "said_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(nullptr, "said_create: device %d out of range (%d visible)", device, ndev);
+    if (max_batch_eff < 1 || max_frames < 1) return fail(nullptr, "said_create: bad sizes");
+    if (in_channels != 32) return fail(nullptr, "said_create: in_channels must be 32 (got %d)", in_channels);
+    if (ctx_dim < 16 || ctx_dim % 16) return fail(nullptr, "said_create: ctx_dim must be a positive multiple of 16 (got %d)", ctx_dim);
+    {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return fail(nullptr, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, device);
+        if (e != hipSuccess) return fail(nullptr, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(nullptr, "said_create: device is %s; this library is built for gfx950 only", prop.gcnArchName);
+    }
+    ctx = new said_ctx();
+    ctx->device = device; ctx->maxBe = max_batch_eff; ctx->maxT = max_frames; ctx->cin = in_channels; ctx->ctx_dim = ctx_dim;
+    ctx->maxTp = rup(max_frames, 32);
+    ctx->maxNp = rup(std::max(1024, max_batch_eff), 32);
+    configure_gemm_kernels();
+    configure_attn_kernels();
+
+    const size_t Be = max_batch_eff, Tp = ctx->maxTp, np = Tp / 32;
+    const size_t act = Be * MC * Tp, stt = Be * MC * np * 2;
+    int rc = 0;
+    rc |= dalloc(ctx, &ctx->x_cm, Be * 32 * Tp);
+    rc |= dalloc(ctx, &ctx->eps_cm, Be * 32 * Tp);
+    for (ActBuf* a : {&ctx->H0, &ctx->H1, &ctx->P, &ctx->Q, &ctx->M}) { rc |= dalloc(ctx, &a->p, act); rc |= dalloc(ctx, &a->st, stt); }
+    rc |= dalloc(ctx, &ctx->X1, act); rc |= dalloc(ctx, &ctx->X2, act); rc |= dalloc(ctx, &ctx->X3, act);
+    rc |= dalloc(ctx, &ctx->O, 2 * act);  // same batch stride as QK so attention can share one stride
+    rc |= dalloc(ctx, &ctx->QK, 2 * act);
+    rc |= dalloc(ctx, &ctx->VT, Be * HEADS * Tp * HD);
+    rc |= dalloc(ctx, &ctx->F, Be * FFI * Tp);
+    rc |= dalloc(ctx, &ctx->KV, Be * NST * 2 * MC * Tp);
+    rc |= dalloc(ctx, &ctx->CTX, Be * (size_t)ctx_dim * Tp);
+    const size_t Np = ctx->maxNp;
+    rc |= dalloc(ctx, &ctx->E0, MC * Np); rc |= dalloc(ctx, &ctx->E1, TE * Np); rc |= dalloc(ctx, &ctx->E2, TE * Np);
+    rc |= dalloc(ctx, &ctx->EO, NRES * MC * Np);
+    rc |= dalloc(ctx, &ctx->ts_dev, Np); rc |= dalloc(ctx, &ctx->coef_dev, Np * 8); rc |= dalloc(ctx, &ctx->coef1_dev, 8);
+    rc |= dalloc(ctx, &ctx->step_dev, 4);
+    rc |= dalloc(ctx, &ctx->axpby_coef, 2 * Np);
+    rc |= dalloc(ctx, &ctx->band_lo, Tp); rc |= dalloc(ctx, &ctx->band_hi, Tp);
+    rc |= dalloc(ctx, &ctx->init_cm, Be * 32 * Tp); rc |= dalloc(ctx, &ctx->enoise_cm, Be * 32 * Tp); rc |= dalloc(ctx, &ctx->mask_cm, Be * 32 * Tp);
+    rc |= dalloc(ctx, &ctx->rescale_part, Be * 2 * 64 * 3);
+    rc |= dalloc(ctx, &ctx->freqs, MC / 2);
+    if (rc) { g_create_err = ctx->err; said_destroy(ctx); return -1; }
+    *out = ctx;
+    return 0;
+}
+
+int said_destroy(said_ctx* ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
+    if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
+    for (void* p : ctx->allocs) (void)hipFree(p);
+    delete ctx;
+    return 0;
+}
+
+int said_set_weight(said_ctx* ctx, const char* name, const float* data_host, const int64_t* shape, int ndim) {
+    if (!ctx) return -1;
+    if (ctx->finalized) return fail(ctx, "said_set_weight after finalize");
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    t.data.assign(data_host, data_host + t.numel());
+    ctx->host_w[name] = std::move(t);
+    return 0;
+}
+
+int said_set_timestep_freqs(said_ctx* ctx, const float* f, int n) {
+    if (!ctx) return -1;
+    if (n != MC / 2) return fail(ctx, "said_set_timestep_freqs: expected %d entries, got %d", MC / 2, n);
+    HIPCHK(hipMemcpy(ctx->freqs, f, n * sizeof(float), hipMemcpyHostToDevice));
+    ctx->freqs_set = true;
+    return 0;
+}
+
+int said_finalize_weights(said_ctx* ctx, void* stream) {
+    (void)stream;
+    if (!ctx) return -1;
+    if (ctx->finalized) return fail(ctx, "weights already finalized");
+    HIPCHK(hipSetDevice(ctx->device));
+    const std::string D = "denoiser.model.";
+    const int CD = ctx->ctx_dim;
+    size_t used = 0;
+    auto count_prefix = [&](const std::string& p) { size_t n = 0; for (auto& kv : ctx->host_w) if (kv.first.rfind(p, 0) == 0) ++n; return n; };
+
+    // ---- UNet ----
+    if (make_pw(ctx, &ctx->te1, D + "time_embed.0.weight", D + "time_embed.0.bias", TE, MC, 0)) return -1;
+    if (make_pw(ctx, &ctx->te2, D + "time_embed.2.weight", D + "time_embed.2.bias", TE, TE, 0)) return -1;
+    if (make_pw(ctx, &ctx->conv_in, D + "input_blocks.0.0.weight", D + "input_blocks.0.0.bias", MC, ctx->cin, 3)) return -1;
+    if (make_pw(ctx, &ctx->conv_out, D + "out.2.weight", D + "out.2.bias", ctx->cin, MC, 3)) return -1;
+    if (upvec(ctx, &ctx->out_g, D + "out.0.weight", MC) || upvec(ctx, &ctx->out_b, D + "out.0.bias", MC)) return -1;
+    used += 8;
+    const char* res_names[NRES] = {"input_blocks.1.0", "middle_block.0", "middle_block.2", "output_blocks.0.0", "output_blocks.1.0"};
+    const char* st_names[NST] = {"input_blocks.1.1", "middle_block.1", "output_blocks.0.1", "output_blocks.1.1"};
+    std::vector<float> emb_w((size_t)NRES * MC * TE), emb_b((size_t)NRES * MC);
+    for (int r = 0; r < NRES; ++r) {
+        const std::string p = D + res_names[r];
+        ResW& rw = ctx->res[r];
+        rw.cin = r >= 3 ? 2 * MC : MC;
+        rw.has_skip = r >= 3;
+        if (upvec(ctx, &rw.g1, p + ".in_layers.0.weight", rw.cin) || upvec(ctx, &rw.b1, p + ".in_layers.0.bias", rw.cin)) return -1;
+        if (make_pw(ctx, &rw.conv1, p + ".in_layers.2.weight", p + ".in_layers.2.bias", MC, rw.cin, 3, rw.has_skip ? 2 : 1)) return -1;
+        if (upvec(ctx, &rw.g2, p + ".out_layers.0.weight", MC) || upvec(ctx, &rw.b2, p + ".out_layers.0.bias", MC)) return -1;
+        if (make_pw(ctx, &rw.conv2, p + ".out_layers.3.weight", p + ".out_layers.3.bias", MC, MC, 3)) return -1;
+        const HostTensor* ew = getw(ctx, p + ".emb_layers.1.weight", {MC, TE});
+        const HostTensor* eb = getw(ctx, p + ".emb_layers.1.bias", {MC});
+        if (!ew || !eb) return -1;
+        std::copy(ew->data.begin(), ew->data.end(), emb_w.begin() + (size_t)r * MC * TE);
+        std::copy(eb->data.begin(), eb->data.end(), emb_b.begin() + (size_t)r * MC);
+        used += 10;
+        rw.bias2 = nullptr;
+        if (rw.has_skip) {
+            if (make_pw(ctx, &rw.skip, p + ".skip_connection.weight", p + ".skip_connection.bias", MC, 2 * MC, 1, 2)) return -1;
+            const HostTensor* b2 = getw(ctx, p + ".out_layers.3.bias", {MC});
+            const HostTensor* bs = getw(ctx, p + ".skip_connection.bias", {MC});
+            std::vector<float> sum(MC);
+            for (int i = 0; i < MC; ++i) sum[i] = b2->data[i] + bs->data[i];
+            if (upload(ctx, &rw.bias2, sum.data(), MC)) return -1;
+            used += 2;
+        }
+    }
+    {   // all five emb_layers as one GEMM (960 x 768)
+        ctx->host_w["__emb_all.w"] = HostTensor{emb_w, {NRES * MC, TE}};
+        ctx->host_w["__emb_all.b"] = HostTensor{emb_b, {NRES * MC}};
+        if (make_pw(ctx, &ctx->emb_all, "__emb_all.w", "__emb_all.b", NRES * MC, TE, 0)) return -1;
+    }
+    std::vector<float> kv_w((size_t)NST * 2 * MC * CD);
+    for (int i = 0; i < NST; ++i) {
+        const std::string p = D + st_names[i], b = p + ".transformer_blocks.0";
+        STW& sw = ctx->st[i];
+        if (upvec(ctx, &sw.gn_g, p + ".norm.weight", MC) || upvec(ctx, &sw.gn_b, p + ".norm.bias", MC)) return -1;
+        if (upvec(ctx, &sw.l1g, b + ".norm1.weight", MC) || upvec(ctx, &sw.l1b, b + ".norm1.bias", MC)) return -1;
+        if (upvec(ctx, &sw.l2g, b + ".norm2.weight", MC) || upvec(ctx, &sw.l2b, b + ".norm2.bias", MC)) return -1;
+        if (upvec(ctx, &sw.l3g, b + ".norm3.weight", MC) || upvec(ctx, &sw.l3b, b + ".norm3.bias", MC)) return -1;
+        const HostTensor* wq = getw(ctx, b + ".attn1.to_q.weight", {MC, MC});
+        const HostTensor* wk = getw(ctx, b + ".attn1.to_k.weight", {MC, MC});
+        const HostTensor* wv = getw(ctx, b + ".attn1.to_v.weight", {MC, MC});
+        if (!wq || !wk || !wv) return -1;
+        std::vector<float> qkv;
+        qkv.insert(qkv.end(), wq->data.begin(), wq->data.end());
+        qkv.insert(qkv.end(), wk->data.begin(), wk->data.end());
+        qkv.insert(qkv.end(), wv->data.begin(), wv->data.end());
+        ctx->host_w["__qkv"] = HostTensor{qkv, {3 * MC, MC}};
+        if (make_pw(ctx, &sw.qkv, "__qkv", "", 3 * MC, MC, 0)) return -1;
+        if (make_pw(ctx, &sw.out1, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", MC, MC, 0)) return -1;
+        if (make_pw(ctx, &sw.q2, b + ".attn2.to_q.weight", "", MC, MC, 0)) return -1;
+        const HostTensor* k2 = getw(ctx, b + ".attn2.to_k.weight", {MC, CD});
+        const HostTensor* v2 = getw(ctx, b + ".attn2.to_v.weight", {MC, CD});
+        if (!k2 || !v2) return -1;
+        std::copy(k2->data.begin(), k2->data.end(), kv_w.begin() + (size_t)(i * 2) * MC * CD);
+        std::copy(v2->data.begin(), v2->data.end(), kv_w.begin() + (size_t)(i * 2 + 1) * MC * CD);
+        if (make_pw(ctx, &sw.out2, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", MC, MC, 0)) return -1;
+        if (make_pw(ctx, &sw.ff1, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", 2 * FFI, MC, 0)) return -1;
+        if (make_pw(ctx, &sw.ff2, b + ".ff.net.2.weight", b + ".ff.net.2.bias", MC, FFI, 0)) return -1;
+        if (make_pw(ctx, &sw.proj, p + ".proj_out.weight", p + ".proj_out.bias", MC, MC, 1)) return -1;
+        used += 24;
+    }
+    ctx->host_w["__kv_all"] = HostTensor{kv_w, {NST * 2 * MC, CD}};
+    if (make_pw(ctx, &ctx->kv_all, "__kv_all", "", NST * 2 * MC, CD, 0)) return -1;
+    {
+        const HostTensor* nc = getw(ctx, "null_cond_emb", {1, 1, CD});
+        if (!nc) return -1;
+        if (upload(ctx, &ctx->null_cond, nc->data.data(), CD)) return -1;
+        used += 1;
+    }
+    if (count_prefix("denoiser.") != 160) return fail(ctx, "unexpected key(s) in state dict: %zu denoiser.* tensors, expected 160", count_prefix("denoiser."));
+
+    // ---- audio encoder (optional as a group: absent => said_audio_encode is unavailable) ----
+    const std::string A = "audio_encoder.";
+    const size_t n_audio = count_prefix(A);
+    if (n_audio > 0) {
+        int cin = 1;
+        for (int i = 0; i < 7; ++i) {
+            const std::string wn = A + "feature_extractor.conv_layers." + std::to_string(i) + ".conv.weight";
+            auto it = ctx->host_w.find(wn);
+            if (it == ctx->host_w.end() || it->second.shape.size() != 3) return fail(ctx, "missing key in state dict: %s", wn.c_str());
+            const int k = (int)it->second.shape[2];
+            ctx->w2v_kernel[i] = k;
+            if (!getw(ctx, wn, {W2V_CONV, cin, k})) return -1;
+            if (i == 0) {
+                if (upload(ctx, &ctx->c0_w, it->second.data.data(), (size_t)W2V_CONV * k)) return -1;
+                if (upvec(ctx, &ctx->c0_g, A + "feature_extractor.conv_layers.0.layer_norm.weight", W2V_CONV)) return -1;
+                if (upvec(ctx, &ctx->c0_b, A + "feature_extractor.conv_layers.0.layer_norm.bias", W2V_CONV)) return -1;
+            } else {
+                if (make_pw(ctx, &ctx->aconv[i], wn, "", W2V_CONV, W2V_CONV, k)) return -1;
+            }
+            cin = W2V_CONV;
+        }
+        if (upvec(ctx, &ctx->fp_lng, A + "feature_projection.layer_norm.weight", W2V_CONV)) return -1;
+        if (upvec(ctx, &ctx->fp_lnb, A + "feature_projection.layer_norm.bias", W2V_CONV)) return -1;
+        if (make_pw(ctx, &ctx->fproj, A + "feature_projection.projection.weight", A + "feature_projection.projection.bias", W2V_H, W2V_CONV, 0)) return -1;
+        if (!getw(ctx, A + "masked_spec_embed", {W2V_H})) return -1;
+        {   // positional conv: weight_norm(dim=2) folded on the host, then grouped packing (16 groups of 48)
+            auto ig = ctx->host_w.find(A + "encoder.pos_conv_embed.conv.weight_g");
+            if (ig == ctx->host_w.end() || ig->second.shape.size() != 3) return fail(ctx, "missing key in state dict: %sencoder.pos_conv_embed.conv.weight_g", A.c_str());
+            const int K = (int)ig->second.shape[2];
+            const int G = 16, CG = W2V_H / G;
+            const HostTensor* wg = getw(ctx, A + "encoder.pos_conv_embed.conv.weight_g", {1, 1, K});
+            const HostTensor* wv = getw(ctx, A + "encoder.pos_conv_embed.conv.weight_v", {W2V_H, CG, K});
+            if (!wg || !wv) return -1;
+            std::vector<double> nrm(K, 0.0);
+            for (size_t i = 0; i < wv->data.size(); ++i) nrm[i % K] += (double)wv->data[i] * wv->data[i];
+            std::vector<float> wfull(wv->data.size());
+            for (size_t i = 0; i < wv->data.size(); ++i) {
+                const float nk = (float)std::sqrt(nrm[i % K]);
+                wfull[i] = wv->data[i] * (wg->data[i % K] / nk);
+            }
+            PW& pw = ctx->posconv;
+            pw.N = CG; pw.taps = K; pw.nseg = 1; pw.C[0] = CG;
+            std::vector<float> packed;
+            for (int g = 0; g < G; ++g) {
+                auto rows = rows_dense(CG, g * CG);
+                auto part = pack_rows(wfull.data(), CG, K, rows, (CG + 31) / 32, 0, CG);
+                packed.insert(packed.end(), part.begin(), part.end());
+            }
+            if (upload(ctx, &pw.w[0], packed.data(), packed.size())) return -1;
+            if (upvec(ctx, &pw.bias, A + "encoder.pos_conv_embed.conv.bias", W2V_H)) return -1;
+        }
+        if (upvec(ctx, &ctx->enc_lng, A + "encoder.layer_norm.weight", W2V_H) || upvec(ctx, &ctx->enc_lnb, A + "encoder.layer_norm.bias", W2V_H)) return -1;
+        int L = 0;
+        while (ctx->host_w.count(A + "encoder.layers." + std::to_string(L) + ".layer_norm.weight")) ++L;
+        ctx->w2v_layers = L;
+        ctx->layers.resize(L);
+        for (int l = 0; l < L; ++l) {
+            const std::string p = A + "encoder.layers." + std::to_string(l);
+            W2VLayer& ly = ctx->layers[l];
+            std::vector<float> qkv, qb;
+            for (const char* n : {"q_proj", "k_proj", "v_proj"}) {
+                const HostTensor* w = getw(ctx, p + ".attention." + n + ".weight", {W2V_H, W2V_H});
+                const HostTensor* b = getw(ctx, p + ".attention." + n + ".bias", {W2V_H});
+                if (!w || !b) return -1;
+                qkv.insert(qkv.end(), w->data.begin(), w->data.end());
+                qb.insert(qb.end(), b->data.begin(), b->data.end());
+            }
+            ctx->host_w["__aqkv.w"] = HostTensor{qkv, {3 * W2V_H, W2V_H}};
+            ctx->host_w["__aqkv.b"] = HostTensor{qb, {3 * W2V_H}};
+            if (make_pw(ctx, &ly.qkv, "__aqkv.w", "__aqkv.b", 3 * W2V_H, W2V_H, 0)) return -1;
+            if (make_pw(ctx, &ly.out, p + ".attention.out_proj.weight", p + ".attention.out_proj.bias", W2V_H, W2V_H, 0)) return -1;
+            if (make_pw(ctx, &ly.ff1, p + ".feed_forward.intermediate_dense.weight", p + ".feed_forward.intermediate_dense.bias", W2V_FFN, W2V_H, 0)) return -1;
+            if (make_pw(ctx, &ly.ff2, p + ".feed_forward.output_dense.weight", p + ".feed_forward.output_dense.bias", W2V_H, W2V_FFN, 0)) return -1;
+            if (upvec(ctx, &ly.ln1g, p + ".layer_norm.weight", W2V_H) || upvec(ctx, &ly.ln1b, p + ".layer_norm.bias", W2V_H)) return -1;
+            if (upvec(ctx, &ly.ln2g, p + ".final_layer_norm.weight", W2V_H) || upvec(ctx, &ly.ln2b, p + ".final_layer_norm.bias", W2V_H)) return -1;
+        }
+        const size_t expect = 1 + 7 + 2 + 4 + 3 + 2 + (size_t)L * 16;
+        if (n_audio != expect) return fail(ctx, "unexpected key(s) in state dict: %zu audio_encoder.* tensors, expected %zu", n_audio, expect);
+        ctx->has_audio = true;
+    }
+    if (ctx->host_w.count("audio_proj_layer.weight")) {
+        if (make_pw(ctx, &ctx->aproj, "audio_proj_layer.weight", "audio_proj_layer.bias", CD, W2V_H, 0)) return -1;
+        ctx->has_audio_proj = true;
+    }
+    for (auto& kv : ctx->host_w) {
+        const std::string& k = kv.first;
+        if (k.rfind("denoiser.", 0) == 0 || k.rfind(A, 0) == 0 || k.rfind("__", 0) == 0 || k == "null_cond_emb" ||
+            k == "audio_proj_layer.weight" || k == "audio_proj_layer.bias")
+            continue;
+        return fail(ctx, "unexpected key(s) in state dict: %s", k.c_str());
+    }
+    if (!ctx->freqs_set) {
+        std::vector<float> f(MC / 2);
+        for (int k = 0; k < MC / 2; ++k) f[k] = (float)std::exp(-std::log(10000.0) * k / (MC / 2));
+        HIPCHK(hipMemcpy(ctx->freqs, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    set_timestep_freqs_dev(ctx->freqs);
+    ctx->host_w.clear();
+    ctx->finalized = true;
+    (void)used;
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// SAID.forward
+// --------------------------------------------------------------------------------------------
+int said_unet_forward(said_ctx* ctx, const float* sample_dev, const int64_t* timesteps_host, const float* context_dev,
+                      int Be, int T, int S, float* out_dev, void* stream) {
+    if (check_ready(ctx)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (Be < 1 || Be > ctx->maxBe) return fail(ctx, "batch %d exceeds the context's max_batch_eff %d", Be, ctx->maxBe);
+    if (T < 1 || T > ctx->maxT || S < 1 || S > ctx->maxT) return fail(ctx, "frames %d / context length %d exceed max_frames %d", T, S, ctx->maxT);
+    if (set_band(ctx, T, S)) return -1;
+    UGeo g = make_geo(ctx, Be, 0, T, S);
+    g.emb_b_stride = 1;
+    std::vector<long long> ts(timesteps_host, timesteps_host + Be);
+    HIPCHK(hipMemcpyAsync(ctx->ts_dev, ts.data(), Be * sizeof(long long), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));  // ts is a stack-local staging buffer
+    ctx->dbg_count = 0;
+    run_time_embed(ctx, Be, s);
+    launch_tm_to_cm(context_dev, ctx->CTX, Be, S, ctx->ctx_dim, g.Sp, (long long)ctx->ctx_dim * g.Sp, s);
+    run_kv(ctx, Be, S, g.Sp, s);
+    launch_tm_to_cm(sample_dev, ctx->x_cm, Be, T, ctx->cin, g.Tp, (long long)ctx->cin * g.Tp, s);
+    run_unet(ctx, g, s);
+    launch_cm_to_tm(ctx->eps_cm, out_dev, Be, T, ctx->cin, g.Tp, (long long)ctx->cin * g.Tp, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// SAID.inference loop
+// --------------------------------------------------------------------------------------------
+int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
+    if (check_ready(ctx)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int B = p->batch, T = p->frames, N = p->num_steps, C = ctx->cin;
+    const bool cfg = p->guidance_scale > 1.0f;
+    const int Be = cfg ? 2 * B : B;
+    if (B < 1 || Be > ctx->maxBe) return fail(ctx, "effective batch %d exceeds the context's max_batch_eff %d", Be, ctx->maxBe);
+    if (T < 1 || T > ctx->maxT) return fail(ctx, "frames %d exceed max_frames %d", T, ctx->maxT);
+    if (N < 0 || N > ctx->maxNp) return fail(ctx, "num_steps %d exceeds %d", N, ctx->maxNp);
+    if (p->prediction_type < 0 || p->prediction_type > 2) return fail(ctx, "bad prediction_type %d", p->prediction_type);
+    if (!p->latents_dev || !p->context_dev) return fail(ctx, "latents_dev/context_dev must not be null");
+    if (p->use_mask && !(p->init_latents_dev && p->edit_noise_dev && p->mask_dev)) return fail(ctx, "use_mask needs init_latents_dev, edit_noise_dev and mask_dev");
+    if (p->use_step_noise && !p->step_noise_dev) return fail(ctx, "use_step_noise needs step_noise_dev");
+    if (p->save_intermediate && !p->intermediates_dev) return fail(ctx, "save_intermediate needs intermediates_dev");
+    if (set_band(ctx, T, T)) return -1;
+    UGeo g = make_geo(ctx, Be, cfg ? B : 0, T, T);
+    g.step_ptr = ctx->step_dev;
+    const long long xs = (long long)C * g.Tp;
+
+    // per-clip, step-invariant work
+    if (N > 0) {
+        HIPCHK(hipMemcpyAsync(ctx->ts_dev, p->timesteps_host, N * sizeof(long long), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(ctx->coef_dev, p->coef_host, (size_t)N * 8 * sizeof(float), hipMemcpyHostToDevice, s));
+        run_time_embed(ctx, N, s);
+    }
+    const long long cs = (long long)ctx->ctx_dim * g.Sp;
+    if (cfg) {  // uncond FIRST (diffusion.py:397-400): null_cond_emb repeated over (B, S)
+        launch_fill_cm_vec(ctx->null_cond, ctx->CTX, B, T, ctx->ctx_dim, g.Sp, cs, s);
+        launch_tm_to_cm(p->context_dev, ctx->CTX + (long long)B * cs, B, T, ctx->ctx_dim, g.Sp, cs, s);
+    } else {
+        launch_tm_to_cm(p->context_dev, ctx->CTX, B, T, ctx->ctx_dim, g.Sp, cs, s);
+    }
+    run_kv(ctx, Be, T, g.Sp, s);
+    launch_tm_to_cm(p->latents_dev, ctx->x_cm, B, T, C, g.Tp, xs, s);
+    if (p->use_mask) {
+        launch_tm_to_cm(p->init_latents_dev, ctx->init_cm, B, T, C, g.Tp, xs, s);
+        launch_tm_to_cm(p->edit_noise_dev, ctx->enoise_cm, B, T, C, g.Tp, xs, s);
+        launch_tm_to_cm(p->mask_dev, ctx->mask_cm, B, T, C, g.Tp, xs, s);
+    }
+    if (p->use_step_noise && N > 0) {
+        const size_t need = (size_t)N * B * xs;
+        if (need > ctx->noise_cm_elems) {
+            HIPCHK(hipStreamSynchronize(s));
+            if (dalloc(ctx, &ctx->noise_cm, need)) return -1;
+            ctx->noise_cm_elems = need;
+        }
+        launch_tm_to_cm(p->step_noise_dev, ctx->noise_cm, N * B, T, C, g.Tp, xs, s);
+    }
+    HIPCHK(hipMemsetAsync(ctx->step_dev, 0xFF, sizeof(int), s));  // step = -1
+
+    // per-step graph
+    SchedArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.eps = ctx->eps_cm; sa.eps_bstride = xs; sa.pitch = g.Tp; sa.B = B; sa.T = T; sa.C = C; sa.cfg = cfg ? 1 : 0;
+    sa.guidance_scale = p->guidance_scale; sa.guidance_rescale = (cfg && p->guidance_rescale > 0.f) ? p->guidance_rescale : 0.f;
+    sa.rescale_part = ctx->rescale_part; sa.rescale_nblk = 16; sa.prediction_type = p->prediction_type;
+    sa.coef = ctx->coef_dev; sa.step_ptr = ctx->step_dev; sa.x = ctx->x_cm; sa.x_bstride = xs;
+    sa.step_noise = p->use_step_noise ? ctx->noise_cm : nullptr;
+    sa.init = p->use_mask ? ctx->init_cm : nullptr; sa.edit_noise = p->use_mask ? ctx->enoise_cm : nullptr;
+    sa.mask = p->use_mask ? ctx->mask_cm : nullptr;
+    sa.inter = p->save_intermediate ? p->intermediates_dev : nullptr; sa.latent_scale = p->latent_scale;
+
+    if (N > 0) {
+        float gs = p->guidance_scale, gr = sa.guidance_rescale, ls = p->latent_scale;
+        int gsi, gri, lsi;
+        memcpy(&gsi, &gs, 4); memcpy(&gri, &gr, 4); memcpy(&lsi, &ls, 4);
+        std::vector<long long> key = {B, T, cfg, gsi, gri, lsi, p->prediction_type, p->use_mask, p->use_step_noise,
+                                      (long long)(uintptr_t)sa.inter, (long long)(uintptr_t)sa.step_noise, (long long)(uintptr_t)s};
+        if (!ctx->gexec || key != ctx->gkey) {
+            if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
+            if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            launch_step_advance(ctx->step_dev, s);
+            run_unet(ctx, g, s);
+            if (sa.guidance_rescale > 0.f) launch_rescale_partials(sa, ctx->rescale_part, s);
+            launch_sched_step(sa, s);
+            hipError_t e = hipStreamEndCapture(s, &ctx->graph);
+            if (e != hipSuccess) return fail(ctx, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            HIPCHK(hipGraphInstantiate(&ctx->gexec, ctx->graph, nullptr, nullptr, 0));
+            size_t nn = 0;
+            (void)hipGraphGetNodes(ctx->graph, nullptr, &nn);
+            ctx->gnodes = (int)nn;
+            ctx->gkey = key;
+        }
+        for (int k = 0; k < N; ++k) HIPCHK(hipGraphLaunch(ctx->gexec, s));
+    }
+    launch_finish(ctx->x_cm, xs, g.Tp, B, T, C, p->latent_scale, p->latents_dev, p->result_dev, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int said_ddim_step(said_ctx* ctx, const float* eps_dev, const float* eps_uncond_dev, float guidance_scale,
+                   const float* sample_dev, const float* coef_host, int prediction_type, const float* step_noise_dev,
+                   const float* init_latents_dev, const float* edit_noise_dev, const float* mask_dev, float* prev_sample_dev,
+                   int64_t n, void* stream) {
+    if (!ctx) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (prediction_type < 0 || prediction_type > 2) return fail(ctx, "bad prediction_type %d", prediction_type);
+    if (mask_dev && !(init_latents_dev && edit_noise_dev)) return fail(ctx, "mask needs init_latents_dev and edit_noise_dev");
+    HIPCHK(hipMemcpyAsync(ctx->coef1_dev, coef_host, 8 * sizeof(float), hipMemcpyHostToDevice, s));
+    if (n > 0)
+        launch_ddim_flat(eps_dev, eps_uncond_dev, guidance_scale, sample_dev, ctx->coef1_dev, prediction_type, step_noise_dev,
+                         init_latents_dev, edit_noise_dev, mask_dev, prev_sample_dev, n, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int said_axpby(said_ctx* ctx, const float* a_host, const float* x_dev, const float* c_host, const float* y_dev, float* out_dev,
+               int batch, int64_t n_per_batch, void* stream) {
+    if (!ctx) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (batch < 1 || batch > ctx->maxNp) return fail(ctx, "said_axpby: batch %d out of range", batch);
+    // coefficient staging shares the (otherwise idle here) E0 table: 2 * batch floats
+    std::vector<float> ac(2 * (size_t)batch, 0.f);
+    for (int b = 0; b < batch; ++b) { ac[b] = a_host[b]; ac[batch + b] = (y_dev && c_host) ? c_host[b] : 0.f; }
+    HIPCHK(hipMemcpyAsync(ctx->axpby_coef, ac.data(), ac.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (n_per_batch > 0) launch_axpby(ctx->axpby_coef, x_dev, ctx->axpby_coef + batch, y_dev, out_dev, batch, n_per_batch, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int said_debug_stop_after(said_ctx* ctx, int n) {
+    if (!ctx) return -1;
+    ctx->dbg_stop = n;
+    return 0;
+}
+
+int said_debug_read(said_ctx* ctx, const char* name, float* out_host, int64_t n) {
+    if (!ctx) return -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    const std::map<std::string, const float*> m = {
+        {"H0", ctx->H0.p}, {"H1", ctx->H1.p}, {"P", ctx->P.p}, {"Q", ctx->Q.p}, {"M", ctx->M.p},
+        {"stH0", ctx->H0.st}, {"stH1", ctx->H1.st}, {"stP", ctx->P.st}, {"stQ", ctx->Q.st}, {"stM", ctx->M.st},
+        {"X1", ctx->X1}, {"X2", ctx->X2}, {"X3", ctx->X3}, {"O", ctx->O}, {"QK", ctx->QK}, {"VT", ctx->VT}, {"F", ctx->F},
+        {"KV", ctx->KV}, {"CTX", ctx->CTX}, {"EO", ctx->EO}, {"E0", ctx->E0}, {"E1", ctx->E1}, {"E2", ctx->E2},
+        {"x", ctx->x_cm}, {"eps", ctx->eps_cm}, {"aH", ctx->aH}, {"aT", ctx->aT}, {"aX", ctx->aX}, {"aPOS", ctx->aPOS},
+        {"aQK", ctx->aQK}, {"aO", ctx->aO}, {"aF", ctx->aF}, {"abufA", ctx->abufA}, {"abufB", ctx->abufB}};
+    auto it = m.find(name);
+    if (it == m.end() || !it->second) return fail(ctx, "said_debug_read: unknown or unallocated buffer %s", name);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_host, it->second, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int said_graph_num_nodes(const said_ctx* ctx) { return ctx ? ctx->gnodes : 0; }
+
+double said_unet_algorithmic_bytes(int Be, int T, int bytes_per_elem) {
+    // W + Be*T*A, A = 63,232 B/token at fp32
+    return 6992672.0 * bytes_per_elem + (double)Be * T * (63232.0 * bytes_per_elem / 4.0);
+}
+double said_unet_algorithmic_flops(int Be, int T) {
+    // banded cross-attention, cross K/V precomputed
+    const double lin = 5492736.0 - 1179648.0;
+    return 2.0 * Be * (lin * T + 1536.0 * T * (double)T + 4608.0 * T) + 2.0 * Be * 1474560.0;
+}
+
+// --------------------------------------------------------------------------------------------
+// Audio encoder
+// --------------------------------------------------------------------------------------------
+int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int num_frames, int apply_proj, float* out_dev,
+                      int* out_frames, void* stream) {
+    if (check_ready(ctx)) return -1;
+    if (!ctx->has_audio) return fail(ctx, "audio_encoder.* weights were not loaded");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    int L[7];
+    {
+        int len = Ta;
+        for (int i = 0; i < 7; ++i) {
+            len = (len - ctx->w2v_kernel[i]) / ctx->w2v_stride[i] + 1;
+            if (len < 1) return fail(ctx, "waveform of %d samples is too short for the feature extractor", Ta);
+            L[i] = len;
+        }
+    }
+    const int Fr = num_frames > 0 ? num_frames : L[6];
+    if (out_frames) *out_frames = Fr;
+    const int Fp = rup(Fr, 32);
+    if (apply_proj && !ctx->has_audio_proj) return fail(ctx, "apply_proj requested but audio_proj_layer.* was not loaded");
+    const int out_dim = apply_proj ? ctx->ctx_dim : W2V_H;
+    // workspace: ping-pong conv buffers + token-domain buffers, for `chunk` clips at a time
+    const int chunk = std::min(B, 8);
+    const size_t eA = (size_t)chunk * W2V_CONV * rup(L[0], 32), eB = (size_t)chunk * W2V_CONV * rup(L[1], 32);
+    const size_t tok = (size_t)chunk * Fp;
+    if (eA > ctx->abuf_elems[0] || eB > ctx->abuf_elems[1] || tok > ctx->a_tok_elems) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (dalloc(ctx, &ctx->abufA, eA) || dalloc(ctx, &ctx->abufB, eB)) return -1;
+        ctx->abuf_elems[0] = eA; ctx->abuf_elems[1] = eB;
+        if (dalloc(ctx, &ctx->aX, tok * W2V_CONV) || dalloc(ctx, &ctx->aH, tok * W2V_H) || dalloc(ctx, &ctx->aT, tok * W2V_H) ||
+            dalloc(ctx, &ctx->aO, tok * 2 * W2V_H) || dalloc(ctx, &ctx->aQK, tok * 2 * W2V_H) || dalloc(ctx, &ctx->aVT, tok * W2V_H) ||
+            dalloc(ctx, &ctx->aF, tok * W2V_FFN) || dalloc(ctx, &ctx->aPOS, tok * W2V_H))
+            return -1;
+        ctx->a_tok_elems = tok;
+    }
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = std::min(chunk, B - b0);
+        // ---- feature extractor ----
+        int pitch = rup(L[0], 32);
+        long long bs = (long long)W2V_CONV * pitch;
+        launch_conv0(wav_dev + (long long)b0 * Ta, ctx->c0_w, ctx->abufA, nb, Ta, W2V_CONV, ctx->w2v_kernel[0], ctx->w2v_stride[0], L[0], pitch, bs, s);
+        launch_rownorm_gelu(ctx->abufA, ctx->c0_g, ctx->c0_b, W2V_CONV, nb, L[0], pitch, bs, 1e-5f, s);
+        float* src = ctx->abufA;
+        float* dst = ctx->abufB;
+        for (int i = 1; i < 7; ++i) {
+            const int po = rup(L[i], 32);
+            const long long bo = (long long)W2V_CONV * po;
+            GemmArgs a = mkargs(L[i], W2V_CONV);
+            a.nseg = 1;
+            a.seg[0] = mkseg(src, bs, pitch, W2V_CONV, ctx->w2v_kernel[i], 0, ctx->w2v_stride[i], L[i - 1], XF_NONE, ctx->aconv[i].w[0]);
+            a.act = ACT_GELU;
+            a.y = dst; a.y_bstride = bo; a.y_pitch = po;
+            const LaunchCfg lc = pick_cfg((long long)nb * ((L[i] + 31) / 32), W2V_CONV / 32, false);
+            launch_gemm(a, EPI_STORE, nb, lc.NB, lc.KS, s);
+            std::swap(src, dst);
+            pitch = po; bs = bo;
+        }
+        // ---- interpolation to the frame count (wav2vec2.py:41-44) ----
+        const long long xs = (long long)W2V_CONV * Fp, hs = (long long)W2V_H * Fp;
+        const float* feat = src; long long feat_bs = bs; int feat_pitch = pitch;
+        if (num_frames > 0) {
+            launch_interp_linear(src, ctx->aX, nb, W2V_CONV, L[6], Fr, pitch, Fp, bs, xs, s);
+            feat = ctx->aX; feat_bs = xs; feat_pitch = Fp;
+        }
+        const long long tt = (long long)nb * ((Fr + 31) / 32);
+        {   // feature_projection: LayerNorm(512) -> Linear(512, 768)
+            GemmArgs a = mkargs(Fr, W2V_H);
+            a.nseg = 1;
+            a.seg[0] = mkseg(feat, feat_bs, feat_pitch, W2V_CONV, 1, 0, 1, Fr, XF_LN, ctx->fproj.w[0]);
+            a.seg[0].ln_gamma = ctx->fp_lng; a.seg[0].ln_beta = ctx->fp_lnb; a.seg[0].ln_eps = 1e-5f;
+            a.bias = ctx->fproj.bias;
+            a.y = ctx->aH; a.y_bstride = hs; a.y_pitch = Fp;
+            const LaunchCfg lc = pick_cfg(tt, W2V_H / 32);
+            launch_gemm(a, EPI_STORE, nb, lc.NB, lc.KS, s);
+        }
+        {   // positional conv embedding: grouped Conv1d(k=128, pad=64, groups=16) + GELU; last frame dropped
+            GemmArgs a = mkargs(Fr, W2V_H / 16);
+            a.groups = 16; a.ntiles_per_group = 2;
+            a.nseg = 1;
+            a.seg[0] = mkseg(ctx->aH, hs, Fp, W2V_H / 16, ctx->posconv.taps, ctx->posconv.taps / 2, 1, Fr, XF_NONE, ctx->posconv.w[0]);
+            a.seg[0].c_group_stride = W2V_H / 16;
+            a.bias = ctx->posconv.bias; a.act = ACT_GELU;
+            a.y = ctx->aPOS; a.y_bstride = hs; a.y_pitch = Fp;
+            launch_gemm(a, EPI_STORE, nb, tt * 32 <= 2048 ? 1 : 2, 8, s);
+        }
+        launch_layernorm_cm(ctx->aH, ctx->aPOS, ctx->aH, ctx->enc_lng, ctx->enc_lnb, nb, W2V_H, Fr, Fp, hs, 1e-5f, s);
+        const int vt_rows = Fp;
+        for (int l = 0; l < ctx->w2v_layers; ++l) {
+            const W2VLayer& ly = ctx->layers[l];
+            {
+                GemmArgs a = mkargs(Fr, 3 * W2V_H);
+                a.nseg = 1;
+                a.seg[0] = mkseg(ctx->aH, hs, Fp, W2V_H, 1, 0, 1, Fr, XF_NONE, ly.qkv.w[0]);
+                a.bias = ly.qkv.bias;
+                a.y = ctx->aQK; a.y_bstride = 2 * hs; a.y_pitch = Fp;
+                a.vt = ctx->aVT; a.vt_first_tile = 2 * W2V_H / 32; a.vt_heads = W2V_HEADS; a.vt_dim = W2V_HD; a.vt_rows = vt_rows;
+                const bool big = tt * 72 > 4096;
+                launch_gemm(a, EPI_QKV, nb, big ? 6 : 2, big ? 4 : 8, s);
+            }
+            {
+                AttnArgs a;
+                a.q = ctx->aQK; a.k = ctx->aQK + hs; a.vt = ctx->aVT; a.o = ctx->aO;
+                a.qkv_bstride = 2 * hs; a.pitch = Fp; a.T = Fr; a.heads = W2V_HEADS; a.vt_rows = vt_rows; a.scale = 0.125f;
+                launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : (tt * W2V_HEADS <= 8192 ? 4 : 1), s);
+            }
+            {
+                GemmArgs a = mkargs(Fr, W2V_H);
+                a.nseg = 1;
+                a.seg[0] = mkseg(ctx->aO, 2 * hs, Fp, W2V_H, 1, 0, 1, Fr, XF_NONE, ly.out.w[0]);
+                a.bias = ly.out.bias;
+                a.res_kind = RES_PLAIN; a.res = ctx->aH; a.res_bstride = hs; a.res_pitch = Fp;
+                a.y = ctx->aT; a.y_bstride = hs; a.y_pitch = Fp;
+                const LaunchCfg lc = pick_cfg(tt, W2V_H / 32);
+                launch_gemm(a, EPI_STORE, nb, lc.NB, lc.KS, s);
+            }
+            launch_layernorm_cm(ctx->aT, nullptr, ctx->aH, ly.ln1g, ly.ln1b, nb, W2V_H, Fr, Fp, hs, 1e-5f, s);
+            {
+                GemmArgs a = mkargs(Fr, W2V_FFN);
+                a.nseg = 1;
+                a.seg[0] = mkseg(ctx->aH, hs, Fp, W2V_H, 1, 0, 1, Fr, XF_NONE, ly.ff1.w[0]);
+                a.bias = ly.ff1.bias; a.act = ACT_GELU;
+                a.y = ctx->aF; a.y_bstride = (long long)W2V_FFN * Fp; a.y_pitch = Fp;
+                const LaunchCfg lc = pick_cfg(tt, W2V_FFN / 32);
+                launch_gemm(a, EPI_STORE, nb, lc.NB, lc.KS, s);
+            }
+            {
+                GemmArgs a = mkargs(Fr, W2V_H);
+                a.nseg = 1;
+                a.seg[0] = mkseg(ctx->aF, (long long)W2V_FFN * Fp, Fp, W2V_FFN, 1, 0, 1, Fr, XF_NONE, ly.ff2.w[0]);
+                a.bias = ly.ff2.bias;
+                a.res_kind = RES_PLAIN; a.res = ctx->aH; a.res_bstride = hs; a.res_pitch = Fp;
+                a.y = ctx->aT; a.y_bstride = hs; a.y_pitch = Fp;
+                const LaunchCfg lc = pick_cfg(tt, W2V_H / 32);
+                launch_gemm(a, EPI_STORE, nb, lc.NB, lc.KS, s);
+            }
+            launch_layernorm_cm(ctx->aT, nullptr, ctx->aH, ly.ln2g, ly.ln2b, nb, W2V_H, Fr, Fp, hs, 1e-5f, s);
+        }
+        const float* fin = ctx->aH; long long fin_bs = hs;
+        if (apply_proj) {  // diffusion.py:228-229
+            GemmArgs a = mkargs(Fr, out_dim);
+            a.nseg = 1;
+            a.seg[0] = mkseg(ctx->aH, hs, Fp, W2V_H, 1, 0, 1, Fr, XF_NONE, ctx->aproj.w[0]);
+            a.bias = ctx->aproj.bias;
+            a.y = ctx->aT; a.y_bstride = (long long)out_dim * Fp; a.y_pitch = Fp;
+            launch_gemm(a, EPI_STORE, nb, 1, 8, s);
+            fin = ctx->aT; fin_bs = (long long)out_dim * Fp;
+        }
+        launch_cm_to_tm(fin, out_dev + (long long)b0 * Fr * out_dim, nb, Fr, out_dim, Fp, fin_bs, s);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

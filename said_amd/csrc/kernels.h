@@ -1,0 +1,180 @@
+// kernels.h — launch-level interface between engine.cpp and the gfx950 kernels.
+//
+// Activation layout ("channel-major"): X[b][c][t], t contiguous, row pitch `pitch`
+// floats (multiple of 32, >= T).  This is the layout of the reference's Conv1d
+// tensors (said/model/unet_1d_condition.py:73-75) and makes every MFMA operand
+// fetch a coalesced 128-byte row segment: for v_mfma_f32_32x32x2_f32 the B operand
+// of lane l is X[c0 + (l>>5)][t0 + (l&31)].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace said {
+
+// operand transforms applied while loading X (fused producer-side elementwise work)
+enum XForm : int {
+    XF_NONE = 0,
+    XF_GN_SILU = 1,  // silu(groupnorm(x))           ResBlock in_layers/out_layers, UNet `out`
+    XF_LN = 2,       // layernorm over channels      norm2 / norm3
+    XF_GN_LN = 3,    // layernorm(groupnorm(x))      SpatialTransformer.norm -> norm1
+    XF_SILU = 4,     // silu(x)                      emb_layers
+};
+
+enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2 };
+enum Res : int { RES_NONE = 0, RES_PLAIN = 1, RES_GN = 2 };
+enum Epi : int { EPI_STORE = 0, EPI_QKV = 1, EPI_GEGLU = 2, EPI_BAND = 3 };
+
+// One K-segment of a GEMM: out[n][t] += sum_{tap,c} W[n][c][tap] * xform(X[c][t*stride + tap - pad])
+struct Seg {
+    const float* x;        // source, channel 0 of this segment, batch 0
+    const float* w;        // packed weights [groups][ntiles][taps][C/2][64]
+    const float* gn_part;  // GN partial stats of the source [B][C][nparts][2] (mean, M2), channel 0 of segment
+    const float* gn_gamma; // GN affine (segment channel 0)
+    const float* gn_beta;
+    const float* ln_gamma; // LN affine
+    const float* ln_beta;
+    long long x_bstride;   // floats between batches of the source
+    long long gn_part_bstride;
+    int x_pitch;           // floats between channels of the source
+    int C;                 // channels in this segment (per group)
+    int taps, pad, stride;
+    int Tin;               // valid source length
+    int xform;
+    int gn_cpg;            // channels per GN group
+    int gn_nparts;         // partials per channel
+    float gn_eps, ln_eps;
+    int b_mod;             // source batch = b % b_mod when > 0 (CFG: both halves read the same latents)
+    int c_group_stride;    // source channel offset per conv group (grouped conv), else 0
+};
+
+struct BandArgs {          // banded cross-attention fused behind the q projection
+    const float* k;        // [Be][C][Sp] channel-major keys (precomputed per clip)
+    const float* v;
+    const int* lo;         // [T] first visible key of query t (ldm/attention.py:184-189)
+    const int* hi;         // [T] one past the last visible key
+    long long kv_bstride;
+    int kv_pitch;
+    int wmax;              // max(hi - lo)
+    float scale;           // dim_head ** -0.5, applied after QK^T (ldm/attention.py:101)
+};
+
+struct GemmArgs {
+    Seg seg[3];
+    int nseg;
+    int T;                 // output length
+    int N;                 // output channels per group
+    int groups;            // conv groups (1 unless grouped conv)
+    int ntiles_per_group;  // ceil(N / 32)
+    const float* bias;     // [groups*N] or null
+    int act;               // Act, applied after bias
+    // + emb[row][n]: per-(row, channel) additive term (ResBlock emb_layers output)
+    const float* emb;      // [(n)][emb_pitch] channel-major table, or null
+    const int* step_ptr;   // device step counter: row = *step_ptr (loop) ...
+    int emb_b_stride;      // ... + b * emb_b_stride (forward(): row = b)
+    int emb_pitch;
+    // residual
+    int res_kind;
+    const float* res;      // [B][N][res_pitch]
+    long long res_bstride;
+    int res_pitch;
+    const float* res_gn_part;  // RES_GN: partial stats of `res`, gamma/beta/eps
+    const float* res_gn_gamma;
+    const float* res_gn_beta;
+    long long res_gn_part_bstride;
+    int res_gn_cpg, res_gn_nparts;
+    float res_gn_eps;
+    // output
+    float* y;              // channel-major [B][groups*N][y_pitch]
+    long long y_bstride;
+    int y_pitch;
+    float* stats_out;      // GN partials of y: [B][groups*N][ceil(T/32)][2], or null
+    long long stats_bstride;
+    // EPI_QKV: tiles >= vt_first_tile are written token-major: vt[b][h][t][d]
+    float* vt;
+    int vt_first_tile;
+    int vt_heads, vt_dim, vt_rows;   // rows = padded T of the vt buffer
+    // EPI_GEGLU: gate tile = value tile + geglu_gate_tiles
+    int geglu_gate_tiles;
+    BandArgs band;
+};
+
+struct AttnArgs {
+    const float* q;        // [B][H*D][pitch]
+    const float* k;
+    const float* vt;       // [B][H][rows][D]
+    float* o;              // [B][H*D][pitch]
+    long long qkv_bstride; // floats between batches for q/k/o
+    int pitch;
+    int T;                 // queries == keys
+    int heads;
+    int vt_rows;
+    float scale;
+};
+
+// tile shape selection: NB 32-row tiles per workgroup, KS waves splitting K
+void launch_gemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s);
+void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s);
+
+// token-major (B,T,C) <-> channel-major [B][C][pitch]
+void launch_tm_to_cm(const float* src, float* dst, int B, int T, int C, int pitch, long long dst_bstride, hipStream_t s);
+void launch_cm_to_tm(const float* src, float* dst, int B, int T, int C, int pitch, long long src_bstride, hipStream_t s);
+// broadcast one vector to every column of a channel-major tensor (null_cond_emb.repeat)
+void launch_fill_cm_vec(const float* vec, float* dst, int B, int T, int C, int pitch, long long dst_bstride, hipStream_t s);
+// sinusoidal timestep embedding, channel-major [dim][pitch], column r <- timesteps[r] (ldm/util.py:66-90)
+void launch_timestep_embedding(const long long* timesteps_dev, float* dst, int n, int dim, int pitch, hipStream_t s);
+void set_timestep_freqs_dev(const float* freqs_dev);  // [dim/2] table used by launch_timestep_embedding
+void launch_step_advance(int* step_ptr, hipStream_t s);
+void configure_gemm_kernels();   // raise the dynamic-LDS limit of every instantiation (call once, outside capture)
+void configure_attn_kernels();
+
+struct SchedArgs {
+    const float* eps;          // channel-major [Be][C][pitch] model output
+    long long eps_bstride;
+    int pitch;
+    int B, T, C;
+    int cfg;                   // 1: eps = e_c + s*(e_c - e_u), uncond half first (diffusion.py:430-434)
+    float guidance_scale;
+    float guidance_rescale;    // > 0: rescale_noise_cfg using rescale_stats
+    const float* rescale_part; // [B][2][nblk][3] partial (n, mean, M2) of e_c and eps_cfg
+    int rescale_nblk;
+    int prediction_type;
+    const float* coef;         // device [nsteps][8]
+    const int* step_ptr;       // device step counter
+    float* x;                  // latents, channel-major [B][C][pitch], updated in place
+    long long x_bstride;
+    const float* step_noise;   // channel-major [nsteps][B][C][pitch] or null
+    const float* init;         // channel-major or null
+    const float* edit_noise;
+    const float* mask;
+    float* inter;              // token-major (nsteps, B, T, C) or null: pre-step latents / latent_scale
+    float latent_scale;
+};
+void launch_sched_step(const SchedArgs& a, hipStream_t s);
+// pre-pass for guidance_rescale > 0: per-block Welford partials of e_c and eps_cfg
+void launch_rescale_partials(const SchedArgs& a, float* part_out, hipStream_t s);
+// standalone elementwise scheduler step on token-major buffers (said_ddim_step)
+void launch_ddim_flat(const float* eps, const float* eps_u, float gs, const float* x, const float* coef_dev, int pred,
+                      const float* noise, const float* init, const float* edit_noise, const float* mask, float* out,
+                      long long n, hipStream_t s);
+// out[b][i] = a[b]*x[b][i] + c[b]*y[b][i] (explicitly rounded mul, mul, add); coefficients live in device memory
+void launch_axpby(const float* a_dev, const float* x, const float* c_dev, const float* y, float* out, int B, long long n,
+                  hipStream_t s);
+// result = clamp(x / latent_scale, 0, 1), channel-major -> token-major; also copies latents out
+void launch_finish(const float* x_cm, long long x_bstride, int pitch, int B, int T, int C, float latent_scale,
+                   float* latents_tm, float* result_tm, hipStream_t s);
+
+// ---- audio-encoder specific kernels ----
+// conv0: 1 -> C channels, kernel K, stride S, no bias (Wav2Vec2 feature extractor layer 0)
+void launch_conv0(const float* wav, const float* w, float* y, int B, int Ta, int C, int K, int S, int Tout, int pitch,
+                  long long y_bstride, hipStream_t s);
+// per-row (b, c) mean/rstd over Tout, then y = gelu(gamma*(y-mean)*rstd+beta) in place
+void launch_rownorm_gelu(float* y, const float* gamma, const float* beta, int rows_per_batch, int B, int T, int pitch,
+                         long long bstride, float eps, hipStream_t s);
+// linear interpolation along t with align_corners=True (wav2vec2.py:41-44)
+void launch_interp_linear(const float* src, float* dst, int B, int C, int Tin, int Tout, int src_pitch, int dst_pitch,
+                          long long src_bstride, long long dst_bstride, hipStream_t s);
+// materialising LayerNorm over channels of a channel-major tensor: y = LN(x (+ add))
+void launch_layernorm_cm(const float* x, const float* add, float* y, const float* gamma, const float* beta, int B, int C,
+                         int T, int pitch, long long bstride, float eps, hipStream_t s);
+
+}  // namespace said

@@ -1,0 +1,432 @@
+// misc.hip — layout changes, timestep embedding, the scheduler update, and the small
+// audio-encoder kernels (conv0, per-row GroupNorm+GELU, linear interpolation, LayerNorm).
+// All are HBM/latency-bound elementwise or row-reduction kernels: coalesced along t.
+#include <cstdio>
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace said {
+
+// ------------------------------------------------------------------------------------------
+// token-major (B,T,C) <-> channel-major [B][C][pitch]
+// ------------------------------------------------------------------------------------------
+__global__ void tm_to_cm_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, int C, int pitch,
+                                long long dst_bstride) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, c = c0 + tx;
+        tile[r][tx] = (t < T && c < C) ? src[((long long)b * T + t) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, t = t0 + tx;
+        if (c < C && t < T) dst[(long long)b * dst_bstride + (long long)c * pitch + t] = tile[tx][r];
+    }
+}
+__global__ void cm_to_tm_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, int C, int pitch,
+                                long long src_bstride) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, t = t0 + tx;
+        tile[r][tx] = (t < T && c < C) ? src[(long long)b * src_bstride + (long long)c * pitch + t] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, c = c0 + tx;
+        if (c < C && t < T) dst[((long long)b * T + t) * C + c] = tile[tx][r];
+    }
+}
+void launch_tm_to_cm(const float* src, float* dst, int B, int T, int C, int pitch, long long dst_bstride, hipStream_t s) {
+    dim3 grid((T + 31) / 32, (C + 31) / 32, B);
+    hipLaunchKernelGGL(tm_to_cm_kernel, grid, dim3(256), 0, s, src, dst, T, C, pitch, dst_bstride);
+}
+void launch_cm_to_tm(const float* src, float* dst, int B, int T, int C, int pitch, long long src_bstride, hipStream_t s) {
+    dim3 grid((T + 31) / 32, (C + 31) / 32, B);
+    hipLaunchKernelGGL(cm_to_tm_kernel, grid, dim3(256), 0, s, src, dst, T, C, pitch, src_bstride);
+}
+
+__global__ void fill_cm_vec_kernel(const float* __restrict__ vec, float* __restrict__ dst, int T, int pitch,
+                                   long long dst_bstride) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) dst[(long long)b * dst_bstride + (long long)c * pitch + t] = vec[c];
+}
+void launch_fill_cm_vec(const float* vec, float* dst, int B, int T, int C, int pitch, long long dst_bstride, hipStream_t s) {
+    dim3 grid((T + 255) / 256, C, B);
+    hipLaunchKernelGGL(fill_cm_vec_kernel, grid, dim3(256), 0, s, vec, dst, T, pitch, dst_bstride);
+}
+
+// ------------------------------------------------------------------------------------------
+// timestep_embedding (ldm/util.py:66-90): dst[k][r] = cos(t_r f_k), dst[half+k][r] = sin(t_r f_k)
+// freqs are supplied by the host (computed with the reference's own fp32 op order).
+// ------------------------------------------------------------------------------------------
+__global__ void temb_kernel(const long long* __restrict__ ts, const float* __restrict__ freqs, float* __restrict__ dst,
+                            int n, int half, int pitch) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (r >= n) return;
+    const float arg = __fmul_rn((float)ts[r], freqs[k]);
+    dst[(long long)k * pitch + r] = cosf(arg);
+    dst[(long long)(k + half) * pitch + r] = sinf(arg);
+}
+static const float* g_freqs_dev = nullptr;
+void set_timestep_freqs_dev(const float* f) { g_freqs_dev = f; }
+void launch_timestep_embedding(const long long* timesteps_dev, float* dst, int n, int dim, int pitch, hipStream_t s) {
+    dim3 grid((n + 63) / 64, dim / 2);
+    hipLaunchKernelGGL(temb_kernel, grid, dim3(64), 0, s, timesteps_dev, g_freqs_dev, dst, n, dim / 2, pitch);
+}
+
+__global__ void step_advance_kernel(int* p) { *p = *p + 1; }
+void launch_step_advance(int* step_ptr, hipStream_t s) { hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, step_ptr); }
+
+// ------------------------------------------------------------------------------------------
+// Scheduler arithmetic.  Every operation is an explicitly rounded fp32 op in diffusers'
+// DDIMScheduler.step order (no FMA contraction), so given the same eps the result is
+// bit-identical to the CPU restatement (oracle/scheduler.py).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cfg_combine(float e_c, float e_u, float s) {
+    // diffusion.py:430-434: noise_pred_audio + guidance_scale * (noise_pred_audio - noise_pred_uncond)
+    return __fadd_rn(e_c, __fmul_rn(s, __fsub_rn(e_c, e_u)));
+}
+__device__ __forceinline__ float ddim_prev(float model_out, float x, const float* cf, int pred) {
+    const float sa = cf[0], sb = cf[1], sap = cf[2], dir = cf[3];
+    float x0, e;
+    if (pred == 0) {
+        x0 = __fdiv_rn(__fsub_rn(x, __fmul_rn(sb, model_out)), sa);
+        e = model_out;
+    } else if (pred == 1) {
+        x0 = model_out;
+        e = __fdiv_rn(__fsub_rn(x, __fmul_rn(sa, x0)), sb);
+    } else {
+        x0 = __fsub_rn(__fmul_rn(sa, x), __fmul_rn(sb, model_out));
+        e = __fadd_rn(__fmul_rn(sa, model_out), __fmul_rn(sb, x));
+    }
+    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);  // clip_sample=True, range 1.0
+    return __fadd_rn(__fmul_rn(sap, x0), __fmul_rn(dir, e));
+}
+__device__ __forceinline__ float mask_blend(float prev, float init, float enoise, float mask, const float* cf) {
+    // diffusion.py:446-456: add_noise(init, noise, t_next) * mask + latents * (1 - mask)
+    const float noisy = __fadd_rn(__fmul_rn(cf[5], init), __fmul_rn(cf[6], enoise));
+    return __fadd_rn(__fmul_rn(noisy, mask), __fmul_rn(prev, __fsub_rn(1.0f, mask)));
+}
+
+// Welford partials of e_c and eps_cfg for rescale_noise_cfg: part[b][which][blk] = (n, mean, M2)
+__global__ void rescale_partials_kernel(const SchedArgs a, float* __restrict__ part) {
+    __shared__ float red[2][4][3];
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    const int total = a.C * a.T;
+    const int per = (total + nblk - 1) / nblk;
+    const int lo = blk * per, hi = min(total, lo + per);
+    const float* ec = a.eps + (long long)(a.B + b) * a.eps_bstride;
+    const float* eu = a.eps + (long long)b * a.eps_bstride;
+    float n = 0.f, m0 = 0.f, q0 = 0.f, m1 = 0.f, q1 = 0.f;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int c = i / a.T, t = i % a.T;
+        const float vc = ec[(long long)c * a.pitch + t];
+        const float vu = eu[(long long)c * a.pitch + t];
+        const float vg = cfg_combine(vc, vu, a.guidance_scale);
+        n += 1.f;
+        float d = vc - m0; m0 += d / n; q0 += d * (vc - m0);
+        d = vg - m1; m1 += d / n; q1 += d * (vg - m1);
+    }
+    // merge lanes then waves (Chan)
+    auto merge = [](float& na, float& ma, float& qa, float nb, float mb, float qb) {
+        const float nt = na + nb;
+        if (nt > 0.f) {
+            const float d = mb - ma;
+            ma += d * nb / nt;
+            qa += qb + d * d * na * nb / nt;
+        }
+        na = nt;
+    };
+    float n1 = n;
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float nb_ = __shfl_xor(n, o), mb0 = __shfl_xor(m0, o), qb0 = __shfl_xor(q0, o);
+        const float mb1 = __shfl_xor(m1, o), qb1 = __shfl_xor(q1, o);
+        float na = n;
+        merge(na, m0, q0, nb_, mb0, qb0);
+        merge(n1, m1, q1, nb_, mb1, qb1);
+        n = na;
+        n1 = n;
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][w][0] = n; red[0][w][1] = m0; red[0][w][2] = q0;
+        red[1][w][0] = n; red[1][w][1] = m1; red[1][w][2] = q1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int k = threadIdx.x;
+        float na = red[k][0][0], ma = red[k][0][1], qa = red[k][0][2];
+        for (int w2 = 1; w2 < (int)(blockDim.x >> 6); ++w2) merge(na, ma, qa, red[k][w2][0], red[k][w2][1], red[k][w2][2]);
+        float* o = part + (((long long)b * 2 + k) * nblk + blk) * 3;
+        o[0] = na; o[1] = ma; o[2] = qa;
+    }
+}
+void launch_rescale_partials(const SchedArgs& a, float* part_out, hipStream_t s) {
+    dim3 grid(a.rescale_nblk, a.B);
+    hipLaunchKernelGGL(rescale_partials_kernel, grid, dim3(256), 0, s, a, part_out);
+}
+
+__global__ void sched_step_kernel(const SchedArgs a) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int step = *a.step_ptr;
+    const float* cf = a.coef + step * 8;
+    float ratio = 1.f;
+    if (a.guidance_rescale > 0.f) {  // uniform branch
+        // combine partials of sample b (tiny: rescale_nblk entries each)
+        float nn[2], mm[2], qq[2];
+        for (int k = 0; k < 2; ++k) {
+            const float* p = a.rescale_part + ((long long)b * 2 + k) * a.rescale_nblk * 3;
+            float na = p[0], ma = p[1], qa = p[2];
+            for (int i = 1; i < a.rescale_nblk; ++i) {
+                const float nb_ = p[3 * i], mb = p[3 * i + 1], qb = p[3 * i + 2];
+                const float nt = na + nb_;
+                const float d = mb - ma;
+                ma += d * nb_ / nt;
+                qa += qb + d * d * na * nb_ / nt;
+                na = nt;
+            }
+            nn[k] = na; mm[k] = ma; qq[k] = qa;
+        }
+        const float std_text = sqrtf(qq[0] / (nn[0] - 1.f));
+        const float std_cfg = sqrtf(qq[1] / (nn[1] - 1.f));
+        ratio = std_text / std_cfg;
+        (void)mm;
+    }
+    if (t >= a.T) return;
+    const long long off = (long long)c * a.pitch + t;
+    float e;
+    if (a.cfg) {
+        const float eu = a.eps[(long long)b * a.eps_bstride + off];
+        const float ec = a.eps[(long long)(a.B + b) * a.eps_bstride + off];
+        e = cfg_combine(ec, eu, a.guidance_scale);
+        if (a.guidance_rescale > 0.f) {
+            // rescale_noise_cfg: phi * (cfg * std_text/std_cfg) + (1 - phi) * cfg
+            const float resc = __fmul_rn(e, ratio);
+            e = __fadd_rn(__fmul_rn(a.guidance_rescale, resc), __fmul_rn(__fsub_rn(1.0f, a.guidance_rescale), e));
+        }
+    } else {
+        e = a.eps[(long long)b * a.eps_bstride + off];
+    }
+    float* xp = a.x + (long long)b * a.x_bstride + off;
+    const float x = *xp;
+    if (a.inter) a.inter[(((long long)step * a.B + b) * a.T + t) * a.C + c] = x / a.latent_scale;
+    float prev = ddim_prev(e, x, cf, a.prediction_type);
+    if (a.step_noise) {
+        const float nz = a.step_noise[((long long)step * a.B + b) * a.x_bstride + off];
+        prev = __fadd_rn(prev, __fmul_rn(cf[4], nz));
+    }
+    if (a.mask) {
+        const long long o2 = (long long)b * a.x_bstride + off;
+        prev = mask_blend(prev, a.init[o2], a.edit_noise[o2], a.mask[o2], cf);
+    }
+    *xp = prev;
+}
+void launch_sched_step(const SchedArgs& a, hipStream_t s) {
+    dim3 grid((a.T + 63) / 64, a.C, a.B);
+    hipLaunchKernelGGL(sched_step_kernel, grid, dim3(64), 0, s, a);
+}
+
+__global__ void ddim_flat_kernel(const float* __restrict__ eps, const float* __restrict__ eps_u, float gs,
+                                 const float* __restrict__ x, const float* __restrict__ cf, int pred,
+                                 const float* __restrict__ noise, const float* __restrict__ init,
+                                 const float* __restrict__ enoise, const float* __restrict__ mask, float* __restrict__ out,
+                                 long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float e = eps[i];
+    if (eps_u) e = cfg_combine(e, eps_u[i], gs);
+    float prev = ddim_prev(e, x[i], cf, pred);
+    if (noise) prev = __fadd_rn(prev, __fmul_rn(cf[4], noise[i]));
+    if (mask) prev = mask_blend(prev, init[i], enoise[i], mask[i], cf);
+    out[i] = prev;
+}
+void launch_ddim_flat(const float* eps, const float* eps_u, float gs, const float* x, const float* coef_dev, int pred,
+                      const float* noise, const float* init, const float* edit_noise, const float* mask, float* out,
+                      long long n, hipStream_t s) {
+    hipLaunchKernelGGL(ddim_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, eps, eps_u, gs, x, coef_dev, pred,
+                       noise, init, edit_noise, mask, out, n);
+}
+
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ c,
+                             const float* __restrict__ y, float* __restrict__ out, long long n) {
+    const int b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long o = (long long)b * n + i;
+    float v = __fmul_rn(a[b], x[o]);
+    if (y) v = __fadd_rn(v, __fmul_rn(c[b], y[o]));
+    out[o] = v;
+}
+void launch_axpby(const float* a_dev, const float* x, const float* c_dev, const float* y, float* out, int B, long long n,
+                  hipStream_t s) {
+    dim3 grid((unsigned)((n + 255) / 256), B);
+    hipLaunchKernelGGL(axpby_kernel, grid, dim3(256), 0, s, a_dev, x, c_dev, y, out, n);
+}
+
+__global__ void finish_kernel(const float* __restrict__ x, long long x_bstride, int pitch, int T, int C, float latent_scale,
+                              float* __restrict__ latents_tm, float* __restrict__ result_tm) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, t = t0 + tx;
+        tile[r][tx] = (t < T && c < C) ? x[(long long)b * x_bstride + (long long)c * pitch + t] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, c = c0 + tx;
+        if (c < C && t < T) {
+            const float v = tile[tx][r];
+            const long long o = ((long long)b * T + t) * C + c;
+            if (latents_tm) latents_tm[o] = v;
+            if (result_tm) result_tm[o] = fminf(fmaxf(v / latent_scale, 0.f), 1.f);  // diffusion.py:470
+        }
+    }
+}
+void launch_finish(const float* x_cm, long long x_bstride, int pitch, int B, int T, int C, float latent_scale,
+                   float* latents_tm, float* result_tm, hipStream_t s) {
+    dim3 grid((T + 31) / 32, (C + 31) / 32, B);
+    hipLaunchKernelGGL(finish_kernel, grid, dim3(256), 0, s, x_cm, x_bstride, pitch, T, C, latent_scale, latents_tm, result_tm);
+}
+
+// ------------------------------------------------------------------------------------------
+// Audio encoder helpers
+// ------------------------------------------------------------------------------------------
+// conv0: y[b][c][t] = sum_k w[c][k] * wav[b][t*S + k]   (K <= 16; 8 channels per thread)
+__global__ void conv0_kernel(const float* __restrict__ wav, const float* __restrict__ w, float* __restrict__ y, int Ta, int C,
+                             int K, int S, int Tout, int pitch, long long y_bstride) {
+    const int b = blockIdx.z, c0 = blockIdx.y * 8;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Tout) return;
+    float xv[16];
+    const float* xp = wav + (long long)b * Ta + (long long)t * S;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xv[k] = (k < K) ? xp[k] : 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+        const int c = c0 + cc;
+        if (c < C) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < K) acc = fmaf(w[c * K + k], xv[k], acc);
+            y[(long long)b * y_bstride + (long long)c * pitch + t] = acc;
+        }
+    }
+}
+void launch_conv0(const float* wav, const float* w, float* y, int B, int Ta, int C, int K, int S, int Tout, int pitch,
+                  long long y_bstride, hipStream_t s) {
+    if (K > 16) { fprintf(stderr, "said: conv0 kernel size %d > 16 unsupported\n", K); abort(); }
+    dim3 grid((Tout + 255) / 256, (C + 7) / 8, B);
+    hipLaunchKernelGGL(conv0_kernel, grid, dim3(256), 0, s, wav, w, y, Ta, C, K, S, Tout, pitch, y_bstride);
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// GroupNorm with one channel per group (Wav2Vec2GroupNormConvLayer) + exact GELU, in place.
+__global__ void rownorm_gelu_kernel(float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    int T, int pitch, long long bstride, float eps) {
+    __shared__ float sh[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    float* row = y + (long long)b * bstride + (long long)c * pitch;
+    float s = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) s += row[t];
+    const float mean = block_sum_256(s, sh) / (float)T;
+    float q = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const float d = row[t] - mean;
+        q = fmaf(d, d, q);
+    }
+    const float var = block_sum_256(q, sh) / (float)T;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float g = gamma[c] * rstd, bb = beta[c] - mean * gamma[c] * rstd;
+    for (int t = threadIdx.x; t < T; t += 256) row[t] = gelu_exact(fmaf(row[t], g, bb));
+}
+void launch_rownorm_gelu(float* y, const float* gamma, const float* beta, int rows_per_batch, int B, int T, int pitch,
+                         long long bstride, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(rownorm_gelu_kernel, dim3(rows_per_batch, B), dim3(256), 0, s, y, gamma, beta, T, pitch, bstride, eps);
+}
+
+// F.interpolate(mode="linear", align_corners=True) along t (wav2vec2.py:41-44)
+__global__ void interp_linear_kernel(const float* __restrict__ src, float* __restrict__ dst, int Tin, int Tout, int src_pitch,
+                                     int dst_pitch, long long src_bstride, long long dst_bstride, float scale) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Tout) return;
+    const float pos = __fmul_rn(scale, (float)i);
+    int i0 = (int)pos;
+    i0 = min(i0, Tin - 1);
+    const int i1 = i0 + ((i0 < Tin - 1) ? 1 : 0);
+    const float l1 = __fsub_rn(pos, (float)i0), l0 = __fsub_rn(1.0f, l1);
+    const float* sp = src + (long long)b * src_bstride + (long long)c * src_pitch;
+    dst[(long long)b * dst_bstride + (long long)c * dst_pitch + i] = __fadd_rn(__fmul_rn(l0, sp[i0]), __fmul_rn(l1, sp[i1]));
+}
+void launch_interp_linear(const float* src, float* dst, int B, int C, int Tin, int Tout, int src_pitch, int dst_pitch,
+                          long long src_bstride, long long dst_bstride, hipStream_t s) {
+    const float scale = (Tout > 1) ? (float)(Tin - 1) / (float)(Tout - 1) : 0.f;
+    dim3 grid((Tout + 63) / 64, C, B);
+    hipLaunchKernelGGL(interp_linear_kernel, grid, dim3(64), 0, s, src, dst, Tin, Tout, src_pitch, dst_pitch, src_bstride,
+                       dst_bstride, scale);
+}
+
+// y[b][c][t] = LN_c(x[b][c][t] + add[b][c][t]) for a channel-major tensor; block = 32 tokens x 8 channel groups
+__global__ void layernorm_cm_kernel(const float* __restrict__ x, const float* __restrict__ add, float* __restrict__ y,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, int C, int T, int pitch,
+                                    long long bstride, float eps) {
+    __shared__ float red[8][32];
+    const int b = blockIdx.y, tx = threadIdx.x & 31, gy = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + tx;
+    const int tc = min(t, T - 1);
+    const float* xb = x + (long long)b * bstride + tc;
+    const float* ab = add ? add + (long long)b * bstride + tc : nullptr;
+    float s = 0.f;
+    for (int c = gy; c < C; c += 8) s += xb[(long long)c * pitch] + (ab ? ab[(long long)c * pitch] : 0.f);
+    red[gy][tx] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) tot += red[g][tx];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float q = 0.f;
+    for (int c = gy; c < C; c += 8) {
+        const float d = xb[(long long)c * pitch] + (ab ? ab[(long long)c * pitch] : 0.f) - mean;
+        q = fmaf(d, d, q);
+    }
+    red[gy][tx] = q;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) tot += red[g][tx];
+    const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
+    if (t < T) {
+        float* yb = y + (long long)b * bstride + t;
+        for (int c = gy; c < C; c += 8) {
+            const float v = xb[(long long)c * pitch] + (ab ? ab[(long long)c * pitch] : 0.f);
+            yb[(long long)c * pitch] = fmaf((v - mean) * rstd, gamma[c], beta[c]);
+        }
+    }
+}
+void launch_layernorm_cm(const float* x, const float* add, float* y, const float* gamma, const float* beta, int B, int C,
+                         int T, int pitch, long long bstride, float eps, hipStream_t s) {
+    dim3 grid((T + 31) / 32, B);
+    hipLaunchKernelGGL(layernorm_cm_kernel, grid, dim3(256), 0, s, x, add, y, gamma, beta, C, T, pitch, bstride, eps);
+}
+
+}  // namespace said

@@ -1,0 +1,224 @@
+"""SAiD diffusion pipeline on the MI355X engine.
+
+Drop-in for the inference surface of /root/reference/said/model/diffusion.py:
+``SAIDInferenceOutput``, ``SAIDNoiseAdditionOutput``, ``SAID``, ``SAID_UNet1D``
+with the reference's constructor / method signatures and ``state_dict()`` key
+layout (``null_cond_emb``, ``audio_encoder.*``, ``denoiser.model.*``, optional
+``audio_proj_layer.*``).  Host code only owns tensors and tables; all device
+math is in hand-written HIP kernels (include/said_hip.h).  No CPU fallback.
+
+Extensions that do not change the reference signatures (keyword-only, default
+off): ``inference(..., init_latents=, edit_noise=, step_noise=)`` inject the
+three random draws of the reference (``torch.randn`` at diffusion.py:364, inside
+``add_noise`` at :383-385, and per-step inside ``scheduler.step`` for eta > 0)
+so a CPU oracle and the GPU path can be fed identical noise.
+"""
+from __future__ import annotations
+
+import weakref
+from abc import ABC
+from dataclasses import dataclass
+from typing import List, Optional, Type, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _engine
+from ..scheduler import DDIMScheduler
+from .processor import AudioProcessor
+from .unet_1d_condition import UNet1DConditionModel
+from .wav2vec2 import AudioConfig, ModifiedWav2Vec2Model
+
+
+@dataclass
+class SAIDInferenceOutput:
+    """Dataclass for the inference output"""
+
+    result: torch.FloatTensor  # (Batch_size, sample_seq_len, x_dim), generated blendshape coefficients
+    intermediates: List[torch.FloatTensor]  # (Batch_size, sample_seq_len, x_dim), pre-step latents
+
+
+@dataclass
+class SAIDNoiseAdditionOutput:
+    """Dataclass for the noise addition output"""
+
+    noisy_sample: torch.FloatTensor
+    noise: torch.FloatTensor
+    velocity: torch.FloatTensor
+
+
+class SAID(ABC, nn.Module):
+    """Abstract class of SAiD models"""
+
+    denoiser: nn.Module
+
+    def __init__(self, audio_config=None, audio_processor=None, noise_scheduler: Type = DDIMScheduler, in_channels: int = 32,
+                 feature_dim: int = -1, diffusion_steps: int = 1000, latent_scale: float = 1,
+                 prediction_type: str = "epsilon"):
+        super().__init__()
+        # Audio-related
+        self.audio_config = audio_config if audio_config is not None else AudioConfig()
+        self.audio_encoder = ModifiedWav2Vec2Model(self.audio_config)
+        # The reference downloads facebook/wav2vec2-base-960h's processor here; its only effect on
+        # this path is zero-mean/unit-variance normalisation, provided offline by AudioProcessor.
+        self.audio_processor = audio_processor if audio_processor is not None else AudioProcessor(16000)
+        self.sampling_rate = self.audio_processor.feature_extractor.sampling_rate
+        self.latent_scale = latent_scale
+        # Noise scheduler
+        self.noise_scheduler = noise_scheduler(num_train_timesteps=diffusion_steps, beta_schedule="squaredcos_cap_v2",
+                                               prediction_type=prediction_type)
+        # Feature embedding
+        self.feature_dim = feature_dim
+        hidden = self.audio_config.output_hidden_size
+        if self.feature_dim > 0:
+            self.audio_proj_layer = nn.Linear(hidden, self.feature_dim)
+            self.null_cond_emb = nn.Parameter(torch.randn(1, 1, self.feature_dim))
+        else:
+            self.null_cond_emb = nn.Parameter(torch.randn(1, 1, hidden))
+        self._eng: Optional[_engine.Engine] = None
+        self._eng_key = None
+        self.audio_encoder._owner = weakref.ref(self)
+
+    # ---- engine management ---------------------------------------------------
+    def _weights_key(self):
+        ps = list(self.parameters())
+        return (str(ps[0].device), sum(p._version for p in ps), sum(p.data_ptr() for p in ps) & 0xFFFFFFFFFFFF)
+
+    def _get_engine(self, batch_eff: int, frames: int) -> _engine.Engine:
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise _engine.EngineError(f"model is on {dev}: said_amd runs on MI355X only — call .to('cuda:N') "
+                                      "(the CPU restatement lives in oracle/ and is test infrastructure)")
+        key = self._weights_key()
+        e = self._eng
+        if e is None or key != self._eng_key or e.max_batch_eff < batch_eff or e.max_frames < frames:
+            cap_b = max(batch_eff, e.max_batch_eff if e else 2)
+            cap_t = max((frames + 63) // 64 * 64, e.max_frames if e else 64)
+            if e is not None:
+                e.close()
+            ctx_dim = self.feature_dim if self.feature_dim > 0 else self.audio_config.hidden_size
+            e = _engine.Engine(dev, cap_b, cap_t, self.denoiser.in_channels, ctx_dim)
+            e.load_weights(self.state_dict())
+            self._eng, self._eng_key = e, key
+            self.noise_scheduler._engine = e
+        return e
+
+    # ---- reference surface -----------------------------------------------------
+    def forward(self, noisy_samples: torch.FloatTensor, timesteps: torch.LongTensor, audio_embedding: torch.FloatTensor) -> torch.FloatTensor:
+        """Predicted noise for (B, T, C) noisy coefficients, timesteps (B,)|(1,)|(), audio tokens (B, S, D)."""
+        timestep_size = timesteps.size()
+        if len(timestep_size) == 0 or timestep_size[0] == 1:
+            timesteps = timesteps.reshape(-1)[:1].repeat(noisy_samples.shape[0])
+        return self.denoiser(noisy_samples, timesteps, audio_embedding)
+
+    def pred_original_sample(self, noisy_samples, noise, timesteps):
+        """x_0 = (x_t - sqrt(1-ā) eps) / sqrt(ā)  (diffusion.py:157-186)."""
+        ac = self.noise_scheduler.alphas_cumprod[torch.as_tensor(timesteps).cpu()].reshape(-1)
+        inv = (1.0 / ac ** 0.5).tolist()
+        nb = (-(1 - ac) ** 0.5 / ac ** 0.5).tolist()
+        e = self._get_engine(noisy_samples.shape[0], noisy_samples.shape[1])
+        return e.axpby(inv, noisy_samples, nb, noise)
+
+    def process_audio(self, waveform: Union[np.ndarray, torch.Tensor, List[np.ndarray]]) -> torch.FloatTensor:
+        """(audio_seq_len,) or list thereof → (B, T_a) processed mono waveform (CPU, as in the reference)."""
+        return self.audio_processor(waveform, sampling_rate=self.sampling_rate, return_tensors="pt")["input_values"]
+
+    def get_audio_embedding(self, waveform: torch.FloatTensor, num_frames: Optional[int]) -> torch.FloatTensor:
+        """(B, T_a) → (B, num_frames, hidden or feature_dim)."""
+        e = self._get_engine(1, num_frames or 1)
+        return e.audio_encode(waveform, num_frames, apply_proj=self.feature_dim > 0)
+
+    def get_random_timesteps(self, batch_size: int) -> torch.LongTensor:
+        return torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (batch_size,), dtype=torch.long)
+
+    def add_noise(self, sample: torch.FloatTensor, timestep: torch.LongTensor, noise: Optional[torch.Tensor] = None) -> SAIDNoiseAdditionOutput:
+        self._get_engine(sample.shape[0], sample.shape[1])
+        if noise is None:
+            noise = torch.randn(sample.shape, device=sample.device)
+        noisy_sample = self.noise_scheduler.add_noise(sample, noise, timestep)
+        velocity = self.noise_scheduler.get_velocity(sample, noise, timestep)
+        return SAIDNoiseAdditionOutput(noisy_sample=noisy_sample, noise=noise, velocity=velocity)
+
+    def encode_samples(self, samples: torch.FloatTensor) -> torch.FloatTensor:
+        return samples.clone()
+
+    def decode_latent(self, latent: torch.FloatTensor) -> torch.FloatTensor:
+        return latent.clone()
+
+    def inference(self, waveform_processed: torch.FloatTensor, init_samples: Optional[torch.FloatTensor] = None,
+                  mask: Optional[torch.FloatTensor] = None, num_inference_steps: int = 100, strength: float = 1.0,
+                  guidance_scale: float = 2.5, guidance_rescale: float = 0.0, eta: float = 0.0, fps: int = 60,
+                  save_intermediate: bool = False, show_process: bool = False, *,
+                  init_latents: Optional[torch.Tensor] = None, edit_noise: Optional[torch.Tensor] = None,
+                  step_noise: Optional[torch.Tensor] = None,
+                  audio_embedding: Optional[torch.Tensor] = None) -> SAIDInferenceOutput:
+        """Inference pipeline (diffusion.py:308-472): schedule, start noise, optional init/mask
+        editing, classifier-free guidance, DDIM updates, final clamp to [0, 1]."""
+        batch_size, waveform_len = waveform_processed.shape
+        in_channels = self.denoiser.in_channels
+        device = waveform_processed.device
+        do_cfg = guidance_scale > 1.0
+        window_size = int(waveform_len / self.sampling_rate * fps)
+        eng = self._get_engine(2 * batch_size if do_cfg else batch_size, window_size)
+        sch = self.noise_scheduler
+        sch.set_timesteps(num_inference_steps)
+
+        if init_samples is None:
+            latents = init_latents.to(device) if init_latents is not None else torch.randn(batch_size, window_size, in_channels, device=device)
+        else:
+            latents = self.encode_samples(init_samples)
+        scale0 = self.latent_scale * sch.init_noise_sigma
+        if scale0 != 1.0:
+            latents = eng.axpby([scale0] * batch_size, latents)
+        init_lat = latents.clone()
+        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+
+        noise = None
+        if init_samples is not None:
+            t0 = sch.timesteps[-init_timestep]
+            timesteps0 = torch.tensor([int(t0)] * batch_size, dtype=torch.long)
+            noise = edit_noise.to(device) if edit_noise is not None else torch.randn(latents.shape, device=device)
+            latents = sch.add_noise(latents, noise, timesteps0)
+
+        if audio_embedding is None:
+            audio_embedding = self.get_audio_embedding(waveform_processed, window_size)
+
+        t_start = num_inference_steps - init_timestep
+        ts = sch.timesteps[t_start:].cpu().numpy().astype(np.int64)
+        n_run = len(ts)
+        coef = sch.coef_table(ts, float(eta))
+        noise_steps = None
+        if eta > 0 and n_run > 0:
+            if step_noise is not None:
+                noise_steps = step_noise.to(device)
+            else:  # one draw per step, in step order, as scheduler.step does
+                noise_steps = torch.empty(n_run, batch_size, window_size, in_channels, device=device)
+                for k in range(n_run):
+                    noise_steps[k] = torch.randn(batch_size, window_size, in_channels, device=device)
+        use_mask = init_samples is not None and mask is not None
+        result, _, inter = eng.denoise_loop(
+            latents=latents, context=audio_embedding, timesteps=ts, coef=coef,
+            prediction_type=sch.config.prediction_type, guidance_scale=guidance_scale, guidance_rescale=guidance_rescale,
+            latent_scale=self.latent_scale, step_noise=noise_steps,
+            init_latents=init_lat if use_mask else None, edit_noise=noise if use_mask else None,
+            mask=mask.to(device) if use_mask else None, save_intermediate=save_intermediate)
+        intermediates = [inter[k] for k in range(n_run)] if save_intermediate else []
+        return SAIDInferenceOutput(result=result, intermediates=intermediates)
+
+
+class SAID_UNet1D(SAID):
+    """SAiD model implemented using U-Net 1D model"""
+
+    def __init__(self, audio_config=None, audio_processor=None, noise_scheduler: Type = DDIMScheduler, in_channels: int = 32,
+                 feature_dim: int = -1, diffusion_steps: int = 1000, latent_scale: float = 1,
+                 prediction_type: str = "epsilon"):
+        # NB: like the reference (diffusion.py:510-518) `noise_scheduler` is accepted but not
+        # forwarded, so the scheduler is always DDIM.
+        super().__init__(audio_config=audio_config, audio_processor=audio_processor, in_channels=in_channels,
+                         feature_dim=feature_dim, diffusion_steps=diffusion_steps, latent_scale=latent_scale,
+                         prediction_type=prediction_type)
+        self.denoiser = UNet1DConditionModel(
+            in_channels=in_channels, out_channels=in_channels,
+            cross_attention_dim=self.feature_dim if self.feature_dim > 0 else self.audio_config.hidden_size)
+        self.denoiser._owner = weakref.ref(self)

@@ -1,0 +1,107 @@
+"""Kernel bring-up aid (run on the GPU box): stops the UNet schedule after every launch and
+compares the buffer that launch produced against the oracle's trace of the same stage.
+
+    python tests/debug_stages.py [B] [T]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import unet as ou  # noqa: E402
+from said_amd import _engine  # noqa: E402
+from said_amd.util import synth  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 48
+    S = int(sys.argv[3]) if len(sys.argv) > 3 else T
+    dev = torch.device("cuda:0")
+    sd_u = synth.fill_state_dict(synth.unet_param_shapes())
+    sd = {"denoiser." + k: v for k, v in sd_u.items()}
+    sd["null_cond_emb"] = synth.fill_tensor("null_cond_emb", (1, 1, 768))
+    eng = _engine.Engine(dev, max(B, 2), max(T, S, 64))
+    eng.load_weights(sd)
+    x = synth.synth_latents(21, (B, T, 32))
+    c = synth.synth_latents(121, (B, S, 768))
+    ts = torch.tensor([999, 17, 500, 3][:B])
+    ou.TRACE = []
+    ref = ou.unet1d_forward(sd_u, x, ts, c)
+    trace = ou.TRACE
+    ou.TRACE = None
+    Tp = (T + 31) // 32 * 32
+
+    def cm(name, C, bstride_rows=None):  # read channel-major buffer -> (B, C, T)
+        rows = bstride_rows or C
+        a = eng.debug_read(name, (B, rows, Tp))
+        return a[:, :C, :T]
+
+    def tm(t):  # oracle (B,T,C) -> (B,C,T)
+        return t.transpose(1, 2).numpy()
+
+    # launch index -> (trace name suffix, reader)
+    stages = []
+    k = 0
+    def add(tname, reader):
+        nonlocal k
+        k += 1
+        stages.append((k, tname, reader))
+    add("conv_in", lambda: cm("H0", 192))
+    def rb(p, outbuf):
+        add(p + ":mid", lambda: cm("M", 192))
+        add(p + ":out", lambda: cm(outbuf, 192))
+    def st(p, outbuf):
+        b = p + ".transformer_blocks.0"
+        add(b + ".attn1:qkv", lambda: None)
+        add(b + ".attn1:attn", lambda: cm("O", 192, 384))
+        add(b + ":x1", lambda: cm("X1", 192))
+        add(b + ".attn2:attn", lambda: cm("O", 192, 384))
+        add(b + ":x2", lambda: cm("X2", 192))
+        add(b + ".ff:geglu", lambda: cm("F", 768))
+        add(b + ":x3", lambda: cm("X3", 192))
+        add(p + ":out", lambda: cm(outbuf, 192))
+    rb("model.input_blocks.1.0", "P"); st("model.input_blocks.1.1", "H1")
+    rb("model.middle_block.0", "P"); st("model.middle_block.1", "Q")
+    rb("model.middle_block.2", "P")
+    rb("model.output_blocks.0.0", "Q"); st("model.output_blocks.0.1", "P")
+    rb("model.output_blocks.1.0", "Q"); st("model.output_blocks.1.1", "P")
+
+    tdict = {}
+    for n, t in trace:
+        tdict.setdefault(n, []).append(t)
+    xd, cd = x.to(dev), c.to(dev)
+    worst = 0.0
+    for (k, tname, reader) in stages:
+        eng.debug_stop_after(k)
+        eng.unet_forward(xd, ts, cd)
+        if tname.endswith(":qkv"):
+            base = tname[:-4]
+            qk = eng.debug_read("QK", (B, 384, Tp))[:, :, :T]
+            Tr = Tp
+            vt = eng.debug_read("VT", (B, 6, Tr, 32))[:, :, :T, :]
+            q, kk, v = (tdict[base + s][0] for s in (":q", ":k", ":v"))
+            e1 = np.abs(qk[:, :192] - tm(q)).max(); e2 = np.abs(qk[:, 192:] - tm(kk)).max()
+            vref = v.reshape(B, T, 6, 32).permute(0, 2, 1, 3).numpy()
+            e3 = np.abs(vt - vref).max()
+            err, scale = max(e1, e2, e3), float(np.abs(tm(q)).max())
+        else:
+            got = reader()
+            t = tdict[tname][0]
+            want = tm(t) if tname.endswith((":attn", ":x1", ":x2", ":x3", ":geglu")) else t.numpy()
+            err, scale = float(np.abs(got - want).max()), float(np.abs(want).max())
+        worst = max(worst, err / max(scale, 1e-9))
+        flag = "" if err <= 2e-4 * max(scale, 1.0) else "   <<<<<< MISMATCH"
+        print(f"launch {k:2d} {tname:58s} max|err|={err:.3e} (max|ref|={scale:.3e}){flag}", flush=True)
+    eng.debug_stop_after(-1)
+    out = eng.unet_forward(xd, ts, cd).cpu()
+    err = float((out - ref).abs().max())
+    print(f"final eps: max|err|={err:.3e}  max|ref|={float(ref.abs().max()):.3e}   worst stage rel err {worst:.3e}")
+
+
+if __name__ == "__main__":
+    main()
