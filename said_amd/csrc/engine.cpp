@@ -99,6 +99,7 @@ struct said_ctx {
     size_t a_tok_elems = 0; int a_chunk = 0;
 
     // ---- per-step graph ----
+    hipStream_t cap_stream = nullptr;  // private stream used only to capture the per-step graph
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     std::vector<long long> gkey;
@@ -520,6 +521,7 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     ctx->maxNp = rup(std::max(1024, max_batch_eff), 32);
     configure_gemm_kernels();
     configure_attn_kernels();
+    if (hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, "hipStreamCreateWithFlags failed"); }
 
     const size_t Be = max_batch_eff, Tp = ctx->maxTp, np = Tp / 32;
     const size_t act = Be * MC * Tp, stt = Be * MC * np * 2;
@@ -554,6 +556,7 @@ int said_destroy(said_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
+    if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     for (void* p : ctx->allocs) (void)hipFree(p);
     delete ctx;
     return 0;
@@ -870,16 +873,19 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
         int gsi, gri, lsi;
         memcpy(&gsi, &gs, 4); memcpy(&gri, &gr, 4); memcpy(&lsi, &ls, 4);
         std::vector<long long> key = {B, T, cfg, gsi, gri, lsi, p->prediction_type, p->use_mask, p->use_step_noise,
-                                      (long long)(uintptr_t)sa.inter, (long long)(uintptr_t)sa.step_noise, (long long)(uintptr_t)s};
+                                      (long long)(uintptr_t)sa.inter, (long long)(uintptr_t)sa.step_noise};
         if (!ctx->gexec || key != ctx->gkey) {
             if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
             if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
-            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            launch_step_advance(ctx->step_dev, s);
-            run_unet(ctx, g, s);
-            if (sa.guidance_rescale > 0.f) launch_rescale_partials(sa, ctx->rescale_part, s);
-            launch_sched_step(sa, s);
-            hipError_t e = hipStreamEndCapture(s, &ctx->graph);
+            // capture on a private stream: the caller's stream may be the legacy default stream,
+            // which cannot be captured; the instantiated graph is then replayed on the caller's stream
+            hipStream_t cs = ctx->cap_stream;
+            HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+            launch_step_advance(ctx->step_dev, cs);
+            run_unet(ctx, g, cs);
+            if (sa.guidance_rescale > 0.f) launch_rescale_partials(sa, ctx->rescale_part, cs);
+            launch_sched_step(sa, cs);
+            hipError_t e = hipStreamEndCapture(cs, &ctx->graph);
             if (e != hipSuccess) return fail(ctx, "hipStreamEndCapture: %s", hipGetErrorString(e));
             HIPCHK(hipGraphInstantiate(&ctx->gexec, ctx->graph, nullptr, nullptr, 0));
             size_t nn = 0;

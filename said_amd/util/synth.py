@@ -176,7 +176,9 @@ def fill_tensor(name: str, shape: Tuple[int, ...], salt: int = 0) -> torch.Tenso
 
 
 def fill_state_dict(shapes: Dict[str, Tuple[int, ...]], prefix: str = "", salt: int = 0) -> Dict[str, torch.Tensor]:
-    return {prefix + k: fill_tensor(prefix + k, shp, salt) for k, shp in shapes.items()}
+    """Values are keyed by the *unprefixed* name, so ``denoiser.model.x`` inside a full SAID
+    state dict equals ``model.x`` of a standalone UNet fill (the golden vectors' weights)."""
+    return {prefix + k: fill_tensor(k, shp, salt) for k, shp in shapes.items()}
 
 
 def said_state_dict(num_w2v_layers: int = W2V_LAYERS, ctx_dim: int = 768, salt: int = 0) -> Dict[str, torch.Tensor]:

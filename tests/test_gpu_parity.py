@@ -1,0 +1,293 @@
+"""Parity tests proper (run on the MI355X with `-m gpu`): the HIP path through the C ABI
+versus the CPU oracle and the committed golden vectors.
+
+Stated tolerances: single UNet evaluation <= 1e-4 of the output range;
+scheduler arithmetic bit-exact given identical eps; end-to-end result <= 1e-3 abs on the
+[0,1]-clamped coefficients (5e-3 after long stochastic chains, stated per test)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline as op
+from oracle import scheduler as osch
+from oracle import unet as ou
+from oracle import wav2vec2 as ow
+from said_amd.util import synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    from said_amd.model.diffusion import SAID_UNet1D
+    m = SAID_UNet1D()
+    m.load_state_dict(synth.said_state_dict(), strict=True)
+    m.to(dev).eval()
+    return m
+
+
+@pytest.fixture(scope="module")
+def sd_full():
+    return synth.said_state_dict()
+
+
+def test_engine_library_is_loaded(model, dev):
+    import ctypes
+    from said_amd import _engine
+    assert isinstance(_engine.load_library(), ctypes.CDLL)
+    model._get_engine(2, 64)
+    assert any("libsaid_hip.so" in ln for ln in open("/proc/self/maps"))
+
+
+def test_cpu_device_is_refused():
+    from said_amd import _engine
+    from said_amd.model.diffusion import SAID_UNet1D
+    m = SAID_UNet1D()
+    with pytest.raises(_engine.EngineError):
+        m.inference(torch.zeros(1, 1600))
+
+
+# ---------------------------------------------------------------- UNet (SAID.forward)
+@pytest.mark.parametrize("B,T,seed", [(1, 48, 21), (2, 48, 22), (1, 600, 23), (2, 600, 24), (2, 37, 25)])
+def test_unet_forward_vs_golden_and_oracle(golden, unet_sd, model, dev, B, T, seed):
+    x = synth.synth_latents(seed, (B, T, 32))
+    c = synth.synth_latents(seed + 100, (B, T, 768))
+    ts = torch.tensor([999, 17][:B])
+    out = model(x.to(dev), ts.to(dev), c.to(dev)).cpu().numpy()
+    ref = golden("g4_unet")[f"out_B{B}_T{T}"]  # captured from the reference's own UNet
+    scale = np.abs(ref).max()
+    assert np.abs(out - ref).max() <= 1e-4 * scale
+    orc = ou.unet1d_forward(unet_sd, x, ts, c).numpy()
+    assert np.abs(out - orc).max() <= 1e-4 * scale
+
+
+def test_unet_forward_context_length_differs(golden, model, dev):
+    x = synth.synth_latents(26, (1, 40, 32))
+    c = synth.synth_latents(126, (1, 25, 768))
+    out = model(x.to(dev), torch.tensor([321]).to(dev), c.to(dev)).cpu().numpy()
+    ref = golden("g4_unet")["out_B1_T40_S25"]
+    assert np.abs(out - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_unet_scalar_and_single_timestep_broadcast(model, unet_sd, dev):
+    x = synth.synth_latents(5, (3, 33, 32))
+    c = synth.synth_latents(6, (3, 33, 768))
+    ref = ou.unet1d_forward(unet_sd, x, torch.tensor([77, 77, 77]), c).numpy()
+    for t in (torch.tensor(77), torch.tensor([77])):
+        out = model(x.to(dev), t.to(dev), c.to(dev)).cpu().numpy()
+        assert np.abs(out - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_unet_large_batch_tiling_path(model, unet_sd, dev):
+    """Be*T large enough to take the NB=6/KS=4 workgroup shape; same numbers expected."""
+    B, T = 24, 352
+    x = synth.synth_latents(41, (B, T, 32))
+    c = synth.synth_latents(42, (B, T, 768))
+    ts = torch.arange(B) * 41 % 1000
+    out = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+    ref = ou.unet1d_forward(unet_sd, x[:3], ts[:3], c[:3])
+    assert float((out[:3] - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    ref_last = ou.unet1d_forward(unet_sd, x[-1:], ts[-1:], c[-1:])
+    assert float((out[-1:] - ref_last).abs().max()) <= 1e-4 * float(ref_last.abs().max())
+
+
+# ---------------------------------------------------------------- scheduler arithmetic
+@pytest.mark.parametrize("pred", ["epsilon", "sample", "v_prediction"])
+@pytest.mark.parametrize("N,eta", [(1000, 0.0), (50, 0.0), (100, 1.0), (7, 0.5)])
+def test_scheduler_step_bit_exact(model, dev, pred, N, eta):
+    from said_amd.scheduler import DDIMScheduler
+    eng = model._get_engine(2, 64)
+    sch = DDIMScheduler(prediction_type=pred)
+    sch._engine = eng
+    sch.set_timesteps(N)
+    o = osch.OracleDDIM(1000, pred)
+    o.set_timesteps(N)
+    assert torch.equal(sch.timesteps, o.timesteps)
+    assert torch.equal(sch.alphas_cumprod, o.alphas_cumprod)
+    g = torch.Generator().manual_seed(N)
+    for t in [int(sch.timesteps[0]), int(sch.timesteps[len(sch.timesteps) // 2]), int(sch.timesteps[-1])]:
+        eps = torch.randn(2, 19, 32, generator=g)
+        x = torch.randn(2, 19, 32, generator=g) * 1.5
+        nz = torch.randn(2, 19, 32, generator=g)
+        ref = o.step(eps, t, x, eta=eta, variance_noise=nz if eta > 0 else None)
+        got = sch.step(eps.to(dev), t, x.to(dev), eta=eta, variance_noise=nz.to(dev) if eta > 0 else None).prev_sample.cpu()
+        assert torch.equal(got, ref), f"t={t}: max diff {(got - ref).abs().max()}"
+
+
+def test_add_noise_velocity_cfg_and_blend_bit_exact(model, dev):
+    eng = model._get_engine(2, 64)
+    sch = model.noise_scheduler
+    sch.set_timesteps(100)
+    o = osch.OracleDDIM(1000, "epsilon")
+    o.set_timesteps(100)
+    g = torch.Generator().manual_seed(3)
+    x, n = torch.randn(3, 11, 32, generator=g), torch.randn(3, 11, 32, generator=g)
+    ts = torch.tensor([990, 500, 0])
+    assert torch.equal(sch.add_noise(x.to(dev), n.to(dev), ts).cpu(), o.add_noise(x, n, ts))
+    assert torch.equal(sch.get_velocity(x.to(dev), n.to(dev), ts).cpu(), o.get_velocity(x, n, ts))
+    # CFG combine + step + mask blend through said_ddim_step
+    e_c, e_u = torch.randn(3, 11, 32, generator=g), torch.randn(3, 11, 32, generator=g)
+    init, mask = torch.rand(3, 11, 32, generator=g), (torch.rand(3, 11, 32, generator=g) > 0.5).float()
+    t, t_next = 500, 490
+    row = sch._coef_row(t, 0.0, t_next)
+    got = eng.ddim_step(e_c.to(dev), x.to(dev), row, "epsilon", eps_uncond=e_u.to(dev), guidance_scale=2.0,
+                        init_latents=init.to(dev), edit_noise=n.to(dev), mask=mask.to(dev)).cpu()
+    eps = e_c + 2.0 * (e_c - e_u)
+    prev = o.step(eps, t, x)
+    ref = o.add_noise(init, n, torch.tensor(t_next)) * mask + prev * (1 - mask)
+    assert torch.equal(got, ref)
+
+
+def test_scheduler_self_consistency():
+    """Unpinned scheduler: properties that must hold for any correct DDIM restatement."""
+    o = osch.OracleDDIM(1000, "epsilon")
+    ac = o.alphas_cumprod
+    assert bool((ac[1:] < ac[:-1]).all()) and 0 < float(ac[-1]) < float(ac[0]) < 1
+    o.set_timesteps(1000)
+    assert o.timesteps.tolist() == list(range(999, -1, -1))
+    o.set_timesteps(50)
+    assert o.timesteps.tolist() == list(range(980, -1, -20))
+    # feeding the true noise returns sqrt(a_prev) x0 + sqrt(1 - a_prev) eps (x0 inside the clip range)
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.rand(2, 5, 32, generator=g) * 1.6 - 0.8
+    eps = torch.randn(2, 5, 32, generator=g)
+    t = 500
+    xt = o.add_noise(x0, eps, torch.tensor([t, t]))
+    prev = o.step(eps, t, xt)
+    want = o.add_noise(x0, eps, torch.tensor([t - 20, t - 20]))
+    assert float((prev - want).abs().max()) < 1e-5
+    # eta = 1, N = 1000: variance equals the DDPM posterior variance
+    o.set_timesteps(1000)
+    v = o._get_variance(500, 499)
+    beta_t = 1 - ac[500] / ac[499]
+    assert abs(float(v) - float((1 - ac[499]) / (1 - ac[500]) * beta_t)) < 1e-7
+
+
+# ---------------------------------------------------------------- audio encoder
+def test_audio_encoder_vs_golden(golden, model, w2v_sd, dev):
+    g = golden("g5_wav2vec2")
+    proc = model.process_audio(synth.synth_waveform(0, 16000))
+    assert torch.equal(proc, op.process_audio(synth.synth_waveform(0, 16000)))
+    lhs = model.get_audio_embedding(proc.to(dev), 60).cpu().numpy()
+    ref = g["last_hidden_state"]  # captured from the reference's ModifiedWav2Vec2Model
+    assert np.abs(lhs - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+    proc2 = model.process_audio([synth.synth_waveform(1, 8000).numpy(), synth.synth_waveform(2, 8000).numpy()])
+    lhs2 = model.get_audio_embedding(proc2.to(dev), 30).cpu().numpy()
+    assert np.abs(lhs2 - g["lhs_b2_f30"]).max() <= 2e-3 * max(1.0, np.abs(g["lhs_b2_f30"]).max())
+    lhs3 = model.audio_encoder(proc2[:1].to(dev), num_frames=None).last_hidden_state.cpu().numpy()
+    assert lhs3.shape == g["lhs_noint"].shape
+    assert np.abs(lhs3 - g["lhs_noint"]).max() <= 2e-3 * max(1.0, np.abs(g["lhs_noint"]).max())
+
+
+def test_audio_encoder_3s_vs_oracle(model, w2v_sd, dev):
+    proc = op.process_audio(synth.synth_waveform(7, 48000))
+    ref = ow.wav2vec2_forward(w2v_sd, proc, 180)[0].numpy()
+    got = model.get_audio_embedding(proc.to(dev), 180).cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+
+
+# ---------------------------------------------------------------- full loop
+def _loop_case(model, sd_full, dev, *, B, Ta, N, gs, eta=0.0, rescale=0.0, pred="epsilon", edit=False, strength=1.0,
+               save_intermediate=False, tol=1e-3):
+    T = int(Ta / 16000 * 60)
+    wav = torch.stack([synth.synth_waveform(10 + i, Ta) for i in range(B)])
+    proc = op.process_audio([w.numpy() for w in wav])
+    init_lat = synth.synth_latents(100, (B, T, 32))
+    kw = {}
+    okw = {}
+    if edit:
+        init_samples = torch.sigmoid(synth.synth_latents(101, (B, T, 32))) * 0.5
+        mask = torch.zeros(B, T, 32)
+        mask[:, : T // 3] = 1.0
+        mask[:, :, :4] = 1.0
+        en = synth.synth_latents(102, (B, T, 32))
+        kw = dict(init_samples=init_samples.to(dev), mask=mask.to(dev), edit_noise=en.to(dev))
+        okw = dict(init_samples=init_samples, mask=mask, edit_noise=en)
+    init_t = min(int(N * strength), N)
+    sn = synth.synth_latents(103, (init_t, B, T, 32)) if eta > 0 else None
+    model.noise_scheduler.config.prediction_type = pred
+    try:
+        out = model.inference(proc.to(dev), num_inference_steps=N, strength=strength, guidance_scale=gs, guidance_rescale=rescale,
+                              eta=eta, init_latents=init_lat.to(dev), step_noise=None if sn is None else sn.to(dev),
+                              save_intermediate=save_intermediate, **kw)
+    finally:
+        model.noise_scheduler.config.prediction_type = "epsilon"
+    ref = op.inference(sd_full, proc, init_latents=init_lat, num_inference_steps=N, strength=strength, guidance_scale=gs,
+                       guidance_rescale=rescale, eta=eta, prediction_type=pred, step_noise=sn, save_intermediate=save_intermediate, **okw)
+    got = out.result.cpu()
+    assert got.shape == (B, T, 32) and float(got.min()) >= 0.0 and float(got.max()) <= 1.0
+    err = float((got - ref.result).abs().max())
+    assert err <= tol, f"end-to-end max abs err {err}"
+    if save_intermediate:
+        assert len(out.intermediates) == len(ref.intermediates) == init_t
+        for a, b in zip(out.intermediates, ref.intermediates):
+            assert float((a.cpu() - b).abs().max()) <= 10 * tol
+    return got, ref.result
+
+
+def test_loop_cfg_1s_50steps(model, sd_full, dev):
+    _loop_case(model, sd_full, dev, B=2, Ta=16000, N=50, gs=2.0)
+
+
+def test_loop_no_guidance_intermediates(model, sd_full, dev):
+    _loop_case(model, sd_full, dev, B=1, Ta=16000, N=20, gs=1.0, save_intermediate=True)
+
+
+def test_loop_eta_and_rescale(model, sd_full, dev):
+    _loop_case(model, sd_full, dev, B=2, Ta=8000, N=25, gs=2.5, eta=1.0, rescale=0.7, tol=2e-3)
+
+
+@pytest.mark.parametrize("pred", ["sample", "v_prediction"])
+def test_loop_prediction_types(model, sd_full, dev, pred):
+    _loop_case(model, sd_full, dev, B=1, Ta=8000, N=10, gs=2.0, pred=pred)
+
+
+def test_loop_editing_mask_strength(model, sd_full, dev):
+    got, ref = _loop_case(model, sd_full, dev, B=2, Ta=16000, N=30, gs=2.0, edit=True, strength=0.6, save_intermediate=True)
+
+
+def test_loop_zero_steps_returns_clamped_start(model, dev):
+    proc = op.process_audio(synth.synth_waveform(0, 8000))
+    lat = synth.synth_latents(1, (1, 30, 32))
+    init = torch.rand(1, 30, 32)
+    out = model.inference(proc.to(dev), init_samples=init.to(dev), num_inference_steps=10, strength=0.0, guidance_scale=2.0,
+                          edit_noise=lat.to(dev))
+    # strength 0 -> init_timestep 0 -> timesteps[-0] is timesteps[0]; no loop steps run (diffusion.py:373-409)
+    sch = osch.OracleDDIM()
+    sch.set_timesteps(10)
+    want = sch.add_noise(init, lat, torch.tensor([int(sch.timesteps[0])])).clamp(0, 1)
+    assert torch.equal(out.result.cpu(), want)
+
+
+def test_loop_is_deterministic_and_graph_replayed(model, dev):
+    proc = op.process_audio(synth.synth_waveform(3, 16000)).to(dev)
+    lat = synth.synth_latents(9, (1, 60, 32)).to(dev)
+    a = model.inference(proc, num_inference_steps=12, guidance_scale=2.0, init_latents=lat).result
+    b = model.inference(proc, num_inference_steps=12, guidance_scale=2.0, init_latents=lat).result
+    assert torch.equal(a, b)
+    assert model._eng.graph_num_nodes() >= 40  # one captured graph covers the whole step
+
+
+def test_idempotent_clamp_and_linearity_properties_full_size(model, dev):
+    """BASELINE cfg2 size (T=600): size-independent properties instead of an oracle run."""
+    T = 600
+    x = synth.synth_latents(51, (1, T, 32)).to(dev)
+    c = synth.synth_latents(52, (1, T, 768)).to(dev)
+    t = torch.tensor([400]).to(dev)
+    e1 = model(x, t, c)
+    e2 = model(x, t, c)
+    assert torch.equal(e1, e2)  # fixed reduction order => bit-reproducible
+    # batch independence: evaluating a sample alone or inside a batch gives the same bits
+    xb = torch.cat([x, x.flip(1)])
+    cb = torch.cat([c, c.flip(1)])
+    eb = model(xb, torch.tensor([400, 400]).to(dev), cb)
+    assert torch.equal(eb[:1], e1)
+    # time-reversal equivariance of the whole network (convs are not symmetric, so only check finiteness + scale)
+    assert torch.isfinite(eb).all() and float(eb.abs().max()) < 1e3
