@@ -158,6 +158,14 @@ int said_graph_num_nodes(const said_ctx* ctx);
 double said_unet_algorithmic_bytes(int batch_eff, int frames, int bytes_per_elem);
 double said_unet_algorithmic_flops(int batch_eff, int frames);
 
+/* Per-launch timing of one UNet evaluation's kernel schedule at (batch_eff, frames): stage k is
+ * replayed `reps` times back to back (one hipGraph) between two HIP events on `stream`.
+ * Outputs per stage: average microseconds, algorithmic bytes (weights + operands + result),
+ * flops, kind (0 = GEMM/conv, 1 = attention), epilogue id, tile shape (NB, KS).
+ * Used by bench.py's roofline block; internal buffers must hold finite data (run a forward first). */
+int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int reps, int max_stages, float* us_out, double* bytes_out,
+                      double* flops_out, int* kind_out, int* epi_out, int* nb_out, int* ks_out, int* n_stages_out, void* stream);
+
 /* ---- debugging aids (used by tests/ only) ---------------------------------- */
 
 /* Stop the UNet schedule after `n_launches` kernel launches (< 0: run everything). */

@@ -51,6 +51,8 @@ EXPORTS = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "said_axpby": (c_int, [c_void_p, POINTER(c_float), c_void_p, POINTER(c_float), c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "said_graph_num_nodes": (c_int, [c_void_p]),
+    "said_profile_unet": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, POINTER(c_int), c_void_p]),
     "said_debug_stop_after": (c_int, [c_void_p, c_int]),
     "said_debug_read": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
     "said_unet_algorithmic_bytes": (c_double, [c_int, c_int, c_int]),
@@ -252,6 +254,20 @@ class Engine:
         with torch.cuda.device(self.index):
             self._chk(self.lib.said_axpby(self.h, av, _ptr(x), cv, _ptr(y), _ptr(out), B, x.numel() // B, _stream()), "said_axpby")
         return out
+
+    def profile_unet(self, batch_eff: int, frames: int, reps: int = 50):
+        """Per-launch (us, bytes, flops, kind, epi, NB, KS) of the UNet kernel schedule, HIP-event timed."""
+        M = 128
+        us = np.zeros(M, np.float32); by = np.zeros(M, np.float64); fl = np.zeros(M, np.float64)
+        kind = np.zeros(M, np.int32); epi = np.zeros(M, np.int32); nb = np.zeros(M, np.int32); ks = np.zeros(M, np.int32)
+        n = c_int(0)
+        vp = lambda a: a.ctypes.data_as(c_void_p)
+        with torch.cuda.device(self.index):
+            self._chk(self.lib.said_profile_unet(self.h, batch_eff, frames, reps, M, vp(us), vp(by), vp(fl), vp(kind), vp(epi), vp(nb),
+                                                 vp(ks), ctypes.byref(n), _stream()), "said_profile_unet")
+        k = n.value
+        return [dict(us=float(us[i]), bytes=float(by[i]), flops=float(fl[i]), kind=int(kind[i]), epi=int(epi[i]), NB=int(nb[i]), KS=int(ks[i]))
+                for i in range(k)]
 
     # ---- debugging aids (tests only) ----
     def debug_stop_after(self, n: int):

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -104,7 +105,10 @@ struct said_ctx {
     hipGraphExec_t gexec = nullptr;
     std::vector<long long> gkey;
     int gnodes = 0;
-    int dbg_stop = -1, dbg_count = 0;
+    int dbg_stop = -1, dbg_count = 0, dbg_only = -1;
+    bool log_on = false;
+    struct StageInfo { int kind, epi, NB, KS; double bytes, flops; };
+    std::vector<StageInfo> stage_log;
 };
 
 namespace {
@@ -118,6 +122,9 @@ int fail(said_ctx* c, const char* fmt, ...) {
     if (c) c->err = buf; else g_create_err = buf;
     return -1;
 }
+
+static bool trace_on() { static int v = -1; if (v < 0) v = getenv("SAID_TRACE") ? 1 : 0; return v == 1; }
+#define TRACE(msg) do { if (trace_on()) { fprintf(stderr, "[said] %s:%d %s\n", __FILE__, __LINE__, msg); fflush(stderr); } } while (0)
 
 #define HIPCHK(expr)                                                                                  \
     do {                                                                                              \
@@ -239,7 +246,45 @@ struct UGeo {
     int emb_b_stride;
 };
 
-inline bool dbg_go(said_ctx* c) { return c->dbg_stop < 0 || c->dbg_count++ < c->dbg_stop; }
+inline bool dbg_go(said_ctx* c) {
+    const int k = c->dbg_count++;
+    if (c->dbg_only >= 0) return k == c->dbg_only;
+    return c->dbg_stop < 0 || k < c->dbg_stop;
+}
+
+// algorithmic HBM bytes / flops of one launch: weights + operands in + residual + result out
+void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s) {
+    if (c->log_on) {
+        double w = 0, in = 0, fl = 0;
+        const double nout = (double)a.groups * a.N * (epi == EPI_GEGLU ? 2 : 1);
+        for (int i = 0; i < a.nseg; ++i) {
+            const Seg& sg = a.seg[i];
+            w += nout * sg.C * sg.taps * 4.0;
+            in += (double)batch * a.groups * sg.C * sg.Tin * 4.0;
+            fl += 2.0 * batch * nout * sg.C * sg.taps * a.T;
+        }
+        double out = (double)batch * a.groups * a.N * a.T * 4.0;
+        if (a.res_kind != RES_NONE) in += out;
+        if (epi == EPI_BAND) in += 2.0 * batch * a.N * a.T * 4.0;  // this block's K and V rows
+        c->stage_log.push_back({0, epi, NB, KS, w + in + out, fl});
+    }
+    if (dbg_go(c)) {
+        if (trace_on()) { fprintf(stderr, "[said] gemm #%d epi=%d NB=%d KS=%d T=%d N=%d batch=%d\n", c->dbg_count - 1, epi, NB, KS, a.T, a.N, batch); fflush(stderr); }
+        launch_gemm(a, epi, batch, NB, KS, s);
+        if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
+    }
+}
+void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s) {
+    if (c->log_on) {
+        const double e = (double)batch * a.heads * head_dim * a.T;
+        c->stage_log.push_back({1, -1, head_dim / 32, KS, 4.0 * e * 4.0, 4.0 * e * a.T});
+    }
+    if (dbg_go(c)) {
+        if (trace_on()) { fprintf(stderr, "[said] attn #%d D=%d KS=%d T=%d batch=%d\n", c->dbg_count - 1, head_dim, KS, a.T, batch); fflush(stderr); }
+        launch_attn(a, batch, head_dim, KS, s);
+        if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
+    }
+}
 
 void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, const ActBuf& in0, const ActBuf* in1, const ActBuf& out, hipStream_t s) {
     const int cpg = rw.cin / 32;
@@ -258,7 +303,7 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
         a.y = c->M.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         a.stats_out = c->M.st; a.stats_bstride = g.sts;
         const LaunchCfg lc = pick_cfg(tt, 6);
-        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+        do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     {   // out_layers: GN -> SiLU -> conv3 ; + skip(x)   (openaimodel.py:226-227)
         GemmArgs a = mkargs(g.T, MC);
@@ -277,7 +322,7 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
         a.y = out.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         a.stats_out = out.st; a.stats_bstride = g.sts;
         const LaunchCfg lc = pick_cfg(tt, 6);
-        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+        do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
 }
 
@@ -294,7 +339,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.y = c->QK; a.y_bstride = 2LL * MC * g.Tp; a.y_pitch = g.Tp;
         a.vt = c->VT; a.vt_first_tile = 12; a.vt_heads = HEADS; a.vt_dim = HD; a.vt_rows = vt_rows;
         const LaunchCfg lc = big ? LaunchCfg{6, 4} : LaunchCfg{1, 8};
-        if (dbg_go(c)) launch_gemm(a, EPI_QKV, g.Be, lc.NB, lc.KS, s);
+        do_gemm(c, a, EPI_QKV, g.Be, lc.NB, lc.KS, s);
     }
     {   // softmax(q k^T * scale) v   (attention.py:99-126)
         AttnArgs a;
@@ -304,7 +349,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         // q/k/o share a batch stride only if O is laid out like QK; O has its own stride -> separate launch arg
         AttnArgs b = a;
         (void)b;
-        if (dbg_go(c)) launch_attn(a, g.Be, HD, tt * HEADS <= 2048 ? 8 : (tt * HEADS <= 8192 ? 4 : 1), s);
+        do_attn(c, a, g.Be, HD, tt * HEADS <= 2048 ? 8 : (tt * HEADS <= 8192 ? 4 : 1), s);
     }
     {   // x1 = to_out(attn) + x, with x = GroupNorm(in) recomputed on the fly   (attention.py:127, 168)
         GemmArgs a = mkargs(g.T, MC);
@@ -316,7 +361,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.res_gn_gamma = sw.gn_g; a.res_gn_beta = sw.gn_b;
         a.y = c->X1; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         const LaunchCfg lc = pick_cfg(tt, 6);
-        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+        do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     {   // attn2: q = to_q(norm2(x1)); banded softmax over the precomputed audio K/V   (attention.py:170-191)
         GemmArgs a = mkargs(g.T, MC);
@@ -328,7 +373,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.band.v = c->KV + (long long)(blk * 2 * MC + MC) * g.Sp;
         a.band.kv_bstride = (long long)NST * 2 * MC * g.Sp; a.band.kv_pitch = g.Sp;
         a.band.lo = c->band_lo; a.band.hi = c->band_hi; a.band.wmax = c->band_wmax; a.band.scale = 0.17677669529663687f;
-        if (dbg_go(c)) launch_gemm(a, EPI_BAND, g.Be, 1, big ? 4 : 8, s);
+        do_gemm(c, a, EPI_BAND, g.Be, 1, big ? 4 : 8, s);
     }
     {   // x2 = to_out(attn2) + x1
         GemmArgs a = mkargs(g.T, MC);
@@ -338,7 +383,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.res_kind = RES_PLAIN; a.res = c->X1; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = c->X2; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         const LaunchCfg lc = pick_cfg(tt, 6);
-        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+        do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     {   // GEGLU: proj(norm3(x2)) -> a * gelu(gate)   (attention.py:25-32)
         GemmArgs a = mkargs(g.T, FFI);
@@ -347,7 +392,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.seg[0].ln_gamma = sw.l3g; a.seg[0].ln_beta = sw.l3b; a.seg[0].ln_eps = 1e-5f;
         a.bias = sw.ff1.bias; a.geglu_gate_tiles = FFI / 32;
         a.y = c->F; a.y_bstride = (long long)FFI * g.Tp; a.y_pitch = g.Tp;
-        if (dbg_go(c)) launch_gemm(a, EPI_GEGLU, g.Be, big ? 3 : 1, big ? 4 : 8, s);
+        do_gemm(c, a, EPI_GEGLU, g.Be, big ? 3 : 1, big ? 4 : 8, s);
     }
     {   // x3 = net.2(h) + x2
         GemmArgs a = mkargs(g.T, MC);
@@ -357,7 +402,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.res_kind = RES_PLAIN; a.res = c->X2; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = c->X3; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         const LaunchCfg lc = pick_cfg(tt, 6);
-        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+        do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     {   // proj_out (1x1 conv) + x_in   (attention.py:232-234)
         GemmArgs a = mkargs(g.T, MC);
@@ -368,7 +413,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.y = out.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         a.stats_out = out.st; a.stats_bstride = g.sts;
         const LaunchCfg lc = pick_cfg(tt, 6);
-        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+        do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
 }
 
@@ -383,7 +428,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
         a.bias = c->conv_in.bias;
         a.y = c->H0.p; a.y_bstride = g.hs; a.y_pitch = g.Tp; a.stats_out = c->H0.st; a.stats_bstride = g.sts;
         const LaunchCfg lc = pick_cfg(tt, 6);
-        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+        do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     run_resblock(c, g, c->res[0], 0, c->H0, nullptr, c->P, s);       // input_blocks.1.0
     run_transformer(c, g, c->st[0], 0, c->P, c->H1, s);              // input_blocks.1.1   (hs: H0, H1)
@@ -401,7 +446,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
         seg_gn(a.seg[0], c->P.st, g.sts, 6, g.np, 1e-5f, c->out_g, c->out_b);
         a.bias = c->conv_out.bias;
         a.y = c->eps_cm; a.y_bstride = (long long)c->cin * g.Tp; a.y_pitch = g.Tp;
-        if (dbg_go(c)) launch_gemm(a, EPI_STORE, g.Be, 1, 8, s);
+        do_gemm(c, a, EPI_STORE, g.Be, 1, 8, s);
     }
 }
 
@@ -825,6 +870,7 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     g.step_ptr = ctx->step_dev;
     const long long xs = (long long)C * g.Tp;
 
+    TRACE("loop: begin");
     // per-clip, step-invariant work
     if (N > 0) {
         HIPCHK(hipMemcpyAsync(ctx->ts_dev, p->timesteps_host, N * sizeof(long long), hipMemcpyHostToDevice, s));
@@ -838,7 +884,9 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     } else {
         launch_tm_to_cm(p->context_dev, ctx->CTX, B, T, ctx->ctx_dim, g.Sp, cs, s);
     }
+    TRACE("loop: ctx done");
     run_kv(ctx, Be, T, g.Sp, s);
+    TRACE("loop: kv launched");
     launch_tm_to_cm(p->latents_dev, ctx->x_cm, B, T, C, g.Tp, xs, s);
     if (p->use_mask) {
         launch_tm_to_cm(p->init_latents_dev, ctx->init_cm, B, T, C, g.Tp, xs, s);
@@ -877,6 +925,20 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
         if (!ctx->gexec || key != ctx->gkey) {
             if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
             if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+            // Eager warm-up of the exact step sequence first: the first launch of a kernel inside a
+            // stream capture hangs on ROCm 7.2 (lazy per-kernel initialisation is not capturable).
+            // The step is run on step index 0 and its effect on the latents is undone afterwards.
+            TRACE("loop: warmup begin");
+            launch_step_advance(ctx->step_dev, s);
+            if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said] step_advance -> %s\n", hipGetErrorString(e)); fflush(stderr); }
+            run_unet(ctx, g, s);
+            TRACE("loop: warmup unet launched");
+            if (sa.guidance_rescale > 0.f) launch_rescale_partials(sa, ctx->rescale_part, s);
+            launch_sched_step(sa, s);
+            launch_tm_to_cm(p->latents_dev, ctx->x_cm, B, T, C, g.Tp, xs, s);
+            HIPCHK(hipMemsetAsync(ctx->step_dev, 0xFF, sizeof(int), s));
+            HIPCHK(hipStreamSynchronize(s));
+            TRACE("loop: warmup synced");
             // capture on a private stream: the caller's stream may be the legacy default stream,
             // which cannot be captured; the instantiated graph is then replayed on the caller's stream
             hipStream_t cs = ctx->cap_stream;
@@ -885,6 +947,7 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
             run_unet(ctx, g, cs);
             if (sa.guidance_rescale > 0.f) launch_rescale_partials(sa, ctx->rescale_part, cs);
             launch_sched_step(sa, cs);
+            TRACE("loop: capture recorded");
             hipError_t e = hipStreamEndCapture(cs, &ctx->graph);
             if (e != hipSuccess) return fail(ctx, "hipStreamEndCapture: %s", hipGetErrorString(e));
             HIPCHK(hipGraphInstantiate(&ctx->gexec, ctx->graph, nullptr, nullptr, 0));
@@ -892,9 +955,11 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
             (void)hipGraphGetNodes(ctx->graph, nullptr, &nn);
             ctx->gnodes = (int)nn;
             ctx->gkey = key;
+            TRACE("loop: graph instantiated");
         }
         for (int k = 0; k < N; ++k) HIPCHK(hipGraphLaunch(ctx->gexec, s));
     }
+    TRACE("loop: graphs launched");
     launch_finish(ctx->x_cm, xs, g.Tp, B, T, C, p->latent_scale, p->latents_dev, p->result_dev, s);
     HIPCHK(hipGetLastError());
     return 0;
@@ -953,6 +1018,57 @@ int said_debug_read(said_ctx* ctx, const char* name, float* out_host, int64_t n)
     if (it == m.end() || !it->second) return fail(ctx, "said_debug_read: unknown or unallocated buffer %s", name);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out_host, it->second, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int said_profile_unet(said_ctx* ctx, int Be, int T, int reps, int max_stages, float* us_out, double* bytes_out, double* flops_out,
+                      int* kind_out, int* epi_out, int* nb_out, int* ks_out, int* n_stages_out, void* stream) {
+    if (check_ready(ctx)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (Be < 1 || Be > ctx->maxBe || T < 1 || T > ctx->maxT) return fail(ctx, "said_profile_unet: shape out of range");
+    if (set_band(ctx, T, T)) return -1;
+    UGeo g = make_geo(ctx, Be, 0, T, T);
+    g.emb_b_stride = 0;
+    run_unet(ctx, g, s);  // eager warm-up: kernels must not see their first launch inside a capture
+    HIPCHK(hipStreamSynchronize(s));
+    // pass 0: log the schedule without launching anything
+    ctx->stage_log.clear();
+    ctx->log_on = true; ctx->dbg_only = -1; ctx->dbg_stop = 0; ctx->dbg_count = 0;
+    run_unet(ctx, g, ctx->cap_stream);
+    ctx->log_on = false; ctx->dbg_stop = -1;
+    const int n = (int)ctx->stage_log.size();
+    if (n_stages_out) *n_stages_out = n;
+    if (n > max_stages) return fail(ctx, "said_profile_unet: %d stages > max_stages %d", n, max_stages);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int k = 0; k < n; ++k) {
+        // `reps` back-to-back launches of stage k captured in one graph, timed with HIP events on `s`
+        hipGraph_t gr = nullptr;
+        hipGraphExec_t ge = nullptr;
+        ctx->dbg_only = k;
+        HIPCHK(hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal));
+        for (int r = 0; r < reps; ++r) { ctx->dbg_count = 0; run_unet(ctx, g, ctx->cap_stream); }
+        hipError_t e = hipStreamEndCapture(ctx->cap_stream, &gr);
+        ctx->dbg_only = -1;
+        if (e != hipSuccess) return fail(ctx, "profile capture: %s", hipGetErrorString(e));
+        HIPCHK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        HIPCHK(hipGraphLaunch(ge, s));  // warm-up
+        HIPCHK(hipEventRecord(e0, s));
+        HIPCHK(hipGraphLaunch(ge, s));
+        HIPCHK(hipEventRecord(e1, s));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        const auto& si = ctx->stage_log[k];
+        us_out[k] = ms * 1000.f / reps;
+        bytes_out[k] = si.bytes; flops_out[k] = si.flops; kind_out[k] = si.kind; epi_out[k] = si.epi; nb_out[k] = si.NB; ks_out[k] = si.KS;
+        (void)hipGraphExecDestroy(ge);
+        (void)hipGraphDestroy(gr);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return 0;
 }
 
