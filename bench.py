@@ -56,7 +56,7 @@ def cpu_baseline(args, T, Ta):
     from oracle import unet as ou
     from said_amd.util import synth
     torch.set_grad_enabled(False)
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     sd = synth.said_state_dict()
     sd_a, sd_u, null = op.split_state_dict(sd)
@@ -72,13 +72,18 @@ def cpu_baseline(args, T, Ta):
     n = max(2, args.cpu_steps)
     ou.unet1d_forward(sd_u, torch.cat([lat] * 2) if do_cfg else lat, sch.timesteps[:1].repeat(2 if do_cfg else 1), ctx)  # warm
     t0 = time.perf_counter()
+    done = 0
     for t in sch.timesteps[:n]:
+        if done >= 3 and time.perf_counter() - t0 > 20.0:  # bounded sample: ~20 s of CPU work
+            break
+        done += 1
         x = torch.cat([lat] * 2) if do_cfg else lat
         pred = ou.unet1d_forward(sd_u, x, t.repeat(x.shape[0]), ctx)
         if do_cfg:
             e_u, e_c = pred.chunk(2)
             pred = e_c + args.guidance_scale * (e_c - e_u)
         lat = sch.step(pred, int(t), lat)
+    n = done
     t_step = (time.perf_counter() - t0) / n
     total = t_audio + args.num_steps * t_step
     return {"value": round(T / total, 3), "unit": "frames/s", "cores": cores, "kind": "port",
@@ -92,7 +97,8 @@ def roofline(model, Be, T, step_ms):
     stages = eng.profile_unet(Be, T, reps=40)
     agg = {}
     for st in stages:
-        name = f"attn<D{32 * st['NB']},KS{st['KS']}>" if st["kind"] == 1 else f"cgemm<NB{st['NB']},KS{st['KS']},{EPI_NAMES[st['epi']]}>"
+        name = (f"attn_kernel<D{32 * st['NB']},KS{st['KS']}>" if st["kind"] == 1 else
+                f"{'ugemm' if st['kind'] == 2 else 'cgemm'}_kernel<NB{st['NB']},KS{st['KS']},{EPI_NAMES[st['epi']]}>")
         a = agg.setdefault(name, dict(us=0.0, bytes=0.0, flops=0.0, launches=0))
         a["us"] += st["us"]; a["bytes"] += st["bytes"]; a["flops"] += st["flops"]; a["launches"] += 1
     dom = max(agg, key=lambda k: agg[k]["us"])

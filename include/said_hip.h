@@ -161,7 +161,7 @@ double said_unet_algorithmic_flops(int batch_eff, int frames);
 /* Per-launch timing of one UNet evaluation's kernel schedule at (batch_eff, frames): stage k is
  * replayed `reps` times back to back (one hipGraph) between two HIP events on `stream`.
  * Outputs per stage: average microseconds, algorithmic bytes (weights + operands + result),
- * flops, kind (0 = GEMM/conv, 1 = attention), epilogue id, tile shape (NB, KS).
+ * flops, kind (0 = generic GEMM/conv kernel, 1 = attention, 2 = LDS-staged UNet GEMM), epilogue id, tile shape (NB, KS).
  * Used by bench.py's roofline block; internal buffers must hold finite data (run a forward first). */
 int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int reps, int max_stages, float* us_out, double* bytes_out,
                       double* flops_out, int* kind_out, int* epi_out, int* nb_out, int* ks_out, int* n_stages_out, void* stream);
@@ -170,6 +170,9 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int reps, int ma
 
 /* Stop the UNet schedule after `n_launches` kernel launches (< 0: run everything). */
 int said_debug_stop_after(said_ctx* ctx, int n_launches);
+/* Enable/disable per-phase shader-clock stamps in the GEMM kernels of the next UNet evaluations and
+ * (if out_host != NULL) read back the [64 launches][8 waves][8 slots] stamp table. */
+int said_debug_clocks(said_ctx* ctx, int enable, long long* out_host);
 /* Synchronously copy `n` floats from the start of the named internal buffer
  * ("H0","H1","P","Q","M","X1","X2","X3","O","QK","VT","F","KV","CTX","EO","E0","E1","E2",
  *  "x","eps","stH0","stP","stM", ...) to host memory. */

@@ -54,6 +54,7 @@ EXPORTS = {
     "said_profile_unet": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, POINTER(c_int), c_void_p]),
     "said_debug_stop_after": (c_int, [c_void_p, c_int]),
+    "said_debug_clocks": (c_int, [c_void_p, c_int, c_void_p]),
     "said_debug_read": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
     "said_unet_algorithmic_bytes": (c_double, [c_int, c_int, c_int]),
     "said_unet_algorithmic_flops": (c_double, [c_int, c_int]),
@@ -272,6 +273,11 @@ class Engine:
     # ---- debugging aids (tests only) ----
     def debug_stop_after(self, n: int):
         self._chk(self.lib.said_debug_stop_after(self.h, int(n)), "said_debug_stop_after")
+
+    def debug_clocks(self, enable: bool, read: bool = False):
+        out = np.zeros((64, 8, 16), dtype=np.int64) if read else None
+        self._chk(self.lib.said_debug_clocks(self.h, int(enable), out.ctypes.data_as(c_void_p) if read else None), "said_debug_clocks")
+        return out
 
     def debug_read(self, name: str, shape) -> np.ndarray:
         out = np.empty(shape, dtype=np.float32)

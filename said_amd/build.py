@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsaid_hip.so")
-SOURCES = ["gemm.hip", "attn.hip", "misc.hip", "engine.cpp"]
+SOURCES = ["gemm.hip", "gemm_lds.hip", "attn.hip", "misc.hip", "engine.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
 
@@ -37,7 +37,7 @@ def _stale(target: str, deps) -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "kernels.h"), os.path.join(os.path.dirname(HERE), "include", "said_hip.h")]
+    headers = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(os.path.dirname(HERE), "include", "said_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)

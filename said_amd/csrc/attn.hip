@@ -44,16 +44,26 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const AttnArgs a) {
         for (int r = 0; r < 16; ++r) o[nd][r] = 0.f;
 
     const int nkt = (T + 31) >> 5;
-    for (int kt = w; kt < nkt; kt += KS) {
+    // K and V fragments of a key tile are fetched together and one tile ahead of the MFMAs that use
+    // them (register double buffer): with <= 3 tiles per wave the loop is pure memory latency otherwise.
+    auto load_kv = [&](int kt, float (&kf)[ND * 16], float (&vf)[ND][16]) {
+        const int j0 = min(kt, nkt - 1) * 32;
+#pragma unroll
+        for (int dp = 0; dp < ND * 16; ++dp) kf[dp] = kb[(long long)(2 * dp + lh) * pitch + j0 + lt];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) vf[nd][r] = vb[(long long)j * D + nd * 32 + lt];
+        }
+    };
+    auto compute = [&](int kt, const float (&kf)[ND * 16], const float (&vf)[ND][16]) {
         const int j0 = kt * 32;
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int dp = 0; dp < ND * 16; ++dp) {
-            const float kf = kb[(long long)(2 * dp + lh) * pitch + j0 + lt];
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf, qf[dp], s, 0, 0, 0);
-        }
+        for (int dp = 0; dp < ND * 16; ++dp) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[dp], qf[dp], s, 0, 0, 0);
         float mx = -1.0e30f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -77,13 +87,27 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[nd][r] *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) {
-                const float vf = vb[(long long)j * D + nd * 32 + lt];
-                o[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], o[nd], 0, 0, 0);
+            for (int nd = 0; nd < ND; ++nd) o[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[nd][r], s[r], o[nd], 0, 0, 0);
+    };
+    if constexpr (ND == 1) {
+        float kA[ND * 16], vA[ND][16], kB[ND * 16], vB[ND][16];
+        if (w < nkt) load_kv(w, kA, vA);
+        for (int kt = w; kt < nkt; kt += 2 * KS) {
+            const bool more = kt + KS < nkt;
+            if (more) load_kv(kt + KS, kB, vB);
+            compute(kt, kA, vA);
+            if (more) {
+                if (kt + 2 * KS < nkt) load_kv(kt + 2 * KS, kA, vA);
+                compute(kt + KS, kB, vB);
             }
+        }
+    } else {  // head_dim 64: one register buffer (a second one would spill); loads of a tile still go out together
+        float kA[ND * 16], vA[ND][16];
+        for (int kt = w; kt < nkt; kt += KS) {
+            load_kv(kt, kA, vA);
+            compute(kt, kA, vA);
         }
     }
     lsum += __shfl_xor(lsum, 32);

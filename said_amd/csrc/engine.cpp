@@ -38,6 +38,7 @@ struct HostTensor {
 
 struct PW {  // packed GEMM weight (up to 2 K-segments) + bias
     float* w[2] = {nullptr, nullptr};
+    float* w4[2] = {nullptr, nullptr};   // dwordx4 packing for the LDS-staged kernel
     float* bias = nullptr;
     int N = 0, C[2] = {0, 0}, taps = 1, nseg = 1;
 };
@@ -93,6 +94,9 @@ struct said_ctx {
     float* noise_cm = nullptr; size_t noise_cm_elems = 0;
     float* coef1_dev = nullptr;  // one row for said_ddim_step
     float* axpby_coef = nullptr;
+    long long* clk_dev = nullptr;  // [64 launches][8 waves][8 slots]
+    bool clk_on = false;
+    bool use_ugemm = true;   // SAID_NO_UGEMM=1 forces the generic kernel everywhere (A/B testing)
 
     // ---- audio workspace (lazily sized) ----
     float *abufA = nullptr, *abufB = nullptr; size_t abuf_elems[2] = {0, 0};
@@ -182,6 +186,21 @@ std::vector<float> pack_rows(const float* W, int Ctot, int taps, const std::vect
                 }
     return out;
 }
+// dwordx4 packing: Wq[tile][tap][c/8][lane][4]; value j of lane l = W[tile*32 + (l & 31)][c_begin + 8*cq + 2*j + (l >> 5)][tap]
+std::vector<float> pack_rows4(const float* W, int Ctot, int taps, const std::vector<int>& row_of, int ntiles_total, int c_begin, int C) {
+    std::vector<float> out((size_t)ntiles_total * taps * (C / 8) * 256);
+    size_t o = 0;
+    for (int tile = 0; tile < ntiles_total; ++tile)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int cq = 0; cq < C / 8; ++cq)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = row_of[tile * 32 + (l & 31)];
+                        const int c = c_begin + 8 * cq + 2 * j + (l >> 5);
+                        out[o++] = row < 0 ? 0.f : W[((size_t)row * Ctot + c) * taps + tap];
+                    }
+    return out;
+}
 std::vector<int> rows_dense(int N, int row0 = 0) {
     const int nt = (N + 31) / 32;
     std::vector<int> r(nt * 32, -1);
@@ -203,6 +222,10 @@ int make_pw(said_ctx* ctx, PW* pw, const std::string& wname, const std::string& 
         pw->C[s] = C;
         auto packed = pack_rows(t->data.data(), Ctot, tp, rows, (N + 31) / 32, s * C, C);
         if (upload(ctx, &pw->w[s], packed.data(), packed.size())) return -1;
+        if (C % 8 == 0 && (tp == 1 || tp == 3)) {
+            auto p4 = pack_rows4(t->data.data(), Ctot, tp, rows, (N + 31) / 32, s * C, C);
+            if (upload(ctx, &pw->w4[s], p4.data(), p4.size())) return -1;
+        }
     }
     if (!bname.empty()) { if (upvec(ctx, &pw->bias, bname, N)) return -1; }
     return 0;
@@ -227,6 +250,7 @@ Seg mkseg(const float* x, long long bstride, int pitch, int C, int taps, int pad
     s.Tin = Tin; s.xform = xform; s.gn_cpg = 1; s.gn_nparts = 1;
     return s;
 }
+inline Seg with_w4(Seg s, const float* w4) { s.w4 = w4; return s; }
 void seg_gn(Seg& s, const float* part, long long part_bstride, int cpg, int nparts, float eps, const float* g, const float* b) {
     s.gn_part = part; s.gn_part_bstride = part_bstride; s.gn_cpg = cpg; s.gn_nparts = nparts; s.gn_eps = eps; s.gn_gamma = g; s.gn_beta = b;
 }
@@ -266,11 +290,14 @@ void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS,
         double out = (double)batch * a.groups * a.N * a.T * 4.0;
         if (a.res_kind != RES_NONE) in += out;
         if (epi == EPI_BAND) in += 2.0 * batch * a.N * a.T * 4.0;  // this block's K and V rows
-        c->stage_log.push_back({0, epi, NB, KS, w + in + out, fl});
+        c->stage_log.push_back({(c->use_ugemm && ugemm_supports(a, epi, NB, KS)) ? 2 : 0, epi, NB, KS, w + in + out, fl});
     }
+    GemmArgs a2 = a;
+    if (c->clk_on && c->dbg_count < 64) a2.clk = c->clk_dev + (long long)c->dbg_count * 128;
     if (dbg_go(c)) {
         if (trace_on()) { fprintf(stderr, "[said] gemm #%d epi=%d NB=%d KS=%d T=%d N=%d batch=%d\n", c->dbg_count - 1, epi, NB, KS, a.T, a.N, batch); fflush(stderr); }
-        launch_gemm(a, epi, batch, NB, KS, s);
+        if (c->use_ugemm && ugemm_supports(a2, epi, NB, KS)) launch_ugemm(a2, epi, batch, NB, KS, s);
+        else launch_gemm(a2, epi, batch, NB, KS, s);
         if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
     }
 }
@@ -292,10 +319,10 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
     {   // in_layers: GN -> SiLU -> conv3 ; + emb_layers(emb)   (openaimodel.py:205-225)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = in1 ? 2 : 1;
-        a.seg[0] = mkseg(in0.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[0]);
+        a.seg[0] = with_w4(mkseg(in0.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[0]), rw.conv1.w4[0]);
         seg_gn(a.seg[0], in0.st, g.sts, cpg, g.np, 1e-5f, rw.g1, rw.b1);
         if (in1) {
-            a.seg[1] = mkseg(in1->p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[1]);
+            a.seg[1] = with_w4(mkseg(in1->p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[1]), rw.conv1.w4[1]);
             seg_gn(a.seg[1], in1->st, g.sts, cpg, g.np, 1e-5f, rw.g1 + MC, rw.b1 + MC);
         }
         a.bias = rw.conv1.bias;
@@ -308,11 +335,11 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
     {   // out_layers: GN -> SiLU -> conv3 ; + skip(x)   (openaimodel.py:226-227)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = mkseg(c->M.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv2.w[0]);
+        a.seg[0] = with_w4(mkseg(c->M.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv2.w[0]), rw.conv2.w4[0]);
         seg_gn(a.seg[0], c->M.st, g.sts, 6, g.np, 1e-5f, rw.g2, rw.b2);
         if (rw.has_skip) {  // 1x1 conv over the concatenated input folded in as two extra K segments
-            a.seg[1] = mkseg(in0.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, rw.skip.w[0]);
-            a.seg[2] = mkseg(in1->p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, rw.skip.w[1]);
+            a.seg[1] = with_w4(mkseg(in0.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, rw.skip.w[0]), rw.skip.w4[0]);
+            a.seg[2] = with_w4(mkseg(in1->p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, rw.skip.w[1]), rw.skip.w4[1]);
             a.nseg = 3;
             a.bias = rw.bias2;
         } else {
@@ -333,7 +360,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // x = norm(x) (GroupNorm eps 1e-6); q,k,v = to_{q,k,v}(norm1(x))   (attention.py:227, 168, 93-97)
         GemmArgs a = mkargs(g.T, 3 * MC);
         a.nseg = 1;
-        a.seg[0] = mkseg(in.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_GN_LN, sw.qkv.w[0]);
+        a.seg[0] = with_w4(mkseg(in.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_GN_LN, sw.qkv.w[0]), sw.qkv.w4[0]);
         seg_gn(a.seg[0], in.st, g.sts, 6, g.np, 1e-6f, sw.gn_g, sw.gn_b);
         a.seg[0].ln_gamma = sw.l1g; a.seg[0].ln_beta = sw.l1b; a.seg[0].ln_eps = 1e-5f;
         a.y = c->QK; a.y_bstride = 2LL * MC * g.Tp; a.y_pitch = g.Tp;
@@ -354,7 +381,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // x1 = to_out(attn) + x, with x = GroupNorm(in) recomputed on the fly   (attention.py:127, 168)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = mkseg(c->O, 2LL * MC * g.Tp, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out1.w[0]);
+        a.seg[0] = with_w4(mkseg(c->O, 2LL * MC * g.Tp, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out1.w[0]), sw.out1.w4[0]);
         a.bias = sw.out1.bias;
         a.res_kind = RES_GN; a.res = in.p; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.res_gn_part = in.st; a.res_gn_part_bstride = g.sts; a.res_gn_cpg = 6; a.res_gn_nparts = g.np; a.res_gn_eps = 1e-6f;
@@ -366,7 +393,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // attn2: q = to_q(norm2(x1)); banded softmax over the precomputed audio K/V   (attention.py:170-191)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = mkseg(c->X1, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.q2.w[0]);
+        a.seg[0] = with_w4(mkseg(c->X1, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.q2.w[0]), sw.q2.w4[0]);
         a.seg[0].ln_gamma = sw.l2g; a.seg[0].ln_beta = sw.l2b; a.seg[0].ln_eps = 1e-5f;
         a.y = c->O; a.y_bstride = 2LL * MC * g.Tp; a.y_pitch = g.Tp;
         a.band.k = c->KV + (long long)(blk * 2 * MC) * g.Sp;
@@ -378,7 +405,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // x2 = to_out(attn2) + x1
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = mkseg(c->O, 2LL * MC * g.Tp, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out2.w[0]);
+        a.seg[0] = with_w4(mkseg(c->O, 2LL * MC * g.Tp, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out2.w[0]), sw.out2.w4[0]);
         a.bias = sw.out2.bias;
         a.res_kind = RES_PLAIN; a.res = c->X1; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = c->X2; a.y_bstride = g.hs; a.y_pitch = g.Tp;
@@ -388,7 +415,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // GEGLU: proj(norm3(x2)) -> a * gelu(gate)   (attention.py:25-32)
         GemmArgs a = mkargs(g.T, FFI);
         a.nseg = 1;
-        a.seg[0] = mkseg(c->X2, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.ff1.w[0]);
+        a.seg[0] = with_w4(mkseg(c->X2, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.ff1.w[0]), sw.ff1.w4[0]);
         a.seg[0].ln_gamma = sw.l3g; a.seg[0].ln_beta = sw.l3b; a.seg[0].ln_eps = 1e-5f;
         a.bias = sw.ff1.bias; a.geglu_gate_tiles = FFI / 32;
         a.y = c->F; a.y_bstride = (long long)FFI * g.Tp; a.y_pitch = g.Tp;
@@ -397,7 +424,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // x3 = net.2(h) + x2
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = mkseg(c->F, (long long)FFI * g.Tp, g.Tp, FFI, 1, 0, 1, g.T, XF_NONE, sw.ff2.w[0]);
+        a.seg[0] = with_w4(mkseg(c->F, (long long)FFI * g.Tp, g.Tp, FFI, 1, 0, 1, g.T, XF_NONE, sw.ff2.w[0]), sw.ff2.w4[0]);
         a.bias = sw.ff2.bias;
         a.res_kind = RES_PLAIN; a.res = c->X2; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = c->X3; a.y_bstride = g.hs; a.y_pitch = g.Tp;
@@ -407,7 +434,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // proj_out (1x1 conv) + x_in   (attention.py:232-234)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = mkseg(c->X3, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.proj.w[0]);
+        a.seg[0] = with_w4(mkseg(c->X3, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.proj.w[0]), sw.proj.w4[0]);
         a.bias = sw.proj.bias;
         a.res_kind = RES_PLAIN; a.res = in.p; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = out.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
@@ -423,7 +450,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
     {   // input_blocks.0: Conv1d(32 -> 192, k3)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = mkseg(c->x_cm, (long long)c->cin * g.Tp, g.Tp, c->cin, 3, 1, 1, g.T, XF_NONE, c->conv_in.w[0]);
+        a.seg[0] = with_w4(mkseg(c->x_cm, (long long)c->cin * g.Tp, g.Tp, c->cin, 3, 1, 1, g.T, XF_NONE, c->conv_in.w[0]), c->conv_in.w4[0]);
         a.seg[0].b_mod = g.B_lat;
         a.bias = c->conv_in.bias;
         a.y = c->H0.p; a.y_bstride = g.hs; a.y_pitch = g.Tp; a.stats_out = c->H0.st; a.stats_bstride = g.sts;
@@ -442,7 +469,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
     {   // out: GN -> SiLU -> Conv1d(192 -> 32, k3)
         GemmArgs a = mkargs(g.T, c->cin);
         a.nseg = 1;
-        a.seg[0] = mkseg(c->P.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, c->conv_out.w[0]);
+        a.seg[0] = with_w4(mkseg(c->P.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, c->conv_out.w[0]), c->conv_out.w4[0]);
         seg_gn(a.seg[0], c->P.st, g.sts, 6, g.np, 1e-5f, c->out_g, c->out_b);
         a.bias = c->conv_out.bias;
         a.y = c->eps_cm; a.y_bstride = (long long)c->cin * g.Tp; a.y_pitch = g.Tp;
@@ -458,7 +485,7 @@ void run_time_embed(said_ctx* c, int n, hipStream_t s) {
     {
         GemmArgs a = mkargs(n, TE);
         a.nseg = 1;
-        a.seg[0] = mkseg(c->E0, 0, Np, MC, 1, 0, 1, n, XF_NONE, c->te1.w[0]);
+        a.seg[0] = with_w4(mkseg(c->E0, 0, Np, MC, 1, 0, 1, n, XF_NONE, c->te1.w[0]), c->te1.w4[0]);
         a.bias = c->te1.bias; a.act = ACT_SILU;
         a.y = c->E1; a.y_pitch = Np;
         const LaunchCfg lc = pick_cfg(tt, TE / 32);
@@ -467,7 +494,7 @@ void run_time_embed(said_ctx* c, int n, hipStream_t s) {
     {
         GemmArgs a = mkargs(n, TE);
         a.nseg = 1;
-        a.seg[0] = mkseg(c->E1, 0, Np, TE, 1, 0, 1, n, XF_NONE, c->te2.w[0]);
+        a.seg[0] = with_w4(mkseg(c->E1, 0, Np, TE, 1, 0, 1, n, XF_NONE, c->te2.w[0]), c->te2.w4[0]);
         a.bias = c->te2.bias;
         a.y = c->E2; a.y_pitch = Np;
         const LaunchCfg lc = pick_cfg(tt, TE / 32);
@@ -476,7 +503,7 @@ void run_time_embed(said_ctx* c, int n, hipStream_t s) {
     {
         GemmArgs a = mkargs(n, NRES * MC);
         a.nseg = 1;
-        a.seg[0] = mkseg(c->E2, 0, Np, TE, 1, 0, 1, n, XF_SILU, c->emb_all.w[0]);
+        a.seg[0] = with_w4(mkseg(c->E2, 0, Np, TE, 1, 0, 1, n, XF_SILU, c->emb_all.w[0]), c->emb_all.w4[0]);
         a.bias = c->emb_all.bias;
         a.y = c->EO; a.y_pitch = Np;
         const LaunchCfg lc = pick_cfg(tt, NRES * MC / 32);
@@ -488,7 +515,7 @@ void run_time_embed(said_ctx* c, int n, hipStream_t s) {
 void run_kv(said_ctx* c, int Be, int S, int Sp, hipStream_t s) {
     GemmArgs a = mkargs(S, NST * 2 * MC);
     a.nseg = 1;
-    a.seg[0] = mkseg(c->CTX, (long long)c->ctx_dim * Sp, Sp, c->ctx_dim, 1, 0, 1, S, XF_NONE, c->kv_all.w[0]);
+    a.seg[0] = with_w4(mkseg(c->CTX, (long long)c->ctx_dim * Sp, Sp, c->ctx_dim, 1, 0, 1, S, XF_NONE, c->kv_all.w[0]), c->kv_all.w4[0]);
     a.y = c->KV; a.y_bstride = (long long)NST * 2 * MC * Sp; a.y_pitch = Sp;
     const LaunchCfg lc = pick_cfg((long long)Be * ((S + 31) / 32), NST * 2 * MC / 32);
     launch_gemm(a, EPI_STORE, Be, lc.NB, lc.KS, s);
@@ -565,7 +592,9 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     ctx->maxTp = rup(max_frames, 32);
     ctx->maxNp = rup(std::max(1024, max_batch_eff), 32);
     configure_gemm_kernels();
+    configure_ugemm_kernels();
     configure_attn_kernels();
+    ctx->use_ugemm = getenv("SAID_NO_UGEMM") == nullptr;
     if (hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, "hipStreamCreateWithFlags failed"); }
 
     const size_t Be = max_batch_eff, Tp = ctx->maxTp, np = Tp / 32;
@@ -587,6 +616,7 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     rc |= dalloc(ctx, &ctx->ts_dev, Np); rc |= dalloc(ctx, &ctx->coef_dev, Np * 8); rc |= dalloc(ctx, &ctx->coef1_dev, 8);
     rc |= dalloc(ctx, &ctx->step_dev, 4);
     rc |= dalloc(ctx, &ctx->axpby_coef, 2 * Np);
+    rc |= dalloc(ctx, &ctx->clk_dev, 64 * 128);
     rc |= dalloc(ctx, &ctx->band_lo, Tp); rc |= dalloc(ctx, &ctx->band_hi, Tp);
     rc |= dalloc(ctx, &ctx->init_cm, Be * 32 * Tp); rc |= dalloc(ctx, &ctx->enoise_cm, Be * 32 * Tp); rc |= dalloc(ctx, &ctx->mask_cm, Be * 32 * Tp);
     rc |= dalloc(ctx, &ctx->rescale_part, Be * 2 * 64 * 3);
@@ -995,6 +1025,17 @@ int said_axpby(said_ctx* ctx, const float* a_host, const float* x_dev, const flo
     HIPCHK(hipStreamSynchronize(s));
     if (n_per_batch > 0) launch_axpby(ctx->axpby_coef, x_dev, ctx->axpby_coef + batch, y_dev, out_dev, batch, n_per_batch, s);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int said_debug_clocks(said_ctx* ctx, int enable, long long* out_host /* [64][8][8] or null */) {
+    if (!ctx) return -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->clk_on = enable != 0;
+    if (out_host) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(out_host, ctx->clk_dev, 64 * 128 * sizeof(long long), hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 

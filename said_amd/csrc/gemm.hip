@@ -21,112 +21,169 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "kernels.h"
+#include "gemm_common.h"
 
 namespace said {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+// ------------------------------------------------------------------------------------------------
+// K loop.  A wave owns channels [c_lo, c_lo + 2*npairs) of a segment; its work is taps * npairs
+// (tap, channel-pair) elements, one MFMA per element and output tile.  Elements move in sub-chunks of
+// SUB = 4 through a ring of DMAX register buffers; a buffer is refilled right after it is consumed, so
+// DMAX-1 sub-chunks of loads are always in flight.  For the small-batch tile shape (one output tile per
+// workgroup) DMAX covers a whole 3-tap 192-channel convolution slice: every operand of the wave is
+// requested at kernel entry — together with the statistics partials and the epilogue operands — and the
+// kernel pays ONE memory round trip (about 2.5k clocks on this part) instead of one per stage.
+// Per element the instruction stream is one buffer_load for X, one per tile for W (immediate offsets),
+// one ds_read_b64 for norm coefficients, the transform, and the MFMAs.
+// Fast path: npairs % SUB == 0.  Other shapes (C = 32, 48) take a cursor-based path.
+// ------------------------------------------------------------------------------------------------
+constexpr int SUB = 4;
+template <int NACC> struct RingCfg { static constexpr int DMAX = (NACC == 1) ? 9 : (NACC == 2 ? 6 : (NACC <= 4 ? 3 : 2)); };
 
-__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+struct SegCtx {
+    rsrc_t rx, rw;
+    int vx;        // per-lane byte offset into X: (lh * pitch + (t0+lt)*stride - pad) * 4
+    int vw;        // per-lane byte offset into W: lane * 4
+    int tq;        // (t0 + lt) * stride - pad
+    int taps, Tin, pitch4 /* pitch * 4 */, halfC, c_lo, npairs, lh;
+    int wtile_bytes;  // bytes between consecutive output tiles in W
+};
 
-__device__ __forceinline__ float wave_sum(float v) {
+template <int NACC>
+__device__ __forceinline__ void sub_load(const SegCtx& k, const int (&tile_wo)[NACC], int tap, int cp0, float (&xr)[SUB],
+                                         float (&wr)[NACC][SUB]) {
+    // The hardware range check covers voffset + immediate only (the SGPR offset is added to the base
+    // unchecked), so everything lane- or tap-dependent lives in voffset and halo lanes get an
+    // out-of-range voffset, which reads as 0.
+    const int tin = k.tq + tap;
+    const int vx = ((unsigned)tin < (unsigned)k.Tin) ? (k.vx + tap * 4) : (int)0x80000000;
+    const int sx = (k.c_lo + 2 * cp0) * k.pitch4;
+    const int sw = (tap * k.halfC + (k.c_lo >> 1) + cp0) * 256;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float half_sum(float v) {  // within each 32-lane half
+    for (int j = 0; j < SUB; ++j) {
+        xr[j] = bload(k.rx, vx, sx + j * 2 * k.pitch4);
 #pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+        for (int i = 0; i < NACC; ++i) wr[i][j] = bload(k.rw, k.vw + j * 256, sw + tile_wo[i]);
+    }
 }
 
-// Combine the Welford partials of one GroupNorm group and emit per-channel affine
-// coefficients a_c = rstd*gamma_c, b_c = beta_c - mean*a_c for channels [c_begin, c_end).
-// part: [C][nparts][2] for this batch; executed by one whole wave.
-__device__ __forceinline__ void gn_group_coefs(const float* part, int nparts, int Tin, int cpg, int grp, float eps,
-                                               const float* gamma, const float* beta, int c_begin, int c_end,
-                                               float* outA, float* outB, int out_base, int lane) {
-    const int entries = cpg * nparts;
-    const float* p = part + (long long)grp * cpg * nparts * 2;
-    float s = 0.f;
-    for (int e = lane; e < entries; e += 64) {
-        const int pi = e % nparts;
-        const float cnt = (float)min(32, Tin - pi * 32);
-        s += cnt * p[2 * e];
-    }
-    const float total = (float)cpg * (float)Tin;
-    const float mean = wave_sum(s) / total;
-    float q = 0.f;
-    for (int e = lane; e < entries; e += 64) {
-        const int pi = e % nparts;
-        const float cnt = (float)min(32, Tin - pi * 32);
-        const float d = p[2 * e] - mean;
-        q += p[2 * e + 1] + cnt * d * d;
-    }
-    const float var = wave_sum(q) / total;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    if (lane < cpg) {
-        const int c = grp * cpg + lane;
-        if (c >= c_begin && c < c_end) {
-            const float av = rstd * gamma[c];
-            outA[c - out_base] = av;
-            outB[c - out_base] = beta[c] - mean * av;
+template <int XF, int NACC, bool TRANS>
+__device__ __forceinline__ void sub_compute(const SegCtx& k, int tap, int cp0, const float (&xr)[SUB], const float (&wr)[NACC][SUB],
+                                            const float2* coefGN, const float2* coefLN, float mu, float rs, f32x16 (&acc)[NACC]) {
+    const int tin = k.tq + tap;
+    const bool valid = (unsigned)tin < (unsigned)k.Tin;
+    const int c0 = k.c_lo + 2 * cp0 + k.lh;
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) {
+        float2 gn = make_float2(1.f, 0.f), ln = make_float2(1.f, 0.f);
+        if (XF == XF_GN_SILU || XF == XF_GN_LN) gn = coefGN[c0 + 2 * j];
+        if (XF == XF_LN || XF == XF_GN_LN) ln = coefLN[c0 + 2 * j];
+        float xv = xform_apply<XF>(xr[j], gn, mu, rs, ln);
+        xv = valid ? xv : 0.f;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+            if (TRANS)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, wr[i][j], acc[i], 0, 0, 0);
+            else
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i][j], xv, acc[i], 0, 0, 0);
         }
     }
 }
 
-template <int XF>
-__device__ __forceinline__ float xform_apply(float v, float2 gn, float mu, float rs, float2 ln) {
-    if (XF == XF_NONE) return v;
-    if (XF == XF_SILU) return silu_f(v);
-    if (XF == XF_GN_SILU) return silu_f(fmaf(v, gn.x, gn.y));
-    if (XF == XF_LN) return fmaf((v - mu) * rs, ln.x, ln.y);
-    if (XF == XF_GN_LN) return fmaf((fmaf(v, gn.x, gn.y) - mu) * rs, ln.x, ln.y);
-    return v;
+struct Ring {  // cursor over sub-chunks: (tap, cp0)
+    int tap, cp0;
+    __device__ __forceinline__ void next(int npairs) {
+        cp0 += SUB;
+        if (cp0 >= npairs) { cp0 = 0; ++tap; }
+    }
+};
+
+// issue the first min(Nq, DMAX) sub-chunks of a segment
+template <int NACC, int DMAX>
+__device__ __forceinline__ void ring_preload(const SegCtx& k, const int (&tile_wo)[NACC], float (&xr)[DMAX][SUB],
+                                             float (&wr)[DMAX][NACC][SUB]) {
+    const int Nq = k.taps * (k.npairs / SUB);
+    Ring ld = {0, 0};
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+        if (d < Nq) sub_load<NACC>(k, tile_wo, ld.tap, ld.cp0, xr[d], wr[d]);
+        ld.next(k.npairs);
+    }
 }
 
-// LDS carve (floats).  Must match gemm_smem_floats() on the host side below.
-__host__ __device__ inline int seg_coef_floats(const Seg& s) {
-    int f = 0;
-    if (s.xform == XF_GN_SILU || s.xform == XF_GN_LN) f += 2 * s.C;
-    if (s.xform == XF_LN || s.xform == XF_GN_LN) f += 2 * s.C;
-    return f;
-}
-template <int NACC>
-__host__ __device__ inline int epi_scratch_floats(int epi, int KS) {
-    if (epi == EPI_BAND) return 32 * 32 + (KS * 2) * 8 * 32;  // q tile + score partials [groups][wmax<=8][32]
-    return 2 * 32 * NACC;                                      // residual GN coefficients
+template <int XF, int NACC, bool TRANS, int DMAX>
+__device__ __forceinline__ void seg_run_fast(const SegCtx& k, const int (&tile_wo)[NACC], const float2* coefGN, const float2* coefLN,
+                                             float mu, float rs, f32x16 (&acc)[NACC], float (&xr)[DMAX][SUB],
+                                             float (&wr)[DMAX][NACC][SUB]) {
+    const int nsub = k.npairs / SUB;
+    const int Nq = k.taps * nsub;
+    Ring cm = {0, 0};
+    Ring ld = {DMAX / nsub, (DMAX % nsub) * SUB};  // sub-chunk DMAX
+    for (int q0 = 0; q0 < Nq; q0 += DMAX) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+            if (q0 + d < Nq) {
+                sub_compute<XF, NACC, TRANS>(k, cm.tap, cm.cp0, xr[d], wr[d], coefGN, coefLN, mu, rs, acc);
+                if (q0 + d + DMAX < Nq) sub_load<NACC>(k, tile_wo, ld.tap, ld.cp0, xr[d], wr[d]);
+            }
+            cm.next(k.npairs);
+            ld.next(k.npairs);
+        }
+    }
 }
 
+// Generic path (npairs not a multiple of SUB): element cursor with clamped loads, two buffers.
 template <int XF, int NACC, bool TRANS>
-__device__ __forceinline__ void seg_accumulate(const Seg& sg, const float* __restrict__ xb, const float* __restrict__ wb,
-                                               const long long tile_wstride, const int* tile_off, int t0, int lt, int lh,
-                                               int l, int c_lo, int cw, const float2* coefGN, const float2* coefLN,
-                                               float mu, float rs, f32x16 (&acc)[NACC]) {
-    const int taps = sg.taps, pitch = sg.x_pitch, halfC = sg.C >> 1;
-    for (int tap = 0; tap < taps; ++tap) {
-        const int tin = (t0 + lt) * sg.stride + tap - sg.pad;
-        const bool valid = (tin >= 0) && (tin < sg.Tin);
-        const float* xp = xb + (long long)(c_lo + lh) * pitch + (valid ? tin : 0);
-        const float* wp = wb + ((long long)tap * halfC + (c_lo >> 1)) * 64 + l;
-#pragma unroll 4
-        for (int cp = 0; cp < (cw >> 1); ++cp) {
-            float xv = xp[(long long)(2 * cp) * pitch];
-            const int c = c_lo + 2 * cp + lh;
+__device__ __forceinline__ void seg_run_generic(const SegCtx& k, const int (&tile_wo)[NACC], const float2* coefGN,
+                                                const float2* coefLN, float mu, float rs, f32x16 (&acc)[NACC]) {
+    const int E = k.taps * k.npairs;
+    int lt_ = 0, lc_ = 0, ct_ = 0, cc_ = 0;
+    float xa[SUB], wa[NACC][SUB], xb[SUB], wb[NACC][SUB];
+    auto load = [&](float (&xr)[SUB], float (&wr)[NACC][SUB]) {
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+            const bool live = lt_ < k.taps;
+            const int tp = live ? lt_ : 0, cq = live ? lc_ : 0;
+            const int tin = k.tq + tp;
+            const int vx = ((unsigned)tin < (unsigned)k.Tin) ? (k.vx + tp * 4) : (int)0x80000000;
+            xr[j] = bload(k.rx, vx, (k.c_lo + 2 * cq) * k.pitch4);
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) wr[i][j] = bload(k.rw, k.vw, (tp * k.halfC + (k.c_lo >> 1) + cq) * 256 + tile_wo[i]);
+            if (++lc_ == k.npairs) { lc_ = 0; ++lt_; }
+        }
+    };
+    auto compute = [&](const float (&xr)[SUB], const float (&wr)[NACC][SUB]) {
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+            const bool live = ct_ < k.taps;
+            const int tin = k.tq + ct_;
+            const bool valid = live && ((unsigned)tin < (unsigned)k.Tin);
+            const int c = k.c_lo + 2 * (live ? cc_ : 0) + k.lh;
             float2 gn = make_float2(1.f, 0.f), ln = make_float2(1.f, 0.f);
             if (XF == XF_GN_SILU || XF == XF_GN_LN) gn = coefGN[c];
             if (XF == XF_LN || XF == XF_GN_LN) ln = coefLN[c];
-            xv = xform_apply<XF>(xv, gn, mu, rs, ln);
+            float xv = xform_apply<XF>(xr[j], gn, mu, rs, ln);
             xv = valid ? xv : 0.f;
+            if (live) {
 #pragma unroll
-            for (int i = 0; i < NACC; ++i) {
-                const float wv = wp[(long long)tile_off[i] * tile_wstride + (long long)cp * 64];
-                if (TRANS)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, wv, acc[i], 0, 0, 0);
-                else
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, xv, acc[i], 0, 0, 0);
+                for (int i = 0; i < NACC; ++i) {
+                    if (TRANS)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, wr[i][j], acc[i], 0, 0, 0);
+                    else
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i][j], xv, acc[i], 0, 0, 0);
+                }
             }
+            if (++cc_ == k.npairs) { cc_ = 0; ++ct_; }
+        }
+    };
+    load(xa, wa);
+    for (int e0 = 0; e0 < E; e0 += 2 * SUB) {
+        const bool more = e0 + SUB < E;
+        if (more) load(xb, wb);
+        compute(xa, wa);
+        if (more) {
+            if (e0 + 2 * SUB < E) load(xa, wa);
+            compute(xb, wb);
         }
     }
 }
@@ -134,6 +191,11 @@ __device__ __forceinline__ void seg_accumulate(const Seg& sg, const float* __res
 template <int NB, int KS, int EPI, bool TRANS>
 __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
     constexpr int NACC = (EPI == EPI_GEGLU) ? 2 * NB : NB;
+    constexpr int DMAX = RingCfg<NACC>::DMAX;
+    constexpr int NV = NB * 16;  // value vectors (one per (tile, acc register))
+    static_assert(NV % KS == 0, "NB*16 must be divisible by KS");
+    constexpr int VPW = NV / KS;
+    constexpr bool EPRE = (VPW <= 4) && (EPI == EPI_STORE || EPI == EPI_QKV) && !TRANS;  // prefetch epilogue operands
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t0 = blockIdx.x * 32;
@@ -142,17 +204,46 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
     const int g = blockIdx.y / tb_per_group;
     const int tile0 = (blockIdx.y % tb_per_group) * NB;
     const int w_tiles_pg = (EPI == EPI_GEGLU) ? a.ntiles_per_group + a.geglu_gate_tiles : a.ntiles_per_group;
-    (void)w_tiles_pg;
-
-    int tile_off[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) tile_off[i] = (i < NB) ? (tile0 + i) : (tile0 + (i - NB) + a.geglu_gate_tiles);
 
     const int epi_sz = epi_scratch_floats<NACC>(EPI, KS);
     float* epiS = smem;
-    float* mainS = smem + epi_sz;
+    float* gnS = smem + epi_sz + w * GN_SCRATCH;   // per-wave GroupNorm scratch
+    float* mainS = smem + epi_sz + KS * GN_SCRATCH;
+    clk_stamp(a, w, l, 0);
 
-    // ---- prologue A: GroupNorm coefficients (main-loop segments and residual) ----
+    auto make_seg = [&](int s, int (&tile_wo)[NACC]) {
+        const Seg& sg = a.seg[s];
+        SegCtx k;
+        const int cw = sg.C / KS;
+        const int sb = sg.b_mod > 0 ? b % sg.b_mod : b;
+        const float* xbase = sg.x + (long long)sb * sg.x_bstride + (long long)g * sg.c_group_stride * sg.x_pitch;
+        k.rx = make_rsrc(xbase, (unsigned)sg.C * (unsigned)sg.x_pitch * 4u);
+        k.wtile_bytes = sg.taps * (sg.C >> 1) * 256;
+        const float* wbase = sg.w + (long long)g * w_tiles_pg * (k.wtile_bytes >> 2);
+        k.rw = make_rsrc(wbase, (unsigned)w_tiles_pg * (unsigned)k.wtile_bytes);
+        k.tq = (t0 + lt) * sg.stride - sg.pad;
+        k.vx = (lh * sg.x_pitch + k.tq) * 4;
+        k.vw = l * 4;
+        k.taps = sg.taps; k.Tin = sg.Tin; k.pitch4 = sg.x_pitch * 4; k.halfC = sg.C >> 1;
+        k.c_lo = w * cw; k.npairs = cw >> 1; k.lh = lh;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+            tile_wo[i] = ((i < NB) ? (tile0 + i) : (tile0 + (i - NB) + a.geglu_gate_tiles)) * k.wtile_bytes;
+        return k;
+    };
+
+    // ================= phase 0: put every load this wave will need in flight =================
+    float xr[DMAX][SUB], wr[DMAX][NACC][SUB];
+    int tile_wo0[NACC];
+    const SegCtx k0 = make_seg(0, tile_wo0);
+    const bool fast0 = (k0.npairs % SUB) == 0;
+    const int Nq0 = k0.taps * (k0.npairs / SUB);
+    if (fast0) ring_preload<NACC, DMAX>(k0, tile_wo0, xr, wr);
+    clk_stamp(a, w, l, 1);
+
+    // GroupNorm partials of the wave's own channel slice (up to two normalised segments: concat input)
+    GnLoads gl[2];
+    rsrc_t grp_rsrc[2];
     int coef_off[3];
     {
         int off = 0;
@@ -161,138 +252,221 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
             off += seg_coef_floats(a.seg[s]);
         }
     }
-    for (int s = 0; s < a.nseg; ++s) {
-        const Seg& sg = a.seg[s];
-        if (sg.xform == XF_GN_SILU || sg.xform == XF_GN_LN) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (s < a.nseg && (a.seg[s].xform == XF_GN_SILU || a.seg[s].xform == XF_GN_LN)) {
+            const Seg& sg = a.seg[s];
             const int sb = sg.b_mod > 0 ? b % sg.b_mod : b;
-            const float* part = sg.gn_part + (long long)sb * sg.gn_part_bstride;
-            float* cA = mainS + coef_off[s];  // interleaved (a, b) pairs
-            const int G = sg.C / sg.gn_cpg;
-            for (int grp = w; grp < G; grp += KS) {
-                // write interleaved: use stride-2 views
-                const int entries = sg.gn_cpg * sg.gn_nparts;
-                const float* p = part + (long long)grp * entries * 2;
-                float sacc = 0.f;
-                for (int e = l; e < entries; e += 64) {
-                    const int pi = e % sg.gn_nparts;
-                    sacc += (float)min(32, sg.Tin - pi * 32) * p[2 * e];
-                }
-                const float total = (float)sg.gn_cpg * (float)sg.Tin;
-                const float mean = wave_sum(sacc) / total;
-                float q = 0.f;
-                for (int e = l; e < entries; e += 64) {
-                    const int pi = e % sg.gn_nparts;
-                    const float d = p[2 * e] - mean;
-                    q += p[2 * e + 1] + (float)min(32, sg.Tin - pi * 32) * d * d;
-                }
-                const float var = wave_sum(q) / total;
-                const float rstd = 1.0f / sqrtf(var + sg.gn_eps);
-                if (l < sg.gn_cpg) {
-                    const int c = grp * sg.gn_cpg + l;
-                    const float av = rstd * sg.gn_gamma[c];
-                    cA[2 * c] = av;
-                    cA[2 * c + 1] = sg.gn_beta[c] - mean * av;
-                }
-            }
+            grp_rsrc[s] = make_rsrc(sg.gn_part + (long long)sb * sg.gn_part_bstride, (unsigned)sg.C * (unsigned)sg.gn_nparts * 8u);
+            gn_issue(gnp_of(sg), grp_rsrc[s], w * (sg.C / KS), sg.C / KS, l, gl[s]);
         }
-        if (sg.xform == XF_LN || sg.xform == XF_GN_LN) {
-            float* cL = mainS + coef_off[s] + ((sg.xform == XF_GN_LN) ? 2 * sg.C : 0);
-            for (int c = tid; c < sg.C; c += 64 * KS) {
-                cL[2 * c] = sg.ln_gamma[c];
-                cL[2 * c + 1] = sg.ln_beta[c];
+    }
+    // LayerNorm: common shift (raw channel 0 of each token) and the affine of the wave's own channels
+    float ln_ref = 0.f;
+    const bool has_ln = (a.seg[0].xform == XF_LN || a.seg[0].xform == XF_GN_LN);
+    if (has_ln) ln_ref = bload(k0.rx, min(t0 + lt, a.seg[0].Tin - 1) * 4, 0);
+
+    // epilogue operands (bias / timestep-embedding term / residual) of the VPW vectors this thread finalises
+    float e_bias[EPRE ? VPW : 1], e_emb[EPRE ? VPW : 1], e_res[EPRE ? VPW : 1];
+    if (EPRE) {
+#pragma unroll
+        for (int j = 0; j < VPW; ++j) {
+            const int v = w + j * KS;
+            const int i = v >> 4, r = v & 15;
+            const int nl = (tile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int t = t0 + lt;
+            const bool nok = nl < a.N;
+            const int ng = g * a.N + (nok ? nl : 0);
+            e_bias[j] = (a.bias && nok) ? a.bias[ng] : 0.f;
+            e_emb[j] = 0.f;
+            if (a.emb && nok) {
+                const int row = (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride;
+                e_emb[j] = a.emb[(long long)ng * a.emb_pitch + row];
             }
+            e_res[j] = 0.f;
+            if (EPI == EPI_STORE && a.res_kind != RES_NONE && nok && t < a.T)
+                e_res[j] = a.res[(long long)b * a.res_bstride + (long long)ng * a.res_pitch + t];
+        }
+    }
+    // banded cross-attention: window bounds of this thread's query
+    int band_lo = 0, band_hi = 0;
+    if (EPI == EPI_BAND) {
+        const int t = t0 + (tid & 31);
+        if (t < a.T) { band_lo = a.band.lo[t]; band_hi = a.band.hi[t]; }
+    }
+    clk_stamp(a, w, l, 2);
+
+    // ================= phase 1: GroupNorm coefficients (own slice; per-wave LDS only) =================
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (s < a.nseg && (a.seg[s].xform == XF_GN_SILU || a.seg[s].xform == XF_GN_LN)) {
+            const Seg& sg = a.seg[s];
+            gn_finish(gnp_of(sg), grp_rsrc[s], w * (sg.C / KS), sg.C / KS, l, gl[s], gnS, mainS + coef_off[s]);
+        }
+    }
+    if (has_ln) {
+        const Seg& sg = a.seg[0];
+        float* cL = mainS + coef_off[0] + ((sg.xform == XF_GN_LN) ? 2 * sg.C : 0);
+        const int cw = sg.C / KS;
+        for (int c = w * cw + l; c < (w + 1) * cw; c += 64) {
+            cL[2 * c] = sg.ln_gamma[c];
+            cL[2 * c + 1] = sg.ln_beta[c];
         }
     }
     if (EPI == EPI_STORE && a.res_kind == RES_GN) {
+        // GroupNorm of the residual tensor: groups overlapping this workgroup's output channels, one wave each
         const float* part = a.res_gn_part + (long long)b * a.res_gn_part_bstride;
+        const rsrc_t rp = make_rsrc(part, (unsigned)(a.groups * a.N) * (unsigned)a.res_gn_nparts * 8u);
         const int c_begin = tile0 * 32, c_end = min(a.N, (tile0 + NB) * 32);
         const int g_first = c_begin / a.res_gn_cpg, g_last = (c_end - 1) / a.res_gn_cpg;
-        for (int grp = g_first + w; grp <= g_last; grp += KS)
-            gn_group_coefs(part, a.res_gn_nparts, a.T, a.res_gn_cpg, grp, a.res_gn_eps, a.res_gn_gamma, a.res_gn_beta,
-                           c_begin, c_end, epiS, epiS + 32 * NACC, c_begin, l);
-    }
-    __syncthreads();
-
-    // ---- prologue B: LayerNorm statistics of this token tile (segment 0 only) ----
-    float mu = 0.f, rs = 1.f;
-    {
-        const Seg& sg = a.seg[0];
-        if (sg.xform == XF_LN || sg.xform == XF_GN_LN) {
-            const float2* cGN = reinterpret_cast<const float2*>(mainS + coef_off[0]);
-            float* lnred = mainS + coef_off[a.nseg - 1] + seg_coef_floats(a.seg[a.nseg - 1]);
-            const float* xb = sg.x + (long long)(sg.b_mod > 0 ? b % sg.b_mod : b) * sg.x_bstride;
-            const int t = min(t0 + lt, sg.Tin - 1);
-            const int cw = sg.C / KS, c_lo = w * cw;
-            float ref = xb[t];
-            if (sg.xform == XF_GN_LN) ref = fmaf(ref, cGN[0].x, cGN[0].y);
-            float s1 = 0.f, s2 = 0.f;
-            for (int c = c_lo + lh; c < c_lo + cw; c += 2) {
-                float v = xb[(long long)c * sg.x_pitch + t];
-                if (sg.xform == XF_GN_LN) v = fmaf(v, cGN[c].x, cGN[c].y);
-                const float d = v - ref;
-                s1 += d;
-                s2 = fmaf(d, d, s2);
+        const GnP fake = {a.res_gn_cpg, a.res_gn_nparts, a.T, a.res_gn_eps, a.res_gn_gamma, a.res_gn_beta};
+        for (int gb = g_first; gb <= g_last; gb += KS) {
+            const int grp = min(gb + w, g_last);
+            GnLoads L;
+            gn_issue(fake, rp, grp * a.res_gn_cpg, a.res_gn_cpg, l, L);
+            // coefficients land in a per-wave temp (segment-channel indexed), then the in-range ones are copied
+            float* tmp = gnS + 64 * 3 + 32;  // [2 * 12] floats
+            gn_finish(fake, rp, grp * a.res_gn_cpg, a.res_gn_cpg, l, L, gnS, tmp - 2 * grp * a.res_gn_cpg);
+            if (gb + w <= g_last && l < a.res_gn_cpg) {
+                const int c = grp * a.res_gn_cpg + l;
+                if (c >= c_begin && c < c_end) {
+                    epiS[c - c_begin] = tmp[2 * l];
+                    epiS[32 * NACC + c - c_begin] = tmp[2 * l + 1];
+                }
             }
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (lh == 0) {
-                lnred[(w * 32 + lt) * 2] = s1;
-                lnred[(w * 32 + lt) * 2 + 1] = s2;
-            }
-            __syncthreads();
-            float S1 = 0.f, S2 = 0.f;
-#pragma unroll
-            for (int w2 = 0; w2 < KS; ++w2) {
-                S1 += lnred[(w2 * 32 + lt) * 2];
-                S2 += lnred[(w2 * 32 + lt) * 2 + 1];
-            }
-            const float invC = 1.0f / (float)sg.C;
-            const float md = S1 * invC;
-            const float var = fmaxf(S2 * invC - md * md, 0.f);
-            mu = ref + md;
-            rs = 1.0f / sqrtf(var + sg.ln_eps);
         }
     }
+    clk_stamp(a, w, l, 3);
 
-    // ---- main loop ----
+    // ================= phase 2: LayerNorm statistics of this token tile =================
+    float mu = 0.f, rs = 1.f;
+    if (has_ln) {
+        const Seg& sg = a.seg[0];
+        const float2* cGN = reinterpret_cast<const float2*>(mainS + coef_off[0]);
+        float* lnred = mainS + coef_off[a.nseg - 1] + seg_coef_floats(a.seg[a.nseg - 1]);
+        const bool gnx = sg.xform == XF_GN_LN;
+        float s1 = 0.f, s2 = 0.f;
+        if (fast0 && sg.taps == 1 && Nq0 <= DMAX) {
+            // the wave's operand registers ARE its share of the token rows: no extra loads
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                if (d < Nq0) {
+#pragma unroll
+                    for (int j = 0; j < SUB; ++j) {
+                        float vv = xr[d][j];
+                        if (gnx) { const float2 cg = cGN[k0.c_lo + 2 * (d * SUB + j) + lh]; vv = fmaf(vv, cg.x, cg.y); }
+                        const float dd = vv - ln_ref;
+                        s1 += dd;
+                        s2 = fmaf(dd, dd, s2);
+                    }
+                }
+            }
+        } else {
+            const int t = min(t0 + lt, sg.Tin - 1);
+            const int nper = k0.npairs;
+            const int vx = (lh * sg.x_pitch + t) * 4;
+            for (int q0 = 0; q0 < nper; q0 += 12) {
+                float v[12];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) v[j] = bload(k0.rx, vx, (k0.c_lo + 2 * min(q0 + j, nper - 1)) * k0.pitch4);
+#pragma unroll
+                for (int j = 0; j < 12; ++j) {
+                    float vv = v[j];
+                    if (gnx) { const float2 cg = cGN[k0.c_lo + 2 * min(q0 + j, nper - 1) + lh]; vv = fmaf(vv, cg.x, cg.y); }
+                    const float dd = (q0 + j < nper) ? (vv - ln_ref) : 0.f;
+                    s1 += dd;
+                    s2 = fmaf(dd, dd, s2);
+                }
+            }
+        }
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lh == 0) {
+            lnred[(w * 32 + lt) * 2] = s1;
+            lnred[(w * 32 + lt) * 2 + 1] = s2;
+        }
+        __syncthreads();
+        float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < KS; ++w2) {
+            S1 += lnred[(w2 * 32 + lt) * 2];
+            S2 += lnred[(w2 * 32 + lt) * 2 + 1];
+        }
+        const float invC = 1.0f / (float)sg.C;
+        const float md = S1 * invC;
+        const float var = fmaxf(S2 * invC - md * md, 0.f);
+        mu = ln_ref + md;
+        rs = 1.0f / sqrtf(var + sg.ln_eps);
+    }
+    clk_stamp(a, w, l, 4);
+
+    // banded cross-attention: this thread's K and V window values, requested before the main loop
+    constexpr int BNG = KS * 2, BDPG = (32 / BNG) > 0 ? (32 / BNG) : 1;
+    float kq[EPI == EPI_BAND ? BDPG : 1][8], vq[EPI == EPI_BAND ? BDPG : 1][8];
+    if (EPI == EPI_BAND) {
+        const long long kvo = (long long)b * a.band.kv_bstride + (long long)(tile0 * 32) * a.band.kv_pitch;
+        const rsrc_t rk = make_rsrc(a.band.k + kvo, 32u * (unsigned)a.band.kv_pitch * 4u);
+        const rsrc_t rv_ = make_rsrc(a.band.v + kvo, 32u * (unsigned)a.band.kv_pitch * 4u);
+        const int gi = tid >> 5;
+#pragma unroll
+        for (int dd = 0; dd < BDPG; ++dd)
+#pragma unroll
+            for (int wi = 0; wi < 8; ++wi) {
+                const bool vis = (wi < a.band.wmax) && (band_lo + wi < band_hi);
+                const int vo = vis ? ((gi * BDPG + dd) * a.band.kv_pitch + band_lo + wi) * 4 : (int)0x80000000;
+                kq[dd][wi] = bload(rk, vo, 0);
+                vq[dd][wi] = bload(rv_, vo, 0);
+            }
+    }
+
+    // ================= phase 3: MFMA main loop =================
     f32x16 acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    clk_stamp(a, w, l, 5);
 
     for (int s = 0; s < a.nseg; ++s) {
         const Seg& sg = a.seg[s];
-        const int cw = sg.C / KS, c_lo = w * cw;
-        const float* xb = sg.x + (long long)(sg.b_mod > 0 ? b % sg.b_mod : b) * sg.x_bstride +
-                          (long long)g * sg.c_group_stride * sg.x_pitch;
-        const long long tile_wstride = (long long)sg.taps * (sg.C >> 1) * 64;
-        const float* wb = sg.w + (long long)g * w_tiles_pg * tile_wstride;
+        int tile_wo[NACC];
+        const SegCtx k = make_seg(s, tile_wo);
         const float2* cGN = reinterpret_cast<const float2*>(mainS + coef_off[s]);
         const float2* cLN = reinterpret_cast<const float2*>(mainS + coef_off[s] + ((sg.xform == XF_GN_LN) ? 2 * sg.C : 0));
-        switch (sg.xform) {
-            case XF_NONE: seg_accumulate<XF_NONE, NACC, TRANS>(sg, xb, wb, tile_wstride, tile_off, t0, lt, lh, l, c_lo, cw, cGN, cLN, mu, rs, acc); break;
-            case XF_GN_SILU: seg_accumulate<XF_GN_SILU, NACC, TRANS>(sg, xb, wb, tile_wstride, tile_off, t0, lt, lh, l, c_lo, cw, cGN, cLN, mu, rs, acc); break;
-            case XF_LN: seg_accumulate<XF_LN, NACC, TRANS>(sg, xb, wb, tile_wstride, tile_off, t0, lt, lh, l, c_lo, cw, cGN, cLN, mu, rs, acc); break;
-            case XF_GN_LN: seg_accumulate<XF_GN_LN, NACC, TRANS>(sg, xb, wb, tile_wstride, tile_off, t0, lt, lh, l, c_lo, cw, cGN, cLN, mu, rs, acc); break;
-            default: seg_accumulate<XF_SILU, NACC, TRANS>(sg, xb, wb, tile_wstride, tile_off, t0, lt, lh, l, c_lo, cw, cGN, cLN, mu, rs, acc); break;
+        if ((k.npairs % SUB) == 0) {
+            if (s > 0) ring_preload<NACC, DMAX>(k, tile_wo, xr, wr);
+            switch (sg.xform) {
+                case XF_NONE: seg_run_fast<XF_NONE, NACC, TRANS, DMAX>(k, tile_wo, cGN, cLN, mu, rs, acc, xr, wr); break;
+                case XF_GN_SILU: seg_run_fast<XF_GN_SILU, NACC, TRANS, DMAX>(k, tile_wo, cGN, cLN, mu, rs, acc, xr, wr); break;
+                case XF_LN: seg_run_fast<XF_LN, NACC, TRANS, DMAX>(k, tile_wo, cGN, cLN, mu, rs, acc, xr, wr); break;
+                case XF_GN_LN: seg_run_fast<XF_GN_LN, NACC, TRANS, DMAX>(k, tile_wo, cGN, cLN, mu, rs, acc, xr, wr); break;
+                default: seg_run_fast<XF_SILU, NACC, TRANS, DMAX>(k, tile_wo, cGN, cLN, mu, rs, acc, xr, wr); break;
+            }
+        } else {
+            switch (sg.xform) {
+                case XF_NONE: seg_run_generic<XF_NONE, NACC, TRANS>(k, tile_wo, cGN, cLN, mu, rs, acc); break;
+                case XF_GN_SILU: seg_run_generic<XF_GN_SILU, NACC, TRANS>(k, tile_wo, cGN, cLN, mu, rs, acc); break;
+                case XF_LN: seg_run_generic<XF_LN, NACC, TRANS>(k, tile_wo, cGN, cLN, mu, rs, acc); break;
+                case XF_GN_LN: seg_run_generic<XF_GN_LN, NACC, TRANS>(k, tile_wo, cGN, cLN, mu, rs, acc); break;
+                default: seg_run_generic<XF_SILU, NACC, TRANS>(k, tile_wo, cGN, cLN, mu, rs, acc); break;
+            }
         }
     }
+    clk_stamp(a, w, l, 6);
 
-    // ---- split-K reduction through LDS (fixed order => deterministic) ----
+    // ================= phase 4: split-K reduction through LDS (fixed order => deterministic) =================
     __syncthreads();
+    clk_stamp(a, w, l, 7);
     float* red = mainS;
 #pragma unroll
     for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[((w * NACC + i) * 16 + r) * 64 + l] = acc[i][r];
     __syncthreads();
+    clk_stamp(a, w, l, 8);
 
-    constexpr int NV = NB * 16;  // value vectors (one per (tile, acc register))
-    static_assert(NV % KS == 0, "NB*16 must be divisible by KS");
-    constexpr int VPW = NV / KS;
+    // ================= phase 5: epilogue =================
     const int nparts_out = (a.T + 31) >> 5;
-
 #pragma unroll
     for (int j = 0; j < VPW; ++j) {
         const int v = w + j * KS;
@@ -338,18 +512,28 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
         }
 
         // EPI_STORE / EPI_QKV (normal orientation)
-        if (nl < a.N) {
-            if (a.bias) val += a.bias[ng];
+        float rv = 0.f;
+        if (EPRE) {
+            val += e_bias[j];
             if (a.act == ACT_SILU) val = silu_f(val);
             else if (a.act == ACT_GELU) val = gelu_f(val);
-            if (a.emb) {
-                const int row = (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride;
-                val += a.emb[(long long)ng * a.emb_pitch + row];
+            val += e_emb[j];
+            rv = e_res[j];
+        } else {
+            if (nl < a.N) {
+                if (a.bias) val += a.bias[ng];
+                if (a.act == ACT_SILU) val = silu_f(val);
+                else if (a.act == ACT_GELU) val = gelu_f(val);
+                if (a.emb) {
+                    const int row = (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride;
+                    val += a.emb[(long long)ng * a.emb_pitch + row];
+                }
             }
+            if (EPI == EPI_STORE && ok && a.res_kind != RES_NONE)
+                rv = a.res[(long long)b * a.res_bstride + (long long)ng * a.res_pitch + t];
         }
         if (EPI == EPI_STORE) {
             if (ok && a.res_kind != RES_NONE) {
-                float rv = a.res[(long long)b * a.res_bstride + (long long)ng * a.res_pitch + t];
                 if (a.res_kind == RES_GN) rv = fmaf(rv, epiS[nl - tile0 * 32], epiS[32 * NACC + nl - tile0 * 32]);
                 val += rv;
             }
@@ -358,9 +542,9 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
         if (EPI == EPI_STORE && a.stats_out) {
             const float cnt = (float)min(32, a.T - t0);
             const float vv = (t < a.T) ? val : 0.f;
-            const float mean = half_sum(vv) / cnt;
+            const float mean = half32_sum(vv) / cnt;
             const float d = (t < a.T) ? (val - mean) : 0.f;
-            const float m2 = half_sum(d * d);
+            const float m2 = half32_sum(d * d);
             if (lt == 0 && nl < a.N) {
                 float* so = a.stats_out + (long long)b * a.stats_bstride + ((long long)ng * nparts_out + blockIdx.x) * 2;
                 so[0] = mean;
@@ -369,10 +553,10 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
         }
     }
 
+    clk_stamp(a, w, l, 9);
     if (EPI == EPI_BAND) {
         // banded cross-attention on the finished q tile (one head x 32 queries)
         static_assert(EPI != EPI_BAND || NB == 1, "EPI_BAND needs NB == 1");
-        __syncthreads();
         constexpr int NG = KS * 2;        // 32-thread groups
         constexpr int DPG = 32 / NG;      // head-dim rows per group
         const float* qt = epiS;
@@ -380,22 +564,18 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
         const int gi = tid >> 5, tt = tid & 31;
         const int t = t0 + tt;
         const bool tv = t < a.T;
-        const int lo = tv ? a.band.lo[t] : 0, hi = tv ? a.band.hi[t] : 0;
+        const int lo = band_lo, hi = band_hi;
         const int head = tile0;
-        const float* kb = a.band.k + (long long)b * a.band.kv_bstride + (long long)(head * 32) * a.band.kv_pitch;
-        const float* vb = a.band.v + (long long)b * a.band.kv_bstride + (long long)(head * 32) * a.band.kv_pitch;
         const int wmax = a.band.wmax;
-        for (int wi = 0; wi < wmax; ++wi) {
-            const int s = lo + wi;
-            float p = 0.f;
-            if (s < hi) {
+        __syncthreads();
 #pragma unroll
-                for (int dd = 0; dd < DPG; ++dd) {
-                    const int d = gi * DPG + dd;
-                    p = fmaf(qt[d * 32 + tt], kb[(long long)d * a.band.kv_pitch + s], p);
-                }
+        for (int wi = 0; wi < 8; ++wi) {
+            if (wi < wmax) {
+                float p = 0.f;
+#pragma unroll
+                for (int dd = 0; dd < DPG; ++dd) p = fmaf(qt[(gi * DPG + dd) * 32 + tt], kq[dd][wi], p);
+                part[(gi * 8 + wi) * 32 + tt] = p;
             }
-            part[(gi * 8 + wi) * 32 + tt] = p;
         }
         __syncthreads();
         float sc[8];
@@ -425,8 +605,7 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
                 const int d = gi * DPG + dd;
                 float o = 0.f;
 #pragma unroll
-                for (int wi = 0; wi < 8; ++wi)
-                    if ((wi < wmax) && (lo + wi < hi)) o = fmaf(sc[wi] * inv, vb[(long long)d * a.band.kv_pitch + lo + wi], o);
+                for (int wi = 0; wi < 8; ++wi) o = fmaf(sc[wi] * inv, vq[dd][wi], o);
                 a.y[(long long)b * a.y_bstride + (long long)(head * 32 + d) * a.y_pitch + t] = o;
             }
         }
@@ -454,7 +633,7 @@ static int gemm_smem_floats(const GemmArgs& a, int KS) {
     for (int s = 0; s < a.nseg; ++s) coef += seg_coef_floats(a.seg[s]);
     coef += KS * 32 * 2;  // LN reduction scratch
     const int red = KS * NACC * 16 * 64;
-    return epi_scratch_floats<NACC>(EPI, KS) + (coef > red ? coef : red);
+    return epi_scratch_floats<NACC>(EPI, KS) + KS * GN_SCRATCH + (coef > red ? coef : red);
 }
 
 constexpr int kMaxLdsBytes = 160 * 1024;

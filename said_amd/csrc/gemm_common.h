@@ -1,0 +1,217 @@
+// gemm_common.h — device helpers shared by the generic GEMM (gemm.hip) and the LDS-staged UNet GEMM (gemm_lds.hip).
+#pragma once
+#include <cstddef>
+
+#include "kernels.h"
+
+namespace said {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float half_sum(float v) {  // within each 32-lane half
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- argument block access without scalar-memory round trips ----
+// GemmArgs is four 256-byte blocks [common][seg0][seg1][seg2].  Each wave fetches them with four coalesced
+// vector loads (lane k holds dword k of every block) and reads fields with v_readlane.
+struct ArgView { unsigned h, s0, s1, s2; };
+__device__ __forceinline__ ArgView arg_view(int lane) {
+    const unsigned* p = (const unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+    ArgView v;
+    v.h = p[lane]; v.s0 = p[64 + lane]; v.s1 = p[128 + lane]; v.s2 = p[192 + lane];
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T rl(unsigned v, int dw) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_readlane((int)v, dw));
+    } else {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)v, dw), hi = (unsigned)__builtin_amdgcn_readlane((int)v, dw + 1);
+        return __builtin_bit_cast(T, (unsigned long long)lo | ((unsigned long long)hi << 32));
+    }
+}
+#define AH(f) rl<decltype(GemmCommon::f)>(V.h, (int)(offsetof(GemmCommon, f) / 4))
+#define AB(f) rl<decltype(BandArgs::f)>(V.h, (int)((offsetof(GemmCommon, band) + offsetof(BandArgs, f)) / 4))
+#define AS(sv, f) rl<decltype(SegFields::f)>(sv, (int)(offsetof(SegFields, f) / 4))
+
+// optional phase timing (GemmArgs::clk != null): wave w of workgroup (1,0,0) stamps the shader clock
+__device__ __forceinline__ void clk_stamp(const GemmArgs& a, int w, int lane, int slot) {
+    if (a.clk && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        if (lane == 0) a.clk[w * 16 + slot] = (long long)t;
+    }
+}
+
+__device__ __forceinline__ void clk_stamp_p(long long* clk, int w, int lane, int slot) {
+    if (clk && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        if (lane == 0) clk[w * 16 + slot] = (long long)t;
+    }
+}
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+// 32-bit-offset load: byte address = base + voff (VGPR) + soff (SGPR) [+ folded immediate]; out-of-range
+// offsets (e.g. the t = -1 halo of the first row) return 0 from the hardware bounds check.
+__device__ __forceinline__ float bload(rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float2 bload2(rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+
+// ---- cross-lane sums on DPP (1 VALU each) instead of ds_bpermute chains ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(float, x);
+}
+// sum over each 16-lane row, result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    v = dpp_add<0x140>(v);  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float half32_sum(float v) { v = row16_sum(v); return v + __shfl_xor(v, 16); }
+
+template <int XF>
+__device__ __forceinline__ float xform_apply(float v, float2 gn, float mu, float rs, float2 ln) {
+    if (XF == XF_NONE) return v;
+    if (XF == XF_SILU) return silu_f(v);
+    if (XF == XF_GN_SILU) return silu_f(fmaf(v, gn.x, gn.y));
+    if (XF == XF_LN) return fmaf((v - mu) * rs, ln.x, ln.y);
+    if (XF == XF_GN_LN) return fmaf((fmaf(v, gn.x, gn.y) - mu) * rs, ln.x, ln.y);
+    return v;
+}
+
+// LDS carve (floats).  Must match gemm_smem_floats() on the host side below.
+__host__ __device__ inline int seg_coef_floats(const Seg& s) {
+    int f = 0;
+    if (s.xform == XF_GN_SILU || s.xform == XF_GN_LN) f += 2 * s.C;
+    if (s.xform == XF_LN || s.xform == XF_GN_LN) f += 2 * s.C;
+    return f;
+}
+constexpr int GN_SCRATCH = 64 * 3 + 32 + 32;  // per-wave GroupNorm scratch (floats)
+template <int NACC>
+__host__ __device__ inline int epi_scratch_floats(int epi, int KS) {
+    if (epi == EPI_BAND) return 32 * 32 + (KS * 2) * 8 * 32;  // q tile + score partials [groups][wmax<=8][32]
+    return 2 * 32 * NACC;                                      // residual GN coefficients
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm coefficients of the wave's own channel slice [c_lo, c_lo + cw), cw <= 64, cpg | cw.
+// lane <-> (channel, phase): each lane accumulates its channel's Welford partials (relative to the
+// group's first partial mean) over every NPH-th 32-token tile with all loads in flight; the 6/12
+// channels of a group are then combined through a small per-wave LDS scratch (no shuffle chains).
+// scratch: 64*3 + 16*2 floats per wave.
+// ------------------------------------------------------------------------------------------------
+struct GnLoads { float2 v[10]; float ref; float gamma, beta; };
+struct GnP { int gn_cpg, gn_nparts, Tin; float gn_eps; const float* gn_gamma; const float* gn_beta; };
+__device__ __forceinline__ GnP gnp_of(const Seg& sg) { return {sg.gn_cpg, sg.gn_nparts, sg.Tin, sg.gn_eps, sg.gn_gamma, sg.gn_beta}; }
+
+__device__ __forceinline__ void gn_issue(const GnP sg, rsrc_t rp, int c_lo, int cw, int lane, GnLoads& L) {
+    const int nph = (cw <= 32) ? 2 : 1;
+    const int ch = (nph == 2) ? (lane & 31) : lane;
+    const int ph = (nph == 2) ? (lane >> 5) : 0;
+    const bool chok = ch < cw;
+    const int c = c_lo + (chok ? ch : 0);
+    const int gfirst = c - (c % sg.gn_cpg);
+    L.ref = bload(rp, gfirst * sg.gn_nparts * 8, 0);
+    L.gamma = sg.gn_gamma[c];
+    L.beta = sg.gn_beta[c];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const int pi = ph + nph * r;
+        const bool ok = chok && (pi < sg.gn_nparts);
+        L.v[r] = bload2(rp, ok ? (c * sg.gn_nparts + pi) * 8 : (int)0x80000000, 0);
+    }
+}
+
+__device__ __forceinline__ void gn_finish(const GnP sg, rsrc_t rp, int c_lo, int cw, int lane, const GnLoads& L, float* scratch,
+                                          float* cA /* interleaved (a,b), indexed by segment channel */) {
+    const int nph = (cw <= 32) ? 2 : 1;
+    const int ch = (nph == 2) ? (lane & 31) : lane;
+    const int ph = (nph == 2) ? (lane >> 5) : 0;
+    const bool chok = ch < cw;
+    const int c = c_lo + (chok ? ch : 0);
+    const int nparts = sg.gn_nparts;
+    const int tail = sg.Tin - (nparts - 1) * 32;
+    float s1 = 0.f, s2 = 0.f, sm = 0.f;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const int pi = ph + nph * r;
+        const bool ok = chok && (pi < nparts);
+        const float cnt = ok ? ((pi == nparts - 1) ? (float)tail : 32.f) : 0.f;
+        const float d = L.v[r].x - L.ref;
+        s1 = fmaf(cnt, d, s1);
+        s2 = fmaf(cnt * d, d, s2);
+        sm += ok ? L.v[r].y : 0.f;
+    }
+    for (int r0 = 10; ph + nph * r0 < nparts; r0 += 10) {  // long sequences: further rounds of 10 tiles
+        float2 v[10];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const int pi = ph + nph * (r0 + r);
+            const bool ok = chok && (pi < nparts);
+            v[r] = bload2(rp, ok ? (c * nparts + pi) * 8 : (int)0x80000000, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const int pi = ph + nph * (r0 + r);
+            const bool ok = chok && (pi < nparts);
+            const float cnt = ok ? ((pi == nparts - 1) ? (float)tail : 32.f) : 0.f;
+            const float d = v[r].x - L.ref;
+            s1 = fmaf(cnt, d, s1);
+            s2 = fmaf(cnt * d, d, s2);
+            sm += ok ? v[r].y : 0.f;
+        }
+    }
+    if (nph == 2) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        sm += __shfl_xor(sm, 32);
+    }
+    float* sc = scratch;            // [64][3]
+    float* gs = scratch + 64 * 3;   // [16][2] (mean, rstd) per group of this wave
+    if (ph == 0 && chok) { sc[ch * 3] = s1; sc[ch * 3 + 1] = s2; sc[ch * 3 + 2] = sm; }
+    const int gpw = cw / sg.gn_cpg;
+    if (lane < gpw) {
+        float S1 = 0.f, S2 = 0.f, SM = 0.f;
+        for (int q = 0; q < sg.gn_cpg; ++q) {
+            const int cc = lane * sg.gn_cpg + q;
+            S1 += sc[cc * 3]; S2 += sc[cc * 3 + 1]; SM += sc[cc * 3 + 2];
+        }
+        const float total = (float)sg.gn_cpg * (float)sg.Tin;
+        const float md = S1 / total;
+        const float var = fmaxf((SM + S2 - total * md * md) / total, 0.f);
+        gs[lane * 2] = md;  // mean relative to the group's ref; each lane adds its own ref back
+        gs[lane * 2 + 1] = 1.0f / sqrtf(var + sg.gn_eps);
+    }
+    if (ph == 0 && chok) {
+        const int gi = ch / sg.gn_cpg;
+        const float mean = L.ref + gs[gi * 2];
+        const float av = gs[gi * 2 + 1] * L.gamma;
+        cA[2 * c] = av;
+        cA[2 * c + 1] = L.beta - mean * av;
+    }
+}
+
+
+}  // namespace said

@@ -25,9 +25,10 @@ enum Res : int { RES_NONE = 0, RES_PLAIN = 1, RES_GN = 2 };
 enum Epi : int { EPI_STORE = 0, EPI_QKV = 1, EPI_GEGLU = 2, EPI_BAND = 3 };
 
 // One K-segment of a GEMM: out[n][t] += sum_{tap,c} W[n][c][tap] * xform(X[c][t*stride + tap - pad])
-struct Seg {
+struct SegFields {
     const float* x;        // source, channel 0 of this segment, batch 0
     const float* w;        // packed weights [groups][ntiles][taps][C/2][64]
+    const float* w4;       // same weights packed for dwordx4 fetch [ntiles][taps][C/8][64 lanes][4 k-pairs] (or null)
     const float* gn_part;  // GN partial stats of the source [B][C][nparts][2] (mean, M2), channel 0 of segment
     const float* gn_gamma; // GN affine (segment channel 0)
     const float* gn_beta;
@@ -46,6 +47,11 @@ struct Seg {
     int b_mod;             // source batch = b % b_mod when > 0 (CFG: both halves read the same latents)
     int c_group_stride;    // source channel offset per conv group (grouped conv), else 0
 };
+// padded to 256 bytes: the LDS-staged kernel fetches the argument block with one coalesced 256-B vector
+// load per block and extracts fields with v_readlane (a by-value struct read field-by-field costs one
+// serialized scalar-memory round trip per field group — measured ~8k clocks per kernel)
+struct Seg : SegFields { char pad_[256 - sizeof(SegFields)]; };
+static_assert(sizeof(Seg) == 256, "Seg must be one 256-byte block");
 
 struct BandArgs {          // banded cross-attention fused behind the q projection
     const float* k;        // [Be][C][Sp] channel-major keys (precomputed per clip)
@@ -58,15 +64,14 @@ struct BandArgs {          // banded cross-attention fused behind the q projecti
     float scale;           // dim_head ** -0.5, applied after QK^T (ldm/attention.py:101)
 };
 
-struct GemmArgs {
-    Seg seg[3];
+struct GemmCommon {
     int nseg;
     int T;                 // output length
     int N;                 // output channels per group
     int groups;            // conv groups (1 unless grouped conv)
     int ntiles_per_group;  // ceil(N / 32)
-    const float* bias;     // [groups*N] or null
     int act;               // Act, applied after bias
+    const float* bias;     // [groups*N] or null
     // + emb[row][n]: per-(row, channel) additive term (ResBlock emb_layers output)
     const float* emb;      // [(n)][emb_pitch] channel-major table, or null
     const int* step_ptr;   // device step counter: row = *step_ptr (loop) ...
@@ -74,9 +79,9 @@ struct GemmArgs {
     int emb_pitch;
     // residual
     int res_kind;
+    int res_pitch;
     const float* res;      // [B][N][res_pitch]
     long long res_bstride;
-    int res_pitch;
     const float* res_gn_part;  // RES_GN: partial stats of `res`, gamma/beta/eps
     const float* res_gn_gamma;
     const float* res_gn_beta;
@@ -84,9 +89,9 @@ struct GemmArgs {
     int res_gn_cpg, res_gn_nparts;
     float res_gn_eps;
     // output
+    int y_pitch;
     float* y;              // channel-major [B][groups*N][y_pitch]
     long long y_bstride;
-    int y_pitch;
     float* stats_out;      // GN partials of y: [B][groups*N][ceil(T/32)][2], or null
     long long stats_bstride;
     // EPI_QKV: tiles >= vt_first_tile are written token-major: vt[b][h][t][d]
@@ -95,8 +100,16 @@ struct GemmArgs {
     int vt_heads, vt_dim, vt_rows;   // rows = padded T of the vt buffer
     // EPI_GEGLU: gate tile = value tile + geglu_gate_tiles
     int geglu_gate_tiles;
+    int pad0_;
     BandArgs band;
+    long long* clk;        // optional [KS][16] shader-clock stamps of workgroup (1,0,0) (debug)
 };
+struct GemmArgs : GemmCommon {
+    char pad_[256 - sizeof(GemmCommon)];
+    Seg seg[3];
+};
+static_assert(sizeof(GemmCommon) <= 256, "common block must fit 256 bytes");
+static_assert(sizeof(GemmArgs) == 1024, "GemmArgs = 4 blocks of 256 bytes");
 
 struct AttnArgs {
     const float* q;        // [B][H*D][pitch]
@@ -114,6 +127,10 @@ struct AttnArgs {
 // tile shape selection: NB 32-row tiles per workgroup, KS waves splitting K
 void launch_gemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s);
 void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s);
+// LDS-staged UNet GEMM (gemm_lds.hip): same arguments; only for shapes ugemm_supports() accepts
+bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS);
+void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s);
+void configure_ugemm_kernels();
 
 // token-major (B,T,C) <-> channel-major [B][C][pitch]
 void launch_tm_to_cm(const float* src, float* dst, int B, int T, int C, int pitch, long long dst_bstride, hipStream_t s);
