@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const AttnArgs a) {
     constexpr int D = 32 * ND;
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+    const int i0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z + a.b0;
     const int T = a.T, pitch = a.pitch;
     const float* qb = a.q + (long long)b * a.qkv_bstride + (long long)(h * D) * pitch;
     const float* kb = a.k + (long long)b * a.qkv_bstride + (long long)(h * D) * pitch;

@@ -96,6 +96,10 @@ struct said_ctx {
     float* axpby_coef = nullptr;
     long long* clk_dev = nullptr;  // [64 launches][8 waves][8 slots]
     bool clk_on = false;
+    int cur_b0 = 0;          // batch offset applied to every launch issued by run_unet (parallel graph branches)
+    hipStream_t cap_stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool use_branches = false;  // SAID_BRANCHES=1: capture the two halves of the UNet batch as parallel graph branches
     bool use_ugemm = true;   // SAID_NO_UGEMM=1 forces the generic kernel everywhere (A/B testing)
 
     // ---- audio workspace (lazily sized) ----
@@ -268,6 +272,8 @@ struct UGeo {
     long long sts;     // batch stride of its stats
     const int* step_ptr;
     int emb_b_stride;
+    int b0;            // first sample of this launch range (Be = number of samples in the range)
+    int* step_inc;     // if set: the first kernel of the schedule increments this counter
 };
 
 inline bool dbg_go(said_ctx* c) {
@@ -293,10 +299,11 @@ void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS,
         c->stage_log.push_back({(c->use_ugemm && ugemm_supports(a, epi, NB, KS)) ? 2 : 0, epi, NB, KS, w + in + out, fl});
     }
     GemmArgs a2 = a;
+    a2.b0 = c->cur_b0;
     if (c->clk_on && c->dbg_count < 64) a2.clk = c->clk_dev + (long long)c->dbg_count * 128;
     if (dbg_go(c)) {
         if (trace_on()) { fprintf(stderr, "[said] gemm #%d epi=%d NB=%d KS=%d T=%d N=%d batch=%d\n", c->dbg_count - 1, epi, NB, KS, a.T, a.N, batch); fflush(stderr); }
-        if (c->use_ugemm && ugemm_supports(a2, epi, NB, KS)) launch_ugemm(a2, epi, batch, NB, KS, s);
+        if (c->use_ugemm && !a2.step_inc && ugemm_supports(a2, epi, NB, KS)) launch_ugemm(a2, epi, batch, NB, KS, s);
         else launch_gemm(a2, epi, batch, NB, KS, s);
         if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
     }
@@ -308,7 +315,9 @@ void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hi
     }
     if (dbg_go(c)) {
         if (trace_on()) { fprintf(stderr, "[said] attn #%d D=%d KS=%d T=%d batch=%d\n", c->dbg_count - 1, head_dim, KS, a.T, batch); fflush(stderr); }
-        launch_attn(a, batch, head_dim, KS, s);
+        AttnArgs a2 = a;
+        a2.b0 = c->cur_b0;
+        launch_attn(a2, batch, head_dim, KS, s);
         if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
     }
 }
@@ -365,7 +374,8 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.seg[0].ln_gamma = sw.l1g; a.seg[0].ln_beta = sw.l1b; a.seg[0].ln_eps = 1e-5f;
         a.y = c->QK; a.y_bstride = 2LL * MC * g.Tp; a.y_pitch = g.Tp;
         a.vt = c->VT; a.vt_first_tile = 12; a.vt_heads = HEADS; a.vt_dim = HD; a.vt_rows = vt_rows;
-        const LaunchCfg lc = big ? LaunchCfg{6, 4} : LaunchCfg{1, 8};
+        static const int qkv_nb = getenv("SAID_QKV_NB") ? atoi(getenv("SAID_QKV_NB")) : 1;
+        const LaunchCfg lc = big ? LaunchCfg{6, 4} : LaunchCfg{qkv_nb, 8};
         do_gemm(c, a, EPI_QKV, g.Be, lc.NB, lc.KS, s);
     }
     {   // softmax(q k^T * scale) v   (attention.py:99-126)
@@ -419,7 +429,8 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.seg[0].ln_gamma = sw.l3g; a.seg[0].ln_beta = sw.l3b; a.seg[0].ln_eps = 1e-5f;
         a.bias = sw.ff1.bias; a.geglu_gate_tiles = FFI / 32;
         a.y = c->F; a.y_bstride = (long long)FFI * g.Tp; a.y_pitch = g.Tp;
-        do_gemm(c, a, EPI_GEGLU, g.Be, big ? 3 : 1, big ? 4 : 8, s);
+        static const int geglu_nb = getenv("SAID_GEGLU_NB") ? atoi(getenv("SAID_GEGLU_NB")) : 2;   // measured: 671 -> 637 us per step at Be=2
+        do_gemm(c, a, EPI_GEGLU, g.Be, big ? 3 : geglu_nb, big ? 4 : 8, s);
     }
     {   // x3 = net.2(h) + x2
         GemmArgs a = mkargs(g.T, MC);
@@ -446,12 +457,14 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
 
 // UNetModel.forward (openaimodel.py:677-709): x_cm (latents) -> eps_cm.  Needs KV, band tables and EO ready.
 void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
+    c->cur_b0 = g.b0;
     const long long tt = (long long)g.Be * ((g.T + 31) / 32);
     {   // input_blocks.0: Conv1d(32 -> 192, k3)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
         a.seg[0] = with_w4(mkseg(c->x_cm, (long long)c->cin * g.Tp, g.Tp, c->cin, 3, 1, 1, g.T, XF_NONE, c->conv_in.w[0]), c->conv_in.w4[0]);
         a.seg[0].b_mod = g.B_lat;
+        a.step_inc = g.step_inc;   // the loop's device step counter is advanced by the first kernel of the step
         a.bias = c->conv_in.bias;
         a.y = c->H0.p; a.y_bstride = g.hs; a.y_pitch = g.Tp; a.stats_out = c->H0.st; a.stats_bstride = g.sts;
         const LaunchCfg lc = pick_cfg(tt, 6);
@@ -546,7 +559,7 @@ UGeo make_geo(said_ctx* c, int Be, int B_lat, int T, int S) {
     UGeo g;
     g.Be = Be; g.B_lat = B_lat; g.T = T; g.Tp = rup(T, 32); g.np = (T + 31) / 32; g.S = S; g.Sp = rup(S, 32);
     g.hs = (long long)MC * g.Tp; g.sts = (long long)MC * g.np * 2;
-    g.step_ptr = nullptr; g.emb_b_stride = 0;
+    g.step_ptr = nullptr; g.emb_b_stride = 0; g.b0 = 0; g.step_inc = nullptr;
     return g;
 }
 
@@ -595,6 +608,10 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     configure_ugemm_kernels();
     configure_attn_kernels();
     ctx->use_ugemm = getenv("SAID_NO_UGEMM") == nullptr;
+    ctx->use_branches = getenv("SAID_BRANCHES") != nullptr;   // parallel graph branches measured no faster on ROCm 7.2: off by default
+    if (hipStreamCreateWithFlags(&ctx->cap_stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return fail(nullptr, "stream/event creation failed"); }
     if (hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, "hipStreamCreateWithFlags failed"); }
 
     const size_t Be = max_batch_eff, Tp = ctx->maxTp, np = Tp / 32;
@@ -632,6 +649,9 @@ int said_destroy(said_ctx* ctx) {
     if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
+    if (ctx->cap_stream2) (void)hipStreamDestroy(ctx->cap_stream2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (void* p : ctx->allocs) (void)hipFree(p);
     delete ctx;
     return 0;
@@ -955,11 +975,12 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
         if (!ctx->gexec || key != ctx->gkey) {
             if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
             if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+            const bool fold_step = !(ctx->use_branches && Be >= 2);   // conv_in advances the step counter itself
             // Eager warm-up of the exact step sequence first: the first launch of a kernel inside a
             // stream capture hangs on ROCm 7.2 (lazy per-kernel initialisation is not capturable).
             // The step is run on step index 0 and its effect on the latents is undone afterwards.
             TRACE("loop: warmup begin");
-            launch_step_advance(ctx->step_dev, s);
+            if (fold_step) g.step_inc = ctx->step_dev; else launch_step_advance(ctx->step_dev, s);
             if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said] step_advance -> %s\n", hipGetErrorString(e)); fflush(stderr); }
             run_unet(ctx, g, s);
             TRACE("loop: warmup unet launched");
@@ -973,8 +994,22 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
             // which cannot be captured; the instantiated graph is then replayed on the caller's stream
             hipStream_t cs = ctx->cap_stream;
             HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-            launch_step_advance(ctx->step_dev, cs);
-            run_unet(ctx, g, cs);
+            if (!fold_step) launch_step_advance(ctx->step_dev, cs);
+            if (ctx->use_branches && Be >= 2) {
+                // The two halves of the UNet batch (unconditional / conditional under CFG) are independent until
+                // the scheduler: capture them as parallel branches so their per-kernel latencies overlap.
+                UGeo ga = g, gb = g;
+                ga.Be = Be / 2; ga.b0 = 0;
+                gb.Be = Be - Be / 2; gb.b0 = Be / 2;
+                HIPCHK(hipEventRecord(ctx->ev_fork, cs));
+                HIPCHK(hipStreamWaitEvent(ctx->cap_stream2, ctx->ev_fork, 0));
+                run_unet(ctx, ga, cs);
+                run_unet(ctx, gb, ctx->cap_stream2);
+                HIPCHK(hipEventRecord(ctx->ev_join, ctx->cap_stream2));
+                HIPCHK(hipStreamWaitEvent(cs, ctx->ev_join, 0));
+            } else {
+                run_unet(ctx, g, cs);
+            }
             if (sa.guidance_rescale > 0.f) launch_rescale_partials(sa, ctx->rescale_part, cs);
             launch_sched_step(sa, cs);
             TRACE("loop: capture recorded");

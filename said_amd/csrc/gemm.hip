@@ -199,7 +199,8 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t0 = blockIdx.x * 32;
-    const int b = blockIdx.z;
+    const int b = blockIdx.z + a.b0;
+    if (a.step_inc && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.step_inc += 1;
     const int tb_per_group = a.ntiles_per_group / NB;
     const int g = blockIdx.y / tb_per_group;
     const int tile0 = (blockIdx.y % tb_per_group) * NB;

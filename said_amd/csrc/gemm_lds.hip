@@ -54,9 +54,9 @@ __device__ __forceinline__ void ugemm_body(float* smem) {
     constexpr int TMAX = (EPI == EPI_STORE) ? 3 : 1;   // only plain convolutions have 3 taps
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     const ArgView V = arg_view(l);   // the whole argument block: 4 coalesced loads, fields via v_readlane
+    const int b = blockIdx.z + AH(b0);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t0 = blockIdx.x * 32;
-    const int b = blockIdx.z;
     const int tile0 = blockIdx.y * NB;
     const int nseg = AH(nseg), aT = AH(T), aN = AH(N);
     const int gate_tiles = AH(geglu_gate_tiles);
@@ -602,7 +602,7 @@ static void uconfigure_one() {
 #define SAID_UGEMM_CONFIGS(X)               \
     X(EPI_STORE, 1, 8) X(EPI_STORE, 2, 8)   \
     X(EPI_QKV, 1, 8) X(EPI_QKV, 2, 8)       \
-    X(EPI_GEGLU, 1, 8)                      \
+    X(EPI_GEGLU, 1, 8) X(EPI_GEGLU, 2, 8)   \
     X(EPI_BAND, 1, 8)
 
 void configure_ugemm_kernels() {

@@ -64,45 +64,42 @@ struct BandArgs {          // banded cross-attention fused behind the q projecti
     float scale;           // dim_head ** -0.5, applied after QK^T (ldm/attention.py:101)
 };
 
-struct GemmCommon {
+struct GemmCommon {        // 8-byte members first, then 4-byte ones: no internal padding, <= 256 bytes
+    const float* bias;     // [groups*N] or null
+    // + emb[row][n]: per-(row, channel) additive term (ResBlock emb_layers output)
+    const float* emb;      // [(n)][emb_pitch] channel-major table, or null
+    const int* step_ptr;   // device step counter: row = *step_ptr (loop) + b * emb_b_stride (forward(): row = b)
+    const float* res;      // residual [B][N][res_pitch]
+    long long res_bstride;
+    const float* res_gn_part;  // RES_GN: partial stats of `res`, gamma/beta/eps
+    const float* res_gn_gamma;
+    const float* res_gn_beta;
+    float* y;              // output, channel-major [B][groups*N][y_pitch]
+    long long y_bstride;
+    float* stats_out;      // GN partials of y: [B][groups*N][ceil(T/32)][2], or null
+    float* vt;             // EPI_QKV: tiles >= vt_first_tile are written token-major: vt[b][h][t][d]
+    BandArgs band;
+    long long* clk;        // optional [KS][16] shader-clock stamps of workgroup (1,0,0) (debug)
+    int* step_inc;         // if set, workgroup (0,0,0) increments *step_inc before anything else (loop step counter)
     int nseg;
     int T;                 // output length
     int N;                 // output channels per group
     int groups;            // conv groups (1 unless grouped conv)
     int ntiles_per_group;  // ceil(N / 32)
     int act;               // Act, applied after bias
-    const float* bias;     // [groups*N] or null
-    // + emb[row][n]: per-(row, channel) additive term (ResBlock emb_layers output)
-    const float* emb;      // [(n)][emb_pitch] channel-major table, or null
-    const int* step_ptr;   // device step counter: row = *step_ptr (loop) ...
-    int emb_b_stride;      // ... + b * emb_b_stride (forward(): row = b)
+    int emb_b_stride;
     int emb_pitch;
-    // residual
     int res_kind;
     int res_pitch;
-    const float* res;      // [B][N][res_pitch]
-    long long res_bstride;
-    const float* res_gn_part;  // RES_GN: partial stats of `res`, gamma/beta/eps
-    const float* res_gn_gamma;
-    const float* res_gn_beta;
-    long long res_gn_part_bstride;
+    int res_gn_part_bstride;
     int res_gn_cpg, res_gn_nparts;
     float res_gn_eps;
-    // output
     int y_pitch;
-    float* y;              // channel-major [B][groups*N][y_pitch]
-    long long y_bstride;
-    float* stats_out;      // GN partials of y: [B][groups*N][ceil(T/32)][2], or null
-    long long stats_bstride;
-    // EPI_QKV: tiles >= vt_first_tile are written token-major: vt[b][h][t][d]
-    float* vt;
+    int stats_bstride;
     int vt_first_tile;
     int vt_heads, vt_dim, vt_rows;   // rows = padded T of the vt buffer
-    // EPI_GEGLU: gate tile = value tile + geglu_gate_tiles
-    int geglu_gate_tiles;
-    int pad0_;
-    BandArgs band;
-    long long* clk;        // optional [KS][16] shader-clock stamps of workgroup (1,0,0) (debug)
+    int geglu_gate_tiles;  // EPI_GEGLU: gate tile = value tile + geglu_gate_tiles
+    int b0;                // batch offset: this launch covers samples [b0, b0 + gridDim.z)
 };
 struct GemmArgs : GemmCommon {
     char pad_[256 - sizeof(GemmCommon)];
@@ -122,6 +119,7 @@ struct AttnArgs {
     int heads;
     int vt_rows;
     float scale;
+    int b0;                // batch offset
 };
 
 // tile shape selection: NB 32-row tiles per workgroup, KS waves splitting K
