@@ -141,3 +141,17 @@ def test_cli_parser_has_reference_flags():
     for k in ("weights_path", "audio_path", "output_path", "output_image_path", "intermediate_dir"):
         assert hasattr(ns, k)
     assert mod.build_parser().parse_args(["--save_image", "False"]).save_image is True  # type=bool quirk kept
+
+
+def test_batch_driver_parser_and_enumeration(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("said_test_inference", os.path.join(ROOT, "script", "test_inference.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ns = mod.build_parser().parse_args([])
+    assert (ns.num_steps, ns.guidance_scale, ns.num_repeats, ns.batch_size, ns.seed, ns.device) == (1000, 2.0, 72, 64, 0, "cuda:0")
+    pid = mod.PERSON_IDS_TEST[1]
+    os.makedirs(tmp_path / pid)
+    for n in ("sentence40.wav", "sentence02.wav", "sentence41.wav", "other.wav"):
+        (tmp_path / pid / n).write_bytes(b"")
+    assert [os.path.basename(p) for _, p in mod.test_audio_paths(str(tmp_path))] == ["sentence02.wav", "sentence40.wav"]
