@@ -44,7 +44,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
+            extra = ["-mllvm", "-amdgpu-kernarg-preload-count=16"] if (src == "gemm_lds.hip" and not os.environ.get("SAID_NO_PRELOAD")) else []
+            cmd = [hipcc] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):

@@ -26,8 +26,8 @@ __device__ __forceinline__ float half_sum(float v) {  // within each 32-lane hal
 // GemmArgs is four 256-byte blocks [common][seg0][seg1][seg2].  Each wave fetches them with four coalesced
 // vector loads (lane k holds dword k of every block) and reads fields with v_readlane.
 struct ArgView { unsigned h, s0, s1, s2; };
-__device__ __forceinline__ ArgView arg_view(int lane) {
-    const unsigned* p = (const unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+__device__ __forceinline__ ArgView arg_view(int lane, int dword_offset = 0) {
+    const unsigned* p = (const unsigned*)__builtin_amdgcn_kernarg_segment_ptr() + dword_offset;
     ArgView v;
     v.h = p[lane]; v.s0 = p[64 + lane]; v.s1 = p[128 + lane]; v.s2 = p[192 + lane];
     return v;
@@ -55,7 +55,7 @@ __device__ __forceinline__ void clk_stamp(const GemmArgs& a, int w, int lane, in
 }
 
 __device__ __forceinline__ void clk_stamp_p(long long* clk, int w, int lane, int slot) {
-    if (clk && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0) {
+    if (clk && blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0) {
         unsigned long long t;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
         if (lane == 0) clk[w * 16 + slot] = (long long)t;

@@ -34,6 +34,19 @@ constexpr int NRMAX = 3;      // row rounds per block: CB = 8 * NR <= 24 channel
 template <int XF>
 __device__ __forceinline__ float xf1(float v, float2 gn, float mu, float rs, float2 ln) { return xform_apply<XF>(v, gn, mu, rs, ln); }
 
+// 16 dwords of launch-invariant scalars passed as LEADING kernel parameters: with -amdgpu-kernarg-preload-count=16
+// the command processor delivers them in SGPRs, so the first operand loads need no memory round trip at all.
+struct FastHdr {
+    const float* x;    // segment 0 source (batch 0)
+    const float* w4;   // segment 0 packed weights
+    int pack;          // C | taps << 16 | xform << 20 | nseg << 24
+    int pitch, Tin, bstride;   // segment 0 pitch, valid length, batch stride (floats)
+    int bmod_b0;       // b_mod | b0 << 16
+    int T, N, ntiles, gate_tiles;
+    int r0, r1, r2;
+};
+static_assert(sizeof(FastHdr) == 64, "FastHdr must be exactly 16 dwords");
+
 struct UBlock {   // one (segment, channel block) of this wave
     rsrc_t rx, rw;
     int c0;        // first channel of the block (segment-relative)
@@ -45,7 +58,7 @@ struct UBlock {   // one (segment, channel block) of this wave
 };
 
 template <int NB, int KS, int EPI, bool TRANS>
-__device__ __forceinline__ void ugemm_body(float* smem) {
+__device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int bx, int by, int bz) {
     constexpr int NACC = (EPI == EPI_GEGLU) ? 2 * NB : NB;
     constexpr int NV = NB * 16;
     static_assert(NV % KS == 0, "NB*16 must be divisible by KS");
@@ -53,63 +66,40 @@ __device__ __forceinline__ void ugemm_body(float* smem) {
     constexpr bool EPRE = (VPW <= 4) && (EPI == EPI_STORE || EPI == EPI_QKV) && !TRANS;
     constexpr int TMAX = (EPI == EPI_STORE) ? 3 : 1;   // only plain convolutions have 3 taps
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
-    const ArgView V = arg_view(l);   // the whole argument block: 4 coalesced loads, fields via v_readlane
-    const int b = blockIdx.z + AH(b0);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t0 = blockIdx.x * 32;
-    const int tile0 = blockIdx.y * NB;
-    const int nseg = AH(nseg), aT = AH(T), aN = AH(N);
-    const int gate_tiles = AH(geglu_gate_tiles);
-    const int w_tiles = (EPI == EPI_GEGLU) ? AH(ntiles_per_group) + gate_tiles : AH(ntiles_per_group);
-    long long* const clkp = AH(clk);
-    auto SV = [&](int s) -> unsigned { return s == 0 ? V.s0 : (s == 1 ? V.s1 : V.s2); };
+    const int b = bz + (hd.bmod_b0 >> 16);
+    const int t0 = bx * 32;
+    const int tile0 = by * NB;
+    const int nseg = (hd.pack >> 24) & 3, aT = hd.T, aN = hd.N;
+    const int gate_tiles = hd.gate_tiles;
+    const int w_tiles = (EPI == EPI_GEGLU) ? hd.ntiles + gate_tiles : hd.ntiles;
     const int sr = l >> 3, sq = l & 7;   // staging map: row-in-round, token quad
+    const int C0 = hd.pack & 0xffff, taps0 = (hd.pack >> 16) & 15, xf0 = (hd.pack >> 20) & 15;
 
     const int epi_sz = epi_scratch_floats<NACC>(EPI, KS);
     float* epiS = smem;
     float* gnS = smem + epi_sz + w * GN_SCRATCH;
     float* mainS = smem + epi_sz + KS * GN_SCRATCH;
-    clk_stamp_p(clkp, w, l, 0);
 
-    int coef_off[3];
-    int coef_total = 0;
-    for (int s = 0; s < nseg; ++s) {
-        coef_off[s] = coef_total;
-        const int xf = AS(SV(s), xform), sc = AS(SV(s), C);
-        coef_total += ((xf == XF_GN_SILU || xf == XF_GN_LN) ? 2 * sc : 0) + ((xf == XF_LN || xf == XF_GN_LN) ? 2 * sc : 0);
-    }
-    float* lnred = mainS + coef_total;                      // [KS][32][2]
-    float* xt = lnred + KS * 64 + w * (8 * NRMAX * XP);    // this wave's X tile [CB][XP]
-
-    int tile_wo[NACC];   // byte offset of each output tile in a segment's packed weights (per segment: scaled below)
+    int tile_wo[NACC];   // output tile index of each accumulator
 #pragma unroll
     for (int i = 0; i < NACC; ++i) tile_wo[i] = (i < NB) ? (tile0 + i) : (tile0 + (i - NB) + gate_tiles);
 
-    auto make_block = [&](int s, int blk) {
-        const unsigned sv = SV(s);
-        UBlock u;
-        const int sC = AS(sv, C), pitch = AS(sv, x_pitch), taps = AS(sv, taps), bmod = AS(sv, b_mod);
-        const int cw = sC / KS;
-        const int cb = (cw % 24 == 0) ? 24 : cw;   // host guarantees cw % 24 == 0 or cw in {8, 16}
+    // block 0 of segment 0 entirely from the preloaded header: its operand loads are issued first thing
+    UBlock u0;
+    {
+        const int cw = C0 / KS;
+        const int cb = (cw % 24 == 0) ? 24 : cw;
+        const int bmod = hd.bmod_b0 & 0xffff;
         const int sb = bmod > 0 ? b % bmod : b;
-        u.rx = make_rsrc(AS(sv, x) + (long long)sb * AS(sv, x_bstride), (unsigned)sC * (unsigned)pitch * 4u);
-        u.rw = make_rsrc(AS(sv, w4), (unsigned)w_tiles * (unsigned)taps * (unsigned)(sC >> 3) * 1024u);
-        u.c0 = w * cw + blk * cb;
-        u.nr = cb >> 3;
-        u.taps = taps; u.Tin = AS(sv, Tin); u.pitch4 = pitch * 4; u.C8 = sC >> 3; u.xform = AS(sv, xform);
-        u.cGN = reinterpret_cast<const float2*>(mainS + coef_off[s]);
-        u.cLN = reinterpret_cast<const float2*>(mainS + coef_off[s] + ((u.xform == XF_GN_LN) ? 2 * sC : 0));
-        return u;
-    };
-    auto nblocks = [&](int s) {
-        const int cw = AS(SV(s), C) / KS;
-        return (cw % 24 == 0) ? cw / 24 : 1;
-    };
-    auto seg_gnp = [&](int s) {
-        const unsigned sv = SV(s);
-        GnP p = {AS(sv, gn_cpg), AS(sv, gn_nparts), AS(sv, Tin), AS(sv, gn_eps), AS(sv, gn_gamma), AS(sv, gn_beta)};
-        return p;
-    };
+        u0.rx = make_rsrc(hd.x + (long long)sb * hd.bstride, (unsigned)C0 * (unsigned)hd.pitch * 4u);
+        u0.rw = make_rsrc(hd.w4, (unsigned)w_tiles * (unsigned)taps0 * (unsigned)(C0 >> 3) * 1024u);
+        u0.c0 = w * cw;
+        u0.nr = cb >> 3;
+        u0.taps = taps0; u0.Tin = hd.Tin; u0.pitch4 = hd.pitch * 4; u0.C8 = C0 >> 3; u0.xform = xf0;
+        u0.cGN = reinterpret_cast<const float2*>(mainS);
+        u0.cLN = reinterpret_cast<const float2*>(mainS + ((xf0 == XF_GN_LN) ? 2 * C0 : 0));
+    }
 
     // raw X slice of a block -> registers: NR dwordx4 (row sr of each round, tokens t0+4*sq..+3) + halo dwords
     auto issue_x = [&](const UBlock& u, f32x4 (&xv)[NRMAX], float& halo) {
@@ -141,12 +131,55 @@ __device__ __forceinline__ void ugemm_body(float* smem) {
     // ================= phase 0: requests =================
     f32x4 xv[NRMAX], wv[TMAX][NRMAX][NACC];
     float halo;
-    const UBlock u0 = make_block(0, 0);
+    // request order matters: vector loads return in order, so the argument block goes first (GroupNorm partial loads
+    // wait on it), then the operands, which need only the preloaded header
+    const ArgView V = arg_view(l, 16);   // the rest of the argument block: 4 coalesced loads, fields via v_readlane
     issue_x(u0, xv, halo);
-    const int xf0 = AS(V.s0, xform);
     const bool has_ln = (xf0 == XF_LN || xf0 == XF_GN_LN);
     f32x4 lnref = {0.f, 0.f, 0.f, 0.f};
     if (has_ln) lnref = bload4(u0.rx, (t0 + 4 * sq) * 4, 0);   // raw channel 0 of this lane's 4 tokens: common shift
+    // Weights are not needed before the MFMA loop.  If segment 0 is GroupNorm'ed, its statistics partials are the
+    // head of the critical chain (partials -> coefficients -> staging), so they must be requested BEFORE the weights
+    // (loads return in order) — but they need the argument block; otherwise the weights go out right away.
+    const bool gn0 = (xf0 == XF_GN_SILU || xf0 == XF_GN_LN);
+    if (!gn0) issue_w(u0, wv);
+    long long* const clkp = AH(clk);
+    clk_stamp_p(clkp, w, l, 0);
+    auto SV = [&](int s) -> unsigned { return s == 0 ? V.s0 : (s == 1 ? V.s1 : V.s2); };
+    int coef_off[3];
+    int coef_total = 0;
+    for (int s = 0; s < nseg; ++s) {
+        coef_off[s] = coef_total;
+        const int xf = AS(SV(s), xform), sc = AS(SV(s), C);
+        coef_total += ((xf == XF_GN_SILU || xf == XF_GN_LN) ? 2 * sc : 0) + ((xf == XF_LN || xf == XF_GN_LN) ? 2 * sc : 0);
+    }
+    float* lnred = mainS + coef_total;                      // [KS][32][2]
+    float* xt = lnred + KS * 64 + w * (8 * NRMAX * XP);    // this wave's X tile [CB][XP]
+    auto make_block = [&](int s, int blk) {
+        const unsigned sv = SV(s);
+        UBlock u;
+        const int sC = AS(sv, C), pitch = AS(sv, x_pitch), taps = AS(sv, taps), bmod = AS(sv, b_mod);
+        const int cw = sC / KS;
+        const int cb = (cw % 24 == 0) ? 24 : cw;   // host guarantees cw % 24 == 0 or cw in {8, 16}
+        const int sb = bmod > 0 ? b % bmod : b;
+        u.rx = make_rsrc(AS(sv, x) + (long long)sb * AS(sv, x_bstride), (unsigned)sC * (unsigned)pitch * 4u);
+        u.rw = make_rsrc(AS(sv, w4), (unsigned)w_tiles * (unsigned)taps * (unsigned)(sC >> 3) * 1024u);
+        u.c0 = w * cw + blk * cb;
+        u.nr = cb >> 3;
+        u.taps = taps; u.Tin = AS(sv, Tin); u.pitch4 = pitch * 4; u.C8 = sC >> 3; u.xform = AS(sv, xform);
+        u.cGN = reinterpret_cast<const float2*>(mainS + coef_off[s]);
+        u.cLN = reinterpret_cast<const float2*>(mainS + coef_off[s] + ((u.xform == XF_GN_LN) ? 2 * sC : 0));
+        return u;
+    };
+    auto nblocks = [&](int s) {
+        const int cw = AS(SV(s), C) / KS;
+        return (cw % 24 == 0) ? cw / 24 : 1;
+    };
+    auto seg_gnp = [&](int s) {
+        const unsigned sv = SV(s);
+        GnP p = {AS(sv, gn_cpg), AS(sv, gn_nparts), AS(sv, Tin), AS(sv, gn_eps), AS(sv, gn_gamma), AS(sv, gn_beta)};
+        return p;
+    };
     GnLoads gl[2];
     rsrc_t grp_rsrc[2];
 #pragma unroll
@@ -160,7 +193,7 @@ __device__ __forceinline__ void ugemm_body(float* smem) {
             gn_issue(seg_gnp(s), grp_rsrc[s], w * (sC / KS), sC / KS, l, gl[s]);
         }
     }
-    issue_w(u0, wv);
+    if (gn0) issue_w(u0, wv);
     float e_bias[EPRE ? VPW : 1], e_emb[EPRE ? VPW : 1], e_res[EPRE ? VPW : 1];
     const float* const e_biasp = AH(bias);
     const int e_act = AH(act);
@@ -204,7 +237,6 @@ __device__ __forceinline__ void ugemm_body(float* smem) {
             gn_finish(seg_gnp(s), grp_rsrc[s], w * (sC / KS), sC / KS, l, gl[s], gnS, mainS + coef_off[s]);
         }
     }
-    const int C0 = AS(V.s0, C);
     if (has_ln) {
         float* cL = mainS + coef_off[0] + ((xf0 == XF_GN_LN) ? 2 * C0 : 0);
         const float* lg = AS(V.s0, ln_gamma);
@@ -382,16 +414,34 @@ __device__ __forceinline__ void ugemm_body(float* smem) {
     };
 
     {
-        bool first = true;
-        for (int s = 0; s < nseg; ++s) {
-            const int nb = nblocks(s);
-            for (int blk = 0; blk < nb; ++blk) {
-                const UBlock u = (s == 0 && blk == 0) ? u0 : make_block(s, blk);
-                if (!first) {   // later blocks: fetch now (their latency is exposed)
-                    issue_x(u, xv, halo);
-                    issue_w(u, wv);
+        // flattened (segment, block) list; with one accumulator tile per wave there are registers to spare, so the
+        // NEXT block's operands are requested before the current block is staged and multiplied (double buffer)
+        int nblk_seg[3] = {0, 0, 0}, nblk_total = 0;
+        for (int s = 0; s < nseg; ++s) { nblk_seg[s] = nblocks(s); nblk_total += nblk_seg[s]; }
+        auto block_at = [&](int i) {
+            int s = 0;
+            while (s < 2 && i >= nblk_seg[s]) { i -= nblk_seg[s]; ++s; }
+            return make_block(s, i);
+        };
+        if constexpr (NACC == 1) {
+            f32x4 xv2[NRMAX], wv2[TMAX][NRMAX][NACC];
+            float halo2 = 0.f;
+            UBlock ua = u0, ub = u0;
+            for (int i = 0; i < nblk_total; i += 2) {
+                const bool has_b = i + 1 < nblk_total;
+                if (has_b) { ub = block_at(i + 1); issue_x(ub, xv2, halo2); issue_w(ub, wv2); }
+                stage(ua, xv, halo);
+                mma_block(ua, wv);
+                if (has_b) {
+                    if (i + 2 < nblk_total) { ua = block_at(i + 2); issue_x(ua, xv, halo); issue_w(ua, wv); }
+                    stage(ub, xv2, halo2);
+                    mma_block(ub, wv2);
                 }
-                first = false;
+            }
+        } else {
+            for (int i = 0; i < nblk_total; ++i) {
+                const UBlock u = (i == 0) ? u0 : block_at(i);
+                if (i > 0) { issue_x(u, xv, halo); issue_w(u, wv); }
                 stage(u, xv, halo);
                 mma_block(u, wv);
             }
@@ -492,7 +542,7 @@ __device__ __forceinline__ void ugemm_body(float* smem) {
             const float d = (t < aT) ? (val - mean) : 0.f;
             const float m2 = half32_sum(d * d);
             if (lt == 0 && nl < aN) {
-                float* so = statsp + (long long)b * AH(stats_bstride) + ((long long)ng * nparts_out + blockIdx.x) * 2;
+                float* so = statsp + (long long)b * AH(stats_bstride) + ((long long)ng * nparts_out + bx) * 2;
                 so[0] = mean;
                 so[1] = m2;
             }
@@ -558,18 +608,27 @@ __device__ __forceinline__ void ugemm_body(float* smem) {
 }
 
 template <int NB, int KS, int EPI>
-__global__ __launch_bounds__(64 * KS) void ugemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const float* hw4, int hpack, int hpitch, int hTin, int hbstride,
+                                                        int hbmod_b0, int hT, int hN, int hntiles, int hgate, int hvft, int r1, int r2,
+                                                        const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // `a` only reserves the kernarg layout; the body reads it through arg_view() (see gemm_common.h)
+    // the 16 leading dwords are the preloaded FastHdr; `a` only reserves the kernarg layout for arg_view()
+    const FastHdr hd = {hx, hw4, hpack, hpitch, hTin, hbstride, hbmod_b0, hT, hN, hntiles, hgate, hvft, r1, r2};
+    // XCD-aware block order.  Hardware places block id on XCD id % 8; with the natural order every XCD's L2 ends up
+    // fetching ALL weights and ALL activations of the launch (rocprofv3 FETCH_SIZE: 4x the algorithmic bytes).  Here
+    // each XCD gets a contiguous run of the logical order (n-tile fastest, then batch, then t-tile), i.e. a few whole
+    // token tiles: it still needs every weight tile but only its own slice of X.  Placement affects speed only.
+    const int ny = hntiles / NB, nz = r1 /* batch count */, nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, q = nwg >> 3, r = nwg & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int by = L % ny, bz = (L / ny) % nz, bx = L / (ny * nz);
     if constexpr (EPI == EPI_QKV) {
-        const unsigned* kp = (const unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
-        const int vft = (int)kp[offsetof(GemmCommon, vt_first_tile) / 4];
-        if ((int)blockIdx.y * NB >= vft) {
-            ugemm_body<NB, KS, EPI, true>(smem);
+        if (by * NB >= hvft) {
+            ugemm_body<NB, KS, EPI, true>(hd, smem, bx, by, bz);
             return;
         }
     }
-    ugemm_body<NB, KS, EPI, false>(smem);
+    ugemm_body<NB, KS, EPI, false>(hd, smem, bx, by, bz);
 }
 
 template <int NB, int EPI>
@@ -589,8 +648,12 @@ static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s) {
     static const int min_lds = getenv("SAID_MIN_LDS") ? atoi(getenv("SAID_MIN_LDS")) : 0;   // experiment: force one workgroup per CU
     if (smem < min_lds) smem = min_lds;
     if (smem > kMaxLds) { fprintf(stderr, "said: ugemm needs %d B of LDS\n", smem); abort(); }
-    dim3 grid((a.T + 31) / 32, a.ntiles_per_group / NB, batch);
-    hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI>), grid, dim3(64 * KS), smem, s, a);
+    dim3 grid(((a.T + 31) / 32) * (a.ntiles_per_group / NB) * batch);   // 1-D: decoded XCD-aware in the kernel
+    const Seg& s0 = a.seg[0];
+    const int pack = s0.C | (s0.taps << 16) | (s0.xform << 20) | (a.nseg << 24);
+    const int bmod_b0 = (s0.b_mod & 0xffff) | (a.b0 << 16);
+    hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI>), grid, dim3(64 * KS), smem, s, s0.x, s0.w4, pack, s0.x_pitch, s0.Tin, (int)s0.x_bstride,
+                       bmod_b0, a.T, a.N, a.ntiles_per_group, a.geglu_gate_tiles, a.vt_first_tile, batch, 0, a);
 }
 template <int NB, int KS, int EPI>
 static void uconfigure_one() {
@@ -619,6 +682,7 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS) {
     SAID_UGEMM_CONFIGS(X)
 #undef X
     if (!cfg || a.groups != 1 || a.ntiles_per_group % NB) return false;
+    if (a.seg[0].x_bstride > 0x7fffffffLL || a.b0 > 0x7fff || a.seg[0].b_mod > 0xffff || a.seg[0].C > 0xffff) return false;
     for (int s = 0; s < a.nseg; ++s) {
         const Seg& sg = a.seg[s];
         if (!sg.w4 || sg.stride != 1 || !(sg.taps == 1 || sg.taps == 3) || sg.pad != (sg.taps - 1) / 2) return false;
