@@ -41,6 +41,7 @@ struct PW {  // packed GEMM weight (up to 2 K-segments) + bias
     float* w4[2] = {nullptr, nullptr};   // dwordx4 packing for the LDS-staged kernel
     float* bias = nullptr;
     int N = 0, C[2] = {0, 0}, taps = 1, nseg = 1;
+    bool gn_tail = false;                // w4[s] is followed by the GroupNorm gamma[C] and beta[C] of its source segment
 };
 struct ResW { float *g1, *b1, *g2, *b2; PW conv1, conv2, skip; int cin; bool has_skip; float* bias2; };
 struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj; };
@@ -213,7 +214,10 @@ std::vector<int> rows_dense(int N, int row0 = 0) {
 }
 
 // Linear/conv weight `name` (N, Ctot[, taps]) -> PW with the K range split into `nseg` equal segments.
-int make_pw(said_ctx* ctx, PW* pw, const std::string& wname, const std::string& bname, int N, int Ctot, int taps, int nseg = 1) {
+// gn_gamma/gn_beta (optional): affine of the GroupNorm applied to this GEMM's source; appended to each segment's w4
+// block so that the LDS-staged kernel can locate them from its preloaded header alone (gemm_lds.hip, FastHdr).
+int make_pw(said_ctx* ctx, PW* pw, const std::string& wname, const std::string& bname, int N, int Ctot, int taps, int nseg = 1,
+            const std::string& gn_gamma = "", const std::string& gn_beta = "") {
     const HostTensor* t = taps > 0 && ctx->host_w.count(wname) && ctx->host_w[wname].shape.size() == 3
                               ? getw(ctx, wname, {N, Ctot, taps})
                               : getw(ctx, wname, {N, Ctot});
@@ -228,6 +232,14 @@ int make_pw(said_ctx* ctx, PW* pw, const std::string& wname, const std::string& 
         if (upload(ctx, &pw->w[s], packed.data(), packed.size())) return -1;
         if (C % 8 == 0 && (tp == 1 || tp == 3)) {
             auto p4 = pack_rows4(t->data.data(), Ctot, tp, rows, (N + 31) / 32, s * C, C);
+            if (!gn_gamma.empty()) {
+                const HostTensor* gg = getw(ctx, gn_gamma, {Ctot});
+                const HostTensor* gb = getw(ctx, gn_beta, {Ctot});
+                if (!gg || !gb) return -1;
+                p4.insert(p4.end(), gg->data.begin() + s * C, gg->data.begin() + (s + 1) * C);
+                p4.insert(p4.end(), gb->data.begin() + s * C, gb->data.begin() + (s + 1) * C);
+                pw->gn_tail = true;
+            }
             if (upload(ctx, &pw->w4[s], p4.data(), p4.size())) return -1;
         }
     }
@@ -254,7 +266,7 @@ Seg mkseg(const float* x, long long bstride, int pitch, int C, int taps, int pad
     s.Tin = Tin; s.xform = xform; s.gn_cpg = 1; s.gn_nparts = 1;
     return s;
 }
-inline Seg with_w4(Seg s, const float* w4) { s.w4 = w4; return s; }
+inline Seg with_w4(Seg s, const float* w4, bool gn_tail = false) { s.w4 = w4; s.w4_gn_tail = gn_tail ? 1 : 0; return s; }
 void seg_gn(Seg& s, const float* part, long long part_bstride, int cpg, int nparts, float eps, const float* g, const float* b) {
     s.gn_part = part; s.gn_part_bstride = part_bstride; s.gn_cpg = cpg; s.gn_nparts = nparts; s.gn_eps = eps; s.gn_gamma = g; s.gn_beta = b;
 }
@@ -328,10 +340,10 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
     {   // in_layers: GN -> SiLU -> conv3 ; + emb_layers(emb)   (openaimodel.py:205-225)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = in1 ? 2 : 1;
-        a.seg[0] = with_w4(mkseg(in0.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[0]), rw.conv1.w4[0]);
+        a.seg[0] = with_w4(mkseg(in0.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[0]), rw.conv1.w4[0], rw.conv1.gn_tail);
         seg_gn(a.seg[0], in0.st, g.sts, cpg, g.np, 1e-5f, rw.g1, rw.b1);
         if (in1) {
-            a.seg[1] = with_w4(mkseg(in1->p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[1]), rw.conv1.w4[1]);
+            a.seg[1] = with_w4(mkseg(in1->p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[1]), rw.conv1.w4[1], rw.conv1.gn_tail);
             seg_gn(a.seg[1], in1->st, g.sts, cpg, g.np, 1e-5f, rw.g1 + MC, rw.b1 + MC);
         }
         a.bias = rw.conv1.bias;
@@ -344,7 +356,7 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
     {   // out_layers: GN -> SiLU -> conv3 ; + skip(x)   (openaimodel.py:226-227)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->M.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv2.w[0]), rw.conv2.w4[0]);
+        a.seg[0] = with_w4(mkseg(c->M.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv2.w[0]), rw.conv2.w4[0], rw.conv2.gn_tail);
         seg_gn(a.seg[0], c->M.st, g.sts, 6, g.np, 1e-5f, rw.g2, rw.b2);
         if (rw.has_skip) {  // 1x1 conv over the concatenated input folded in as two extra K segments
             a.seg[1] = with_w4(mkseg(in0.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, rw.skip.w[0]), rw.skip.w4[0]);
@@ -369,12 +381,15 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // x = norm(x) (GroupNorm eps 1e-6); q,k,v = to_{q,k,v}(norm1(x))   (attention.py:227, 168, 93-97)
         GemmArgs a = mkargs(g.T, 3 * MC);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(in.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_GN_LN, sw.qkv.w[0]), sw.qkv.w4[0]);
+        a.seg[0] = with_w4(mkseg(in.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_GN_LN, sw.qkv.w[0]), sw.qkv.w4[0], sw.qkv.gn_tail);
         seg_gn(a.seg[0], in.st, g.sts, 6, g.np, 1e-6f, sw.gn_g, sw.gn_b);
         a.seg[0].ln_gamma = sw.l1g; a.seg[0].ln_beta = sw.l1b; a.seg[0].ln_eps = 1e-5f;
         a.y = c->QK; a.y_bstride = 2LL * MC * g.Tp; a.y_pitch = g.Tp;
         a.vt = c->VT; a.vt_first_tile = 12; a.vt_heads = HEADS; a.vt_dim = HD; a.vt_rows = vt_rows;
-        static const int qkv_nb = getenv("SAID_QKV_NB") ? atoi(getenv("SAID_QKV_NB")) : 1;
+        // tiles per workgroup: the largest shape that still gives every CU a workgroup in ONE round (at Be=2, T=600:
+        // NB=3 -> 228 workgroups, 27.5 -> 13.8 us per launch against NB=1's 684 workgroups in 2.7 rounds)
+        static const int qkv_env = getenv("SAID_QKV_NB") ? atoi(getenv("SAID_QKV_NB")) : 0;
+        const int qkv_nb = qkv_env ? qkv_env : (tt * 6 >= 192 ? 3 : (tt * 9 >= 192 ? 2 : 1));
         const LaunchCfg lc = big ? LaunchCfg{6, 4} : LaunchCfg{qkv_nb, 8};
         do_gemm(c, a, EPI_QKV, g.Be, lc.NB, lc.KS, s);
     }
@@ -429,7 +444,8 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.seg[0].ln_gamma = sw.l3g; a.seg[0].ln_beta = sw.l3b; a.seg[0].ln_eps = 1e-5f;
         a.bias = sw.ff1.bias; a.geglu_gate_tiles = FFI / 32;
         a.y = c->F; a.y_bstride = (long long)FFI * g.Tp; a.y_pitch = g.Tp;
-        static const int geglu_nb = getenv("SAID_GEGLU_NB") ? atoi(getenv("SAID_GEGLU_NB")) : 2;   // measured: 671 -> 637 us per step at Be=2
+        static const int geglu_env = getenv("SAID_GEGLU_NB") ? atoi(getenv("SAID_GEGLU_NB")) : 0;
+        const int geglu_nb = geglu_env ? geglu_env : (tt * 6 >= 192 ? 4 : (tt * 12 >= 192 ? 2 : 1));   // one round of workgroups, as for qkv
         do_gemm(c, a, EPI_GEGLU, g.Be, big ? 3 : geglu_nb, big ? 4 : 8, s);
     }
     {   // x3 = net.2(h) + x2
@@ -482,7 +498,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
     {   // out: GN -> SiLU -> Conv1d(192 -> 32, k3)
         GemmArgs a = mkargs(g.T, c->cin);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->P.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, c->conv_out.w[0]), c->conv_out.w4[0]);
+        a.seg[0] = with_w4(mkseg(c->P.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, c->conv_out.w[0]), c->conv_out.w4[0], c->conv_out.gn_tail);
         seg_gn(a.seg[0], c->P.st, g.sts, 6, g.np, 1e-5f, c->out_g, c->out_b);
         a.bias = c->conv_out.bias;
         a.y = c->eps_cm; a.y_bstride = (long long)c->cin * g.Tp; a.y_pitch = g.Tp;
@@ -689,7 +705,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
     if (make_pw(ctx, &ctx->te1, D + "time_embed.0.weight", D + "time_embed.0.bias", TE, MC, 0)) return -1;
     if (make_pw(ctx, &ctx->te2, D + "time_embed.2.weight", D + "time_embed.2.bias", TE, TE, 0)) return -1;
     if (make_pw(ctx, &ctx->conv_in, D + "input_blocks.0.0.weight", D + "input_blocks.0.0.bias", MC, ctx->cin, 3)) return -1;
-    if (make_pw(ctx, &ctx->conv_out, D + "out.2.weight", D + "out.2.bias", ctx->cin, MC, 3)) return -1;
+    if (make_pw(ctx, &ctx->conv_out, D + "out.2.weight", D + "out.2.bias", ctx->cin, MC, 3, 1, D + "out.0.weight", D + "out.0.bias")) return -1;
     if (upvec(ctx, &ctx->out_g, D + "out.0.weight", MC) || upvec(ctx, &ctx->out_b, D + "out.0.bias", MC)) return -1;
     used += 8;
     const char* res_names[NRES] = {"input_blocks.1.0", "middle_block.0", "middle_block.2", "output_blocks.0.0", "output_blocks.1.0"};
@@ -701,9 +717,9 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
         rw.cin = r >= 3 ? 2 * MC : MC;
         rw.has_skip = r >= 3;
         if (upvec(ctx, &rw.g1, p + ".in_layers.0.weight", rw.cin) || upvec(ctx, &rw.b1, p + ".in_layers.0.bias", rw.cin)) return -1;
-        if (make_pw(ctx, &rw.conv1, p + ".in_layers.2.weight", p + ".in_layers.2.bias", MC, rw.cin, 3, rw.has_skip ? 2 : 1)) return -1;
+        if (make_pw(ctx, &rw.conv1, p + ".in_layers.2.weight", p + ".in_layers.2.bias", MC, rw.cin, 3, rw.has_skip ? 2 : 1, p + ".in_layers.0.weight", p + ".in_layers.0.bias")) return -1;
         if (upvec(ctx, &rw.g2, p + ".out_layers.0.weight", MC) || upvec(ctx, &rw.b2, p + ".out_layers.0.bias", MC)) return -1;
-        if (make_pw(ctx, &rw.conv2, p + ".out_layers.3.weight", p + ".out_layers.3.bias", MC, MC, 3)) return -1;
+        if (make_pw(ctx, &rw.conv2, p + ".out_layers.3.weight", p + ".out_layers.3.bias", MC, MC, 3, 1, p + ".out_layers.0.weight", p + ".out_layers.0.bias")) return -1;
         const HostTensor* ew = getw(ctx, p + ".emb_layers.1.weight", {MC, TE});
         const HostTensor* eb = getw(ctx, p + ".emb_layers.1.bias", {MC});
         if (!ew || !eb) return -1;
@@ -743,7 +759,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
         qkv.insert(qkv.end(), wk->data.begin(), wk->data.end());
         qkv.insert(qkv.end(), wv->data.begin(), wv->data.end());
         ctx->host_w["__qkv"] = HostTensor{qkv, {3 * MC, MC}};
-        if (make_pw(ctx, &sw.qkv, "__qkv", "", 3 * MC, MC, 0)) return -1;
+        if (make_pw(ctx, &sw.qkv, "__qkv", "", 3 * MC, MC, 0, 1, p + ".norm.weight", p + ".norm.bias")) return -1;
         if (make_pw(ctx, &sw.out1, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", MC, MC, 0)) return -1;
         if (make_pw(ctx, &sw.q2, b + ".attn2.to_q.weight", "", MC, MC, 0)) return -1;
         const HostTensor* k2 = getw(ctx, b + ".attn2.to_k.weight", {MC, CD});

@@ -18,6 +18,7 @@
 // KS waves splitting K by input channel, fixed-order LDS reduction, fused epilogues.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "gemm_common.h"
 
@@ -38,12 +39,18 @@ __device__ __forceinline__ float xf1(float v, float2 gn, float mu, float rs, flo
 // the command processor delivers them in SGPRs, so the first operand loads need no memory round trip at all.
 struct FastHdr {
     const float* x;    // segment 0 source (batch 0)
-    const float* w4;   // segment 0 packed weights
-    int pack;          // C | taps << 16 | xform << 20 | nseg << 24
-    int pitch, Tin, bstride;   // segment 0 pitch, valid length, batch stride (floats)
+    const float* w4;   // segment 0 packed weights (+ GroupNorm gamma/beta tail)
+    int pack;          // C | taps << 16 | xform << 20 | nseg << 24 | (gn_eps == 1e-6) << 26
+    int pitch, T, bstride;   // segment 0 pitch, length (stride-1 conv: Tin == T), batch stride (floats)
     int bmod_b0;       // b_mod | b0 << 16
-    int T, N, ntiles, gate_tiles;
-    int r0, r1, r2;
+    int N;
+    int gate_vft;      // EPI_GEGLU: gate tile offset; EPI_QKV: first token-major tile
+    int nbatch;        // samples in this launch (the grid is 1-D)
+    // GroupNorm statistics of segment 0: with these the partial loads — the head of the longest dependent chain of
+    // a GroupNorm'ed GEMM — go out at kernel entry instead of one memory round trip later
+    const float* gn_part;
+    int gn_bstride;    // floats between batches of the partials
+    int gn_cfg;        // gn_cpg | gn_nparts << 16
 };
 static_assert(sizeof(FastHdr) == 64, "FastHdr must be exactly 16 dwords");
 
@@ -57,24 +64,37 @@ struct UBlock {   // one (segment, channel block) of this wave
     const float2* cLN;
 };
 
-template <int NB, int KS, int EPI, bool TRANS>
+// VAR (compile-time launch variant): which conditional load groups exist.  Every vector-memory request of the request
+// phase is then UNCONDITIONAL code (lanes/groups that do not apply use an out-of-range offset and get 0 back), so the
+// compiler can count outstanding loads exactly.  With loads inside run-time branches it falls back to
+// s_waitcnt vmcnt(0) and e.g. the GroupNorm coefficients wait for the epilogue operands requested after them: one
+// extra memory round trip on the critical path (measured 21.7k -> see profiles/ for the phase clocks).
+enum UVar : int { UV_T3 = 1 /* segment 0 is a 3-tap conv */, UV_GN0 = 2 /* GroupNorm'ed segment 0 */,
+                  UV_GN1 = 4 /* GroupNorm'ed segment 1 (concatenated skip) */, UV_RGN = 8 /* GroupNorm'ed residual */ };
+
+template <int NB, int KS, int EPI, int VAR, bool TRANS>
 __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int bx, int by, int bz) {
     constexpr int NACC = (EPI == EPI_GEGLU) ? 2 * NB : NB;
     constexpr int NV = NB * 16;
     static_assert(NV % KS == 0, "NB*16 must be divisible by KS");
     constexpr int VPW = NV / KS;
     constexpr bool EPRE = (VPW <= 4) && (EPI == EPI_STORE || EPI == EPI_QKV) && !TRANS;
-    constexpr int TMAX = (EPI == EPI_STORE) ? 3 : 1;   // only plain convolutions have 3 taps
+    constexpr bool T3 = (VAR & UV_T3) != 0, GN0 = (VAR & UV_GN0) != 0, GN1 = (VAR & UV_GN1) != 0, RGN = (VAR & UV_RGN) != 0;
+    constexpr bool HAS_LN = (EPI != EPI_STORE);   // q/k/v, GEGLU and band projections read LayerNorm'ed input
+    static_assert(EPI == EPI_STORE || (VAR & ~UV_GN0) == 0, "variants other than GN0 exist only for EPI_STORE");
+    static_assert(EPI != EPI_QKV || GN0, "q/k/v reads GroupNorm -> LayerNorm input");
+    constexpr int TMAX = T3 ? 3 : 1;
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = bz + (hd.bmod_b0 >> 16);
     const int t0 = bx * 32;
     const int tile0 = by * NB;
     const int nseg = (hd.pack >> 24) & 3, aT = hd.T, aN = hd.N;
-    const int gate_tiles = hd.gate_tiles;
-    const int w_tiles = (EPI == EPI_GEGLU) ? hd.ntiles + gate_tiles : hd.ntiles;
+    const int gate_tiles = (EPI == EPI_GEGLU) ? hd.gate_vft : 0;
+    const int ntiles = (aN + 31) >> 5;
+    const int w_tiles = (EPI == EPI_GEGLU) ? ntiles + gate_tiles : ntiles;
     const int sr = l >> 3, sq = l & 7;   // staging map: row-in-round, token quad
-    const int C0 = hd.pack & 0xffff, taps0 = (hd.pack >> 16) & 15, xf0 = (hd.pack >> 20) & 15;
+    const int C0 = hd.pack & 0xffff, taps0 = T3 ? 3 : 1, xf0 = (hd.pack >> 20) & 15;
 
     const int epi_sz = epi_scratch_floats<NACC>(EPI, KS);
     float* epiS = smem;
@@ -96,63 +116,92 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         u0.rw = make_rsrc(hd.w4, (unsigned)w_tiles * (unsigned)taps0 * (unsigned)(C0 >> 3) * 1024u);
         u0.c0 = w * cw;
         u0.nr = cb >> 3;
-        u0.taps = taps0; u0.Tin = hd.Tin; u0.pitch4 = hd.pitch * 4; u0.C8 = C0 >> 3; u0.xform = xf0;
+        u0.taps = taps0; u0.Tin = hd.T; u0.pitch4 = hd.pitch * 4; u0.C8 = C0 >> 3; u0.xform = xf0;
         u0.cGN = reinterpret_cast<const float2*>(mainS);
-        u0.cLN = reinterpret_cast<const float2*>(mainS + ((xf0 == XF_GN_LN) ? 2 * C0 : 0));
+        u0.cLN = reinterpret_cast<const float2*>(mainS + (GN0 ? 2 * C0 : 0));
     }
 
-    // raw X slice of a block -> registers: NR dwordx4 (row sr of each round, tokens t0+4*sq..+3) + halo dwords
-    auto issue_x = [&](const UBlock& u, f32x4 (&xv)[NRMAX], float& halo) {
+    // raw X slice of a block -> registers: NR dwordx4 (row sr of each round, tokens t0+4*sq..+3) + halo dwords.
+    // `valid` = false turns every request into an out-of-range one (software-pipeline tail).
+    auto issue_x = [&](const UBlock& u, f32x4 (&xv)[NRMAX], float& halo, bool valid) {
 #pragma unroll
         for (int rr = 0; rr < NRMAX; ++rr) {
-            const bool on = rr < u.nr;
-            xv[rr] = bload4(u.rx, on ? (sr * u.pitch4 + (t0 + 4 * sq) * 4) : (int)0x80000000, (u.c0 + rr * 8) * u.pitch4);
+            const int oor = (valid && rr < u.nr) ? 0 : (int)0x80000000;   // scalar select, no branch
+            xv[rr] = bload4(u.rx, (sr * u.pitch4 + (t0 + 4 * sq) * 4) | oor, (u.c0 + rr * 8) * u.pitch4);
         }
         halo = 0.f;
-        if (u.taps == 3) {   // lane -> (row = l >> 1, side = l & 1): token t0-1 or t0+32
+        if constexpr (T3) {   // lane -> (row = l >> 1, side = l & 1): token t0-1 or t0+32
             const int row = l >> 1, tin = (l & 1) ? (t0 + 32) : (t0 - 1);
-            const bool ok = (row < u.nr * 8) && ((unsigned)tin < (unsigned)u.Tin);
+            const bool ok = valid && (u.taps == 3) && (row < u.nr * 8) && ((unsigned)tin < (unsigned)u.Tin);
             halo = bload(u.rx, ok ? (row * u.pitch4 + tin * 4) : (int)0x80000000, u.c0 * u.pitch4);
         }
     };
-    auto issue_w = [&](const UBlock& u, f32x4 (&wv)[TMAX][NRMAX][NACC]) {
+    // With 8 accumulator tiles the weight fragments of a whole block (3 rounds x 8 tiles x 4 registers) no longer fit
+    // beside the accumulators: ROLL keeps two rounds in flight and requests round 2 into round 0's registers once
+    // round 0 has been multiplied (it lands during round 1's 32 MFMAs).
+    constexpr bool ROLL = (NACC >= 8);
+    static_assert(!ROLL || TMAX == 1, "rolling weight rounds are for 1-tap GEMMs");
+    constexpr int WR = ROLL ? 2 : NRMAX;
+    auto issue_w_round = [&](const UBlock& u, int rr, f32x4 (&wr)[NACC], bool valid) {
 #pragma unroll
-        for (int tap = 0; tap < TMAX; ++tap)
+        for (int i = 0; i < NACC; ++i) {
+            const int oor = (valid && rr < u.nr) ? 0 : (int)0x80000000;
+            const int so = (tile_wo[i] * u.C8 + (u.c0 >> 3) + rr) * 1024;
+            wr[i] = bload4(u.rw, (l * 16) | oor, so);   // the range check covers voffset only: soffset is don't-care when masked
+        }
+    };
+    auto issue_w = [&](const UBlock& u, f32x4 (&wv)[TMAX][WR][NACC], bool valid) {
+        if constexpr (ROLL) {
+            issue_w_round(u, 0, wv[0][0], valid);
+            issue_w_round(u, 1, wv[0][1], valid);
+        } else {
 #pragma unroll
-            for (int rr = 0; rr < NRMAX; ++rr)
+            for (int tap = 0; tap < TMAX; ++tap)
 #pragma unroll
-                for (int i = 0; i < NACC; ++i) {
-                    const bool on = (tap < u.taps) && (rr < u.nr);
-                    const int so = ((tile_wo[i] * u.taps + tap) * u.C8 + (u.c0 >> 3) + rr) * 1024;
-                    wv[tap][rr][i] = bload4(u.rw, on ? l * 16 : (int)0x80000000, on ? so : 0);
-                }
+                for (int rr = 0; rr < NRMAX; ++rr)
+#pragma unroll
+                    for (int i = 0; i < NACC; ++i) {
+                        const int oor = (valid && (tap < u.taps) && (rr < u.nr)) ? 0 : (int)0x80000000;
+                        const int so = ((tile_wo[i] * u.taps + tap) * u.C8 + (u.c0 >> 3) + rr) * 1024;
+                        wv[tap][rr][i] = bload4(u.rw, (l * 16) | oor, so);
+                    }
+        }
     };
 
     // ================= phase 0: requests =================
-    f32x4 xv[NRMAX], wv[TMAX][NRMAX][NACC];
+    f32x4 xv[NRMAX], wv[TMAX][WR][NACC];
     float halo;
-    // request order matters: vector loads return in order, so the argument block goes first (GroupNorm partial loads
-    // wait on it), then the operands, which need only the preloaded header
+    // request order matters (vector loads return in order): the statistics partials of a GroupNorm'ed segment 0 head the
+    // longest chain (partials -> coefficients -> staging) and need only the header; then the rest of the argument
+    // block, the operands, and last the weights, which are not needed before the MFMA loop
+    GnLoads gl0, gl1, glr;
+    rsrc_t grp_rsrc0 = u0.rx, grp_rsrc1 = u0.rx, grp_rsrcr = u0.rx;
+    GnP gp0 = {1, 1, hd.T, 1e-5f, nullptr, nullptr};
+    if constexpr (GN0) {
+        const float* gb = hd.w4 + (long long)w_tiles * taps0 * (C0 >> 3) * 256;   // gamma[C0], beta[C0] behind the weights
+        gp0 = {hd.gn_cfg & 0xffff, hd.gn_cfg >> 16, hd.T, ((hd.pack >> 26) & 1) ? 1e-6f : 1e-5f, gb, gb + C0};
+        const int bmod = hd.bmod_b0 & 0xffff;
+        const int sb = bmod > 0 ? b % bmod : b;
+        grp_rsrc0 = make_rsrc(hd.gn_part + (long long)sb * hd.gn_bstride, (unsigned)C0 * (unsigned)gp0.gn_nparts * 8u);
+        gn_issue(gp0, grp_rsrc0, w * (C0 / KS), C0 / KS, l, gl0);
+    }
     const ArgView V = arg_view(l, 16);   // the rest of the argument block: 4 coalesced loads, fields via v_readlane
-    issue_x(u0, xv, halo);
-    const bool has_ln = (xf0 == XF_LN || xf0 == XF_GN_LN);
+    issue_x(u0, xv, halo, true);
     f32x4 lnref = {0.f, 0.f, 0.f, 0.f};
-    if (has_ln) lnref = bload4(u0.rx, (t0 + 4 * sq) * 4, 0);   // raw channel 0 of this lane's 4 tokens: common shift
-    // Weights are not needed before the MFMA loop.  If segment 0 is GroupNorm'ed, its statistics partials are the
-    // head of the critical chain (partials -> coefficients -> staging), so they must be requested BEFORE the weights
-    // (loads return in order) — but they need the argument block; otherwise the weights go out right away.
-    const bool gn0 = (xf0 == XF_GN_SILU || xf0 == XF_GN_LN);
-    if (!gn0) issue_w(u0, wv);
+    if constexpr (HAS_LN) lnref = bload4(u0.rx, (t0 + 4 * sq) * 4, 0);   // raw channel 0 of this lane's 4 tokens: common shift
+    issue_w(u0, wv, true);
     long long* const clkp = AH(clk);
     clk_stamp_p(clkp, w, l, 0);
     auto SV = [&](int s) -> unsigned { return s == 0 ? V.s0 : (s == 1 ? V.s1 : V.s2); };
-    int coef_off[3];
-    int coef_total = 0;
-    for (int s = 0; s < nseg; ++s) {
-        coef_off[s] = coef_total;
+    auto seg_coefs = [&](int s) {
         const int xf = AS(SV(s), xform), sc = AS(SV(s), C);
-        coef_total += ((xf == XF_GN_SILU || xf == XF_GN_LN) ? 2 * sc : 0) + ((xf == XF_LN || xf == XF_GN_LN) ? 2 * sc : 0);
-    }
+        return ((xf == XF_GN_SILU || xf == XF_GN_LN) ? 2 * sc : 0) + ((xf == XF_LN || xf == XF_GN_LN) ? 2 * sc : 0);
+    };
+    const int coef_off0 = 0;
+    const int coef_off1 = seg_coefs(0);
+    const int coef_off2 = coef_off1 + (nseg > 1 ? seg_coefs(1) : 0);
+    const int coef_total = coef_off2 + (nseg > 2 ? seg_coefs(2) : 0);
+    auto coef_off = [&](int s) { return s == 0 ? coef_off0 : (s == 1 ? coef_off1 : coef_off2); };
     float* lnred = mainS + coef_total;                      // [KS][32][2]
     float* xt = lnred + KS * 64 + w * (8 * NRMAX * XP);    // this wave's X tile [CB][XP]
     auto make_block = [&](int s, int blk) {
@@ -167,8 +216,8 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         u.c0 = w * cw + blk * cb;
         u.nr = cb >> 3;
         u.taps = taps; u.Tin = AS(sv, Tin); u.pitch4 = pitch * 4; u.C8 = sC >> 3; u.xform = AS(sv, xform);
-        u.cGN = reinterpret_cast<const float2*>(mainS + coef_off[s]);
-        u.cLN = reinterpret_cast<const float2*>(mainS + coef_off[s] + ((u.xform == XF_GN_LN) ? 2 * sC : 0));
+        u.cGN = reinterpret_cast<const float2*>(mainS + coef_off(s));
+        u.cLN = reinterpret_cast<const float2*>(mainS + coef_off(s) + ((u.xform == XF_GN_LN) ? 2 * sC : 0));
         return u;
     };
     auto nblocks = [&](int s) {
@@ -180,32 +229,55 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         GnP p = {AS(sv, gn_cpg), AS(sv, gn_nparts), AS(sv, Tin), AS(sv, gn_eps), AS(sv, gn_gamma), AS(sv, gn_beta)};
         return p;
     };
-    GnLoads gl[2];
-    rsrc_t grp_rsrc[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int xfs = (s < nseg) ? AS(SV(s), xform) : XF_NONE;
-        if (xfs == XF_GN_SILU || xfs == XF_GN_LN) {
-            const unsigned sv = SV(s);
-            const int bmod = AS(sv, b_mod), sC = AS(sv, C);
-            const int sb = bmod > 0 ? b % bmod : b;
-            grp_rsrc[s] = make_rsrc(AS(sv, gn_part) + (long long)sb * AS(sv, gn_part_bstride), (unsigned)sC * (unsigned)AS(sv, gn_nparts) * 8u);
-            gn_issue(seg_gnp(s), grp_rsrc[s], w * (sC / KS), sC / KS, l, gl[s]);
-        }
+    GnP gp1 = gp0, gpr = gp0;
+    int sC1 = 0;
+    if constexpr (GN1) {   // segment 1 (concatenated skip input of a ResBlock): GroupNorm parameters from the argument block
+        const unsigned sv = SV(1);
+        const int bmod = AS(sv, b_mod);
+        sC1 = AS(sv, C);
+        const int sb = bmod > 0 ? b % bmod : b;
+        gp1 = seg_gnp(1);
+        grp_rsrc1 = make_rsrc(AS(sv, gn_part) + (long long)sb * AS(sv, gn_part_bstride), (unsigned)sC1 * (unsigned)gp1.gn_nparts * 8u);
+        gn_issue(gp1, grp_rsrc1, w * (sC1 / KS), sC1 / KS, l, gl1);
     }
-    if (gn0) issue_w(u0, wv);
+    // GroupNorm'ed residual (SpatialTransformer: x_in of attention.py:226 is the un-normalised input, the residual
+    // of attn1 inside the block is norm(x)): wave w finalises group g_first + w of the workgroup's channel range
+    int rg_first = 0, rg_last = 0, rg_grp = 0;
+    if constexpr (RGN) {
+        const int rcpg = AH(res_gn_cpg), rnp = AH(res_gn_nparts);
+        const float* part = AH(res_gn_part) + (long long)b * AH(res_gn_part_bstride);
+        grp_rsrcr = make_rsrc(part, (unsigned)aN * (unsigned)rnp * 8u);
+        const int c_begin = tile0 * 32, c_end = min(aN, (tile0 + NB) * 32);
+        rg_first = c_begin / rcpg; rg_last = (c_end - 1) / rcpg;   // host guarantees rg_last - rg_first < KS
+        rg_grp = min(rg_first + w, rg_last);
+        gpr = {rcpg, rnp, aT, AH(res_gn_eps), AH(res_gn_gamma), AH(res_gn_beta)};
+        gn_issue(gpr, grp_rsrcr, rg_grp * rcpg, rcpg, l, glr);
+    }
+    float ln_g = 0.f, ln_b = 0.f;
+    if constexpr (HAS_LN) {   // LayerNorm affine of the wave's channel slice (<= 24 channels): lane c
+        const int cw = C0 / KS;
+        const rsrc_t rg = make_rsrc(AS(V.s0, ln_gamma), (unsigned)C0 * 4u), rb = make_rsrc(AS(V.s0, ln_beta), (unsigned)C0 * 4u);
+        const int vo = (l < cw) ? (w * cw + l) * 4 : (int)0x80000000;
+        ln_g = bload(rg, vo, 0);
+        ln_b = bload(rb, vo, 0);
+    }
     float e_bias[EPRE ? VPW : 1], e_emb[EPRE ? VPW : 1], e_res[EPRE ? VPW : 1];
     const float* const e_biasp = AH(bias);
     const int e_act = AH(act);
     const int res_kind = (EPI == EPI_STORE) ? AH(res_kind) : RES_NONE;
+    // null-safe descriptors: a null pointer becomes an empty range, every load from it returns 0
+    const int nbias = (EPI == EPI_GEGLU) ? (gate_tiles * 32 + aN) : aN;
+    const rsrc_t r_bias = make_rsrc(e_biasp, e_biasp ? (unsigned)nbias * 4u : 0u);
     if (EPRE) {
         const float* embp = AH(emb);
         int erow = 0;
         if (embp) { const int* sp = AH(step_ptr); erow = (sp ? *sp : 0) + b * AH(emb_b_stride); }
         const int emb_pitch = AH(emb_pitch);
+        const rsrc_t r_emb = make_rsrc(embp, embp ? (unsigned)aN * (unsigned)emb_pitch * 4u : 0u);
         const float* resp = AH(res);
-        const long long res_bs = AH(res_bstride);
+        const bool has_res = (EPI == EPI_STORE) && res_kind != RES_NONE;
         const int res_pitch = AH(res_pitch);
+        const rsrc_t r_res = make_rsrc(resp + (has_res ? (long long)b * AH(res_bstride) : 0LL), has_res ? (unsigned)aN * (unsigned)res_pitch * 4u : 0u);
 #pragma unroll
         for (int j = 0; j < VPW; ++j) {
             const int v = w + j * KS;
@@ -213,59 +285,48 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             const int nl = (tile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int t = t0 + lt;
             const bool nok = nl < aN;
-            const int ng = nok ? nl : 0;
-            e_bias[j] = (e_biasp && nok) ? e_biasp[ng] : 0.f;
-            e_emb[j] = (embp && nok) ? embp[(long long)ng * emb_pitch + erow] : 0.f;
-            e_res[j] = 0.f;
-            if (EPI == EPI_STORE && res_kind != RES_NONE && nok && t < aT)
-                e_res[j] = resp[(long long)b * res_bs + (long long)ng * res_pitch + t];
+            e_bias[j] = bload(r_bias, nok ? nl * 4 : (int)0x80000000, 0);
+            e_emb[j] = bload(r_emb, nok ? (nl * emb_pitch + erow) * 4 : (int)0x80000000, 0);
+            e_res[j] = bload(r_res, (nok && t < aT) ? (nl * res_pitch + t) * 4 : (int)0x80000000, 0);
         }
     }
+    // GEGLU: the value and gate biases of the workgroup's tiles go through LDS (one load per thread, requested here)
+    float geglu_bias = 0.f;
+    if constexpr (EPI == EPI_GEGLU) {
+        const int half = tid / (32 * NB), k = tid % (32 * NB);
+        const int nl = tile0 * 32 + k;
+        geglu_bias = bload(r_bias, (tid < 64 * NB && nl < aN) ? (nl + half * gate_tiles * 32) * 4 : (int)0x80000000, 0);
+    }
     int band_lo = 0, band_hi = 0;
-    if (EPI == EPI_BAND) {
+    if constexpr (EPI == EPI_BAND) {
         const int t = t0 + (tid & 31);
-        if (t < aT) { band_lo = AB(lo)[t]; band_hi = AB(hi)[t]; }
+        const rsrc_t rlo = make_rsrc(AB(lo), (unsigned)aT * 4u), rhi = make_rsrc(AB(hi), (unsigned)aT * 4u);
+        band_lo = __builtin_bit_cast(int, bload(rlo, t * 4, 0));
+        band_hi = __builtin_bit_cast(int, bload(rhi, t * 4, 0));
     }
     clk_stamp_p(clkp, w, l, 1);
 
     // ================= phase 1: GroupNorm coefficients of the wave's own slice; LN affine =================
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int xfs = (s < nseg) ? AS(SV(s), xform) : XF_NONE;
-        if (xfs == XF_GN_SILU || xfs == XF_GN_LN) {
-            const int sC = AS(SV(s), C);
-            gn_finish(seg_gnp(s), grp_rsrc[s], w * (sC / KS), sC / KS, l, gl[s], gnS, mainS + coef_off[s]);
-        }
-    }
-    if (has_ln) {
-        float* cL = mainS + coef_off[0] + ((xf0 == XF_GN_LN) ? 2 * C0 : 0);
-        const float* lg = AS(V.s0, ln_gamma);
-        const float* lb = AS(V.s0, ln_beta);
+    if constexpr (GN0) gn_finish(gp0, grp_rsrc0, w * (C0 / KS), C0 / KS, l, gl0, gnS, mainS + coef_off(0));
+    if constexpr (GN1) gn_finish(gp1, grp_rsrc1, w * (sC1 / KS), sC1 / KS, l, gl1, gnS, mainS + coef_off(1));
+    if constexpr (HAS_LN) {
+        float* cL = mainS + coef_off(0) + (GN0 ? 2 * C0 : 0);
         const int cw = C0 / KS;
-        for (int c = w * cw + l; c < (w + 1) * cw; c += 64) {
-            cL[2 * c] = lg[c];
-            cL[2 * c + 1] = lb[c];
+        if (l < cw) {
+            cL[2 * (w * cw + l)] = ln_g;
+            cL[2 * (w * cw + l) + 1] = ln_b;
         }
     }
-    if (EPI == EPI_STORE && res_kind == RES_GN) {
-        const int rcpg = AH(res_gn_cpg), rnp = AH(res_gn_nparts);
-        const float* part = AH(res_gn_part) + (long long)b * AH(res_gn_part_bstride);
-        const rsrc_t rp = make_rsrc(part, (unsigned)aN * (unsigned)rnp * 8u);
+    if constexpr (RGN) {
+        const int rcpg = gpr.gn_cpg;
         const int c_begin = tile0 * 32, c_end = min(aN, (tile0 + NB) * 32);
-        const int g_first = c_begin / rcpg, g_last = (c_end - 1) / rcpg;
-        const GnP fake = {rcpg, rnp, aT, AH(res_gn_eps), AH(res_gn_gamma), AH(res_gn_beta)};
-        for (int gb = g_first; gb <= g_last; gb += KS) {
-            const int grp = min(gb + w, g_last);
-            GnLoads L;
-            gn_issue(fake, rp, grp * rcpg, rcpg, l, L);
-            float* tmp = gnS + 64 * 3 + 32;
-            gn_finish(fake, rp, grp * rcpg, rcpg, l, L, gnS, tmp - 2 * grp * rcpg);
-            if (gb + w <= g_last && l < rcpg) {
-                const int c = grp * rcpg + l;
-                if (c >= c_begin && c < c_end) {
-                    epiS[c - c_begin] = tmp[2 * l];
-                    epiS[32 * NACC + c - c_begin] = tmp[2 * l + 1];
-                }
+        float* tmp = gnS + 64 * 3 + 32;
+        gn_finish(gpr, grp_rsrcr, rg_grp * rcpg, rcpg, l, glr, gnS, tmp - 2 * rg_grp * rcpg);
+        if (rg_first + w <= rg_last && l < rcpg) {
+            const int c = rg_grp * rcpg + l;
+            if (c >= c_begin && c < c_end) {
+                epiS[c - c_begin] = tmp[2 * l];
+                epiS[32 * NACC + c - c_begin] = tmp[2 * l + 1];
             }
         }
     }
@@ -273,8 +334,8 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 
     // ================= phase 2: LayerNorm statistics from the staged registers =================
     f32x4 mu4 = {0.f, 0.f, 0.f, 0.f}, rs4 = {1.f, 1.f, 1.f, 1.f};
-    if (has_ln) {   // single block (host guarantees C/KS == CB), taps == 1
-        const bool gnx = xf0 == XF_GN_LN;
+    if constexpr (HAS_LN) {   // single block (host guarantees C/KS == CB), taps == 1
+        constexpr bool gnx = GN0;
         const float ln_eps = AS(V.s0, ln_eps);
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -353,43 +414,67 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     clk_stamp_p(clkp, w, l, 4);
 
     // transform the staged registers once and write the wave-private LDS tile
-    auto stage = [&](const UBlock& u, const f32x4 (&xs)[NRMAX], float hl) {
+    // (one copy per transform: a run-time switch per element compiled to a jump table per value)
+    auto stage_t = [&](auto xfc, const UBlock& u, const f32x4 (&xs)[NRMAX], float hl) {
+        constexpr int XF = decltype(xfc)::value;
+        constexpr bool GNX = (XF == XF_GN_SILU || XF == XF_GN_LN), LNX = (XF == XF_LN || XF == XF_GN_LN);
 #pragma unroll
         for (int rr = 0; rr < NRMAX; ++rr) {
             if (rr < u.nr) {
                 const int c = u.c0 + rr * 8 + sr;
                 float2 gn = make_float2(1.f, 0.f), ln = make_float2(1.f, 0.f);
-                if (u.xform == XF_GN_SILU || u.xform == XF_GN_LN) gn = u.cGN[c];
-                if (u.xform == XF_LN || u.xform == XF_GN_LN) ln = u.cLN[c];
+                if constexpr (GNX) gn = u.cGN[c];
+                if constexpr (LNX) ln = u.cLN[c];
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = xs[rr][e];
-                    switch (u.xform) {
-                        case XF_NONE: break;
-                        case XF_GN_SILU: v = xf1<XF_GN_SILU>(v, gn, 0.f, 1.f, ln); break;
-                        case XF_LN: v = xf1<XF_LN>(v, gn, mu4[e], rs4[e], ln); break;
-                        case XF_GN_LN: v = xf1<XF_GN_LN>(v, gn, mu4[e], rs4[e], ln); break;
-                        default: v = xf1<XF_SILU>(v, gn, 0.f, 1.f, ln); break;
-                    }
+                    const float v = xf1<XF>(xs[rr][e], gn, mu4[e], rs4[e], ln);
                     o[e] = (t0 + 4 * sq + e < u.Tin) ? v : 0.f;
                 }
                 *reinterpret_cast<f32x4*>(xt + (rr * 8 + sr) * XP + 4 + 4 * sq) = o;
             }
         }
-        if (u.taps == 3) {
-            const int row = l >> 1, tin = (l & 1) ? (t0 + 32) : (t0 - 1);
-            if (row < u.nr * 8) {
-                float v = hl;
-                if (u.xform == XF_GN_SILU) v = xf1<XF_GN_SILU>(v, u.cGN[u.c0 + row], 0.f, 1.f, make_float2(1.f, 0.f));
-                else if (u.xform == XF_SILU) v = xf1<XF_SILU>(v, make_float2(1.f, 0.f), 0.f, 1.f, make_float2(1.f, 0.f));
-                xt[row * XP + ((l & 1) ? 36 : 3)] = ((unsigned)tin < (unsigned)u.Tin) ? v : 0.f;
+        if constexpr (T3) {
+            if (u.taps == 3) {
+                const int row = l >> 1, tin = (l & 1) ? (t0 + 32) : (t0 - 1);
+                if (row < u.nr * 8) {
+                    float2 gn = make_float2(1.f, 0.f);
+                    if constexpr (GNX) gn = u.cGN[u.c0 + row];
+                    const float v = xf1<XF>(hl, gn, 0.f, 1.f, make_float2(1.f, 0.f));
+                    xt[row * XP + ((l & 1) ? 36 : 3)] = ((unsigned)tin < (unsigned)u.Tin) ? v : 0.f;
+                }
             }
         }
     };
+    auto stage = [&](const UBlock& u, const f32x4 (&xs)[NRMAX], float hl) {
+        if constexpr (EPI == EPI_QKV) {
+            stage_t(std::integral_constant<int, XF_GN_LN>{}, u, xs, hl);
+        } else if constexpr (HAS_LN) {
+            stage_t(std::integral_constant<int, XF_LN>{}, u, xs, hl);
+        } else {
+            if ((GN0 || GN1) && u.xform == XF_GN_SILU) stage_t(std::integral_constant<int, XF_GN_SILU>{}, u, xs, hl);
+            else if (u.xform == XF_SILU) stage_t(std::integral_constant<int, XF_SILU>{}, u, xs, hl);
+            else stage_t(std::integral_constant<int, XF_NONE>{}, u, xs, hl);
+        }
+    };
     // pure ds_read + MFMA loop over the block
-    auto mma_block = [&](const UBlock& u, const f32x4 (&ws)[TMAX][NRMAX][NACC]) {
+    auto mma_block = [&](const UBlock& u, f32x4 (&ws)[TMAX][WR][NACC]) {
         const float* xrow = xt + lh * XP + lt + 3 + ((u.taps == 3) ? 0 : 1);   // col = lt + tap + 4 - pad
+        if constexpr (ROLL) {
+#pragma unroll
+            for (int rr = 0; rr < NRMAX; ++rr) {
+                if (rr < u.nr) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xf = xrow[(rr * 8 + 2 * j) * XP];
+#pragma unroll
+                        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[0][rr & 1][i][j], xf, acc[i], 0, 0, 0);
+                    }
+                    if (rr == 0 && u.nr > 2) issue_w_round(u, 2, ws[0][0], true);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int tap = 0; tap < TMAX; ++tap) {
             if (tap < u.taps) {
@@ -414,51 +499,121 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     };
 
     {
-        // flattened (segment, block) list; with one accumulator tile per wave there are registers to spare, so the
-        // NEXT block's operands are requested before the current block is staged and multiplied (double buffer)
-        int nblk_seg[3] = {0, 0, 0}, nblk_total = 0;
-        for (int s = 0; s < nseg; ++s) { nblk_seg[s] = nblocks(s); nblk_total += nblk_seg[s]; }
+        // flattened (segment, block) list, software-pipelined D blocks deep: the operands of block i + D - 1 are requested
+        // before block i is staged and multiplied.  Requests past the end are issued out of range (they return 0 and
+        // cost an issue slot each) so that the loop body contains no conditional loads.
+        const int nb0 = nblocks(0), nb1 = nseg > 1 ? nblocks(1) : 0, nb2 = nseg > 2 ? nblocks(2) : 0;
+        const int nblk_total = nb0 + nb1 + nb2;
         auto block_at = [&](int i) {
-            int s = 0;
-            while (s < 2 && i >= nblk_seg[s]) { i -= nblk_seg[s]; ++s; }
-            return make_block(s, i);
+            if (i < nb0) return make_block(0, i);
+            if (i < nb0 + nb1) return make_block(1, i - nb0);
+            return make_block(2, i - nb0 - nb1);
         };
-        if constexpr (NACC == 1) {
-            f32x4 xv2[NRMAX], wv2[TMAX][NRMAX][NACC];
-            float halo2 = 0.f;
-            UBlock ua = u0, ub = u0;
-            for (int i = 0; i < nblk_total; i += 2) {
-                const bool has_b = i + 1 < nblk_total;
-                if (has_b) { ub = block_at(i + 1); issue_x(ub, xv2, halo2); issue_w(ub, wv2); }
-                stage(ua, xv, halo);
-                mma_block(ua, wv);
-                if (has_b) {
-                    if (i + 2 < nblk_total) { ua = block_at(i + 2); issue_x(ua, xv, halo); issue_w(ua, wv); }
-                    stage(ub, xv2, halo2);
-                    mma_block(ub, wv2);
-                }
-            }
-        } else {
+        if (ROLL || nblk_total == 1) {   // ROLL: the host guarantees a single block
+            stage(u0, xv, halo);
+            clk_stamp_p(clkp, w, l, 5);
+            mma_block(u0, wv);
+        } else if constexpr (!((NACC == 1) || (TMAX == 1 && NACC <= 3))) {
             for (int i = 0; i < nblk_total; ++i) {
                 const UBlock u = (i == 0) ? u0 : block_at(i);
-                if (i > 0) { issue_x(u, xv, halo); issue_w(u, wv); }
+                if (i > 0) { issue_x(u, xv, halo, true); issue_w(u, wv, true); }
                 stage(u, xv, halo);
+                if (i == 0) clk_stamp_p(clkp, w, l, 5);
                 mma_block(u, wv);
+            }
+        } else {
+            constexpr int D = (TMAX == 1 && NACC == 1) ? 3 : 2;
+            f32x4 xq[D - 1][NRMAX], wq[D - 1][TMAX][WR][NACC];
+            float hq[D - 1];
+            UBlock uq[D - 1];
+            const int last = nblk_total - 1;
+#pragma unroll
+            for (int d = 0; d < D - 2; ++d) {   // prologue (D == 3): block 1
+                uq[d] = block_at(min(d + 1, last));
+                issue_x(uq[d], xq[d], hq[d], d + 1 <= last);
+                issue_w(uq[d], wq[d], d + 1 <= last);
+            }
+            UBlock uc = u0;
+            for (int i = 0; i < nblk_total; ++i) {
+                const int nb = i + D - 1;
+                uq[D - 2] = block_at(min(nb, last));
+                issue_x(uq[D - 2], xq[D - 2], hq[D - 2], nb <= last);
+                issue_w(uq[D - 2], wq[D - 2], nb <= last);
+                stage(uc, xv, halo);
+                if (i == 0) clk_stamp_p(clkp, w, l, 5);
+                mma_block(uc, wv);
+                // rotate the queue (register renaming after unrolling)
+                uc = uq[0];
+#pragma unroll
+                for (int rr = 0; rr < NRMAX; ++rr) xv[rr] = xq[0][rr];
+                halo = hq[0];
+#pragma unroll
+                for (int tap = 0; tap < TMAX; ++tap)
+#pragma unroll
+                    for (int rr = 0; rr < WR; ++rr)
+#pragma unroll
+                        for (int ii = 0; ii < NACC; ++ii) wv[tap][rr][ii] = wq[0][tap][rr][ii];
+#pragma unroll
+                for (int d = 0; d + 1 < D - 1; ++d) {
+                    uq[d] = uq[d + 1];
+                    hq[d] = hq[d + 1];
+#pragma unroll
+                    for (int rr = 0; rr < NRMAX; ++rr) xq[d][rr] = xq[d + 1][rr];
+#pragma unroll
+                    for (int tap = 0; tap < TMAX; ++tap)
+#pragma unroll
+                        for (int rr = 0; rr < WR; ++rr)
+#pragma unroll
+                            for (int ii = 0; ii < NACC; ++ii) wq[d][tap][rr][ii] = wq[d + 1][tap][rr][ii];
+                }
             }
         }
     }
     clk_stamp_p(clkp, w, l, 6);
 
     // ================= phase 4: split-K reduction through LDS (fixed order => deterministic) =================
+    if (EPI == EPI_GEGLU && tid < 64 * NB) epiS[tid] = geglu_bias;
     __syncthreads();
     clk_stamp_p(clkp, w, l, 7);
     float* red = mainS;
+    // RP reduction passes: GEGLU with 4 value + 4 gate tiles would need 256 KB for one pass, so the value tiles and the
+    // gate tiles go through the same buffer one after the other (the summation order per element is unchanged)
+    constexpr int RP = (KS * NACC * 16 * 64 * 4 > 128 * 1024) ? 2 : 1;
+    constexpr int NPP = NACC / RP;   // accumulator tiles per pass
+    static_assert(RP == 1 || (EPI == EPI_GEGLU && NPP == NB), "two-pass reduction is the GEGLU value/gate split");
+    float vsum[VPW], gsum[EPI == EPI_GEGLU ? VPW : 1];
 #pragma unroll
-    for (int i = 0; i < NACC; ++i)
+    for (int ps = 0; ps < RP; ++ps) {
+        if (ps > 0) __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[((w * NACC + i) * 16 + r) * 64 + l] = acc[i][r];
-    __syncthreads();
-    clk_stamp_p(clkp, w, l, 8);
+        for (int i = 0; i < NPP; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((w * NPP + i) * 16 + r) * 64 + l] = acc[ps * NPP + i][r];
+        __syncthreads();
+        if (ps == 0) clk_stamp_p(clkp, w, l, 8);
+#pragma unroll
+        for (int j = 0; j < VPW; ++j) {
+            const int v = w + j * KS;
+            const int i = v >> 4, r = v & 15;
+            if (RP == 1) {
+                float a0 = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < KS; ++w2) a0 += red[((w2 * NPP + i) * 16 + r) * 64 + l];
+                vsum[j] = a0;
+                if (EPI == EPI_GEGLU) {
+                    float g0 = 0.f;
+#pragma unroll
+                    for (int w2 = 0; w2 < KS; ++w2) g0 += red[((w2 * NPP + i + NB) * 16 + r) * 64 + l];
+                    gsum[j] = g0;
+                }
+            } else {
+                float a0 = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < KS; ++w2) a0 += red[((w2 * NPP + i) * 16 + r) * 64 + l];
+                if (ps == 0) vsum[j] = a0; else gsum[EPI == EPI_GEGLU ? j : 0] = a0;
+            }
+        }
+    }
 
     // ================= phase 5: epilogue (same as gemm.hip) =================
     const int nparts_out = (aT + 31) >> 5;
@@ -470,13 +625,8 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     for (int j = 0; j < VPW; ++j) {
         const int v = w + j * KS;
         const int i = v >> 4, r = v & 15;
-        float val = 0.f, gate = 0.f;
-#pragma unroll
-        for (int w2 = 0; w2 < KS; ++w2) val += red[((w2 * NACC + i) * 16 + r) * 64 + l];
-        if (EPI == EPI_GEGLU) {
-#pragma unroll
-            for (int w2 = 0; w2 < KS; ++w2) gate += red[((w2 * NACC + i + NB) * 16 + r) * 64 + l];
-        }
+        float val = vsum[j];
+        const float gate = (EPI == EPI_GEGLU) ? gsum[EPI == EPI_GEGLU ? j : 0] : 0.f;
         const int frow = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int tile = tile0 + i;
 
@@ -497,8 +647,9 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         const int ng = nl;
         if (EPI == EPI_GEGLU) {
             const int ngate = nl + gate_tiles * 32;
-            const float xv_ = val + (e_biasp ? e_biasp[nl] : 0.f);
-            const float gv = gate + (e_biasp ? e_biasp[ngate] : 0.f);
+            (void)ngate;
+            const float xv_ = val + epiS[i * 32 + frow];
+            const float gv = gate + epiS[(NB + i) * 32 + frow];
             if (ok) yp[(long long)b * y_bs + (long long)nl * y_pitch + t] = xv_ * gelu_f(gv);
             continue;
         }
@@ -607,28 +758,28 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     }
 }
 
-template <int NB, int KS, int EPI>
-__global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const float* hw4, int hpack, int hpitch, int hTin, int hbstride,
-                                                        int hbmod_b0, int hT, int hN, int hntiles, int hgate, int hvft, int r1, int r2,
-                                                        const GemmArgs a) {
+template <int NB, int KS, int EPI, int VAR>
+__global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const float* hw4, int hpack, int hpitch, int hT, int hbstride,
+                                                        int hbmod_b0, int hN, int hgate_vft, int hnbatch, const float* hgn_part,
+                                                        int hgn_bstride, int hgn_cfg, const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // the 16 leading dwords are the preloaded FastHdr; `a` only reserves the kernarg layout for arg_view()
-    const FastHdr hd = {hx, hw4, hpack, hpitch, hTin, hbstride, hbmod_b0, hT, hN, hntiles, hgate, hvft, r1, r2};
+    const FastHdr hd = {hx, hw4, hpack, hpitch, hT, hbstride, hbmod_b0, hN, hgate_vft, hnbatch, hgn_part, hgn_bstride, hgn_cfg};
     // XCD-aware block order.  Hardware places block id on XCD id % 8; with the natural order every XCD's L2 ends up
     // fetching ALL weights and ALL activations of the launch (rocprofv3 FETCH_SIZE: 4x the algorithmic bytes).  Here
     // each XCD gets a contiguous run of the logical order (n-tile fastest, then batch, then t-tile), i.e. a few whole
     // token tiles: it still needs every weight tile but only its own slice of X.  Placement affects speed only.
-    const int ny = hntiles / NB, nz = r1 /* batch count */, nwg = gridDim.x;
+    const int ny = ((hN + 31) >> 5) / NB, nz = hnbatch, nwg = gridDim.x;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, q = nwg >> 3, r = nwg & 7;
     const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     const int by = L % ny, bz = (L / ny) % nz, bx = L / (ny * nz);
     if constexpr (EPI == EPI_QKV) {
-        if (by * NB >= hvft) {
-            ugemm_body<NB, KS, EPI, true>(hd, smem, bx, by, bz);
+        if (by * NB >= hgate_vft) {
+            ugemm_body<NB, KS, EPI, VAR, true>(hd, smem, bx, by, bz);
             return;
         }
     }
-    ugemm_body<NB, KS, EPI, false>(hd, smem, bx, by, bz);
+    ugemm_body<NB, KS, EPI, VAR, false>(hd, smem, bx, by, bz);
 }
 
 template <int NB, int EPI>
@@ -637,12 +788,12 @@ static int ugemm_smem_floats(const GemmArgs& a, int KS) {
     int coef = 0;
     for (int s = 0; s < a.nseg; ++s) coef += seg_coef_floats(a.seg[s]);
     const int stage = coef + KS * 64 + KS * 8 * NRMAX * XP;
-    const int red = KS * NACC * 16 * 64;
+    const int red = (KS * NACC * 16 * 64 * 4 > 128 * 1024) ? KS * (NACC / 2) * 16 * 64 : KS * NACC * 16 * 64;
     return epi_scratch_floats<NACC>(EPI, KS) + KS * GN_SCRATCH + (stage > red ? stage : red);
 }
 
 constexpr int kMaxLds = 160 * 1024;
-template <int NB, int KS, int EPI>
+template <int NB, int KS, int EPI, int VAR>
 static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s) {
     int smem = ugemm_smem_floats<NB, EPI>(a, KS) * (int)sizeof(float);
     static const int min_lds = getenv("SAID_MIN_LDS") ? atoi(getenv("SAID_MIN_LDS")) : 0;   // experiment: force one workgroup per CU
@@ -650,39 +801,82 @@ static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s) {
     if (smem > kMaxLds) { fprintf(stderr, "said: ugemm needs %d B of LDS\n", smem); abort(); }
     dim3 grid(((a.T + 31) / 32) * (a.ntiles_per_group / NB) * batch);   // 1-D: decoded XCD-aware in the kernel
     const Seg& s0 = a.seg[0];
-    const int pack = s0.C | (s0.taps << 16) | (s0.xform << 20) | (a.nseg << 24);
+    const bool gn0 = s0.xform == XF_GN_SILU || s0.xform == XF_GN_LN;
+    const int pack = s0.C | (s0.taps << 16) | (s0.xform << 20) | (a.nseg << 24) | ((gn0 && s0.gn_eps == 1e-6f) ? (1 << 26) : 0);
     const int bmod_b0 = (s0.b_mod & 0xffff) | (a.b0 << 16);
-    hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI>), grid, dim3(64 * KS), smem, s, s0.x, s0.w4, pack, s0.x_pitch, s0.Tin, (int)s0.x_bstride,
-                       bmod_b0, a.T, a.N, a.ntiles_per_group, a.geglu_gate_tiles, a.vt_first_tile, batch, 0, a);
+    const int gate_vft = (EPI == EPI_GEGLU) ? a.geglu_gate_tiles : a.vt_first_tile;
+    hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI, VAR>), grid, dim3(64 * KS), smem, s, s0.x, s0.w4, pack, s0.x_pitch, a.T, (int)s0.x_bstride, bmod_b0,
+                       a.N, gate_vft, batch, gn0 ? s0.gn_part : nullptr, (int)s0.gn_part_bstride, s0.gn_cpg | (s0.gn_nparts << 16), a);
 }
-template <int NB, int KS, int EPI>
+template <int NB, int KS, int EPI, int VAR>
 static void uconfigure_one() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ugemm_kernel<NB, KS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ugemm_kernel<NB, KS, EPI, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
 }
 
-// small-batch tile shapes only (<= 2 accumulators per wave keep every weight fragment of a block in
-// registers); large batches use the generic kernel's NB = 3..6 shapes
-#define SAID_UGEMM_CONFIGS(X)               \
-    X(EPI_STORE, 1, 8) X(EPI_STORE, 2, 8)   \
-    X(EPI_QKV, 1, 8) X(EPI_QKV, 2, 8)       \
-    X(EPI_GEGLU, 1, 8) X(EPI_GEGLU, 2, 8)   \
-    X(EPI_BAND, 1, 8)
+// (epilogue, NB, KS, variant): small-batch tile shapes; large batches use the generic kernel's NB = 3..6 shapes
+#ifdef SAID_DEV_ONE_CONFIG   // development aid: compile a single instantiation (resource-usage experiments)
+#define SAID_UGEMM_EXPAND(X, ...) X(__VA_ARGS__)
+#define SAID_UGEMM_CONFIGS(X) SAID_UGEMM_EXPAND(X, SAID_DEV_ONE_CONFIG)
+#else
+#define SAID_UGEMM_CONFIGS(X)                                                                                    \
+    X(EPI_STORE, 1, 8, 0) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_GN1)          \
+    X(EPI_STORE, 1, 8, UV_RGN)                                                                                   \
+    X(EPI_STORE, 2, 8, 0) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_GN1)          \
+    X(EPI_QKV, 1, 8, UV_GN0) X(EPI_QKV, 2, 8, UV_GN0) X(EPI_QKV, 3, 8, UV_GN0)                                   \
+    X(EPI_GEGLU, 1, 8, 0) X(EPI_GEGLU, 2, 8, 0) X(EPI_GEGLU, 4, 8, 0)                                            \
+    X(EPI_BAND, 1, 8, 0)
+#endif
 
 void configure_ugemm_kernels() {
-#define X(E, nb, ks) uconfigure_one<nb, ks, E>();
+#define X(E, nb, ks, var) uconfigure_one<nb, ks, E, var>();
     SAID_UGEMM_CONFIGS(X)
 #undef X
+}
+
+static inline bool is_gn(int xf) { return xf == XF_GN_SILU || xf == XF_GN_LN; }
+static int uvar_of(const GemmArgs& a, int epi) {
+    int v = 0;
+    if (a.seg[0].taps == 3) v |= UV_T3;
+    if (is_gn(a.seg[0].xform)) v |= UV_GN0;
+    if (a.nseg > 1 && is_gn(a.seg[1].xform)) v |= UV_GN1;
+    if (epi == EPI_STORE && a.res_kind == RES_GN) v |= UV_RGN;
+    return v;
 }
 
 // The LDS-staged kernel covers stride-1, k in {1,3}, ungrouped GEMMs whose per-wave channel slice is a
 // multiple of 24 (or 8 / 16); everything else stays on the generic kernel.
 bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS) {
     bool cfg = false;
-#define X(E, nb, ks) cfg = cfg || (epi == E && NB == nb && KS == ks);
+    const int var = uvar_of(a, epi);
+#define X(E, nb, ks, v) cfg = cfg || (epi == E && NB == nb && KS == ks && var == (v));
     SAID_UGEMM_CONFIGS(X)
 #undef X
     if (!cfg || a.groups != 1 || a.ntiles_per_group % NB) return false;
+    {   // what the compile-time variant assumes about the arguments
+        const int xf0 = a.seg[0].xform;
+        if (epi == EPI_QKV && xf0 != XF_GN_LN) return false;
+        if ((epi == EPI_GEGLU || epi == EPI_BAND) && xf0 != XF_LN) return false;
+        if (epi == EPI_STORE && !(xf0 == XF_NONE || xf0 == XF_SILU || xf0 == XF_GN_SILU)) return false;
+        if (a.nseg > 2 && is_gn(a.seg[2].xform)) return false;
+        const int nacc = (epi == EPI_GEGLU) ? 2 * NB : NB;
+        if (nacc >= 8 && !(a.nseg == 1 && a.seg[0].C == 24 * KS)) return false;   // rolling weight rounds: one block only
+        if (epi != EPI_STORE && a.res_kind != RES_NONE) return false;
+        if (!(var & UV_T3))
+            for (int s = 0; s < a.nseg; ++s) if (a.seg[s].taps != 1) return false;
+        if (var & UV_RGN) {   // one residual GroupNorm group per wave
+            const int c_span = NB * 32;
+            if (a.res_gn_cpg <= 0 || (c_span + a.res_gn_cpg - 1) / a.res_gn_cpg + 1 > KS) return false;
+        }
+    }
     if (a.seg[0].x_bstride > 0x7fffffffLL || a.b0 > 0x7fff || a.seg[0].b_mod > 0xffff || a.seg[0].C > 0xffff) return false;
+    if (a.seg[0].Tin != a.T || a.ntiles_per_group != (a.N + 31) / 32) return false;
+    {   // header-only GroupNorm path of segment 0: parameters behind the weights, eps one of two known values
+        const Seg& s0 = a.seg[0];
+        if (s0.xform == XF_GN_SILU || s0.xform == XF_GN_LN) {
+            if (!s0.w4_gn_tail || !(s0.gn_eps == 1e-5f || s0.gn_eps == 1e-6f)) return false;
+            if (s0.gn_part_bstride > 0x7fffffffLL || s0.gn_cpg > 0xffff || s0.gn_nparts > 0x7fff) return false;
+        }
+    }
     for (int s = 0; s < a.nseg; ++s) {
         const Seg& sg = a.seg[s];
         if (!sg.w4 || sg.stride != 1 || !(sg.taps == 1 || sg.taps == 3) || sg.pad != (sg.taps - 1) / 2) return false;
@@ -697,8 +891,9 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS) {
 }
 
 void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s) {
-#define X(E, nb, ks) \
-    if (epi == E && NB == nb && KS == ks) { ulaunch_one<nb, ks, E>(a, batch, s); return; }
+    const int var = uvar_of(a, epi);
+#define X(E, nb, ks, v) \
+    if (epi == E && NB == nb && KS == ks && var == (v)) { ulaunch_one<nb, ks, E, v>(a, batch, s); return; }
     SAID_UGEMM_CONFIGS(X)
 #undef X
     fprintf(stderr, "said: unsupported ugemm config epi=%d NB=%d KS=%d\n", epi, NB, KS);

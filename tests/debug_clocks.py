@@ -16,7 +16,7 @@ eng.unet_forward(x, ts, c)
 eng.debug_clocks(True)
 eng.unet_forward(x, ts, c)
 clk = eng.debug_clocks(False, read=True)
-labels = ["ld-issue", "aux-issue", "gn", "ln", "kv/acc", "main", "bar1", "ldsw+bar2", "epi"]
+labels = ["issue", "gn-fin", "ln-stat", "band-ld", "stage", "mma", "bar1", "ldsw+bar2", "epi"]
 for k in range(44):
     if clk[k, 0, 0] == 0:
         print(k, "(no stamps)"); continue
@@ -25,6 +25,6 @@ for k in range(44):
     d = np.diff(st, axis=1)
     tot = st[:, 9].max() - base
     print(f"launch {k:2d} total {tot:6d} clk | " + " ".join(f"{n}:{int(d[:, i].mean()):5d}" for i, n in enumerate(labels)))
-    if k in (1, 7):
+    if k in (1, 9):
         for w in range(8):
             print("      wave", w, " ".join(f"{int(v - base):6d}" for v in st[w]))
