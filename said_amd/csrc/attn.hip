@@ -1,15 +1,25 @@
-// attn.hip — fp32 self-attention for channel-major activations on gfx950.
+// attn.hip — fp32 self-attention on gfx950.
 //
 // One workgroup = one (batch, head, 32-query tile); its KS waves split the key tiles
 // (flash-decoding style) and merge their online-softmax states through LDS in a fixed order.
 // Everything stays in registers between the two MFMAs:
-//   S^T[j][i] = sum_d K[d][j] Q[d][i]      A = K fragment (coalesced row of K[d][.]), B = Q fragment
-//   O^T[d][i] = sum_j V[j][d] P^T[j][i]    A = V fragment (coalesced row of Vt[j][.]), B = p[r] as-is
+//   S^T[j][i] = sum_d K[j][d] Q[i][d]      A = K fragment, B = Q fragment
+//   O^T[d][i] = sum_j V[d][j] P^T[j][i]    A = V fragment, B = p[r] as-is
 // Computing S transposed leaves each lane with one query column (i = lane & 31), so the row max /
 // row sum are in-lane reductions plus one exchange with lane^32, the rescale factor is a per-lane
 // scalar, and — because v_mfma_f32_32x32x2_f32 consumes exactly the two keys (j, j+4) that lanes
 // l and l+32 already hold in accumulator register r — P feeds the second MFMA without any
 // cross-lane movement or LDS round trip.
+//
+// Operand layouts are chosen so that every fragment is fetched with dwordx4 loads (a CU issues ~13 clocks
+// per vector-memory instruction whatever its width: 112 dword loads per wave were the kernel's bottleneck):
+//   * q and k arrive token-major [row][d] (the q/k/v projection writes them that way).  The contraction
+//     index of MFMA number dp is d = lh * D/2 + dp for lane half lh — any pairing works as long as A and B
+//     agree — so a lane needs D/2 CONSECUTIVE floats of its row: D/8 dwordx4 loads;
+//   * v arrives channel-major [d][j]: MFMA r of the second product needs keys j0 + 8*(r>>2) + 4*lh + (r&3),
+//     i.e. register quadruple r>>2 is one dwordx4 at column j0 + 8*(r>>2) + 4*lh of row d.
+// Columns j >= T of v are never written by the projection and stay at their (finite) initial value; their
+// probabilities are exactly 0.
 // Reference semantics: ldm/attention.py:86-128 (scale after QK^T, softmax over all keys).
 #include <cstdio>
 #include <cstdlib>
@@ -19,22 +29,23 @@
 namespace said {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4a __attribute__((ext_vector_type(4)));
 
 template <int ND, int KS>
 __global__ __launch_bounds__(64 * KS) void attn_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int D = 32 * ND;
+    constexpr int D = 32 * ND, NQ = D / 8;   // NQ dwordx4 per lane and operand row
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z + a.b0;
-    const int T = a.T, pitch = a.pitch;
-    const float* qb = a.q + (long long)b * a.qkv_bstride + (long long)(h * D) * pitch;
-    const float* kb = a.k + (long long)b * a.qkv_bstride + (long long)(h * D) * pitch;
-    const float* vb = a.vt + ((long long)b * a.heads + h) * (long long)a.vt_rows * D;
+    const int T = a.T, pitch = a.pitch, H = a.heads, rows = a.rows;
+    const float* qb = a.qk + (((long long)b * 2 * H + h) * rows) * D + lh * (D / 2);
+    const float* kb = a.qk + (((long long)b * 2 * H + H + h) * rows) * D + lh * (D / 2);
+    const float* vb = a.v + (long long)b * a.v_bstride + (long long)(h * D + lt) * pitch + 4 * lh;
 
-    float qf[ND * 16];
+    f32x4a qf[NQ];
 #pragma unroll
-    for (int dp = 0; dp < ND * 16; ++dp) qf[dp] = qb[(long long)(2 * dp + lh) * pitch + i0 + lt];
+    for (int q = 0; q < NQ; ++q) qf[q] = *reinterpret_cast<const f32x4a*>(qb + (long long)(i0 + lt) * D + 4 * q);
 
     float m = -1.0e30f, lsum = 0.f;
     f32x16 o[ND];
@@ -44,26 +55,27 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const AttnArgs a) {
         for (int r = 0; r < 16; ++r) o[nd][r] = 0.f;
 
     const int nkt = (T + 31) >> 5;
-    // K and V fragments of a key tile are fetched together and one tile ahead of the MFMAs that use
-    // them (register double buffer): with <= 3 tiles per wave the loop is pure memory latency otherwise.
-    auto load_kv = [&](int kt, float (&kf)[ND * 16], float (&vf)[ND][16]) {
+    // K and V fragments of a key tile are fetched together and one tile ahead of the MFMAs that use them
+    // (register double buffer).  Every load is unconditional — tiles past the end re-read the last tile —
+    // so that the compiler can count outstanding loads exactly instead of draining them all.
+    auto load_kv = [&](int kt, f32x4a (&kf)[NQ], f32x4a (&vf)[ND][4]) {
         const int j0 = min(kt, nkt - 1) * 32;
 #pragma unroll
-        for (int dp = 0; dp < ND * 16; ++dp) kf[dp] = kb[(long long)(2 * dp + lh) * pitch + j0 + lt];
+        for (int q = 0; q < NQ; ++q) kf[q] = *reinterpret_cast<const f32x4a*>(kb + (long long)(j0 + lt) * D + 4 * q);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) vf[nd][r] = vb[(long long)j * D + nd * 32 + lt];
-        }
+            for (int q = 0; q < 4; ++q)
+                vf[nd][q] = *reinterpret_cast<const f32x4a*>(vb + (long long)(nd * 32) * pitch + j0 + 8 * q);
     };
-    auto compute = [&](int kt, const float (&kf)[ND * 16], const float (&vf)[ND][16]) {
+    auto compute = [&](int kt, const f32x4a (&kf)[NQ], const f32x4a (&vf)[ND][4]) {
         const int j0 = kt * 32;
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int dp = 0; dp < ND * 16; ++dp) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[dp], qf[dp], s, 0, 0, 0);
+        for (int dp = 0; dp < ND * 16; ++dp)
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[dp >> 2][dp & 3], qf[dp >> 2][dp & 3], s, 0, 0, 0);
         float mx = -1.0e30f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -89,22 +101,19 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) o[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[nd][r], s[r], o[nd], 0, 0, 0);
+            for (int nd = 0; nd < ND; ++nd) o[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[nd][r >> 2][r & 3], s[r], o[nd], 0, 0, 0);
     };
     if constexpr (ND == 1) {
-        float kA[ND * 16], vA[ND][16], kB[ND * 16], vB[ND][16];
-        if (w < nkt) load_kv(w, kA, vA);
+        f32x4a kA[NQ], vA[ND][4], kB[NQ], vB[ND][4];
+        load_kv(w, kA, vA);
         for (int kt = w; kt < nkt; kt += 2 * KS) {
-            const bool more = kt + KS < nkt;
-            if (more) load_kv(kt + KS, kB, vB);
+            load_kv(kt + KS, kB, vB);
             compute(kt, kA, vA);
-            if (more) {
-                if (kt + 2 * KS < nkt) load_kv(kt + 2 * KS, kA, vA);
-                compute(kt + KS, kB, vB);
-            }
+            load_kv(kt + 2 * KS, kA, vA);
+            if (kt + KS < nkt) compute(kt + KS, kB, vB);
         }
     } else {  // head_dim 64: one register buffer (a second one would spill); loads of a tile still go out together
-        float kA[ND * 16], vA[ND][16];
+        f32x4a kA[NQ], vA[ND][4];
         for (int kt = w; kt < nkt; kt += KS) {
             load_kv(kt, kA, vA);
             compute(kt, kA, vA);
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const AttnArgs a) {
     const float invL = 1.0f / L;
     constexpr int NV = ND * 16;
     static_assert(NV % KS == 0, "");
-    float* ob_out = a.o + (long long)b * a.qkv_bstride + (long long)(h * D) * pitch;
+    float* ob_out = a.o + (long long)b * a.o_bstride + (long long)(h * D) * pitch;
 #pragma unroll
     for (int jv = 0; jv < NV / KS; ++jv) {
         const int v = w + jv * KS;

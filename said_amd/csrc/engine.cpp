@@ -384,8 +384,11 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.seg[0] = with_w4(mkseg(in.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_GN_LN, sw.qkv.w[0]), sw.qkv.w4[0], sw.qkv.gn_tail);
         seg_gn(a.seg[0], in.st, g.sts, 6, g.np, 1e-6f, sw.gn_g, sw.gn_b);
         a.seg[0].ln_gamma = sw.l1g; a.seg[0].ln_beta = sw.l1b; a.seg[0].ln_eps = 1e-5f;
-        a.y = c->QK; a.y_bstride = 2LL * MC * g.Tp; a.y_pitch = g.Tp;
-        a.vt = c->VT; a.vt_first_tile = 12; a.vt_heads = HEADS; a.vt_dim = HD; a.vt_rows = vt_rows;
+        // q and k tiles (0..11) token-major into QK [Be][2*heads][rows][32]; v tiles channel-major into VT [Be][192][Tp]
+        // (y is biased so that output channel n = 384 + c lands on row c)
+        a.tm_tiles = 2 * MC / 32;
+        a.vt = c->QK; a.vt_heads = 2 * HEADS; a.vt_dim = HD; a.vt_rows = vt_rows;
+        a.y = c->VT - (long long)a.tm_tiles * 32 * g.Tp; a.y_bstride = (long long)MC * g.Tp; a.y_pitch = g.Tp;
         // tiles per workgroup: the largest shape that still gives every CU a workgroup in ONE round (at Be=2, T=600:
         // NB=3 -> 228 workgroups, 27.5 -> 13.8 us per launch against NB=1's 684 workgroups in 2.7 rounds)
         static const int qkv_env = getenv("SAID_QKV_NB") ? atoi(getenv("SAID_QKV_NB")) : 0;
@@ -395,12 +398,10 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     }
     {   // softmax(q k^T * scale) v   (attention.py:99-126)
         AttnArgs a;
-        a.q = c->QK; a.k = c->QK + (long long)MC * g.Tp; a.vt = c->VT; a.o = c->O;
-        a.qkv_bstride = 2LL * MC * g.Tp; a.pitch = g.Tp; a.T = g.T; a.heads = HEADS; a.vt_rows = vt_rows;
+        a.qk = c->QK; a.v = c->VT; a.o = c->O;
+        a.v_bstride = (long long)MC * g.Tp; a.o_bstride = 2LL * MC * g.Tp;
+        a.pitch = g.Tp; a.T = g.T; a.heads = HEADS; a.rows = vt_rows; a.b0 = 0;
         a.scale = 0.17677669529663687f;  // 32 ** -0.5
-        // q/k/o share a batch stride only if O is laid out like QK; O has its own stride -> separate launch arg
-        AttnArgs b = a;
-        (void)b;
         do_attn(c, a, g.Be, HD, tt * HEADS <= 2048 ? 8 : (tt * HEADS <= 8192 ? 4 : 1), s);
     }
     {   // x1 = to_out(attn) + x, with x = GroupNorm(in) recomputed on the fly   (attention.py:127, 168)
@@ -1272,15 +1273,17 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                 a.nseg = 1;
                 a.seg[0] = mkseg(ctx->aH, hs, Fp, W2V_H, 1, 0, 1, Fr, XF_NONE, ly.qkv.w[0]);
                 a.bias = ly.qkv.bias;
-                a.y = ctx->aQK; a.y_bstride = 2 * hs; a.y_pitch = Fp;
-                a.vt = ctx->aVT; a.vt_first_tile = 2 * W2V_H / 32; a.vt_heads = W2V_HEADS; a.vt_dim = W2V_HD; a.vt_rows = vt_rows;
+                a.tm_tiles = 2 * W2V_H / 32;
+                a.vt = ctx->aQK; a.vt_heads = 2 * W2V_HEADS; a.vt_dim = W2V_HD; a.vt_rows = vt_rows;
+                a.y = ctx->aVT - (long long)a.tm_tiles * 32 * Fp; a.y_bstride = hs; a.y_pitch = Fp;
                 const bool big = tt * 72 > 4096;
                 launch_gemm(a, EPI_QKV, nb, big ? 6 : 2, big ? 4 : 8, s);
             }
             {
                 AttnArgs a;
-                a.q = ctx->aQK; a.k = ctx->aQK + hs; a.vt = ctx->aVT; a.o = ctx->aO;
-                a.qkv_bstride = 2 * hs; a.pitch = Fp; a.T = Fr; a.heads = W2V_HEADS; a.vt_rows = vt_rows; a.scale = 0.125f;
+                a.qk = ctx->aQK; a.v = ctx->aVT; a.o = ctx->aO;
+                a.v_bstride = hs; a.o_bstride = 2 * hs; a.b0 = 0;
+                a.pitch = Fp; a.T = Fr; a.heads = W2V_HEADS; a.rows = vt_rows; a.scale = 0.125f;
                 launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : (tt * W2V_HEADS <= 8192 ? 4 : 1), s);
             }
             {

@@ -487,7 +487,7 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
             const int nl = tile * 32 + lt;
             const int t = t0 + frow;
             if (a.bias) val += a.bias[nl];
-            const int vn = (tile - a.vt_first_tile) * 32 + lt;
+            const int vn = tile * 32 + lt;
             const int h = vn / a.vt_dim, d = vn % a.vt_dim;
             if (t < a.T && nl < a.N)
                 a.vt[(((long long)b * a.vt_heads + h) * a.vt_rows + t) * a.vt_dim + d] = val;
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(64 * KS) void cgemm_kernel(const GemmArgs a) {
     if constexpr (EPI == EPI_QKV) {
         const int tb_per_group = a.ntiles_per_group / NB;
         const int tile0 = (blockIdx.y % tb_per_group) * NB;
-        if (tile0 >= a.vt_first_tile) {
+        if (tile0 < a.tm_tiles) {
             cgemm_body<NB, KS, EPI, true>(a, smem);
             return;
         }

@@ -44,7 +44,7 @@ struct FastHdr {
     int pitch, T, bstride;   // segment 0 pitch, length (stride-1 conv: Tin == T), batch stride (floats)
     int bmod_b0;       // b_mod | b0 << 16
     int N;
-    int gate_vft;      // EPI_GEGLU: gate tile offset; EPI_QKV: first token-major tile
+    int gate_vft;      // EPI_GEGLU: gate tile offset; EPI_QKV: number of leading token-major tiles
     int nbatch;        // samples in this launch (the grid is 1-D)
     // GroupNorm statistics of segment 0: with these the partial loads — the head of the longest dependent chain of
     // a GroupNorm'ed GEMM — go out at kernel entry instead of one memory round trip later
@@ -635,7 +635,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             const int t = t0 + frow;
             if (e_biasp) val += e_biasp[nl];
             const int vdim = AH(vt_dim);
-            const int vn = (tile - AH(vt_first_tile)) * 32 + lt;
+            const int vn = tile * 32 + lt;
             const int h = vn / vdim, d = vn % vdim;
             if (t < aT && nl < aN)
                 AH(vt)[(((long long)b * AH(vt_heads) + h) * AH(vt_rows) + t) * vdim + d] = val;
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const f
     const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     const int by = L % ny, bz = (L / ny) % nz, bx = L / (ny * nz);
     if constexpr (EPI == EPI_QKV) {
-        if (by * NB >= hgate_vft) {
+        if (by * NB < hgate_vft) {
             ugemm_body<NB, KS, EPI, VAR, true>(hd, smem, bx, by, bz);
             return;
         }
@@ -804,7 +804,7 @@ static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s) {
     const bool gn0 = s0.xform == XF_GN_SILU || s0.xform == XF_GN_LN;
     const int pack = s0.C | (s0.taps << 16) | (s0.xform << 20) | (a.nseg << 24) | ((gn0 && s0.gn_eps == 1e-6f) ? (1 << 26) : 0);
     const int bmod_b0 = (s0.b_mod & 0xffff) | (a.b0 << 16);
-    const int gate_vft = (EPI == EPI_GEGLU) ? a.geglu_gate_tiles : a.vt_first_tile;
+    const int gate_vft = (EPI == EPI_GEGLU) ? a.geglu_gate_tiles : a.tm_tiles;
     hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI, VAR>), grid, dim3(64 * KS), smem, s, s0.x, s0.w4, pack, s0.x_pitch, a.T, (int)s0.x_bstride, bmod_b0,
                        a.N, gate_vft, batch, gn0 ? s0.gn_part : nullptr, (int)s0.gn_part_bstride, s0.gn_cpg | (s0.gn_nparts << 16), a);
 }

@@ -78,7 +78,9 @@ struct GemmCommon {        // 8-byte members first, then 4-byte ones: no interna
     float* y;              // output, channel-major [B][groups*N][y_pitch]
     long long y_bstride;
     float* stats_out;      // GN partials of y: [B][groups*N][ceil(T/32)][2], or null
-    float* vt;             // EPI_QKV: tiles >= vt_first_tile are written token-major: vt[b][h][t][d]
+    float* vt;             // EPI_QKV: tiles < tm_tiles (q and k) are written token-major: vt[b][h][t][d], h over vt_heads
+                           // = 2 * heads (q heads, then k heads); the remaining tiles (v) go to y channel-major with
+                           // channel index n - 32 * tm_tiles.  This is the operand layout attn.hip fetches with dwordx4.
     BandArgs band;
     long long* clk;        // optional [KS][16] shader-clock stamps of workgroup (1,0,0) (debug)
     int* step_inc;         // if set, workgroup (0,0,0) increments *step_inc before anything else (loop step counter)
@@ -97,7 +99,7 @@ struct GemmCommon {        // 8-byte members first, then 4-byte ones: no interna
     float res_gn_eps;
     int y_pitch;
     int stats_bstride;
-    int vt_first_tile;
+    int tm_tiles;
     int vt_heads, vt_dim, vt_rows;   // rows = padded T of the vt buffer
     int geglu_gate_tiles;  // EPI_GEGLU: gate tile = value tile + geglu_gate_tiles
     int b0;                // batch offset: this launch covers samples [b0, b0 + gridDim.z)
@@ -110,15 +112,15 @@ static_assert(sizeof(GemmCommon) <= 256, "common block must fit 256 bytes");
 static_assert(sizeof(GemmArgs) == 1024, "GemmArgs = 4 blocks of 256 bytes");
 
 struct AttnArgs {
-    const float* q;        // [B][H*D][pitch]
-    const float* k;
-    const float* vt;       // [B][H][rows][D]
-    float* o;              // [B][H*D][pitch]
-    long long qkv_bstride; // floats between batches for q/k/o
+    const float* qk;       // token-major [B][2*H][rows][D]: q heads, then k heads
+    const float* v;        // channel-major [B][H*D][pitch]
+    float* o;              // channel-major [B][H*D][pitch]
+    long long v_bstride;   // floats between batches of v
+    long long o_bstride;
     int pitch;
     int T;                 // queries == keys
     int heads;
-    int vt_rows;
+    int rows;              // padded T of the token-major buffer
     float scale;
     int b0;                // batch offset
 };
