@@ -248,6 +248,8 @@ int make_pw(said_ctx* ctx, PW* pw, const std::string& wname, const std::string& 
 }
 
 struct LaunchCfg { int NB, KS; };
+// experiment knob: SAID_BIG=cgemm restores the generic kernel's large-batch tile shapes
+static bool big_cgemm() { static const bool v = getenv("SAID_BIG") && !strcmp(getenv("SAID_BIG"), "cgemm"); return v; }
 LaunchCfg pick_cfg(long long t_tiles_total, int ntiles, bool allow6 = true) {
     // small problems: maximise workgroups (split K over 8 waves, one tile each);
     // large problems: amortise the operand transform over more tiles per workgroup.
@@ -257,6 +259,13 @@ LaunchCfg pick_cfg(long long t_tiles_total, int ntiles, bool allow6 = true) {
     if (ntiles % 4 == 0) return {4, 4};
     if (ntiles % 3 == 0) return {3, 4};
     return {2, 8};
+}
+
+// UNet GEMMs with 6 output tiles (192 channels): the LDS-staged kernel at every batch size — two tiles per workgroup
+// as soon as that still fills the chip (measured at Be=32: 47 TFLOP/s against 34 for the generic NB=6 shape)
+LaunchCfg pick_unet(long long t_tiles_total) {
+    if (big_cgemm()) return pick_cfg(t_tiles_total, 6);
+    return t_tiles_total * 3 >= 192 ? LaunchCfg{2, 8} : LaunchCfg{1, 8};
 }
 
 Seg mkseg(const float* x, long long bstride, int pitch, int C, int taps, int pad, int stride, int Tin, int xform, const float* w) {
@@ -350,7 +359,7 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
         a.emb = c->EO + (long long)rb_index * MC * c->maxNp; a.emb_pitch = c->maxNp; a.step_ptr = g.step_ptr; a.emb_b_stride = g.emb_b_stride;
         a.y = c->M.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         a.stats_out = c->M.st; a.stats_bstride = g.sts;
-        const LaunchCfg lc = pick_cfg(tt, 6);
+        const LaunchCfg lc = pick_unet(tt);
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     {   // out_layers: GN -> SiLU -> conv3 ; + skip(x)   (openaimodel.py:226-227)
@@ -369,14 +378,15 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
         }
         a.y = out.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         a.stats_out = out.st; a.stats_bstride = g.sts;
-        const LaunchCfg lc = pick_cfg(tt, 6);
+        const LaunchCfg lc = pick_unet(tt);
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
 }
 
 void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const ActBuf& in, const ActBuf& out, hipStream_t s) {
     const long long tt = (long long)g.Be * ((g.T + 31) / 32);
-    const bool big = tt * 6 > 1536;
+    const bool big = big_cgemm() && tt * 6 > 1536;
+    const bool big_qkv = tt * 6 > 1536 && !getenv("SAID_QKV_UGEMM");   // q/k/v: the generic NB=6 shape is faster at large batch (30 vs 24 TFLOP/s)
     const int vt_rows = rup(g.T, 32);
     {   // x = norm(x) (GroupNorm eps 1e-6); q,k,v = to_{q,k,v}(norm1(x))   (attention.py:227, 168, 93-97)
         GemmArgs a = mkargs(g.T, 3 * MC);
@@ -393,7 +403,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         // NB=3 -> 228 workgroups, 27.5 -> 13.8 us per launch against NB=1's 684 workgroups in 2.7 rounds)
         static const int qkv_env = getenv("SAID_QKV_NB") ? atoi(getenv("SAID_QKV_NB")) : 0;
         const int qkv_nb = qkv_env ? qkv_env : (tt * 6 >= 192 ? 3 : (tt * 9 >= 192 ? 2 : 1));
-        const LaunchCfg lc = big ? LaunchCfg{6, 4} : LaunchCfg{qkv_nb, 8};
+        const LaunchCfg lc = big_qkv ? LaunchCfg{6, 4} : LaunchCfg{qkv_nb, 8};
         do_gemm(c, a, EPI_QKV, g.Be, lc.NB, lc.KS, s);
     }
     {   // softmax(q k^T * scale) v   (attention.py:99-126)
@@ -413,7 +423,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.res_gn_part = in.st; a.res_gn_part_bstride = g.sts; a.res_gn_cpg = 6; a.res_gn_nparts = g.np; a.res_gn_eps = 1e-6f;
         a.res_gn_gamma = sw.gn_g; a.res_gn_beta = sw.gn_b;
         a.y = c->X1; a.y_bstride = g.hs; a.y_pitch = g.Tp;
-        const LaunchCfg lc = pick_cfg(tt, 6);
+        const LaunchCfg lc = big_cgemm() ? pick_unet(tt) : LaunchCfg{1, 8};   // the GroupNorm'ed-residual variant exists for NB = 1
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     {   // attn2: q = to_q(norm2(x1)); banded softmax over the precomputed audio K/V   (attention.py:170-191)
@@ -435,7 +445,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.bias = sw.out2.bias;
         a.res_kind = RES_PLAIN; a.res = c->X1; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = c->X2; a.y_bstride = g.hs; a.y_pitch = g.Tp;
-        const LaunchCfg lc = pick_cfg(tt, 6);
+        const LaunchCfg lc = pick_unet(tt);
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     {   // GEGLU: proj(norm3(x2)) -> a * gelu(gate)   (attention.py:25-32)
@@ -456,7 +466,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.bias = sw.ff2.bias;
         a.res_kind = RES_PLAIN; a.res = c->X2; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = c->X3; a.y_bstride = g.hs; a.y_pitch = g.Tp;
-        const LaunchCfg lc = pick_cfg(tt, 6);
+        const LaunchCfg lc = pick_unet(tt);
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     {   // proj_out (1x1 conv) + x_in   (attention.py:232-234)
@@ -467,7 +477,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.res_kind = RES_PLAIN; a.res = in.p; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = out.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         a.stats_out = out.st; a.stats_bstride = g.sts;
-        const LaunchCfg lc = pick_cfg(tt, 6);
+        const LaunchCfg lc = pick_unet(tt);
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
 }
@@ -484,7 +494,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
         a.step_inc = g.step_inc;   // the loop's device step counter is advanced by the first kernel of the step
         a.bias = c->conv_in.bias;
         a.y = c->H0.p; a.y_bstride = g.hs; a.y_pitch = g.Tp; a.stats_out = c->H0.st; a.stats_bstride = g.sts;
-        const LaunchCfg lc = pick_cfg(tt, 6);
+        const LaunchCfg lc = pick_unet(tt);
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     run_resblock(c, g, c->res[0], 0, c->H0, nullptr, c->P, s);       // input_blocks.1.0
