@@ -295,6 +295,7 @@ struct UGeo {
     int emb_b_stride;
     int b0;            // first sample of this launch range (Be = number of samples in the range)
     int* step_inc;     // if set: the first kernel of the schedule increments this counter
+    const OutSchedArgs* out_sched;   // if set: the `out` conv is fused with the scheduler update (loop only)
 };
 
 inline bool dbg_go(said_ctx* c) {
@@ -506,7 +507,9 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
     run_transformer(c, g, c->st[2], 2, c->Q, c->P, s);               // output_blocks.0.1
     run_resblock(c, g, c->res[4], 4, c->P, &c->H0, c->Q, s);         // output_blocks.1.0  cat([h, H0])
     run_transformer(c, g, c->st[3], 3, c->Q, c->P, s);               // output_blocks.1.1
-    {   // out: GN -> SiLU -> Conv1d(192 -> 32, k3)
+    if (g.out_sched) {   // out conv + guidance + DDIM update in one kernel (out_sched.hip)
+        if (dbg_go(c)) launch_out_sched(*g.out_sched, s);
+    } else {   // out: GN -> SiLU -> Conv1d(192 -> 32, k3)
         GemmArgs a = mkargs(g.T, c->cin);
         a.nseg = 1;
         a.seg[0] = with_w4(mkseg(c->P.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, c->conv_out.w[0]), c->conv_out.w4[0], c->conv_out.gn_tail);
@@ -586,7 +589,7 @@ UGeo make_geo(said_ctx* c, int Be, int B_lat, int T, int S) {
     UGeo g;
     g.Be = Be; g.B_lat = B_lat; g.T = T; g.Tp = rup(T, 32); g.np = (T + 31) / 32; g.S = S; g.Sp = rup(S, 32);
     g.hs = (long long)MC * g.Tp; g.sts = (long long)MC * g.np * 2;
-    g.step_ptr = nullptr; g.emb_b_stride = 0; g.b0 = 0; g.step_inc = nullptr;
+    g.step_ptr = nullptr; g.emb_b_stride = 0; g.b0 = 0; g.step_inc = nullptr; g.out_sched = nullptr;
     return g;
 }
 
@@ -634,6 +637,7 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     configure_gemm_kernels();
     configure_ugemm_kernels();
     configure_attn_kernels();
+    configure_out_sched_kernel();
     ctx->use_ugemm = getenv("SAID_NO_UGEMM") == nullptr;
     ctx->use_branches = getenv("SAID_BRANCHES") != nullptr;   // parallel graph branches measured no faster on ROCm 7.2: off by default
     if (hipStreamCreateWithFlags(&ctx->cap_stream2, hipStreamNonBlocking) != hipSuccess ||
@@ -993,6 +997,19 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     sa.mask = p->use_mask ? ctx->mask_cm : nullptr;
     sa.inter = p->save_intermediate ? p->intermediates_dev : nullptr; sa.latent_scale = p->latent_scale;
 
+    OutSchedArgs osa;
+    memset(&osa, 0, sizeof osa);
+    osa.x = ctx->P.p; osa.gn_part = ctx->P.st; osa.gn_gamma = ctx->out_g; osa.gn_beta = ctx->out_b;
+    osa.w4 = ctx->conv_out.w4[0]; osa.bias = ctx->conv_out.bias; osa.coef = ctx->coef_dev; osa.step_ptr = ctx->step_dev;
+    osa.lat = ctx->x_cm; osa.step_noise = sa.step_noise; osa.init = sa.init; osa.edit_noise = sa.edit_noise; osa.mask = sa.mask;
+    osa.inter = sa.inter; osa.x_bstride = g.hs; osa.gn_part_bstride = g.sts; osa.lat_bstride = xs;
+    osa.pitch = g.Tp; osa.T = T; osa.B = B; osa.Cin = MC; osa.Cout = C; osa.gn_nparts = g.np; osa.cfg = cfg ? 1 : 0;
+    osa.prediction_type = p->prediction_type; osa.guidance_scale = p->guidance_scale; osa.guidance_rescale = sa.guidance_rescale;
+    osa.latent_scale = p->latent_scale;
+    static const bool no_fuse = getenv("SAID_NO_FUSE_SCHED") != nullptr;
+    const bool fused = !no_fuse && !ctx->use_branches && ctx->conv_out.w4[0] && out_sched_supports(osa);
+    if (fused) g.out_sched = &osa;
+
     if (N > 0) {
         float gs = p->guidance_scale, gr = sa.guidance_rescale, ls = p->latent_scale;
         int gsi, gri, lsi;
@@ -1011,8 +1028,10 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
             if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said] step_advance -> %s\n", hipGetErrorString(e)); fflush(stderr); }
             run_unet(ctx, g, s);
             TRACE("loop: warmup unet launched");
-            if (sa.guidance_rescale > 0.f) launch_rescale_partials(sa, ctx->rescale_part, s);
-            launch_sched_step(sa, s);
+            if (!fused) {
+                if (sa.guidance_rescale > 0.f) launch_rescale_partials(sa, ctx->rescale_part, s);
+                launch_sched_step(sa, s);
+            }
             launch_tm_to_cm(p->latents_dev, ctx->x_cm, B, T, C, g.Tp, xs, s);
             HIPCHK(hipMemsetAsync(ctx->step_dev, 0xFF, sizeof(int), s));
             HIPCHK(hipStreamSynchronize(s));
@@ -1037,8 +1056,10 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
             } else {
                 run_unet(ctx, g, cs);
             }
-            if (sa.guidance_rescale > 0.f) launch_rescale_partials(sa, ctx->rescale_part, cs);
-            launch_sched_step(sa, cs);
+            if (!fused) {
+                if (sa.guidance_rescale > 0.f) launch_rescale_partials(sa, ctx->rescale_part, cs);
+                launch_sched_step(sa, cs);
+            }
             TRACE("loop: capture recorded");
             hipError_t e = hipStreamEndCapture(cs, &ctx->graph);
             if (e != hipSuccess) return fail(ctx, "hipStreamEndCapture: %s", hipGetErrorString(e));

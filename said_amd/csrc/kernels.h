@@ -168,6 +168,32 @@ struct SchedArgs {
     float latent_scale;
 };
 void launch_sched_step(const SchedArgs& a, hipStream_t s);
+
+// out conv (GN -> SiLU -> Conv1d(192 -> Cout, k3)) + guidance + DDIM update in one kernel (out_sched.hip)
+struct OutSchedArgs {
+    const float* x;            // last hidden state, channel-major [Be][192][pitch]
+    const float* gn_part;      // its GroupNorm partials [Be][192][gn_nparts][2]
+    const float* gn_gamma;     // out.0
+    const float* gn_beta;
+    const float* w4;           // out.2 weights, dwordx4 packing [1][3][24][64][4]
+    const float* bias;
+    const float* coef;         // device [nsteps][8] scheduler coefficients
+    const int* step_ptr;       // device step counter
+    float* lat;                // latents, channel-major [B][Cout][pitch], updated in place
+    const float* step_noise;   // channel-major [nsteps][B][Cout][pitch] or null
+    const float* init;         // channel-major or null (editing)
+    const float* edit_noise;
+    const float* mask;
+    float* inter;              // token-major (nsteps, B, T, Cout) or null: pre-step latents / latent_scale
+    long long x_bstride, gn_part_bstride, lat_bstride;
+    int pitch, T, B, Cin, Cout, gn_nparts;
+    int cfg;                   // 1: samples [0, B) unconditional, [B, 2B) conditional
+    int prediction_type;
+    float guidance_scale, guidance_rescale, latent_scale;
+};
+bool out_sched_supports(const OutSchedArgs& a);
+void launch_out_sched(const OutSchedArgs& a, hipStream_t s);
+void configure_out_sched_kernel();
 // pre-pass for guidance_rescale > 0: per-block Welford partials of e_c and eps_cfg
 void launch_rescale_partials(const SchedArgs& a, float* part_out, hipStream_t s);
 // standalone elementwise scheduler step on token-major buffers (said_ddim_step)

@@ -1,0 +1,199 @@
+// out_sched.hip — the last kernel of a denoise step: `out` of the UNet (GroupNorm -> SiLU -> Conv1d(192 -> 32, k=3),
+// openaimodel.py:652-656, 709) fused with classifier-free guidance (diffusion.py:430-434), the DDIM update
+// (DDIMScheduler.step as called at diffusion.py:441-443), the eta noise and the editing mask blend
+// (diffusion.py:446-456).  The model output never reaches HBM: a workgroup computes the unconditional AND the
+// conditional 32-channel x 32-token tile of one clip (two accumulators sharing every weight fragment), combines them
+// and updates the latents in place.
+//
+// Structure = gemm_lds.hip's 3-tap GroupNorm variant: 8 waves split the 192 input channels, each stages its
+// 24-channel x 32-token slice (per half) through a wave-private LDS tile after applying GroupNorm+SiLU once, the
+// main loop is ds_read + v_mfma_f32_32x32x2_f32, the split-K partials are summed through LDS in a fixed order.
+// The scheduler arithmetic is sched_math.h's explicitly rounded op sequence, so given the same model output the
+// update is bit-identical to the stand-alone scheduler kernel (and to oracle/scheduler.py).
+// guidance_rescale > 0 needs per-sample standard deviations of the whole model output (rescale_noise_cfg): that case
+// keeps the unfused path (conv -> partial statistics -> sched_step_kernel).
+#include "gemm_common.h"
+#include "sched_math.h"
+
+namespace said {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ f32x4 bload4(rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+constexpr int OS_KS = 8, OS_C = 192, OS_CW = OS_C / OS_KS, OS_XP = 40;
+static_assert(OS_CW == 24, "one 24-channel block per wave");
+
+template <bool CFG>
+__global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NH = CFG ? 2 : 1;
+    const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * 32, b = blockIdx.y;
+    const int T = a.T, pitch4 = a.pitch * 4;
+    const int sr = l >> 3, sq = l & 7;
+    float* coefS = smem;                                   // [NH][2 * 192] GroupNorm (a, b) per channel
+    float* gnS = coefS + NH * 2 * OS_C + w * GN_SCRATCH;   // per-wave GroupNorm scratch
+    float* mainS = coefS + NH * 2 * OS_C + OS_KS * GN_SCRATCH;
+    float* xt = mainS + w * (NH * OS_CW * OS_XP);          // this wave's X tiles [NH][24][XP]
+    float* red = mainS;                                    // [KS][NH][16][64] after the MFMA loop
+
+    // ---- requests: statistics partials first (head of the dependent chain), then operands, weights last ----
+    const GnP gp = {OS_C / 32, a.gn_nparts, T, 1e-5f, a.gn_gamma, a.gn_beta};
+    GnLoads gl[NH];
+    rsrc_t rp[NH], rx[NH];
+    f32x4 xv[NH][3];
+    float halo[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const int sb = b + h * a.B;   // unconditional half first (diffusion.py:397-400)
+        rp[h] = make_rsrc(a.gn_part + (long long)sb * a.gn_part_bstride, (unsigned)OS_C * (unsigned)a.gn_nparts * 8u);
+        gn_issue(gp, rp[h], w * OS_CW, OS_CW, l, gl[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const int sb = b + h * a.B;
+        rx[h] = make_rsrc(a.x + (long long)sb * a.x_bstride, (unsigned)OS_C * (unsigned)a.pitch * 4u);
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) xv[h][rr] = bload4(rx[h], sr * pitch4 + (t0 + 4 * sq) * 4, (w * OS_CW + rr * 8) * pitch4);
+        const int row = l >> 1, tin = (l & 1) ? (t0 + 32) : (t0 - 1);
+        const bool ok = (row < OS_CW) && ((unsigned)tin < (unsigned)T);
+        halo[h] = bload(rx[h], ok ? (row * pitch4 + tin * 4) : (int)0x80000000, (w * OS_CW) * pitch4);
+    }
+    const rsrc_t rw = make_rsrc(a.w4, 3u * (OS_C / 8) * 1024u);
+    f32x4 wv[3][3];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) wv[tap][rr] = bload4(rw, l * 16, (tap * (OS_C / 8) + 3 * w + rr) * 1024);
+    // epilogue operands of this wave's two output rows (channels n0, n1 of token t0 + lt)
+    const int step = *a.step_ptr;
+    const float* cf = a.coef + step * 8;
+    float cfv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cfv[i] = cf[i];
+    const int t = t0 + lt;
+    const bool tok = t < T;
+    const rsrc_t rlat = make_rsrc(a.lat + (long long)b * a.lat_bstride, (unsigned)a.Cout * (unsigned)a.pitch * 4u);
+    const rsrc_t rnz = make_rsrc(a.step_noise ? a.step_noise + ((long long)step * a.B + b) * a.lat_bstride : nullptr,
+                                 a.step_noise ? (unsigned)a.Cout * (unsigned)a.pitch * 4u : 0u);
+    const rsrc_t rin = make_rsrc(a.mask ? a.init + (long long)b * a.lat_bstride : nullptr, a.mask ? (unsigned)a.Cout * (unsigned)a.pitch * 4u : 0u);
+    const rsrc_t ren = make_rsrc(a.mask ? a.edit_noise + (long long)b * a.lat_bstride : nullptr, a.mask ? (unsigned)a.Cout * (unsigned)a.pitch * 4u : 0u);
+    const rsrc_t rmk = make_rsrc(a.mask ? a.mask + (long long)b * a.lat_bstride : nullptr, a.mask ? (unsigned)a.Cout * (unsigned)a.pitch * 4u : 0u);
+    float e_x[2], e_nz[2], e_in[2], e_en[2], e_mk[2], e_bias[2];
+    int e_n[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = w + j * OS_KS;
+        const int n = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        e_n[j] = n;
+        const int vo = (tok && n < a.Cout) ? (n * a.pitch + t) * 4 : (int)0x80000000;
+        e_x[j] = bload(rlat, vo, 0);
+        e_nz[j] = bload(rnz, vo, 0);
+        e_in[j] = bload(rin, vo, 0);
+        e_en[j] = bload(ren, vo, 0);
+        e_mk[j] = bload(rmk, vo, 0);
+        e_bias[j] = a.bias[n < a.Cout ? n : 0];
+    }
+
+    // ---- GroupNorm coefficients of the wave's own 24 channels, per half ----
+#pragma unroll
+    for (int h = 0; h < NH; ++h) gn_finish(gp, rp[h], w * OS_CW, OS_CW, l, gl[h], gnS, coefS + h * 2 * OS_C);
+
+    // ---- stage: GroupNorm + SiLU once per element, wave-private LDS tiles ----
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        float* xth = xt + h * (OS_CW * OS_XP);
+        const float2* cG = reinterpret_cast<const float2*>(coefS + h * 2 * OS_C);
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const float2 g = cG[w * OS_CW + rr * 8 + sr];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = silu_f(fmaf(xv[h][rr][e], g.x, g.y));
+                o[e] = (t0 + 4 * sq + e < T) ? v : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(xth + (rr * 8 + sr) * OS_XP + 4 + 4 * sq) = o;
+        }
+        const int row = l >> 1, tin = (l & 1) ? (t0 + 32) : (t0 - 1);
+        if (row < OS_CW) {
+            const float2 g = cG[w * OS_CW + row];
+            const float v = silu_f(fmaf(halo[h], g.x, g.y));
+            xth[row * OS_XP + ((l & 1) ? 36 : 3)] = ((unsigned)tin < (unsigned)T) ? v : 0.f;
+        }
+    }
+
+    // ---- MFMA: both halves share every weight fragment ----
+    f32x16 acc[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+    const float* xrow = xt + lh * OS_XP + lt + 3;
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const float xf = xrow[h * (OS_CW * OS_XP) + (rr * 8 + 2 * j) * OS_XP + tap];
+                    acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[tap][rr][j], xf, acc[h], 0, 0, 0);
+                }
+
+    // ---- split-K reduction (fixed order) ----
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((w * NH + h) * 16 + r) * 64 + l] = acc[h][r];
+    __syncthreads();
+
+    // ---- epilogue: bias, guidance, DDIM update, noise, mask blend; latents updated in place ----
+    float* latp = a.lat + (long long)b * a.lat_bstride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = w + j * OS_KS;
+        float eh[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            float s = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < OS_KS; ++w2) s += red[((w2 * NH + h) * 16 + r) * 64 + l];
+            eh[h] = s + e_bias[j];
+        }
+        const float e = CFG ? cfg_combine(eh[NH - 1], eh[0], a.guidance_scale) : eh[0];
+        const int n = e_n[j];
+        if (!(tok && n < a.Cout)) continue;
+        const float x = e_x[j];
+        if (a.inter) a.inter[(((long long)step * a.B + b) * T + t) * a.Cout + n] = x / a.latent_scale;
+        float prev = ddim_prev(e, x, cfv, a.prediction_type);
+        if (a.step_noise) prev = __fadd_rn(prev, __fmul_rn(cfv[4], e_nz[j]));
+        if (a.mask) prev = mask_blend(prev, e_in[j], e_en[j], e_mk[j], cfv);
+        latp[(long long)n * a.pitch + t] = prev;
+    }
+}
+
+static int out_sched_smem(bool cfg) {
+    const int nh = cfg ? 2 : 1;
+    const int stage = OS_KS * nh * OS_CW * OS_XP, red = OS_KS * nh * 16 * 64;
+    return (nh * 2 * OS_C + OS_KS * GN_SCRATCH + (stage > red ? stage : red)) * (int)sizeof(float);
+}
+void configure_out_sched_kernel() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+bool out_sched_supports(const OutSchedArgs& a) {
+    return a.Cin == OS_C && a.Cout <= 32 && a.guidance_rescale <= 0.f && a.gn_nparts < 0x7fff;
+}
+void launch_out_sched(const OutSchedArgs& a, hipStream_t s) {
+    dim3 grid((a.T + 31) / 32, a.B);
+    if (a.cfg) hipLaunchKernelGGL(out_sched_kernel<true>, grid, dim3(64 * OS_KS), out_sched_smem(true), s, a);
+    else hipLaunchKernelGGL(out_sched_kernel<false>, grid, dim3(64 * OS_KS), out_sched_smem(false), s, a);
+}
+
+}  // namespace said
