@@ -218,7 +218,7 @@ def main():
             torch.cuda.synchronize()
             step_ms = ev0.elapsed_time(ev1) / args.num_steps
             line["roofline"] = roofline(model, Be, T, step_ms)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N=1 only: other ranks would sit in the final barrier
             line["cpu_baseline"] = cpu_baseline(args, T, Ta)
         print(json.dumps(line), flush=True)
     if world > 1:
