@@ -42,6 +42,7 @@ struct PW {  // packed GEMM weight (up to 2 K-segments) + bias
     float* bias = nullptr;
     int N = 0, C[2] = {0, 0}, taps = 1, nseg = 1;
     bool gn_tail = false;                // w4[s] is followed by the GroupNorm gamma[C] and beta[C] of its source segment
+    bool ln_tail = false;                // ... and then by the LayerNorm gamma[C] and beta[C]
 };
 struct ResW { float *g1, *b1, *g2, *b2; PW conv1, conv2, skip; int cin; bool has_skip; float* bias2; };
 struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj; };
@@ -217,7 +218,8 @@ std::vector<int> rows_dense(int N, int row0 = 0) {
 // gn_gamma/gn_beta (optional): affine of the GroupNorm applied to this GEMM's source; appended to each segment's w4
 // block so that the LDS-staged kernel can locate them from its preloaded header alone (gemm_lds.hip, FastHdr).
 int make_pw(said_ctx* ctx, PW* pw, const std::string& wname, const std::string& bname, int N, int Ctot, int taps, int nseg = 1,
-            const std::string& gn_gamma = "", const std::string& gn_beta = "") {
+            const std::string& gn_gamma = "", const std::string& gn_beta = "", const std::string& ln_gamma = "",
+            const std::string& ln_beta = "") {
     const HostTensor* t = taps > 0 && ctx->host_w.count(wname) && ctx->host_w[wname].shape.size() == 3
                               ? getw(ctx, wname, {N, Ctot, taps})
                               : getw(ctx, wname, {N, Ctot});
@@ -239,6 +241,14 @@ int make_pw(said_ctx* ctx, PW* pw, const std::string& wname, const std::string& 
                 p4.insert(p4.end(), gg->data.begin() + s * C, gg->data.begin() + (s + 1) * C);
                 p4.insert(p4.end(), gb->data.begin() + s * C, gb->data.begin() + (s + 1) * C);
                 pw->gn_tail = true;
+            }
+            if (!ln_gamma.empty()) {
+                const HostTensor* lg = getw(ctx, ln_gamma, {Ctot});
+                const HostTensor* lb = getw(ctx, ln_beta, {Ctot});
+                if (!lg || !lb) return -1;
+                p4.insert(p4.end(), lg->data.begin() + s * C, lg->data.begin() + (s + 1) * C);
+                p4.insert(p4.end(), lb->data.begin() + s * C, lb->data.begin() + (s + 1) * C);
+                pw->ln_tail = true;
             }
             if (upload(ctx, &pw->w4[s], p4.data(), p4.size())) return -1;
         }
@@ -275,7 +285,7 @@ Seg mkseg(const float* x, long long bstride, int pitch, int C, int taps, int pad
     s.Tin = Tin; s.xform = xform; s.gn_cpg = 1; s.gn_nparts = 1;
     return s;
 }
-inline Seg with_w4(Seg s, const float* w4, bool gn_tail = false) { s.w4 = w4; s.w4_gn_tail = gn_tail ? 1 : 0; return s; }
+inline Seg with_w4(Seg s, const float* w4, bool gn_tail = false, bool ln_tail = false) { s.w4 = w4; s.w4_gn_tail = gn_tail ? 1 : 0; s.w4_ln_tail = ln_tail ? 1 : 0; return s; }
 void seg_gn(Seg& s, const float* part, long long part_bstride, int cpg, int nparts, float eps, const float* g, const float* b) {
     s.gn_part = part; s.gn_part_bstride = part_bstride; s.gn_cpg = cpg; s.gn_nparts = nparts; s.gn_eps = eps; s.gn_gamma = g; s.gn_beta = b;
 }
@@ -392,7 +402,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // x = norm(x) (GroupNorm eps 1e-6); q,k,v = to_{q,k,v}(norm1(x))   (attention.py:227, 168, 93-97)
         GemmArgs a = mkargs(g.T, 3 * MC);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(in.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_GN_LN, sw.qkv.w[0]), sw.qkv.w4[0], sw.qkv.gn_tail);
+        a.seg[0] = with_w4(mkseg(in.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_GN_LN, sw.qkv.w[0]), sw.qkv.w4[0], sw.qkv.gn_tail, sw.qkv.ln_tail);
         seg_gn(a.seg[0], in.st, g.sts, 6, g.np, 1e-6f, sw.gn_g, sw.gn_b);
         a.seg[0].ln_gamma = sw.l1g; a.seg[0].ln_beta = sw.l1b; a.seg[0].ln_eps = 1e-5f;
         // q and k tiles (0..11) token-major into QK [Be][2*heads][rows][32]; v tiles channel-major into VT [Be][192][Tp]
@@ -430,7 +440,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // attn2: q = to_q(norm2(x1)); banded softmax over the precomputed audio K/V   (attention.py:170-191)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->X1, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.q2.w[0]), sw.q2.w4[0]);
+        a.seg[0] = with_w4(mkseg(c->X1, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.q2.w[0]), sw.q2.w4[0], false, sw.q2.ln_tail);
         a.seg[0].ln_gamma = sw.l2g; a.seg[0].ln_beta = sw.l2b; a.seg[0].ln_eps = 1e-5f;
         a.y = c->O; a.y_bstride = 2LL * MC * g.Tp; a.y_pitch = g.Tp;
         a.band.k = c->KV + (long long)(blk * 2 * MC) * g.Sp;
@@ -452,7 +462,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // GEGLU: proj(norm3(x2)) -> a * gelu(gate)   (attention.py:25-32)
         GemmArgs a = mkargs(g.T, FFI);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->X2, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.ff1.w[0]), sw.ff1.w4[0]);
+        a.seg[0] = with_w4(mkseg(c->X2, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.ff1.w[0]), sw.ff1.w4[0], false, sw.ff1.ln_tail);
         a.seg[0].ln_gamma = sw.l3g; a.seg[0].ln_beta = sw.l3b; a.seg[0].ln_eps = 1e-5f;
         a.bias = sw.ff1.bias; a.geglu_gate_tiles = FFI / 32;
         a.y = c->F; a.y_bstride = (long long)FFI * g.Tp; a.y_pitch = g.Tp;
@@ -774,16 +784,16 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
         qkv.insert(qkv.end(), wk->data.begin(), wk->data.end());
         qkv.insert(qkv.end(), wv->data.begin(), wv->data.end());
         ctx->host_w["__qkv"] = HostTensor{qkv, {3 * MC, MC}};
-        if (make_pw(ctx, &sw.qkv, "__qkv", "", 3 * MC, MC, 0, 1, p + ".norm.weight", p + ".norm.bias")) return -1;
+        if (make_pw(ctx, &sw.qkv, "__qkv", "", 3 * MC, MC, 0, 1, p + ".norm.weight", p + ".norm.bias", b + ".norm1.weight", b + ".norm1.bias")) return -1;
         if (make_pw(ctx, &sw.out1, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", MC, MC, 0)) return -1;
-        if (make_pw(ctx, &sw.q2, b + ".attn2.to_q.weight", "", MC, MC, 0)) return -1;
+        if (make_pw(ctx, &sw.q2, b + ".attn2.to_q.weight", "", MC, MC, 0, 1, "", "", b + ".norm2.weight", b + ".norm2.bias")) return -1;
         const HostTensor* k2 = getw(ctx, b + ".attn2.to_k.weight", {MC, CD});
         const HostTensor* v2 = getw(ctx, b + ".attn2.to_v.weight", {MC, CD});
         if (!k2 || !v2) return -1;
         std::copy(k2->data.begin(), k2->data.end(), kv_w.begin() + (size_t)(i * 2) * MC * CD);
         std::copy(v2->data.begin(), v2->data.end(), kv_w.begin() + (size_t)(i * 2 + 1) * MC * CD);
         if (make_pw(ctx, &sw.out2, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", MC, MC, 0)) return -1;
-        if (make_pw(ctx, &sw.ff1, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", 2 * FFI, MC, 0)) return -1;
+        if (make_pw(ctx, &sw.ff1, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", 2 * FFI, MC, 0, 1, "", "", b + ".norm3.weight", b + ".norm3.bias")) return -1;
         if (make_pw(ctx, &sw.ff2, b + ".ff.net.2.weight", b + ".ff.net.2.bias", MC, FFI, 0)) return -1;
         if (make_pw(ctx, &sw.proj, p + ".proj_out.weight", p + ".proj_out.bias", MC, MC, 1)) return -1;
         used += 24;

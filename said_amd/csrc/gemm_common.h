@@ -32,6 +32,17 @@ __device__ __forceinline__ ArgView arg_view(int lane, int dword_offset = 0) {
     v.h = p[lane]; v.s0 = p[64 + lane]; v.s1 = p[128 + lane]; v.s2 = p[192 + lane];
     return v;
 }
+// only the blocks a kernel variant reads: the common block, plus segments 1 and 2 for multi-segment launches (segment 0
+// is fully described by the preloaded header).  Every vector load costs the CU's address path >= 13 clocks and all
+// 8 waves fetch the same block, so the three spare loads were ~300 clocks of queueing per workgroup.
+template <bool MULTI>
+__device__ __forceinline__ ArgView arg_view_hs(int lane, int dword_offset) {
+    const unsigned* p = (const unsigned*)__builtin_amdgcn_kernarg_segment_ptr() + dword_offset;
+    ArgView v;
+    v.h = p[lane]; v.s0 = 0u; v.s1 = 0u; v.s2 = 0u;
+    if constexpr (MULTI) { v.s1 = p[128 + lane]; v.s2 = p[192 + lane]; }
+    return v;
+}
 template <typename T>
 __device__ __forceinline__ T rl(unsigned v, int dw) {
     if constexpr (sizeof(T) == 4) {

@@ -70,7 +70,8 @@ struct UBlock {   // one (segment, channel block) of this wave
 // s_waitcnt vmcnt(0) and e.g. the GroupNorm coefficients wait for the epilogue operands requested after them: one
 // extra memory round trip on the critical path (measured 21.7k -> see profiles/ for the phase clocks).
 enum UVar : int { UV_T3 = 1 /* segment 0 is a 3-tap conv */, UV_GN0 = 2 /* GroupNorm'ed segment 0 */,
-                  UV_GN1 = 4 /* GroupNorm'ed segment 1 (concatenated skip) */, UV_RGN = 8 /* GroupNorm'ed residual */ };
+                  UV_GN1 = 4 /* GroupNorm'ed segment 1 (concatenated skip) */, UV_RGN = 8 /* GroupNorm'ed residual */,
+                  UV_MULTI = 16 /* more than one K segment: the argument blocks of segments 1, 2 are fetched */ };
 
 template <int NB, int KS, int EPI, int VAR, bool TRANS>
 __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int bx, int by, int bz) {
@@ -80,6 +81,8 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     constexpr int VPW = NV / KS;
     constexpr bool EPRE = (VPW <= 4) && (EPI == EPI_STORE || EPI == EPI_QKV) && !TRANS;
     constexpr bool T3 = (VAR & UV_T3) != 0, GN0 = (VAR & UV_GN0) != 0, GN1 = (VAR & UV_GN1) != 0, RGN = (VAR & UV_RGN) != 0;
+    constexpr bool MULTI = (VAR & UV_MULTI) != 0;
+    static_assert(!GN1 || MULTI, "a GroupNorm'ed segment 1 implies several segments");
     constexpr bool HAS_LN = (EPI != EPI_STORE);   // q/k/v, GEGLU and band projections read LayerNorm'ed input
     static_assert(EPI == EPI_STORE || (VAR & ~UV_GN0) == 0, "variants other than GN0 exist only for EPI_STORE");
     static_assert(EPI != EPI_QKV || GN0, "q/k/v reads GroupNorm -> LayerNorm input");
@@ -89,7 +92,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     const int b = bz + (hd.bmod_b0 >> 16);
     const int t0 = bx * 32;
     const int tile0 = by * NB;
-    const int nseg = (hd.pack >> 24) & 3, aT = hd.T, aN = hd.N;
+    const int nseg = MULTI ? ((hd.pack >> 24) & 3) : 1, aT = hd.T, aN = hd.N;
     const int gate_tiles = (EPI == EPI_GEGLU) ? hd.gate_vft : 0;
     const int ntiles = (aN + 31) >> 5;
     const int w_tiles = (EPI == EPI_GEGLU) ? ntiles + gate_tiles : ntiles;
@@ -185,26 +188,31 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         grp_rsrc0 = make_rsrc(hd.gn_part + (long long)sb * hd.gn_bstride, (unsigned)C0 * (unsigned)gp0.gn_nparts * 8u);
         gn_issue(gp0, grp_rsrc0, w * (C0 / KS), C0 / KS, l, gl0);
     }
-    const ArgView V = arg_view(l, 16);   // the rest of the argument block: 4 coalesced loads, fields via v_readlane
+    const ArgView V = arg_view_hs<MULTI>(l, 16);   // common block (+ segments 1, 2): coalesced loads, fields via v_readlane
     issue_x(u0, xv, halo, true);
     f32x4 lnref = {0.f, 0.f, 0.f, 0.f};
     if constexpr (HAS_LN) lnref = bload4(u0.rx, (t0 + 4 * sq) * 4, 0);   // raw channel 0 of this lane's 4 tokens: common shift
     issue_w(u0, wv, true);
     long long* const clkp = AH(clk);
     clk_stamp_p(clkp, w, l, 0);
-    auto SV = [&](int s) -> unsigned { return s == 0 ? V.s0 : (s == 1 ? V.s1 : V.s2); };
-    auto seg_coefs = [&](int s) {
+    auto SV = [&](int s) -> unsigned { return s == 1 ? V.s1 : V.s2; };   // segment 0 lives in the header
+    auto seg_coefs = [&](int s) {   // segments 1, 2 only (segment 0 comes from the header)
         const int xf = AS(SV(s), xform), sc = AS(SV(s), C);
         return ((xf == XF_GN_SILU || xf == XF_GN_LN) ? 2 * sc : 0) + ((xf == XF_LN || xf == XF_GN_LN) ? 2 * sc : 0);
     };
     const int coef_off0 = 0;
-    const int coef_off1 = seg_coefs(0);
+    const int coef_off1 = (GN0 ? 2 * C0 : 0) + (HAS_LN ? 2 * C0 : 0);
     const int coef_off2 = coef_off1 + (nseg > 1 ? seg_coefs(1) : 0);
     const int coef_total = coef_off2 + (nseg > 2 ? seg_coefs(2) : 0);
     auto coef_off = [&](int s) { return s == 0 ? coef_off0 : (s == 1 ? coef_off1 : coef_off2); };
     float* lnred = mainS + coef_total;                      // [KS][32][2]
     float* xt = lnred + KS * 64 + w * (8 * NRMAX * XP);    // this wave's X tile [CB][XP]
     auto make_block = [&](int s, int blk) {
+        if (s == 0) {   // further channel blocks of segment 0 (K slices wider than 24 channels)
+            UBlock u = u0;
+            u.c0 = w * (C0 / KS) + blk * 24;
+            return u;
+        }
         const unsigned sv = SV(s);
         UBlock u;
         const int sC = AS(sv, C), pitch = AS(sv, x_pitch), taps = AS(sv, taps), bmod = AS(sv, b_mod);
@@ -221,7 +229,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         return u;
     };
     auto nblocks = [&](int s) {
-        const int cw = AS(SV(s), C) / KS;
+        const int cw = (s == 0 ? C0 : AS(SV(s), C)) / KS;
         return (cw % 24 == 0) ? cw / 24 : 1;
     };
     auto seg_gnp = [&](int s) {
@@ -256,10 +264,12 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     float ln_g = 0.f, ln_b = 0.f;
     if constexpr (HAS_LN) {   // LayerNorm affine of the wave's channel slice (<= 24 channels): lane c
         const int cw = C0 / KS;
-        const rsrc_t rg = make_rsrc(AS(V.s0, ln_gamma), (unsigned)C0 * 4u), rb = make_rsrc(AS(V.s0, ln_beta), (unsigned)C0 * 4u);
+        // gamma[C0], beta[C0] sit behind the weights (after the GroupNorm pair, if any)
+        const float* lnp = hd.w4 + (long long)w_tiles * taps0 * (C0 >> 3) * 256 + (GN0 ? 2 * C0 : 0);
+        const rsrc_t rg = make_rsrc(lnp, (unsigned)C0 * 8u);
         const int vo = (l < cw) ? (w * cw + l) * 4 : (int)0x80000000;
         ln_g = bload(rg, vo, 0);
-        ln_b = bload(rb, vo, 0);
+        ln_b = bload(rg, vo, C0 * 4);
     }
     float e_bias[EPRE ? VPW : 1], e_emb[EPRE ? VPW : 1], e_res[EPRE ? VPW : 1];
     const float* const e_biasp = AH(bias);
@@ -336,7 +346,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     f32x4 mu4 = {0.f, 0.f, 0.f, 0.f}, rs4 = {1.f, 1.f, 1.f, 1.f};
     if constexpr (HAS_LN) {   // single block (host guarantees C/KS == CB), taps == 1
         constexpr bool gnx = GN0;
-        const float ln_eps = AS(V.s0, ln_eps);
+        const float ln_eps = 1e-5f;   // host guarantees (ugemm_supports)
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int rr = 0; rr < NRMAX; ++rr) {
@@ -819,9 +829,10 @@ static void uconfigure_one() {
 #define SAID_UGEMM_CONFIGS(X) SAID_UGEMM_EXPAND(X, SAID_DEV_ONE_CONFIG)
 #else
 #define SAID_UGEMM_CONFIGS(X)                                                                                    \
-    X(EPI_STORE, 1, 8, 0) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_GN1)          \
-    X(EPI_STORE, 1, 8, UV_RGN)                                                                                   \
-    X(EPI_STORE, 2, 8, 0) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_GN1)          \
+    X(EPI_STORE, 1, 8, 0) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_MULTI)        \
+    X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_GN1 | UV_MULTI) X(EPI_STORE, 1, 8, UV_RGN)                            \
+    X(EPI_STORE, 2, 8, 0) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_MULTI)        \
+    X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_GN1 | UV_MULTI)                                                       \
     X(EPI_QKV, 1, 8, UV_GN0) X(EPI_QKV, 2, 8, UV_GN0) X(EPI_QKV, 3, 8, UV_GN0)                                   \
     X(EPI_GEGLU, 1, 8, 0) X(EPI_GEGLU, 2, 8, 0) X(EPI_GEGLU, 4, 8, 0)                                            \
     X(EPI_BAND, 1, 8, 0)
@@ -840,6 +851,7 @@ static int uvar_of(const GemmArgs& a, int epi) {
     if (is_gn(a.seg[0].xform)) v |= UV_GN0;
     if (a.nseg > 1 && is_gn(a.seg[1].xform)) v |= UV_GN1;
     if (epi == EPI_STORE && a.res_kind == RES_GN) v |= UV_RGN;
+    if (a.nseg > 1) v |= UV_MULTI;
     return v;
 }
 
@@ -858,6 +870,7 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS) {
         if ((epi == EPI_GEGLU || epi == EPI_BAND) && xf0 != XF_LN) return false;
         if (epi == EPI_STORE && !(xf0 == XF_NONE || xf0 == XF_SILU || xf0 == XF_GN_SILU)) return false;
         if (a.nseg > 2 && is_gn(a.seg[2].xform)) return false;
+        if ((xf0 == XF_LN || xf0 == XF_GN_LN) && !(a.seg[0].w4_ln_tail && a.seg[0].ln_eps == 1e-5f)) return false;
         const int nacc = (epi == EPI_GEGLU) ? 2 * NB : NB;
         if (nacc >= 8 && !(a.nseg == 1 && a.seg[0].C == 24 * KS)) return false;   // rolling weight rounds: one block only
         if (epi != EPI_STORE && a.res_kind != RES_NONE) return false;

@@ -47,6 +47,7 @@ struct SegFields {
     int b_mod;             // source batch = b % b_mod when > 0 (CFG: both halves read the same latents)
     int c_group_stride;    // source channel offset per conv group (grouped conv), else 0
     int w4_gn_tail;        // 1: w4 is followed by gn_gamma[C], gn_beta[C] of this segment (copies; see FastHdr)
+    int w4_ln_tail;        // 1: ... and then by ln_gamma[C], ln_beta[C]
 };
 // padded to 256 bytes: the LDS-staged kernel fetches the argument block with one coalesced 256-B vector
 // load per block and extracts fields with v_readlane (a by-value struct read field-by-field costs one
