@@ -283,7 +283,6 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         int erow = 0;
         if (embp) { const int* sp = AH(step_ptr); erow = (sp ? *sp : 0) + b * AH(emb_b_stride); }
         const int emb_pitch = AH(emb_pitch);
-        const rsrc_t r_emb = make_rsrc(embp, embp ? (unsigned)aN * (unsigned)emb_pitch * 4u : 0u);
         const float* resp = AH(res);
         const bool has_res = (EPI == EPI_STORE) && res_kind != RES_NONE;
         const int res_pitch = AH(res_pitch);
@@ -295,8 +294,14 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             const int nl = (tile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int t = t0 + lt;
             const bool nok = nl < aN;
-            e_bias[j] = bload(r_bias, nok ? nl * 4 : (int)0x80000000, 0);
-            e_emb[j] = bload(r_emb, nok ? (nl * emb_pitch + erow) * 4 : (int)0x80000000, 0);
+            // bias and timestep-embedding term are per-row constants: two uniform addresses per row (lane halves) ->
+            // scalar loads, which do not occupy the CU's vector address path
+            const int na = (tile0 + i) * 32 + (r & 3) + 8 * (r >> 2), nb = na + 4;
+            const float b_a = (e_biasp && na < aN) ? e_biasp[na] : 0.f, b_b = (e_biasp && nb < aN) ? e_biasp[nb] : 0.f;
+            const float m_a = (embp && na < aN) ? embp[(long long)na * emb_pitch + erow] : 0.f;
+            const float m_b = (embp && nb < aN) ? embp[(long long)nb * emb_pitch + erow] : 0.f;
+            e_bias[j] = lh ? b_b : b_a;
+            e_emb[j] = lh ? m_b : m_a;
             e_res[j] = bload(r_res, (nok && t < aT) ? (nl * res_pitch + t) * 4 : (int)0x80000000, 0);
         }
     }
@@ -397,22 +402,23 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 
     // banded cross-attention: this thread's K and V window values, requested before the main loop
     constexpr int BNG = KS * 2, BDPG = (32 / BNG) > 0 ? (32 / BNG) : 1;
-    float kq[EPI == EPI_BAND ? BDPG : 1][8], vq[EPI == EPI_BAND ? BDPG : 1][8];
+    f32x4 kraw[EPI == EPI_BAND ? BDPG : 1][2], vraw[EPI == EPI_BAND ? BDPG : 1][2];
     if (EPI == EPI_BAND) {
+        // the window of query t is keys lo .. lo+wmax-1, contiguous in a K/V row: two dwordx4 per row instead of eight
+        // dword loads (the second one is masked out of range when the band is at most 4 wide); the registers are only
+        // touched again in the band epilogue
         const int kvp = AB(kv_pitch), bwmax = AB(wmax);
         const long long kvo = (long long)b * AB(kv_bstride) + (long long)(tile0 * 32) * kvp;
         const rsrc_t rk = make_rsrc(AB(k) + kvo, 32u * (unsigned)kvp * 4u);
         const rsrc_t rv_ = make_rsrc(AB(v) + kvo, 32u * (unsigned)kvp * 4u);
         const int gi = tid >> 5;
+        const int oor_hi = (bwmax > 4) ? 0 : (int)0x80000000;
 #pragma unroll
-        for (int dd = 0; dd < BDPG; ++dd)
-#pragma unroll
-            for (int wi = 0; wi < 8; ++wi) {
-                const bool vis = (wi < bwmax) && (band_lo + wi < band_hi);
-                const int vo = vis ? ((gi * BDPG + dd) * kvp + band_lo + wi) * 4 : (int)0x80000000;
-                kq[dd][wi] = bload(rk, vo, 0);
-                vq[dd][wi] = bload(rv_, vo, 0);
-            }
+        for (int dd = 0; dd < BDPG; ++dd) {
+            const int vo = ((gi * BDPG + dd) * kvp + band_lo) * 4;
+            kraw[dd][0] = bload4(rk, vo, 0); kraw[dd][1] = bload4(rk, (vo + 16) | oor_hi, 0);
+            vraw[dd][0] = bload4(rv_, vo, 0); vraw[dd][1] = bload4(rv_, (vo + 16) | oor_hi, 0);
+        }
     }
 
     // ================= phase 3: stage -> LDS, MFMA =================
@@ -729,7 +735,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             if (wi < wmax) {
                 float p = 0.f;
 #pragma unroll
-                for (int dd = 0; dd < DPG; ++dd) p = fmaf(qt[(gi * DPG + dd) * 32 + tt], kq[dd][wi], p);
+                for (int dd = 0; dd < DPG; ++dd) p = fmaf(qt[(gi * DPG + dd) * 32 + tt], kraw[dd][wi >> 2][wi & 3], p);
                 part[(gi * 8 + wi) * 32 + tt] = p;
             }
         }
@@ -761,7 +767,10 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                 const int d = gi * DPG + dd;
                 float o = 0.f;
 #pragma unroll
-                for (int wi = 0; wi < 8; ++wi) o = fmaf(sc[wi] * inv, vq[dd][wi], o);
+                for (int wi = 0; wi < 8; ++wi) {
+                    const bool vis = (wi < wmax) && (lo + wi < hi);   // invisible slots may hold another row's data
+                    o = fmaf(sc[wi] * inv, vis ? vraw[dd][wi >> 2][wi & 3] : 0.f, o);
+                }
                 yp[(long long)b * y_bs + (long long)(head * 32 + d) * y_pitch + t] = o;
             }
         }

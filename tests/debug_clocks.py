@@ -25,6 +25,6 @@ for k in range(44):
     d = np.diff(st, axis=1)
     tot = st[:, 9].max() - base
     print(f"launch {k:2d} total {tot:6d} clk | " + " ".join(f"{n}:{int(d[:, i].mean()):5d}" for i, n in enumerate(labels)))
-    if k in (1, 9):
+    if k in (1, 3):
         for w in range(8):
             print("      wave", w, " ".join(f"{int(v - base):6d}" for v in st[w]))
