@@ -59,6 +59,38 @@ def fit_audio_unet(waveform: torch.Tensor, sampling_rate: int, fps: int, divisor
     return waveform, window_len
 
 
+def resample_direct(x: np.ndarray, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> np.ndarray:
+    """Direct-form restatement of torchaudio.functional.resample (sinc_interp_hann, default parameters) as called at
+    said/util/audio.py:36-37: output sample m sits at time m/new_freq and is the Hann-windowed-sinc weighted sum of the
+    input samples within `lowpass_filter_width` zero crossings of the (rolled-off) lower Nyquist rate.  One output at a
+    time in float64 — no polyphase bank, no strided convolution — so that it shares nothing with the product's fast
+    formulation except the published formula.  torchaudio itself is absent here: parity unpinned.
+    """
+    g = math.gcd(orig_freq, new_freq)
+    orig, new = orig_freq // g, new_freq // g
+    cutoff = min(orig, new) * rolloff            # in units where the input rate is `orig`
+    width = math.ceil(lowpass_filter_width * orig / cutoff)
+    n = x.shape[-1]
+    m_total = math.ceil(new * n / orig)
+    y = np.zeros(m_total, dtype=np.float64)
+    xd = x.astype(np.float64)
+    for m in range(m_total):
+        j, i = divmod(m, new)                    # frame and phase
+        # taps k = -width .. width + orig - 1 relative to input index j*orig (zero outside the signal)
+        k = np.arange(-width, width + orig)
+        idx = j * orig + k
+        ok = (idx >= 0) & (idx < n)
+        t = (k / orig - np.float64(np.float32(i / new))) * cutoff     # the phase offset is a float32 quotient upstream
+        t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
+        win = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+        tp = t * math.pi
+        with np.errstate(invalid="ignore", divide="ignore"):
+            h = np.where(tp == 0, 1.0, np.sin(tp) / tp) * win * (cutoff / orig)
+        h = h.astype(np.float32).astype(np.float64)                      # the bank is stored in float32
+        y[m] = np.dot(xd[idx[ok]], h[ok])
+    return y.astype(np.float32)
+
+
 def get_audio_embedding(sd_audio: SD, waveform: torch.Tensor, num_frames: Optional[int]) -> torch.Tensor:
     """diffusion.py:209-230 (feature_dim <= 0: no projection)."""
     return ow2v.wav2vec2_forward(sd_audio, waveform, num_frames)[0]

@@ -1,9 +1,12 @@
-"""Audio utilities of the inference CLI boundary.
+"""Audio ingest of the inference CLI boundary: WAV -> mono float waveform at the model's rate, padded for the UNet.
 
-Counterparts of /root/reference/said/util/audio.py:20-75 (``load_audio``,
-``fit_audio_unet``).  WAV decoding uses ``scipy.io.wavfile`` (torchaudio is not
-part of this stack); only 16 kHz input is pinned — resampling parity with
-``torchaudio.functional.resample`` is SURVEY.md §8(f) item 2.
+Counterparts of the reference's `load_audio` and `fit_audio_unet` (/root/reference/said/util/audio.py:20-39, 42-75).
+The reference decodes and resamples with torchaudio, which is not part of this stack: WAV decoding uses
+`scipy.io.wavfile` with torchaudio's integer normalisation, and `resample` restates torchaudio's published
+`functional.resample` algorithm (band-limited interpolation with a Hann-windowed sinc, defaults
+lowpass_filter_width=6, rolloff=0.99).  torchaudio is absent from /root/reference and from this image, so that
+restatement is **parity-unpinned**; tests check it against an independent direct-form evaluation and against
+signal-level properties (length rule, DC gain, tone preservation).
 """
 from __future__ import annotations
 
@@ -16,44 +19,79 @@ import torch
 
 @dataclass
 class FittedWaveform:
-    """Fitted waveform using the window"""
+    """A waveform zero-padded for the UNet and the number of coefficient frames the original audio covers."""
 
     waveform: torch.FloatTensor
     window_size: int
 
 
-def load_audio(audio_path: str, sampling_rate: int) -> torch.FloatTensor:
-    """Load a WAV file as a mono float waveform in [-1, 1] at ``sampling_rate``."""
+def _sinc_filter_bank(orig: int, new: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """Polyphase filter bank (new, 1, taps) of the Hann-windowed sinc interpolator and its half width.
+
+    `orig`, `new`: the two rates divided by their gcd.  Phase i produces output sample j*new + i from the input
+    samples around j*orig; times are measured in units of the lower of the two rates times `rolloff`.
+    """
+    cutoff = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / cutoff)
+    taps = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    phase = torch.arange(0, -new, -1)[:, None, None] / new          # int64 / int -> float32, as in torchaudio
+    t = (phase + taps) * cutoff
+    t = t.clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernel = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (cutoff / orig)
+    return kernel.to(torch.float32), width
+
+
+def resample(waveform: torch.Tensor, orig_freq: int, new_freq: int) -> torch.Tensor:
+    """Band-limited resampling of (..., time) float32 audio from `orig_freq` to `new_freq` Hz."""
+    if orig_freq == new_freq:
+        return waveform
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    kernel, width = _sinc_filter_bank(orig, new)
+    lead = waveform.shape[:-1]
+    flat = waveform.reshape(-1, waveform.shape[-1]).to(torch.float32)
+    length = flat.shape[-1]
+    padded = torch.nn.functional.pad(flat, (width, width + orig))
+    frames = torch.nn.functional.conv1d(padded[:, None], kernel, stride=orig)    # (n, new, frames)
+    out = frames.transpose(1, 2).reshape(flat.shape[0], -1)
+    out = out[:, : math.ceil(new * length / orig)]
+    return out.reshape(*lead, out.shape[-1])
+
+
+def _decode_wav(path: str):
+    """(channels, time) float32 in [-1, 1) and the file's sample rate (integer PCM scaled by 2**-(bits-1))."""
     from scipy.io import wavfile
 
-    sr, data = wavfile.read(audio_path)
-    if data.dtype == np.int16:
-        wav = data.astype(np.float32) / 32768.0
-    elif data.dtype == np.int32:
-        wav = data.astype(np.float32) / 2147483648.0
-    elif data.dtype == np.uint8:
-        wav = (data.astype(np.float32) - 128.0) / 128.0
+    rate, data = wavfile.read(path)
+    if data.dtype == np.uint8:
+        pcm = (data.astype(np.float32) - 128.0) / 128.0
+    elif np.issubdtype(data.dtype, np.integer):
+        pcm = data.astype(np.float32) / float(2 ** (8 * data.dtype.itemsize - 1))
     else:
-        wav = data.astype(np.float32)
-    wav_t = torch.from_numpy(wav)
-    if wav_t.dim() == 2:  # (frames, channels) -> mean over channels
-        wav_t = wav_t.mean(dim=1)
-    if sr != sampling_rate:
-        raise NotImplementedError(
-            f"{audio_path}: sample rate {sr} != {sampling_rate}; resample the file first "
-            "(torchaudio-compatible resampling is not part of this build yet)")
-    return wav_t
+        pcm = data.astype(np.float32)
+    pcm = pcm[:, None] if pcm.ndim == 1 else pcm
+    return torch.from_numpy(np.ascontiguousarray(pcm.T)), int(rate)
+
+
+def load_audio(audio_path: str, sampling_rate: int) -> torch.FloatTensor:
+    """Mono waveform (T_a,) at `sampling_rate`: decode, resample each channel if needed, average the channels."""
+    channels, rate = _decode_wav(audio_path)
+    if rate != sampling_rate:
+        channels = resample(channels, rate, sampling_rate)
+    return channels.mean(dim=0)
 
 
 def fit_audio_unet(waveform: torch.FloatTensor, sampling_rate: int, fps: int, divisor_unet: int) -> FittedWaveform:
-    """Zero-pad the waveform so the frame count divides ``divisor_unet``."""
-    gcd = math.gcd(sampling_rate, fps)
-    divisor_waveform = sampling_rate // gcd * divisor_unet
-    waveform_len = waveform.shape[0]
-    window_len = int(waveform_len / sampling_rate * fps)
-    waveform_len_fit = math.ceil(waveform_len / divisor_waveform) * divisor_waveform
-    if waveform_len_fit > waveform_len:
-        tmp = torch.zeros(waveform_len_fit)
-        tmp[:waveform_len] = waveform[:]
-        waveform = tmp
-    return FittedWaveform(waveform=waveform, window_size=window_len)
+    """Zero-pad at the end so that the audio spans a whole number of `divisor_unet`-frame groups.
+
+    One coefficient frame lasts sampling_rate/fps samples; in lowest terms that is `sampling_rate // gcd` samples per
+    `fps // gcd` frames, and the reference pads to a multiple of `sampling_rate // gcd * divisor_unet` samples
+    (audio.py:64-73).  `window_size` is the frame count of the UN-padded audio, floor(len / sampling_rate * fps).
+    """
+    quantum = sampling_rate // math.gcd(sampling_rate, fps) * divisor_unet
+    n = int(waveform.shape[0])
+    missing = -n % quantum
+    padded = torch.nn.functional.pad(waveform, (0, missing)) if missing else waveform
+    return FittedWaveform(waveform=padded, window_size=int(n / sampling_rate * fps))

@@ -155,3 +155,51 @@ def test_batch_driver_parser_and_enumeration(tmp_path):
     for n in ("sentence40.wav", "sentence02.wav", "sentence41.wav", "other.wav"):
         (tmp_path / pid / n).write_bytes(b"")
     assert [os.path.basename(p) for _, p in mod.test_audio_paths(str(tmp_path))] == ["sentence02.wav", "sentence40.wav"]
+
+
+# ---------------------------------------------------------------- WAV ingest
+@pytest.mark.parametrize("orig,new,n", [(22050, 16000, 3000), (48000, 16000, 4801), (8000, 16000, 1234), (44100, 16000, 2000), (16000, 16000, 100)])
+def test_resample_fast_form_matches_direct_form(orig, new, n):
+    """Polyphase/conv formulation of the product vs the oracle's one-output-at-a-time evaluation of the same formula."""
+    import math
+    from oracle import pipeline as op
+    from said_amd.util import audio
+    x = synth.synth_waveform(5, n)
+    got = audio.resample(x, orig, new)
+    assert got.shape[-1] == math.ceil(n * new / orig)          # torchaudio's length rule
+    if orig == new:
+        assert torch.equal(got, x)
+        return
+    want = torch.from_numpy(op.resample_direct(x.numpy(), orig, new))
+    assert float((got - want).abs().max()) <= 2e-6
+
+
+def test_resample_signal_properties():
+    """Independent of any restatement: DC gain ~ 1 away from the edges and a 440 Hz tone survives 48k -> 16k."""
+    import math
+    from said_amd.util import audio
+    dc = audio.resample(torch.ones(4800), 48000, 16000)
+    assert float((dc[100:-100] - 1.0).abs().max()) <= 2e-3
+    t48 = torch.arange(9600, dtype=torch.float64) / 48000
+    tone = torch.sin(2 * math.pi * 440 * t48).float()
+    y = audio.resample(tone, 48000, 16000)
+    t16 = torch.arange(y.shape[0], dtype=torch.float64) / 16000
+    assert float((y[200:-200] - torch.sin(2 * math.pi * 440 * t16).float()[200:-200]).abs().max()) <= 2e-3
+
+
+def test_load_audio_stereo_48k_int16(tmp_path):
+    """load_audio: int16 scaling by 2**-15, per-channel resampling to 16 kHz, channel mean (audio.py:34-38)."""
+    from scipy.io import wavfile
+    from said_amd.util import audio
+    a = (synth.synth_waveform(7, 4800).numpy() * 3 * 32767).clip(-32768, 32767).astype(np.int16)
+    b = (synth.synth_waveform(8, 4800).numpy() * 3 * 32767).clip(-32768, 32767).astype(np.int16)
+    path = str(tmp_path / "s.wav")
+    wavfile.write(path, 48000, np.stack([a, b], axis=1))
+    got = audio.load_audio(path, 16000)
+    assert got.shape == (1600,) and got.dtype == torch.float32
+    ch = torch.from_numpy(np.stack([a, b]).astype(np.float32) / 32768.0)
+    want = audio.resample(ch, 48000, 16000).mean(dim=0)
+    assert torch.equal(got, want)
+    mono16 = str(tmp_path / "m.wav")
+    wavfile.write(mono16, 16000, a)
+    assert torch.equal(audio.load_audio(mono16, 16000), torch.from_numpy(a.astype(np.float32) / 32768.0))
