@@ -76,6 +76,20 @@ def test_unet_forward_context_length_differs(golden, model, dev):
     assert np.abs(out - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("B,T,S", [(1, 7, 10), (1, 31, 31), (3, 33, 33), (2, 65, 50), (1, 100, 77), (5, 96, 96), (4, 160, 201),
+                                   (9, 64, 64)])
+def test_unet_forward_ragged_shapes_vs_oracle(model, unet_sd, dev, B, T, S):
+    """Frame counts that are not multiples of the 32-token tile, fewer frames than one tile, context lengths shorter and
+    longer than the frame count (general alignment windows), odd batch sizes, and the batch sizes at which the tile
+    shapes change (NB=1 -> 2 at 64 token tiles)."""
+    x = synth.synth_latents(300 + T, (B, T, 32))
+    c = synth.synth_latents(400 + S, (B, S, 768))
+    ts = (torch.arange(B) * 137 + 11) % 1000
+    out = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+    ref = ou.unet1d_forward(unet_sd, x, ts, c)
+    assert float((out - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
 def test_unet_scalar_and_single_timestep_broadcast(model, unet_sd, dev):
     x = synth.synth_latents(5, (3, 33, 32))
     c = synth.synth_latents(6, (3, 33, 768))
