@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--num_steps", type=int, default=1000, help="denoising steps per clip")
     p.add_argument("--guidance_scale", type=float, default=2.0)
     p.add_argument("--eta", type=float, default=0.0)
+    p.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                   help="f32 (BASELINE configs[1]) or bf16 multiplies with fp32 accumulation (configs[2]: --batch 32 --num_steps 50 --dtype bf16)")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
     p.add_argument("--cpu_steps", type=int, default=40, help="UNet evaluations in the CPU-baseline sample")
@@ -158,6 +160,7 @@ def main():
     model = SAID_UNet1D()
     model.load_state_dict(synth.said_state_dict(), strict=True)
     model.to(dev).eval()
+    model.set_mfma_dtype("bf16" if args.dtype == "bf16" else "fp32")
     # synthetic inputs, resident in HBM before the timed region
     wav = [synth.synth_waveform(rank * B + i, Ta).numpy() for i in range(B)]
     proc = model.process_audio(wav).to(dev)
@@ -196,12 +199,13 @@ def main():
             "metric": "blendshape frames/sec (and clips/sec) at 1000 DDPM steps, 10 s audio",
             "value": round(frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "clips_per_s": round(world * B * args.steps / elapsed, 4),
             "realtime_factor": round(frames / elapsed / 60.0, 2),
             "config": {"workload": f"{B} clip(s)/GPU x {args.seconds:g} s synthetic audio (T={T} frames), audio encode + "
                                    f"{args.num_steps} DDIM steps (eta={args.eta:g}), guidance_scale={args.guidance_scale:g} "
-                                   f"(UNet batch {Be}), fp32; BASELINE.json configs[1]",
+                                   f"(UNet batch {Be}), " + ("fp32; BASELINE.json configs[1]" if args.dtype == "f32" else
+                                                              "bf16 multiplies / fp32 accumulation and storage; BASELINE.json configs[2] shape"),
                        "batch_per_gpu": B, "frames": T, "num_steps": args.num_steps, "guidance_scale": args.guidance_scale,
                        "eta": args.eta, "parallelism": f"clips sharded over {world} GPU(s), one RCCL all-gather" if world > 1 else "single GPU",
                        "graph_nodes_per_step": model._eng.graph_num_nodes()},

@@ -149,6 +149,16 @@ int said_ddim_step(said_ctx* ctx, const float* eps_dev, const float* eps_uncond_
 int said_axpby(said_ctx* ctx, const float* a_host, const float* x_dev, const float* c_host, const float* y_dev,
                float* out_dev, int batch, int64_t n_per_batch, void* stream);
 
+/* ---- precision ----------------------------------------------------------- */
+
+/* bf16_mfma != 0: every GEMM / convolution served by the LDS-staged UNet kernel multiplies operands rounded to
+ * bfloat16 (weights once at said_finalize_weights, activations after their fused normalisation) with fp32
+ * accumulation; statistics, normalisations, softmax, the scheduler and all tensors in HBM stay fp32.  This is the
+ * "bf16" of BASELINE.json configs[2]; the reference itself (diffusion.py) only runs fp32, the closest analogue being
+ * torch.autocast(bfloat16) around its matmuls/convs.  Default 0.  Takes effect at the next call. */
+int said_set_precision(said_ctx* ctx, int bf16_mfma);
+int said_get_precision(const said_ctx* ctx);
+
 /* ---- introspection ------------------------------------------------------- */
 
 /* Number of kernel launches captured in the current per-step graph (0 if none). */

@@ -51,6 +51,8 @@ EXPORTS = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "said_axpby": (c_int, [c_void_p, POINTER(c_float), c_void_p, POINTER(c_float), c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "said_graph_num_nodes": (c_int, [c_void_p]),
+    "said_set_precision": (c_int, [c_void_p, c_int]),
+    "said_get_precision": (c_int, [c_void_p]),
     "said_profile_unet": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, POINTER(c_int), c_void_p]),
     "said_debug_stop_after": (c_int, [c_void_p, c_int]),
@@ -286,6 +288,13 @@ class Engine:
 
     def graph_num_nodes(self) -> int:
         return int(self.lib.said_graph_num_nodes(self.h))
+
+    def set_precision(self, bf16_mfma: bool) -> None:
+        """bf16 multiplies (fp32 accumulation, fp32 everything else) in the UNet GEMMs; see said_set_precision."""
+        self._chk(self.lib.said_set_precision(self.h, 1 if bf16_mfma else 0), "said_set_precision")
+
+    def get_precision(self) -> str:
+        return "bf16" if self.lib.said_get_precision(self.h) else "fp32"
 
 
 def unet_algorithmic_bytes(batch_eff: int, frames: int, bytes_per_elem: int = 4) -> float:

@@ -39,6 +39,7 @@ struct HostTensor {
 struct PW {  // packed GEMM weight (up to 2 K-segments) + bias
     float* w[2] = {nullptr, nullptr};
     float* w4[2] = {nullptr, nullptr};   // dwordx4 packing for the LDS-staged kernel
+    float* w2[2] = {nullptr, nullptr};   // bf16 packing for the LDS-staged kernel's bf16 MFMA mode (same tails as w4)
     float* bias = nullptr;
     int N = 0, C[2] = {0, 0}, taps = 1, nseg = 1;
     bool gn_tail = false;                // w4[s] is followed by the GroupNorm gamma[C] and beta[C] of its source segment
@@ -102,6 +103,7 @@ struct said_ctx {
     hipStream_t cap_stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool use_branches = false;  // SAID_BRANCHES=1: capture the two halves of the UNet batch as parallel graph branches
+    bool bf16_mode = false;  // said_set_precision: multiply in bf16 wherever the LDS-staged kernel is used
     bool use_ugemm = true;   // SAID_NO_UGEMM=1 forces the generic kernel everywhere (A/B testing)
 
     // ---- audio workspace (lazily sized) ----
@@ -207,6 +209,31 @@ std::vector<float> pack_rows4(const float* W, int Ctot, int taps, const std::vec
                     }
     return out;
 }
+// round-to-nearest-even fp32 -> bf16 (finite inputs)
+inline uint16_t bf16_rne(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    x += 0x7fffu + ((x >> 16) & 1u);
+    return (uint16_t)(x >> 16);
+}
+// bf16 packing for v_mfma_f32_32x32x8_bf16_1k: Wb[tile][tap][c/8][lane][4]; value j of lane l =
+// W[tile*32 + (l & 31)][c_begin + 8*cq + 4*(l >> 5) + j][tap].  Returned as float storage (2 bf16 per float).
+std::vector<float> pack_rows_bf16(const float* W, int Ctot, int taps, const std::vector<int>& row_of, int ntiles_total, int c_begin, int C) {
+    std::vector<uint16_t> h((size_t)ntiles_total * taps * (C / 8) * 256);
+    size_t o = 0;
+    for (int tile = 0; tile < ntiles_total; ++tile)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int cq = 0; cq < C / 8; ++cq)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = row_of[tile * 32 + (l & 31)];
+                        const int c = c_begin + 8 * cq + 4 * (l >> 5) + j;
+                        h[o++] = row < 0 ? (uint16_t)0 : bf16_rne(W[((size_t)row * Ctot + c) * taps + tap]);
+                    }
+    std::vector<float> out(h.size() / 2);
+    memcpy(out.data(), h.data(), h.size() * 2);
+    return out;
+}
 std::vector<int> rows_dense(int N, int row0 = 0) {
     const int nt = (N + 31) / 32;
     std::vector<int> r(nt * 32, -1);
@@ -234,6 +261,8 @@ int make_pw(said_ctx* ctx, PW* pw, const std::string& wname, const std::string& 
         if (upload(ctx, &pw->w[s], packed.data(), packed.size())) return -1;
         if (C % 8 == 0 && (tp == 1 || tp == 3)) {
             auto p4 = pack_rows4(t->data.data(), Ctot, tp, rows, (N + 31) / 32, s * C, C);
+            auto p2 = pack_rows_bf16(t->data.data(), Ctot, tp, rows, (N + 31) / 32, s * C, C);
+            const size_t w4_floats = p4.size();
             if (!gn_gamma.empty()) {
                 const HostTensor* gg = getw(ctx, gn_gamma, {Ctot});
                 const HostTensor* gb = getw(ctx, gn_beta, {Ctot});
@@ -250,7 +279,9 @@ int make_pw(said_ctx* ctx, PW* pw, const std::string& wname, const std::string& 
                 p4.insert(p4.end(), lb->data.begin() + s * C, lb->data.begin() + (s + 1) * C);
                 pw->ln_tail = true;
             }
+            p2.insert(p2.end(), p4.begin() + w4_floats, p4.end());   // the GroupNorm / LayerNorm tails, unchanged
             if (upload(ctx, &pw->w4[s], p4.data(), p4.size())) return -1;
+            if (upload(ctx, &pw->w2[s], p2.data(), p2.size())) return -1;
         }
     }
     if (!bname.empty()) { if (upvec(ctx, &pw->bias, bname, N)) return -1; }
@@ -286,6 +317,11 @@ Seg mkseg(const float* x, long long bstride, int pitch, int C, int taps, int pad
     return s;
 }
 inline Seg with_w4(Seg s, const float* w4, bool gn_tail = false, bool ln_tail = false) { s.w4 = w4; s.w4_gn_tail = gn_tail ? 1 : 0; s.w4_ln_tail = ln_tail ? 1 : 0; return s; }
+// attach K-segment k of a packed weight: both packings for the LDS-staged kernel and what follows them
+inline Seg with_pw(Seg s, const PW& pw, int k) {
+    s.w4 = pw.w4[k]; s.w2 = pw.w2[k]; s.w4_gn_tail = pw.gn_tail ? 1 : 0; s.w4_ln_tail = pw.ln_tail ? 1 : 0;
+    return s;
+}
 void seg_gn(Seg& s, const float* part, long long part_bstride, int cpg, int nparts, float eps, const float* g, const float* b) {
     s.gn_part = part; s.gn_part_bstride = part_bstride; s.gn_cpg = cpg; s.gn_nparts = nparts; s.gn_eps = eps; s.gn_gamma = g; s.gn_beta = b;
 }
@@ -328,14 +364,15 @@ void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS,
         double out = (double)batch * a.groups * a.N * a.T * 4.0;
         if (a.res_kind != RES_NONE) in += out;
         if (epi == EPI_BAND) in += 2.0 * batch * a.N * a.T * 4.0;  // this block's K and V rows
-        c->stage_log.push_back({(c->use_ugemm && ugemm_supports(a, epi, NB, KS)) ? 2 : 0, epi, NB, KS, w + in + out, fl});
+        c->stage_log.push_back({(c->use_ugemm && ugemm_supports(a, epi, NB, KS, c->bf16_mode)) ? 2 : 0, epi, NB, KS, w + in + out, fl});
     }
     GemmArgs a2 = a;
     a2.b0 = c->cur_b0;
     if (c->clk_on && c->dbg_count < 64) a2.clk = c->clk_dev + (long long)c->dbg_count * 128;
     if (dbg_go(c)) {
         if (trace_on()) { fprintf(stderr, "[said] gemm #%d epi=%d NB=%d KS=%d T=%d N=%d batch=%d\n", c->dbg_count - 1, epi, NB, KS, a.T, a.N, batch); fflush(stderr); }
-        if (c->use_ugemm && !a2.step_inc && ugemm_supports(a2, epi, NB, KS)) launch_ugemm(a2, epi, batch, NB, KS, s);
+        if (c->use_ugemm && !a2.step_inc && c->bf16_mode && ugemm_supports(a2, epi, NB, KS, true)) launch_ugemm(a2, epi, batch, NB, KS, s, true);
+        else if (c->use_ugemm && !a2.step_inc && ugemm_supports(a2, epi, NB, KS)) launch_ugemm(a2, epi, batch, NB, KS, s);
         else launch_gemm(a2, epi, batch, NB, KS, s);
         if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
     }
@@ -360,10 +397,10 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
     {   // in_layers: GN -> SiLU -> conv3 ; + emb_layers(emb)   (openaimodel.py:205-225)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = in1 ? 2 : 1;
-        a.seg[0] = with_w4(mkseg(in0.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[0]), rw.conv1.w4[0], rw.conv1.gn_tail);
+        a.seg[0] = with_pw(mkseg(in0.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[0]), rw.conv1, 0);
         seg_gn(a.seg[0], in0.st, g.sts, cpg, g.np, 1e-5f, rw.g1, rw.b1);
         if (in1) {
-            a.seg[1] = with_w4(mkseg(in1->p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[1]), rw.conv1.w4[1], rw.conv1.gn_tail);
+            a.seg[1] = with_pw(mkseg(in1->p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv1.w[1]), rw.conv1, 1);
             seg_gn(a.seg[1], in1->st, g.sts, cpg, g.np, 1e-5f, rw.g1 + MC, rw.b1 + MC);
         }
         a.bias = rw.conv1.bias;
@@ -376,11 +413,11 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
     {   // out_layers: GN -> SiLU -> conv3 ; + skip(x)   (openaimodel.py:226-227)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->M.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv2.w[0]), rw.conv2.w4[0], rw.conv2.gn_tail);
+        a.seg[0] = with_pw(mkseg(c->M.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, rw.conv2.w[0]), rw.conv2, 0);
         seg_gn(a.seg[0], c->M.st, g.sts, 6, g.np, 1e-5f, rw.g2, rw.b2);
         if (rw.has_skip) {  // 1x1 conv over the concatenated input folded in as two extra K segments
-            a.seg[1] = with_w4(mkseg(in0.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, rw.skip.w[0]), rw.skip.w4[0]);
-            a.seg[2] = with_w4(mkseg(in1->p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, rw.skip.w[1]), rw.skip.w4[1]);
+            a.seg[1] = with_pw(mkseg(in0.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, rw.skip.w[0]), rw.skip, 0);
+            a.seg[2] = with_pw(mkseg(in1->p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, rw.skip.w[1]), rw.skip, 1);
             a.nseg = 3;
             a.bias = rw.bias2;
         } else {
@@ -397,12 +434,12 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
 void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const ActBuf& in, const ActBuf& out, hipStream_t s) {
     const long long tt = (long long)g.Be * ((g.T + 31) / 32);
     const bool big = big_cgemm() && tt * 6 > 1536;
-    const bool big_qkv = tt * 6 > 1536 && !getenv("SAID_QKV_UGEMM");   // q/k/v: the generic NB=6 shape is faster at large batch (30 vs 24 TFLOP/s)
+    const bool big_qkv = tt * 6 > 1536 && !getenv("SAID_QKV_UGEMM") && !c->bf16_mode;   // q/k/v: the generic NB=6 shape is faster at large batch (30 vs 24 TFLOP/s)
     const int vt_rows = rup(g.T, 32);
     {   // x = norm(x) (GroupNorm eps 1e-6); q,k,v = to_{q,k,v}(norm1(x))   (attention.py:227, 168, 93-97)
         GemmArgs a = mkargs(g.T, 3 * MC);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(in.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_GN_LN, sw.qkv.w[0]), sw.qkv.w4[0], sw.qkv.gn_tail, sw.qkv.ln_tail);
+        a.seg[0] = with_pw(mkseg(in.p, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_GN_LN, sw.qkv.w[0]), sw.qkv, 0);
         seg_gn(a.seg[0], in.st, g.sts, 6, g.np, 1e-6f, sw.gn_g, sw.gn_b);
         a.seg[0].ln_gamma = sw.l1g; a.seg[0].ln_beta = sw.l1b; a.seg[0].ln_eps = 1e-5f;
         // q and k tiles (0..11) token-major into QK [Be][2*heads][rows][32]; v tiles channel-major into VT [Be][192][Tp]
@@ -428,7 +465,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // x1 = to_out(attn) + x, with x = GroupNorm(in) recomputed on the fly   (attention.py:127, 168)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->O, 2LL * MC * g.Tp, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out1.w[0]), sw.out1.w4[0]);
+        a.seg[0] = with_pw(mkseg(c->O, 2LL * MC * g.Tp, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out1.w[0]), sw.out1, 0);
         a.bias = sw.out1.bias;
         a.res_kind = RES_GN; a.res = in.p; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.res_gn_part = in.st; a.res_gn_part_bstride = g.sts; a.res_gn_cpg = 6; a.res_gn_nparts = g.np; a.res_gn_eps = 1e-6f;
@@ -440,7 +477,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // attn2: q = to_q(norm2(x1)); banded softmax over the precomputed audio K/V   (attention.py:170-191)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->X1, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.q2.w[0]), sw.q2.w4[0], false, sw.q2.ln_tail);
+        a.seg[0] = with_pw(mkseg(c->X1, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.q2.w[0]), sw.q2, 0);
         a.seg[0].ln_gamma = sw.l2g; a.seg[0].ln_beta = sw.l2b; a.seg[0].ln_eps = 1e-5f;
         a.y = c->O; a.y_bstride = 2LL * MC * g.Tp; a.y_pitch = g.Tp;
         a.band.k = c->KV + (long long)(blk * 2 * MC) * g.Sp;
@@ -452,7 +489,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // x2 = to_out(attn2) + x1
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->O, 2LL * MC * g.Tp, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out2.w[0]), sw.out2.w4[0]);
+        a.seg[0] = with_pw(mkseg(c->O, 2LL * MC * g.Tp, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out2.w[0]), sw.out2, 0);
         a.bias = sw.out2.bias;
         a.res_kind = RES_PLAIN; a.res = c->X1; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = c->X2; a.y_bstride = g.hs; a.y_pitch = g.Tp;
@@ -462,7 +499,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // GEGLU: proj(norm3(x2)) -> a * gelu(gate)   (attention.py:25-32)
         GemmArgs a = mkargs(g.T, FFI);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->X2, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.ff1.w[0]), sw.ff1.w4[0], false, sw.ff1.ln_tail);
+        a.seg[0] = with_pw(mkseg(c->X2, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.ff1.w[0]), sw.ff1, 0);
         a.seg[0].ln_gamma = sw.l3g; a.seg[0].ln_beta = sw.l3b; a.seg[0].ln_eps = 1e-5f;
         a.bias = sw.ff1.bias; a.geglu_gate_tiles = FFI / 32;
         a.y = c->F; a.y_bstride = (long long)FFI * g.Tp; a.y_pitch = g.Tp;
@@ -473,7 +510,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // x3 = net.2(h) + x2
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->F, (long long)FFI * g.Tp, g.Tp, FFI, 1, 0, 1, g.T, XF_NONE, sw.ff2.w[0]), sw.ff2.w4[0]);
+        a.seg[0] = with_pw(mkseg(c->F, (long long)FFI * g.Tp, g.Tp, FFI, 1, 0, 1, g.T, XF_NONE, sw.ff2.w[0]), sw.ff2, 0);
         a.bias = sw.ff2.bias;
         a.res_kind = RES_PLAIN; a.res = c->X2; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = c->X3; a.y_bstride = g.hs; a.y_pitch = g.Tp;
@@ -483,7 +520,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     {   // proj_out (1x1 conv) + x_in   (attention.py:232-234)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->X3, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.proj.w[0]), sw.proj.w4[0]);
+        a.seg[0] = with_pw(mkseg(c->X3, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.proj.w[0]), sw.proj, 0);
         a.bias = sw.proj.bias;
         a.res_kind = RES_PLAIN; a.res = in.p; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = out.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
@@ -500,7 +537,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
     {   // input_blocks.0: Conv1d(32 -> 192, k3)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->x_cm, (long long)c->cin * g.Tp, g.Tp, c->cin, 3, 1, 1, g.T, XF_NONE, c->conv_in.w[0]), c->conv_in.w4[0]);
+        a.seg[0] = with_pw(mkseg(c->x_cm, (long long)c->cin * g.Tp, g.Tp, c->cin, 3, 1, 1, g.T, XF_NONE, c->conv_in.w[0]), c->conv_in, 0);
         a.seg[0].b_mod = g.B_lat;
         a.step_inc = g.step_inc;   // the loop's device step counter is advanced by the first kernel of the step
         a.bias = c->conv_in.bias;
@@ -522,7 +559,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
     } else {   // out: GN -> SiLU -> Conv1d(192 -> 32, k3)
         GemmArgs a = mkargs(g.T, c->cin);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->P.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, c->conv_out.w[0]), c->conv_out.w4[0], c->conv_out.gn_tail);
+        a.seg[0] = with_pw(mkseg(c->P.p, g.hs, g.Tp, MC, 3, 1, 1, g.T, XF_GN_SILU, c->conv_out.w[0]), c->conv_out, 0);
         seg_gn(a.seg[0], c->P.st, g.sts, 6, g.np, 1e-5f, c->out_g, c->out_b);
         a.bias = c->conv_out.bias;
         a.y = c->eps_cm; a.y_bstride = (long long)c->cin * g.Tp; a.y_pitch = g.Tp;
@@ -538,7 +575,7 @@ void run_time_embed(said_ctx* c, int n, hipStream_t s) {
     {
         GemmArgs a = mkargs(n, TE);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->E0, 0, Np, MC, 1, 0, 1, n, XF_NONE, c->te1.w[0]), c->te1.w4[0]);
+        a.seg[0] = with_pw(mkseg(c->E0, 0, Np, MC, 1, 0, 1, n, XF_NONE, c->te1.w[0]), c->te1, 0);
         a.bias = c->te1.bias; a.act = ACT_SILU;
         a.y = c->E1; a.y_pitch = Np;
         const LaunchCfg lc = pick_cfg(tt, TE / 32);
@@ -547,7 +584,7 @@ void run_time_embed(said_ctx* c, int n, hipStream_t s) {
     {
         GemmArgs a = mkargs(n, TE);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->E1, 0, Np, TE, 1, 0, 1, n, XF_NONE, c->te2.w[0]), c->te2.w4[0]);
+        a.seg[0] = with_pw(mkseg(c->E1, 0, Np, TE, 1, 0, 1, n, XF_NONE, c->te2.w[0]), c->te2, 0);
         a.bias = c->te2.bias;
         a.y = c->E2; a.y_pitch = Np;
         const LaunchCfg lc = pick_cfg(tt, TE / 32);
@@ -556,7 +593,7 @@ void run_time_embed(said_ctx* c, int n, hipStream_t s) {
     {
         GemmArgs a = mkargs(n, NRES * MC);
         a.nseg = 1;
-        a.seg[0] = with_w4(mkseg(c->E2, 0, Np, TE, 1, 0, 1, n, XF_SILU, c->emb_all.w[0]), c->emb_all.w4[0]);
+        a.seg[0] = with_pw(mkseg(c->E2, 0, Np, TE, 1, 0, 1, n, XF_SILU, c->emb_all.w[0]), c->emb_all, 0);
         a.bias = c->emb_all.bias;
         a.y = c->EO; a.y_pitch = Np;
         const LaunchCfg lc = pick_cfg(tt, NRES * MC / 32);
@@ -568,7 +605,7 @@ void run_time_embed(said_ctx* c, int n, hipStream_t s) {
 void run_kv(said_ctx* c, int Be, int S, int Sp, hipStream_t s) {
     GemmArgs a = mkargs(S, NST * 2 * MC);
     a.nseg = 1;
-    a.seg[0] = with_w4(mkseg(c->CTX, (long long)c->ctx_dim * Sp, Sp, c->ctx_dim, 1, 0, 1, S, XF_NONE, c->kv_all.w[0]), c->kv_all.w4[0]);
+    a.seg[0] = with_pw(mkseg(c->CTX, (long long)c->ctx_dim * Sp, Sp, c->ctx_dim, 1, 0, 1, S, XF_NONE, c->kv_all.w[0]), c->kv_all, 0);
     a.y = c->KV; a.y_bstride = (long long)NST * 2 * MC * Sp; a.y_pitch = Sp;
     const LaunchCfg lc = pick_cfg((long long)Be * ((S + 31) / 32), NST * 2 * MC / 32);
     launch_gemm(a, EPI_STORE, Be, lc.NB, lc.KS, s);
@@ -1207,6 +1244,17 @@ int said_profile_unet(said_ctx* ctx, int Be, int T, int reps, int max_stages, fl
 }
 
 int said_graph_num_nodes(const said_ctx* ctx) { return ctx ? ctx->gnodes : 0; }
+
+int said_set_precision(said_ctx* ctx, int bf16_mfma) {
+    if (!ctx) return -1;
+    const bool want = bf16_mfma != 0;
+    if (want != ctx->bf16_mode) {
+        ctx->bf16_mode = want;
+        ctx->gkey.clear();   // the captured step graph holds the other kernels
+    }
+    return 0;
+}
+int said_get_precision(const said_ctx* ctx) { return (ctx && ctx->bf16_mode) ? 1 : 0; }
 
 double said_unet_algorithmic_bytes(int Be, int T, int bytes_per_elem) {
     // W + Be*T*A, A = 63,232 B/token at fp32

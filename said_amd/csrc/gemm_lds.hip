@@ -29,7 +29,11 @@ __device__ __forceinline__ f32x4 bload4(rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int XP = 40;        // LDS tile pitch (floats): col = tin - t0 + 4  (halo at 3 and 36)
+// bf16 MFMA mode (BF): the tile is kept token-major in bf16, X[col = tin - t0 + 1][channel], pitch PB halfs, so that the
+// B operand of v_mfma_f32_32x32x8_bf16_1k — 4 consecutive channels of one token — is a single ds_read_b64
+constexpr int PB = 28;
 constexpr int NRMAX = 3;      // row rounds per block: CB = 8 * NR <= 24 channels
 
 template <int XF>
@@ -73,8 +77,12 @@ enum UVar : int { UV_T3 = 1 /* segment 0 is a 3-tap conv */, UV_GN0 = 2 /* Group
                   UV_GN1 = 4 /* GroupNorm'ed segment 1 (concatenated skip) */, UV_RGN = 8 /* GroupNorm'ed residual */,
                   UV_MULTI = 16 /* more than one K segment: the argument blocks of segments 1, 2 are fetched */ };
 
-template <int NB, int KS, int EPI, int VAR, bool TRANS>
+template <int NB, int KS, int EPI, int VAR, bool TRANS, bool BF>
 __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int bx, int by, int bz) {
+    // BF: operands are rounded to bf16 (weights on the host, activations after the fused transform) and multiplied with
+    // v_mfma_f32_32x32x8_bf16_1k; everything else — statistics, transforms, accumulation, epilogues — stays fp32.
+    using WT = std::conditional_t<BF, float2, f32x4>;   // one lane's weight fragment of an 8-channel round
+    constexpr int WB = BF ? 512 : 1024;                  // bytes per (tile, tap, 8-channel round) in the packed weights
     constexpr int NACC = (EPI == EPI_GEGLU) ? 2 * NB : NB;
     constexpr int NV = NB * 16;
     static_assert(NV % KS == 0, "NB*16 must be divisible by KS");
@@ -116,7 +124,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         const int bmod = hd.bmod_b0 & 0xffff;
         const int sb = bmod > 0 ? b % bmod : b;
         u0.rx = make_rsrc(hd.x + (long long)sb * hd.bstride, (unsigned)C0 * (unsigned)hd.pitch * 4u);
-        u0.rw = make_rsrc(hd.w4, (unsigned)w_tiles * (unsigned)taps0 * (unsigned)(C0 >> 3) * 1024u);
+        u0.rw = make_rsrc(hd.w4, (unsigned)w_tiles * (unsigned)taps0 * (unsigned)(C0 >> 3) * (unsigned)WB);
         u0.c0 = w * cw;
         u0.nr = cb >> 3;
         u0.taps = taps0; u0.Tin = hd.T; u0.pitch4 = hd.pitch * 4; u0.C8 = C0 >> 3; u0.xform = xf0;
@@ -145,15 +153,18 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     constexpr bool ROLL = (NACC >= 8);
     static_assert(!ROLL || TMAX == 1, "rolling weight rounds are for 1-tap GEMMs");
     constexpr int WR = ROLL ? 2 : NRMAX;
-    auto issue_w_round = [&](const UBlock& u, int rr, f32x4 (&wr)[NACC], bool valid) {
+    auto wload = [&](rsrc_t r, int oor, int so) -> WT {
+        if constexpr (BF) return bload2(r, (l * 8) | oor, so);
+        else return bload4(r, (l * 16) | oor, so);   // the range check covers voffset only: soffset is don't-care when masked
+    };
+    auto issue_w_round = [&](const UBlock& u, int rr, WT (&wr)[NACC], bool valid) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) {
             const int oor = (valid && rr < u.nr) ? 0 : (int)0x80000000;
-            const int so = (tile_wo[i] * u.C8 + (u.c0 >> 3) + rr) * 1024;
-            wr[i] = bload4(u.rw, (l * 16) | oor, so);   // the range check covers voffset only: soffset is don't-care when masked
+            wr[i] = wload(u.rw, oor, (tile_wo[i] * u.C8 + (u.c0 >> 3) + rr) * WB);
         }
     };
-    auto issue_w = [&](const UBlock& u, f32x4 (&wv)[TMAX][WR][NACC], bool valid) {
+    auto issue_w = [&](const UBlock& u, WT (&wv)[TMAX][WR][NACC], bool valid) {
         if constexpr (ROLL) {
             issue_w_round(u, 0, wv[0][0], valid);
             issue_w_round(u, 1, wv[0][1], valid);
@@ -165,14 +176,14 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 #pragma unroll
                     for (int i = 0; i < NACC; ++i) {
                         const int oor = (valid && (tap < u.taps) && (rr < u.nr)) ? 0 : (int)0x80000000;
-                        const int so = ((tile_wo[i] * u.taps + tap) * u.C8 + (u.c0 >> 3) + rr) * 1024;
-                        wv[tap][rr][i] = bload4(u.rw, (l * 16) | oor, so);
+                        wv[tap][rr][i] = wload(u.rw, oor, ((tile_wo[i] * u.taps + tap) * u.C8 + (u.c0 >> 3) + rr) * WB);
                     }
         }
     };
 
     // ================= phase 0: requests =================
-    f32x4 xv[NRMAX], wv[TMAX][WR][NACC];
+    f32x4 xv[NRMAX];
+    WT wv[TMAX][WR][NACC];
     float halo;
     // request order matters (vector loads return in order): the statistics partials of a GroupNorm'ed segment 0 head the
     // longest chain (partials -> coefficients -> staging) and need only the header; then the rest of the argument
@@ -181,7 +192,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     rsrc_t grp_rsrc0 = u0.rx, grp_rsrc1 = u0.rx, grp_rsrcr = u0.rx;
     GnP gp0 = {1, 1, hd.T, 1e-5f, nullptr, nullptr};
     if constexpr (GN0) {
-        const float* gb = hd.w4 + (long long)w_tiles * taps0 * (C0 >> 3) * 256;   // gamma[C0], beta[C0] behind the weights
+        const float* gb = hd.w4 + (long long)w_tiles * taps0 * (C0 >> 3) * (WB / 4);   // gamma[C0], beta[C0] behind the weights
         gp0 = {hd.gn_cfg & 0xffff, hd.gn_cfg >> 16, hd.T, ((hd.pack >> 26) & 1) ? 1e-6f : 1e-5f, gb, gb + C0};
         const int bmod = hd.bmod_b0 & 0xffff;
         const int sb = bmod > 0 ? b % bmod : b;
@@ -220,7 +231,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         const int cb = (cw % 24 == 0) ? 24 : cw;   // host guarantees cw % 24 == 0 or cw in {8, 16}
         const int sb = bmod > 0 ? b % bmod : b;
         u.rx = make_rsrc(AS(sv, x) + (long long)sb * AS(sv, x_bstride), (unsigned)sC * (unsigned)pitch * 4u);
-        u.rw = make_rsrc(AS(sv, w4), (unsigned)w_tiles * (unsigned)taps * (unsigned)(sC >> 3) * 1024u);
+        u.rw = make_rsrc(BF ? AS(sv, w2) : AS(sv, w4), (unsigned)w_tiles * (unsigned)taps * (unsigned)(sC >> 3) * (unsigned)WB);
         u.c0 = w * cw + blk * cb;
         u.nr = cb >> 3;
         u.taps = taps; u.Tin = AS(sv, Tin); u.pitch4 = pitch * 4; u.C8 = sC >> 3; u.xform = AS(sv, xform);
@@ -265,7 +276,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     if constexpr (HAS_LN) {   // LayerNorm affine of the wave's channel slice (<= 24 channels): lane c
         const int cw = C0 / KS;
         // gamma[C0], beta[C0] sit behind the weights (after the GroupNorm pair, if any)
-        const float* lnp = hd.w4 + (long long)w_tiles * taps0 * (C0 >> 3) * 256 + (GN0 ? 2 * C0 : 0);
+        const float* lnp = hd.w4 + (long long)w_tiles * taps0 * (C0 >> 3) * (WB / 4) + (GN0 ? 2 * C0 : 0);
         const rsrc_t rg = make_rsrc(lnp, (unsigned)C0 * 8u);
         const int vo = (l < cw) ? (w * cw + l) * 4 : (int)0x80000000;
         ln_g = bload(rg, vo, 0);
@@ -447,7 +458,13 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                     const float v = xf1<XF>(xs[rr][e], gn, mu4[e], rs4[e], ln);
                     o[e] = (t0 + 4 * sq + e < u.Tin) ? v : 0.f;
                 }
-                *reinterpret_cast<f32x4*>(xt + (rr * 8 + sr) * XP + 4 + 4 * sq) = o;
+                if constexpr (BF) {
+                    __bf16* xb = reinterpret_cast<__bf16*>(xt);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xb[(1 + 4 * sq + e) * PB + rr * 8 + sr] = (__bf16)o[e];
+                } else {
+                    *reinterpret_cast<f32x4*>(xt + (rr * 8 + sr) * XP + 4 + 4 * sq) = o;
+                }
             }
         }
         if constexpr (T3) {
@@ -457,7 +474,9 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                     float2 gn = make_float2(1.f, 0.f);
                     if constexpr (GNX) gn = u.cGN[u.c0 + row];
                     const float v = xf1<XF>(hl, gn, 0.f, 1.f, make_float2(1.f, 0.f));
-                    xt[row * XP + ((l & 1) ? 36 : 3)] = ((unsigned)tin < (unsigned)u.Tin) ? v : 0.f;
+                    const float hv = ((unsigned)tin < (unsigned)u.Tin) ? v : 0.f;
+                    if constexpr (BF) reinterpret_cast<__bf16*>(xt)[((l & 1) ? 33 : 0) * PB + row] = (__bf16)hv;
+                    else xt[row * XP + ((l & 1) ? 36 : 3)] = hv;
                 }
             }
         }
@@ -474,7 +493,43 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         }
     };
     // pure ds_read + MFMA loop over the block
-    auto mma_block = [&](const UBlock& u, f32x4 (&ws)[TMAX][WR][NACC]) {
+    auto mma_block = [&](const UBlock& u, WT (&ws)[TMAX][WR][NACC]) {
+        if constexpr (BF) {
+            // token row = lt + tap + 1 - pad; this lane's 4 channels of an 8-channel round start at 4 * lh
+            const __bf16* xb = reinterpret_cast<const __bf16*>(xt) + (lt + ((u.taps == 3) ? 0 : 1)) * PB + 4 * lh;
+            if constexpr (ROLL) {
+#pragma unroll
+                for (int rr = 0; rr < NRMAX; ++rr) {
+                    if (rr < u.nr) {
+                        const s16x4 xf = *reinterpret_cast<const s16x4*>(xb + rr * 8);
+#pragma unroll
+                        for (int i = 0; i < NACC; ++i)
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, ws[0][rr & 1][i]), xf, acc[i], 0, 0, 0);
+                        if (rr == 0 && u.nr > 2) issue_w_round(u, 2, ws[0][0], true);
+                    }
+                }
+                return;
+            } else {
+#pragma unroll
+                for (int tap = 0; tap < TMAX; ++tap) {
+                    if (tap < u.taps) {
+#pragma unroll
+                        for (int rr = 0; rr < NRMAX; ++rr) {
+                            if (rr < u.nr) {
+                                const s16x4 xf = *reinterpret_cast<const s16x4*>(xb + tap * PB + rr * 8);
+#pragma unroll
+                                for (int i = 0; i < NACC; ++i) {
+                                    const s16x4 wf = __builtin_bit_cast(s16x4, ws[tap][rr][i]);
+                                    acc[i] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(xf, wf, acc[i], 0, 0, 0)
+                                                   : __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(wf, xf, acc[i], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                }
+                return;
+            }
+        } else {
         const float* xrow = xt + lh * XP + lt + 3 + ((u.taps == 3) ? 0 : 1);   // col = lt + tap + 4 - pad
         if constexpr (ROLL) {
 #pragma unroll
@@ -512,6 +567,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                 }
             }
         }
+        }
     };
 
     {
@@ -539,7 +595,8 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             }
         } else {
             constexpr int D = (TMAX == 1 && NACC == 1) ? 3 : 2;
-            f32x4 xq[D - 1][NRMAX], wq[D - 1][TMAX][WR][NACC];
+            f32x4 xq[D - 1][NRMAX];
+            WT wq[D - 1][TMAX][WR][NACC];
             float hq[D - 1];
             UBlock uq[D - 1];
             const int last = nblk_total - 1;
@@ -777,7 +834,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     }
 }
 
-template <int NB, int KS, int EPI, int VAR>
+template <int NB, int KS, int EPI, int VAR, bool BF>
 __global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const float* hw4, int hpack, int hpitch, int hT, int hbstride,
                                                         int hbmod_b0, int hN, int hgate_vft, int hnbatch, const float* hgn_part,
                                                         int hgn_bstride, int hgn_cfg, const GemmArgs a) {
@@ -794,11 +851,11 @@ __global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const f
     const int by = L % ny, bz = (L / ny) % nz, bx = L / (ny * nz);
     if constexpr (EPI == EPI_QKV) {
         if (by * NB < hgate_vft) {
-            ugemm_body<NB, KS, EPI, VAR, true>(hd, smem, bx, by, bz);
+            ugemm_body<NB, KS, EPI, VAR, true, BF>(hd, smem, bx, by, bz);
             return;
         }
     }
-    ugemm_body<NB, KS, EPI, VAR, false>(hd, smem, bx, by, bz);
+    ugemm_body<NB, KS, EPI, VAR, false, BF>(hd, smem, bx, by, bz);
 }
 
 template <int NB, int EPI>
@@ -812,7 +869,7 @@ static int ugemm_smem_floats(const GemmArgs& a, int KS) {
 }
 
 constexpr int kMaxLds = 160 * 1024;
-template <int NB, int KS, int EPI, int VAR>
+template <int NB, int KS, int EPI, int VAR, bool BF>
 static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s) {
     int smem = ugemm_smem_floats<NB, EPI>(a, KS) * (int)sizeof(float);
     static const int min_lds = getenv("SAID_MIN_LDS") ? atoi(getenv("SAID_MIN_LDS")) : 0;   // experiment: force one workgroup per CU
@@ -824,12 +881,12 @@ static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s) {
     const int pack = s0.C | (s0.taps << 16) | (s0.xform << 20) | (a.nseg << 24) | ((gn0 && s0.gn_eps == 1e-6f) ? (1 << 26) : 0);
     const int bmod_b0 = (s0.b_mod & 0xffff) | (a.b0 << 16);
     const int gate_vft = (EPI == EPI_GEGLU) ? a.geglu_gate_tiles : a.tm_tiles;
-    hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI, VAR>), grid, dim3(64 * KS), smem, s, s0.x, s0.w4, pack, s0.x_pitch, a.T, (int)s0.x_bstride, bmod_b0,
+    hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI, VAR, BF>), grid, dim3(64 * KS), smem, s, s0.x, BF ? s0.w2 : s0.w4, pack, s0.x_pitch, a.T, (int)s0.x_bstride, bmod_b0,
                        a.N, gate_vft, batch, gn0 ? s0.gn_part : nullptr, (int)s0.gn_part_bstride, s0.gn_cpg | (s0.gn_nparts << 16), a);
 }
-template <int NB, int KS, int EPI, int VAR>
+template <int NB, int KS, int EPI, int VAR, bool BF>
 static void uconfigure_one() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ugemm_kernel<NB, KS, EPI, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ugemm_kernel<NB, KS, EPI, VAR, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
 }
 
 // (epilogue, NB, KS, variant): small-batch tile shapes; large batches use the generic kernel's NB = 3..6 shapes
@@ -848,7 +905,7 @@ static void uconfigure_one() {
 #endif
 
 void configure_ugemm_kernels() {
-#define X(E, nb, ks, var) uconfigure_one<nb, ks, E, var>();
+#define X(E, nb, ks, var) uconfigure_one<nb, ks, E, var, false>(); uconfigure_one<nb, ks, E, var, true>();
     SAID_UGEMM_CONFIGS(X)
 #undef X
 }
@@ -866,7 +923,7 @@ static int uvar_of(const GemmArgs& a, int epi) {
 
 // The LDS-staged kernel covers stride-1, k in {1,3}, ungrouped GEMMs whose per-wave channel slice is a
 // multiple of 24 (or 8 / 16); everything else stays on the generic kernel.
-bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS) {
+bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16) {
     bool cfg = false;
     const int var = uvar_of(a, epi);
 #define X(E, nb, ks, v) cfg = cfg || (epi == E && NB == nb && KS == ks && var == (v));
@@ -901,6 +958,7 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS) {
     }
     for (int s = 0; s < a.nseg; ++s) {
         const Seg& sg = a.seg[s];
+        if (bf16 && !sg.w2) return false;
         if (!sg.w4 || sg.stride != 1 || !(sg.taps == 1 || sg.taps == 3) || sg.pad != (sg.taps - 1) / 2) return false;
         if (sg.taps == 3 && epi != EPI_STORE) return false;
         if (sg.C % KS) return false;
@@ -912,10 +970,14 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS) {
     return true;
 }
 
-void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s) {
+void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s, bool bf16) {
     const int var = uvar_of(a, epi);
 #define X(E, nb, ks, v) \
-    if (epi == E && NB == nb && KS == ks && var == (v)) { ulaunch_one<nb, ks, E, v>(a, batch, s); return; }
+    if (epi == E && NB == nb && KS == ks && var == (v)) {                   \
+        if (bf16) ulaunch_one<nb, ks, E, v, true>(a, batch, s);             \
+        else ulaunch_one<nb, ks, E, v, false>(a, batch, s);                 \
+        return;                                                             \
+    }
     SAID_UGEMM_CONFIGS(X)
 #undef X
     fprintf(stderr, "said: unsupported ugemm config epi=%d NB=%d KS=%d\n", epi, NB, KS);

@@ -29,6 +29,8 @@ struct SegFields {
     const float* x;        // source, channel 0 of this segment, batch 0
     const float* w;        // packed weights [groups][ntiles][taps][C/2][64]
     const float* w4;       // same weights packed for dwordx4 fetch [ntiles][taps][C/8][64 lanes][4 k-pairs] (or null)
+    const float* w2;       // bf16 packing for v_mfma_f32_32x32x8_bf16_1k: [ntiles][taps][C/8][64 lanes][4 bf16], value j of
+                           // lane l = W[tile*32 + (l&31)][8*cq + 4*(l>>5) + j][tap]; same tails as w4 (or null)
     const float* gn_part;  // GN partial stats of the source [B][C][nparts][2] (mean, M2), channel 0 of segment
     const float* gn_gamma; // GN affine (segment channel 0)
     const float* gn_beta;
@@ -130,8 +132,9 @@ struct AttnArgs {
 void launch_gemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s);
 void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s);
 // LDS-staged UNet GEMM (gemm_lds.hip): same arguments; only for shapes ugemm_supports() accepts
-bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS);
-void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s);
+// bf16 = true: multiply in bf16 (v_mfma_f32_32x32x8_bf16_1k; needs Seg::w2), everything else stays fp32
+bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16 = false);
+void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s, bool bf16 = false);
 void configure_ugemm_kernels();
 
 // token-major (B,T,C) <-> channel-major [B][C][pitch]

@@ -78,6 +78,7 @@ class SAID(ABC, nn.Module):
             self.null_cond_emb = nn.Parameter(torch.randn(1, 1, hidden))
         self._eng: Optional[_engine.Engine] = None
         self._eng_key = None
+        self.mfma_dtype = "fp32"   # "bf16": bf16 multiplies in the UNet GEMMs (BASELINE.json configs[2]); set_mfma_dtype()
         self.audio_encoder._owner = weakref.ref(self)
 
     # ---- engine management ---------------------------------------------------
@@ -102,7 +103,16 @@ class SAID(ABC, nn.Module):
             e.load_weights(self.state_dict())
             self._eng, self._eng_key = e, key
             self.noise_scheduler._engine = e
+        e.set_precision(self.mfma_dtype == "bf16")
         return e
+
+    def set_mfma_dtype(self, dtype: str) -> "SAID":
+        """"fp32" (default; the reference's precision) or "bf16": operands of the UNet GEMMs / convolutions are rounded
+        to bfloat16, accumulation and everything else stays fp32.  Not part of the reference surface."""
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError(f"mfma dtype must be 'fp32' or 'bf16', got {dtype!r}")
+        self.mfma_dtype = dtype
+        return self
 
     # ---- reference surface -----------------------------------------------------
     def forward(self, noisy_samples: torch.FloatTensor, timesteps: torch.LongTensor, audio_embedding: torch.FloatTensor) -> torch.FloatTensor:

@@ -357,3 +357,48 @@ def test_batch32_matches_single_clip_runs(model, dev):
     for i in (0, 17, 31):
         one = model.inference(wav[i:i + 1], audio_embedding=ctx[i:i + 1], num_inference_steps=N, guidance_scale=2.0, init_latents=lat[i:i + 1]).result
         assert float((big[i:i + 1] - one).abs().max()) <= 2e-5
+
+
+# ---------------------------------------------------------------- bf16 multiplies (BASELINE.json configs[2])
+def test_bf16_mfma_mode_error_vs_fp32_oracle(model, unet_sd, dev):
+    """configs[2] precision: operands of the UNet GEMMs rounded to bf16, fp32 accumulation / statistics / storage.
+    No bit-exactness claim: the error against the fp32 oracle is bounded and reported; the switch must
+    actually change the arithmetic and must be reversible."""
+    B, T = 2, 600
+    x = synth.synth_latents(21, (B, T, 32))
+    c = synth.synth_latents(121, (B, T, 768))
+    ts = torch.tensor([999, 17])
+    ref = ou.unet1d_forward(unet_sd, x, ts, c)
+    scale = float(ref.abs().max())
+    o32 = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+    try:
+        model.set_mfma_dtype("bf16")
+        o16 = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+        assert model._eng.get_precision() == "bf16"
+    finally:
+        model.set_mfma_dtype("fp32")
+    e16 = float((o16 - ref).abs().max()) / scale
+    rms = float((o16 - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f"bf16 UNet: max err {e16:.2e} of range, rms rel {rms:.2e}")
+    assert 1e-5 < e16 <= 2e-2 and rms <= 2e-2          # measured 5.8e-3 / 5.9e-3
+    again = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+    assert torch.equal(again, o32) and float((o32 - ref).abs().max()) <= 1e-4 * scale
+
+
+def test_bf16_loop_cfg_batch32_shape(model, dev):
+    """configs[2] shape (32 clips, guidance, T=600) in bf16 for a few steps against the same loop in fp32: finite,
+    clamped, close (random-weight networks amplify rounding over long chains, so the chain is kept short)."""
+    B, T, N = 32, 600, 3
+    ctx = synth.synth_latents(130, (B, T, 768)).to(dev)
+    lat = synth.synth_latents(131, (B, T, 32)).to(dev)
+    wav = torch.zeros(B, T * 16000 // 60, device=dev)
+    r32 = model.inference(wav, audio_embedding=ctx, num_inference_steps=N, guidance_scale=2.0, init_latents=lat).result
+    try:
+        model.set_mfma_dtype("bf16")
+        r16 = model.inference(wav, audio_embedding=ctx, num_inference_steps=N, guidance_scale=2.0, init_latents=lat).result
+    finally:
+        model.set_mfma_dtype("fp32")
+    assert torch.isfinite(r16).all() and float(r16.min()) >= 0 and float(r16.max()) <= 1
+    d = (r16 - r32).abs()
+    print(f"bf16 loop: max abs diff {float(d.max()):.3e}, mean {float(d.mean()):.3e}")
+    assert float(d.mean()) <= 1e-2 and float(d.max()) <= 0.25
