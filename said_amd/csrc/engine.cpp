@@ -351,7 +351,27 @@ inline bool dbg_go(said_ctx* c) {
 }
 
 // algorithmic HBM bytes / flops of one launch: weights + operands in + residual + result out
+// Multi-tile workgroups (gemm_lds.hip, MT): once a launch would have several thousand workgroups, each workgroup walks
+// over `tt` consecutive token tiles instead, keeping its weights in registers; tt is chosen so that ~4 workgroups per
+// CU remain.  Returns 1 when the launch is not eligible.
+static int pick_tt(said_ctx* c, const GemmArgs& a, int epi, int batch, int& NB, int KS, bool bf) {
+    static const bool mt_off = getenv("SAID_NO_MT") != nullptr;
+    if (mt_off || !c->use_ugemm || a.step_inc) return 1;
+    if (epi == EPI_GEGLU || epi == EPI_BAND) return 1;   // measured slower multi-tile (B=32: GEGLU NB=2 x tt vs NB=4, band)
+    int nb = NB;
+    const long long ntt = (a.T + 31) / 32;
+    const long long wgs = ntt * (a.ntiles_per_group / nb) * batch;
+    int tt = (int)std::min<long long>(std::min<long long>(8, wgs / 1024), ntt);
+    if (tt <= 1 || !ugemm_supports(a, epi, nb, KS, bf, tt)) return 1;
+    NB = nb;
+    return tt;
+}
+
 void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s) {
+    GemmArgs a2 = a;
+    a2.b0 = c->cur_b0;
+    const bool bf = c->bf16_mode;
+    const int tt = pick_tt(c, a2, epi, batch, NB, KS, bf);
     if (c->log_on) {
         double w = 0, in = 0, fl = 0;
         const double nout = (double)a.groups * a.N * (epi == EPI_GEGLU ? 2 : 1);
@@ -364,15 +384,15 @@ void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS,
         double out = (double)batch * a.groups * a.N * a.T * 4.0;
         if (a.res_kind != RES_NONE) in += out;
         if (epi == EPI_BAND) in += 2.0 * batch * a.N * a.T * 4.0;  // this block's K and V rows
-        c->stage_log.push_back({(c->use_ugemm && ugemm_supports(a, epi, NB, KS, c->bf16_mode)) ? 2 : 0, epi, NB, KS, w + in + out, fl});
+        c->stage_log.push_back({(c->use_ugemm && (tt > 1 || ugemm_supports(a, epi, NB, KS, bf) || ugemm_supports(a, epi, NB, KS))) ? 2 : 0, epi, NB, KS, w + in + out, fl});
     }
-    GemmArgs a2 = a;
-    a2.b0 = c->cur_b0;
     if (c->clk_on && c->dbg_count < 64) a2.clk = c->clk_dev + (long long)c->dbg_count * 128;
     if (dbg_go(c)) {
-        if (trace_on()) { fprintf(stderr, "[said] gemm #%d epi=%d NB=%d KS=%d T=%d N=%d batch=%d\n", c->dbg_count - 1, epi, NB, KS, a.T, a.N, batch); fflush(stderr); }
-        if (c->use_ugemm && !a2.step_inc && c->bf16_mode && ugemm_supports(a2, epi, NB, KS, true)) launch_ugemm(a2, epi, batch, NB, KS, s, true);
-        else if (c->use_ugemm && !a2.step_inc && ugemm_supports(a2, epi, NB, KS)) launch_ugemm(a2, epi, batch, NB, KS, s);
+        if (trace_on()) { fprintf(stderr, "[said] gemm #%d epi=%d NB=%d KS=%d T=%d N=%d batch=%d tt=%d\n", c->dbg_count - 1, epi, NB, KS, a.T, a.N, batch, tt); fflush(stderr); }
+        const bool ug = c->use_ugemm && !a2.step_inc;
+        if (tt > 1) launch_ugemm(a2, epi, batch, NB, KS, s, bf, tt);
+        else if (ug && bf && ugemm_supports(a2, epi, NB, KS, true)) launch_ugemm(a2, epi, batch, NB, KS, s, true);
+        else if (ug && ugemm_supports(a2, epi, NB, KS)) launch_ugemm(a2, epi, batch, NB, KS, s);
         else launch_gemm(a2, epi, batch, NB, KS, s);
         if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
     }
@@ -434,7 +454,7 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
 void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const ActBuf& in, const ActBuf& out, hipStream_t s) {
     const long long tt = (long long)g.Be * ((g.T + 31) / 32);
     const bool big = big_cgemm() && tt * 6 > 1536;
-    const bool big_qkv = tt * 6 > 1536 && !getenv("SAID_QKV_UGEMM") && !c->bf16_mode;   // q/k/v: the generic NB=6 shape is faster at large batch (30 vs 24 TFLOP/s)
+    const bool big_qkv = tt * 6 > 1536 && getenv("SAID_NO_MT") && !c->bf16_mode;   // without multi-tile workgroups the generic NB=6 shape wins in fp32   // q/k/v: the generic NB=6 shape is faster at large batch (30 vs 24 TFLOP/s)
     const int vt_rows = rup(g.T, 32);
     {   // x = norm(x) (GroupNorm eps 1e-6); q,k,v = to_{q,k,v}(norm1(x))   (attention.py:227, 168, 93-97)
         GemmArgs a = mkargs(g.T, 3 * MC);

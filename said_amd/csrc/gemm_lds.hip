@@ -77,8 +77,13 @@ enum UVar : int { UV_T3 = 1 /* segment 0 is a 3-tap conv */, UV_GN0 = 2 /* Group
                   UV_GN1 = 4 /* GroupNorm'ed segment 1 (concatenated skip) */, UV_RGN = 8 /* GroupNorm'ed residual */,
                   UV_MULTI = 16 /* more than one K segment: the argument blocks of segments 1, 2 are fetched */ };
 
-template <int NB, int KS, int EPI, int VAR, bool TRANS, bool BF>
+template <int NB, int KS, int EPI, int VAR, bool TRANS, bool BF, bool MT>
 __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int bx, int by, int bz) {
+    // MT (multi-tile, large batches): the workgroup walks over up to `tt_run` consecutive 32-token tiles of one sample.
+    // Weights, arguments and GroupNorm coefficients are fetched / finalised ONCE and stay in registers / LDS; per tile
+    // only X (requested one tile ahead), the per-tile epilogue operands and the LayerNorm statistics are new.  At large
+    // batch the per-tile weight re-fetch (147 of 171 KB for a two-tile conv workgroup) is what saturates a CU's load
+    // path.  Single-block launches only (the host checks).
     // BF: operands are rounded to bf16 (weights on the host, activations after the fused transform) and multiplied with
     // v_mfma_f32_32x32x8_bf16_1k; everything else — statistics, transforms, accumulation, epilogues — stays fp32.
     using WT = std::conditional_t<BF, float2, f32x4>;   // one lane's weight fragment of an 8-channel round
@@ -98,7 +103,10 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = bz + (hd.bmod_b0 >> 16);
-    const int t0 = bx * 32;
+    const int tt_run = MT ? ((hd.pack >> 28) & 15) : 1;   // tiles per workgroup
+    const int ntt_all = (hd.T + 31) >> 5;
+    const int ntr = MT ? min(tt_run, ntt_all - bx * tt_run) : 1;
+    int t0 = bx * tt_run * 32;   // first token of the current tile
     const int tile0 = by * NB;
     const int nseg = MULTI ? ((hd.pack >> 24) & 3) : 1, aT = hd.T, aN = hd.N;
     const int gate_tiles = (EPI == EPI_GEGLU) ? hd.gate_vft : 0;
@@ -134,23 +142,25 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 
     // raw X slice of a block -> registers: NR dwordx4 (row sr of each round, tokens t0+4*sq..+3) + halo dwords.
     // `valid` = false turns every request into an out-of-range one (software-pipeline tail).
-    auto issue_x = [&](const UBlock& u, f32x4 (&xv)[NRMAX], float& halo, bool valid) {
+    auto issue_x_at = [&](const UBlock& u, f32x4 (&xv)[NRMAX], float& halo, bool valid, int tb) {
 #pragma unroll
         for (int rr = 0; rr < NRMAX; ++rr) {
             const int oor = (valid && rr < u.nr) ? 0 : (int)0x80000000;   // scalar select, no branch
-            xv[rr] = bload4(u.rx, (sr * u.pitch4 + (t0 + 4 * sq) * 4) | oor, (u.c0 + rr * 8) * u.pitch4);
+            xv[rr] = bload4(u.rx, (sr * u.pitch4 + (tb + 4 * sq) * 4) | oor, (u.c0 + rr * 8) * u.pitch4);
         }
         halo = 0.f;
-        if constexpr (T3) {   // lane -> (row = l >> 1, side = l & 1): token t0-1 or t0+32
-            const int row = l >> 1, tin = (l & 1) ? (t0 + 32) : (t0 - 1);
+        if constexpr (T3) {   // lane -> (row = l >> 1, side = l & 1): token tb-1 or tb+32
+            const int row = l >> 1, tin = (l & 1) ? (tb + 32) : (tb - 1);
             const bool ok = valid && (u.taps == 3) && (row < u.nr * 8) && ((unsigned)tin < (unsigned)u.Tin);
             halo = bload(u.rx, ok ? (row * u.pitch4 + tin * 4) : (int)0x80000000, u.c0 * u.pitch4);
         }
     };
+    auto issue_x = [&](const UBlock& u, f32x4 (&xv)[NRMAX], float& halo, bool valid) { issue_x_at(u, xv, halo, valid, t0); };
     // With 8 accumulator tiles the weight fragments of a whole block (3 rounds x 8 tiles x 4 registers) no longer fit
     // beside the accumulators: ROLL keeps two rounds in flight and requests round 2 into round 0's registers once
     // round 0 has been multiplied (it lands during round 1's 32 MFMAs).
-    constexpr bool ROLL = (NACC >= 8);
+    constexpr bool ROLL = (NACC >= 8) && !BF;   // bf16 fragments are half the size: all three rounds fit
+    static_assert(!(MT && ROLL), "multi-tile mode keeps every weight fragment in registers");
     static_assert(!ROLL || TMAX == 1, "rolling weight rounds are for 1-tap GEMMs");
     constexpr int WR = ROLL ? 2 : NRMAX;
     auto wload = [&](rsrc_t r, int oor, int so) -> WT {
@@ -289,22 +299,38 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     // null-safe descriptors: a null pointer becomes an empty range, every load from it returns 0
     const int nbias = (EPI == EPI_GEGLU) ? (gate_tiles * 32 + aN) : aN;
     const rsrc_t r_bias = make_rsrc(e_biasp, e_biasp ? (unsigned)nbias * 4u : 0u);
+    const bool has_res = (EPI == EPI_STORE) && res_kind != RES_NONE;
+    const int res_pitch = AH(res_pitch);
+    const rsrc_t r_res = make_rsrc(AH(res) + (has_res ? (long long)b * AH(res_bstride) : 0LL), has_res ? (unsigned)aN * (unsigned)res_pitch * 4u : 0u);
+    int band_lo = 0, band_hi = 0;
+    // operands that change from tile to tile: residual rows and the alignment window of the tile's queries
+    auto issue_tile_operands = [&](int tb) {
+        if (EPRE) {
+#pragma unroll
+            for (int j = 0; j < VPW; ++j) {
+                const int v = w + j * KS;
+                const int i = v >> 4, r = v & 15;
+                const int nl = (tile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int t = tb + lt;
+                e_res[j] = bload(r_res, (nl < aN && t < aT) ? (nl * res_pitch + t) * 4 : (int)0x80000000, 0);
+            }
+        }
+        if constexpr (EPI == EPI_BAND) {
+            const int t = tb + (tid & 31);
+            const rsrc_t rlo = make_rsrc(AB(lo), (unsigned)aT * 4u), rhi = make_rsrc(AB(hi), (unsigned)aT * 4u);
+            band_lo = __builtin_bit_cast(int, bload(rlo, t * 4, 0));
+            band_hi = __builtin_bit_cast(int, bload(rhi, t * 4, 0));
+        }
+    };
     if (EPRE) {
         const float* embp = AH(emb);
         int erow = 0;
         if (embp) { const int* sp = AH(step_ptr); erow = (sp ? *sp : 0) + b * AH(emb_b_stride); }
         const int emb_pitch = AH(emb_pitch);
-        const float* resp = AH(res);
-        const bool has_res = (EPI == EPI_STORE) && res_kind != RES_NONE;
-        const int res_pitch = AH(res_pitch);
-        const rsrc_t r_res = make_rsrc(resp + (has_res ? (long long)b * AH(res_bstride) : 0LL), has_res ? (unsigned)aN * (unsigned)res_pitch * 4u : 0u);
 #pragma unroll
         for (int j = 0; j < VPW; ++j) {
             const int v = w + j * KS;
             const int i = v >> 4, r = v & 15;
-            const int nl = (tile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int t = t0 + lt;
-            const bool nok = nl < aN;
             // bias and timestep-embedding term are per-row constants: two uniform addresses per row (lane halves) ->
             // scalar loads, which do not occupy the CU's vector address path
             const int na = (tile0 + i) * 32 + (r & 3) + 8 * (r >> 2), nb = na + 4;
@@ -313,22 +339,15 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             const float m_b = (embp && nb < aN) ? embp[(long long)nb * emb_pitch + erow] : 0.f;
             e_bias[j] = lh ? b_b : b_a;
             e_emb[j] = lh ? m_b : m_a;
-            e_res[j] = bload(r_res, (nok && t < aT) ? (nl * res_pitch + t) * 4 : (int)0x80000000, 0);
         }
     }
+    issue_tile_operands(t0);
     // GEGLU: the value and gate biases of the workgroup's tiles go through LDS (one load per thread, requested here)
     float geglu_bias = 0.f;
     if constexpr (EPI == EPI_GEGLU) {
         const int half = tid / (32 * NB), k = tid % (32 * NB);
         const int nl = tile0 * 32 + k;
         geglu_bias = bload(r_bias, (tid < 64 * NB && nl < aN) ? (nl + half * gate_tiles * 32) * 4 : (int)0x80000000, 0);
-    }
-    int band_lo = 0, band_hi = 0;
-    if constexpr (EPI == EPI_BAND) {
-        const int t = t0 + (tid & 31);
-        const rsrc_t rlo = make_rsrc(AB(lo), (unsigned)aT * 4u), rhi = make_rsrc(AB(hi), (unsigned)aT * 4u);
-        band_lo = __builtin_bit_cast(int, bload(rlo, t * 4, 0));
-        band_hi = __builtin_bit_cast(int, bload(rhi, t * 4, 0));
     }
     clk_stamp_p(clkp, w, l, 1);
 
@@ -358,6 +377,16 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     }
     clk_stamp_p(clkp, w, l, 2);
 
+    // next tile's X (MT): requested before the current tile is staged
+    f32x4 xvn[MT ? NRMAX : 1];
+    float halon = 0.f;
+    f32x4 lnrefn = {0.f, 0.f, 0.f, 0.f};
+    for (int ti = 0; ti < ntr; ++ti) {
+    if constexpr (MT) {
+        const bool more = ti + 1 < ntr;
+        issue_x_at(u0, xvn, halon, more, t0 + 32);
+        if constexpr (HAS_LN) lnrefn = bload4(u0.rx, ((t0 + 32 + 4 * sq) * 4) | (more ? 0 : (int)0x80000000), 0);
+    }
     // ================= phase 2: LayerNorm statistics from the staged registers =================
     f32x4 mu4 = {0.f, 0.f, 0.f, 0.f}, rs4 = {1.f, 1.f, 1.f, 1.f};
     if constexpr (HAS_LN) {   // single block (host guarantees C/KS == CB), taps == 1
@@ -581,7 +610,10 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             if (i < nb0 + nb1) return make_block(1, i - nb0);
             return make_block(2, i - nb0 - nb1);
         };
-        if (ROLL || nblk_total == 1) {   // ROLL: the host guarantees a single block
+        if constexpr (MT) {   // the host guarantees a single block: no block pipeline (and none of its registers)
+            stage(u0, xv, halo);
+            mma_block(u0, wv);
+        } else if (ROLL || nblk_total == 1) {   // ROLL: the host guarantees a single block
             stage(u0, xv, halo);
             clk_stamp_p(clkp, w, l, 5);
             mma_block(u0, wv);
@@ -648,7 +680,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     if (EPI == EPI_GEGLU && tid < 64 * NB) epiS[tid] = geglu_bias;
     __syncthreads();
     clk_stamp_p(clkp, w, l, 7);
-    float* red = mainS;
+    float* red = MT ? mainS + coef_total : mainS;   // MT: the coefficient tables live on for the next tile
     // RP reduction passes: GEGLU with 4 value + 4 gate tiles would need 256 KB for one pass, so the value tiles and the
     // gate tiles go through the same buffer one after the other (the summation order per element is unchanged)
     constexpr int RP = (KS * NACC * 16 * 64 * 4 > 128 * 1024) ? 2 : 1;
@@ -766,7 +798,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             const float d = (t < aT) ? (val - mean) : 0.f;
             const float m2 = half32_sum(d * d);
             if (lt == 0 && nl < aN) {
-                float* so = statsp + (long long)b * AH(stats_bstride) + ((long long)ng * nparts_out + bx) * 2;
+                float* so = statsp + (long long)b * AH(stats_bstride) + ((long long)ng * nparts_out + (t0 >> 5)) * 2;
                 so[0] = mean;
                 so[1] = m2;
             }
@@ -832,9 +864,21 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             }
         }
     }
+    if constexpr (MT) {
+        if (ti + 1 < ntr) {
+            __syncthreads();   // everybody is done with this tile's LDS (reduction buffer, band scratch)
+#pragma unroll
+            for (int rr = 0; rr < NRMAX; ++rr) xv[rr] = xvn[rr];
+            halo = halon;
+            lnref = lnrefn;
+            t0 += 32;
+            issue_tile_operands(t0);
+        }
+    }
+    }   // tile loop
 }
 
-template <int NB, int KS, int EPI, int VAR, bool BF>
+template <int NB, int KS, int EPI, int VAR, bool BF, bool MT>
 __global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const float* hw4, int hpack, int hpitch, int hT, int hbstride,
                                                         int hbmod_b0, int hN, int hgate_vft, int hnbatch, const float* hgn_part,
                                                         int hgn_bstride, int hgn_cfg, const GemmArgs a) {
@@ -851,42 +895,45 @@ __global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const f
     const int by = L % ny, bz = (L / ny) % nz, bx = L / (ny * nz);
     if constexpr (EPI == EPI_QKV) {
         if (by * NB < hgate_vft) {
-            ugemm_body<NB, KS, EPI, VAR, true, BF>(hd, smem, bx, by, bz);
+            ugemm_body<NB, KS, EPI, VAR, true, BF, MT>(hd, smem, bx, by, bz);
             return;
         }
     }
-    ugemm_body<NB, KS, EPI, VAR, false, BF>(hd, smem, bx, by, bz);
+    ugemm_body<NB, KS, EPI, VAR, false, BF, MT>(hd, smem, bx, by, bz);
 }
 
 template <int NB, int EPI>
-static int ugemm_smem_floats(const GemmArgs& a, int KS) {
+static int ugemm_smem_floats(const GemmArgs& a, int KS, bool mt = false) {
     constexpr int NACC = (EPI == EPI_GEGLU) ? 2 * NB : NB;
     int coef = 0;
     for (int s = 0; s < a.nseg; ++s) coef += seg_coef_floats(a.seg[s]);
     const int stage = coef + KS * 64 + KS * 8 * NRMAX * XP;
     const int red = (KS * NACC * 16 * 64 * 4 > 128 * 1024) ? KS * (NACC / 2) * 16 * 64 : KS * NACC * 16 * 64;
-    return epi_scratch_floats<NACC>(EPI, KS) + KS * GN_SCRATCH + (stage > red ? stage : red);
+    const int red_end = mt ? coef + red : red;   // multi-tile: the reduction buffer sits behind the coefficient tables
+    return epi_scratch_floats<NACC>(EPI, KS) + KS * GN_SCRATCH + (stage > red_end ? stage : red_end);
 }
 
 constexpr int kMaxLds = 160 * 1024;
-template <int NB, int KS, int EPI, int VAR, bool BF>
-static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s) {
-    int smem = ugemm_smem_floats<NB, EPI>(a, KS) * (int)sizeof(float);
+template <int NB, int KS, int EPI, int VAR, bool BF, bool MT>
+static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s, int tt) {
+    int smem = ugemm_smem_floats<NB, EPI>(a, KS, MT) * (int)sizeof(float);
     static const int min_lds = getenv("SAID_MIN_LDS") ? atoi(getenv("SAID_MIN_LDS")) : 0;   // experiment: force one workgroup per CU
     if (smem < min_lds) smem = min_lds;
     if (smem > kMaxLds) { fprintf(stderr, "said: ugemm needs %d B of LDS\n", smem); abort(); }
-    dim3 grid(((a.T + 31) / 32) * (a.ntiles_per_group / NB) * batch);   // 1-D: decoded XCD-aware in the kernel
+    const int ntt = (a.T + 31) / 32;
+    dim3 grid(((MT ? (ntt + tt - 1) / tt : ntt)) * (a.ntiles_per_group / NB) * batch);   // 1-D: decoded XCD-aware in the kernel
     const Seg& s0 = a.seg[0];
     const bool gn0 = s0.xform == XF_GN_SILU || s0.xform == XF_GN_LN;
-    const int pack = s0.C | (s0.taps << 16) | (s0.xform << 20) | (a.nseg << 24) | ((gn0 && s0.gn_eps == 1e-6f) ? (1 << 26) : 0);
+    const int pack = s0.C | (s0.taps << 16) | (s0.xform << 20) | (a.nseg << 24) | ((gn0 && s0.gn_eps == 1e-6f) ? (1 << 26) : 0) |
+                     ((MT ? tt : 0) << 28);
     const int bmod_b0 = (s0.b_mod & 0xffff) | (a.b0 << 16);
     const int gate_vft = (EPI == EPI_GEGLU) ? a.geglu_gate_tiles : a.tm_tiles;
-    hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI, VAR, BF>), grid, dim3(64 * KS), smem, s, s0.x, BF ? s0.w2 : s0.w4, pack, s0.x_pitch, a.T, (int)s0.x_bstride, bmod_b0,
+    hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI, VAR, BF, MT>), grid, dim3(64 * KS), smem, s, s0.x, BF ? s0.w2 : s0.w4, pack, s0.x_pitch, a.T, (int)s0.x_bstride, bmod_b0,
                        a.N, gate_vft, batch, gn0 ? s0.gn_part : nullptr, (int)s0.gn_part_bstride, s0.gn_cpg | (s0.gn_nparts << 16), a);
 }
-template <int NB, int KS, int EPI, int VAR, bool BF>
+template <int NB, int KS, int EPI, int VAR, bool BF, bool MT>
 static void uconfigure_one() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ugemm_kernel<NB, KS, EPI, VAR, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ugemm_kernel<NB, KS, EPI, VAR, BF, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
 }
 
 // (epilogue, NB, KS, variant): small-batch tile shapes; large batches use the generic kernel's NB = 3..6 shapes
@@ -904,9 +951,25 @@ static void uconfigure_one() {
     X(EPI_BAND, 1, 8, 0)
 #endif
 
+// multi-tile shapes (large batches; single-block launches).  fp32 GEGLU uses NB = 2: with 8 accumulator tiles the
+// weight fragments only fit by rolling them through the registers, which a multi-tile workgroup cannot do.
+#ifdef SAID_DEV_ONE_CONFIG
+#define SAID_UGEMM_MT_CONFIGS(X)
+#else
+#define SAID_UGEMM_MT_CONFIGS(X)                                                                   \
+    X(EPI_STORE, 2, 8, 0, 0) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0, 0) X(EPI_STORE, 1, 8, UV_RGN, 0)   \
+    X(EPI_STORE, 2, 8, 0, 1) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0, 1) X(EPI_STORE, 1, 8, UV_RGN, 1)   \
+    X(EPI_QKV, 3, 8, UV_GN0, 0) X(EPI_QKV, 3, 8, UV_GN0, 1)                                        \
+    X(EPI_GEGLU, 2, 8, 0, 0) X(EPI_GEGLU, 2, 8, 0, 1)                                              \
+    X(EPI_BAND, 1, 8, 0, 0) X(EPI_BAND, 1, 8, 0, 1)
+#endif
+
 void configure_ugemm_kernels() {
-#define X(E, nb, ks, var) uconfigure_one<nb, ks, E, var, false>(); uconfigure_one<nb, ks, E, var, true>();
+#define X(E, nb, ks, var) uconfigure_one<nb, ks, E, var, false, false>(); uconfigure_one<nb, ks, E, var, true, false>();
     SAID_UGEMM_CONFIGS(X)
+#undef X
+#define X(E, nb, ks, var, bf) uconfigure_one<nb, ks, E, var, bf != 0, true>();
+    SAID_UGEMM_MT_CONFIGS(X)
 #undef X
 }
 
@@ -923,9 +986,17 @@ static int uvar_of(const GemmArgs& a, int epi) {
 
 // The LDS-staged kernel covers stride-1, k in {1,3}, ungrouped GEMMs whose per-wave channel slice is a
 // multiple of 24 (or 8 / 16); everything else stays on the generic kernel.
-bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16) {
+bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16, int tt) {
     bool cfg = false;
     const int var = uvar_of(a, epi);
+    if (tt > 1) {   // multi-tile: own shape list, one K block per wave, at most 15 tiles per workgroup
+        bool mt = false;
+#define X(E, nb, ks, v, bf) mt = mt || (epi == E && NB == nb && KS == ks && var == (v) && bf16 == (bf != 0));
+        SAID_UGEMM_MT_CONFIGS(X)
+#undef X
+        const int cw = a.seg[0].C / KS;
+        if (!mt || tt > 15 || a.nseg != 1 || !(cw == 24 || cw == 8 || cw == 16)) return false;
+    }
 #define X(E, nb, ks, v) cfg = cfg || (epi == E && NB == nb && KS == ks && var == (v));
     SAID_UGEMM_CONFIGS(X)
 #undef X
@@ -970,12 +1041,18 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16) {
     return true;
 }
 
-void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s, bool bf16) {
+void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s, bool bf16, int tt) {
     const int var = uvar_of(a, epi);
+    if (tt > 1) {
+#define X(E, nb, ks, v, bf) \
+        if (epi == E && NB == nb && KS == ks && var == (v) && bf16 == (bf != 0)) { ulaunch_one<nb, ks, E, v, bf != 0, true>(a, batch, s, tt); return; }
+        SAID_UGEMM_MT_CONFIGS(X)
+#undef X
+    }
 #define X(E, nb, ks, v) \
     if (epi == E && NB == nb && KS == ks && var == (v)) {                   \
-        if (bf16) ulaunch_one<nb, ks, E, v, true>(a, batch, s);             \
-        else ulaunch_one<nb, ks, E, v, false>(a, batch, s);                 \
+        if (bf16) ulaunch_one<nb, ks, E, v, true, false>(a, batch, s, 1);   \
+        else ulaunch_one<nb, ks, E, v, false, false>(a, batch, s, 1);       \
         return;                                                             \
     }
     SAID_UGEMM_CONFIGS(X)

@@ -133,8 +133,9 @@ void launch_gemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStrea
 void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s);
 // LDS-staged UNet GEMM (gemm_lds.hip): same arguments; only for shapes ugemm_supports() accepts
 // bf16 = true: multiply in bf16 (v_mfma_f32_32x32x8_bf16_1k; needs Seg::w2), everything else stays fp32
-bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16 = false);
-void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s, bool bf16 = false);
+// tt > 1: multi-tile workgroups (each walks over tt consecutive 32-token tiles keeping its weights in registers)
+bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16 = false, int tt = 1);
+void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s, bool bf16 = false, int tt = 1);
 void configure_ugemm_kernels();
 
 // token-major (B,T,C) <-> channel-major [B][C][pitch]
