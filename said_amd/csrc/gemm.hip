@@ -672,6 +672,10 @@ void launch_gemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStrea
     if (epi == E && NB == nb && KS == ks) { launch_one<nb, ks, E>(a, batch, s); return; }
     SAID_GEMM_CONFIGS(X)
 #undef X
+    // A tile shape chosen for the LDS-staged kernel that this kernel does not instantiate (the launch was not eligible
+    // there after all): every epilogue exists as one tile x 8 waves, and the q/k/v token-major split needs
+    // tm_tiles % NB == 0, which NB = 1 always satisfies.
+    if (!(NB == 1 && KS == 8)) { launch_gemm(a, epi, batch, 1, 8, s); return; }
     fprintf(stderr, "said: unsupported gemm config epi=%d NB=%d KS=%d\n", epi, NB, KS);
     abort();
 }
