@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-SAID_NO_UGEMM=1 timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "not bf16" 2>&1 | tail -4
+timeout 900 python -m pytest tests -q -x -m gpu 2>&1 | tail -3
+timeout 300 python bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_roofline 2>&1 | tail -1 | cut -c1-330
