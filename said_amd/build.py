@@ -45,6 +45,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
             extra = ["-mllvm", "-amdgpu-kernarg-preload-count=16"] if (src == "gemm_lds.hip" and not os.environ.get("SAID_NO_PRELOAD")) else []
+            extra += os.environ.get("SAID_EXTRA_DEFS", "").split()   # development: -D switches for A/B builds (scripts/gpu_ab_build.sh)
             cmd = [hipcc] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
             jobs.append(cmd)
 

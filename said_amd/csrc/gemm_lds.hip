@@ -435,7 +435,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             const float md = S1 * invC;
             const float var = fmaxf(S2 * invC - md * md, 0.f);
             mu4[e] = lnref[e] + md;
-            rs4[e] = 1.0f / sqrtf(var + ln_eps);
+            rs4[e] = __builtin_amdgcn_rsqf(var + ln_eps);   // v_rsq_f32 (1 ulp): the IEEE 1/sqrt sequence is ~40 VALU ops
         }
     }
     clk_stamp_p(clkp, w, l, 3);
@@ -626,7 +626,10 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                 mma_block(u, wv);
             }
         } else {
-            constexpr int D = (TMAX == 1 && NACC == 1) ? 3 : 2;
+#ifndef SAID_PIPE_DEPTH_1TAP
+#define SAID_PIPE_DEPTH_1TAP 3
+#endif
+            constexpr int D = (TMAX == 1 && NACC == 1) ? SAID_PIPE_DEPTH_1TAP : 2;
             f32x4 xq[D - 1][NRMAX];
             WT wq[D - 1][TMAX][WR][NACC];
             float hq[D - 1];
@@ -794,7 +797,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         if (EPI == EPI_STORE && statsp) {
             const float cnt = (float)min(32, aT - t0);
             const float vv = (t < aT) ? val : 0.f;
-            const float mean = half32_sum(vv) / cnt;
+            const float mean = half32_sum(vv) * __builtin_amdgcn_rcpf(cnt);
             const float d = (t < aT) ? (val - mean) : 0.f;
             const float m2 = half32_sum(d * d);
             if (lt == 0 && nl < aN) {
