@@ -154,7 +154,9 @@ __device__ __forceinline__ void gn_issue(const GnP sg, rsrc_t rp, int c_lo, int 
     const int ph = (nph == 2) ? (lane >> 5) : 0;
     const bool chok = ch < cw;
     const int c = c_lo + (chok ? ch : 0);
-    const int gfirst = c - (c % sg.gn_cpg);
+    // c / cpg for small non-negative ints through one float multiply (exact: the +0.5 keeps the quotient clear of
+    // rounding at multiples of cpg); an integer division is ~25 dependent instructions per lane
+    const int gfirst = (int)(((float)c + 0.5f) * __builtin_amdgcn_rcpf((float)sg.gn_cpg)) * sg.gn_cpg;
     L.ref = bload(rp, gfirst * sg.gn_nparts * 8, 0);
     L.gamma = sg.gn_gamma[c];
     L.beta = sg.gn_beta[c];
@@ -213,7 +215,8 @@ __device__ __forceinline__ void gn_finish(const GnP sg, rsrc_t rp, int c_lo, int
     float* sc = scratch;            // [64][3]
     float* gs = scratch + 64 * 3;   // [16][2] (mean, rstd) per group of this wave
     if (ph == 0 && chok) { sc[ch * 3] = s1; sc[ch * 3 + 1] = s2; sc[ch * 3 + 2] = sm; }
-    const int gpw = cw / sg.gn_cpg;
+    const float rcp_cpg = __builtin_amdgcn_rcpf((float)sg.gn_cpg);
+    const int gpw = (int)(((float)cw + 0.5f) * rcp_cpg);
     if (lane < gpw) {
         float S1 = 0.f, S2 = 0.f, SM = 0.f;
         for (int q = 0; q < sg.gn_cpg; ++q) {
@@ -228,7 +231,7 @@ __device__ __forceinline__ void gn_finish(const GnP sg, rsrc_t rp, int c_lo, int
         gs[lane * 2 + 1] = __builtin_amdgcn_rsqf(var + sg.gn_eps);
     }
     if (ph == 0 && chok) {
-        const int gi = ch / sg.gn_cpg;
+        const int gi = (int)(((float)ch + 0.5f) * rcp_cpg);
         const float mean = L.ref + gs[gi * 2];
         const float av = gs[gi * 2 + 1] * L.gamma;
         cA[2 * c] = av;

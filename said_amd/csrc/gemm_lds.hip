@@ -892,10 +892,26 @@ __global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const f
     // fetching ALL weights and ALL activations of the launch (rocprofv3 FETCH_SIZE: 4x the algorithmic bytes).  Here
     // each XCD gets a contiguous run of the logical order (n-tile fastest, then batch, then t-tile), i.e. a few whole
     // token tiles: it still needs every weight tile but only its own slice of X.  Placement affects speed only.
-    const int ny = ((hN + 31) >> 5) / NB, nz = hnbatch, nwg = gridDim.x;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, q = nwg >> 3, r = nwg & 7;
-    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    const int by = L % ny, bz = (L / ny) % nz, bx = L / (ny * nz);
+    // The grid is (token-tile runs x n-tile groups, samples): blocks of one sample with equal blockIdx.x & 7 share an
+    // XCD whatever the row's phase, so the decode needs no division by the batch count; the one division left, by the
+    // number of n-tile groups, is by one of a few small constants (a run-time integer division is ~25 dependent
+    // instructions, and this sits in front of the first load request of every wave).
+    const unsigned ny = (unsigned)(((hN + 31) >> 5) / NB), gx = gridDim.x;
+    const unsigned cls = blockIdx.x & 7u, slot = blockIdx.x >> 3, q = gx >> 3, r = gx & 7u;
+    const unsigned L = (cls < r ? cls * (q + 1) : r * (q + 1) + (cls - r) * q) + slot;
+    unsigned ubx;
+    switch (ny) {
+        case 1: ubx = L; break;
+        case 2: ubx = L >> 1; break;
+        case 3: ubx = L / 3u; break;
+        case 4: ubx = L >> 2; break;
+        case 6: ubx = L / 6u; break;
+        case 8: ubx = L >> 3; break;
+        case 12: ubx = L / 12u; break;
+        default: ubx = L / ny; break;
+    }
+    const int bx = (int)ubx, by = (int)(L - ubx * ny), bz = (int)blockIdx.y;
+    (void)hnbatch;
     if constexpr (EPI == EPI_QKV) {
         if (by * NB < hgate_vft) {
             ugemm_body<NB, KS, EPI, VAR, true, BF, MT>(hd, smem, bx, by, bz);
@@ -924,7 +940,7 @@ static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s, int tt) {
     if (smem < min_lds) smem = min_lds;
     if (smem > kMaxLds) { fprintf(stderr, "said: ugemm needs %d B of LDS\n", smem); abort(); }
     const int ntt = (a.T + 31) / 32;
-    dim3 grid(((MT ? (ntt + tt - 1) / tt : ntt)) * (a.ntiles_per_group / NB) * batch);   // 1-D: decoded XCD-aware in the kernel
+    dim3 grid(((MT ? (ntt + tt - 1) / tt : ntt)) * (a.ntiles_per_group / NB), batch);   // x: decoded XCD-aware in the kernel
     const Seg& s0 = a.seg[0];
     const bool gn0 = s0.xform == XF_GN_SILU || s0.xform == XF_GN_LN;
     const int pack = s0.C | (s0.taps << 16) | (s0.xform << 20) | (a.nseg << 24) | ((gn0 && s0.gn_eps == 1e-6f) ? (1 << 26) : 0) |
