@@ -277,7 +277,9 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         const float* part = AH(res_gn_part) + (long long)b * AH(res_gn_part_bstride);
         grp_rsrcr = make_rsrc(part, (unsigned)aN * (unsigned)rnp * 8u);
         const int c_begin = tile0 * 32, c_end = min(aN, (tile0 + NB) * 32);
-        rg_first = c_begin / rcpg; rg_last = (c_end - 1) / rcpg;   // host guarantees rg_last - rg_first < KS
+        const float rcp_rcpg = __builtin_amdgcn_rcpf((float)rcpg);   // small-int division by one float multiply
+        rg_first = (int)(((float)c_begin + 0.5f) * rcp_rcpg);
+        rg_last = (int)(((float)(c_end - 1) + 0.5f) * rcp_rcpg);   // host guarantees rg_last - rg_first < KS
         rg_grp = min(rg_first + w, rg_last);
         gpr = {rcpg, rnp, aT, AH(res_gn_eps), AH(res_gn_gamma), AH(res_gn_beta)};
         gn_issue(gpr, grp_rsrcr, rg_grp * rcpg, rcpg, l, glr);
@@ -744,7 +746,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             if (e_biasp) val += e_biasp[nl];
             const int vdim = AH(vt_dim);
             const int vn = tile * 32 + lt;
-            const int h = vn / vdim, d = vn % vdim;
+            const int h = vn >> __builtin_ctz(vdim), d = vn & (vdim - 1);   // head_dim is a power of two (host checks)
             if (t < aT && nl < aN)
                 AH(vt)[(((long long)b * AH(vt_heads) + h) * AH(vt_rows) + t) * vdim + d] = val;
             continue;
@@ -1022,7 +1024,7 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16, int t
     if (!cfg || a.groups != 1 || a.ntiles_per_group % NB) return false;
     {   // what the compile-time variant assumes about the arguments
         const int xf0 = a.seg[0].xform;
-        if (epi == EPI_QKV && xf0 != XF_GN_LN) return false;
+        if (epi == EPI_QKV && (xf0 != XF_GN_LN || a.vt_dim <= 0 || (a.vt_dim & (a.vt_dim - 1)))) return false;
         if ((epi == EPI_GEGLU || epi == EPI_BAND) && xf0 != XF_LN) return false;
         if (epi == EPI_STORE && !(xf0 == XF_NONE || xf0 == XF_SILU || xf0 == XF_GN_SILU)) return false;
         if (a.nseg > 2 && is_gn(a.seg[2].xform)) return false;
