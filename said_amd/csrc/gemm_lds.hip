@@ -41,22 +41,25 @@ __device__ __forceinline__ float xf1(float v, float2 gn, float mu, float rs, flo
 
 // 16 dwords of launch-invariant scalars passed as LEADING kernel parameters: with -amdgpu-kernarg-preload-count=16
 // the command processor delivers them in SGPRs, so the first operand loads need no memory round trip at all.
-struct FastHdr {
+struct FastHdr {       // unpacked view of the preloaded kernel parameters
     const float* x;    // segment 0 source (batch 0)
-    const float* w4;   // segment 0 packed weights (+ GroupNorm gamma/beta tail)
-    int pack;          // C | taps << 16 | xform << 20 | nseg << 24 | (gn_eps == 1e-6) << 26
+    const float* w4;   // segment 0 packed weights (+ GroupNorm / LayerNorm affine tails)
+    int pack;          // C | taps << 16 | xform << 20 | nseg << 24 | (gn_eps == 1e-6) << 26 | tiles per workgroup << 28
     int pitch, T, bstride;   // segment 0 pitch, length (stride-1 conv: Tin == T), batch stride (floats)
     int bmod_b0;       // b_mod | b0 << 16
     int N;
     int gate_vft;      // EPI_GEGLU: gate tile offset; EPI_QKV: number of leading token-major tiles
-    int nbatch;        // samples in this launch (the grid is 1-D)
     // GroupNorm statistics of segment 0: with these the partial loads — the head of the longest dependent chain of
     // a GroupNorm'ed GEMM — go out at kernel entry instead of one memory round trip later
     const float* gn_part;
     int gn_bstride;    // floats between batches of the partials
     int gn_cfg;        // gn_cpg | gn_nparts << 16
 };
-static_assert(sizeof(FastHdr) == 64, "FastHdr must be exactly 16 dwords");
+// The header travels as the 14 leading dwords of the kernel parameters: that is how many the hardware preloads into
+// SGPRs (2 of the 16 user SGPRs hold the kernarg pointer).  Anything beyond — and implicit arguments such as gridDim —
+// costs a scalar-memory round trip before the first request can be issued, so T|N and pitch|gate_vft share dwords
+// and the grid width is passed explicitly.
+constexpr int kHdrDwords = 14;
 
 struct UBlock {   // one (segment, channel block) of this wave
     rsrc_t rx, rw;
@@ -209,7 +212,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         grp_rsrc0 = make_rsrc(hd.gn_part + (long long)sb * hd.gn_bstride, (unsigned)C0 * (unsigned)gp0.gn_nparts * 8u);
         gn_issue(gp0, grp_rsrc0, w * (C0 / KS), C0 / KS, l, gl0);
     }
-    const ArgView V = arg_view_hs<MULTI>(l, 16);   // common block (+ segments 1, 2): coalesced loads, fields via v_readlane
+    const ArgView V = arg_view_hs<MULTI>(l, kHdrDwords);   // common block (+ segments 1, 2): coalesced loads, fields via v_readlane
     issue_x(u0, xv, halo, true);
     f32x4 lnref = {0.f, 0.f, 0.f, 0.f};
     if constexpr (HAS_LN) lnref = bload4(u0.rx, (t0 + 4 * sq) * 4, 0);   // raw channel 0 of this lane's 4 tokens: common shift
@@ -884,21 +887,22 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 }
 
 template <int NB, int KS, int EPI, int VAR, bool BF, bool MT>
-__global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const float* hw4, int hpack, int hpitch, int hT, int hbstride,
-                                                        int hbmod_b0, int hN, int hgate_vft, int hnbatch, const float* hgn_part,
-                                                        int hgn_bstride, int hgn_cfg, const GemmArgs a) {
+__global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const float* hw4, int hpack, int hTN, int hpitch_gv, int hbstride,
+                                                        int hbmod_b0, int hgx, const float* hgn_part, int hgn_bstride, int hgn_cfg,
+                                                        const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // the 16 leading dwords are the preloaded FastHdr; `a` only reserves the kernarg layout for arg_view()
-    const FastHdr hd = {hx, hw4, hpack, hpitch, hT, hbstride, hbmod_b0, hN, hgate_vft, hnbatch, hgn_part, hgn_bstride, hgn_cfg};
+    // the leading dwords are the preloaded header; `a` only reserves the kernarg layout for arg_view_hs()
+    const int hN = (int)((unsigned)hTN >> 16), hgate_vft = (int)((unsigned)hpitch_gv >> 16);
+    const FastHdr hd = {hx, hw4, hpack, hpitch_gv & 0xffff, hTN & 0xffff, hbstride, hbmod_b0, hN, hgate_vft, hgn_part, hgn_bstride, hgn_cfg};
     // XCD-aware block order.  Hardware places block id on XCD id % 8; with the natural order every XCD's L2 ends up
     // fetching ALL weights and ALL activations of the launch (rocprofv3 FETCH_SIZE: 4x the algorithmic bytes).  Here
-    // each XCD gets a contiguous run of the logical order (n-tile fastest, then batch, then t-tile), i.e. a few whole
-    // token tiles: it still needs every weight tile but only its own slice of X.  Placement affects speed only.
+    // each XCD gets a contiguous run of the logical order (n-tile fastest, then t-tile), i.e. a few whole token tiles:
+    // it still needs every weight tile but only its own slice of X.  Placement affects speed only.
     // The grid is (token-tile runs x n-tile groups, samples): blocks of one sample with equal blockIdx.x & 7 share an
     // XCD whatever the row's phase, so the decode needs no division by the batch count; the one division left, by the
     // number of n-tile groups, is by one of a few small constants (a run-time integer division is ~25 dependent
     // instructions, and this sits in front of the first load request of every wave).
-    const unsigned ny = (unsigned)(((hN + 31) >> 5) / NB), gx = gridDim.x;
+    const unsigned ny = (unsigned)(((hN + 31) >> 5) / NB), gx = (unsigned)hgx;
     const unsigned cls = blockIdx.x & 7u, slot = blockIdx.x >> 3, q = gx >> 3, r = gx & 7u;
     const unsigned L = (cls < r ? cls * (q + 1) : r * (q + 1) + (cls - r) * q) + slot;
     unsigned ubx;
@@ -913,7 +917,6 @@ __global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const f
         default: ubx = L / ny; break;
     }
     const int bx = (int)ubx, by = (int)(L - ubx * ny), bz = (int)blockIdx.y;
-    (void)hnbatch;
     if constexpr (EPI == EPI_QKV) {
         if (by * NB < hgate_vft) {
             ugemm_body<NB, KS, EPI, VAR, true, BF, MT>(hd, smem, bx, by, bz);
@@ -949,8 +952,9 @@ static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s, int tt) {
                      ((MT ? tt : 0) << 28);
     const int bmod_b0 = (s0.b_mod & 0xffff) | (a.b0 << 16);
     const int gate_vft = (EPI == EPI_GEGLU) ? a.geglu_gate_tiles : a.tm_tiles;
-    hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI, VAR, BF, MT>), grid, dim3(64 * KS), smem, s, s0.x, BF ? s0.w2 : s0.w4, pack, s0.x_pitch, a.T, (int)s0.x_bstride, bmod_b0,
-                       a.N, gate_vft, batch, gn0 ? s0.gn_part : nullptr, (int)s0.gn_part_bstride, s0.gn_cpg | (s0.gn_nparts << 16), a);
+    hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI, VAR, BF, MT>), grid, dim3(64 * KS), smem, s, s0.x, BF ? s0.w2 : s0.w4, pack,
+                       a.T | (a.N << 16), s0.x_pitch | (gate_vft << 16), (int)s0.x_bstride, bmod_b0, (int)grid.x,
+                       gn0 ? s0.gn_part : nullptr, (int)s0.gn_part_bstride, s0.gn_cpg | (s0.gn_nparts << 16), a);
 }
 template <int NB, int KS, int EPI, int VAR, bool BF, bool MT>
 static void uconfigure_one() {
@@ -1041,6 +1045,7 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16, int t
     }
     if (a.seg[0].x_bstride > 0x7fffffffLL || a.b0 > 0x7fff || a.seg[0].b_mod > 0xffff || a.seg[0].C > 0xffff) return false;
     if (a.seg[0].Tin != a.T || a.ntiles_per_group != (a.N + 31) / 32) return false;
+    if (a.T > 0xffff || a.N > 0xffff || a.seg[0].x_pitch > 0xffff || a.geglu_gate_tiles > 0xffff || a.tm_tiles > 0xffff) return false;   // packed header fields
     {   // header-only GroupNorm path of segment 0: parameters behind the weights, eps one of two known values
         const Seg& s0 = a.seg[0];
         if (s0.xform == XF_GN_SILU || s0.xform == XF_GN_LN) {
