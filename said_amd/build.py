@@ -44,7 +44,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
-            extra = ["-mllvm", "-amdgpu-kernarg-preload-count=16"] if (src == "gemm_lds.hip" and not os.environ.get("SAID_NO_PRELOAD")) else []
+            # leading scalar kernel parameters arrive in SGPRs (14 is what the hardware has room for): see gemm_lds.hip, attn.hip
+            extra = ["-mllvm", "-amdgpu-kernarg-preload-count=14"] if (src in ("gemm_lds.hip", "attn.hip") and not os.environ.get("SAID_NO_PRELOAD")) else []
             extra += os.environ.get("SAID_EXTRA_DEFS", "").split()   # development: -D switches for A/B builds (scripts/gpu_ab_build.sh)
             cmd = [hipcc] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
             jobs.append(cmd)

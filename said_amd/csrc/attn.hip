@@ -31,9 +31,19 @@ namespace said {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 
+// The arguments are 14 scalar kernel parameters — exactly what the hardware preloads into SGPRs (build.py compiles this
+// file with -amdgpu-kernarg-preload-count=14) — so the first operand request needs no scalar-memory round trip.
+struct AttnView {
+    const float* qk; const float* v; float* o;
+    int v_bstride, o_bstride, pitch, T, heads, rows;
+    float scale;
+    int b0;
+};
 template <int ND, int KS>
-__global__ __launch_bounds__(64 * KS) void attn_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const float* pv, float* po, int v_bstride, int o_bstride, int ppitch,
+                                                       int pT, int pheads, int prows, float pscale, int pb0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AttnView a = {pqk, pv, po, v_bstride, o_bstride, ppitch, pT, pheads, prows, pscale, pb0};
     constexpr int D = 32 * ND, NQ = D / 8;   // NQ dwordx4 per lane and operand row
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -164,7 +174,9 @@ template <int ND, int KS>
 static void launch_attn_one(const AttnArgs& a, int batch, hipStream_t s) {
     const int smem = (KS * 64 + KS * ND * 16 * 64) * (int)sizeof(float);
     dim3 grid((a.T + 31) / 32, a.heads, batch);
-    hipLaunchKernelGGL((attn_kernel<ND, KS>), grid, dim3(64 * KS), smem, s, a);
+    if (a.v_bstride > 0x7fffffffLL || a.o_bstride > 0x7fffffffLL) { fprintf(stderr, "said: attention batch stride exceeds 31 bits\n"); abort(); }
+    hipLaunchKernelGGL((attn_kernel<ND, KS>), grid, dim3(64 * KS), smem, s, a.qk, a.v, a.o, (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T,
+                       a.heads, a.rows, a.scale, a.b0);
 }
 template <int ND, int KS>
 static void configure_attn_one() {
