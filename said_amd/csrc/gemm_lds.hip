@@ -132,8 +132,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     {
         const int cw = C0 / KS;
         const int cb = (cw % 24 == 0) ? 24 : cw;
-        const int bmod = hd.bmod_b0 & 0xffff;
-        const int sb = bmod > 0 ? b % bmod : b;
+        const int sb = b;   // b_mod (all samples reading sample b % b_mod) exists only on the generic kernel: the host checks
         u0.rx = make_rsrc(hd.x + (long long)sb * hd.bstride, (unsigned)C0 * (unsigned)hd.pitch * 4u);
         u0.rw = make_rsrc(hd.w4, (unsigned)w_tiles * (unsigned)taps0 * (unsigned)(C0 >> 3) * (unsigned)WB);
         u0.c0 = w * cw;
@@ -207,8 +206,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     if constexpr (GN0) {
         const float* gb = hd.w4 + (long long)w_tiles * taps0 * (C0 >> 3) * (WB / 4);   // gamma[C0], beta[C0] behind the weights
         gp0 = {hd.gn_cfg & 0xffff, hd.gn_cfg >> 16, hd.T, ((hd.pack >> 26) & 1) ? 1e-6f : 1e-5f, gb, gb + C0};
-        const int bmod = hd.bmod_b0 & 0xffff;
-        const int sb = bmod > 0 ? b % bmod : b;
+        const int sb = b;
         grp_rsrc0 = make_rsrc(hd.gn_part + (long long)sb * hd.gn_bstride, (unsigned)C0 * (unsigned)gp0.gn_nparts * 8u);
         gn_issue(gp0, grp_rsrc0, w * (C0 / KS), C0 / KS, l, gl0);
     }
@@ -239,10 +237,10 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         }
         const unsigned sv = SV(s);
         UBlock u;
-        const int sC = AS(sv, C), pitch = AS(sv, x_pitch), taps = AS(sv, taps), bmod = AS(sv, b_mod);
+        const int sC = AS(sv, C), pitch = AS(sv, x_pitch), taps = AS(sv, taps);
         const int cw = sC / KS;
         const int cb = (cw % 24 == 0) ? 24 : cw;   // host guarantees cw % 24 == 0 or cw in {8, 16}
-        const int sb = bmod > 0 ? b % bmod : b;
+        const int sb = b;
         u.rx = make_rsrc(AS(sv, x) + (long long)sb * AS(sv, x_bstride), (unsigned)sC * (unsigned)pitch * 4u);
         u.rw = make_rsrc(BF ? AS(sv, w2) : AS(sv, w4), (unsigned)w_tiles * (unsigned)taps * (unsigned)(sC >> 3) * (unsigned)WB);
         u.c0 = w * cw + blk * cb;
@@ -265,9 +263,8 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     int sC1 = 0;
     if constexpr (GN1) {   // segment 1 (concatenated skip input of a ResBlock): GroupNorm parameters from the argument block
         const unsigned sv = SV(1);
-        const int bmod = AS(sv, b_mod);
         sC1 = AS(sv, C);
-        const int sb = bmod > 0 ? b % bmod : b;
+        const int sb = b;
         gp1 = seg_gnp(1);
         grp_rsrc1 = make_rsrc(AS(sv, gn_part) + (long long)sb * AS(sv, gn_part_bstride), (unsigned)sC1 * (unsigned)gp1.gn_nparts * 8u);
         gn_issue(gp1, grp_rsrc1, w * (sC1 / KS), sC1 / KS, l, gl1);
@@ -1043,7 +1040,8 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16, int t
             if (a.res_gn_cpg <= 0 || (c_span + a.res_gn_cpg - 1) / a.res_gn_cpg + 1 > KS) return false;
         }
     }
-    if (a.seg[0].x_bstride > 0x7fffffffLL || a.b0 > 0x7fff || a.seg[0].b_mod > 0xffff || a.seg[0].C > 0xffff) return false;
+    if (a.seg[0].x_bstride > 0x7fffffffLL || a.b0 > 0x7fff || a.seg[0].C > 0xffff) return false;
+    for (int s = 0; s < a.nseg; ++s) if (a.seg[s].b_mod != 0) return false;   // sample aliasing (b % b_mod) stays on the generic kernel
     if (a.seg[0].Tin != a.T || a.ntiles_per_group != (a.N + 31) / 32) return false;
     if (a.T > 0xffff || a.N > 0xffff || a.seg[0].x_pitch > 0xffff || a.geglu_gate_tiles > 0xffff || a.tm_tiles > 0xffff) return false;   // packed header fields
     {   // header-only GroupNorm path of segment 0: parameters behind the weights, eps one of two known values
