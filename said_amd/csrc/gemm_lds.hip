@@ -64,7 +64,6 @@ constexpr int kHdrDwords = 14;
 struct UBlock {   // one (segment, channel block) of this wave
     rsrc_t rx, rw;
     int c0;        // first channel of the block (segment-relative)
-    int nr;        // row rounds (CB / 8)
     int taps, Tin, pitch4, C8 /* C / 8 */;
     int xform;
     const float2* cGN;   // LDS coefficient tables, indexed by segment channel
@@ -131,12 +130,10 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     UBlock u0;
     {
         const int cw = C0 / KS;
-        const int cb = (cw % 24 == 0) ? 24 : cw;
         const int sb = b;   // b_mod (all samples reading sample b % b_mod) exists only on the generic kernel: the host checks
         u0.rx = make_rsrc(hd.x + (long long)sb * hd.bstride, (unsigned)C0 * (unsigned)hd.pitch * 4u);
         u0.rw = make_rsrc(hd.w4, (unsigned)w_tiles * (unsigned)taps0 * (unsigned)(C0 >> 3) * (unsigned)WB);
         u0.c0 = w * cw;
-        u0.nr = cb >> 3;
         u0.taps = taps0; u0.Tin = hd.T; u0.pitch4 = hd.pitch * 4; u0.C8 = C0 >> 3; u0.xform = xf0;
         u0.cGN = reinterpret_cast<const float2*>(mainS);
         u0.cLN = reinterpret_cast<const float2*>(mainS + (GN0 ? 2 * C0 : 0));
@@ -147,13 +144,13 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     auto issue_x_at = [&](const UBlock& u, f32x4 (&xv)[NRMAX], float& halo, bool valid, int tb) {
 #pragma unroll
         for (int rr = 0; rr < NRMAX; ++rr) {
-            const int oor = (valid && rr < u.nr) ? 0 : (int)0x80000000;   // scalar select, no branch
+            const int oor = valid ? 0 : (int)0x80000000;   // scalar select, no branch
             xv[rr] = bload4(u.rx, (sr * u.pitch4 + (tb + 4 * sq) * 4) | oor, (u.c0 + rr * 8) * u.pitch4);
         }
         halo = 0.f;
         if constexpr (T3) {   // lane -> (row = l >> 1, side = l & 1): token tb-1 or tb+32
             const int row = l >> 1, tin = (l & 1) ? (tb + 32) : (tb - 1);
-            const bool ok = valid && (u.taps == 3) && (row < u.nr * 8) && ((unsigned)tin < (unsigned)u.Tin);
+            const bool ok = valid && (u.taps == 3) && (row < NRMAX * 8) && ((unsigned)tin < (unsigned)u.Tin);
             halo = bload(u.rx, ok ? (row * u.pitch4 + tin * 4) : (int)0x80000000, u.c0 * u.pitch4);
         }
     };
@@ -172,7 +169,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     auto issue_w_round = [&](const UBlock& u, int rr, WT (&wr)[NACC], bool valid) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) {
-            const int oor = (valid && rr < u.nr) ? 0 : (int)0x80000000;
+            const int oor = valid ? 0 : (int)0x80000000;
             wr[i] = wload(u.rw, oor, (tile_wo[i] * u.C8 + (u.c0 >> 3) + rr) * WB);
         }
     };
@@ -187,7 +184,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                 for (int rr = 0; rr < NRMAX; ++rr)
 #pragma unroll
                     for (int i = 0; i < NACC; ++i) {
-                        const int oor = (valid && (tap < u.taps) && (rr < u.nr)) ? 0 : (int)0x80000000;
+                        const int oor = (valid && (tap < u.taps)) ? 0 : (int)0x80000000;
                         wv[tap][rr][i] = wload(u.rw, oor, ((tile_wo[i] * u.taps + tap) * u.C8 + (u.c0 >> 3) + rr) * WB);
                     }
         }
@@ -239,12 +236,11 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         UBlock u;
         const int sC = AS(sv, C), pitch = AS(sv, x_pitch), taps = AS(sv, taps);
         const int cw = sC / KS;
-        const int cb = (cw % 24 == 0) ? 24 : cw;   // host guarantees cw % 24 == 0 or cw in {8, 16}
+        constexpr int cb = 24;   // every block is three 8-channel rounds (the host guarantees cw % 24 == 0)
         const int sb = b;
         u.rx = make_rsrc(AS(sv, x) + (long long)sb * AS(sv, x_bstride), (unsigned)sC * (unsigned)pitch * 4u);
         u.rw = make_rsrc(BF ? AS(sv, w2) : AS(sv, w4), (unsigned)w_tiles * (unsigned)taps * (unsigned)(sC >> 3) * (unsigned)WB);
         u.c0 = w * cw + blk * cb;
-        u.nr = cb >> 3;
         u.taps = taps; u.Tin = AS(sv, Tin); u.pitch4 = pitch * 4; u.C8 = sC >> 3; u.xform = AS(sv, xform);
         u.cGN = reinterpret_cast<const float2*>(mainS + coef_off(s));
         u.cLN = reinterpret_cast<const float2*>(mainS + coef_off(s) + ((u.xform == XF_GN_LN) ? 2 * sC : 0));
@@ -252,7 +248,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     };
     auto nblocks = [&](int s) {
         const int cw = (s == 0 ? C0 : AS(SV(s), C)) / KS;
-        return (cw % 24 == 0) ? cw / 24 : 1;
+        return cw / 24;
     };
     auto seg_gnp = [&](int s) {
         const unsigned sv = SV(s);
@@ -397,7 +393,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int rr = 0; rr < NRMAX; ++rr) {
-            if (rr < u0.nr) {
+            {
                 const int c = u0.c0 + rr * 8 + sr;
                 float2 cg = make_float2(1.f, 0.f);
                 if (gnx) cg = u0.cGN[c];
@@ -478,7 +474,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         constexpr bool GNX = (XF == XF_GN_SILU || XF == XF_GN_LN), LNX = (XF == XF_LN || XF == XF_GN_LN);
 #pragma unroll
         for (int rr = 0; rr < NRMAX; ++rr) {
-            if (rr < u.nr) {
+            {
                 const int c = u.c0 + rr * 8 + sr;
                 float2 gn = make_float2(1.f, 0.f), ln = make_float2(1.f, 0.f);
                 if constexpr (GNX) gn = u.cGN[c];
@@ -501,7 +497,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         if constexpr (T3) {
             if (u.taps == 3) {
                 const int row = l >> 1, tin = (l & 1) ? (t0 + 32) : (t0 - 1);
-                if (row < u.nr * 8) {
+                if (row < NRMAX * 8) {
                     float2 gn = make_float2(1.f, 0.f);
                     if constexpr (GNX) gn = u.cGN[u.c0 + row];
                     const float v = xf1<XF>(hl, gn, 0.f, 1.f, make_float2(1.f, 0.f));
@@ -531,12 +527,12 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             if constexpr (ROLL) {
 #pragma unroll
                 for (int rr = 0; rr < NRMAX; ++rr) {
-                    if (rr < u.nr) {
+                    {
                         const s16x4 xf = *reinterpret_cast<const s16x4*>(xb + rr * 8);
 #pragma unroll
                         for (int i = 0; i < NACC; ++i)
                             acc[i] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, ws[0][rr & 1][i]), xf, acc[i], 0, 0, 0);
-                        if (rr == 0 && u.nr > 2) issue_w_round(u, 2, ws[0][0], true);
+                        if (rr == 0) issue_w_round(u, 2, ws[0][0], true);
                     }
                 }
                 return;
@@ -546,7 +542,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                     if (tap < u.taps) {
 #pragma unroll
                         for (int rr = 0; rr < NRMAX; ++rr) {
-                            if (rr < u.nr) {
+                            {
                                 const s16x4 xf = *reinterpret_cast<const s16x4*>(xb + tap * PB + rr * 8);
 #pragma unroll
                                 for (int i = 0; i < NACC; ++i) {
@@ -565,14 +561,14 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         if constexpr (ROLL) {
 #pragma unroll
             for (int rr = 0; rr < NRMAX; ++rr) {
-                if (rr < u.nr) {
+                {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float xf = xrow[(rr * 8 + 2 * j) * XP];
 #pragma unroll
                         for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[0][rr & 1][i][j], xf, acc[i], 0, 0, 0);
                     }
-                    if (rr == 0 && u.nr > 2) issue_w_round(u, 2, ws[0][0], true);
+                    if (rr == 0) issue_w_round(u, 2, ws[0][0], true);
                 }
             }
             return;
@@ -582,7 +578,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             if (tap < u.taps) {
 #pragma unroll
                 for (int rr = 0; rr < NRMAX; ++rr) {
-                    if (rr < u.nr) {
+                    {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float xf = xrow[(rr * 8 + 2 * j) * XP + tap];
@@ -1017,7 +1013,7 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16, int t
         SAID_UGEMM_MT_CONFIGS(X)
 #undef X
         const int cw = a.seg[0].C / KS;
-        if (!mt || tt > 15 || a.nseg != 1 || !(cw == 24 || cw == 8 || cw == 16)) return false;
+        if (!mt || tt > 15 || a.nseg != 1 || cw != 24) return false;
     }
 #define X(E, nb, ks, v) cfg = cfg || (epi == E && NB == nb && KS == ks && var == (v));
     SAID_UGEMM_CONFIGS(X)
@@ -1058,7 +1054,7 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16, int t
         if (sg.taps == 3 && epi != EPI_STORE) return false;
         if (sg.C % KS) return false;
         const int cw = sg.C / KS;
-        if (!(cw % 24 == 0 || cw == 8 || cw == 16)) return false;
+        if (cw % 24 != 0) return false;   // blocks of three 8-channel rounds; narrower slices stay on the generic kernel
         if ((sg.xform == XF_GN_SILU || sg.xform == XF_GN_LN) && (cw % sg.gn_cpg || cw > 64)) return false;
         if ((sg.xform == XF_LN || sg.xform == XF_GN_LN) && (sg.taps != 1 || cw > 24 || s != 0)) return false;
     }
