@@ -76,7 +76,14 @@ __device__ __forceinline__ void clk_stamp(const GemmArgs& a, int w, int lane, in
     }
 }
 
+// Compiled in only with -DSAID_CLK_STAMPS (SAID_EXTRA_DEFS=-DSAID_CLK_STAMPS python -m said_amd.build --force, as
+// tests/debug_clocks.py's header says): ten inlined stamp sites are ~1 KB of instructions and ten branches on the hot
+// path of every wave, and a kernel's first pass through its code is instruction-cache cold.
 __device__ __forceinline__ void clk_stamp_p(long long* clk, int w, int lane, int slot) {
+#ifndef SAID_CLK_STAMPS
+    (void)clk; (void)w; (void)lane; (void)slot;
+    return;
+#endif
     if (clk && blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0) {
         unsigned long long t;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");

@@ -1,4 +1,8 @@
-"""Bring-up aid: per-phase shader-clock stamps of every GEMM launch of one UNet evaluation."""
+"""Bring-up aid: per-phase shader-clock stamps of every GEMM launch of one UNet evaluation.
+
+The stamp sites are compiled out of the product library; build it with them first:
+    SAID_EXTRA_DEFS=-DSAID_CLK_STAMPS python -m said_amd.build --force
+"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
