@@ -77,7 +77,8 @@ struct UBlock {   // one (segment, channel block) of this wave
 // extra memory round trip on the critical path (measured 21.7k -> see profiles/ for the phase clocks).
 enum UVar : int { UV_T3 = 1 /* segment 0 is a 3-tap conv */, UV_GN0 = 2 /* GroupNorm'ed segment 0 */,
                   UV_GN1 = 4 /* GroupNorm'ed segment 1 (concatenated skip) */, UV_RGN = 8 /* GroupNorm'ed residual */,
-                  UV_MULTI = 16 /* more than one K segment: the argument blocks of segments 1, 2 are fetched */ };
+                  UV_MULTI = 16 /* more than one K segment: the argument blocks of segments 1, 2 are fetched */,
+                  UV_DEEP = 32 /* single segment whose per-wave K slice spans several 24-channel blocks (FF out) */ };
 
 template <int NB, int KS, int EPI, int VAR, bool TRANS, bool BF, bool MT>
 __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int bx, int by, int bz) {
@@ -96,10 +97,12 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     constexpr int VPW = NV / KS;
     constexpr bool EPRE = (VPW <= 4) && (EPI == EPI_STORE || EPI == EPI_QKV) && !TRANS;
     constexpr bool T3 = (VAR & UV_T3) != 0, GN0 = (VAR & UV_GN0) != 0, GN1 = (VAR & UV_GN1) != 0, RGN = (VAR & UV_RGN) != 0;
-    constexpr bool MULTI = (VAR & UV_MULTI) != 0;
+    constexpr bool MULTI = (VAR & UV_MULTI) != 0, DEEP = (VAR & UV_DEEP) != 0;
+    constexpr bool ONE_BLOCK = MT || (!MULTI && !DEEP);   // exactly one (segment, block) per wave: no block loop at all
     static_assert(!GN1 || MULTI, "a GroupNorm'ed segment 1 implies several segments");
     constexpr bool HAS_LN = (EPI != EPI_STORE);   // q/k/v, GEGLU and band projections read LayerNorm'ed input
     static_assert(EPI == EPI_STORE || (VAR & ~UV_GN0) == 0, "variants other than GN0 exist only for EPI_STORE");
+    static_assert(!(MULTI && DEEP), "DEEP describes single-segment launches");
     static_assert(EPI != EPI_QKV || GN0, "q/k/v reads GroupNorm -> LayerNorm input");
     constexpr int TMAX = T3 ? 3 : 1;
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
@@ -514,9 +517,13 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         } else if constexpr (HAS_LN) {
             stage_t(std::integral_constant<int, XF_LN>{}, u, xs, hl);
         } else {
-            if ((GN0 || GN1) && u.xform == XF_GN_SILU) stage_t(std::integral_constant<int, XF_GN_SILU>{}, u, xs, hl);
-            else if (u.xform == XF_SILU) stage_t(std::integral_constant<int, XF_SILU>{}, u, xs, hl);
-            else stage_t(std::integral_constant<int, XF_NONE>{}, u, xs, hl);
+            if constexpr (GN0 && !MULTI) {   // the only segment is the GroupNorm'ed one
+                stage_t(std::integral_constant<int, XF_GN_SILU>{}, u, xs, hl);
+            } else {
+                if ((GN0 || GN1) && u.xform == XF_GN_SILU) stage_t(std::integral_constant<int, XF_GN_SILU>{}, u, xs, hl);
+                else if (u.xform == XF_SILU) stage_t(std::integral_constant<int, XF_SILU>{}, u, xs, hl);
+                else stage_t(std::integral_constant<int, XF_NONE>{}, u, xs, hl);
+            }
         }
     };
     // pure ds_read + MFMA loop over the block
@@ -608,7 +615,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             if (i < nb0 + nb1) return make_block(1, i - nb0);
             return make_block(2, i - nb0 - nb1);
         };
-        if constexpr (MT) {   // the host guarantees a single block: no block pipeline (and none of its registers)
+        if constexpr (ONE_BLOCK) {   // no block pipeline (and none of its code or registers)
             stage(u0, xv, halo);
             mma_block(u0, wv);
         } else if (ROLL || nblk_total == 1) {   // ROLL: the host guarantees a single block
@@ -960,9 +967,11 @@ static void uconfigure_one() {
 #define SAID_UGEMM_CONFIGS(X) SAID_UGEMM_EXPAND(X, SAID_DEV_ONE_CONFIG)
 #else
 #define SAID_UGEMM_CONFIGS(X)                                                                                    \
-    X(EPI_STORE, 1, 8, 0) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_MULTI)        \
+    X(EPI_STORE, 1, 8, 0) X(EPI_STORE, 1, 8, UV_DEEP) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0)                         \
+    X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_MULTI)                                                                \
     X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_GN1 | UV_MULTI) X(EPI_STORE, 1, 8, UV_RGN)                            \
-    X(EPI_STORE, 2, 8, 0) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_MULTI)        \
+    X(EPI_STORE, 2, 8, 0) X(EPI_STORE, 2, 8, UV_DEEP) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0)                         \
+    X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_MULTI)                                                                \
     X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_GN1 | UV_MULTI)                                                       \
     X(EPI_QKV, 1, 8, UV_GN0) X(EPI_QKV, 2, 8, UV_GN0) X(EPI_QKV, 3, 8, UV_GN0)                                   \
     X(EPI_GEGLU, 1, 8, 0) X(EPI_GEGLU, 2, 8, 0) X(EPI_GEGLU, 4, 8, 0)                                            \
@@ -999,6 +1008,7 @@ static int uvar_of(const GemmArgs& a, int epi) {
     if (a.nseg > 1 && is_gn(a.seg[1].xform)) v |= UV_GN1;
     if (epi == EPI_STORE && a.res_kind == RES_GN) v |= UV_RGN;
     if (a.nseg > 1) v |= UV_MULTI;
+    else if (a.seg[0].C > 24 * 8) v |= UV_DEEP;   // KS = 8 everywhere: more than one 24-channel block per wave
     return v;
 }
 
