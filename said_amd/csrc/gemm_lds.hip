@@ -617,6 +617,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         };
         if constexpr (ONE_BLOCK) {   // no block pipeline (and none of its code or registers)
             stage(u0, xv, halo);
+            clk_stamp_p(clkp, w, l, 5);
             mma_block(u0, wv);
         } else if (ROLL || nblk_total == 1) {   // ROLL: the host guarantees a single block
             stage(u0, xv, halo);
