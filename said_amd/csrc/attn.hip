@@ -115,12 +115,19 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const f
     };
     if constexpr (ND == 1) {
         f32x4a kA[NQ], vA[ND][4], kB[NQ], vB[ND][4];
+        // sched_barrier: without it the machine scheduler sinks the prefetch loads down between the MFMAs that consume
+        // them (s_waitcnt vmcnt(0) in front of every fourth MFMA) and the double buffer hides nothing
         load_kv(w, kA, vA);
+        __builtin_amdgcn_sched_barrier(0);
         for (int kt = w; kt < nkt; kt += 2 * KS) {
             load_kv(kt + KS, kB, vB);
+            __builtin_amdgcn_sched_barrier(0);
             compute(kt, kA, vA);
+            __builtin_amdgcn_sched_barrier(0);
             load_kv(kt + 2 * KS, kA, vA);
+            __builtin_amdgcn_sched_barrier(0);
             if (kt + KS < nkt) compute(kt + KS, kB, vB);
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {  // head_dim 64: one register buffer (a second one would spill); loads of a tile still go out together
         f32x4a kA[NQ], vA[ND][4];

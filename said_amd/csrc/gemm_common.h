@@ -91,6 +91,17 @@ __device__ __forceinline__ void clk_stamp_p(long long* clk, int w, int lane, int
     }
 }
 
+// Loads through pointers rebuilt from v_readlane values have no known address space: the compiler emits flat_load,
+// which counts on BOTH vmcnt and lgkmcnt and makes every later wait a full drain (s_waitcnt vmcnt(0) lgkmcnt(0)).
+// cload: uniform address, read-only data -> constant address space -> s_load.  gload: per-lane address -> global_load.
+typedef const float __attribute__((address_space(4))) * cfloat_p;
+typedef const int __attribute__((address_space(4))) * cint_p;
+typedef const float __attribute__((address_space(1))) * gfloat_p;
+__device__ __forceinline__ float cload(const float* p, long long i) { return ((cfloat_p)(unsigned long long)p)[i]; }
+__device__ __forceinline__ int cload(const int* p, long long i) { return ((cint_p)(unsigned long long)p)[i]; }
+__device__ __forceinline__ float gload(const float* p, long long i) { return ((gfloat_p)(unsigned long long)p)[i]; }
+__device__ __forceinline__ void gstore(float* p, long long i, float v) { ((float __attribute__((address_space(1)))*)(unsigned long long)p)[i] = v; }
+
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
@@ -165,8 +176,8 @@ __device__ __forceinline__ void gn_issue(const GnP sg, rsrc_t rp, int c_lo, int 
     // rounding at multiples of cpg); an integer division is ~25 dependent instructions per lane
     const int gfirst = (int)(((float)c + 0.5f) * __builtin_amdgcn_rcpf((float)sg.gn_cpg)) * sg.gn_cpg;
     L.ref = bload(rp, gfirst * sg.gn_nparts * 8, 0);
-    L.gamma = sg.gn_gamma[c];
-    L.beta = sg.gn_beta[c];
+    L.gamma = gload(sg.gn_gamma, c);
+    L.beta = gload(sg.gn_beta, c);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const int pi = ph + nph * r;

@@ -326,7 +326,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     if (EPRE) {
         const float* embp = AH(emb);
         int erow = 0;
-        if (embp) { const int* sp = AH(step_ptr); erow = (sp ? *sp : 0) + b * AH(emb_b_stride); }
+        if (embp) { const int* sp = AH(step_ptr); erow = (sp ? cload(sp, 0) : 0) + b * AH(emb_b_stride); }
         const int emb_pitch = AH(emb_pitch);
 #pragma unroll
         for (int j = 0; j < VPW; ++j) {
@@ -335,9 +335,9 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             // bias and timestep-embedding term are per-row constants: two uniform addresses per row (lane halves) ->
             // scalar loads, which do not occupy the CU's vector address path
             const int na = (tile0 + i) * 32 + (r & 3) + 8 * (r >> 2), nb = na + 4;
-            const float b_a = (e_biasp && na < aN) ? e_biasp[na] : 0.f, b_b = (e_biasp && nb < aN) ? e_biasp[nb] : 0.f;
-            const float m_a = (embp && na < aN) ? embp[(long long)na * emb_pitch + erow] : 0.f;
-            const float m_b = (embp && nb < aN) ? embp[(long long)nb * emb_pitch + erow] : 0.f;
+            const float b_a = (e_biasp && na < aN) ? cload(e_biasp, na) : 0.f, b_b = (e_biasp && nb < aN) ? cload(e_biasp, nb) : 0.f;
+            const float m_a = (embp && na < aN) ? cload(embp, (long long)na * emb_pitch + erow) : 0.f;
+            const float m_b = (embp && nb < aN) ? cload(embp, (long long)nb * emb_pitch + erow) : 0.f;
             e_bias[j] = lh ? b_b : b_a;
             e_emb[j] = lh ? m_b : m_a;
         }
@@ -747,12 +747,12 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         if (EPI == EPI_QKV && TRANS) {
             const int nl = tile * 32 + lt;
             const int t = t0 + frow;
-            if (e_biasp) val += e_biasp[nl];
+            if (e_biasp) val += gload(e_biasp, nl);
             const int vdim = AH(vt_dim);
             const int vn = tile * 32 + lt;
             const int h = vn >> __builtin_ctz(vdim), d = vn & (vdim - 1);   // head_dim is a power of two (host checks)
             if (t < aT && nl < aN)
-                AH(vt)[(((long long)b * AH(vt_heads) + h) * AH(vt_rows) + t) * vdim + d] = val;
+                gstore(AH(vt), (((long long)b * AH(vt_heads) + h) * AH(vt_rows) + t) * vdim + d, val);
             continue;
         }
         const int nl = tile * 32 + frow;
@@ -764,7 +764,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             (void)ngate;
             const float xv_ = val + epiS[i * 32 + frow];
             const float gv = gate + epiS[(NB + i) * 32 + frow];
-            if (ok) yp[(long long)b * y_bs + (long long)nl * y_pitch + t] = xv_ * gelu_f(gv);
+            if (ok) gstore(yp, (long long)b * y_bs + (long long)nl * y_pitch + t, xv_ * gelu_f(gv));
             continue;
         }
         if (EPI == EPI_BAND) {
@@ -780,14 +780,14 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             rv = e_res[j];
         } else {
             if (nl < aN) {
-                if (e_biasp) val += e_biasp[ng];
+                if (e_biasp) val += gload(e_biasp, ng);
                 if (e_act == ACT_SILU) val = silu_f(val);
                 else if (e_act == ACT_GELU) val = gelu_f(val);
                 const float* embp = AH(emb);
                 if (embp) {
                     const int* sp = AH(step_ptr);
-                    const int row = (sp ? *sp : 0) + b * AH(emb_b_stride);
-                    val += embp[(long long)ng * AH(emb_pitch) + row];
+                    const int row = (sp ? cload(sp, 0) : 0) + b * AH(emb_b_stride);
+                    val += gload(embp, (long long)ng * AH(emb_pitch) + row);
                 }
             }
             if (EPI == EPI_STORE && ok && res_kind != RES_NONE)
@@ -799,7 +799,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                 val += rv;
             }
         }
-        if (ok) yp[(long long)b * y_bs + (long long)ng * y_pitch + t] = val;
+        if (ok) gstore(yp, (long long)b * y_bs + (long long)ng * y_pitch + t, val);
         if (EPI == EPI_STORE && statsp) {
             const float cnt = (float)min(32, aT - t0);
             const float vv = (t < aT) ? val : 0.f;
@@ -808,8 +808,8 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             const float m2 = half32_sum(d * d);
             if (lt == 0 && nl < aN) {
                 float* so = statsp + (long long)b * AH(stats_bstride) + ((long long)ng * nparts_out + (t0 >> 5)) * 2;
-                so[0] = mean;
-                so[1] = m2;
+                gstore(so, 0, mean);
+                gstore(so, 1, m2);
             }
         }
     }
@@ -869,7 +869,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                     const bool vis = (wi < wmax) && (lo + wi < hi);   // invisible slots may hold another row's data
                     o = fmaf(sc[wi] * inv, vis ? vraw[dd][wi >> 2][wi & 3] : 0.f, o);
                 }
-                yp[(long long)b * y_bs + (long long)(head * 32 + d) * y_pitch + t] = o;
+                gstore(yp, (long long)b * y_bs + (long long)(head * 32 + d) * y_pitch + t, o);
             }
         }
     }

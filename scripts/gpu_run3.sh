@@ -1,3 +1,6 @@
 cd $GRAFT_REPO_ROOT
-touch said_amd/csrc/gemm_common.h; SAID_EXTRA_DEFS=-DSAID_CLK_STAMPS python -m said_amd.build > /dev/null 2>&1
-timeout 200 python tests/debug_clocks.py > gpurun_out/clk.log 2>&1; grep -c "^launch" gpurun_out/clk.log
+timeout 900 python -m pytest tests -q -x -m gpu 2>&1 | tail -3
+for i in 1 2 3; do timeout 300 python bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_roofline 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'): d=json.loads(l); print('   ms', d['ms_per_step'])"; done
