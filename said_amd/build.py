@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsaid_hip.so")
-SOURCES = ["gemm.hip", "gemm_lds.hip", "attn.hip", "misc.hip", "out_sched.hip", "engine.cpp"]
+SOURCES = ["gemm.hip", "gemm_lds.hip", "attn.hip", "misc.hip", "out_sched.hip", "conv_in.hip", "engine.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
 
@@ -45,7 +45,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
             # leading scalar kernel parameters arrive in SGPRs (14 is what the hardware has room for): see gemm_lds.hip, attn.hip
-            extra = ["-mllvm", "-amdgpu-kernarg-preload-count=14"] if (src in ("gemm_lds.hip", "attn.hip") and not os.environ.get("SAID_NO_PRELOAD")) else []
+            extra = ["-mllvm", "-amdgpu-kernarg-preload-count=14"] if (src in ("gemm_lds.hip", "attn.hip", "conv_in.hip") and not os.environ.get("SAID_NO_PRELOAD")) else []
             extra += os.environ.get("SAID_EXTRA_DEFS", "").split()   # development: -D switches for A/B builds (scripts/gpu_ab_build.sh)
             cmd = [hipcc] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
             jobs.append(cmd)

@@ -555,7 +555,16 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
 void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
     c->cur_b0 = g.b0;
     const long long tt = (long long)g.Be * ((g.T + 31) / 32);
-    {   // input_blocks.0: Conv1d(32 -> 192, k3)
+    const int in_copies = (g.B_lat > 0 && g.Be % g.B_lat == 0) ? g.Be / g.B_lat : 0;   // samples sharing one clip's latents
+    static const bool no_conv_in = getenv("SAID_NO_CONV_IN") != nullptr;
+    if (!no_conv_in && g.b0 == 0 && in_copies >= 1 && c->conv_in.w4[0] && !c->clk_on &&
+        conv_in_supports(c->cin, MC, c->conv_in.taps, g.T, g.Tp, in_copies)) {
+        // input_blocks.0: Conv1d(32 -> 192, k3), computed once per clip (conv_in.hip)
+        if (dbg_go(c)) launch_conv_in(c->x_cm, c->conv_in.w4[0], c->conv_in.bias, c->H0.p, c->H0.st, g.step_inc, g.B_lat, in_copies, g.T, g.Tp, MC, s);
+        if (c->log_on)
+            c->stage_log.push_back({0, EPI_STORE, 1, 4, 4.0 * ((double)MC * c->cin * 3 + (double)g.B_lat * c->cin * g.T + (double)g.Be * MC * g.T),
+                                    2.0 * g.B_lat * MC * c->cin * 3 * g.T});
+    } else {   // input_blocks.0: Conv1d(32 -> 192, k3)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
         a.seg[0] = with_pw(mkseg(c->x_cm, (long long)c->cin * g.Tp, g.Tp, c->cin, 3, 1, 1, g.T, XF_NONE, c->conv_in.w[0]), c->conv_in, 0);

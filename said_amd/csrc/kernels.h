@@ -212,6 +212,12 @@ void launch_axpby(const float* a_dev, const float* x, const float* c_dev, const 
 void launch_finish(const float* x_cm, long long x_bstride, int pitch, int B, int T, int C, float latent_scale,
                    float* latents_tm, float* result_tm, hipStream_t s);
 
+// UNet input conv (32 -> Cout, k3) + GroupNorm partials + step-counter increment (conv_in.hip): one result per clip,
+// written to `copies` batch halves (clip b -> samples b, b + B, ...)
+bool conv_in_supports(int Cin, int Cout, int taps, int T, int pitch, int copies);
+void launch_conv_in(const float* x, const float* w4, const float* bias, float* y, float* stats, int* step_inc, int B, int copies, int T,
+                    int pitch, int Cout, hipStream_t s);
+
 // ---- audio-encoder specific kernels ----
 // conv0: 1 -> C channels, kernel K, stride S, no bias (Wav2Vec2 feature extractor layer 0)
 void launch_conv0(const float* wav, const float* w, float* y, int B, int Ta, int C, int K, int S, int Tout, int pitch,
