@@ -46,7 +46,7 @@ struct FastHdr {       // unpacked view of the preloaded kernel parameters
     const float* w4;   // segment 0 packed weights (+ GroupNorm / LayerNorm affine tails)
     int pack;          // C | taps << 16 | xform << 20 | nseg << 24 | (gn_eps == 1e-6) << 26 | tiles per workgroup << 28
     int pitch, T, bstride;   // segment 0 pitch, length (stride-1 conv: Tin == T), batch stride (floats)
-    int bmod_b0;       // b_mod | b0 << 16
+    int bmod_b0;       // ny_magic (17 bits) | b0 << 17  (ny_magic = floor(65536 / ny) + 1: block decode without a division)
     int N;
     int gate_vft;      // EPI_GEGLU: gate tile offset; EPI_QKV: number of leading token-major tiles
     // GroupNorm statistics of segment 0: with these the partial loads — the head of the longest dependent chain of
@@ -107,7 +107,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     constexpr int TMAX = T3 ? 3 : 1;
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = bz + (hd.bmod_b0 >> 16);
+    const int b = bz + (hd.bmod_b0 >> 17);
     const int tt_run = MT ? ((hd.pack >> 28) & 15) : 1;   // tiles per workgroup
     const int ntt_all = (hd.T + 31) >> 5;
     const int ntr = MT ? min(tt_run, ntt_all - bx * tt_run) : 1;
@@ -324,20 +324,27 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         }
     };
     if (EPRE) {
-        const float* embp = AH(emb);
-        int erow = 0;
-        if (embp) { const int* sp = AH(step_ptr); erow = (sp ? cload(sp, 0) : 0) + b * AH(emb_b_stride); }
-        const int emb_pitch = AH(emb_pitch);
+        // Unconditional scalar loads: an absent bias / embedding table / step counter is read from the start of the
+        // weight block instead (always mapped, finite) and multiplied by 0 — a pointer select costs two scalar ops, a
+        // null test per load costs a branch and 64-bit compares, and this code runs in front of every wave's MFMAs.
+        const float* embp0 = AH(emb);
+        const int* sp0 = AH(step_ptr);
+        const float* bp = e_biasp ? e_biasp : hd.w4;
+        const float* mp = embp0 ? embp0 : hd.w4;
+        const float bsc = e_biasp ? 1.f : 0.f, msc = embp0 ? 1.f : 0.f;
+        const int mhas = embp0 ? 1 : 0;
+        const int step_now = cload(sp0 ? sp0 : reinterpret_cast<const int*>(hd.w4), 0) * (sp0 ? 1 : 0);
+        const int erow = (step_now + b * AH(emb_b_stride)) * mhas;
+        const int emb_pitch = AH(emb_pitch) * mhas;
 #pragma unroll
         for (int j = 0; j < VPW; ++j) {
             const int v = w + j * KS;
             const int i = v >> 4, r = v & 15;
-            // bias and timestep-embedding term are per-row constants: two uniform addresses per row (lane halves) ->
-            // scalar loads, which do not occupy the CU's vector address path
-            const int na = (tile0 + i) * 32 + (r & 3) + 8 * (r >> 2), nb = na + 4;
-            const float b_a = (e_biasp && na < aN) ? cload(e_biasp, na) : 0.f, b_b = (e_biasp && nb < aN) ? cload(e_biasp, nb) : 0.f;
-            const float m_a = (embp && na < aN) ? cload(embp, (long long)na * emb_pitch + erow) : 0.f;
-            const float m_b = (embp && nb < aN) ? cload(embp, (long long)nb * emb_pitch + erow) : 0.f;
+            // per-row constants: two uniform addresses per row (lane halves) -> scalar loads, which do not occupy the
+            // CU's vector address path; rows past N read row N-1 (never stored)
+            const int na = min((tile0 + i) * 32 + (r & 3) + 8 * (r >> 2), aN - 1), nb = min(na + 4, aN - 1);
+            const float b_a = cload(bp, na) * bsc, b_b = cload(bp, nb) * bsc;
+            const float m_a = cload(mp, (long long)na * emb_pitch + erow) * msc, m_b = cload(mp, (long long)nb * emb_pitch + erow) * msc;
             e_bias[j] = lh ? b_b : b_a;
             e_emb[j] = lh ? m_b : m_a;
         }
@@ -906,17 +913,8 @@ __global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const f
     const unsigned ny = (unsigned)(((hN + 31) >> 5) / NB), gx = (unsigned)hgx;
     const unsigned cls = blockIdx.x & 7u, slot = blockIdx.x >> 3, q = gx >> 3, r = gx & 7u;
     const unsigned L = (cls < r ? cls * (q + 1) : r * (q + 1) + (cls - r) * q) + slot;
-    unsigned ubx;
-    switch (ny) {
-        case 1: ubx = L; break;
-        case 2: ubx = L >> 1; break;
-        case 3: ubx = L / 3u; break;
-        case 4: ubx = L >> 2; break;
-        case 6: ubx = L / 6u; break;
-        case 8: ubx = L >> 3; break;
-        case 12: ubx = L / 12u; break;
-        default: ubx = L / ny; break;
-    }
+    // L / ny as a multiply-shift with the host's magic number (exact for every L < grid width: the host checks)
+    const unsigned ubx = (L * ((unsigned)hbmod_b0 & 0x1ffffu)) >> 16;
     const int bx = (int)ubx, by = (int)(L - ubx * ny), bz = (int)blockIdx.y;
     if constexpr (EPI == EPI_QKV) {
         if (by * NB < hgate_vft) {
@@ -951,7 +949,10 @@ static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s, int tt) {
     const bool gn0 = s0.xform == XF_GN_SILU || s0.xform == XF_GN_LN;
     const int pack = s0.C | (s0.taps << 16) | (s0.xform << 20) | (a.nseg << 24) | ((gn0 && s0.gn_eps == 1e-6f) ? (1 << 26) : 0) |
                      ((MT ? tt : 0) << 28);
-    const int bmod_b0 = (s0.b_mod & 0xffff) | (a.b0 << 16);
+    const unsigned ny_host = (unsigned)(a.ntiles_per_group / NB), magic = 65536u / ny_host + 1u;
+    for (unsigned L = 0; L < grid.x; ++L)   // exactness of the multiply-shift over this launch's range (a few thousand at most)
+        if (((L * magic) >> 16) != L / ny_host) { fprintf(stderr, "said: block decode magic inexact (grid %u, ny %u)\n", grid.x, ny_host); abort(); }
+    const int bmod_b0 = (int)(magic & 0x1ffffu) | (a.b0 << 17);
     const int gate_vft = (EPI == EPI_GEGLU) ? a.geglu_gate_tiles : a.tm_tiles;
     hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI, VAR, BF, MT>), grid, dim3(64 * KS), smem, s, s0.x, BF ? s0.w2 : s0.w4, pack,
                        a.T | (a.N << 16), s0.x_pitch | (gate_vft << 16), (int)s0.x_bstride, bmod_b0, (int)grid.x,
@@ -1047,7 +1048,7 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16, int t
             if (a.res_gn_cpg <= 0 || (c_span + a.res_gn_cpg - 1) / a.res_gn_cpg + 1 > KS) return false;
         }
     }
-    if (a.seg[0].x_bstride > 0x7fffffffLL || a.b0 > 0x7fff || a.seg[0].C > 0xffff) return false;
+    if (a.seg[0].x_bstride > 0x7fffffffLL || a.b0 > 0x3fff || a.seg[0].C > 0xffff) return false;
     for (int s = 0; s < a.nseg; ++s) if (a.seg[s].b_mod != 0) return false;   // sample aliasing (b % b_mod) stays on the generic kernel
     if (a.seg[0].Tin != a.T || a.ntiles_per_group != (a.N + 31) / 32) return false;
     if (a.T > 0xffff || a.N > 0xffff || a.seg[0].x_pitch > 0xffff || a.geglu_gate_tiles > 0xffff || a.tm_tiles > 0xffff) return false;   // packed header fields
