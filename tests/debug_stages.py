@@ -81,13 +81,13 @@ def main():
         eng.unet_forward(xd, ts, cd)
         if tname.endswith(":qkv"):
             base = tname[:-4]
-            qk = eng.debug_read("QK", (B, 384, Tp))[:, :, :T]
-            Tr = Tp
-            vt = eng.debug_read("VT", (B, 6, Tr, 32))[:, :, :T, :]
+            # q and k are token-major [B][2*heads][rows][32] (q heads, then k heads), v channel-major [B][192][Tp]
+            qkt = eng.debug_read("QK", (B, 12, Tp, 32))[:, :, :T, :]
+            vc = eng.debug_read("VT", (B, 192, Tp))[:, :, :T]
             q, kk, v = (tdict[base + s][0] for s in (":q", ":k", ":v"))
-            e1 = np.abs(qk[:, :192] - tm(q)).max(); e2 = np.abs(qk[:, 192:] - tm(kk)).max()
-            vref = v.reshape(B, T, 6, 32).permute(0, 2, 1, 3).numpy()
-            e3 = np.abs(vt - vref).max()
+            heads = lambda t: t.reshape(B, T, 6, 32).permute(0, 2, 1, 3).numpy()
+            e1 = np.abs(qkt[:, :6] - heads(q)).max(); e2 = np.abs(qkt[:, 6:] - heads(kk)).max()
+            e3 = np.abs(vc - tm(v)).max()
             err, scale = max(e1, e2, e3), float(np.abs(tm(q)).max())
         else:
             got = reader()
