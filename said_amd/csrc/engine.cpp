@@ -683,7 +683,7 @@ int check_ready(said_ctx* ctx) {
 // ============================================================================================
 extern "C" {
 
-int said_abi_version(void) { return 1; }
+int said_abi_version(void) { return 2; }   // 2: said_set_precision / said_get_precision
 
 const char* said_last_error(const said_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
