@@ -30,6 +30,13 @@ namespace said {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4a __attribute__((ext_vector_type(4)));
+typedef short s16x4a __attribute__((ext_vector_type(4)));
+// four floats -> four bf16 (round to nearest even), as the 32x32x8 bf16 MFMA operand of one lane
+static __device__ __forceinline__ s16x4a pk_bf16(float a, float b, float c, float d) {
+    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+    const bf4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+    return __builtin_bit_cast(s16x4a, v);
+}
 
 // The arguments are 14 scalar kernel parameters — exactly what the hardware preloads into SGPRs (build.py compiles this
 // file with -amdgpu-kernarg-preload-count=14) — so the first operand request needs no scalar-memory round trip.
@@ -39,7 +46,11 @@ struct AttnView {
     float scale;
     int b0;
 };
-template <int ND, int KS>
+// BF: both products run on v_mfma_f32_32x32x8_bf16_1k (said_set_precision).  The operand registers are the same ones:
+// MFMA m of S^T contracts d = lh * D/2 + 4m + (0..3), i.e. the m-th loaded quad of each lane half; MFMA m of O^T
+// contracts keys j0 + 8m + 4lh + (0..3), i.e. accumulator registers 4m..4m+3 and the m-th V quad.  Scores, softmax
+// statistics and accumulation stay fp32.
+template <int ND, int KS, bool BF>
 __global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const float* pv, float* po, int v_bstride, int o_bstride, int ppitch,
                                                        int pT, int pheads, int prows, float pscale, int pb0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -84,8 +95,15 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const f
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int dp = 0; dp < ND * 16; ++dp)
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[dp >> 2][dp & 3], qf[dp >> 2][dp & 3], s, 0, 0, 0);
+        for (int dp = 0; dp < ND * 16; ++dp) {
+            if constexpr (BF) {
+                if ((dp & 3) == 0)
+                    s = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(pk_bf16(kf[dp >> 2][0], kf[dp >> 2][1], kf[dp >> 2][2], kf[dp >> 2][3]),
+                                                                 pk_bf16(qf[dp >> 2][0], qf[dp >> 2][1], qf[dp >> 2][2], qf[dp >> 2][3]), s, 0, 0, 0);
+            } else {
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[dp >> 2][dp & 3], qf[dp >> 2][dp & 3], s, 0, 0, 0);
+            }
+        }
         float mx = -1.0e30f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -111,7 +129,15 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const f
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) o[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[nd][r >> 2][r & 3], s[r], o[nd], 0, 0, 0);
+            for (int nd = 0; nd < ND; ++nd) {
+                if constexpr (BF) {
+                    if ((r & 3) == 0)
+                        o[nd] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(pk_bf16(vf[nd][r >> 2][0], vf[nd][r >> 2][1], vf[nd][r >> 2][2], vf[nd][r >> 2][3]),
+                                                                         pk_bf16(s[r], s[r + 1], s[r + 2], s[r + 3]), o[nd], 0, 0, 0);
+                } else {
+                    o[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[nd][r >> 2][r & 3], s[r], o[nd], 0, 0, 0);
+                }
+            }
     };
     if constexpr (ND == 1) {
         f32x4a kA[NQ], vA[ND][4], kB[NQ], vB[ND][4];
@@ -177,31 +203,31 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const f
     }
 }
 
-template <int ND, int KS>
+template <int ND, int KS, bool BF>
 static void launch_attn_one(const AttnArgs& a, int batch, hipStream_t s) {
     const int smem = (KS * 64 + KS * ND * 16 * 64) * (int)sizeof(float);
     dim3 grid((a.T + 31) / 32, a.heads, batch);
     if (a.v_bstride > 0x7fffffffLL || a.o_bstride > 0x7fffffffLL) { fprintf(stderr, "said: attention batch stride exceeds 31 bits\n"); abort(); }
-    hipLaunchKernelGGL((attn_kernel<ND, KS>), grid, dim3(64 * KS), smem, s, a.qk, a.v, a.o, (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T,
+    hipLaunchKernelGGL((attn_kernel<ND, KS, BF>), grid, dim3(64 * KS), smem, s, a.qk, a.v, a.o, (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T,
                        a.heads, a.rows, a.scale, a.b0);
 }
-template <int ND, int KS>
+template <int ND, int KS, bool BF>
 static void configure_attn_one() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<ND, KS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<ND, KS, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
 }
 void configure_attn_kernels() {
-    configure_attn_one<1, 8>(); configure_attn_one<1, 4>(); configure_attn_one<1, 1>();
-    configure_attn_one<2, 8>(); configure_attn_one<2, 4>(); configure_attn_one<2, 1>();
+    configure_attn_one<1, 8, false>(); configure_attn_one<1, 8, true>(); configure_attn_one<1, 4, false>(); configure_attn_one<1, 4, true>(); configure_attn_one<1, 1, false>(); configure_attn_one<1, 1, true>();
+    configure_attn_one<2, 8, false>(); configure_attn_one<2, 8, true>(); configure_attn_one<2, 4, false>(); configure_attn_one<2, 4, true>(); configure_attn_one<2, 1, false>(); configure_attn_one<2, 1, true>();
 }
 
-void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s) {
-    if (head_dim == 32 && KS == 8) return launch_attn_one<1, 8>(a, batch, s);
-    if (head_dim == 32 && KS == 4) return launch_attn_one<1, 4>(a, batch, s);
-    if (head_dim == 32 && KS == 1) return launch_attn_one<1, 1>(a, batch, s);
-    if (head_dim == 64 && KS == 8) return launch_attn_one<2, 8>(a, batch, s);
-    if (head_dim == 64 && KS == 4) return launch_attn_one<2, 4>(a, batch, s);
-    if (head_dim == 64 && KS == 1) return launch_attn_one<2, 1>(a, batch, s);
+void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s, bool bf16) {
+    if (head_dim == 32 && KS == 8) return bf16 ? launch_attn_one<1, 8, true>(a, batch, s) : launch_attn_one<1, 8, false>(a, batch, s);
+    if (head_dim == 32 && KS == 4) return bf16 ? launch_attn_one<1, 4, true>(a, batch, s) : launch_attn_one<1, 4, false>(a, batch, s);
+    if (head_dim == 32 && KS == 1) return bf16 ? launch_attn_one<1, 1, true>(a, batch, s) : launch_attn_one<1, 1, false>(a, batch, s);
+    if (head_dim == 64 && KS == 8) return bf16 ? launch_attn_one<2, 8, true>(a, batch, s) : launch_attn_one<2, 8, false>(a, batch, s);
+    if (head_dim == 64 && KS == 4) return bf16 ? launch_attn_one<2, 4, true>(a, batch, s) : launch_attn_one<2, 4, false>(a, batch, s);
+    if (head_dim == 64 && KS == 1) return bf16 ? launch_attn_one<2, 1, true>(a, batch, s) : launch_attn_one<2, 1, false>(a, batch, s);
     fprintf(stderr, "said: unsupported attention config D=%d KS=%d\n", head_dim, KS);
     abort();
 }

@@ -407,7 +407,7 @@ void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hi
         if (trace_on()) { fprintf(stderr, "[said] attn #%d D=%d KS=%d T=%d batch=%d\n", c->dbg_count - 1, head_dim, KS, a.T, batch); fflush(stderr); }
         AttnArgs a2 = a;
         a2.b0 = c->cur_b0;
-        launch_attn(a2, batch, head_dim, KS, s);
+        launch_attn(a2, batch, head_dim, KS, s, c->bf16_mode);
         if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
     }
 }
