@@ -16,8 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsaid_hip.so")
+# gfx950 only.  SAID_OFFLOAD_ARCH may narrow the target ID for experiments (e.g. "gfx950:xnack-"; several, comma-separated,
+# give a fat binary from which the runtime picks the one matching the device).
+ARCHS = os.environ.get("SAID_OFFLOAD_ARCH", "gfx950").split(",")
 SOURCES = ["gemm.hip", "gemm_lds.hip", "attn.hip", "misc.hip", "out_sched.hip", "conv_in.hip", "engine.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+FLAGS = [*[f"--offload-arch={a}" for a in ARCHS], "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
 
 def _hipcc() -> str:
@@ -62,7 +65,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([hipcc, *[f"--offload-arch={a}" for a in ARCHS], "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 
 

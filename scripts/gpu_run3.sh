@@ -1,4 +1,9 @@
 cd $GRAFT_REPO_ROOT
-for gs in 1.0 2.0; do timeout 300 python bench.py --steps 3 --warmup 1 --no_cpu_baseline --guidance_scale $gs > gpurun_out/bench2.log 2>&1; python -c "
-import json; d=json.loads([l for l in open('gpurun_out/bench2.log') if l.startswith('{')][-1]); print('gs=$gs', d['value'], d['ms_per_step']); r=d['roofline']
-for k,v in r['by_kernel'].items(): print('  ', k, v)"; done
+for i in 1 2; do
+for arch in gfx950 "gfx950:xnack-"; do
+  SAID_OFFLOAD_ARCH="$arch" python -m said_amd.build --force > /dev/null 2>&1 || { echo "build failed $arch"; continue; }
+  for j in 1 2; do timeout 300 python bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_roofline 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'): d=json.loads(l); print('[$arch]', d['ms_per_step'])"; done
+done; done
