@@ -481,7 +481,11 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.v_bstride = (long long)MC * g.Tp; a.o_bstride = 2LL * MC * g.Tp;
         a.pitch = g.Tp; a.T = g.T; a.heads = HEADS; a.rows = vt_rows; a.b0 = 0;
         a.scale = 0.17677669529663687f;  // 32 ** -0.5
-        do_attn(c, a, g.Be, HD, tt * HEADS <= 2048 ? 8 : (tt * HEADS <= 8192 ? 4 : 1), s);
+        static const int attn_ks_env = getenv("SAID_ATTN_KS") ? atoi(getenv("SAID_ATTN_KS")) : 0;   // experiment knob
+        // waves per workgroup = ways the key tiles are split: 8 only pays while a wave would otherwise hold a single
+        // tile (T <= 256); from there 4 waves with ~5 tiles each merge half as many partial states (B=1: -0.5 % per step)
+        const int attn_ks = (tt * HEADS > 8192) ? 1 : ((g.T <= 256 && tt * HEADS <= 2048) ? 8 : 4);
+        do_attn(c, a, g.Be, HD, attn_ks_env ? attn_ks_env : attn_ks, s);
     }
     {   // x1 = to_out(attn) + x, with x = GroupNorm(in) recomputed on the fly   (attention.py:127, 168)
         GemmArgs a = mkargs(g.T, MC);
