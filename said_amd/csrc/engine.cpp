@@ -362,7 +362,8 @@ static int pick_tt(said_ctx* c, const GemmArgs& a, int epi, int batch, int& NB, 
     int nb = NB;
     const long long ntt = (a.T + 31) / 32;
     const long long wgs = ntt * (a.ntiles_per_group / nb) * batch;
-    int tt = (int)std::min<long long>(std::min<long long>(8, wgs / 1024), ntt);
+    static const long long wgs_per_tile = getenv("SAID_MT_WGS") ? std::max(64, atoi(getenv("SAID_MT_WGS"))) : 1024;   // experiment knob
+    int tt = (int)std::min<long long>(std::min<long long>(8, wgs / wgs_per_tile), ntt);
     if (tt <= 1 || !ugemm_supports(a, epi, nb, KS, bf, tt)) return 1;
     NB = nb;
     return tt;
