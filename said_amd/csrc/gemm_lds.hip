@@ -161,7 +161,17 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     // With 8 accumulator tiles the weight fragments of a whole block (3 rounds x 8 tiles x 4 registers) no longer fit
     // beside the accumulators: ROLL keeps two rounds in flight and requests round 2 into round 0's registers once
     // round 0 has been multiplied (it lands during round 1's 32 MFMAs).
-    constexpr bool ROLL = (NACC >= 8) && !BF;   // bf16 fragments are half the size: all three rounds fit
+    // NSPL (GEGLU, 4 value + 4 gate tiles, fp32): instead of splitting K over the 8 waves — which needs a 2 x 128 KB
+    // reduction through LDS for the 8 tiles — every wave owns ONE output tile over the whole K = 192.  The X tile is
+    // staged cooperatively (the wave-private staging tiles are contiguous, i.e. already one [192][XP] array), each wave
+    // keeps its tile's 24 weight fragments in registers, and the only exchange is the gate tiles handed to the value
+    // waves (16 KB).  Same MFMA count per wave; 8x the ds_read traffic in the main loop, 1/16 of the reduction traffic.
+#ifdef SAID_NO_NSPLIT
+    constexpr bool NSPL = false;
+#else
+    constexpr bool NSPL = (EPI == EPI_GEGLU && NB == 4 && !BF && !MT && KS == 8 && !(VAR & (UV_MULTI | UV_DEEP)));
+#endif
+    constexpr bool ROLL = (NACC >= 8) && !BF && !NSPL;   // bf16 fragments are half the size: all three rounds fit
     static_assert(!(MT && ROLL), "multi-tile mode keeps every weight fragment in registers");
     static_assert(!ROLL || TMAX == 1, "rolling weight rounds are for 1-tap GEMMs");
     constexpr int WR = ROLL ? 2 : NRMAX;
@@ -214,7 +224,14 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     issue_x(u0, xv, halo, true);
     f32x4 lnref = {0.f, 0.f, 0.f, 0.f};
     if constexpr (HAS_LN) lnref = bload4(u0.rx, (t0 + 4 * sq) * 4, 0);   // raw channel 0 of this lane's 4 tokens: common shift
-    issue_w(u0, wv, true);
+    f32x4 wn[NSPL ? 24 : 1];   // NSPL: this wave's tile, all 24 eight-channel rounds
+    if constexpr (NSPL) {
+        const int tw = (w < NB) ? (tile0 + w) : (tile0 + (w - NB) + gate_tiles);
+#pragma unroll
+        for (int rr = 0; rr < 24; ++rr) wn[rr] = bload4(u0.rw, l * 16, (tw * u0.C8 + rr) * 1024);
+    } else {
+        issue_w(u0, wv, true);
+    }
     long long* const clkp = AH(clk);
     clk_stamp_p(clkp, w, l, 0);
     auto SV = [&](int s) -> unsigned { return s == 1 ? V.s1 : V.s2; };   // segment 0 lives in the header
@@ -622,7 +639,17 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             if (i < nb0 + nb1) return make_block(1, i - nb0);
             return make_block(2, i - nb0 - nb1);
         };
-        if constexpr (ONE_BLOCK) {   // no block pipeline (and none of its code or registers)
+        if constexpr (NSPL) {
+            stage(u0, xv, halo);
+            __syncthreads();   // the eight staging tiles together are the [192][XP] X tile every wave multiplies
+            clk_stamp_p(clkp, w, l, 5);
+            const float* xrow = lnred + KS * 64 + lh * XP + lt + 4;
+#pragma unroll
+            for (int rr = 0; rr < 24; ++rr)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wn[rr][j], xrow[(rr * 8 + 2 * j) * XP], acc[0], 0, 0, 0);
+        } else if constexpr (ONE_BLOCK) {   // no block pipeline (and none of its code or registers)
             stage(u0, xv, halo);
             clk_stamp_p(clkp, w, l, 5);
             mma_block(u0, wv);
@@ -696,6 +723,30 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     if (EPI == EPI_GEGLU && tid < 64 * NB) epiS[tid] = geglu_bias;
     __syncthreads();
     clk_stamp_p(clkp, w, l, 7);
+    if constexpr (NSPL) {   // no reduction: gate waves hand their tile to the value wave of the same index
+        float* gx = mainS;
+        if (w >= NB) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gx[((w - NB) * 16 + r) * 64 + l] = acc[0][r];
+        }
+        __syncthreads();
+        clk_stamp_p(clkp, w, l, 8);
+        if (w < NB) {
+            float* const yo = AH(y) + (long long)b * AH(y_bstride);
+            const int yp_ = AH(y_pitch);
+            const int t = t0 + lt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int frow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int nl = (tile0 + w) * 32 + frow;
+                const float xv_ = acc[0][r] + epiS[w * 32 + frow];
+                const float gv = gx[(w * 16 + r) * 64 + l] + epiS[(NB + w) * 32 + frow];
+                if (nl < aN && t < aT) gstore(yo, (long long)nl * yp_ + t, xv_ * gelu_f(gv));
+            }
+        }
+        clk_stamp_p(clkp, w, l, 9);
+        return;
+    }
     float* red = MT ? mainS + coef_total : mainS;   // MT: the coefficient tables live on for the next tile
     // RP reduction passes: GEGLU with 4 value + 4 gate tiles would need 256 KB for one pass, so the value tiles and the
     // gate tiles go through the same buffer one after the other (the summation order per element is unchanged)

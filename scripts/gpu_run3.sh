@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
-for B in 8 16 32; do for w in 1024 512 256; do
-SAID_MT_WGS=$w timeout 300 python bench.py --batch $B --num_steps 50 --steps 2 --warmup 1 --no_cpu_baseline --no_roofline 2>/dev/null | python -c "
+timeout 900 python -m pytest tests -q -x -m gpu 2>&1 | tail -3
+timeout 300 python scripts/bf16_probe.py 2>&1 | grep "fp32 err"
+for B in 1 32; do timeout 300 python bench.py --batch $B --num_steps 50 --steps 2 --warmup 1 --no_cpu_baseline --no_roofline 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
-    if l.startswith('{'): d=json.loads(l); print('B=$B wgs/tile=$w', d['value'], d['ms_per_step'])"
-done; done
+    if l.startswith('{'): d=json.loads(l); print('B=$B', d['value'], d['ms_per_step'])"; done

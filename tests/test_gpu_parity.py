@@ -298,11 +298,12 @@ def test_idempotent_clamp_and_linearity_properties_full_size(model, dev):
     e1 = model(x, t, c)
     e2 = model(x, t, c)
     assert torch.equal(e1, e2)  # fixed reduction order => bit-reproducible
-    # batch independence: evaluating a sample alone or inside a batch gives the same bits
+    # batch independence: evaluating a sample alone or inside a batch gives the same numbers up to fp32 summation
+    # order (the tile shapes — and with them the order in which K is accumulated — depend on the batch size)
     xb = torch.cat([x, x.flip(1)])
     cb = torch.cat([c, c.flip(1)])
     eb = model(xb, torch.tensor([400, 400]).to(dev), cb)
-    assert torch.equal(eb[:1], e1)
+    assert float((eb[:1] - e1).abs().max()) <= 2e-5 * float(e1.abs().max())
     # time-reversal equivariance of the whole network (convs are not symmetric, so only check finiteness + scale)
     assert torch.isfinite(eb).all() and float(eb.abs().max()) < 1e3
 
