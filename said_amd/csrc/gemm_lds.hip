@@ -169,7 +169,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 #ifdef SAID_NO_NSPLIT
     constexpr bool NSPL = false;
 #else
-    constexpr bool NSPL = (EPI == EPI_GEGLU && NB == 4 && !BF && !MT && KS == 8 && !(VAR & (UV_MULTI | UV_DEEP)));
+    constexpr bool NSPL = (EPI == EPI_GEGLU && NB == 4 && !MT && KS == 8 && !(VAR & (UV_MULTI | UV_DEEP)));
 #endif
     constexpr bool ROLL = (NACC >= 8) && !BF && !NSPL;   // bf16 fragments are half the size: all three rounds fit
     static_assert(!(MT && ROLL), "multi-tile mode keeps every weight fragment in registers");
@@ -224,11 +224,11 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     issue_x(u0, xv, halo, true);
     f32x4 lnref = {0.f, 0.f, 0.f, 0.f};
     if constexpr (HAS_LN) lnref = bload4(u0.rx, (t0 + 4 * sq) * 4, 0);   // raw channel 0 of this lane's 4 tokens: common shift
-    f32x4 wn[NSPL ? 24 : 1];   // NSPL: this wave's tile, all 24 eight-channel rounds
+    WT wn[NSPL ? 24 : 1];   // NSPL: this wave's tile, all 24 eight-channel rounds
     if constexpr (NSPL) {
         const int tw = (w < NB) ? (tile0 + w) : (tile0 + (w - NB) + gate_tiles);
 #pragma unroll
-        for (int rr = 0; rr < 24; ++rr) wn[rr] = bload4(u0.rw, l * 16, (tw * u0.C8 + rr) * 1024);
+        for (int rr = 0; rr < 24; ++rr) wn[rr] = wload(u0.rw, 0, (tw * u0.C8 + rr) * WB);
     } else {
         issue_w(u0, wv, true);
     }
@@ -643,12 +643,21 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             stage(u0, xv, halo);
             __syncthreads();   // the eight staging tiles together are the [192][XP] X tile every wave multiplies
             clk_stamp_p(clkp, w, l, 5);
-            const float* xrow = lnred + KS * 64 + lh * XP + lt + 4;
+            if constexpr (BF) {   // eight token-major bf16 tiles [token][24 channels], one per staging wave
+                const __bf16* xb = reinterpret_cast<const __bf16*>(lnred + KS * 64) + (lt + 1) * PB + 4 * lh;
 #pragma unroll
-            for (int rr = 0; rr < 24; ++rr)
+                for (int rr = 0; rr < 24; ++rr) {
+                    const s16x4 xf = *reinterpret_cast<const s16x4*>(xb + (rr / 3) * (2 * 8 * NRMAX * XP) + (rr % 3) * 8);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, wn[rr]), xf, acc[0], 0, 0, 0);
+                }
+            } else {
+                const float* xrow = lnred + KS * 64 + lh * XP + lt + 4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wn[rr][j], xrow[(rr * 8 + 2 * j) * XP], acc[0], 0, 0, 0);
+                for (int rr = 0; rr < 24; ++rr)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wn[rr][j], xrow[(rr * 8 + 2 * j) * XP], acc[0], 0, 0, 0);
+            }
         } else if constexpr (ONE_BLOCK) {   // no block pipeline (and none of its code or registers)
             stage(u0, xv, halo);
             clk_stamp_p(clkp, w, l, 5);
