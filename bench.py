@@ -1,7 +1,9 @@
 """bench.py — throughput of the SAiD denoising hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python bench.py --gpus N --steps K --warmup W            (N >= 1: spawns N ranks itself when not under torchrun)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus 2 --dry_run_gloo                  (CPU: launch / shard / gather plumbing only, stand-in path)
+    BASELINE configs[3] (8 GPUs, 256 clips): python bench.py --gpus 8 --batch 32 --steps 1 --warmup 1
 
 One "step" = one pass of the hot path over one batch: Wav2Vec2 audio encode of B synthetic
 10 s clips + `--num_steps` (1000) denoising steps of the conditional UNet1D with the CLI-default
@@ -28,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured copy
-FP32_MFMA_PEAK_TFLOPS = 157.3
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense peaks (MI355X_MICROARCH.md); never the 2:1-sparsity figures
 EPI_NAMES = {0: "store", 1: "qkv", 2: "geglu", 3: "band", -1: "attn"}
 
 
@@ -47,7 +49,31 @@ def parse():
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
     p.add_argument("--cpu_steps", type=int, default=40, help="UNet evaluations in the CPU-baseline sample")
+    p.add_argument("--dry_run_gloo", action="store_true",
+                   help="no GPU: run the launch / shard / all-gather / timing plumbing on CPU over gloo with a stand-in path")
     return p.parse_args()
+
+
+def cpu_info():
+    """(model name, physical cores, logical cpus) of this host from /proc/cpuinfo."""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+                cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or (os.cpu_count() or 1)), (logical or (os.cpu_count() or 1))
 
 
 def cpu_baseline(args, T, Ta):
@@ -58,7 +84,8 @@ def cpu_baseline(args, T, Ta):
     from oracle import unet as ou
     from said_amd.util import synth
     torch.set_grad_enabled(False)
-    cores = min(os.cpu_count() or 1, 64)
+    cpu_model, phys_cores, logical = cpu_info()
+    cores = max(1, min(phys_cores, os.cpu_count() or 1))   # threads actually used = physical cores visible to this process
     torch.set_num_threads(cores)
     sd = synth.said_state_dict()
     sd_a, sd_u, null = op.split_state_dict(sd)
@@ -89,14 +116,18 @@ def cpu_baseline(args, T, Ta):
     t_step = (time.perf_counter() - t0) / n
     total = t_audio + args.num_steps * t_step
     return {"value": round(T / total, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model, "physical_cores": phys_cores, "logical_cpus": logical,
             "sample": f"1 clip: audio encode ({t_audio:.2f} s) + {n} of {args.num_steps} CFG UNet+scheduler steps "
                       f"({t_step * 1e3:.1f} ms each) on {cores} threads, extrapolated to {args.num_steps} steps",
             "clips_per_s": round(1.0 / total, 5)}
 
 
-def roofline(model, Be, T, step_ms):
+def roofline(model, Be, T, step_ms, dtype):
+    """Per-kernel HIP-event timing of one UNet evaluation (said_profile_unet: every launch of the schedule replayed
+    back to back in a graph on the caller's stream and timed with hipEvents) + the whole-step figures."""
     eng = model._eng
     stages = eng.profile_unet(Be, T, reps=40)
+    peak_tf = MFMA_PEAK_TFLOPS[dtype]
     agg = {}
     for st in stages:
         name = (f"attn_kernel<D{32 * st['NB']},KS{st['KS']}>" if st["kind"] == 1 else
@@ -107,90 +138,118 @@ def roofline(model, Be, T, step_ms):
     d = agg[dom]
     achieved = d["bytes"] / (d["us"] * 1e-6) / 1e9
     from said_amd import _engine
-    unet_bytes = _engine.unet_algorithmic_bytes(Be, T, 4)
+    unet_bytes = _engine.unet_algorithmic_bytes(Be, T, 4)   # activations are stored in fp32 in both modes
     unet_flops = _engine.unet_algorithmic_flops(Be, T)
     sum_us = sum(a["us"] for a in agg.values())
     out = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
            "launches_per_unet": d["launches"], "avg_launch_us": round(d["us"] / d["launches"], 3),
            "alg_bytes_per_launch": round(d["bytes"] / d["launches"]),
            "kernel_tflops": round(d["flops"] / (d["us"] * 1e-6) / 1e12, 3),
-           "kernel_mfma_frac": round(d["flops"] / (d["us"] * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 5),
-           "unet_step": {"ms_graph_replay": round(step_ms, 4), "sum_kernel_us": round(sum_us, 2), "launches": len(stages),
+           "mfma_peak_tflops": peak_tf, "mfma_dtype": dtype,
+           "kernel_mfma_frac": round(d["flops"] / (d["us"] * 1e-6) / 1e12 / peak_tf, 5),
+           "unet_step": {"ms_loop_per_step": round(step_ms, 4), "sum_kernel_us": round(sum_us, 2), "launches": len(stages),
                          "alg_bytes": round(unet_bytes), "alg_gflop": round(unet_flops / 1e9, 3),
                          "hbm_frac": round(unet_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "mfma_fp32_frac": round(unet_flops / (step_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 5)},
+                         "mfma_frac": round(unet_flops / (step_ms * 1e-3) / 1e12 / peak_tf, 5)},
            "by_kernel": {k: {"us": round(v["us"], 2), "launches": v["launches"],
                              "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1),
                              "TFLOPs": round(v["flops"] / (v["us"] * 1e-6) / 1e12, 2)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"])}}
+    # HBM traffic from the PMC counters is collected in its own rocprofv3 pass (scripts/gpu_pmc.sh; --pmc must not be
+    # combined with tracing) and committed: it is NOT measured in this run, hence the explicit source label
     tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tf):
         try:
             tr = json.load(open(tf))
             if tr.get("kernel") == dom:
                 out["traffic"] = tr.get("hbm_bytes_per_launch")
+                out["traffic_source"] = "profiles/traffic_latest.json (" + str(tr.get("source", "separate rocprofv3 --pmc pass")) + ")"
         except Exception:
             pass
     return out
 
 
-def main():
-    args = parse()
+def audio_encode_block(model, proc, T, B):
+    """Audio encoder alone (once per clip): HIP-event time of get_audio_embedding on the current stream."""
+    model.get_audio_embedding(proc, T)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    ev0.record()
+    for _ in range(reps):
+        model.get_audio_embedding(proc, T)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    Ta = proc.shape[1]
+    # SURVEY 2b: conv stack 24.56 GMAC (at 160,000 samples, scales with Ta), projection 0.39 MMAC/frame, pos-conv
+    # 4.72 MMAC/frame, 12 layers x (7.08 MMAC/frame + 2*768*T MAC/frame of attention)
+    mac = 24.56e9 * Ta / 160000.0 + T * (0.393e6 + 4.719e6 + 12 * (7.078e6 + 2 * 768.0 * T))
+    weights_b = 94371712 * 4.0
+    act_b = 512 * ((Ta - 10) // 5 + 1) * 4.0 * 2     # conv0 activation written + read once per clip
+    return {"ms_per_clip": round(ms / B, 4), "ms_per_batch": round(ms, 3), "clips": B,
+            "tflops": round(2 * mac * B / (ms * 1e-3) / 1e12, 2),
+            "mfma_frac_fp32": round(2 * mac * B / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["f32"], 4),
+            "alg_bytes": round(weights_b + B * act_b), "alg_GBps": round((weights_b + B * act_b) / (ms * 1e-3) / 1e9, 1)}
+
+
+def run(args):
+    """One rank of the bench (rank / world from the torchrun-style environment)."""
+    from said_amd import shard
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    B, Ta = args.batch, int(round(args.seconds * 16000))
+    T = int(Ta / 16000 * 60)
+    torch.set_grad_enabled(False)
+
+    if args.dry_run_gloo:
+        # plumbing only: same launch, shard, gather and timing code, CPU stand-in for the path (no HIP, no numbers)
+        dist = shard.init_process_group("gloo", rank, world) if world > 1 else None
+
+        def path_fn(clips):
+            return torch.stack([torch.full((T, 32), float(c)) for c in clips])
+
+        r = shard.timed_sharded_passes(path_fn, rank=rank, world=world, clips_per_rank=B, steps=args.steps, warmup=args.warmup,
+                                       dist=dist, device=torch.device("cpu"))
+        if rank == 0:
+            want = sum(float(c) * T * 32 for c in range(world * B))
+            print(json.dumps({"dry_run": "gloo/cpu stand-in path: NOT a measurement", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "clip_ranges": r.clip_ranges, "gathered_shape": list(r.gathered.shape),
+                              "gathered_checksum": r.checksum, "checksum_ok": r.checksum == want}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: said_amd has no CPU path")
+        raise SystemExit("bench.py needs an MI355X: said_amd has no CPU path (use --dry_run_gloo for the launch plumbing)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dist = shard.init_process_group("nccl", rank, world, dev) if world > 1 else None   # "nccl" IS RCCL on ROCm
 
     from said_amd.model.diffusion import SAID_UNet1D
     from said_amd.util import synth
-    torch.set_grad_enabled(False)
-    B, Ta = args.batch, int(round(args.seconds * 16000))
-    T = int(Ta / 16000 * 60)
     model = SAID_UNet1D()
     model.load_state_dict(synth.said_state_dict(), strict=True)
     model.to(dev).eval()
     model.set_mfma_dtype("bf16" if args.dtype == "bf16" else "fp32")
-    # synthetic inputs, resident in HBM before the timed region
-    wav = [synth.synth_waveform(rank * B + i, Ta).numpy() for i in range(B)]
+    # synthetic inputs, resident in HBM before the timed region (SURVEY.md §8d); keyed by GLOBAL clip id
+    clips = shard.clip_range(rank, world, B)
+    wav = [synth.synth_waveform(c, Ta).numpy() for c in clips]
     proc = model.process_audio(wav).to(dev)
-    lat0 = synth.synth_latents(rank, (B, T, 32)).to(dev)
-    gathered = torch.empty(world * B, T, 32, device=dev) if world > 1 else None
+    lat0 = torch.cat([synth.synth_latents(c, (1, T, 32)) for c in clips]).to(dev)
 
-    def one_pass():
-        out = model.inference(proc, num_inference_steps=args.num_steps, guidance_scale=args.guidance_scale, eta=args.eta,
-                              init_latents=lat0)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out.result)
-        return out.result
+    def path_fn(_clips):
+        return model.inference(proc, num_inference_steps=args.num_steps, guidance_scale=args.guidance_scale, eta=args.eta,
+                               init_latents=lat0).result
 
-    for _ in range(args.warmup):
-        one_pass()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = one_pass()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert torch.isfinite(res).all()
+    r = shard.timed_sharded_passes(path_fn, rank=rank, world=world, clips_per_rank=B, steps=args.steps, warmup=args.warmup,
+                                   dist=dist, device=dev)
+    elapsed = r.elapsed_s
+    assert torch.isfinite(r.gathered).all()
 
     if rank == 0:
         frames = world * B * T * args.steps
@@ -208,10 +267,11 @@ def main():
                                                               "bf16 multiplies / fp32 accumulation and storage; BASELINE.json configs[2] shape"),
                        "batch_per_gpu": B, "frames": T, "num_steps": args.num_steps, "guidance_scale": args.guidance_scale,
                        "eta": args.eta, "parallelism": f"clips sharded over {world} GPU(s), one RCCL all-gather" if world > 1 else "single GPU",
+                       "clip_ranges": r.clip_ranges, "gathered_checksum": r.checksum,
                        "graph_nodes_per_step": model._eng.graph_num_nodes()},
         }
         if not args.no_roofline:
-            # pure denoising step time: time the loop alone (audio embedding precomputed)
+            # denoising loop alone (audio embedding precomputed), HIP events on the stream the engine launches on
             emb = model.get_audio_embedding(proc, T)
             torch.cuda.synchronize()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -221,13 +281,24 @@ def main():
             ev1.record()
             torch.cuda.synchronize()
             step_ms = ev0.elapsed_time(ev1) / args.num_steps
-            line["roofline"] = roofline(model, Be, T, step_ms)
+            line["roofline"] = roofline(model, Be, T, step_ms, args.dtype)
+            line["roofline"]["audio_encode"] = audio_encode_block(model, proc, T, B)
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only: other ranks would sit in the final barrier
             line["cpu_baseline"] = cpu_baseline(args, T, Ta)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: launch the N ranks here (one process per GPU)
+        from said_amd import shard
+        shard.spawn(run, (args,), args.gpus)
+        return
+    run(args)
 
 
 if __name__ == "__main__":

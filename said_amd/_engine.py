@@ -249,6 +249,8 @@ class Engine:
     def axpby(self, a: Sequence[float], x: torch.Tensor, c: Optional[Sequence[float]] = None, y: Optional[torch.Tensor] = None) -> torch.Tensor:
         x = _check_dev(x, "x")
         B = x.shape[0]
+        if len(a) != B or (c is not None and len(c) != B):
+            raise EngineError(f"axpby: need one coefficient per sample ({B}), got {len(a)}" + (f" / {len(c)}" if c is not None else ""))
         av = (c_float * B)(*[float(v) for v in a])
         cv = (c_float * B)(*[float(v) for v in (c if c is not None else [0.0] * B)])
         if y is not None:

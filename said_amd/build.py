@@ -40,7 +40,9 @@ def _stale(target: str, deps) -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(os.path.dirname(HERE), "include", "said_hip.h")]
+    # every header any source may include: a change to one of them rebuilds all objects
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "said_hip.h"))
     objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)

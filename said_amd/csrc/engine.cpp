@@ -113,8 +113,8 @@ struct said_ctx {
 
     // ---- per-step graph ----
     hipStream_t cap_stream = nullptr;  // private stream used only to capture the per-step graph
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t gexec = nullptr;
+    hipGraph_t graph = nullptr, graph_rem = nullptr;       // `gspg` consecutive steps / the N % gspg remaining steps
+    hipGraphExec_t gexec = nullptr, gexec_rem = nullptr;
     std::vector<long long> gkey;
     int gspg = 1;            // denoise steps captured per graph
     int gnodes = 0;
@@ -147,6 +147,13 @@ static bool trace_on() { static int v = -1; if (v < 0) v = getenv("SAID_TRACE") 
 
 inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 
+// said_create / said_destroy must not change the calling thread's current device as a side effect
+struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 template <typename T>
 int dalloc(said_ctx* ctx, T** out, size_t n, bool zero = true) {
     void* p = nullptr;
@@ -155,6 +162,17 @@ int dalloc(said_ctx* ctx, T** out, size_t n, bool zero = true) {
     ctx->allocs.push_back(p);
     *out = static_cast<T*>(p);
     return 0;
+}
+// grow-on-demand buffers: the buffer being replaced is released (the caller has synchronised the stream that used it)
+template <typename T>
+int drealloc(said_ctx* ctx, T** out, size_t n, bool zero = true) {
+    if (*out) {
+        auto it = std::find(ctx->allocs.begin(), ctx->allocs.end(), static_cast<void*>(*out));
+        if (it != ctx->allocs.end()) ctx->allocs.erase(it);
+        HIPCHK(hipFree(*out));
+        *out = nullptr;
+    }
+    return dalloc(ctx, out, n, zero);
 }
 int upload(said_ctx* ctx, float** out, const float* h, size_t n) {
     if (dalloc(ctx, out, n, false)) return -1;
@@ -605,7 +623,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
 // time_embed + the five emb_layers for `n` timesteps already in ts_dev -> EO [5*192][Np]
 void run_time_embed(said_ctx* c, int n, hipStream_t s) {
     const int Np = c->maxNp;
-    launch_timestep_embedding(c->ts_dev, c->E0, n, MC, Np, s);
+    launch_timestep_embedding(c->ts_dev, c->freqs, c->E0, n, MC, Np, s);
     const long long tt = (n + 31) / 32;
     {
         GemmArgs a = mkargs(n, TE);
@@ -647,7 +665,7 @@ void run_kv(said_ctx* c, int Be, int S, int Sp, hipStream_t s) {
 }
 
 // alignment band of ldm/attention.py:170-189 with Python's banker's rounding on doubles
-int set_band(said_ctx* ctx, int T, int S) {
+int set_band(said_ctx* ctx, int T, int S, hipStream_t s) {
     if (ctx->band_T == T && ctx->band_S == S) return 0;
     std::vector<int> lo(T), hi(T);
     const double ratio = (double)S / (double)T, kh = ratio / 2 + 1;
@@ -661,6 +679,9 @@ int set_band(said_ctx* ctx, int T, int S) {
         if (b <= a) return fail(ctx, "empty alignment window at query %d (T=%d, S=%d)", i, T, S);
     }
     if (wmax > 8) return fail(ctx, "alignment window of %d keys exceeds the kernel limit of 8 (T=%d, S=%d)", wmax, T, S);
+    // work queued earlier on the caller's stream may still read the previous tables: drain it before they change
+    // (only happens when the clip length changes)
+    HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipMemcpy(ctx->band_lo, lo.data(), T * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->band_hi, hi.data(), T * sizeof(int), hipMemcpyHostToDevice));
     ctx->band_T = T; ctx->band_S = S; ctx->band_wmax = wmax;
@@ -703,6 +724,7 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     if (max_batch_eff < 1 || max_frames < 1) return fail(nullptr, "said_create: bad sizes");
     if (in_channels != 32) return fail(nullptr, "said_create: in_channels must be 32 (got %d)", in_channels);
     if (ctx_dim < 16 || ctx_dim % 16) return fail(nullptr, "said_create: ctx_dim must be a positive multiple of 16 (got %d)", ctx_dim);
+    DeviceRestore restore_device;
     {
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return fail(nullptr, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
@@ -758,9 +780,12 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
 
 int said_destroy(said_ctx* ctx) {
     if (!ctx) return 0;
+    DeviceRestore restore_device;
     (void)hipSetDevice(ctx->device);
     if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
     if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
+    if (ctx->gexec_rem) (void)hipGraphExecDestroy(ctx->gexec_rem);
+    if (ctx->graph_rem) (void)hipGraphDestroy(ctx->graph_rem);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     if (ctx->cap_stream2) (void)hipStreamDestroy(ctx->cap_stream2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -976,7 +1001,6 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
         for (int k = 0; k < MC / 2; ++k) f[k] = (float)std::exp(-std::log(10000.0) * k / (MC / 2));
         HIPCHK(hipMemcpy(ctx->freqs, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    set_timestep_freqs_dev(ctx->freqs);
     ctx->host_w.clear();
     ctx->finalized = true;
     (void)used;
@@ -993,7 +1017,7 @@ int said_unet_forward(said_ctx* ctx, const float* sample_dev, const int64_t* tim
     HIPCHK(hipSetDevice(ctx->device));
     if (Be < 1 || Be > ctx->maxBe) return fail(ctx, "batch %d exceeds the context's max_batch_eff %d", Be, ctx->maxBe);
     if (T < 1 || T > ctx->maxT || S < 1 || S > ctx->maxT) return fail(ctx, "frames %d / context length %d exceed max_frames %d", T, S, ctx->maxT);
-    if (set_band(ctx, T, S)) return -1;
+    if (set_band(ctx, T, S, s)) return -1;
     UGeo g = make_geo(ctx, Be, 0, T, S);
     g.emb_b_stride = 1;
     std::vector<long long> ts(timesteps_host, timesteps_host + Be);
@@ -1028,7 +1052,7 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     if (p->use_mask && !(p->init_latents_dev && p->edit_noise_dev && p->mask_dev)) return fail(ctx, "use_mask needs init_latents_dev, edit_noise_dev and mask_dev");
     if (p->use_step_noise && !p->step_noise_dev) return fail(ctx, "use_step_noise needs step_noise_dev");
     if (p->save_intermediate && !p->intermediates_dev) return fail(ctx, "save_intermediate needs intermediates_dev");
-    if (set_band(ctx, T, T)) return -1;
+    if (set_band(ctx, T, T, s)) return -1;
     UGeo g = make_geo(ctx, Be, cfg ? B : 0, T, T);
     g.step_ptr = ctx->step_dev;
     const long long xs = (long long)C * g.Tp;
@@ -1060,7 +1084,7 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
         const size_t need = (size_t)N * B * xs;
         if (need > ctx->noise_cm_elems) {
             HIPCHK(hipStreamSynchronize(s));
-            if (dalloc(ctx, &ctx->noise_cm, need)) return -1;
+            if (drealloc(ctx, &ctx->noise_cm, need)) return -1;
             ctx->noise_cm_elems = need;
         }
         launch_tm_to_cm(p->step_noise_dev, ctx->noise_cm, N * B, T, C, g.Tp, xs, s);
@@ -1097,16 +1121,19 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
         int gsi, gri, lsi;
         memcpy(&gsi, &gs, 4); memcpy(&gri, &gr, 4); memcpy(&lsi, &ls, 4);
         // steps per graph: consecutive denoise steps captured back to back in ONE graph (the device-side step counter
-        // makes the copies distinct), so that N / spg graph launches cover the loop; spg = largest divisor of N <= limit
+        // makes the copies distinct): N / spg launches of the spg-step graph cover the loop, and a second graph holding
+        // the N % spg remaining steps finishes it (prime N, e.g. 997 = 99 x 10 + 7)
         static const int spg_limit = getenv("SAID_SPG") ? std::max(1, atoi(getenv("SAID_SPG"))) : 10;   // measured: ~6 us per graph launch boundary; 10 steps per graph recover 1.2 % at B=1
-        int spg = 1;
-        for (int d = std::min(spg_limit, N); d >= 1; --d) if (N % d == 0) { spg = d; break; }
+        int spg = std::min(spg_limit, N);
         if (ctx->use_branches) spg = 1;
-        std::vector<long long> key = {spg, B, T, cfg, gsi, gri, lsi, p->prediction_type, p->use_mask, p->use_step_noise,
+        const int rem = N % spg;
+        std::vector<long long> key = {spg, rem, B, T, cfg, gsi, gri, lsi, p->prediction_type, p->use_mask, p->use_step_noise,
                                       (long long)(uintptr_t)sa.inter, (long long)(uintptr_t)sa.step_noise};
         if (!ctx->gexec || key != ctx->gkey) {
             if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
             if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+            if (ctx->gexec_rem) { (void)hipGraphExecDestroy(ctx->gexec_rem); ctx->gexec_rem = nullptr; }
+            if (ctx->graph_rem) { (void)hipGraphDestroy(ctx->graph_rem); ctx->graph_rem = nullptr; }
             const bool fold_step = !(ctx->use_branches && Be >= 2);   // conv_in advances the step counter itself
             // Eager warm-up of the exact step sequence first: the first launch of a kernel inside a
             // stream capture hangs on ROCm 7.2 (lazy per-kernel initialisation is not capturable).
@@ -1127,33 +1154,38 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
             // capture on a private stream: the caller's stream may be the legacy default stream,
             // which cannot be captured; the instantiated graph is then replayed on the caller's stream
             hipStream_t cs = ctx->cap_stream;
-            HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-            for (int rep = 0; rep < spg; ++rep) {
-            if (!fold_step) launch_step_advance(ctx->step_dev, cs);
-            if (ctx->use_branches && Be >= 2) {
-                // The two halves of the UNet batch (unconditional / conditional under CFG) are independent until
-                // the scheduler: capture them as parallel branches so their per-kernel latencies overlap.
-                UGeo ga = g, gb = g;
-                ga.Be = Be / 2; ga.b0 = 0;
-                gb.Be = Be - Be / 2; gb.b0 = Be / 2;
-                HIPCHK(hipEventRecord(ctx->ev_fork, cs));
-                HIPCHK(hipStreamWaitEvent(ctx->cap_stream2, ctx->ev_fork, 0));
-                run_unet(ctx, ga, cs);
-                run_unet(ctx, gb, ctx->cap_stream2);
-                HIPCHK(hipEventRecord(ctx->ev_join, ctx->cap_stream2));
-                HIPCHK(hipStreamWaitEvent(cs, ctx->ev_join, 0));
-            } else {
-                run_unet(ctx, g, cs);
-            }
-            if (!fused) {
-                if (sa.guidance_rescale > 0.f) launch_rescale_partials(sa, ctx->rescale_part, cs);
-                launch_sched_step(sa, cs);
-            }
-            }   // steps per graph
-            TRACE("loop: capture recorded");
-            hipError_t e = hipStreamEndCapture(cs, &ctx->graph);
-            if (e != hipSuccess) return fail(ctx, "hipStreamEndCapture: %s", hipGetErrorString(e));
-            HIPCHK(hipGraphInstantiate(&ctx->gexec, ctx->graph, nullptr, nullptr, 0));
+            auto capture_steps = [&](int nsteps, hipGraph_t* gr, hipGraphExec_t* ge) -> int {
+                HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+                for (int rep = 0; rep < nsteps; ++rep) {
+                    if (!fold_step) launch_step_advance(ctx->step_dev, cs);
+                    if (ctx->use_branches && Be >= 2) {
+                        // The two halves of the UNet batch (unconditional / conditional under CFG) are independent until
+                        // the scheduler: capture them as parallel branches so their per-kernel latencies overlap.
+                        UGeo ga = g, gb = g;
+                        ga.Be = Be / 2; ga.b0 = 0;
+                        gb.Be = Be - Be / 2; gb.b0 = Be / 2;
+                        HIPCHK(hipEventRecord(ctx->ev_fork, cs));
+                        HIPCHK(hipStreamWaitEvent(ctx->cap_stream2, ctx->ev_fork, 0));
+                        run_unet(ctx, ga, cs);
+                        run_unet(ctx, gb, ctx->cap_stream2);
+                        HIPCHK(hipEventRecord(ctx->ev_join, ctx->cap_stream2));
+                        HIPCHK(hipStreamWaitEvent(cs, ctx->ev_join, 0));
+                    } else {
+                        run_unet(ctx, g, cs);
+                    }
+                    if (!fused) {
+                        if (sa.guidance_rescale > 0.f) launch_rescale_partials(sa, ctx->rescale_part, cs);
+                        launch_sched_step(sa, cs);
+                    }
+                }
+                TRACE("loop: capture recorded");
+                hipError_t e = hipStreamEndCapture(cs, gr);
+                if (e != hipSuccess) return fail(ctx, "hipStreamEndCapture: %s", hipGetErrorString(e));
+                HIPCHK(hipGraphInstantiate(ge, *gr, nullptr, nullptr, 0));
+                return 0;
+            };
+            if (capture_steps(spg, &ctx->graph, &ctx->gexec)) return -1;
+            if (rem > 0 && capture_steps(rem, &ctx->graph_rem, &ctx->gexec_rem)) return -1;
             size_t nn = 0;
             (void)hipGraphGetNodes(ctx->graph, nullptr, &nn);
             ctx->gnodes = (int)nn / spg;
@@ -1162,6 +1194,7 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
             TRACE("loop: graph instantiated");
         }
         for (int k = 0; k < N / ctx->gspg; ++k) HIPCHK(hipGraphLaunch(ctx->gexec, s));
+        if (rem > 0) HIPCHK(hipGraphLaunch(ctx->gexec_rem, s));
     }
     TRACE("loop: graphs launched");
     launch_finish(ctx->x_cm, xs, g.Tp, B, T, C, p->latent_scale, p->latents_dev, p->result_dev, s);
@@ -1242,7 +1275,7 @@ int said_profile_unet(said_ctx* ctx, int Be, int T, int reps, int max_stages, fl
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
     if (Be < 1 || Be > ctx->maxBe || T < 1 || T > ctx->maxT) return fail(ctx, "said_profile_unet: shape out of range");
-    if (set_band(ctx, T, T)) return -1;
+    if (set_band(ctx, T, T, s)) return -1;
     UGeo g = make_geo(ctx, Be, 0, T, T);
     g.emb_b_stride = 0;
     run_unet(ctx, g, s);  // eager warm-up: kernels must not see their first launch inside a capture
@@ -1337,15 +1370,18 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
     const int chunk = std::min(B, 8);
     const size_t eA = (size_t)chunk * W2V_CONV * rup(L[0], 32), eB = (size_t)chunk * W2V_CONV * rup(L[1], 32);
     const size_t tok = (size_t)chunk * Fp;
+    const size_t tw = std::max<size_t>(W2V_H, (size_t)ctx->ctx_dim);   // aT also receives the audio_proj_layer output (ctx_dim wide)
     if (eA > ctx->abuf_elems[0] || eB > ctx->abuf_elems[1] || tok > ctx->a_tok_elems) {
-        HIPCHK(hipStreamSynchronize(s));
-        if (dalloc(ctx, &ctx->abufA, eA) || dalloc(ctx, &ctx->abufB, eB)) return -1;
-        ctx->abuf_elems[0] = eA; ctx->abuf_elems[1] = eB;
-        if (dalloc(ctx, &ctx->aX, tok * W2V_CONV) || dalloc(ctx, &ctx->aH, tok * W2V_H) || dalloc(ctx, &ctx->aT, tok * W2V_H) ||
-            dalloc(ctx, &ctx->aO, tok * 2 * W2V_H) || dalloc(ctx, &ctx->aQK, tok * 2 * W2V_H) || dalloc(ctx, &ctx->aVT, tok * W2V_H) ||
-            dalloc(ctx, &ctx->aF, tok * W2V_FFN) || dalloc(ctx, &ctx->aPOS, tok * W2V_H))
-            return -1;
-        ctx->a_tok_elems = tok;
+        HIPCHK(hipStreamSynchronize(s));   // the buffers being replaced may still be in use by an earlier call
+        if (eA > ctx->abuf_elems[0]) { if (drealloc(ctx, &ctx->abufA, eA)) return -1; ctx->abuf_elems[0] = eA; }
+        if (eB > ctx->abuf_elems[1]) { if (drealloc(ctx, &ctx->abufB, eB)) return -1; ctx->abuf_elems[1] = eB; }
+        if (tok > ctx->a_tok_elems) {
+            if (drealloc(ctx, &ctx->aX, tok * W2V_CONV) || drealloc(ctx, &ctx->aH, tok * W2V_H) || drealloc(ctx, &ctx->aT, tok * tw) ||
+                drealloc(ctx, &ctx->aO, tok * 2 * W2V_H) || drealloc(ctx, &ctx->aQK, tok * 2 * W2V_H) || drealloc(ctx, &ctx->aVT, tok * W2V_H) ||
+                drealloc(ctx, &ctx->aF, tok * W2V_FFN) || drealloc(ctx, &ctx->aPOS, tok * W2V_H))
+                return -1;
+            ctx->a_tok_elems = tok;
+        }
     }
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = std::min(chunk, B - b0);

@@ -144,8 +144,8 @@ void launch_cm_to_tm(const float* src, float* dst, int B, int T, int C, int pitc
 // broadcast one vector to every column of a channel-major tensor (null_cond_emb.repeat)
 void launch_fill_cm_vec(const float* vec, float* dst, int B, int T, int C, int pitch, long long dst_bstride, hipStream_t s);
 // sinusoidal timestep embedding, channel-major [dim][pitch], column r <- timesteps[r] (ldm/util.py:66-90)
-void launch_timestep_embedding(const long long* timesteps_dev, float* dst, int n, int dim, int pitch, hipStream_t s);
-void set_timestep_freqs_dev(const float* freqs_dev);  // [dim/2] table used by launch_timestep_embedding
+// freqs_dev: the context's own [dim/2] frequency table (no process-global state: several contexts may coexist)
+void launch_timestep_embedding(const long long* timesteps_dev, const float* freqs_dev, float* dst, int n, int dim, int pitch, hipStream_t s);
 void launch_step_advance(int* step_ptr, hipStream_t s);
 void configure_gemm_kernels();   // raise the dynamic-LDS limit of every instantiation (call once, outside capture)
 void configure_attn_kernels();

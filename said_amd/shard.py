@@ -1,0 +1,126 @@
+"""Multi-GPU sharding of the SAiD path: clips are independent, so they are partitioned
+contiguously over the ranks (one process per GPU), every rank runs the whole path on its own clips with no
+data-path collective, and ONE all-gather (RCCL over xGMI when the backend is "nccl") assembles the
+(world * B_local, T, C) result in global clip order.
+
+This module is the single implementation of that logic: ``bench.py`` calls it with the HIP path on "nccl",
+``tests/test_shard_gloo.py`` calls the same functions with a CPU stand-in path on "gloo" (world_size 2).
+The reference has no counterpart (its inference is single-device: script/inference.py:103-107, 157-158).
+"""
+from __future__ import annotations
+
+import os
+import socket
+import time
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+import torch
+
+
+def clip_range(rank: int, world: int, clips_per_rank: int) -> range:
+    """Global clip ids owned by `rank` (contiguous shard; weak scaling: every rank owns `clips_per_rank`)."""
+    if not (0 <= rank < world) or clips_per_rank < 1:
+        raise ValueError(f"bad shard request: rank {rank} of {world}, {clips_per_rank} clips per rank")
+    return range(rank * clips_per_rank, (rank + 1) * clips_per_rank)
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def init_process_group(backend: str, rank: int, world: int, device: Optional[torch.device] = None):
+    """Rendezvous on 127.0.0.1 (the container hostname may not resolve); MASTER_PORT must be set by the launcher."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        raise RuntimeError("MASTER_PORT is not set: launch through torch.distributed.run or said_amd.shard.spawn")
+    kw = {}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
+@dataclass
+class ShardedRun:
+    elapsed_s: float              # max over ranks of the timed region
+    gathered: Optional[torch.Tensor]   # (world * B_local, T, C) in global clip order (every rank holds it)
+    clip_ranges: List[List[int]]  # per rank [first, last] global clip ids
+    checksum: float               # float64 sum of the gathered tensor (same on every rank)
+
+
+def gather_clips(dist, local: torch.Tensor, world: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One all-gather of the per-rank (B_local, T, C) results into (world * B_local, T, C): rank r's clips land at
+    rows [r * B_local, (r + 1) * B_local) — the contiguous partition of clip_range()."""
+    if world == 1:
+        return local
+    if out is None:
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out
+
+
+def timed_sharded_passes(path_fn: Callable[[range], torch.Tensor], *, rank: int, world: int, clips_per_rank: int,
+                         steps: int, warmup: int, dist=None, device: Optional[torch.device] = None) -> ShardedRun:
+    """The bench contract: `warmup` untimed passes, then EXACTLY `steps` passes bracketed by a barrier +
+    device synchronisation on both sides; elapsed = MAX over ranks.  One pass = path_fn(own clip ids) +
+    (world > 1) the all-gather, both inside the timed region."""
+    clips = clip_range(rank, world, clips_per_rank)
+    on_gpu = device is not None and device.type == "cuda"
+    sync = (lambda: torch.cuda.synchronize(device)) if on_gpu else (lambda: None)
+    gathered = None
+
+    def one_pass():
+        nonlocal gathered
+        local = path_fn(clips)
+        if local.shape[0] != clips_per_rank:
+            raise RuntimeError(f"path returned {local.shape[0]} clips for a shard of {clips_per_rank}")
+        if world > 1:
+            if gathered is None:
+                gathered = torch.empty((world * clips_per_rank,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+            gather_clips(dist, local, world, gathered)
+        else:
+            gathered = local
+        return gathered
+
+    for _ in range(warmup):
+        one_pass()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_pass()
+    sync()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device if on_gpu else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    checksum = float(gathered.double().sum().item()) if gathered is not None else 0.0
+    ranges = [[clip_range(r, world, clips_per_rank)[0], clip_range(r, world, clips_per_rank)[-1]] for r in range(world)]
+    return ShardedRun(elapsed_s=elapsed, gathered=gathered, clip_ranges=ranges, checksum=checksum)
+
+
+def _spawn_entry(rank: int, world: int, port: int, target, args):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["WORLD_SIZE"] = str(world)
+    os.environ["RANK"] = str(rank)
+    os.environ["LOCAL_RANK"] = str(rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
+    target(*args)
+
+
+def spawn(target, args: tuple, world: int) -> None:
+    """Self-launch `world` ranks on this node (one per GPU): what `torch.distributed.run --nproc-per-node` would do,
+    for callers that were started as a plain `python bench.py --gpus N`."""
+    import torch.multiprocessing as mp
+    mp.spawn(_spawn_entry, args=(world, free_port(), target, args), nprocs=world, join=True)

@@ -182,5 +182,146 @@ def main():
     print("arkit list in reference data == class list:", classes == BLENDSHAPE_CLASSES if classes else "n/a")
 
 
+def g9_loop_control_flow():
+    """G9 — the reference's OWN ``SAID_UNet1D.inference`` (said/model/diffusion.py:308-472) run on CPU.
+
+    ``said.model.diffusion`` imports ``diffusers`` (absent here), so the two names it takes from it —
+    ``DDIMScheduler`` and ``rescale_noise_cfg`` — are provided by a stub module backed by ``oracle/scheduler.py``.
+    What this pins to the reference's code: the loop CONTROL FLOW — guidance order (uncond first, ``e_c + s (e_c - e_u)``),
+    ``t_start``, ``timesteps[-init_timestep]``, the re-noising of ``init_latents`` with the NEXT timestep and the clean
+    init on the last step, ``latents / latent_scale`` and the final clamp, the order of the random draws, the 0-dim
+    timestep broadcast in ``forward`` — together with the reference's own UNet and audio encoder.  What it does NOT
+    pin: the scheduler arithmetic itself, which is the oracle's restatement on both sides (fixture name says so).
+    ``torch.randn`` is replaced by a queue of seeded draws so the same noise can be injected into the oracle / HIP
+    path: start latents (:363-367), editing noise inside ``add_noise`` (:383-385), one draw per step for eta > 0."""
+    from dataclasses import dataclass
+    from oracle import scheduler as osch
+
+    class _StubDDIM:
+        def __init__(self, num_train_timesteps=1000, beta_schedule="squaredcos_cap_v2", prediction_type="epsilon"):
+            assert beta_schedule == "squaredcos_cap_v2"
+            self._o = osch.OracleDDIM(num_train_timesteps, prediction_type)
+            self.config = types.SimpleNamespace(num_train_timesteps=num_train_timesteps, prediction_type=prediction_type)
+            self.init_noise_sigma = self._o.init_noise_sigma
+            self.alphas_cumprod = self._o.alphas_cumprod
+
+        @property
+        def timesteps(self):
+            return self._o.timesteps
+
+        def set_timesteps(self, n, device=None):
+            self._o.set_timesteps(n)
+
+        def scale_model_input(self, sample, timestep=None):
+            return sample
+
+        def step(self, model_output, timestep, sample, eta=0.0):
+            vn = torch.randn(model_output.shape) if eta > 0 else None   # diffusers draws randn_tensor(model_output.shape) here
+            return types.SimpleNamespace(prev_sample=self._o.step(model_output, int(timestep), sample, eta=eta, variance_noise=vn))
+
+        def add_noise(self, original, noise, timesteps):
+            return self._o.add_noise(original, noise, timesteps)
+
+        def get_velocity(self, sample, noise, timesteps):
+            return self._o.get_velocity(sample, noise, timesteps)
+
+    d = types.ModuleType("diffusers")
+    d.DDIMScheduler = _StubDDIM
+    d.SchedulerMixin = object
+    d.__path__ = []
+    pp = types.ModuleType("diffusers.pipelines.stable_diffusion.pipeline_stable_diffusion")
+    pp.rescale_noise_cfg = osch.rescale_noise_cfg
+    for name in ("diffusers", "diffusers.pipelines", "diffusers.pipelines.stable_diffusion"):
+        m = sys.modules.setdefault(name, types.ModuleType(name))
+        m.__path__ = []
+    sys.modules["diffusers"] = d
+    sys.modules["diffusers.pipelines.stable_diffusion.pipeline_stable_diffusion"] = pp
+    import_reference()
+    ref_diff = importlib.import_module("said.model.diffusion")
+
+    from transformers import Wav2Vec2Config, Wav2Vec2FeatureExtractor
+    fe = Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0, do_normalize=True,
+                                  return_attention_mask=False)
+
+    class _Proc:   # the slice of Wav2Vec2Processor the reference touches (diffusion.py:95, 204-206)
+        feature_extractor = fe
+
+        def __call__(self, *a, **k):
+            return fe(*a, **k)
+
+    NL = 2   # encoder layers (a 12-layer encoder adds nothing to what G9 pins; G5 pins the encoder itself)
+    sd = synth.said_state_dict(num_w2v_layers=NL)
+    sd_load = {k.replace("conv.weight_g", "conv.parametrizations.weight.original0").replace(
+        "conv.weight_v", "conv.parametrizations.weight.original1"): v for k, v in sd.items()}
+    real_randn = torch.randn
+    out = {}
+    cases = {
+        "cfg": dict(B=2, Ta=16000, N=20, gs=2.0),
+        "nocfg_inter": dict(B=1, Ta=16000, N=8, gs=1.0, save_intermediate=True),
+        "edit_mask_strength": dict(B=2, Ta=16000, N=15, gs=2.0, edit=True, strength=0.6, save_intermediate=True),
+        "eta_rescale": dict(B=2, Ta=8000, N=10, gs=2.5, eta=1.0, rescale=0.7),
+        "sample_pred": dict(B=1, Ta=8000, N=6, gs=2.0, pred="sample"),
+        "v_pred_scaled": dict(B=1, Ta=8000, N=6, gs=2.0, pred="v_prediction", latent_scale=2.0),
+        "strength0": dict(B=1, Ta=8000, N=10, gs=2.0, edit=True, strength=0.0),
+    }
+    for name, c in cases.items():
+        B, Ta, N = c["B"], c["Ta"], c["N"]
+        T = int(Ta / 16000 * 60)
+        m = ref_diff.SAID_UNet1D(audio_config=Wav2Vec2Config(num_hidden_layers=NL), audio_processor=_Proc(),
+                                 prediction_type=c.get("pred", "epsilon"), latent_scale=c.get("latent_scale", 1))
+        m.load_state_dict(sd_load, strict=True)
+        m.eval()
+        wav = [synth.synth_waveform(10 + i, Ta).numpy() for i in range(B)]
+        proc = m.process_audio(wav)
+        strength = c.get("strength", 1.0)
+        init_t = min(int(N * strength), N)
+        edit = c.get("edit", False)
+        eta = c.get("eta", 0.0)
+        # the draws the reference will make, in its order
+        queue = []
+        if not edit:
+            queue.append(("start", synth.synth_latents(100, (B, T, 32))))
+        else:
+            queue.append(("edit", synth.synth_latents(102, (B, T, 32))))
+        if eta > 0:
+            sn = synth.synth_latents(103, (init_t, B, T, 32))
+            queue += [("step", sn[k]) for k in range(init_t)]
+        drawn = []
+
+        def fake_randn(*shape, **kw):
+            if len(shape) == 1 and not isinstance(shape[0], int):
+                shape = tuple(shape[0])
+            tag, t = queue.pop(0)
+            assert tuple(t.shape) == tuple(shape), (name, tag, t.shape, shape)
+            drawn.append(tag)
+            return t.clone()
+
+        kw = {}
+        if edit:
+            init_samples = torch.sigmoid(synth.synth_latents(101, (B, T, 32))) * 0.5
+            mask = torch.zeros(B, T, 32)
+            mask[:, : T // 3] = 1.0
+            mask[:, :, :4] = 1.0
+            kw = dict(init_samples=init_samples, mask=mask)
+        torch.randn = fake_randn
+        try:
+            with torch.no_grad():
+                o = m.inference(proc, num_inference_steps=N, strength=strength, guidance_scale=c["gs"],
+                                guidance_rescale=c.get("rescale", 0.0), eta=eta, save_intermediate=c.get("save_intermediate", False), **kw)
+        finally:
+            torch.randn = real_randn
+        assert not queue, (name, [q[0] for q in queue])
+        out[name + "_result"] = o.result.numpy()
+        if c.get("save_intermediate", False):
+            out[name + "_inter"] = torch.stack(o.intermediates).numpy()
+        print(f"  g9 {name}: draws {drawn[:3]}{'...' if len(drawn) > 3 else ''} steps {init_t} result range "
+              f"[{float(o.result.min()):.3f}, {float(o.result.max()):.3f}]")
+    save("g9_loop_control_flow_scheduler_leg_unpinned", **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        g9_loop_control_flow()
+    else:
+        main()
+        g9_loop_control_flow()

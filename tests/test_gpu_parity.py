@@ -403,3 +403,130 @@ def test_bf16_loop_cfg_batch32_shape(model, dev):
     d = (r16 - r32).abs()
     print(f"bf16 loop: max abs diff {float(d.max()):.3e}, mean {float(d.mean()):.3e}")
     assert float(d.mean()) <= 1e-2 and float(d.max()) <= 0.25
+
+
+# ---------------------------------------------------------------- round 2: chains at the headline's real length
+def test_loop_cfg_1000_steps_1s_vs_oracle(model, sd_full, dev):
+    """BASELINE configs[1]'s chain length: 1000 DDIM steps, guidance 2, on a 1 s clip (T=60) against the oracle."""
+    got, ref = _loop_case(model, sd_full, dev, B=1, Ta=16000, N=1000, gs=2.0, tol=1e-3)
+    print(f"N=1000 eta=0: max abs err {float((got - ref).abs().max()):.3e}")
+
+
+def test_loop_cfg_1000_steps_eta1_vs_oracle(model, sd_full, dev):
+    """Same chain with eta = 1 (DDPM-like ancestral sampling): 1000 injected noise draws."""
+    got, ref = _loop_case(model, sd_full, dev, B=1, Ta=16000, N=1000, gs=2.0, eta=1.0, tol=2e-3)
+    print(f"N=1000 eta=1: max abs err {float((got - ref).abs().max()):.3e}")
+
+
+def test_loop_editing_100_steps_in_betweening(model, sd_full, dev):
+    """BASELINE configs[4]'s step count (100 DDIM steps) in editing mode with the in-betweening mask, on 2 s."""
+    B, Ta, N = 1, 32000, 100
+    T = 120
+    proc = op.process_audio([synth.synth_waveform(78, Ta).numpy()])
+    init_samples = torch.sigmoid(synth.synth_latents(111, (B, T, 32))) * 0.5
+    mask = torch.zeros(B, T, 32)
+    mask[:, :40] = 1.0
+    mask[:, 80:] = 1.0
+    mask[:, :, :4] = 1.0
+    en = synth.synth_latents(112, (B, T, 32))
+    out = model.inference(proc.to(dev), num_inference_steps=N, guidance_scale=2.0, init_samples=init_samples.to(dev),
+                          mask=mask.to(dev), edit_noise=en.to(dev))
+    ref = op.inference(sd_full, proc, init_latents=en, num_inference_steps=N, guidance_scale=2.0, init_samples=init_samples,
+                       mask=mask, edit_noise=en)
+    err = float((out.result.cpu() - ref.result).abs().max())
+    print(f"editing N=100: max abs err {err:.3e}")
+    assert err <= 1e-3
+    assert float((out.result.cpu()[:, :40] - init_samples[:, :40].clamp(0, 1)).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("N", [11, 13, 23, 997])
+def test_loop_step_counts_not_divisible_by_graph_length(model, sd_full, dev, N):
+    """Steps per graph is 10: N = 11, 13, 23 and the prime 997 run N // 10 ten-step graphs + one remainder graph."""
+    got, ref = _loop_case(model, sd_full, dev, B=1, Ta=8000, N=N, gs=2.0, tol=1e-3)
+    print(f"N={N}: max abs err {float((got - ref).abs().max()):.3e}, nodes/step {model._eng.graph_num_nodes()}")
+
+
+def test_audio_encoder_10s_vs_oracle(model, w2v_sd, dev):
+    """The headline's encode: 160,000 samples -> 499 conv frames -> 600 frames."""
+    proc = op.process_audio(synth.synth_waveform(8, 160000))
+    ref = ow.wav2vec2_forward(w2v_sd, proc, 600)[0].numpy()
+    got = model.get_audio_embedding(proc.to(dev), 600).cpu().numpy()
+    err = np.abs(got - ref).max()
+    print(f"audio 10 s: max abs err {err:.3e} (|ref| max {np.abs(ref).max():.2f})")
+    assert err <= 2e-3 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name", ["cfg", "nocfg_inter", "edit_mask_strength", "eta_rescale", "sample_pred", "v_pred_scaled", "strength0"])
+def test_loop_vs_reference_own_inference_g9(golden, dev, name):
+    """The HIP path against the REFERENCE's own SAID_UNet1D.inference (G9 golden, captured on CPU with diffusers stubbed
+    by the oracle's scheduler: control flow, UNet and encoder are the reference's code; scheduler leg unpinned)."""
+    from said_amd.model.diffusion import SAID_UNet1D
+    from said_amd.model.wav2vec2 import AudioConfig
+    from g9_cases import G9_CASES, g9_inputs
+    c = G9_CASES[name]
+    g = golden("g9_loop_control_flow_scheduler_leg_unpinned")
+    m = SAID_UNet1D(audio_config=AudioConfig(num_hidden_layers=2), prediction_type=c.get("pred", "epsilon"),
+                    latent_scale=c.get("latent_scale", 1))
+    m.load_state_dict(synth.said_state_dict(num_w2v_layers=2), strict=True)
+    m.to(dev).eval()
+    proc, kw, noise, init_t = g9_inputs(c)
+    kw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    noise = {k: v.to(dev) for k, v in noise.items()}
+    out = m.inference(proc.to(dev), **kw, **noise)
+    ref = g[name + "_result"]
+    err = float(np.abs(out.result.cpu().numpy() - ref).max())
+    print(f"g9 {name}: HIP vs reference loop, max abs err {err:.2e}")
+    assert err <= 1e-3
+    if c.get("save_intermediate", False):
+        ri = g[name + "_inter"]
+        assert len(out.intermediates) == ri.shape[0]
+        assert float(np.abs(torch.stack(out.intermediates).cpu().numpy() - ri).max()) <= 1e-2
+
+
+def test_bf16_loop_50_steps_vs_fp32_oracle(model, sd_full, dev):
+    """configs[2]'s chain (50 DDIM steps, guidance) in bf16 mode on a 1 s clip against the FP32 ORACLE."""
+    try:
+        model.set_mfma_dtype("bf16")
+        got, ref = _loop_case(model, sd_full, dev, B=2, Ta=16000, N=50, gs=2.0, tol=1.0)
+    finally:
+        model.set_mfma_dtype("fp32")
+    d = (got - ref).abs()
+    print(f"bf16 50-step loop vs fp32 oracle: max abs err {float(d.max()):.3e}, mean {float(d.mean()):.3e}")
+    assert float(d.max()) <= BF16_LOOP_MAX and float(d.mean()) <= BF16_LOOP_MEAN
+
+
+BF16_LOOP_MAX, BF16_LOOP_MEAN = 0.25, 1e-2   # placeholders until measured on the MI355X: set to 3x the printed values
+
+
+def test_two_contexts_in_one_process(model, unet_sd, dev):
+    """Two engine contexts alive at once (the timestep-frequency table used to be a process global): the
+    second context is created, used and destroyed while the first keeps producing the same numbers."""
+    from said_amd.model.diffusion import SAID_UNet1D
+    x = synth.synth_latents(5, (2, 33, 32)).to(dev)
+    c = synth.synth_latents(6, (2, 33, 768)).to(dev)
+    ts = torch.tensor([77, 901]).to(dev)
+    before = model(x, ts, c)
+    m2 = SAID_UNet1D()
+    m2.load_state_dict(synth.said_state_dict(salt=1), strict=True)
+    m2.to(dev).eval()
+    other = m2(x, ts, c)
+    assert not torch.equal(other, before)
+    m2._eng.close()
+    del m2
+    torch.cuda.synchronize()
+    after = model(x, ts, c)
+    assert torch.equal(before, after)
+    ref = ou.unet1d_forward(unet_sd, x.cpu(), ts.cpu(), c.cpu())
+    assert float((after.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+def test_pred_original_sample_broadcasts_single_timestep(model, dev):
+    """diffusion.py:157-186 with a length-1 / 0-dim timestep and B > 1 (reference: .view(-1, 1, 1) broadcast)."""
+    B = 3
+    x, n = synth.synth_latents(1, (B, 11, 32)), synth.synth_latents(2, (B, 11, 32))
+    ac = model.noise_scheduler.alphas_cumprod
+    for t in (torch.tensor([500]), torch.tensor(500)):
+        got = model.pred_original_sample(x.to(dev), n.to(dev), t).cpu()
+        a = ac[t].view(-1, 1, 1)
+        want = (x - (1 - a) ** 0.5 * n) / a ** 0.5
+        assert float((got - want).abs().max()) <= 1e-5

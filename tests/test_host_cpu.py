@@ -203,3 +203,19 @@ def test_load_audio_stereo_48k_int16(tmp_path):
     mono16 = str(tmp_path / "m.wav")
     wavfile.write(mono16, 16000, a)
     assert torch.equal(audio.load_audio(mono16, 16000), torch.from_numpy(a.astype(np.float32) / 32768.0))
+
+
+@pytest.mark.parametrize("N", [1000, 997, 100, 50, 13, 7, 1])
+@pytest.mark.parametrize("eta", [0.0, 1.0, 0.3])
+def test_coef_table_vectorised_is_bit_identical_to_rowwise(N, eta):
+    """The batched fp32 table (one expression over all steps) against the row-by-row 0-dim-tensor form in
+    DDIMScheduler.step's op order, full loops and strength-truncated loops: same bits."""
+    from said_amd.scheduler import DDIMScheduler
+    for pred in ("epsilon", "v_prediction"):
+        s = DDIMScheduler(prediction_type=pred)
+        s.set_timesteps(N)
+        ts = s.timesteps.numpy()
+        for sub in (ts, ts[N // 3:], ts[:0]):
+            a, b = s.coef_table(sub, eta), s.coef_table_rowwise(sub, eta)
+            assert a.dtype == np.float32 and a.shape == b.shape
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -1,31 +1,41 @@
-"""world_size-2 gloo test of the multi-GPU sharding logic used by bench.py: contiguous clip
-partition, no data-path collective, one all-gather of the (B_local, T, 32) results.  Runs on CPU; the per-rank
-"path" here is a deterministic stand-in keyed by the global clip index (the HIP path itself needs a GPU)."""
+"""world_size-2 gloo tests of the multi-GPU path on CPU.  They drive the SAME code bench.py runs on
+RCCL — said_amd.shard.{clip_range, init_process_group, timed_sharded_passes, gather_clips, spawn} — with a CPU
+stand-in for the per-rank path (the HIP path itself needs a GPU): contiguous clip partition, no data-path collective,
+one all-gather in global clip order, max-over-ranks timing, and bench.py's self-launch of N ranks."""
+import json
 import os
-import socket
+import subprocess
+import sys
+import time
 
 import torch
-import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from said_amd import shard
 
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clip_tensor(c, T):
+    return torch.full((T, 32), float(c)) + torch.arange(32).float() / 100
 
 
 def _worker(rank, world, port, B_local, T, out_q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    clips = [rank * B_local + i for i in range(B_local)]                 # contiguous shard
-    local = torch.stack([torch.full((T, 32), float(c)) + torch.arange(32).float() / 100 for c in clips])
-    gathered = torch.empty(world * B_local, T, 32)
-    dist.all_gather_into_tensor(gathered, local)
-    t = torch.tensor([1.0 + rank], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)                            # bench.py's max-over-ranks timing
+    dist = shard.init_process_group("gloo", rank, world)
+    calls = []
+
+    def path_fn(clips):                      # stand-in keyed by the GLOBAL clip id; rank 1 is the slow rank
+        calls.append(list(clips))
+        if rank == 1:
+            time.sleep(0.05)
+        return torch.stack([_clip_tensor(c, T) for c in clips])
+
+    r = shard.timed_sharded_passes(path_fn, rank=rank, world=world, clips_per_rank=B_local, steps=3, warmup=2, dist=dist,
+                                   device=torch.device("cpu"))
+    out_q.put((rank, r.gathered.clone(), r.elapsed_s, r.clip_ranges, r.checksum, calls))
     dist.barrier()
-    if rank == 0:
-        out_q.put((gathered, float(t)))
     dist.destroy_process_group()
 
 
@@ -33,13 +43,38 @@ def test_shard_and_gather_world2():
     world, B_local, T = 2, 3, 7
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
+    port = shard.free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, B_local, T, q)) for r in range(world)]
     for p in procs: p.start()
-    gathered, tmax = q.get(timeout=120)
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
     for p in procs: p.join(timeout=60)
     assert all(p.exitcode == 0 for p in procs)
-    assert gathered.shape == (world * B_local, T, 32)
-    for c in range(world * B_local):                                     # global clip order preserved
-        assert torch.equal(gathered[c, 0], torch.full((32,), float(c)) + torch.arange(32).float() / 100)
-    assert tmax == 2.0
+    want = torch.stack([_clip_tensor(c, T) for c in range(world * B_local)])
+    for rank, gathered, elapsed, ranges, checksum, calls in res:
+        assert torch.equal(gathered, want)                               # global clip order, on every rank
+        assert ranges == [[0, 2], [3, 5]]
+        assert checksum == float(want.double().sum())
+        assert len(calls) == 5 and all(c == list(shard.clip_range(rank, world, B_local)) for c in calls)   # 2 warm-up + exactly 3 timed
+    # elapsed is the MAX over ranks: both ranks report the slow rank's time (3 timed passes x 50 ms)
+    assert res[0][2] == res[1][2] and res[0][2] >= 0.15
+
+
+def test_clip_range_partitions_without_overlap():
+    for world, B in [(1, 1), (2, 3), (8, 32)]:
+        ids = [c for r in range(world) for c in shard.clip_range(r, world, B)]
+        assert ids == list(range(world * B))
+
+
+def test_bench_self_launches_ranks_dry_run():
+    """`python bench.py --gpus 2` without torchrun must spawn its two ranks itself; on CPU this is
+    exercised through the gloo dry-run flag, which shares launch, shard, gather and timing code with the RCCL run."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2", "--steps", "2", "--warmup", "1",
+                          "--seconds", "0.5", "--dry_run_gloo"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                               # ONE JSON line, from rank 0
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["clip_ranges"] == [[0, 1], [2, 3]] and j["gathered_shape"] == [4, 30, 32] and j["checksum_ok"]
