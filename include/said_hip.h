@@ -188,6 +188,31 @@ int said_debug_clocks(said_ctx* ctx, int enable, long long* out_host);
  *  "x","eps","stH0","stP","stM", ...) to host memory. */
 int said_debug_read(said_ctx* ctx, const char* name, float* out_host, int64_t n);
 
+/* ---- VAE encoder ----------------------------------------------
+ * Replaces the device work of BCVAE.encode -> BCEncoder.forward (said/model/vae.py:26-83,
+ * 228-243) as driven by generate_latents_info (script/test_evaluate.py:53-106): sliding
+ * windows of 120 frames of (T, 32) coefficients -> the 64-d latent mean used by the FD /
+ * WInD / multimodality metrics.  Eval-mode only: BatchNorm1d layers use their running
+ * statistics and are folded into the preceding Conv1d / Linear on the host.  The decoder
+ * (vae.py:115-178) is not on this path; its state-dict keys are accepted and ignored. */
+typedef struct said_vae said_vae;
+/* BCVAE(channels=32, seq_len=120, z_dim=64) (vae.py:181-207); other sizes are refused. */
+int said_vae_create(said_vae** out, int device, int in_channels, int seq_len, int z_dim);
+int said_vae_destroy(said_vae* vae);
+const char* said_vae_last_error(const said_vae* vae);
+/* `name` is the BCVAE state-dict key ("encoder.conv_layers.0.weight", ..., "encoder.fc_mu.bias",
+ * BatchNorm "running_mean"/"running_var" included; "num_batches_tracked" may be passed as a float
+ * scalar or omitted).  Replaces said_vae.load_state_dict(...) + .to(device) (test_evaluate.py:551-553). */
+int said_vae_set_weight(said_vae* vae, const char* name, const float* data_host, const int64_t* shape, int ndim);
+int said_vae_finalize_weights(said_vae* vae);
+/* encode `n_windows` windows of (120, 32) fp32 coefficients.  Window w starts at
+ * coeffs_dev + w * window_stride_floats: 120*32 for a (N, 120, 32) batch of windows,
+ * window_step_size*32 for sliding windows over one (T, 32) sequence
+ * (test_evaluate.py:90-95: n = (T - 120) // step + 1 - padding).  mean_dev and logvar_dev
+ * (nullable) are (n_windows, 64) row-major: BCLatent.mean / .log_var (vae.py:79-83). */
+int said_vae_encode(said_vae* vae, const float* coeffs_dev, long long window_stride_floats, int n_windows, float* mean_dev,
+                    float* logvar_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,12 @@ EXPORTS = {
     "said_debug_read": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
     "said_unet_algorithmic_bytes": (c_double, [c_int, c_int, c_int]),
     "said_unet_algorithmic_flops": (c_double, [c_int, c_int]),
+    "said_vae_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int]),
+    "said_vae_destroy": (c_int, [c_void_p]),
+    "said_vae_last_error": (c_char_p, [c_void_p]),
+    "said_vae_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
+    "said_vae_finalize_weights": (c_int, [c_void_p]),
+    "said_vae_encode": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 
@@ -297,6 +303,60 @@ class Engine:
 
     def get_precision(self) -> str:
         return "bf16" if self.lib.said_get_precision(self.h) else "fp32"
+
+
+class VaeEngine:
+    """BCVAE encoder context on one GPU (include/said_hip.h, "VAE encoder")."""
+
+    def __init__(self, device: torch.device, in_channels: int = 32, seq_len: int = 120, z_dim: int = 64):
+        self.lib = load_library()
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise EngineError(f"said_amd runs on MI355X only (device={device}); there is no CPU fallback")
+        self.device = device
+        self.index = device.index if device.index is not None else torch.cuda.current_device()
+        self.seq_len, self.in_channels, self.z_dim = seq_len, in_channels, z_dim
+        h = c_void_p()
+        if self.lib.said_vae_create(ctypes.byref(h), self.index, in_channels, seq_len, z_dim) != 0:
+            raise EngineError("said_vae_create: " + (self.lib.said_vae_last_error(None) or b"?").decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.said_vae_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int, what: str):
+        if rc != 0:
+            raise EngineError(f"{what}: " + (self.lib.said_vae_last_error(self.h) or b"?").decode())
+
+    def load_weights(self, state_dict: Dict[str, torch.Tensor]):
+        for k, v in state_dict.items():
+            if k.endswith("num_batches_tracked"):
+                continue   # a counter, not a weight
+            a = np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy())
+            shape = (c_int64 * max(a.ndim, 1))(*(a.shape if a.ndim else (1,)))
+            self._chk(self.lib.said_vae_set_weight(self.h, k.encode(), a.ctypes.data_as(c_void_p), shape, max(a.ndim, 1)), f"said_vae_set_weight({k})")
+        self._chk(self.lib.said_vae_finalize_weights(self.h), "said_vae_finalize_weights")
+
+    def encode(self, coeffs: torch.Tensor, n_windows: int, window_stride: int, want_logvar: bool = True):
+        """`coeffs`: contiguous fp32 device tensor holding the windows at `window_stride` floats apart."""
+        coeffs = _check_dev(coeffs, "coeffs")
+        need = (n_windows - 1) * window_stride + self.seq_len * self.in_channels if n_windows > 0 else 0
+        if coeffs.numel() < need:
+            raise EngineError(f"coeffs holds {coeffs.numel()} floats, {n_windows} windows at stride {window_stride} need {need}")
+        mean = torch.empty(n_windows, self.z_dim, device=coeffs.device, dtype=torch.float32)
+        logvar = torch.empty_like(mean) if want_logvar else None
+        with torch.cuda.device(self.index):
+            self._chk(self.lib.said_vae_encode(self.h, _ptr(coeffs), int(window_stride), int(n_windows), _ptr(mean), _ptr(logvar), _stream()),
+                      "said_vae_encode")
+        return mean, logvar
 
 
 def unet_algorithmic_bytes(batch_eff: int, frames: int, bytes_per_elem: int = 4) -> float:

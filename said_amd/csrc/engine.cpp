@@ -1504,3 +1504,214 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
 }
 
 }  // extern "C"
+
+// --------------------------------------------------------------------------------------------
+// VAE encoder (said/model/vae.py:26-112; caller script/test_evaluate.py:53-106) — SURVEY §8(f)4
+// --------------------------------------------------------------------------------------------
+struct said_vae {
+    said_ctx c;            // weight table, allocation list, error string, device (the UNet members stay unused)
+    int seq_len = 120, cin = 32, zdim = 64;
+    int L[5] = {0, 0, 0, 0, 0};           // sequence lengths through the conv stack
+    PW conv[4], fc1, fc2, fc3, head;
+    int conv_k[4] = {3, 3, 4, 3}, conv_s[4] = {1, 1, 2, 1}, conv_n[4] = {32, 64, 64, 32};
+    bool finalized = false;
+    // workspace for `cap` windows at a time
+    int cap = 0;
+    float *X0 = nullptr, *Y[4] = {nullptr, nullptr, nullptr, nullptr}, *F = nullptr, *G1 = nullptr, *G2 = nullptr, *G3 = nullptr, *G4 = nullptr;
+};
+
+namespace {
+// eval-mode BatchNorm1d folded into the preceding conv / linear layer (host, double): y = (W x + b - mean) * g / sqrt(var + eps) + beta
+int fold_bn(said_ctx* ctx, const std::string& wname, const std::string& bname, const std::string& bn, const std::string& out_w,
+            const std::string& out_b) {
+    auto iw = ctx->host_w.find(wname), ib = ctx->host_w.find(bname);
+    if (iw == ctx->host_w.end() || ib == ctx->host_w.end()) return fail(ctx, "missing key in state dict: %s", (iw == ctx->host_w.end() ? wname : bname).c_str());
+    HostTensor W = iw->second, B = ib->second;
+    const int64_t N = W.shape[0];
+    const int64_t per = W.numel() / N;
+    if (!bn.empty()) {
+        const HostTensor* g = getw(ctx, bn + ".weight", {N});
+        const HostTensor* be = getw(ctx, bn + ".bias", {N});
+        const HostTensor* mu = getw(ctx, bn + ".running_mean", {N});
+        const HostTensor* var = getw(ctx, bn + ".running_var", {N});
+        if (!g || !be || !mu || !var) return -1;
+        for (int64_t n = 0; n < N; ++n) {
+            const double sc = (double)g->data[n] / std::sqrt((double)var->data[n] + 1e-5);   // nn.BatchNorm1d default eps
+            for (int64_t i = 0; i < per; ++i) W.data[n * per + i] = (float)((double)W.data[n * per + i] * sc);
+            B.data[n] = (float)(((double)B.data[n] - (double)mu->data[n]) * sc + (double)be->data[n]);
+        }
+    }
+    ctx->host_w[out_w] = std::move(W);
+    ctx->host_w[out_b] = std::move(B);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int said_vae_create(said_vae** out, int device, int in_channels, int seq_len, int z_dim) {
+    if (!out) return fail(nullptr, "said_vae_create: out is null");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "said_vae_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(nullptr, "said_vae_create: device %d out of range (%d visible)", device, ndev);
+    if (in_channels != 32 || seq_len != 120 || z_dim != 64)
+        return fail(nullptr, "said_vae_create: only BCVAE(channels=32, seq_len=120, z_dim=64) is supported (the FC stack is sized for it, vae.py:52)");
+    DeviceRestore restore_device;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, "said_vae_create: cannot query device %d", device);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(nullptr, "said_vae_create: device is %s; this library is built for gfx950 only", prop.gcnArchName);
+    said_vae* v = new said_vae();
+    v->c.device = device;
+    v->seq_len = seq_len; v->cin = in_channels; v->zdim = z_dim;
+    v->L[0] = seq_len;
+    for (int i = 0; i < 4; ++i) v->L[i + 1] = (v->L[i] - v->conv_k[i]) / v->conv_s[i] + 1;   // 118, 116, 57, 55
+    configure_gemm_kernels();
+    *out = v;
+    return 0;
+}
+
+int said_vae_destroy(said_vae* v) {
+    if (!v) return 0;
+    DeviceRestore restore_device;
+    (void)hipSetDevice(v->c.device);
+    for (void* p : v->c.allocs) (void)hipFree(p);
+    delete v;
+    return 0;
+}
+
+const char* said_vae_last_error(const said_vae* v) { return v ? v->c.err.c_str() : g_create_err.c_str(); }
+
+int said_vae_set_weight(said_vae* v, const char* name, const float* data_host, const int64_t* shape, int ndim) {
+    if (!v) return -1;
+    said_ctx* ctx = &v->c;
+    if (v->finalized) return fail(ctx, "said_vae_set_weight after finalize");
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    t.data.assign(data_host, data_host + t.numel());
+    ctx->host_w[name] = std::move(t);
+    return 0;
+}
+
+int said_vae_finalize_weights(said_vae* v) {
+    if (!v) return -1;
+    said_ctx* ctx = &v->c;
+    if (v->finalized) return fail(ctx, "weights already finalized");
+    HIPCHK(hipSetDevice(ctx->device));
+    const std::string E = "encoder.";
+    const char* conv_idx[4] = {"0", "3", "6", "9"};
+    const char* conv_bn[4] = {"1", "4", "7", ""};
+    int cin = v->cin;
+    for (int i = 0; i < 4; ++i) {
+        const std::string w = E + "conv_layers." + conv_idx[i];
+        if (!getw(ctx, w + ".weight", {v->conv_n[i], cin, v->conv_k[i]})) return -1;
+        const std::string bn = conv_bn[i][0] ? E + "conv_layers." + conv_bn[i] : "";
+        const std::string ow = "__vconv" + std::to_string(i) + ".w", ob = "__vconv" + std::to_string(i) + ".b";
+        if (fold_bn(ctx, w + ".weight", w + ".bias", bn, ow, ob)) return -1;
+        if (make_pw(ctx, &v->conv[i], ow, ob, v->conv_n[i], cin, v->conv_k[i])) return -1;
+        cin = v->conv_n[i];
+    }
+    const int flat = v->conv_n[3] * v->L[4];   // 32 * 55 = 1760
+    if (!getw(ctx, E + "fc_layers.0.weight", {256, flat}) || !getw(ctx, E + "fc_layers.3.weight", {128, 256}) ||
+        !getw(ctx, E + "fc_layers.6.weight", {v->zdim, 128}))
+        return -1;
+    if (fold_bn(ctx, E + "fc_layers.0.weight", E + "fc_layers.0.bias", E + "fc_layers.1", "__vfc1.w", "__vfc1.b")) return -1;
+    if (fold_bn(ctx, E + "fc_layers.3.weight", E + "fc_layers.3.bias", E + "fc_layers.4", "__vfc2.w", "__vfc2.b")) return -1;
+    if (make_pw(ctx, &v->fc1, "__vfc1.w", "__vfc1.b", 256, flat, 0)) return -1;
+    if (make_pw(ctx, &v->fc2, "__vfc2.w", "__vfc2.b", 128, 256, 0)) return -1;
+    if (make_pw(ctx, &v->fc3, E + "fc_layers.6.weight", E + "fc_layers.6.bias", v->zdim, 128, 0)) return -1;
+    {   // fc_mu and fc_logvar as one GEMM: rows [0, z) = mean, [z, 2z) = log_var
+        const HostTensor* wm = getw(ctx, E + "fc_mu.weight", {v->zdim, v->zdim});
+        const HostTensor* bm = getw(ctx, E + "fc_mu.bias", {v->zdim});
+        const HostTensor* wl = getw(ctx, E + "fc_logvar.weight", {v->zdim, v->zdim});
+        const HostTensor* bl = getw(ctx, E + "fc_logvar.bias", {v->zdim});
+        if (!wm || !bm || !wl || !bl) return -1;
+        HostTensor W, B;
+        W.shape = {2 * v->zdim, v->zdim}; B.shape = {2 * v->zdim};
+        W.data = wm->data; W.data.insert(W.data.end(), wl->data.begin(), wl->data.end());
+        B.data = bm->data; B.data.insert(B.data.end(), bl->data.begin(), bl->data.end());
+        ctx->host_w["__vhead.w"] = std::move(W);
+        ctx->host_w["__vhead.b"] = std::move(B);
+        if (make_pw(ctx, &v->head, "__vhead.w", "__vhead.b", 2 * v->zdim, v->zdim, 0)) return -1;
+    }
+    // strict key check, like load_state_dict(strict=True) of the encoder half; decoder.* keys are accepted and ignored
+    // (the decoder is not on this path), num_batches_tracked counters are metadata
+    size_t enc = 0;
+    for (auto& kv : ctx->host_w) {
+        const std::string& k = kv.first;
+        if (k.rfind("__", 0) == 0 || k.rfind("decoder.", 0) == 0) continue;
+        if (k.rfind(E, 0) != 0) return fail(ctx, "unexpected key(s) in state dict: %s", k.c_str());
+        ++enc;
+    }
+    const size_t expect_min = 4 * 2 + 3 * 4 + 3 * 2 + 2 * 4 + 4;   // convs, conv BNs, fcs, fc BNs, mu/logvar (+ optional num_batches_tracked)
+    if (enc < expect_min || enc > expect_min + 5) return fail(ctx, "unexpected key(s) in state dict: %zu encoder.* tensors, expected %zu (+5 num_batches_tracked)", enc, expect_min);
+    ctx->host_w.clear();
+    v->finalized = true;
+    return 0;
+}
+
+// BCVAE.encode (vae.py:66-83, 228-243) for `n` windows of (seq_len, 32) coefficients; window w starts at
+// coeffs_dev + w * window_stride floats.  mean_dev / logvar_dev: (n, 64) row-major; logvar_dev may be null.
+int said_vae_encode(said_vae* v, const float* coeffs_dev, long long window_stride, int n, float* mean_dev, float* logvar_dev, void* stream) {
+    if (!v) return -1;
+    said_ctx* ctx = &v->c;
+    if (!v->finalized) return fail(ctx, "weights not finalized: call said_vae_finalize_weights first");
+    if (n < 0 || !coeffs_dev || !mean_dev) return fail(ctx, "said_vae_encode: bad arguments");
+    if (window_stride < 1) return fail(ctx, "said_vae_encode: window_stride must be positive");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int Z = v->zdim, C = v->cin;
+    const int chunk = std::min(n, 4096);
+    const int Np = rup(chunk, 32);
+    const int p0 = rup(v->L[0], 32), p12 = rup(v->L[1], 32), p34 = rup(v->L[3], 32);   // 128, 128, 64
+    const int flat = v->conv_n[3] * v->L[4];
+    if (chunk > v->cap) {
+        HIPCHK(hipStreamSynchronize(s));
+        const size_t c = (size_t)chunk;
+        if (drealloc(ctx, &v->X0, c * C * p0) || drealloc(ctx, &v->Y[0], c * 32 * p12) || drealloc(ctx, &v->Y[1], c * 64 * p12) ||
+            drealloc(ctx, &v->Y[2], c * 64 * p34) || drealloc(ctx, &v->Y[3], c * 32 * p34) || drealloc(ctx, &v->F, (size_t)flat * Np) ||
+            drealloc(ctx, &v->G1, (size_t)256 * Np) || drealloc(ctx, &v->G2, (size_t)128 * Np) || drealloc(ctx, &v->G3, (size_t)Z * Np) ||
+            drealloc(ctx, &v->G4, (size_t)2 * Z * Np))
+            return -1;
+        v->cap = chunk;
+    }
+    for (int w0 = 0; w0 < n; w0 += chunk) {
+        const int nb = std::min(chunk, n - w0);
+        const int np = rup(v->cap, 32);   // feature-major pitch of the FC operands
+        launch_windows_to_cm(coeffs_dev + (long long)w0 * window_stride, window_stride, v->X0, nb, v->L[0], C, p0, (long long)C * p0, s);
+        const float* src = v->X0;
+        int cin = C, pin = p0;
+        for (int i = 0; i < 4; ++i) {   // Conv1d [+ BatchNorm1d folded] [+ LeakyReLU(0.2)]   (vae.py:41-51)
+            const int po = i < 2 ? p12 : p34;
+            GemmArgs a = mkargs(v->L[i + 1], v->conv_n[i]);
+            a.nseg = 1;
+            a.seg[0] = mkseg(src, (long long)cin * pin, pin, cin, v->conv_k[i], 0, v->conv_s[i], v->L[i], XF_NONE, v->conv[i].w[0]);
+            a.bias = v->conv[i].bias;
+            if (i < 3) a.act = ACT_LRELU_02;
+            a.y = v->Y[i]; a.y_bstride = (long long)v->conv_n[i] * po; a.y_pitch = po;
+            launch_gemm(a, EPI_STORE, nb, v->conv_n[i] == 64 ? 2 : 1, 8, s);
+            src = v->Y[i]; cin = v->conv_n[i]; pin = po;
+        }
+        launch_flatten_cm(v->Y[3], (long long)32 * p34, p34, v->F, np, nb, v->conv_n[3], v->L[4], s);   // nn.Flatten (vae.py:51)
+        auto fc = [&](const PW& pw, const float* x, int Cin, float* y, int N, bool act, int NB, int KS) {
+            GemmArgs a = mkargs(nb, N);
+            a.nseg = 1;
+            a.seg[0] = mkseg(x, 0, np, Cin, 1, 0, 1, nb, XF_NONE, pw.w[0]);
+            a.bias = pw.bias;
+            if (act) a.act = ACT_LRELU_001;   // nn.LeakyReLU() default slope 0.01 (vae.py:57, 60)
+            a.y = y; a.y_pitch = np;
+            launch_gemm(a, EPI_STORE, 1, NB, KS, s);
+        };
+        fc(v->fc1, v->F, flat, v->G1, 256, true, 4, 4);
+        fc(v->fc2, v->G1, 256, v->G2, 128, true, 4, 4);
+        fc(v->fc3, v->G2, 128, v->G3, Z, false, 2, 8);
+        fc(v->head, v->G3, Z, v->G4, 2 * Z, false, 4, 4);
+        launch_cm_to_tm(v->G4, mean_dev + (long long)w0 * Z, 1, nb, Z, np, 0, s);
+        if (logvar_dev) launch_cm_to_tm(v->G4 + (long long)Z * np, logvar_dev + (long long)w0 * Z, 1, nb, Z, np, 0, s);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -518,6 +518,7 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
             val += e_bias[j];
             if (a.act == ACT_SILU) val = silu_f(val);
             else if (a.act == ACT_GELU) val = gelu_f(val);
+            else if (a.act >= ACT_LRELU_02) val = val > 0.f ? val : val * (a.act == ACT_LRELU_02 ? 0.2f : 0.01f);
             val += e_emb[j];
             rv = e_res[j];
         } else {
@@ -525,6 +526,7 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
                 if (a.bias) val += a.bias[ng];
                 if (a.act == ACT_SILU) val = silu_f(val);
                 else if (a.act == ACT_GELU) val = gelu_f(val);
+                else if (a.act >= ACT_LRELU_02) val = val > 0.f ? val : val * (a.act == ACT_LRELU_02 ? 0.2f : 0.01f);
                 if (a.emb) {
                     const int row = (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride;
                     val += a.emb[(long long)ng * a.emb_pitch + row];

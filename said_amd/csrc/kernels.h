@@ -20,7 +20,8 @@ enum XForm : int {
     XF_SILU = 4,     // silu(x)                      emb_layers
 };
 
-enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2 };
+// ACT_LRELU_02 / _001: LeakyReLU(0.2) / LeakyReLU() (slope 0.01) of the VAE encoder (said/model/vae.py:41-64)
+enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_LRELU_02 = 3, ACT_LRELU_001 = 4 };
 enum Res : int { RES_NONE = 0, RES_PLAIN = 1, RES_GN = 2 };
 enum Epi : int { EPI_STORE = 0, EPI_QKV = 1, EPI_GEGLU = 2, EPI_BAND = 3 };
 
@@ -217,6 +218,13 @@ void launch_finish(const float* x_cm, long long x_bstride, int pitch, int B, int
 bool conv_in_supports(int Cin, int Cout, int taps, int T, int pitch, int copies);
 void launch_conv_in(const float* x, const float* w4, const float* bias, float* y, float* stats, int* step_inc, int B, int copies, int T,
                     int pitch, int Cout, hipStream_t s);
+
+// ---- VAE encoder (said/model/vae.py:26-112) ----
+// windows of (L, C) token-major coefficients, window w starting at src + w * win_stride floats (win_stride = L*C for a
+// batch of separate windows, step*C for sliding windows over one sequence) -> channel-major [n][C][pitch]
+void launch_windows_to_cm(const float* src, long long win_stride, float* dst, int n, int L, int C, int pitch, long long dst_bstride, hipStream_t s);
+// nn.Flatten of the conv stack's (n, C, T) output into the feature-major FC operand: dst[c * T + t][w] = src[w][c][t]
+void launch_flatten_cm(const float* src, long long src_bstride, int src_pitch, float* dst, int dst_pitch, int n, int C, int T, hipStream_t s);
 
 // ---- audio-encoder specific kernels ----
 // conv0: 1 -> C channels, kernel K, stride S, no bias (Wav2Vec2 feature extractor layer 0)

@@ -51,6 +51,48 @@ void launch_cm_to_tm(const float* src, float* dst, int B, int T, int C, int pitc
     hipLaunchKernelGGL(cm_to_tm_kernel, grid, dim3(256), 0, s, src, dst, T, C, pitch, src_bstride);
 }
 
+// VAE encoder input: window w = (L, C) token-major rows starting at src + w * win_stride -> dst[w][c][t]
+__global__ void windows_to_cm_kernel(const float* __restrict__ src, long long win_stride, float* __restrict__ dst, int L, int C, int pitch,
+                                     long long dst_bstride) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* sw = src + (long long)b * win_stride;
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, c = c0 + tx;
+        tile[r][tx] = (t < L && c < C) ? sw[(long long)t * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, t = t0 + tx;
+        if (c < C && t < L) dst[(long long)b * dst_bstride + (long long)c * pitch + t] = tile[tx][r];
+    }
+}
+void launch_windows_to_cm(const float* src, long long win_stride, float* dst, int n, int L, int C, int pitch, long long dst_bstride, hipStream_t s) {
+    dim3 grid((L + 31) / 32, (C + 31) / 32, n);
+    hipLaunchKernelGGL(windows_to_cm_kernel, grid, dim3(256), 0, s, src, win_stride, dst, L, C, pitch, dst_bstride);
+}
+// nn.Flatten((n, C, T)) as the feature-major FC operand: dst[c * T + t][w] = src[w][c][t]; w is the contiguous index
+__global__ void flatten_cm_kernel(const float* __restrict__ src, long long src_bstride, int src_pitch, float* __restrict__ dst, int dst_pitch,
+                                  int n, int C, int T) {
+    __shared__ float tile[32][33];
+    const int c = blockIdx.z, t0 = blockIdx.y * 32, w0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {   // rows = windows, columns = t (contiguous in src)
+        const int w = w0 + r, t = t0 + tx;
+        tile[r][tx] = (w < n && t < T) ? src[(long long)w * src_bstride + (long long)c * src_pitch + t] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {   // rows = t, columns = windows (contiguous in dst)
+        const int t = t0 + r, w = w0 + tx;
+        if (t < T && w < n) dst[((long long)c * T + t) * dst_pitch + w] = tile[tx][r];
+    }
+}
+void launch_flatten_cm(const float* src, long long src_bstride, int src_pitch, float* dst, int dst_pitch, int n, int C, int T, hipStream_t s) {
+    dim3 grid((n + 31) / 32, (T + 31) / 32, C);
+    hipLaunchKernelGGL(flatten_cm_kernel, grid, dim3(256), 0, s, src, src_bstride, src_pitch, dst, dst_pitch, n, C, T);
+}
+
 __global__ void fill_cm_vec_kernel(const float* __restrict__ vec, float* __restrict__ dst, int T, int pitch,
                                    long long dst_bstride) {
     const int c = blockIdx.y, b = blockIdx.z;

@@ -140,6 +140,47 @@ def w2v_param_shapes(num_layers: int = W2V_LAYERS) -> Dict[str, Tuple[int, ...]]
     return s
 
 
+def vae_encoder_param_shapes() -> Dict[str, Tuple[int, ...]]:
+    """Names/shapes of the ``encoder.*`` half of the reference's BCVAE state dict (said/model/vae.py:26-64;
+    matches model/vae.pth), BatchNorm running statistics included."""
+    s: Dict[str, Tuple[int, ...]] = {}
+    for idx, (co, ci, k) in {0: (32, 32, 3), 3: (64, 32, 3), 6: (64, 64, 4), 9: (32, 64, 3)}.items():
+        s[f"encoder.conv_layers.{idx}.weight"] = (co, ci, k)
+        s[f"encoder.conv_layers.{idx}.bias"] = (co,)
+    for idx, n in {1: 32, 4: 64, 7: 64}.items():
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            s[f"encoder.conv_layers.{idx}.{leaf}"] = (n,)
+    for idx, (co, ci) in {0: (256, 1760), 3: (128, 256), 6: (64, 128)}.items():
+        s[f"encoder.fc_layers.{idx}.weight"] = (co, ci)
+        s[f"encoder.fc_layers.{idx}.bias"] = (co,)
+    for idx, n in {1: 256, 4: 128}.items():
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            s[f"encoder.fc_layers.{idx}.{leaf}"] = (n,)
+    for nme in ("fc_mu", "fc_logvar"):
+        s[f"encoder.{nme}.weight"] = (64, 64)
+        s[f"encoder.{nme}.bias"] = (64,)
+    return s
+
+
+_VAE_BN = ("encoder.conv_layers.1.", "encoder.conv_layers.4.", "encoder.conv_layers.7.", "encoder.fc_layers.1.", "encoder.fc_layers.4.")
+
+
+def vae_encoder_state_dict(salt: int = 0) -> Dict[str, torch.Tensor]:
+    """Deterministic fill of the BCVAE encoder: BatchNorm affine ~ (1, 0) +- 0.1, running_mean ~ 0.1 N(0,1),
+    running_var in [0.5, 1.5]; conv / linear weights variance-preserving."""
+    sd = {}
+    for k, shp in vae_encoder_param_shapes().items():
+        t = fill_tensor(k, shp, salt)
+        if k.startswith(_VAE_BN):
+            g = torch.Generator()
+            g.manual_seed((zlib.crc32(k.encode()) + 7919 * salt) & 0x7FFFFFFF)
+            r = torch.randn(shp, generator=g, dtype=torch.float32)
+            leaf = k.split(".")[-1]
+            t = {"weight": 1.0 + 0.1 * r, "bias": 0.1 * r, "running_mean": 0.1 * r, "running_var": 1.0 + 0.5 * torch.tanh(r)}[leaf]
+        sd[k] = t
+    return sd
+
+
 # ---------------------------------------------------------------------------
 # Deterministic fill
 # ---------------------------------------------------------------------------

@@ -319,9 +319,41 @@ def g9_loop_control_flow():
     save("g9_loop_control_flow_scheduler_leg_unpinned", **out)
 
 
+def g10_vae_encoder():
+    """G10 — the reference's own ``BCVAE.encode`` (said/model/vae.py:26-83, 228-243) in eval mode:
+    (a) deterministic weights of said_amd.util.synth.vae_encoder_state_dict (regenerable on the GPU box);
+    (b) the reference's trained weights model/vae.pth (present only in the build container: the fixture holds the
+        inputs' seeds and the outputs, never the weights)."""
+    import_reference()
+    vae_mod = importlib.import_module("said.model.vae")
+    coeffs = torch.sigmoid(synth.synth_latents(41, (5, 120, 32)))
+    seq = torch.sigmoid(synth.synth_latents(42, (300, 32)))
+    out = {}
+    for tag, sd_enc in (("synth", synth.vae_encoder_state_dict()), ("real", None)):
+        v = vae_mod.BCVAE()
+        if sd_enc is None:
+            v.load_state_dict(torch.load(os.path.join(REF, "model", "vae.pth"), map_location="cpu"), strict=True)
+        else:
+            full = v.state_dict()
+            full.update(sd_enc)
+            v.load_state_dict(full, strict=True)
+        v.eval()
+        lat = v.encode(coeffs)
+        out[tag + "_mean"] = lat.mean.numpy()
+        out[tag + "_log_var"] = lat.log_var.numpy()
+        # the evaluation driver's sliding windows (script/test_evaluate.py:89-95), step 10 and step 1 with padding 3
+        for step, pad in ((10, 0), (1, 3)):
+            n = (seq.shape[0] - v.seq_len) // step + 1 - pad
+            out[f"{tag}_win_s{step}_p{pad}"] = torch.stack([v.encode(seq[None, step * w: step * w + v.seq_len]).mean[0] for w in range(n)]).numpy()
+    save("g10_vae_encoder", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g9":
         g9_loop_control_flow()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g10":
+        g10_vae_encoder()
     else:
         main()
         g9_loop_control_flow()
+        g10_vae_encoder()

@@ -406,16 +406,66 @@ def test_bf16_loop_cfg_batch32_shape(model, dev):
 
 
 # ---------------------------------------------------------------- round 2: chains at the headline's real length
-def test_loop_cfg_1000_steps_1s_vs_oracle(model, sd_full, dev):
-    """BASELINE configs[1]'s chain length: 1000 DDIM steps, guidance 2, on a 1 s clip (T=60) against the oracle."""
-    got, ref = _loop_case(model, sd_full, dev, B=1, Ta=16000, N=1000, gs=2.0, tol=1e-3)
-    print(f"N=1000 eta=0: max abs err {float((got - ref).abs().max()):.3e}")
+# A free-running 1000-step chain of this RANDOM-WEIGHT network is chaotic: the CPU oracle run twice, the second time with
+# its start latents scaled by (1 + 1e-6), differs from itself by 3e-2 after 100 steps and by O(1) after 200 (of 1000; 1 s
+# clip, guidance 2 — measured in the build container).  No implementation pair can meet an end-to-end bound
+# there, so the headline chain length is checked TEACHER-FORCED: every one of the 1000 steps (its own timestep embedding
+# row, coefficient row, noise slice) starts from the oracle's latents of that step and must land on the oracle's next
+# latents; free-running comparisons stay at chain lengths where the oracle's own sensitivity is below the bound.
+def _teacher_forced(model, sd_full, dev, *, N, eta, seg_lens, Ta=16000, gs=2.0, tol_single=2e-4, tol_seg=1e-3, starts=None):
+    B, T = 1, int(Ta / 16000 * 60)
+    proc = op.process_audio([synth.synth_waveform(10, Ta).numpy()])
+    sd_a, _, _ = op.split_state_dict(sd_full)
+    emb = op.get_audio_embedding(sd_a, proc, T)
+    lat0 = synth.synth_latents(100, (B, T, 32))
+    sn = synth.synth_latents(103, (N, B, T, 32)) if eta > 0 else None
+    ref = op.inference(sd_full, proc, init_latents=lat0, num_inference_steps=N, guidance_scale=gs, eta=eta, step_noise=sn,
+                       audio_embedding=emb, save_intermediate=True)
+    xs = ref.intermediates                         # xs[k] = latents entering step k
+    eng = model._get_engine(2 * B, T)
+    sch = model.noise_scheduler
+    sch.set_timesteps(N)
+    ts = sch.timesteps.numpy()
+    coef = sch.coef_table(ts, float(eta))
+    emb_d = emb.to(dev)
+    worst = {}
+    for m in seg_lens:
+        ks = starts[m] if starts and m in starts else (range(0, N - m + 1) if m == 1 else range(0, N - m + 1, max(m, N // 20)))
+        w = 0.0
+        for k in ks:
+            res, latf, _ = eng.denoise_loop(latents=xs[k].to(dev), context=emb_d, timesteps=ts[k:k + m], coef=coef[k:k + m],
+                                            prediction_type="epsilon", guidance_scale=gs, guidance_rescale=0.0, latent_scale=1.0,
+                                            step_noise=None if sn is None else sn[k:k + m].contiguous().to(dev))
+            # note: coefficient rows 5/6 (mask blend with the NEXT timestep) are unused without a mask
+            want = xs[k + m] if k + m < N else None
+            if want is not None:
+                w = max(w, float((latf.cpu() - want).abs().max()))
+            else:
+                w = max(w, float((res.cpu() - ref.result).abs().max()))
+        worst[m] = w
+    return worst
 
 
-def test_loop_cfg_1000_steps_eta1_vs_oracle(model, sd_full, dev):
-    """Same chain with eta = 1 (DDPM-like ancestral sampling): 1000 injected noise draws."""
-    got, ref = _loop_case(model, sd_full, dev, B=1, Ta=16000, N=1000, gs=2.0, eta=1.0, tol=2e-3)
-    print(f"N=1000 eta=1: max abs err {float((got - ref).abs().max()):.3e}")
+def test_loop_1000_steps_teacher_forced_vs_oracle(model, sd_full, dev):
+    """BASELINE configs[1]'s chain: all 1000 DDIM steps (guidance 2, 1 s clip), each started from the oracle's latents;
+    plus 10-step segments (the 10-steps-per-graph replay the headline runs) at 20 places along the chain."""
+    worst = _teacher_forced(model, sd_full, dev, N=1000, eta=0.0, seg_lens=[1, 10])
+    print(f"N=1000 eta=0 teacher-forced: worst single-step err {worst[1]:.3e}, worst 10-step-segment err {worst[10]:.3e}")
+    assert worst[1] <= 2e-4 and worst[10] <= 1e-3
+
+
+def test_loop_1000_steps_eta1_teacher_forced_vs_oracle(model, sd_full, dev):
+    """Same with eta = 1 (ancestral sampling, one injected noise draw per step)."""
+    worst = _teacher_forced(model, sd_full, dev, N=1000, eta=1.0, seg_lens=[1, 10])
+    print(f"N=1000 eta=1 teacher-forced: worst single-step err {worst[1]:.3e}, worst 10-step-segment err {worst[10]:.3e}")
+    assert worst[1] <= 2e-4 and worst[10] <= 1e-3
+
+
+def test_loop_997_steps_remainder_graph_teacher_forced(model, sd_full, dev):
+    """Prime step count: the 997-step schedule in 17-step segments = one 10-step graph + the 7-step remainder graph."""
+    worst = _teacher_forced(model, sd_full, dev, N=997, eta=0.0, seg_lens=[17], Ta=8000, starts={17: [0, 300, 640, 980]})
+    print(f"N=997 teacher-forced 17-step segments (10 + 7): worst err {worst[17]:.3e}")
+    assert worst[17] <= 1e-3
 
 
 def test_loop_editing_100_steps_in_betweening(model, sd_full, dev):
@@ -439,9 +489,9 @@ def test_loop_editing_100_steps_in_betweening(model, sd_full, dev):
     assert float((out.result.cpu()[:, :40] - init_samples[:, :40].clamp(0, 1)).abs().max()) <= 1e-6
 
 
-@pytest.mark.parametrize("N", [11, 13, 23, 997])
+@pytest.mark.parametrize("N", [11, 13, 23])
 def test_loop_step_counts_not_divisible_by_graph_length(model, sd_full, dev, N):
-    """Steps per graph is 10: N = 11, 13, 23 and the prime 997 run N // 10 ten-step graphs + one remainder graph."""
+    """Steps per graph is 10: N = 11, 13, 23 run N // 10 ten-step graphs + one remainder graph (free-running, whole loop)."""
     got, ref = _loop_case(model, sd_full, dev, B=1, Ta=8000, N=N, gs=2.0, tol=1e-3)
     print(f"N={N}: max abs err {float((got - ref).abs().max()):.3e}, nodes/step {model._eng.graph_num_nodes()}")
 

@@ -219,3 +219,25 @@ def test_coef_table_vectorised_is_bit_identical_to_rowwise(N, eta):
             a, b = s.coef_table(sub, eta), s.coef_table_rowwise(sub, eta)
             assert a.dtype == np.float32 and a.shape == b.shape
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_vae_state_dict_layout_and_cpu_refusal():
+    """BCVAE container: the reference's 70-key layout (encoder.* + decoder.*), strict load of the synthetic encoder
+    fill, eval-only, and no CPU path."""
+    from said_amd import _engine
+    from said_amd.model.vae import BCVAE
+    m = BCVAE()
+    sd = m.state_dict()
+    enc = synth.vae_encoder_state_dict()
+    assert len(sd) == 70 and set(enc) <= set(sd)
+    for k, v in enc.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    full = dict(sd)
+    full.update(enc)
+    m.load_state_dict(full, strict=True)
+    assert m.seq_len == 120
+    m.eval()
+    with pytest.raises(_engine.EngineError):
+        m.encode(torch.zeros(1, 120, 32))
+    with pytest.raises(NotImplementedError):
+        m.decode(torch.zeros(1, 64))

@@ -131,3 +131,36 @@ def test_g9_loop_control_flow_vs_reference_inference(golden, name):
         ri = g[name + "_inter"]
         assert len(out.intermediates) == ri.shape[0] == init_t
         assert float(np.abs(torch.stack(out.intermediates).numpy() - ri).max()) <= 2e-3
+
+
+# ---------------------------------------------------------------- G10: VAE encoder
+VAE_PTH = "/root/reference/model/vae.pth"   # the reference's trained weights: build container only
+
+
+def test_g10_vae_encoder_synth_weights(golden):
+    """oracle/vae.py against the reference's own BCVAE.encode (eval mode) with the deterministic weight fill."""
+    import os
+    from oracle import vae as ov
+    g = golden("g10_vae_encoder")
+    sd = synth.vae_encoder_state_dict()
+    coeffs = torch.sigmoid(synth.synth_latents(41, (5, 120, 32)))
+    seq = torch.sigmoid(synth.synth_latents(42, (300, 32)))
+    mean, logvar = ov.encode(sd, coeffs)
+    np.testing.assert_allclose(mean.numpy(), g["synth_mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(logvar.numpy(), g["synth_log_var"], rtol=1e-5, atol=1e-6)
+    for step, pad in ((10, 0), (1, 3)):
+        got = ov.window_latents(sd, seq, step, pad).numpy()
+        ref = g[f"synth_win_s{step}_p{pad}"]
+        assert got.shape == ref.shape == ((300 - 120) // step + 1 - pad, 64)
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(VAE_PTH), reason="model/vae.pth lives in /root/reference (build container only)")
+def test_g10_vae_encoder_reference_weights(golden):
+    from oracle import vae as ov
+    g = golden("g10_vae_encoder")
+    sd = torch.load(VAE_PTH, map_location="cpu")
+    coeffs = torch.sigmoid(synth.synth_latents(41, (5, 120, 32)))
+    mean, logvar = ov.encode(sd, coeffs)
+    np.testing.assert_allclose(mean.numpy(), g["real_mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(logvar.numpy(), g["real_log_var"], rtol=1e-5, atol=1e-6)
