@@ -122,11 +122,11 @@ def cpu_baseline(args, T, Ta):
             "clips_per_s": round(1.0 / total, 5)}
 
 
-def roofline(model, Be, T, step_ms, dtype):
+def roofline(model, Be, T, step_ms, dtype, cfg_clips=0):
     """Per-kernel HIP-event timing of one UNet evaluation (said_profile_unet: every launch of the schedule replayed
     back to back in a graph on the caller's stream and timed with hipEvents) + the whole-step figures."""
     eng = model._eng
-    stages = eng.profile_unet(Be, T, reps=40)
+    stages = eng.profile_unet(Be, T, reps=40, cfg_clips=cfg_clips)
     peak_tf = MFMA_PEAK_TFLOPS[dtype]
     agg = {}
     for st in stages:
@@ -281,7 +281,7 @@ def run(args):
             ev1.record()
             torch.cuda.synchronize()
             step_ms = ev0.elapsed_time(ev1) / args.num_steps
-            line["roofline"] = roofline(model, Be, T, step_ms, args.dtype)
+            line["roofline"] = roofline(model, Be, T, step_ms, args.dtype, cfg_clips=B if args.guidance_scale > 1.0 else 0)
             line["roofline"]["audio_encode"] = audio_encode_block(model, proc, T, B)
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only: other ranks would sit in the final barrier
             line["cpu_baseline"] = cpu_baseline(args, T, Ta)

@@ -172,8 +172,10 @@ double said_unet_algorithmic_flops(int batch_eff, int frames);
  * replayed `reps` times back to back (one hipGraph) between two HIP events on `stream`.
  * Outputs per stage: average microseconds, algorithmic bytes (weights + operands + result),
  * flops, kind (0 = generic GEMM/conv kernel, 1 = attention, 2 = LDS-staged UNet GEMM), epilogue id, tile shape (NB, KS).
+ * cfg_clips > 0 (= batch_eff / 2): the schedule of the classifier-free-guidance loop (unconditional half first; the
+ * prefix shared by the two halves runs once per clip), else the schedule of SAID.forward.
  * Used by bench.py's roofline block; internal buffers must hold finite data (run a forward first). */
-int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int reps, int max_stages, float* us_out, double* bytes_out,
+int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, int reps, int max_stages, float* us_out, double* bytes_out,
                       double* flops_out, int* kind_out, int* epi_out, int* nb_out, int* ks_out, int* n_stages_out, void* stream);
 
 /* ---- debugging aids (used by tests/ only) ---------------------------------- */

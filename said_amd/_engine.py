@@ -53,7 +53,7 @@ EXPORTS = {
     "said_graph_num_nodes": (c_int, [c_void_p]),
     "said_set_precision": (c_int, [c_void_p, c_int]),
     "said_get_precision": (c_int, [c_void_p]),
-    "said_profile_unet": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "said_profile_unet": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, POINTER(c_int), c_void_p]),
     "said_debug_stop_after": (c_int, [c_void_p, c_int]),
     "said_debug_clocks": (c_int, [c_void_p, c_int, c_void_p]),
@@ -266,7 +266,7 @@ class Engine:
             self._chk(self.lib.said_axpby(self.h, av, _ptr(x), cv, _ptr(y), _ptr(out), B, x.numel() // B, _stream()), "said_axpby")
         return out
 
-    def profile_unet(self, batch_eff: int, frames: int, reps: int = 50):
+    def profile_unet(self, batch_eff: int, frames: int, reps: int = 50, cfg_clips: int = 0):
         """Per-launch (us, bytes, flops, kind, epi, NB, KS) of the UNet kernel schedule, HIP-event timed."""
         M = 128
         us = np.zeros(M, np.float32); by = np.zeros(M, np.float64); fl = np.zeros(M, np.float64)
@@ -274,7 +274,7 @@ class Engine:
         n = c_int(0)
         vp = lambda a: a.ctypes.data_as(c_void_p)
         with torch.cuda.device(self.index):
-            self._chk(self.lib.said_profile_unet(self.h, batch_eff, frames, reps, M, vp(us), vp(by), vp(fl), vp(kind), vp(epi), vp(nb),
+            self._chk(self.lib.said_profile_unet(self.h, batch_eff, frames, cfg_clips, reps, M, vp(us), vp(by), vp(fl), vp(kind), vp(epi), vp(nb),
                                                  vp(ks), ctypes.byref(n), _stream()), "said_profile_unet")
         k = n.value
         return [dict(us=float(us[i]), bytes=float(by[i]), flops=float(fl[i]), kind=int(kind[i]), epi=int(epi[i]), NB=int(nb[i]), KS=int(ks[i]))

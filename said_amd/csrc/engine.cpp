@@ -46,7 +46,7 @@ struct PW {  // packed GEMM weight (up to 2 K-segments) + bias
     bool ln_tail = false;                // ... and then by the LayerNorm gamma[C] and beta[C]
 };
 struct ResW { float *g1, *b1, *g2, *b2; PW conv1, conv2, skip; int cin; bool has_skip; float* bias2; };
-struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj; };
+struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj, ffproj; };
 struct W2VLayer { PW qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln2g, *ln2b; };
 
 struct ActBuf {  // channel-major activation + its GroupNorm partial statistics
@@ -72,6 +72,8 @@ struct said_ctx {
     ResW res[NRES];
     STW st[NST];
     float* null_cond = nullptr;
+    float* c2[NST] = {nullptr, nullptr, nullptr, nullptr};   // attn2 output of the unconditional half: to_out(to_v(null_cond_emb)) + bias, per block
+    bool cfg_share = true;   // exploit the guidance structure (shared prefix, constant unconditional cross-attention); SAID_NO_CFG_SHARE=1 disables
     float* freqs = nullptr;
     bool freqs_set = false;
 
@@ -361,6 +363,10 @@ struct UGeo {
     int b0;            // first sample of this launch range (Be = number of samples in the range)
     int* step_inc;     // if set: the first kernel of the schedule increments this counter
     const OutSchedArgs* out_sched;   // if set: the `out` conv is fused with the scheduler update (loop only)
+    int Bc;            // > 0: classifier-free guidance over Bc clips — samples [0, Bc) are the unconditional half (context =
+                       // null_cond_emb repeated), [Bc, 2 Bc) the conditional half, both on the SAME latents and timestep
+                       // (diffusion.py:397-400, 421-423).  Then (a) everything before the first cross-attention is computed
+                       // once per clip, (b) the unconditional half's cross-attention output is the constant c2[blk].
 };
 
 inline bool dbg_go(said_ctx* c) {
@@ -431,9 +437,13 @@ void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hi
     }
 }
 
-void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, const ActBuf& in0, const ActBuf* in1, const ActBuf& out, hipStream_t s) {
+// shared: guidance-shared prefix — only the first g.Bc samples are computed, and the result is ALSO written into the
+// conditional half's slots (values only; its statistics are consumed by kernels that run on the first half alone)
+void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, const ActBuf& in0, const ActBuf* in1, const ActBuf& out, hipStream_t s,
+                  bool shared = false) {
     const int cpg = rw.cin / 32;
-    const long long tt = (long long)g.Be * ((g.T + 31) / 32);
+    const int nb = shared ? g.Bc : g.Be;
+    const long long tt = (long long)nb * ((g.T + 31) / 32);
     {   // in_layers: GN -> SiLU -> conv3 ; + emb_layers(emb)   (openaimodel.py:205-225)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = in1 ? 2 : 1;
@@ -448,7 +458,7 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
         a.y = c->M.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         a.stats_out = c->M.st; a.stats_bstride = g.sts;
         const LaunchCfg lc = pick_unet(tt);
-        do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+        do_gemm(c, a, EPI_STORE, nb, lc.NB, lc.KS, s);
     }
     {   // out_layers: GN -> SiLU -> conv3 ; + skip(x)   (openaimodel.py:226-227)
         GemmArgs a = mkargs(g.T, MC);
@@ -466,16 +476,30 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
         }
         a.y = out.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         a.stats_out = out.st; a.stats_bstride = g.sts;
+        if (shared) { a.y2 = out.p + (long long)g.Bc * g.hs; a.y2_bstride = g.hs; a.y2_add = nullptr; }
         const LaunchCfg lc = pick_unet(tt);
-        do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+        do_gemm(c, a, EPI_STORE, nb, lc.NB, lc.KS, s);
     }
 }
 
-void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const ActBuf& in, const ActBuf& out, hipStream_t s) {
+// shared: guidance-shared prefix (first transformer under classifier-free guidance): self-attention and everything
+// before it run once per clip on samples [0, g.Bc).  With g.Bc > 0 the cross-attention (q projection, band softmax,
+// to_out) runs on the conditional half only — the unconditional half attends to one repeated key/value, so its
+// attn2 output is the per-channel constant c2[blk] and attn1's to_out emits its x2 = x1 + c2 directly.
+void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const ActBuf& in, const ActBuf& out, hipStream_t s,
+                     bool shared = false) {
+    const int n1 = shared ? g.Bc : g.Be;          // samples through self-attention
+    const int n2 = g.Bc > 0 ? g.Bc : g.Be;        // samples through cross-attention
+    // first sample of the cross-attention range in the activations (X1, O): the conditional half, unless the prefix is
+    // shared (then X1 exists once per clip, in slots [0, Bc)); its K/V are always the conditional half's
+    const int x_off = (g.Bc > 0 && !shared) ? g.Bc : 0;
+    const int kv_off = g.Bc > 0 ? g.Bc : 0;
+    const long long tt1 = (long long)n1 * ((g.T + 31) / 32), tt2 = (long long)n2 * ((g.T + 31) / 32);
     const long long tt = (long long)g.Be * ((g.T + 31) / 32);
     const bool big = big_cgemm() && tt * 6 > 1536;
-    const bool big_qkv = tt * 6 > 1536 && getenv("SAID_NO_MT") && !c->bf16_mode;   // without multi-tile workgroups the generic NB=6 shape wins in fp32   // q/k/v: the generic NB=6 shape is faster at large batch (30 vs 24 TFLOP/s)
+    const bool big_qkv = tt1 * 6 > 1536 && getenv("SAID_NO_MT") && !c->bf16_mode;   // without multi-tile workgroups the generic NB=6 shape wins in fp32
     const int vt_rows = rup(g.T, 32);
+    const long long obs = 2LL * MC * g.Tp;   // batch stride of O (shared with QK so attention uses one stride)
     {   // x = norm(x) (GroupNorm eps 1e-6); q,k,v = to_{q,k,v}(norm1(x))   (attention.py:227, 168, 93-97)
         GemmArgs a = mkargs(g.T, 3 * MC);
         a.nseg = 1;
@@ -490,55 +514,60 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         // tiles per workgroup: the largest shape that still gives every CU a workgroup in ONE round (at Be=2, T=600:
         // NB=3 -> 228 workgroups, 27.5 -> 13.8 us per launch against NB=1's 684 workgroups in 2.7 rounds)
         static const int qkv_env = getenv("SAID_QKV_NB") ? atoi(getenv("SAID_QKV_NB")) : 0;
-        const int qkv_nb = qkv_env ? qkv_env : (tt * 6 >= 192 ? 3 : (tt * 9 >= 192 ? 2 : 1));
+        const int qkv_nb = qkv_env ? qkv_env : (tt1 * 6 >= 192 ? 3 : (tt1 * 9 >= 192 ? 2 : 1));
         const LaunchCfg lc = big_qkv ? LaunchCfg{6, 4} : LaunchCfg{qkv_nb, 8};
-        do_gemm(c, a, EPI_QKV, g.Be, lc.NB, lc.KS, s);
+        do_gemm(c, a, EPI_QKV, n1, lc.NB, lc.KS, s);
     }
     {   // softmax(q k^T * scale) v   (attention.py:99-126)
         AttnArgs a;
         a.qk = c->QK; a.v = c->VT; a.o = c->O;
-        a.v_bstride = (long long)MC * g.Tp; a.o_bstride = 2LL * MC * g.Tp;
+        a.v_bstride = (long long)MC * g.Tp; a.o_bstride = obs;
         a.pitch = g.Tp; a.T = g.T; a.heads = HEADS; a.rows = vt_rows; a.b0 = 0;
         a.scale = 0.17677669529663687f;  // 32 ** -0.5
         static const int attn_ks_env = getenv("SAID_ATTN_KS") ? atoi(getenv("SAID_ATTN_KS")) : 0;   // experiment knob
         // waves per workgroup = ways the key tiles are split: 8 only pays while a wave would otherwise hold a single
         // tile (T <= 256); from there 4 waves with ~5 tiles each merge half as many partial states (B=1: -0.5 % per step)
-        const int attn_ks = (tt * HEADS > 8192) ? 1 : ((g.T <= 256 && tt * HEADS <= 2048) ? 8 : 4);
-        do_attn(c, a, g.Be, HD, attn_ks_env ? attn_ks_env : attn_ks, s);
+        const int attn_ks = (tt1 * HEADS > 8192) ? 1 : ((g.T <= 256 && tt1 * HEADS <= 2048) ? 8 : 4);
+        do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s);
     }
     {   // x1 = to_out(attn) + x, with x = GroupNorm(in) recomputed on the fly   (attention.py:127, 168)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = with_pw(mkseg(c->O, 2LL * MC * g.Tp, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out1.w[0]), sw.out1, 0);
+        a.seg[0] = with_pw(mkseg(c->O, obs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out1.w[0]), sw.out1, 0);
         a.bias = sw.out1.bias;
         a.res_kind = RES_GN; a.res = in.p; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.res_gn_part = in.st; a.res_gn_part_bstride = g.sts; a.res_gn_cpg = 6; a.res_gn_nparts = g.np; a.res_gn_eps = 1e-6f;
         a.res_gn_gamma = sw.gn_g; a.res_gn_beta = sw.gn_b;
         a.y = c->X1; a.y_bstride = g.hs; a.y_pitch = g.Tp;
-        const LaunchCfg lc = big_cgemm() ? pick_unet(tt) : LaunchCfg{1, 8};   // the GroupNorm'ed-residual variant exists for NB = 1
-        do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+        if (g.Bc > 0) {   // x2 of the unconditional half: x1 + const (written for every sample of this launch; the
+                          // conditional slots — when this launch covers them — are overwritten by attn2's to_out below)
+            a.y2 = c->X2; a.y2_bstride = g.hs; a.y2_add = c->c2[blk];
+        }
+        const LaunchCfg lc = big_cgemm() ? pick_unet(tt1) : LaunchCfg{1, 8};   // the GroupNorm'ed-residual variant exists for NB = 1
+        do_gemm(c, a, EPI_STORE, n1, lc.NB, lc.KS, s);
     }
     {   // attn2: q = to_q(norm2(x1)); banded softmax over the precomputed audio K/V   (attention.py:170-191)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = with_pw(mkseg(c->X1, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.q2.w[0]), sw.q2, 0);
+        a.seg[0] = with_pw(mkseg(c->X1 + (long long)x_off * g.hs, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_LN, sw.q2.w[0]), sw.q2, 0);
         a.seg[0].ln_gamma = sw.l2g; a.seg[0].ln_beta = sw.l2b; a.seg[0].ln_eps = 1e-5f;
-        a.y = c->O; a.y_bstride = 2LL * MC * g.Tp; a.y_pitch = g.Tp;
-        a.band.k = c->KV + (long long)(blk * 2 * MC) * g.Sp;
-        a.band.v = c->KV + (long long)(blk * 2 * MC + MC) * g.Sp;
-        a.band.kv_bstride = (long long)NST * 2 * MC * g.Sp; a.band.kv_pitch = g.Sp;
+        a.y = c->O + (long long)x_off * obs; a.y_bstride = obs; a.y_pitch = g.Tp;
+        const long long kvbs = (long long)NST * 2 * MC * g.Sp;
+        a.band.k = c->KV + (long long)(blk * 2 * MC) * g.Sp + (long long)kv_off * kvbs;
+        a.band.v = c->KV + (long long)(blk * 2 * MC + MC) * g.Sp + (long long)kv_off * kvbs;
+        a.band.kv_bstride = kvbs; a.band.kv_pitch = g.Sp;
         a.band.lo = c->band_lo; a.band.hi = c->band_hi; a.band.wmax = c->band_wmax; a.band.scale = 0.17677669529663687f;
-        do_gemm(c, a, EPI_BAND, g.Be, 1, big ? 4 : 8, s);
+        do_gemm(c, a, EPI_BAND, n2, 1, big ? 4 : 8, s);
     }
-    {   // x2 = to_out(attn2) + x1
+    {   // x2 = to_out(attn2) + x1   (conditional half only under guidance: its slots are [Bc, 2 Bc) of X2)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
-        a.seg[0] = with_pw(mkseg(c->O, 2LL * MC * g.Tp, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out2.w[0]), sw.out2, 0);
+        a.seg[0] = with_pw(mkseg(c->O + (long long)x_off * obs, obs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.out2.w[0]), sw.out2, 0);
         a.bias = sw.out2.bias;
-        a.res_kind = RES_PLAIN; a.res = c->X1; a.res_bstride = g.hs; a.res_pitch = g.Tp;
-        a.y = c->X2; a.y_bstride = g.hs; a.y_pitch = g.Tp;
-        const LaunchCfg lc = pick_unet(tt);
-        do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+        a.res_kind = RES_PLAIN; a.res = c->X1 + (long long)x_off * g.hs; a.res_bstride = g.hs; a.res_pitch = g.Tp;
+        a.y = c->X2 + (long long)kv_off * g.hs; a.y_bstride = g.hs; a.y_pitch = g.Tp;
+        const LaunchCfg lc = pick_unet(tt2);
+        do_gemm(c, a, EPI_STORE, n2, lc.NB, lc.KS, s);
     }
     {   // GEGLU: proj(norm3(x2)) -> a * gelu(gate)   (attention.py:25-32)
         GemmArgs a = mkargs(g.T, FFI);
@@ -550,6 +579,22 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         static const int geglu_env = getenv("SAID_GEGLU_NB") ? atoi(getenv("SAID_GEGLU_NB")) : 0;
         const int geglu_nb = geglu_env ? geglu_env : (tt * 6 >= 192 ? 4 : (tt * 12 >= 192 ? 2 : 1));   // one round of workgroups, as for qkv
         do_gemm(c, a, EPI_GEGLU, g.Be, big ? 3 : geglu_nb, big ? 4 : 8, s);
+    }
+    static const bool no_fold = getenv("SAID_NO_FFPROJ_FOLD") != nullptr;   // A/B knob: the two unfused launches
+    if (!no_fold) {
+        // x3 = net.2(h) + x2 and out = proj_out(x3) + x_in as ONE GEMM over the K segments [h ; x2] with the host-folded
+        // weights (P F2 | P) — both maps are per-token linear, so nothing but rounding order changes
+        GemmArgs a = mkargs(g.T, MC);
+        a.nseg = 2;
+        a.seg[0] = with_pw(mkseg(c->F, (long long)FFI * g.Tp, g.Tp, FFI, 1, 0, 1, g.T, XF_NONE, sw.ffproj.w[0]), sw.ffproj, 0);
+        a.seg[1] = with_pw(mkseg(c->X2, g.hs, g.Tp, MC, 1, 0, 1, g.T, XF_NONE, sw.ffproj.w[1]), sw.ffproj, 1);
+        a.bias = sw.ffproj.bias;
+        a.res_kind = RES_PLAIN; a.res = in.p; a.res_bstride = g.hs; a.res_pitch = g.Tp;
+        a.y = out.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
+        a.stats_out = out.st; a.stats_bstride = g.sts;
+        const LaunchCfg lc = pick_unet(tt);
+        do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
+        return;
     }
     {   // x3 = net.2(h) + x2
         GemmArgs a = mkargs(g.T, MC);
@@ -598,8 +643,9 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
         const LaunchCfg lc = pick_unet(tt);
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
-    run_resblock(c, g, c->res[0], 0, c->H0, nullptr, c->P, s);       // input_blocks.1.0
-    run_transformer(c, g, c->st[0], 0, c->P, c->H1, s);              // input_blocks.1.1   (hs: H0, H1)
+    const bool sh = g.Bc > 0;   // guidance-shared prefix: the two halves first differ at input_blocks.1.1's cross-attention
+    run_resblock(c, g, c->res[0], 0, c->H0, nullptr, c->P, s, sh);   // input_blocks.1.0
+    run_transformer(c, g, c->st[0], 0, c->P, c->H1, s, sh);          // input_blocks.1.1   (hs: H0, H1)
     run_resblock(c, g, c->res[1], 1, c->H1, nullptr, c->P, s);       // middle_block.0
     run_transformer(c, g, c->st[1], 1, c->P, c->Q, s);               // middle_block.1
     run_resblock(c, g, c->res[2], 2, c->Q, nullptr, c->P, s);        // middle_block.2
@@ -692,7 +738,7 @@ UGeo make_geo(said_ctx* c, int Be, int B_lat, int T, int S) {
     UGeo g;
     g.Be = Be; g.B_lat = B_lat; g.T = T; g.Tp = rup(T, 32); g.np = (T + 31) / 32; g.S = S; g.Sp = rup(S, 32);
     g.hs = (long long)MC * g.Tp; g.sts = (long long)MC * g.np * 2;
-    g.step_ptr = nullptr; g.emb_b_stride = 0; g.b0 = 0; g.step_inc = nullptr; g.out_sched = nullptr;
+    g.step_ptr = nullptr; g.emb_b_stride = 0; g.b0 = 0; g.step_inc = nullptr; g.out_sched = nullptr; g.Bc = 0;
     return g;
 }
 
@@ -709,7 +755,7 @@ int check_ready(said_ctx* ctx) {
 // ============================================================================================
 extern "C" {
 
-int said_abi_version(void) { return 2; }   // 2: said_set_precision / said_get_precision
+int said_abi_version(void) { return 3; }   // 3: said_vae_*, said_profile_unet(cfg_clips)
 
 const char* said_last_error(const said_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -743,7 +789,8 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     configure_attn_kernels();
     configure_out_sched_kernel();
     ctx->use_ugemm = getenv("SAID_NO_UGEMM") == nullptr;
-    ctx->use_branches = getenv("SAID_BRANCHES") != nullptr;   // parallel graph branches measured no faster on ROCm 7.2: off by default
+    ctx->use_branches = getenv("SAID_BRANCHES") != nullptr;
+    ctx->cfg_share = getenv("SAID_NO_CFG_SHARE") == nullptr;   // parallel graph branches measured no faster on ROCm 7.2: off by default
     if (hipStreamCreateWithFlags(&ctx->cap_stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return fail(nullptr, "stream/event creation failed"); }
@@ -890,9 +937,64 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
         std::copy(k2->data.begin(), k2->data.end(), kv_w.begin() + (size_t)(i * 2) * MC * CD);
         std::copy(v2->data.begin(), v2->data.end(), kv_w.begin() + (size_t)(i * 2 + 1) * MC * CD);
         if (make_pw(ctx, &sw.out2, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", MC, MC, 0)) return -1;
+        {   // attn2 output for the unconditional context (null_cond_emb repeated: every key / value identical, softmax
+            // uniform => output = to_v(null)), pushed through to_out: c2 = W_out (W_v null) + b_out, in double
+            const HostTensor* nc = getw(ctx, "null_cond_emb", {1, 1, CD});
+            const HostTensor* wo = getw(ctx, b + ".attn2.to_out.0.weight", {MC, MC});
+            const HostTensor* bo = getw(ctx, b + ".attn2.to_out.0.bias", {MC});
+            if (!nc || !wo || !bo) return -1;
+            std::vector<double> vn(MC, 0.0);
+            for (int r = 0; r < MC; ++r) {
+                double a = 0.0;
+                for (int k = 0; k < CD; ++k) a += (double)v2->data[(size_t)r * CD + k] * nc->data[k];
+                vn[r] = (double)(float)a;   // the reference's value rows are fp32
+            }
+            std::vector<float> c2v(MC);
+            for (int n = 0; n < MC; ++n) {
+                double a = bo->data[n];
+                for (int r = 0; r < MC; ++r) a += (double)wo->data[(size_t)n * MC + r] * vn[r];
+                c2v[n] = (float)a;
+            }
+            if (upload(ctx, &ctx->c2[i], c2v.data(), MC)) return -1;
+        }
         if (make_pw(ctx, &sw.ff1, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", 2 * FFI, MC, 0, 1, "", "", b + ".norm3.weight", b + ".norm3.bias")) return -1;
         if (make_pw(ctx, &sw.ff2, b + ".ff.net.2.weight", b + ".ff.net.2.bias", MC, FFI, 0)) return -1;
         if (make_pw(ctx, &sw.proj, p + ".proj_out.weight", p + ".proj_out.bias", MC, MC, 1)) return -1;
+        {   // proj_out o ff.net.2 folded into ONE GEMM over [h (768) ; x2 (192)]  (attention.py:193 `ff(norm3(x)) + x`, :232-234):
+            //   proj(F2 h + b2 + x2) + bp = (P F2) h + P x2 + (P b2 + bp).  The product is formed in double on the host.
+            const HostTensor* F2 = getw(ctx, b + ".ff.net.2.weight", {MC, FFI});
+            const HostTensor* b2 = getw(ctx, b + ".ff.net.2.bias", {MC});
+            const HostTensor* Pw = ctx->host_w.count(p + ".proj_out.weight") && ctx->host_w[p + ".proj_out.weight"].shape.size() == 3
+                                       ? getw(ctx, p + ".proj_out.weight", {MC, MC, 1}) : getw(ctx, p + ".proj_out.weight", {MC, MC});
+            const HostTensor* bp = getw(ctx, p + ".proj_out.bias", {MC});
+            if (!F2 || !b2 || !Pw || !bp) return -1;
+            HostTensor PF, PX, PB;
+            PF.shape = {MC, FFI}; PF.data.resize((size_t)MC * FFI);
+            PX.shape = {MC, MC}; PX.data = Pw->data;
+            PB.shape = {MC}; PB.data.resize(MC);
+            std::vector<double> row(FFI);
+            for (int n = 0; n < MC; ++n) {
+                std::fill(row.begin(), row.end(), 0.0);
+                double bb = bp->data[n];
+                for (int k = 0; k < MC; ++k) {
+                    const double pk = Pw->data[(size_t)n * MC + k];
+                    bb += pk * b2->data[k];
+                    const float* f2 = &F2->data[(size_t)k * FFI];
+                    for (int c = 0; c < FFI; ++c) row[c] += pk * f2[c];
+                }
+                for (int c = 0; c < FFI; ++c) PF.data[(size_t)n * FFI + c] = (float)row[c];
+                PB.data[n] = (float)bb;
+            }
+            ctx->host_w["__ffproj.w0"] = std::move(PF);
+            ctx->host_w["__ffproj.w1"] = std::move(PX);
+            ctx->host_w["__ffproj.b"] = std::move(PB);
+            PW t0, t1;
+            if (make_pw(ctx, &t0, "__ffproj.w0", "__ffproj.b", MC, FFI, 0) || make_pw(ctx, &t1, "__ffproj.w1", "", MC, MC, 0)) return -1;
+            PW& fp = sw.ffproj;
+            fp.N = MC; fp.taps = 1; fp.nseg = 2; fp.bias = t0.bias;
+            fp.w[0] = t0.w[0]; fp.w4[0] = t0.w4[0]; fp.w2[0] = t0.w2[0]; fp.C[0] = FFI;
+            fp.w[1] = t1.w[0]; fp.w4[1] = t1.w4[0]; fp.w2[1] = t1.w2[0]; fp.C[1] = MC;
+        }
         used += 24;
     }
     ctx->host_w["__kv_all"] = HostTensor{kv_w, {NST * 2 * MC, CD}};
@@ -1055,6 +1157,7 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     if (set_band(ctx, T, T, s)) return -1;
     UGeo g = make_geo(ctx, Be, cfg ? B : 0, T, T);
     g.step_ptr = ctx->step_dev;
+    if (cfg && ctx->cfg_share && !ctx->use_branches) g.Bc = B;
     const long long xs = (long long)C * g.Tp;
 
     TRACE("loop: begin");
@@ -1269,15 +1372,17 @@ int said_debug_read(said_ctx* ctx, const char* name, float* out_host, int64_t n)
     return 0;
 }
 
-int said_profile_unet(said_ctx* ctx, int Be, int T, int reps, int max_stages, float* us_out, double* bytes_out, double* flops_out,
+int said_profile_unet(said_ctx* ctx, int Be, int T, int cfg_clips, int reps, int max_stages, float* us_out, double* bytes_out, double* flops_out,
                       int* kind_out, int* epi_out, int* nb_out, int* ks_out, int* n_stages_out, void* stream) {
     if (check_ready(ctx)) return -1;
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
     if (Be < 1 || Be > ctx->maxBe || T < 1 || T > ctx->maxT) return fail(ctx, "said_profile_unet: shape out of range");
     if (set_band(ctx, T, T, s)) return -1;
-    UGeo g = make_geo(ctx, Be, 0, T, T);
+    if (cfg_clips < 0 || (cfg_clips > 0 && Be != 2 * cfg_clips)) return fail(ctx, "said_profile_unet: cfg_clips must be 0 or batch_eff / 2");
+    UGeo g = make_geo(ctx, Be, cfg_clips, T, T);
     g.emb_b_stride = 0;
+    if (cfg_clips > 0 && ctx->cfg_share && !ctx->use_branches) g.Bc = cfg_clips;   // the schedule the guided loop runs
     run_unet(ctx, g, s);  // eager warm-up: kernels must not see their first launch inside a capture
     HIPCHK(hipStreamSynchronize(s));
     // pass 0: log the schedule without launching anything
@@ -1367,7 +1472,10 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
     if (apply_proj && !ctx->has_audio_proj) return fail(ctx, "apply_proj requested but audio_proj_layer.* was not loaded");
     const int out_dim = apply_proj ? ctx->ctx_dim : W2V_H;
     // workspace: ping-pong conv buffers + token-domain buffers, for `chunk` clips at a time
-    const int chunk = std::min(B, 8);
+    // clips per pass: the 65 MB/clip conv0 activation is what bounds it (32 clips = 2.1 GB of 288 GB); larger launches
+    // amortise the 377 MB of encoder weights over more tokens
+    static const int chunk_max = getenv("SAID_AUDIO_CHUNK") ? std::max(1, atoi(getenv("SAID_AUDIO_CHUNK"))) : 32;
+    const int chunk = std::min(B, chunk_max);
     const size_t eA = (size_t)chunk * W2V_CONV * rup(L[0], 32), eB = (size_t)chunk * W2V_CONV * rup(L[1], 32);
     const size_t tok = (size_t)chunk * Fp;
     const size_t tw = std::max<size_t>(W2V_H, (size_t)ctx->ctx_dim);   // aT also receives the audio_proj_layer output (ctx_dim wide)

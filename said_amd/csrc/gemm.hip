@@ -542,6 +542,8 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
             }
         }
         if (ok) a.y[(long long)b * a.y_bstride + (long long)ng * a.y_pitch + t] = val;
+        if (EPI == EPI_STORE && ok && a.y2)   // second copy (+ per-channel constant): kernels.h GemmCommon::y2
+            a.y2[(long long)b * a.y2_bstride + (long long)ng * a.y_pitch + t] = val + (a.y2_add ? a.y2_add[ng] : 0.f);
         if (EPI == EPI_STORE && a.stats_out) {
             const float cnt = (float)min(32, a.T - t0);
             const float vv = (t < a.T) ? val : 0.f;

