@@ -15,6 +15,7 @@
 
 #include "../../include/said_hip.h"
 #include "kernels.h"
+#include "xattn.h"
 
 using namespace said;
 
@@ -46,7 +47,8 @@ struct PW {  // packed GEMM weight (up to 2 K-segments) + bias
     bool ln_tail = false;                // ... and then by the LayerNorm gamma[C] and beta[C]
 };
 struct ResW { float *g1, *b1, *g2, *b2; PW conv1, conv2, skip; int cin; bool has_skip; float* bias2; };
-struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj, ffproj; };
+struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj, ffproj;
+             float *x_w1, *x_wq, *x_w2; /* pack16 copies of out1 / q2 / out2 for the fused chain kernel (xattn.hip) */ };
 struct W2VLayer { PW qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln2g, *ln2b; };
 
 struct ActBuf {  // channel-major activation + its GroupNorm partial statistics
@@ -95,6 +97,8 @@ struct said_ctx {
     int* step_dev = nullptr;
     int *band_lo = nullptr, *band_hi = nullptr;
     int band_T = -1, band_S = -1, band_wmax = 0;
+    bool band_tile16_ok = false;   // every 16-query tile's windows fit XA_KW key columns (fused chain kernel)
+    bool use_xattn = true;         // SAID_NO_XATTN=1: the three unfused launches at every batch size
     float *init_cm = nullptr, *enoise_cm = nullptr, *mask_cm = nullptr, *rescale_part = nullptr;
     float* noise_cm = nullptr; size_t noise_cm_elems = 0;
     float* coef1_dev = nullptr;  // one row for said_ddim_step
@@ -228,6 +232,17 @@ std::vector<float> pack_rows4(const float* W, int Ctot, int taps, const std::vec
                         const int c = c_begin + 8 * cq + 2 * j + (l >> 5);
                         out[o++] = row < 0 ? 0.f : W[((size_t)row * Ctot + c) * taps + tap];
                     }
+    return out;
+}
+// v_mfma_f32_16x16x4_f32 A-fragment packing of a [N][C] matrix (xattn.hip): Wp[row tile][C/16][lane][4], value e of lane l =
+// W[16 * tile + (l & 15)][16 * kq + 4 * e + (l >> 4)]
+std::vector<float> pack16(const float* W, int N, int C) {
+    std::vector<float> out((size_t)(N / 16) * (C / 16) * 256);
+    size_t o = 0;
+    for (int rt = 0; rt < N / 16; ++rt)
+        for (int kq = 0; kq < C / 16; ++kq)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 4; ++e) out[o++] = W[(size_t)(rt * 16 + (l & 15)) * C + 16 * kq + 4 * e + (l >> 4)];
     return out;
 }
 // round-to-nearest-even fp32 -> bf16 (finite inputs)
@@ -530,6 +545,33 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         const int attn_ks = (tt1 * HEADS > 8192) ? 1 : ((g.T <= 256 && tt1 * HEADS <= 2048) ? 8 : 4);
         do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s);
     }
+    // small batches: attn1.to_out + norm2 + to_q + banded cross-attention + attn2.to_out as ONE launch (xattn.hip); the
+    // weights are re-fetched by every 16-token workgroup, so beyond a few hundred workgroups the three GEMM launches win
+    static const long long xattn_max_wgs = getenv("SAID_XATTN_MAX_WGS") ? atoll(getenv("SAID_XATTN_MAX_WGS")) : 512;
+    const int xs_n = shared ? g.Bc : g.Be;
+    if (c->use_xattn && !c->bf16_mode && c->band_tile16_ok && !c->clk_on && (long long)xs_n * ((g.T + 15) / 16) <= xattn_max_wgs) {
+        XAttnArgs x;
+        memset(&x, 0, sizeof x);
+        x.o = c->O; x.o_bs = obs; x.res = in.p; x.res_bs = g.hs;
+        x.gn_part = in.st; x.gn_part_bs = g.sts; x.gn_gamma = sw.gn_g; x.gn_beta = sw.gn_b; x.gn_nparts = g.np; x.gn_eps = 1e-6f;
+        x.w1 = sw.x_w1; x.b1 = sw.out1.bias; x.ln_g = sw.l2g; x.ln_b = sw.l2b; x.wq = sw.x_wq;
+        x.k = c->KV + (long long)(blk * 2 * MC) * g.Sp; x.v = c->KV + (long long)(blk * 2 * MC + MC) * g.Sp;
+        x.kv_bs = (long long)NST * 2 * MC * g.Sp; x.kv_pitch = g.Sp;
+        x.lo = c->band_lo; x.hi = c->band_hi; x.wmax = c->band_wmax; x.scale = 0.17677669529663687f;
+        x.w2 = sw.x_w2; x.b2 = sw.out2.bias; x.c2 = c->c2[blk];
+        x.x2 = c->X2; x.x2_bs = g.hs; x.pitch = g.Tp; x.T = g.T;
+        x.mode = g.Bc > 0 ? (shared ? 2 : 1) : 0; x.Bc = g.Bc;
+        if (xattn_supports(x, xs_n)) {
+            if (c->log_on) {
+                const double tok = (double)g.T;
+                const double nfull = g.Bc > 0 ? g.Bc : g.Be;
+                c->stage_log.push_back({3, EPI_STORE, 1, 8, 4.0 * (3.0 * MC * MC + (double)xs_n * MC * tok * 2 + (double)g.Be * MC * tok + nfull * 2 * MC * tok),
+                                        2.0 * MC * MC * tok * (xs_n + 2.0 * nfull) + 2.0 * nfull * tok * MC * 2 * c->band_wmax});
+            }
+            if (dbg_go(c)) launch_xattn(x, xs_n, s);
+            goto geglu;
+        }
+    }
     {   // x1 = to_out(attn) + x, with x = GroupNorm(in) recomputed on the fly   (attention.py:127, 168)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
@@ -569,6 +611,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         const LaunchCfg lc = pick_unet(tt2);
         do_gemm(c, a, EPI_STORE, n2, lc.NB, lc.KS, s);
     }
+geglu:
     {   // GEGLU: proj(norm3(x2)) -> a * gelu(gate)   (attention.py:25-32)
         GemmArgs a = mkargs(g.T, FFI);
         a.nseg = 1;
@@ -731,6 +774,13 @@ int set_band(said_ctx* ctx, int T, int S, hipStream_t s) {
     HIPCHK(hipMemcpy(ctx->band_lo, lo.data(), T * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->band_hi, hi.data(), T * sizeof(int), hipMemcpyHostToDevice));
     ctx->band_T = T; ctx->band_S = S; ctx->band_wmax = wmax;
+    bool ok16 = true;
+    for (int t0 = 0; t0 < T; t0 += 16) {
+        const int tl = std::min(t0 + 15, T - 1);
+        if (hi[tl] - lo[t0] > XA_KW) ok16 = false;
+        for (int t = t0; t < tl; ++t) if (lo[t + 1] < lo[t]) ok16 = false;
+    }
+    ctx->band_tile16_ok = ok16;
     return 0;
 }
 
@@ -790,7 +840,9 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     configure_out_sched_kernel();
     ctx->use_ugemm = getenv("SAID_NO_UGEMM") == nullptr;
     ctx->use_branches = getenv("SAID_BRANCHES") != nullptr;
-    ctx->cfg_share = getenv("SAID_NO_CFG_SHARE") == nullptr;   // parallel graph branches measured no faster on ROCm 7.2: off by default
+    ctx->cfg_share = getenv("SAID_NO_CFG_SHARE") == nullptr;
+    ctx->use_xattn = getenv("SAID_NO_XATTN") == nullptr;
+    configure_xattn_kernel();   // parallel graph branches measured no faster on ROCm 7.2: off by default
     if (hipStreamCreateWithFlags(&ctx->cap_stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return fail(nullptr, "stream/event creation failed"); }
@@ -937,6 +989,14 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
         std::copy(k2->data.begin(), k2->data.end(), kv_w.begin() + (size_t)(i * 2) * MC * CD);
         std::copy(v2->data.begin(), v2->data.end(), kv_w.begin() + (size_t)(i * 2 + 1) * MC * CD);
         if (make_pw(ctx, &sw.out2, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", MC, MC, 0)) return -1;
+        {   // 16x16x4 fragment packings for the fused chain kernel
+            const HostTensor* w1 = getw(ctx, b + ".attn1.to_out.0.weight", {MC, MC});
+            const HostTensor* wq2 = getw(ctx, b + ".attn2.to_q.weight", {MC, MC});
+            const HostTensor* w2 = getw(ctx, b + ".attn2.to_out.0.weight", {MC, MC});
+            if (!w1 || !wq2 || !w2) return -1;
+            auto p1 = pack16(w1->data.data(), MC, MC), pq = pack16(wq2->data.data(), MC, MC), p2 = pack16(w2->data.data(), MC, MC);
+            if (upload(ctx, &sw.x_w1, p1.data(), p1.size()) || upload(ctx, &sw.x_wq, pq.data(), pq.size()) || upload(ctx, &sw.x_w2, p2.data(), p2.size())) return -1;
+        }
         {   // attn2 output for the unconditional context (null_cond_emb repeated: every key / value identical, softmax
             // uniform => output = to_v(null)), pushed through to_out: c2 = W_out (W_v null) + b_out, in double
             const HostTensor* nc = getw(ctx, "null_cond_emb", {1, 1, CD});
