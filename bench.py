@@ -170,7 +170,7 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0):
     return out
 
 
-def audio_encode_block(model, proc, T, B):
+def audio_encode_block(model, proc, T, B, dtype):
     """Audio encoder alone (once per clip): HIP-event time of get_audio_embedding on the current stream."""
     model.get_audio_embedding(proc, T)
     torch.cuda.synchronize()
@@ -190,7 +190,7 @@ def audio_encode_block(model, proc, T, B):
     act_b = 512 * ((Ta - 10) // 5 + 1) * 4.0 * 2     # conv0 activation written + read once per clip
     return {"ms_per_clip": round(ms / B, 4), "ms_per_batch": round(ms, 3), "clips": B,
             "tflops": round(2 * mac * B / (ms * 1e-3) / 1e12, 2),
-            "mfma_frac_fp32": round(2 * mac * B / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["f32"], 4),
+            "mfma_dtype": dtype, "mfma_frac": round(2 * mac * B / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[dtype], 4),
             "alg_bytes": round(weights_b + B * act_b), "alg_GBps": round((weights_b + B * act_b) / (ms * 1e-3) / 1e9, 1)}
 
 
@@ -265,7 +265,7 @@ def run(args):
             "config": {"workload": f"{B} clip(s)/GPU x {args.seconds:g} s synthetic audio (T={T} frames), audio encode + "
                                    f"{args.num_steps} DDIM steps (eta={args.eta:g}), guidance_scale={args.guidance_scale:g} "
                                    f"(UNet batch {Be}), " + ("fp32; BASELINE.json configs[1]" if args.dtype == "f32" else
-                                                              "bf16 multiplies / fp32 accumulation and storage; BASELINE.json configs[2] shape"),
+                                                              "bf16 mode (UNet: bf16 multiplies, fp32 accumulation and storage; audio encoder: bf16 GEMM operands and activations, fp32 residual stream); BASELINE.json configs[2] shape"),
                        "batch_per_gpu": B, "frames": T, "num_steps": args.num_steps, "guidance_scale": args.guidance_scale,
                        "eta": args.eta, "parallelism": f"clips sharded over {world} GPU(s), one RCCL all-gather" if world > 1 else "single GPU",
                        "clip_ranges": r.clip_ranges, "gathered_checksum": r.checksum,
@@ -283,7 +283,7 @@ def run(args):
             torch.cuda.synchronize()
             step_ms = ev0.elapsed_time(ev1) / args.num_steps
             line["roofline"] = roofline(model, Be, T, step_ms, args.dtype, cfg_clips=B if args.guidance_scale > 1.0 else 0)
-            line["roofline"]["audio_encode"] = audio_encode_block(model, proc, T, B)
+            line["roofline"]["audio_encode"] = audio_encode_block(model, proc, T, B, args.dtype)
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only: other ranks would sit in the final barrier
             line["cpu_baseline"] = cpu_baseline(args, T, Ta)
         print(json.dumps(line), flush=True)

@@ -15,6 +15,7 @@
 
 #include "../../include/said_hip.h"
 #include "kernels.h"
+#include "tgemm.h"
 #include "xattn.h"
 
 using namespace said;
@@ -111,6 +112,16 @@ struct said_ctx {
     bool use_branches = false;  // SAID_BRANCHES=1: capture the two halves of the UNet batch as parallel graph branches
     bool bf16_mode = false;  // said_set_precision: multiply in bf16 wherever the LDS-staged kernel is used
     bool use_ugemm = true;   // SAID_NO_UGEMM=1 forces the generic kernel everywhere (A/B testing)
+
+    // ---- bf16 audio encoder (tgemm.hip): bf16 weights [N][K] (convs: K = tap-major), token-major workspace ----
+    void* bw_conv[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *bw_fproj = nullptr, *bw_aproj = nullptr;
+    struct BLayer { void *qkv, *out, *ff1, *ff2; };
+    std::vector<BLayer> blayers;
+    void *bA0 = nullptr, *bA1 = nullptr, *bX = nullptr, *bHb = nullptr, *bF = nullptr, *bO = nullptr;
+    float *bH = nullptr, *bT = nullptr, *bPosT = nullptr;
+    size_t b_conv_elems[2] = {0, 0}, b_tok = 0;
+    bool audio_bf16 = true;   // SAID_NO_AUDIO_BF16=1: the fp32 audio encoder also in bf16 mode
 
     // ---- audio workspace (lazily sized) ----
     float *abufA = nullptr, *abufB = nullptr; size_t abuf_elems[2] = {0, 0};
@@ -270,6 +281,19 @@ std::vector<float> pack_rows_bf16(const float* W, int Ctot, int taps, const std:
     memcpy(out.data(), h.data(), h.size() * 2);
     return out;
 }
+// fp32 host matrix -> bf16 (RNE) device array; `perm` (optional) reorders the K axis of a Conv1d weight [N][C][taps] to
+// tap-major [N][taps][C] (the token-major im2col order of tgemm.hip)
+int upload_bf16(said_ctx* ctx, void** out, const float* W, size_t N, size_t C, size_t taps) {
+    std::vector<uint16_t> h(N * C * taps);
+    for (size_t n = 0; n < N; ++n)
+        for (size_t t = 0; t < taps; ++t)
+            for (size_t c = 0; c < C; ++c) h[(n * taps + t) * C + c] = bf16_rne(W[(n * C + c) * taps + t]);
+    uint16_t* d = nullptr;
+    if (dalloc(ctx, &d, h.size(), false)) return -1;
+    HIPCHK(hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    *out = d;
+    return 0;
+}
 std::vector<int> rows_dense(int N, int row0 = 0) {
     const int nt = (N + 31) / 32;
     std::vector<int> r(nt * 32, -1);
@@ -342,6 +366,10 @@ LaunchCfg pick_cfg(long long t_tiles_total, int ntiles, bool allow6 = true) {
 // as soon as that still fills the chip (measured at Be=32: 47 TFLOP/s against 34 for the generic NB=6 shape)
 LaunchCfg pick_unet(long long t_tiles_total) {
     if (big_cgemm()) return pick_cfg(t_tiles_total, 6);
+    // experiment knob SAID_BIG_NB=1: one n-tile per workgroup also at large batch — those multi-tile kernels are compiled for
+    // two workgroups per CU (gemm_lds.hip)
+    static const int big_nb = getenv("SAID_BIG_NB") ? atoi(getenv("SAID_BIG_NB")) : 2;
+    if (big_nb == 1 && t_tiles_total >= 640) return LaunchCfg{1, 8};
     return t_tiles_total * 3 >= 192 ? LaunchCfg{2, 8} : LaunchCfg{1, 8};
 }
 
@@ -842,6 +870,8 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     ctx->use_branches = getenv("SAID_BRANCHES") != nullptr;
     ctx->cfg_share = getenv("SAID_NO_CFG_SHARE") == nullptr;
     ctx->use_xattn = getenv("SAID_NO_XATTN") == nullptr;
+    ctx->audio_bf16 = getenv("SAID_NO_AUDIO_BF16") == nullptr;
+    configure_tgemm_kernel();
     configure_xattn_kernel();   // parallel graph branches measured no faster on ROCm 7.2: off by default
     if (hipStreamCreateWithFlags(&ctx->cap_stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1085,12 +1115,14 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
                 if (upvec(ctx, &ctx->c0_b, A + "feature_extractor.conv_layers.0.layer_norm.bias", W2V_CONV)) return -1;
             } else {
                 if (make_pw(ctx, &ctx->aconv[i], wn, "", W2V_CONV, W2V_CONV, k)) return -1;
+                if (upload_bf16(ctx, &ctx->bw_conv[i], it->second.data.data(), W2V_CONV, W2V_CONV, (size_t)k)) return -1;
             }
             cin = W2V_CONV;
         }
         if (upvec(ctx, &ctx->fp_lng, A + "feature_projection.layer_norm.weight", W2V_CONV)) return -1;
         if (upvec(ctx, &ctx->fp_lnb, A + "feature_projection.layer_norm.bias", W2V_CONV)) return -1;
         if (make_pw(ctx, &ctx->fproj, A + "feature_projection.projection.weight", A + "feature_projection.projection.bias", W2V_H, W2V_CONV, 0)) return -1;
+        if (upload_bf16(ctx, &ctx->bw_fproj, ctx->host_w[A + "feature_projection.projection.weight"].data.data(), W2V_H, W2V_CONV, 1)) return -1;
         if (!getw(ctx, A + "masked_spec_embed", {W2V_H})) return -1;
         {   // positional conv: weight_norm(dim=2) folded on the host, then grouped packing (16 groups of 48)
             auto ig = ctx->host_w.find(A + "encoder.pos_conv_embed.conv.weight_g");
@@ -1123,6 +1155,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
         while (ctx->host_w.count(A + "encoder.layers." + std::to_string(L) + ".layer_norm.weight")) ++L;
         ctx->w2v_layers = L;
         ctx->layers.resize(L);
+        ctx->blayers.resize(L);
         for (int l = 0; l < L; ++l) {
             const std::string p = A + "encoder.layers." + std::to_string(l);
             W2VLayer& ly = ctx->layers[l];
@@ -1140,6 +1173,13 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
             if (make_pw(ctx, &ly.out, p + ".attention.out_proj.weight", p + ".attention.out_proj.bias", W2V_H, W2V_H, 0)) return -1;
             if (make_pw(ctx, &ly.ff1, p + ".feed_forward.intermediate_dense.weight", p + ".feed_forward.intermediate_dense.bias", W2V_FFN, W2V_H, 0)) return -1;
             if (make_pw(ctx, &ly.ff2, p + ".feed_forward.output_dense.weight", p + ".feed_forward.output_dense.bias", W2V_H, W2V_FFN, 0)) return -1;
+            {   // bf16 copies for the bf16-mode encoder (the shapes were validated by make_pw above)
+                said_ctx::BLayer& bl = ctx->blayers[l];
+                if (upload_bf16(ctx, &bl.qkv, qkv.data(), 3 * W2V_H, W2V_H, 1)) return -1;
+                if (upload_bf16(ctx, &bl.out, ctx->host_w[p + ".attention.out_proj.weight"].data.data(), W2V_H, W2V_H, 1)) return -1;
+                if (upload_bf16(ctx, &bl.ff1, ctx->host_w[p + ".feed_forward.intermediate_dense.weight"].data.data(), W2V_FFN, W2V_H, 1)) return -1;
+                if (upload_bf16(ctx, &bl.ff2, ctx->host_w[p + ".feed_forward.output_dense.weight"].data.data(), W2V_H, W2V_FFN, 1)) return -1;
+            }
             if (upvec(ctx, &ly.ln1g, p + ".layer_norm.weight", W2V_H) || upvec(ctx, &ly.ln1b, p + ".layer_norm.bias", W2V_H)) return -1;
             if (upvec(ctx, &ly.ln2g, p + ".final_layer_norm.weight", W2V_H) || upvec(ctx, &ly.ln2b, p + ".final_layer_norm.bias", W2V_H)) return -1;
         }
@@ -1149,6 +1189,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
     }
     if (ctx->host_w.count("audio_proj_layer.weight")) {
         if (make_pw(ctx, &ctx->aproj, "audio_proj_layer.weight", "audio_proj_layer.bias", CD, W2V_H, 0)) return -1;
+        if (upload_bf16(ctx, &ctx->bw_aproj, ctx->host_w["audio_proj_layer.weight"].data.data(), (size_t)CD, W2V_H, 1)) return -1;
         ctx->has_audio_proj = true;
     }
     for (auto& kv : ctx->host_w) {
@@ -1550,6 +1591,128 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                 return -1;
             ctx->a_tok_elems = tok;
         }
+    }
+    // bf16 mode (said_set_precision): token-major bf16 encoder on v_mfma_f32_32x32x16_bf16 (tgemm.hip).  conv0 + its
+    // per-channel GroupNorm, the grouped positional convolution and the attention kernel are shared with the fp32 path.
+    const bool bfa = ctx->bf16_mode && ctx->audio_bf16 && (!apply_proj || ctx->ctx_dim % 128 == 0) && (int)ctx->blayers.size() == ctx->w2v_layers;
+    if (bfa) {
+        const size_t e0 = (size_t)chunk * L[0] * W2V_CONV, e1 = (size_t)chunk * L[1] * W2V_CONV, tk = (size_t)chunk * Fr;
+        if (e0 > ctx->b_conv_elems[0] || e1 > ctx->b_conv_elems[1] || tk > ctx->b_tok) {
+            HIPCHK(hipStreamSynchronize(s));
+            uint16_t** u;
+            if (e0 > ctx->b_conv_elems[0]) { u = reinterpret_cast<uint16_t**>(&ctx->bA0); if (drealloc(ctx, u, e0 + 64)) return -1; ctx->b_conv_elems[0] = e0; }
+            if (e1 > ctx->b_conv_elems[1]) { u = reinterpret_cast<uint16_t**>(&ctx->bA1); if (drealloc(ctx, u, e1 + 64)) return -1; ctx->b_conv_elems[1] = e1; }
+            if (tk > ctx->b_tok) {
+                if (drealloc(ctx, reinterpret_cast<uint16_t**>(&ctx->bX), tk * W2V_CONV) || drealloc(ctx, reinterpret_cast<uint16_t**>(&ctx->bHb), tk * W2V_H) ||
+                    drealloc(ctx, reinterpret_cast<uint16_t**>(&ctx->bF), tk * W2V_FFN) || drealloc(ctx, reinterpret_cast<uint16_t**>(&ctx->bO), tk * W2V_H) ||
+                    drealloc(ctx, &ctx->bH, tk * W2V_H) || drealloc(ctx, &ctx->bT, tk * std::max<size_t>(W2V_H, (size_t)ctx->ctx_dim)) ||
+                    drealloc(ctx, &ctx->bPosT, tk * W2V_H))
+                    return -1;
+                ctx->b_tok = tk;
+            }
+        }
+        for (int b0 = 0; b0 < B; b0 += chunk) {
+            const int nb = std::min(chunk, B - b0);
+            const int pitch0 = rup(L[0], 32);
+            const long long bs0 = (long long)W2V_CONV * pitch0;
+            launch_conv0(wav_dev + (long long)b0 * Ta, ctx->c0_w, ctx->abufA, nb, Ta, W2V_CONV, ctx->w2v_kernel[0], ctx->w2v_stride[0], L[0], pitch0, bs0, s);
+            launch_rownorm_gelu(ctx->abufA, ctx->c0_g, ctx->c0_b, W2V_CONV, nb, L[0], pitch0, bs0, 1e-5f, s);
+            launch_cm_to_tm_bf16(ctx->abufA, bs0, pitch0, ctx->bA0, (long long)L[0] * W2V_CONV, nb, L[0], W2V_CONV, s);
+            void* src = ctx->bA0;
+            void* dst = ctx->bA1;
+            for (int i = 1; i < 7; ++i) {   // Conv1d(512, 512, k, stride 2, no bias) + GELU as a GEMM with overlapping rows
+                TGemmArgs a;
+                memset(&a, 0, sizeof a);
+                a.a = src; a.a_bs = (long long)L[i - 1] * W2V_CONV; a.lda = ctx->w2v_stride[i] * W2V_CONV;
+                a.w = ctx->bw_conv[i]; a.act = 1;
+                a.yb = dst; a.y_bs = (long long)L[i] * W2V_CONV; a.ldy = W2V_CONV;
+                a.M = L[i]; a.N = W2V_CONV; a.K = ctx->w2v_kernel[i] * W2V_CONV;
+                launch_tgemm(a, nb, s);
+                std::swap(src, dst);
+            }
+            // interpolation to the frame count (wav2vec2.py:41-44) + feature_projection.layer_norm
+            launch_interp_ln_tm(src, (long long)L[6] * W2V_CONV, L[6], ctx->bX, (long long)Fr * W2V_CONV, Fr, nb, W2V_CONV, ctx->fp_lng, ctx->fp_lnb, 1e-5f, s);
+            const long long hsT = (long long)Fr * W2V_H;            // token-major batch stride
+            const long long hs = (long long)W2V_H * Fp;             // channel-major batch stride (positional conv, attention operands)
+            const long long tt = (long long)nb * ((Fr + 31) / 32);
+            {   // feature_projection.projection
+                TGemmArgs a;
+                memset(&a, 0, sizeof a);
+                a.a = ctx->bX; a.a_bs = (long long)Fr * W2V_CONV; a.lda = W2V_CONV; a.w = ctx->bw_fproj; a.bias = ctx->fproj.bias;
+                a.yf = ctx->bH; a.y_bs = hsT; a.ldy = W2V_H; a.M = Fr; a.N = W2V_H; a.K = W2V_CONV;
+                launch_tgemm(a, nb, s);
+            }
+            {   // positional conv embedding (grouped, fp32 channel-major kernel) on the projected features
+                launch_tm_to_cm(ctx->bH, ctx->aH, nb, Fr, W2V_H, Fp, hs, s);
+                GemmArgs a = mkargs(Fr, W2V_H / 16);
+                a.groups = 16; a.ntiles_per_group = 2;
+                a.nseg = 1;
+                a.seg[0] = mkseg(ctx->aH, hs, Fp, W2V_H / 16, ctx->posconv.taps, ctx->posconv.taps / 2, 1, Fr, XF_NONE, ctx->posconv.w[0]);
+                a.seg[0].c_group_stride = W2V_H / 16;
+                a.bias = ctx->posconv.bias; a.act = ACT_GELU;
+                a.y = ctx->aPOS; a.y_bstride = hs; a.y_pitch = Fp;
+                launch_gemm(a, EPI_STORE, nb, tt * 32 <= 2048 ? 1 : 2, 8, s);
+                launch_cm_to_tm(ctx->aPOS, ctx->bPosT, nb, Fr, W2V_H, Fp, hs, s);
+            }
+            launch_ln_tm(ctx->bH, ctx->bPosT, ctx->bH, ctx->bHb, ctx->enc_lng, ctx->enc_lnb, (long long)nb * Fr, W2V_H, 1e-5f, s);
+            for (int l = 0; l < ctx->w2v_layers; ++l) {
+                const W2VLayer& ly = ctx->layers[l];
+                const said_ctx::BLayer& bl = ctx->blayers[l];
+                {   // q, k, v projections -> attn.hip's operand layout
+                    TGemmArgs a;
+                    memset(&a, 0, sizeof a);
+                    a.a = ctx->bHb; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.qkv; a.bias = ly.qkv.bias;
+                    a.qk = ctx->aQK; a.vt = ctx->aVT; a.v_bs = hs; a.qk_n = 2 * W2V_H; a.head_dim = W2V_HD; a.rows = Fp; a.heads2 = 2 * W2V_HEADS;
+                    a.v_pitch = Fp; a.M = Fr; a.N = 3 * W2V_H; a.K = W2V_H;
+                    launch_tgemm(a, nb, s);
+                }
+                {
+                    AttnArgs a;
+                    a.qk = ctx->aQK; a.v = ctx->aVT; a.o = ctx->aO;
+                    a.v_bstride = hs; a.o_bstride = 2 * hs; a.b0 = 0;
+                    a.pitch = Fp; a.T = Fr; a.heads = W2V_HEADS; a.rows = Fp; a.scale = 0.125f;
+                    launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : (tt * W2V_HEADS <= 8192 ? 4 : 1), s, true);
+                }
+                launch_cm_to_tm_bf16(ctx->aO, 2 * hs, Fp, ctx->bO, hsT, nb, Fr, W2V_H, s);
+                {   // out_proj + residual, then layer_norm
+                    TGemmArgs a;
+                    memset(&a, 0, sizeof a);
+                    a.a = ctx->bO; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.out; a.bias = ly.out.bias;
+                    a.res = ctx->bH; a.res_bs = hsT; a.ldr = W2V_H;
+                    a.yf = ctx->bT; a.y_bs = hsT; a.ldy = W2V_H; a.M = Fr; a.N = W2V_H; a.K = W2V_H;
+                    launch_tgemm(a, nb, s);
+                }
+                launch_ln_tm(ctx->bT, nullptr, ctx->bH, ctx->bHb, ly.ln1g, ly.ln1b, (long long)nb * Fr, W2V_H, 1e-5f, s);
+                {   // feed_forward.intermediate_dense + GELU
+                    TGemmArgs a;
+                    memset(&a, 0, sizeof a);
+                    a.a = ctx->bHb; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.ff1; a.bias = ly.ff1.bias; a.act = 1;
+                    a.yb = ctx->bF; a.y_bs = (long long)Fr * W2V_FFN; a.ldy = W2V_FFN; a.M = Fr; a.N = W2V_FFN; a.K = W2V_H;
+                    launch_tgemm(a, nb, s);
+                }
+                {   // feed_forward.output_dense + residual, then final_layer_norm
+                    TGemmArgs a;
+                    memset(&a, 0, sizeof a);
+                    a.a = ctx->bF; a.a_bs = (long long)Fr * W2V_FFN; a.lda = W2V_FFN; a.w = bl.ff2; a.bias = ly.ff2.bias;
+                    a.res = ctx->bH; a.res_bs = hsT; a.ldr = W2V_H;
+                    a.yf = ctx->bT; a.y_bs = hsT; a.ldy = W2V_H; a.M = Fr; a.N = W2V_H; a.K = W2V_FFN;
+                    launch_tgemm(a, nb, s);
+                }
+                const bool last = l + 1 == ctx->w2v_layers && !apply_proj;   // the last LayerNorm writes the (B, frames, 768) result itself
+                launch_ln_tm(ctx->bT, nullptr, last ? out_dev + (long long)b0 * Fr * W2V_H : ctx->bH, ctx->bHb, ly.ln2g, ly.ln2b, (long long)nb * Fr, W2V_H, 1e-5f, s);
+            }
+            if (apply_proj) {   // diffusion.py:228-229
+                TGemmArgs a;
+                memset(&a, 0, sizeof a);
+                a.a = ctx->bHb; a.a_bs = hsT; a.lda = W2V_H; a.w = ctx->bw_aproj; a.bias = ctx->aproj.bias;
+                a.yf = out_dev + (long long)b0 * Fr * out_dim; a.y_bs = (long long)Fr * out_dim; a.ldy = out_dim; a.M = Fr; a.N = out_dim; a.K = W2V_H;
+                launch_tgemm(a, nb, s);
+            } else if (ctx->w2v_layers == 0) {
+                HIPCHK(hipMemcpyAsync(out_dev + (long long)b0 * Fr * W2V_H, ctx->bH, (size_t)nb * Fr * W2V_H * sizeof(float), hipMemcpyDeviceToDevice, s));
+            }
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
     }
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = std::min(chunk, B - b0);

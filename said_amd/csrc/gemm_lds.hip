@@ -969,7 +969,9 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 }
 
 template <int NB, int KS, int EPI, int VAR, bool BF, bool MT>
-__global__ __launch_bounds__(64 * KS) void ugemm_kernel(const float* hx, const float* hw4, int hpack, int hTN, int hpitch_gv, int hbstride,
+// multi-tile single-n-tile store kernels are compiled for <= 128 VGPRs (4 waves per SIMD): two workgroups share a CU, so one's
+// staging / reduction / epilogue phases overlap the other's MFMA stream (large batches, SAID_BIG_NB=1)
+__global__ __launch_bounds__(64 * KS, (MT && NB == 1 && EPI == EPI_STORE) ? 4 : 1) void ugemm_kernel(const float* hx, const float* hw4, int hpack, int hTN, int hpitch_gv, int hbstride,
                                                         int hbmod_b0, int hgx, const float* hgn_part, int hgn_bstride, int hgn_cfg,
                                                         const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1064,6 +1066,8 @@ static void uconfigure_one() {
 #define SAID_UGEMM_MT_CONFIGS(X)                                                                   \
     X(EPI_STORE, 2, 8, 0, 0) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0, 0) X(EPI_STORE, 1, 8, UV_RGN, 0)   \
     X(EPI_STORE, 2, 8, 0, 1) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0, 1) X(EPI_STORE, 1, 8, UV_RGN, 1)   \
+    X(EPI_STORE, 1, 8, 0, 0) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0, 0) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_DUP, 0) \
+    X(EPI_STORE, 1, 8, 0, 1) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0, 1) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_DUP, 1) \
     X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_DUP, 0) X(EPI_STORE, 1, 8, UV_RGN | UV_DUP, 0)          \
     X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_DUP, 1) X(EPI_STORE, 1, 8, UV_RGN | UV_DUP, 1)          \
     X(EPI_QKV, 3, 8, UV_GN0, 0) X(EPI_QKV, 3, 8, UV_GN0, 1)                                        \

@@ -46,7 +46,8 @@ constexpr int O_GNS = O_COEF + 2 * XC;        // per-wave GroupNorm scratch
 constexpr int O_PART = O_GNS + XW * GN_SCRATCH;  // band partial dots [24 chunks][8][16]
 constexpr int O_PROB = O_PART + 24 * 8 * XT;  // [6 heads][8][16]
 constexpr int O_LN = O_PROB + 6 * 8 * XT;     // LayerNorm partials [32][16][2] + stats [16][2]
-constexpr int O_END = O_LN + 32 * XT * 2 + XT * 2;
+constexpr int O_VEC = O_LN + 32 * XT * 2 + XT * 2;   // b1, c2, ln gamma, ln beta, b2 (5 x 192): fetched once at kernel entry
+constexpr int O_END = O_VEC + 5 * XC;
 static_assert(O_END * 4 <= 160 * 1024, "LDS carve exceeds a CU's 160 KB");
 
 struct WFrag { f32x4x v[18]; };   // 3 units x 6 dwordx4 (24 k-steps each)
@@ -119,6 +120,22 @@ __global__ __launch_bounds__(64 * XW) void xattn_kernel(const XAttnArgs a) {
     const int voff1 = second ? ((row0 + 128) * pitch + t0 + 4 * q4) * 4 : (int)0x80000000;
     const f32x4x o0 = xa_bload4(ro, voff0, 0), o1 = xa_bload4(ro, voff1, 0);
     const f32x4x r0 = xa_bload4(rr, voff0, 0), r1 = xa_bload4(rr, voff1, 0);
+    // the five per-channel vectors of the chain (each epilogue would otherwise pay its own memory round trip) and this
+    // thread's query window: requested now, parked in LDS / registers
+    float vec0 = 0.f, vec1 = 0.f;
+    {
+        const int i0 = tid, i1 = tid + 512;   // 960 entries over 512 threads
+        const float* const vp[5] = {a.b1, a.c2, a.ln_g, a.ln_b, a.b2};
+        const int k0 = i0 / XC, k1 = i1 / XC;
+        const float* p0 = vp[0];
+        const float* p1 = vp[2];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { if (k0 == k) p0 = vp[k]; if (k1 == k) p1 = vp[k]; }
+        if (p0) vec0 = gload(p0, i0 - k0 * XC);
+        if (i1 < 5 * XC && p1) vec1 = gload(p1, i1 - k1 * XC);
+    }
+    const int tq_ = min(t0 + (tid & 15), T - 1);
+    const int my_lo = cload(a.lo, tq_), my_hi = cload(a.hi, tq_);
     // key / value window of the tile: columns kb .. kb + XKW - 1 of every channel row (host checks that it covers the
     // alignment windows of all 16 queries); loads past the row block read 0 through the descriptor's range check
     const int tl = min(t0 + XT - 1, T - 1);
@@ -169,7 +186,10 @@ __global__ __launch_bounds__(64 * XW) void xattn_kernel(const XAttnArgs a) {
             }
         }
     }
-    __syncthreads();   // coefficient table (written per wave slice) and the o tile are complete
+    float* vecs = sm + O_VEC;
+    vecs[tid] = vec0;
+    if (tid + 512 < 5 * XC) vecs[tid + 512] = vec1;
+    __syncthreads();   // coefficient table (written per wave slice), the o tile and the vector table are complete
     {
         const float2 c0 = *reinterpret_cast<const float2*>(coef + 2 * row0);
         f32x4x z0, z1 = {0.f, 0.f, 0.f, 0.f};
@@ -198,9 +218,9 @@ __global__ __launch_bounds__(64 * XW) void xattn_kernel(const XAttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = ((w >> 1) + 4 * u) * 16 + 4 * (l >> 4) + r;
-                const float v = acc[u][r] + cload(a.b1, row) + tR[row * XT + col];
+                const float v = acc[u][r] + vecs[row] + tR[row * XT + col];
                 tX1[row * XT + col] = v;
-                if (wr_unc && t < T) gstore(yu, (long long)row * pitch + t, v + cload(a.c2, row));
+                if (wr_unc && t < T) gstore(yu, (long long)row * pitch + t, v + vecs[XC + row]);
             }
     }
     if (!full) return;
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(64 * XW) void xattn_kernel(const XAttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int c = part * 6 + i;
-            tA[c * XT + tt] = fmaf((tX1[c * XT + tt] - mu) * rs, cload(a.ln_g, c), cload(a.ln_b, c));
+            tA[c * XT + tt] = fmaf((tX1[c * XT + tt] - mu) * rs, vecs[2 * XC + c], vecs[3 * XC + c]);
         }
     }
     __syncthreads();
@@ -259,8 +279,7 @@ __global__ __launch_bounds__(64 * XW) void xattn_kernel(const XAttnArgs a) {
     // ---------------- phase 5: banded softmax over the audio keys (alignment window of each query) ----------------
     {
         const int tt = tid & 15, ch = tid >> 4;          // 24 chunks of 8 channels (4 per head) x 16 queries
-        const int tq = min(t0 + tt, T - 1);
-        const int lo = cload(a.lo, tq), hi = cload(a.hi, tq);
+        const int lo = my_lo, hi = my_hi;   // tt = tid & 15: the window requested at kernel entry
         const int rel = lo - kb;
         float* part = sm + O_PART;
         float* prob = sm + O_PROB;
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(64 * XW) void xattn_kernel(const XAttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = ((w >> 1) + 4 * u) * 16 + 4 * (l >> 4) + r;
-                const float v = acc[u][r] + cload(a.b2, row) + tX1[row * XT + col];
+                const float v = acc[u][r] + vecs[4 * XC + row] + tX1[row * XT + col];
                 if (t < T) gstore(yf, (long long)row * pitch + t, v);
             }
     }

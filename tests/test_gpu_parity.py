@@ -293,7 +293,7 @@ def test_loop_is_deterministic_and_graph_replayed(model, dev):
     a = model.inference(proc, num_inference_steps=12, guidance_scale=2.0, init_latents=lat).result
     b = model.inference(proc, num_inference_steps=12, guidance_scale=2.0, init_latents=lat).result
     assert torch.equal(a, b)
-    assert model._eng.graph_num_nodes() >= 40  # one captured graph covers the whole step
+    assert model._eng.graph_num_nodes() >= 30  # one captured graph covers the whole step (32 launches with the fused chain kernel, 40 without)
 
 
 def test_idempotent_clamp_and_linearity_properties_full_size(model, dev):
@@ -589,3 +589,30 @@ def test_pred_original_sample_broadcasts_single_timestep(model, dev):
         a = ac[t].view(-1, 1, 1)
         want = (x - (1 - a) ** 0.5 * n) / a ** 0.5
         assert float((got - want).abs().max()) <= 1e-5
+
+
+# ---------------------------------------------------------------- bf16 audio encoder (configs[2]; tgemm.hip)
+BF16_AUDIO_TOL = 0.25   # placeholder until measured on the MI355X: set to 3x the printed max abs error
+
+
+@pytest.mark.parametrize("Ta,frames", [(16000, 60), (160000, 600)])
+def test_bf16_audio_encoder_vs_fp32_oracle(model, w2v_sd, dev, Ta, frames):
+    """bf16 mode routes the Wav2Vec2 encoder through the token-major bf16 GEMM (v_mfma_f32_32x32x16_bf16, bf16 activations
+    between GEMMs, fp32 residual stream / LayerNorm / softmax).  Error against the FP32 ORACLE is reported and bounded;
+    the switch must change the arithmetic and be reversible."""
+    proc = op.process_audio(synth.synth_waveform(8, Ta))
+    ref = ow.wav2vec2_forward(w2v_sd, proc, frames)[0]
+    f32 = model.get_audio_embedding(proc.to(dev), frames).cpu()
+    try:
+        model.set_mfma_dtype("bf16")
+        b16 = model.get_audio_embedding(proc.to(dev), frames).cpu()
+    finally:
+        model.set_mfma_dtype("fp32")
+    again = model.get_audio_embedding(proc.to(dev), frames).cpu()
+    assert torch.equal(again, f32)
+    e = (b16 - ref).abs()
+    rms = float((b16 - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f"bf16 audio encoder {Ta / 16000:g} s: max abs err {float(e.max()):.3e} (|ref| max {float(ref.abs().max()):.2f}), rms rel {rms:.3e}")
+    assert b16.shape == ref.shape and torch.isfinite(b16).all()
+    assert not torch.equal(b16, f32)
+    assert float(e.max()) <= BF16_AUDIO_TOL and rms <= 5e-2
