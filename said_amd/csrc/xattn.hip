@@ -61,16 +61,27 @@ static __device__ __forceinline__ void load_w(const float* wp, int w, int l, WFr
         for (int i = 0; i < 6; ++i) f.v[u * 6 + i] = xa_bload4(r, l * 16, ((((w >> 1) + 4 * u) * 12) + 6 * (w & 1) + i) * 1024);
 }
 
-// acc[u] += W[unit u] . tile[K half of this wave]   (72 MFMAs, 24 ds_read_b32)
+// acc[u] += W[unit u] . tile[K half of this wave]   (72 MFMAs, 24 ds_read_b32 requested ahead of the MFMA stream in three
+// groups of eight so that no MFMA triple waits for its own LDS read)
 static __device__ __forceinline__ void gemm16(const WFrag& f, const float* tile, int w, int l, f32x4x (&acc)[3]) {
     const float* bp = tile + ((w & 1) * 96 + (l >> 4)) * XT + (l & 15);
 #pragma unroll
     for (int u = 0; u < 3; ++u) acc[u] = {0.f, 0.f, 0.f, 0.f};
+    float b[24];
 #pragma unroll
-    for (int ks = 0; ks < 24; ++ks) {
-        const float b = bp[ks * 4 * XT];
+    for (int ks = 0; ks < 8; ++ks) b[ks] = bp[ks * 4 * XT];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[u * 6 + (ks >> 2)][ks & 3], b, acc[u], 0, 0, 0);
+    for (int g = 0; g < 3; ++g) {
+        if (g < 2) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) b[(g + 1) * 8 + ks] = bp[((g + 1) * 8 + ks) * 4 * XT];
+        }
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const int ks = g * 8 + k8;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[u * 6 + (ks >> 2)][ks & 3], b[ks], acc[u], 0, 0, 0);
+        }
     }
 }
 
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(64 * XW) void xattn_kernel(const XAttnArgs a) {
     }
 
     // ---------------- phase 2: x1 = to_out(o) + b + GroupNorm(x_in) ----------------
-    if (full) load_w(a.wq, w, l, wn);   // next GEMM's fragments travel while this one multiplies
+    load_w(a.wq, w, l, wn);   // next GEMM's fragments travel while this one multiplies (unconditional: exact wait counts)
     f32x4x acc[3];
     gemm16(wf, tA, w, l, acc);
     pair_reduce(sm + O_RED, w, l, acc);   // (its barrier also orders the tR writes above)

@@ -592,7 +592,7 @@ def test_pred_original_sample_broadcasts_single_timestep(model, dev):
 
 
 # ---------------------------------------------------------------- bf16 audio encoder (configs[2]; tgemm.hip)
-BF16_AUDIO_TOL = 0.25   # placeholder until measured on the MI355X: set to 3x the printed max abs error
+BF16_AUDIO_TOL = 0.11   # 3x the measured 2.9e-2 (1 s) .. 3.5e-2 (10 s) max abs error on values up to 3.8; rms relative error measured 8e-3
 
 
 @pytest.mark.parametrize("Ta,frames", [(16000, 60), (160000, 600)])
