@@ -47,9 +47,11 @@ struct PW {  // packed GEMM weight (up to 2 K-segments) + bias
     bool gn_tail = false;                // w4[s] is followed by the GroupNorm gamma[C] and beta[C] of its source segment
     bool ln_tail = false;                // ... and then by the LayerNorm gamma[C] and beta[C]
 };
-struct ResW { float *g1, *b1, *g2, *b2; PW conv1, conv2, skip; int cin; bool has_skip; float* bias2; };
+struct ResW { float *g1, *b1, *g2, *b2; PW conv1, conv2, skip; int cin; bool has_skip; float* bias2;
+              void *t_conv1 = nullptr, *t_conv2 = nullptr; /* bf16 [192][taps * cin] (conv2: [576 | 384 skip]) for tgemm.hip */ };
 struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj, ffproj;
-             float *x_w1, *x_wq, *x_w2; /* pack16 copies of out1 / q2 / out2 for the fused chain kernel (xattn.hip) */ };
+             float *x_w1, *x_wq, *x_w2; /* pack16 copies of out1 / q2 / out2 for the fused chain kernel (xattn.hip) */
+             void *t_qkv = nullptr, *t_ff1 = nullptr, *t_ffproj = nullptr; float* t_ff1_bias = nullptr; /* bf16 weights for tgemm.hip */ };
 struct W2VLayer { PW qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln2g, *ln2b; };
 
 struct ActBuf {  // channel-major activation + its GroupNorm partial statistics
@@ -99,7 +101,8 @@ struct said_ctx {
     int *band_lo = nullptr, *band_hi = nullptr;
     int band_T = -1, band_S = -1, band_wmax = 0;
     bool band_tile16_ok = false;   // every 16-query tile's windows fit XA_KW key columns (fused chain kernel)
-    bool use_xattn = true;         // SAID_NO_XATTN=1: the three unfused launches at every batch size
+    bool use_xattn = false;        // SAID_XATTN=1: the fused chain kernel (xattn.hip) at small batches — measured no faster than the
+                                   // three launches it replaces (18.4 vs 17.9 us at B = 1), so it is opt-in
     float *init_cm = nullptr, *enoise_cm = nullptr, *mask_cm = nullptr, *rescale_part = nullptr;
     float* noise_cm = nullptr; size_t noise_cm_elems = 0;
     float* coef1_dev = nullptr;  // one row for said_ddim_step
@@ -122,6 +125,11 @@ struct said_ctx {
     float *bH = nullptr, *bT = nullptr, *bPosT = nullptr;
     size_t b_conv_elems[2] = {0, 0}, b_tok = 0;
     bool audio_bf16 = true;   // SAID_NO_AUDIO_BF16=1: the fp32 audio encoder also in bf16 mode
+    // bf16-mode UNet at large batch: token-major bf16 GEMM operands (tgemm.hip) prepared from the channel-major fp32 activations
+    void *uPA = nullptr, *uPB = nullptr, *uPL = nullptr, *uPH = nullptr, *uPX = nullptr;   // conv operand [Be][T+2][384], raw cat input
+                                                                                            // [Be][T][384], LN'd [Be][T][192], GEGLU out [Be][T][768], raw x2 [Be][T][192]
+    bool unet_tgemm = true;   // SAID_NO_UNET_TGEMM=1 keeps the channel-major kernels in bf16 mode at every batch size
+    long long unet_tgemm_min_tokens = 8192;
 
     // ---- audio workspace (lazily sized) ----
     float *abufA = nullptr, *abufB = nullptr; size_t abuf_elems[2] = {0, 0};
@@ -480,6 +488,45 @@ void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hi
     }
 }
 
+// ---- bf16 mode, large batches: UNet GEMMs on the token-major bf16 kernel (tgemm.hip) ------------------------------------
+// The channel-major fp32 activations stay as they are between kernels (GroupNorm statistics, residuals, attention operands);
+// what changes is the GEMM itself: a prep kernel applies the fused operand transform once and writes the operand token-major
+// in bf16, and the GEMM runs as 128-token tiles on v_mfma_f32_32x32x16_bf16 without any split-K reduction.
+bool use_tg(said_ctx* c, const UGeo& g, int nsamples) {
+    return c->bf16_mode && c->unet_tgemm && !c->clk_on && (long long)nsamples * g.T >= c->unet_tgemm_min_tokens;
+}
+void do_prep(said_ctx* c, const PrepArgs& a, int batch, hipStream_t s) {
+    if (c->log_on) c->stage_log.push_back({5, -2, 0, 0, (double)batch * a.C * a.T * (4.0 + 2.0), 0.0});
+    if (dbg_go(c)) launch_prep(a, batch, s);
+}
+void do_tgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
+    if (c->log_on) {
+        const double out_b = a.geglu ? a.N / 2 * 2.0 : (a.y_cm ? 4.0 * a.N * (a.res_cm ? 2 : 1) : 4.0 * a.N);
+        c->stage_log.push_back({4, a.geglu ? EPI_GEGLU : (a.qk ? EPI_QKV : EPI_STORE), a.N % 128 == 0 ? 128 : 64, 4,
+                                2.0 * a.N * a.K + (double)batch * a.M * (2.0 * a.K + out_b), 2.0 * batch * (double)a.M * a.N * a.K});
+    }
+    if (dbg_go(c)) launch_tgemm(a, batch, s);
+}
+PrepArgs mkprep(const UGeo& g, const float* x, int mode, void* dst, long long dst_bs, int ldd, int coff) {
+    PrepArgs p;
+    memset(&p, 0, sizeof p);
+    p.x = x; p.x_bs = g.hs; p.pitch = g.Tp; p.T = g.T; p.C = MC; p.mode = mode;
+    p.dst = dst; p.dst_bs = dst_bs; p.ldd = ldd; p.coff = coff;
+    return p;
+}
+void prep_gn(PrepArgs& p, const UGeo& g, const float* part, int cpg, float eps, const float* gamma, const float* beta) {
+    p.gn_part = part; p.gn_part_bs = g.sts; p.gn_cpg = cpg; p.gn_nparts = g.np; p.gn_eps = eps; p.gn_gamma = gamma; p.gn_beta = beta;
+}
+TGemmArgs mktg(const UGeo& g, const void* a, long long a_bs, int lda, const void* w, int N, int K) {
+    TGemmArgs t;
+    memset(&t, 0, sizeof t);
+    t.a = a; t.a_bs = a_bs; t.lda = lda; t.w = w; t.M = g.T; t.N = N; t.K = K;
+    return t;
+}
+void tg_cm_out(TGemmArgs& t, const UGeo& g, const ActBuf& out) {
+    t.y_cm = out.p; t.cm_bs = g.hs; t.cm_pitch = g.Tp; t.stats = out.st; t.stats_bs = g.sts;
+}
+
 // shared: guidance-shared prefix — only the first g.Bc samples are computed, and the result is ALSO written into the
 // conditional half's slots (values only; its statistics are consumed by kernels that run on the first half alone)
 void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, const ActBuf& in0, const ActBuf* in1, const ActBuf& out, hipStream_t s,
@@ -487,6 +534,43 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
     const int cpg = rw.cin / 32;
     const int nb = shared ? g.Bc : g.Be;
     const long long tt = (long long)nb * ((g.T + 31) / 32);
+    if (use_tg(c, g, nb)) {
+        const long long T2 = g.T + 2;
+        {   // in_layers: GN -> SiLU -> conv3 + emb term   (openaimodel.py:205-225)
+            PrepArgs p = mkprep(g, in0.p, 0, c->uPA, T2 * rw.cin, rw.cin, 0);
+            prep_gn(p, g, in0.st, cpg, 1e-5f, rw.g1, rw.b1);
+            do_prep(c, p, nb, s);
+            if (in1) {
+                PrepArgs q = mkprep(g, in1->p, 0, c->uPA, T2 * rw.cin, rw.cin, MC);
+                prep_gn(q, g, in1->st, cpg, 1e-5f, rw.g1 + MC, rw.b1 + MC);
+                do_prep(c, q, nb, s);
+            }
+            TGemmArgs t = mktg(g, c->uPA, T2 * rw.cin, rw.cin, rw.t_conv1, MC, 3 * rw.cin);
+            t.bias = rw.conv1.bias;
+            t.emb = c->EO + (long long)rb_index * MC * c->maxNp; t.emb_pitch = c->maxNp; t.step_ptr = g.step_ptr; t.emb_b_stride = g.emb_b_stride;
+            tg_cm_out(t, g, c->M);
+            do_tgemm(c, t, nb, s);
+        }
+        {   // out_layers: GN -> SiLU -> conv3 ; + skip(x)   (openaimodel.py:226-227)
+            PrepArgs p = mkprep(g, c->M.p, 0, c->uPA, T2 * MC, MC, 0);
+            prep_gn(p, g, c->M.st, 6, 1e-5f, rw.g2, rw.b2);
+            do_prep(c, p, nb, s);
+            TGemmArgs t = mktg(g, c->uPA, T2 * MC, MC, rw.t_conv2, MC, 3 * MC);
+            if (rw.has_skip) {   // 1x1 conv over the concatenated raw input as a second K segment
+                do_prep(c, mkprep(g, in0.p, 3, c->uPB, (long long)g.T * 2 * MC, 2 * MC, 0), nb, s);
+                do_prep(c, mkprep(g, in1->p, 3, c->uPB, (long long)g.T * 2 * MC, 2 * MC, MC), nb, s);
+                t.a2 = c->uPB; t.a2_bs = (long long)g.T * 2 * MC; t.lda2 = 2 * MC; t.K1 = 3 * MC; t.K = 5 * MC;
+                t.bias = rw.bias2;
+            } else {
+                t.bias = rw.conv2.bias;
+                t.res_cm = in0.p; t.res_cm_bs = g.hs;
+            }
+            tg_cm_out(t, g, out);
+            if (shared) { t.y2_cm = out.p + (long long)g.Bc * g.hs; t.y2_bs = g.hs; }
+            do_tgemm(c, t, nb, s);
+        }
+        return;
+    }
     {   // in_layers: GN -> SiLU -> conv3 ; + emb_layers(emb)   (openaimodel.py:205-225)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = in1 ? 2 : 1;
@@ -543,6 +627,16 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     const bool big_qkv = tt1 * 6 > 1536 && getenv("SAID_NO_MT") && !c->bf16_mode;   // without multi-tile workgroups the generic NB=6 shape wins in fp32
     const int vt_rows = rup(g.T, 32);
     const long long obs = 2LL * MC * g.Tp;   // batch stride of O (shared with QK so attention uses one stride)
+    const bool tg = use_tg(c, g, n1);
+    if (tg) {   // q, k, v on the bf16 token-major GEMM: operand = LayerNorm(GroupNorm(x)) prepared once
+        PrepArgs p = mkprep(g, in.p, 1, c->uPL, (long long)g.T * MC, MC, 0);
+        prep_gn(p, g, in.st, 6, 1e-6f, sw.gn_g, sw.gn_b);
+        p.ln_gamma = sw.l1g; p.ln_beta = sw.l1b;
+        do_prep(c, p, n1, s);
+        TGemmArgs t = mktg(g, c->uPL, (long long)g.T * MC, MC, sw.t_qkv, 3 * MC, MC);
+        t.qk = c->QK; t.vt = c->VT; t.v_bs = (long long)MC * g.Tp; t.qk_n = 2 * MC; t.head_dim = HD; t.rows = vt_rows; t.heads2 = 2 * HEADS; t.v_pitch = g.Tp;
+        do_tgemm(c, t, n1, s);
+    } else
     {   // x = norm(x) (GroupNorm eps 1e-6); q,k,v = to_{q,k,v}(norm1(x))   (attention.py:227, 168, 93-97)
         GemmArgs a = mkargs(g.T, 3 * MC);
         a.nseg = 1;
@@ -640,6 +734,27 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         do_gemm(c, a, EPI_STORE, n2, lc.NB, lc.KS, s);
     }
 geglu:
+    if (use_tg(c, g, g.Be)) {
+        {   // GEGLU: operand norm3(x2) (and raw x2 for the folded proj_out), value/gate pairs multiplied in the epilogue
+            PrepArgs p = mkprep(g, c->X2, 2, c->uPL, (long long)g.T * MC, MC, 0);
+            p.ln_gamma = sw.l3g; p.ln_beta = sw.l3b;
+            p.dst2 = c->uPX; p.dst2_bs = (long long)g.T * MC; p.ldd2 = MC; p.coff2 = 0;
+            do_prep(c, p, g.Be, s);
+            TGemmArgs t = mktg(g, c->uPL, (long long)g.T * MC, MC, sw.t_ff1, 2 * FFI, MC);
+            t.bias = sw.t_ff1_bias; t.geglu = 1;
+            t.yb = c->uPH; t.y_bs = (long long)g.T * FFI; t.ldy = FFI;
+            do_tgemm(c, t, g.Be, s);
+        }
+        {   // proj_out o ff.net.2 over [h ; x2] + x_in, channel-major result + GroupNorm partials
+            TGemmArgs t = mktg(g, c->uPH, (long long)g.T * FFI, FFI, sw.t_ffproj, MC, FFI + MC);
+            t.a2 = c->uPX; t.a2_bs = (long long)g.T * MC; t.lda2 = MC; t.K1 = FFI;
+            t.bias = sw.ffproj.bias;
+            t.res_cm = in.p; t.res_cm_bs = g.hs;
+            tg_cm_out(t, g, out);
+            do_tgemm(c, t, g.Be, s);
+        }
+        return;
+    }
     {   // GEGLU: proj(norm3(x2)) -> a * gelu(gate)   (attention.py:25-32)
         GemmArgs a = mkargs(g.T, FFI);
         a.nseg = 1;
@@ -869,8 +984,10 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     ctx->use_ugemm = getenv("SAID_NO_UGEMM") == nullptr;
     ctx->use_branches = getenv("SAID_BRANCHES") != nullptr;
     ctx->cfg_share = getenv("SAID_NO_CFG_SHARE") == nullptr;
-    ctx->use_xattn = getenv("SAID_NO_XATTN") == nullptr;
+    ctx->use_xattn = getenv("SAID_XATTN") != nullptr;
     ctx->audio_bf16 = getenv("SAID_NO_AUDIO_BF16") == nullptr;
+    ctx->unet_tgemm = getenv("SAID_NO_UNET_TGEMM") == nullptr;
+    if (getenv("SAID_UNET_TGEMM_MIN")) ctx->unet_tgemm_min_tokens = atoll(getenv("SAID_UNET_TGEMM_MIN"));
     configure_tgemm_kernel();
     configure_xattn_kernel();   // parallel graph branches measured no faster on ROCm 7.2: off by default
     if (hipStreamCreateWithFlags(&ctx->cap_stream2, hipStreamNonBlocking) != hipSuccess ||
@@ -902,6 +1019,14 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     rc |= dalloc(ctx, &ctx->init_cm, Be * 32 * Tp); rc |= dalloc(ctx, &ctx->enoise_cm, Be * 32 * Tp); rc |= dalloc(ctx, &ctx->mask_cm, Be * 32 * Tp);
     rc |= dalloc(ctx, &ctx->rescale_part, Be * 2 * 64 * 3);
     rc |= dalloc(ctx, &ctx->freqs, MC / 2);
+    {   // bf16 operand buffers of the large-batch bf16 path (2 bytes per element; zero-initialised, so padding rows start at 0)
+        const size_t Tm = (size_t)max_frames;
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPA), Be * (Tm + 2) * 2 * MC + 4096);
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPB), Be * Tm * 2 * MC + 4096);
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPL), Be * Tm * MC + 4096);
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPH), Be * Tm * FFI + 4096);
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPX), Be * Tm * MC + 4096);
+    }
     if (rc) { g_create_err = ctx->err; said_destroy(ctx); return -1; }
     *out = ctx;
     return 0;
@@ -971,6 +1096,20 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
         if (make_pw(ctx, &rw.conv1, p + ".in_layers.2.weight", p + ".in_layers.2.bias", MC, rw.cin, 3, rw.has_skip ? 2 : 1, p + ".in_layers.0.weight", p + ".in_layers.0.bias")) return -1;
         if (upvec(ctx, &rw.g2, p + ".out_layers.0.weight", MC) || upvec(ctx, &rw.b2, p + ".out_layers.0.bias", MC)) return -1;
         if (make_pw(ctx, &rw.conv2, p + ".out_layers.3.weight", p + ".out_layers.3.bias", MC, MC, 3, 1, p + ".out_layers.0.weight", p + ".out_layers.0.bias")) return -1;
+        {   // tgemm.hip operands: conv1 [192][3 * cin] tap-major; conv2 [192][576 (+ 384 skip columns)]
+            if (upload_bf16(ctx, &rw.t_conv1, ctx->host_w[p + ".in_layers.2.weight"].data.data(), MC, (size_t)rw.cin, 3)) return -1;
+            const HostTensor& c2w = ctx->host_w[p + ".out_layers.3.weight"];
+            std::vector<float> cat((size_t)MC * (3 * MC + (rw.has_skip ? 2 * MC : 0)));
+            const size_t Kc = 3 * MC + (rw.has_skip ? 2 * MC : 0);
+            const HostTensor* sk = rw.has_skip ? getw(ctx, p + ".skip_connection.weight", {MC, 2 * MC, 1}) : nullptr;
+            if (rw.has_skip && !sk) return -1;
+            for (int n = 0; n < MC; ++n) {
+                for (int t = 0; t < 3; ++t)
+                    for (int cc = 0; cc < MC; ++cc) cat[n * Kc + t * MC + cc] = c2w.data[((size_t)n * MC + cc) * 3 + t];
+                if (sk) for (int cc = 0; cc < 2 * MC; ++cc) cat[n * Kc + 3 * MC + cc] = sk->data[(size_t)n * 2 * MC + cc];
+            }
+            if (upload_bf16(ctx, &rw.t_conv2, cat.data(), MC, Kc, 1)) return -1;
+        }
         const HostTensor* ew = getw(ctx, p + ".emb_layers.1.weight", {MC, TE});
         const HostTensor* eb = getw(ctx, p + ".emb_layers.1.bias", {MC});
         if (!ew || !eb) return -1;
@@ -1080,6 +1219,31 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
             ctx->host_w["__ffproj.b"] = std::move(PB);
             PW t0, t1;
             if (make_pw(ctx, &t0, "__ffproj.w0", "__ffproj.b", MC, FFI, 0) || make_pw(ctx, &t1, "__ffproj.w1", "", MC, MC, 0)) return -1;
+            {   // tgemm.hip operands of this block: q/k/v rows, GEGLU rows tile-interleaved (value, gate), [P F2 | P]
+                if (upload_bf16(ctx, &sw.t_qkv, qkv.data(), 3 * MC, MC, 1)) return -1;
+                const HostTensor* f1 = getw(ctx, b + ".ff.net.0.proj.weight", {2 * FFI, MC});
+                const HostTensor* f1b = getw(ctx, b + ".ff.net.0.proj.bias", {2 * FFI});
+                if (!f1 || !f1b) return -1;
+                std::vector<float> pw((size_t)2 * FFI * MC), pb((size_t)2 * FFI);
+                for (int tile = 0; tile < 2 * FFI / 128; ++tile)
+                    for (int wn = 0; wn < 2; ++wn)
+                        for (int j = 0; j < 2; ++j)
+                            for (int i = 0; i < 32; ++i) {
+                                const int np = tile * 128 + wn * 64 + j * 32 + i;
+                                const int src = (j == 0 ? 0 : FFI) + tile * 64 + wn * 32 + i;
+                                std::copy(f1->data.begin() + (size_t)src * MC, f1->data.begin() + (size_t)(src + 1) * MC, pw.begin() + (size_t)np * MC);
+                                pb[np] = f1b->data[src];
+                            }
+                if (upload_bf16(ctx, &sw.t_ff1, pw.data(), 2 * FFI, MC, 1) || upload(ctx, &sw.t_ff1_bias, pb.data(), pb.size())) return -1;
+                const HostTensor& w0 = ctx->host_w["__ffproj.w0"];
+                const HostTensor& w1 = ctx->host_w["__ffproj.w1"];
+                std::vector<float> cat((size_t)MC * (FFI + MC));
+                for (int n = 0; n < MC; ++n) {
+                    std::copy(w0.data.begin() + (size_t)n * FFI, w0.data.begin() + (size_t)(n + 1) * FFI, cat.begin() + (size_t)n * (FFI + MC));
+                    std::copy(w1.data.begin() + (size_t)n * MC, w1.data.begin() + (size_t)(n + 1) * MC, cat.begin() + (size_t)n * (FFI + MC) + FFI);
+                }
+                if (upload_bf16(ctx, &sw.t_ffproj, cat.data(), MC, FFI + MC, 1)) return -1;
+            }
             PW& fp = sw.ffproj;
             fp.N = MC; fp.taps = 1; fp.nseg = 2; fp.bias = t0.bias;
             fp.w[0] = t0.w[0]; fp.w4[0] = t0.w4[0]; fp.w2[0] = t0.w2[0]; fp.C[0] = FFI;

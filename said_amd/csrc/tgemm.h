@@ -25,10 +25,45 @@ struct TGemmArgs {
     int qk_n, head_dim, rows, heads2, v_pitch;
     int M, N, K;
     int act;               // 0 none, 1 GELU (erf)
+    // ---- second K segment (optional): for k >= K1 the A operand comes from a2 (row m at a2 + b * a2_bs + m * lda2 + (k - K1)):
+    // ResBlock conv + 1x1 skip over the concatenated input, proj_out o ff.net.2 over [h ; x2].  K1 % 64 == 0.
+    const void* a2;
+    long long a2_bs;
+    int lda2, K1;
+    // ---- channel-major fp32 epilogue (UNet activations; used when y_cm != null): y_cm[b][n][cm_pitch] = acc + bias + emb + res,
+    // GroupNorm partial statistics of the result per (channel, 32-token tile), optional second copy (kernels.h GemmCommon::y2)
+    float* y_cm;
+    long long cm_bs;
+    int cm_pitch;
+    const float* emb;      // [n][emb_pitch] timestep-embedding term, row = *step_ptr + b * emb_b_stride (or null)
+    const int* step_ptr;
+    int emb_pitch, emb_b_stride;
+    const float* res_cm;   // channel-major fp32 residual [b][n][cm_pitch] (or null)
+    long long res_cm_bs;
+    float* stats;          // [b][N][ceil(M/32)][2] (mean, M2) or null
+    long long stats_bs;
+    float* y2_cm;          // second copy of the result (or null)
+    long long y2_bs;
+    // ---- GEGLU epilogue (geglu != 0): the weight rows are tile-interleaved on the host so that a wave's two 32-column MFMA
+    // tiles are (value, gate) of the same 32 channels; out[m][c] = value * gelu(gate) -> yb (bf16 token-major, N / 2 channels)
+    int geglu;
 };
 bool tgemm_supports(const TGemmArgs& a);
-void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s);
+void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s);   // N % 128 == 0: 128-wide tiles, else N % 64 == 0: 64-wide
 void configure_tgemm_kernel();
+// UNet operand preparation (bf16 mode, large batches): channel-major fp32 x[b][C][pitch] -> transform -> token-major bf16.
+// mode 0: silu(GroupNorm(x)) into dst[b][1 + t][ldd] at column `coff` (rows 0 and T + 1 zero: Conv1d padding), mode 1:
+// LayerNorm(GroupNorm(x)) -> dst[b][t][ldd], mode 2: LayerNorm(x) -> dst and raw x -> dst2 (both [b][t][*]), mode 3: raw x.
+struct PrepArgs {
+    const float* x; long long x_bs; int pitch, T, C;
+    const float* gn_part; long long gn_part_bs; int gn_cpg, gn_nparts; float gn_eps;
+    const float* gn_gamma; const float* gn_beta;
+    const float* ln_gamma; const float* ln_beta;
+    void* dst; long long dst_bs; int ldd, coff;
+    void* dst2; long long dst2_bs; int ldd2, coff2;
+    int mode;
+};
+void launch_prep(const PrepArgs& a, int batch, hipStream_t s);
 void launch_cm_to_tm_bf16(const float* src, long long src_bs, int pitch, void* dst, long long dst_bs, int B, int T, int C, hipStream_t s);
 void launch_ln_tm(const float* x, const float* add, float* yf, void* yb, const float* gamma, const float* beta, long long ntok, int C, float eps,
                   hipStream_t s);

@@ -26,49 +26,63 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TBM = 128, TBN = 128, TBK = 64, TLP = 72;   // tile, LDS row pitch in halfs
 
+// BN = 128: wave grid 2 x 2, each wave 64 tokens x 64 outputs; BN = 64 (N = 192, 576): each wave 64 tokens x 32 outputs
+template <int BN>
 __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [2 buffers][A 128 x 72 | W 128 x 72]
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [2 buffers][A 128 x 72 | W BN x 72]
+    constexpr int NJ = BN / 64;                 // MFMA column tiles per wave
+    constexpr int WCH = BN * 8 / 256;           // 16-byte W chunks per thread and tile
+    constexpr int BUF = (TBM + BN) * TLP;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
-    const int m0 = blockIdx.x * TBM, n0 = blockIdx.y * TBN, b = blockIdx.z;
+    const int m0 = blockIdx.x * TBM, n0 = blockIdx.y * BN, b = blockIdx.z;
     const unsigned short* A = reinterpret_cast<const unsigned short*>(a.a) + (long long)b * a.a_bs;
+    const unsigned short* A2 = reinterpret_cast<const unsigned short*>(a.a2) + (long long)b * a.a2_bs;
     const unsigned short* W = reinterpret_cast<const unsigned short*>(a.w);
     const int nk = a.K / TBK;
+    const int nk1 = (a.a2 ? a.K1 : a.K) / TBK;   // K tiles served by the first A segment
 
-    // global -> register staging: thread owns 4 chunks of 16 bytes of each operand tile (chunk c: row c >> 3, k piece c & 7)
-    u32x4 ra[4], rw[4];
-    long long aoff[4], woff[4];
-    int loff[4];
+    // global -> register staging: chunk c of a tile: row c >> 3, k piece c & 7 (16 bytes)
+    u32x4 ra[4], rw[WCH];
+    long long aoff[4], a2off[4], woff[WCH];
+    int loff[4], lwoff[WCH];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = tid + 256 * i, row = c >> 3, kp = c & 7;
         const int m = min(m0 + row, a.M - 1);   // rows past M repeat the last row (never stored)
         aoff[i] = (long long)m * a.lda + kp * 8;
-        woff[i] = (long long)(n0 + row) * a.K + kp * 8;
+        a2off[i] = (long long)m * a.lda2 + kp * 8;
         loff[i] = row * TLP + kp * 8;
     }
-    auto gload_tile = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const u32x4*>(A + aoff[i] + (long long)kt * TBK);
-            rw[i] = *reinterpret_cast<const u32x4*>(W + woff[i] + (long long)kt * TBK);
-        }
+    for (int i = 0; i < WCH; ++i) {
+        const int c = tid + 256 * i, row = c >> 3, kp = c & 7;
+        woff[i] = (long long)(n0 + row) * a.K + kp * 8;
+        lwoff[i] = row * TLP + kp * 8;
+    }
+    auto gload_tile = [&](int kt) {
+        const bool first = kt < nk1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ra[i] = first ? *reinterpret_cast<const u32x4*>(A + aoff[i] + (long long)kt * TBK)
+                          : *reinterpret_cast<const u32x4*>(A2 + a2off[i] + (long long)(kt - nk1) * TBK);
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) rw[i] = *reinterpret_cast<const u32x4*>(W + woff[i] + (long long)kt * TBK);
     };
     auto lds_store = [&](int buf) {
-        unsigned short* pa = lds + buf * (2 * TBM * TLP);
+        unsigned short* pa = lds + buf * BUF;
         unsigned short* pw = pa + TBM * TLP;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4*>(pa + loff[i]) = ra[i];
-            *reinterpret_cast<u32x4*>(pw + loff[i]) = rw[i];
-        }
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(pa + loff[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(pw + lwoff[i]) = rw[i];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -78,33 +92,96 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
     const int frow = l & 31, fk = 8 * (l >> 5);
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload_tile(kt + 1);
-        const unsigned short* pa = lds + (kt & 1) * (2 * TBM * TLP);
+        const unsigned short* pa = lds + (kt & 1) * BUF;
         const unsigned short* pw = pa + TBM * TLP;
 #pragma unroll
         for (int ks = 0; ks < TBK / 16; ++ks) {
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[2], fb[NJ];
 #pragma unroll
             for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(pa + (wm * 64 + i * 32 + frow) * TLP + ks * 16 + fk);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(pw + (wn * 64 + j * 32 + frow) * TLP + ks * 16 + fk);
+            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(pw + (wn * (32 * NJ) + j * 32 + frow) * TLP + ks * 16 + fk);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) lds_store((kt + 1) & 1);
         __syncthreads();
     }
 
-    // ---- epilogue: D[i = token][j = output]: lane -> output n (l & 31), register r -> token (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+    // ---- epilogues.  D[i = token][j = output]: lane -> output n (l & 31), register r -> token (r & 3) + 8 (r >> 2) + 4 (l >> 5)
     const int lh = l >> 5;
+    if constexpr (NJ == 2) {
+        if (a.geglu) {   // columns j = 0: value, j = 1: gate of channel c (host tile-interleaving): out = value * gelu(gate)
+            const int c = (n0 >> 1) + wn * 32 + (l & 31);
+            const float bv = a.bias ? a.bias[n0 + wn * 64 + (l & 31)] : 0.f, bg = a.bias ? a.bias[n0 + wn * 64 + 32 + (l & 31)] : 0.f;
+            __bf16* yb = reinterpret_cast<__bf16*>(a.yb) + (long long)b * a.y_bs;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (l & 31);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < a.M) yb[(long long)m * a.ldy + c] = (__bf16)((acc[i][0][r] + bv) * gelu_f(acc[i][1][r] + bg));
+                }
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * (32 * NJ) + j * 32 + (l & 31);
         const float bias = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int mt = m0 + wm * 64 + i * 32;
+            if (a.y_cm) {
+                // channel-major fp32 result: 4 consecutive tokens per register quadruple -> one 16-byte store per lane
+                float add = bias;
+                if (a.emb) add += a.emb[(long long)n * a.emb_pitch + (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride];
+                float* yp = a.y_cm + (long long)b * a.cm_bs + (long long)n * a.cm_pitch;
+                const float* rp = a.res_cm ? a.res_cm + (long long)b * a.res_cm_bs + (long long)n * a.cm_pitch : nullptr;
+                float* y2p = a.y2_cm ? a.y2_cm + (long long)b * a.y2_bs + (long long)n * a.cm_pitch : nullptr;
+                float sum = 0.f;
+                float vals[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mt + 8 * q + 4 * lh;
+                    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (rp && m < a.M) rv = *reinterpret_cast<const float4*>(rp + m);   // pitch >= roundup(M, 32): in-bounds
+                    const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[i][j][4 * q + e] + add + r4[e];
+                        vals[4 * q + e] = v;
+                        sum += (m + e < a.M) ? v : 0.f;
+                    }
+                    if (m < a.M) {   // tokens in [M, roundup(M, 4)) land in the row's padding
+                        const float4 v4 = make_float4(vals[4 * q], vals[4 * q + 1], vals[4 * q + 2], vals[4 * q + 3]);
+                        *reinterpret_cast<float4*>(yp + m) = v4;
+                        if (y2p) *reinterpret_cast<float4*>(y2p + m) = v4;
+                    }
+                }
+                if (a.stats && mt < a.M) {   // Welford partial of this channel over the 32-token tile (lanes l and l ^ 32 hold it)
+                    const float cnt = (float)min(32, a.M - mt);
+                    sum += __shfl_xor(sum, 32);
+                    const float mean = sum / cnt;
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = (mt + 8 * q + 4 * lh + e < a.M) ? vals[4 * q + e] - mean : 0.f;
+                            m2 = fmaf(d, d, m2);
+                        }
+                    m2 += __shfl_xor(m2, 32);
+                    if (lh == 0) {
+                        float* so = a.stats + (long long)b * a.stats_bs + ((long long)n * ((a.M + 31) >> 5) + (mt >> 5)) * 2;
+                        so[0] = mean;
+                        so[1] = m2;
+                    }
+                }
+                continue;
+            }
             if (a.qk && n >= a.qk_n) {
                 // v rows channel-major [c][t] for the attention kernel: 4 consecutive tokens per register quadruple
                 const int c = n - a.qk_n;
@@ -142,16 +219,116 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
 }
 
 bool tgemm_supports(const TGemmArgs& a) {
-    return a.M >= 1 && a.N >= TBN && a.N % TBN == 0 && a.K >= TBK && a.K % TBK == 0 && a.lda % 8 == 0 && a.a_bs % 8 == 0 &&
-           (!a.qk || (a.qk_n % 32 == 0 && a.head_dim % 32 == 0));
+    if (!(a.M >= 1 && a.N >= 64 && a.N % 64 == 0 && a.K >= TBK && a.K % TBK == 0 && a.lda % 8 == 0 && a.a_bs % 8 == 0)) return false;
+    if (a.qk && (a.qk_n % 32 || a.head_dim % 32)) return false;
+    if (a.a2 && (a.K1 % TBK || a.K1 <= 0 || a.K1 >= a.K || a.lda2 % 8 || a.a2_bs % 8)) return false;
+    if (a.geglu && (a.N % 128 || !a.yb)) return false;
+    if (a.y_cm && (a.cm_pitch % 4 || a.cm_pitch < ((a.M + 3) & ~3))) return false;
+    return true;
 }
 void configure_tgemm_kernel() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * TBM * TLP * 2);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TBM + 128) * TLP * 2);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TBM + 64) * TLP * 2);
 }
 void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
     if (!tgemm_supports(a)) { fprintf(stderr, "said: tgemm shape M=%d N=%d K=%d unsupported\n", a.M, a.N, a.K); abort(); }
-    dim3 grid((a.M + TBM - 1) / TBM, a.N / TBN, batch);
-    hipLaunchKernelGGL(tgemm_kernel, grid, dim3(256), 2 * 2 * TBM * TLP * 2, s, a);
+    if (a.N % 128 == 0) {
+        dim3 grid((a.M + TBM - 1) / TBM, a.N / 128, batch);
+        hipLaunchKernelGGL(tgemm_kernel<128>, grid, dim3(256), 2 * (TBM + 128) * TLP * 2, s, a);
+    } else {
+        dim3 grid((a.M + TBM - 1) / TBM, a.N / 64, batch);
+        hipLaunchKernelGGL(tgemm_kernel<64>, grid, dim3(256), 2 * (TBM + 64) * TLP * 2, s, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// UNet operand preparation: one workgroup = 32 tokens x all C (<= 192) channels of one sample.  The GroupNorm
+// coefficients come from the producer's Welford partials exactly as in the GEMM kernels (gemm_common.h), the tile is
+// read with coalesced 128-byte rows, transformed once, and written token-major (C bf16 per token, contiguous).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_kernel(const PrepArgs a) {
+    __shared__ float coef[2 * 192];
+    __shared__ float gns[4 * GN_SCRATCH];
+    __shared__ float tile[192][33];
+    __shared__ float lnp[8][32][2];
+    __shared__ float lnst[32][2];
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int t0 = blockIdx.x * 32, b = blockIdx.y;
+    const int C = a.C, T = a.T;
+    const bool gn = a.mode <= 1, ln = a.mode == 1 || a.mode == 2;
+    if (gn) {   // wave w finalises channels [48 w, 48 w + 48)
+        const GnP gp = {a.gn_cpg, a.gn_nparts, T, a.gn_eps, a.gn_gamma, a.gn_beta};
+        const rsrc_t rp = make_rsrc(a.gn_part + (long long)b * a.gn_part_bs, (unsigned)C * (unsigned)a.gn_nparts * 8u);
+        GnLoads gl;
+        gn_issue(gp, rp, w * 48, 48, l, gl);
+        gn_finish(gp, rp, w * 48, 48, l, gl, gns + w * GN_SCRATCH, coef);
+    }
+    __syncthreads();
+    const float* xb = a.x + (long long)b * a.x_bs;
+    {   // rows: 8 per pass (tid >> 5), 32 tokens per row
+        const int tx = tid & 31;
+        for (int c = tid >> 5; c < C; c += 8) {
+            float v = (t0 + tx < T) ? xb[(long long)c * a.pitch + t0 + tx] : 0.f;
+            tile[c][tx] = v;
+        }
+    }
+    __syncthreads();
+    const int tt = tid & 31, part = tid >> 5;   // 8 parts x 24 channels
+    float mu = 0.f, rs = 1.f;
+    if (ln) {
+        float s1 = 0.f, s2 = 0.f;
+        const float ref = gn ? fmaf(tile[0][tt], coef[0], coef[1]) : tile[0][tt];
+        for (int i = 0; i < 24; ++i) {
+            const int c = part * 24 + i;
+            float v = tile[c][tt];
+            if (gn) v = fmaf(v, coef[2 * c], coef[2 * c + 1]);
+            const float d = v - ref;
+            s1 += d;
+            s2 = fmaf(d, d, s2);
+        }
+        lnp[part][tt][0] = s1;
+        lnp[part][tt][1] = s2;
+        __syncthreads();
+        if (tid < 32) {
+            float S1 = 0.f, S2 = 0.f;
+            for (int p = 0; p < 8; ++p) { S1 += lnp[p][tid][0]; S2 += lnp[p][tid][1]; }
+            const float md = S1 / (float)C;
+            const float var = fmaxf(S2 / (float)C - md * md, 0.f);
+            const float r0 = gn ? fmaf(tile[0][tid], coef[0], coef[1]) : tile[0][tid];
+            lnst[tid][0] = r0 + md;
+            lnst[tid][1] = 1.0f / sqrtf(var + 1e-5f);
+        }
+        __syncthreads();
+        mu = lnst[tt][0];
+        rs = lnst[tt][1];
+    }
+    // write: thread (token tt, part): 24 consecutive channels = 48 bytes
+    const int t = t0 + tt;
+    const int row_off = a.mode == 0 ? 1 : 0;   // conv operand: row 0 is the left padding
+    __bf16* d = reinterpret_cast<__bf16*>(a.dst) + (long long)b * a.dst_bs + (long long)(t + row_off) * a.ldd + a.coff + part * 24;
+    __bf16* d2 = a.dst2 ? reinterpret_cast<__bf16*>(a.dst2) + (long long)b * a.dst2_bs + (long long)t * a.ldd2 + a.coff2 + part * 24 : nullptr;
+    const bool tv = t < T;
+    if (tv || (a.mode == 0 && t == T)) {   // the conv operand's right padding row (token T) is written as zeros
+        for (int i = 0; i < 24; ++i) {
+            const int c = part * 24 + i;
+            const float raw = tile[c][tt];
+            float v = raw;
+            if (gn) v = fmaf(v, coef[2 * c], coef[2 * c + 1]);
+            if (a.mode == 0) v = silu_f(v);
+            if (ln) v = fmaf((v - mu) * rs, a.ln_gamma[c], a.ln_beta[c]);
+            d[i] = (__bf16)(tv ? v : 0.f);
+            if (d2 && tv) d2[i] = (__bf16)raw;
+        }
+    }
+    if (a.mode == 0 && t0 == 0 && tt == 0) {   // left padding row
+        __bf16* z = reinterpret_cast<__bf16*>(a.dst) + (long long)b * a.dst_bs + a.coff + part * 24;
+        for (int i = 0; i < 24; ++i) z[i] = (__bf16)0.f;
+    }
+}
+void launch_prep(const PrepArgs& a, int batch, hipStream_t s) {
+    if (a.C != 192 || a.T < 1) { fprintf(stderr, "said: prep kernel is instantiated for 192 channels (got %d)\n", a.C); abort(); }
+    dim3 grid(a.T / 32 + 1, batch);   // one tile past ceil(T / 32) when T % 32 == 0: the conv operand's right padding row
+    hipLaunchKernelGGL(prep_kernel, grid, dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
