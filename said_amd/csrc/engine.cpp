@@ -126,6 +126,7 @@ struct said_ctx {
     size_t b_conv_elems[2] = {0, 0}, b_tok = 0;
     bool audio_bf16 = true;   // SAID_NO_AUDIO_BF16=1: the fp32 audio encoder also in bf16 mode
     // bf16-mode UNet at large batch: token-major bf16 GEMM operands (tgemm.hip) prepared from the channel-major fp32 activations
+    float* gn_coef = nullptr;   // [2 slots][maxBe][192][2] GroupNorm coefficients for prep_kernel
     void *uPA = nullptr, *uPB = nullptr, *uPL = nullptr, *uPH = nullptr, *uPX = nullptr;   // conv operand [Be][T+2][384], raw cat input
                                                                                             // [Be][T][384], LN'd [Be][T][192], GEGLU out [Be][T][768], raw x2 [Be][T][192]
     bool unet_tgemm = true;   // SAID_NO_UNET_TGEMM=1 keeps the channel-major kernels in bf16 mode at every batch size
@@ -514,8 +515,14 @@ PrepArgs mkprep(const UGeo& g, const float* x, int mode, void* dst, long long ds
     p.dst = dst; p.dst_bs = dst_bs; p.ldd = ldd; p.coff = coff;
     return p;
 }
-void prep_gn(PrepArgs& p, const UGeo& g, const float* part, int cpg, float eps, const float* gamma, const float* beta) {
-    p.gn_part = part; p.gn_part_bs = g.sts; p.gn_cpg = cpg; p.gn_nparts = g.np; p.gn_eps = eps; p.gn_gamma = gamma; p.gn_beta = beta;
+// GroupNorm coefficients of the operand, once per tensor (slot: one of two coefficient tables, so that the two sources of a
+// concatenated input can be prepared back to back)
+void prep_gn(said_ctx* c, PrepArgs& p, const UGeo& g, const float* part, int cpg, float eps, const float* gamma, const float* beta, int nb,
+             int slot, hipStream_t s) {
+    float* co = c->gn_coef + (size_t)slot * c->maxBe * 2 * MC;
+    if (c->log_on) c->stage_log.push_back({5, -2, 0, 0, (double)nb * MC * g.np * 8.0, 0.0});
+    if (dbg_go(c)) launch_gn_coef(part, g.sts, cpg, g.np, g.T, eps, gamma, beta, co, 2 * MC, nb, s);
+    p.coef = co; p.coef_bs = 2 * MC;
 }
 TGemmArgs mktg(const UGeo& g, const void* a, long long a_bs, int lda, const void* w, int N, int K) {
     TGemmArgs t;
@@ -538,11 +545,11 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
         const long long T2 = g.T + 2;
         {   // in_layers: GN -> SiLU -> conv3 + emb term   (openaimodel.py:205-225)
             PrepArgs p = mkprep(g, in0.p, 0, c->uPA, T2 * rw.cin, rw.cin, 0);
-            prep_gn(p, g, in0.st, cpg, 1e-5f, rw.g1, rw.b1);
+            prep_gn(c, p, g, in0.st, cpg, 1e-5f, rw.g1, rw.b1, nb, 0, s);
             do_prep(c, p, nb, s);
             if (in1) {
                 PrepArgs q = mkprep(g, in1->p, 0, c->uPA, T2 * rw.cin, rw.cin, MC);
-                prep_gn(q, g, in1->st, cpg, 1e-5f, rw.g1 + MC, rw.b1 + MC);
+                prep_gn(c, q, g, in1->st, cpg, 1e-5f, rw.g1 + MC, rw.b1 + MC, nb, 1, s);
                 do_prep(c, q, nb, s);
             }
             TGemmArgs t = mktg(g, c->uPA, T2 * rw.cin, rw.cin, rw.t_conv1, MC, 3 * rw.cin);
@@ -553,7 +560,7 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
         }
         {   // out_layers: GN -> SiLU -> conv3 ; + skip(x)   (openaimodel.py:226-227)
             PrepArgs p = mkprep(g, c->M.p, 0, c->uPA, T2 * MC, MC, 0);
-            prep_gn(p, g, c->M.st, 6, 1e-5f, rw.g2, rw.b2);
+            prep_gn(c, p, g, c->M.st, 6, 1e-5f, rw.g2, rw.b2, nb, 0, s);
             do_prep(c, p, nb, s);
             TGemmArgs t = mktg(g, c->uPA, T2 * MC, MC, rw.t_conv2, MC, 3 * MC);
             if (rw.has_skip) {   // 1x1 conv over the concatenated raw input as a second K segment
@@ -630,7 +637,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     const bool tg = use_tg(c, g, n1);
     if (tg) {   // q, k, v on the bf16 token-major GEMM: operand = LayerNorm(GroupNorm(x)) prepared once
         PrepArgs p = mkprep(g, in.p, 1, c->uPL, (long long)g.T * MC, MC, 0);
-        prep_gn(p, g, in.st, 6, 1e-6f, sw.gn_g, sw.gn_b);
+        prep_gn(c, p, g, in.st, 6, 1e-6f, sw.gn_g, sw.gn_b, n1, 0, s);
         p.ln_gamma = sw.l1g; p.ln_beta = sw.l1b;
         do_prep(c, p, n1, s);
         TGemmArgs t = mktg(g, c->uPL, (long long)g.T * MC, MC, sw.t_qkv, 3 * MC, MC);
@@ -1026,6 +1033,7 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
         rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPL), Be * Tm * MC + 4096);
         rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPH), Be * Tm * FFI + 4096);
         rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPX), Be * Tm * MC + 4096);
+        rc |= dalloc(ctx, &ctx->gn_coef, 2 * Be * 2 * MC);
     }
     if (rc) { g_create_err = ctx->err; said_destroy(ctx); return -1; }
     *out = ctx;

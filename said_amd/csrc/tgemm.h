@@ -24,6 +24,7 @@ struct TGemmArgs {
     long long v_bs;
     int qk_n, head_dim, rows, heads2, v_pitch;
     int M, N, K;
+    int batch;             // filled in by launch_tgemm
     int act;               // 0 none, 1 GELU (erf)
     // ---- second K segment (optional): for k >= K1 the A operand comes from a2 (row m at a2 + b * a2_bs + m * lda2 + (k - K1)):
     // ResBlock conv + 1x1 skip over the concatenated input, proj_out o ff.net.2 over [h ; x2].  K1 % 64 == 0.
@@ -56,14 +57,16 @@ void configure_tgemm_kernel();
 // LayerNorm(GroupNorm(x)) -> dst[b][t][ldd], mode 2: LayerNorm(x) -> dst and raw x -> dst2 (both [b][t][*]), mode 3: raw x.
 struct PrepArgs {
     const float* x; long long x_bs; int pitch, T, C;
-    const float* gn_part; long long gn_part_bs; int gn_cpg, gn_nparts; float gn_eps;
-    const float* gn_gamma; const float* gn_beta;
+    const float* coef; long long coef_bs;        // GroupNorm (a, b) per (sample, channel) from launch_gn_coef (modes 0, 1)
     const float* ln_gamma; const float* ln_beta;
     void* dst; long long dst_bs; int ldd, coff;
     void* dst2; long long dst2_bs; int ldd2, coff2;
     int mode;
 };
 void launch_prep(const PrepArgs& a, int batch, hipStream_t s);
+// GroupNorm coefficients of a 192-channel tensor from its Welford partials [b][192][nparts][2] -> coef_out[b][192][2]
+void launch_gn_coef(const float* part, long long part_bs, int cpg, int nparts, int T, float eps, const float* gamma, const float* beta,
+                    float* coef_out, long long coef_bs, int batch, hipStream_t s);
 void launch_cm_to_tm_bf16(const float* src, long long src_bs, int pitch, void* dst, long long dst_bs, int B, int T, int C, hipStream_t s);
 void launch_ln_tm(const float* x, const float* add, float* yf, void* yb, const float* gamma, const float* beta, long long ntok, int C, float eps,
                   hipStream_t s);

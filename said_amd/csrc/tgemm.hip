@@ -35,7 +35,18 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
     constexpr int BUF = (TBM + BN) * TLP;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
-    const int m0 = blockIdx.x * TBM, n0 = blockIdx.y * BN, b = blockIdx.z;
+    // XCD-aware tile order.  The hardware places consecutive workgroup ids on consecutive XCDs (id % 8), each with its own L2.
+    // The N / BN workgroups that share an A tile are given consecutive slots of ONE XCD (n tile fastest), so the A tile is
+    // fetched from HBM / Infinity Cache once and hits that XCD's L2 for the other column tiles; the weights are small and
+    // stay resident in every L2.  (The natural (m, n) grid re-fetched every A tile N / BN times from beyond L2.)
+    // The 1-D grid enumerates (sample, M tile) pairs of the whole batch, so all eight XCDs stay busy whatever M is.
+    const int NT = a.N / BN, MT = (a.M + TBM - 1) / TBM;
+    const unsigned L = blockIdx.x, xcd = L & 7u, slot = L >> 3;
+    const int nt = (int)(slot % (unsigned)NT);
+    const int mg = (int)(slot / (unsigned)NT) * 8 + (int)xcd;   // global M-tile index over the batch
+    const int b = mg / MT, mt_ = mg - b * MT;
+    if (b >= a.batch) return;   // padding of the tile count to a multiple of 8 (the whole workgroup exits together)
+    const int m0 = mt_ * TBM, n0 = nt * BN;
     const unsigned short* A = reinterpret_cast<const unsigned short*>(a.a) + (long long)b * a.a_bs;
     const unsigned short* A2 = reinterpret_cast<const unsigned short*>(a.a2) + (long long)b * a.a2_bs;
     const unsigned short* W = reinterpret_cast<const unsigned short*>(a.w);
@@ -232,57 +243,90 @@ void configure_tgemm_kernel() {
 }
 void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
     if (!tgemm_supports(a)) { fprintf(stderr, "said: tgemm shape M=%d N=%d K=%d unsupported\n", a.M, a.N, a.K); abort(); }
+    TGemmArgs a2 = a;
+    a2.batch = batch;
+    const long long mtiles8 = ((long long)batch * ((a.M + TBM - 1) / TBM) + 7) / 8 * 8;   // (sample, M tile) pairs padded to the 8 XCDs
     if (a.N % 128 == 0) {
-        dim3 grid((a.M + TBM - 1) / TBM, a.N / 128, batch);
-        hipLaunchKernelGGL(tgemm_kernel<128>, grid, dim3(256), 2 * (TBM + 128) * TLP * 2, s, a);
+        dim3 grid((unsigned)(mtiles8 * (a.N / 128)));
+        hipLaunchKernelGGL(tgemm_kernel<128>, grid, dim3(256), 2 * (TBM + 128) * TLP * 2, s, a2);
     } else {
-        dim3 grid((a.M + TBM - 1) / TBM, a.N / 64, batch);
-        hipLaunchKernelGGL(tgemm_kernel<64>, grid, dim3(256), 2 * (TBM + 64) * TLP * 2, s, a);
+        dim3 grid((unsigned)(mtiles8 * (a.N / 64)));
+        hipLaunchKernelGGL(tgemm_kernel<64>, grid, dim3(256), 2 * (TBM + 64) * TLP * 2, s, a2);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// UNet operand preparation: one workgroup = 32 tokens x all C (<= 192) channels of one sample.  The GroupNorm
-// coefficients come from the producer's Welford partials exactly as in the GEMM kernels (gemm_common.h), the tile is
-// read with coalesced 128-byte rows, transformed once, and written token-major (C bf16 per token, contiguous).
+// GroupNorm coefficients (a, b) per (sample, channel) from the producer's Welford partials, once per tensor: the same
+// combination code as inside the GEMM kernels (gemm_common.h), one workgroup per sample, 48 channels per wave.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prep_kernel(const PrepArgs a) {
+__global__ __launch_bounds__(256) void gn_coef_kernel(const float* __restrict__ part, long long part_bs, int cpg, int nparts, int T, float eps,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ coef_out,
+                                                      long long coef_bs) {
     __shared__ float coef[2 * 192];
     __shared__ float gns[4 * GN_SCRATCH];
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, b = blockIdx.x;
+    const GnP gp = {cpg, nparts, T, eps, gamma, beta};
+    const rsrc_t rp = make_rsrc(part + (long long)b * part_bs, 192u * (unsigned)nparts * 8u);
+    GnLoads gl;
+    gn_issue(gp, rp, w * 48, 48, l, gl);
+    gn_finish(gp, rp, w * 48, 48, l, gl, gns + w * GN_SCRATCH, coef);
+    __syncthreads();
+    for (int i = tid; i < 2 * 192; i += 256) coef_out[(long long)b * coef_bs + i] = coef[i];
+}
+void launch_gn_coef(const float* part, long long part_bs, int cpg, int nparts, int T, float eps, const float* gamma, const float* beta,
+                    float* coef_out, long long coef_bs, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(gn_coef_kernel, dim3(batch), dim3(256), 0, s, part, part_bs, cpg, nparts, T, eps, gamma, beta, coef_out, coef_bs);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// UNet operand preparation: one workgroup = 32 tokens x 192 channels of one sample.  The tile is read with six 16-byte
+// loads per thread (all in flight at once), transformed once (GroupNorm affine from the precomputed coefficients, SiLU,
+// LayerNorm over channels), transposed through LDS and written token-major in bf16 with 16-byte stores (a token's 384
+// bytes are contiguous).  HBM-bound by construction: 24.6 KB in, 12.3 KB out per workgroup.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_kernel(const PrepArgs a) {
     __shared__ float tile[192][33];
     __shared__ float lnp[8][32][2];
     __shared__ float lnst[32][2];
-    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x;
     const int t0 = blockIdx.x * 32, b = blockIdx.y;
-    const int C = a.C, T = a.T;
+    const int T = a.T;
     const bool gn = a.mode <= 1, ln = a.mode == 1 || a.mode == 2;
-    if (gn) {   // wave w finalises channels [48 w, 48 w + 48)
-        const GnP gp = {a.gn_cpg, a.gn_nparts, T, a.gn_eps, a.gn_gamma, a.gn_beta};
-        const rsrc_t rp = make_rsrc(a.gn_part + (long long)b * a.gn_part_bs, (unsigned)C * (unsigned)a.gn_nparts * 8u);
-        GnLoads gl;
-        gn_issue(gp, rp, w * 48, 48, l, gl);
-        gn_finish(gp, rp, w * 48, 48, l, gl, gns + w * GN_SCRATCH, coef);
-    }
-    __syncthreads();
     const float* xb = a.x + (long long)b * a.x_bs;
-    {   // rows: 8 per pass (tid >> 5), 32 tokens per row
-        const int tx = tid & 31;
-        for (int c = tid >> 5; c < C; c += 8) {
-            float v = (t0 + tx < T) ? xb[(long long)c * a.pitch + t0 + tx] : 0.f;
-            tile[c][tx] = v;
+    const float* cf = gn ? a.coef + (long long)b * a.coef_bs : nullptr;
+    // ---- load + per-channel transform -> LDS [channel][token]
+    float4 v[6];
+    float2 cc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 3, q = idx & 7;
+        v[i] = (t0 + 4 * q < a.pitch) ? *reinterpret_cast<const float4*>(xb + (long long)row * a.pitch + t0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        cc[i] = gn ? *reinterpret_cast<const float2*>(cf + 2 * row) : make_float2(1.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 3, q = idx & 7;
+        const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float x = (t0 + 4 * q + k < T) ? e[k] : 0.f;
+            if (a.mode != 2) {   // mode 2 keeps the raw value in LDS (it is also written out as is); LayerNorm is applied at the end
+                if (gn) x = fmaf(x, cc[i].x, cc[i].y);
+                if (a.mode == 0) x = silu_f(x);
+            }
+            tile[row][4 * q + k] = x;
         }
     }
     __syncthreads();
-    const int tt = tid & 31, part = tid >> 5;   // 8 parts x 24 channels
+    // ---- LayerNorm statistics per token (modes 1, 2)
     float mu = 0.f, rs = 1.f;
     if (ln) {
+        const int tt = tid & 31, part = tid >> 5;   // 8 parts x 24 channels
+        const float ref = tile[0][tt];
         float s1 = 0.f, s2 = 0.f;
-        const float ref = gn ? fmaf(tile[0][tt], coef[0], coef[1]) : tile[0][tt];
+#pragma unroll
         for (int i = 0; i < 24; ++i) {
-            const int c = part * 24 + i;
-            float v = tile[c][tt];
-            if (gn) v = fmaf(v, coef[2 * c], coef[2 * c + 1]);
-            const float d = v - ref;
+            const float d = tile[part * 24 + i][tt] - ref;
             s1 += d;
             s2 = fmaf(d, d, s2);
         }
@@ -291,42 +335,53 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs a) {
         __syncthreads();
         if (tid < 32) {
             float S1 = 0.f, S2 = 0.f;
+#pragma unroll
             for (int p = 0; p < 8; ++p) { S1 += lnp[p][tid][0]; S2 += lnp[p][tid][1]; }
-            const float md = S1 / (float)C;
-            const float var = fmaxf(S2 / (float)C - md * md, 0.f);
-            const float r0 = gn ? fmaf(tile[0][tid], coef[0], coef[1]) : tile[0][tid];
-            lnst[tid][0] = r0 + md;
+            const float md = S1 * (1.0f / 192.0f);
+            const float var = fmaxf(S2 * (1.0f / 192.0f) - md * md, 0.f);
+            lnst[tid][0] = tile[0][tid] + md;
             lnst[tid][1] = 1.0f / sqrtf(var + 1e-5f);
         }
         __syncthreads();
-        mu = lnst[tt][0];
-        rs = lnst[tt][1];
     }
-    // write: thread (token tt, part): 24 consecutive channels = 48 bytes
+    // ---- write token-major: thread -> (token tid >> 3, 24 channels starting at 24 (tid & 7)) = 48 contiguous bytes
+    const int tt = tid >> 3, part = tid & 7;
     const int t = t0 + tt;
+    if (ln) { mu = lnst[tt][0]; rs = lnst[tt][1]; }
     const int row_off = a.mode == 0 ? 1 : 0;   // conv operand: row 0 is the left padding
-    __bf16* d = reinterpret_cast<__bf16*>(a.dst) + (long long)b * a.dst_bs + (long long)(t + row_off) * a.ldd + a.coff + part * 24;
-    __bf16* d2 = a.dst2 ? reinterpret_cast<__bf16*>(a.dst2) + (long long)b * a.dst2_bs + (long long)t * a.ldd2 + a.coff2 + part * 24 : nullptr;
     const bool tv = t < T;
     if (tv || (a.mode == 0 && t == T)) {   // the conv operand's right padding row (token T) is written as zeros
+        __attribute__((aligned(16))) __bf16 o[24];
+        __attribute__((aligned(16))) __bf16 r[24];
+#pragma unroll
         for (int i = 0; i < 24; ++i) {
             const int c = part * 24 + i;
             const float raw = tile[c][tt];
-            float v = raw;
-            if (gn) v = fmaf(v, coef[2 * c], coef[2 * c + 1]);
-            if (a.mode == 0) v = silu_f(v);
-            if (ln) v = fmaf((v - mu) * rs, a.ln_gamma[c], a.ln_beta[c]);
-            d[i] = (__bf16)(tv ? v : 0.f);
-            if (d2 && tv) d2[i] = (__bf16)raw;
+            float x = raw;
+            if (ln) x = fmaf((x - mu) * rs, a.ln_gamma[c], a.ln_beta[c]);
+            o[i] = (__bf16)(tv ? x : 0.f);
+            r[i] = (__bf16)raw;
+        }
+        u32x4* d = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.dst) + (long long)b * a.dst_bs + (long long)(t + row_off) * a.ldd + a.coff + part * 24);
+        const u32x4* os = reinterpret_cast<const u32x4*>(o);
+        d[0] = os[0]; d[1] = os[1]; d[2] = os[2];
+        if (a.dst2 && tv) {
+            u32x4* d2 = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.dst2) + (long long)b * a.dst2_bs + (long long)t * a.ldd2 + a.coff2 + part * 24);
+            const u32x4* rs_ = reinterpret_cast<const u32x4*>(r);
+            d2[0] = rs_[0]; d2[1] = rs_[1]; d2[2] = rs_[2];
         }
     }
     if (a.mode == 0 && t0 == 0 && tt == 0) {   // left padding row
-        __bf16* z = reinterpret_cast<__bf16*>(a.dst) + (long long)b * a.dst_bs + a.coff + part * 24;
-        for (int i = 0; i < 24; ++i) z[i] = (__bf16)0.f;
+        u32x4* z = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.dst) + (long long)b * a.dst_bs + a.coff + part * 24);
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        z[0] = zero; z[1] = zero; z[2] = zero;
     }
 }
 void launch_prep(const PrepArgs& a, int batch, hipStream_t s) {
-    if (a.C != 192 || a.T < 1) { fprintf(stderr, "said: prep kernel is instantiated for 192 channels (got %d)\n", a.C); abort(); }
+    if (a.C != 192 || a.T < 1 || a.ldd % 8 || a.coff % 8 || a.dst_bs % 8 || (a.dst2 && (a.ldd2 % 8 || a.coff2 % 8 || a.dst2_bs % 8)) || a.pitch % 4) {
+        fprintf(stderr, "said: prep kernel: unsupported shape (C=%d ldd=%d coff=%d)\n", a.C, a.ldd, a.coff);
+        abort();
+    }
     dim3 grid(a.T / 32 + 1, batch);   // one tile past ceil(T / 32) when T % 32 == 0: the conv operand's right padding row
     hipLaunchKernelGGL(prep_kernel, grid, dim3(256), 0, s, a);
 }
