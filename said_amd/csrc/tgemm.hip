@@ -53,8 +53,11 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
     const int nk = a.K / TBK;
     const int nk1 = (a.a2 ? a.K1 : a.K) / TBK;   // K tiles served by the first A segment
 
-    // global -> register staging: chunk c of a tile: row c >> 3, k piece c & 7 (16 bytes)
-    u32x4 ra[4], rw[WCH];
+    // global -> register staging: chunk c of a tile: row c >> 3, k piece c & 7 (16 bytes).  TWO register sets: the tile two
+    // steps ahead is requested while the current one multiplies, so every load has a whole k-step (plus the other
+    // workgroup of the CU) to arrive — one set gave each load only the ~500 clocks of one step's MFMAs.
+    struct RegTile { u32x4 a[4]; u32x4 w[WCH]; };
+    RegTile S0, S1;
     long long aoff[4], a2off[4], woff[WCH];
     int loff[4], lwoff[WCH];
 #pragma unroll
@@ -71,22 +74,22 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
         woff[i] = (long long)(n0 + row) * a.K + kp * 8;
         lwoff[i] = row * TLP + kp * 8;
     }
-    auto gload_tile = [&](int kt) {
+    auto gload_tile = [&](RegTile& R, int kt) {
         const bool first = kt < nk1;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            ra[i] = first ? *reinterpret_cast<const u32x4*>(A + aoff[i] + (long long)kt * TBK)
-                          : *reinterpret_cast<const u32x4*>(A2 + a2off[i] + (long long)(kt - nk1) * TBK);
+            R.a[i] = first ? *reinterpret_cast<const u32x4*>(A + aoff[i] + (long long)kt * TBK)
+                           : *reinterpret_cast<const u32x4*>(A2 + a2off[i] + (long long)(kt - nk1) * TBK);
 #pragma unroll
-        for (int i = 0; i < WCH; ++i) rw[i] = *reinterpret_cast<const u32x4*>(W + woff[i] + (long long)kt * TBK);
+        for (int i = 0; i < WCH; ++i) R.w[i] = *reinterpret_cast<const u32x4*>(W + woff[i] + (long long)kt * TBK);
     };
-    auto lds_store = [&](int buf) {
+    auto lds_store = [&](const RegTile& R, int buf) {
         unsigned short* pa = lds + buf * BUF;
         unsigned short* pw = pa + TBM * TLP;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(pa + loff[i]) = ra[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(pa + loff[i]) = R.a[i];
 #pragma unroll
-        for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(pw + lwoff[i]) = rw[i];
+        for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(pw + lwoff[i]) = R.w[i];
     };
 
     f32x16 acc[2][NJ];
@@ -97,13 +100,9 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload_tile(0);
-    lds_store(0);
-    __syncthreads();
     const int frow = l & 31, fk = 8 * (l >> 5);
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload_tile(kt + 1);
-        const unsigned short* pa = lds + (kt & 1) * BUF;
+    auto compute = [&](int buf) {
+        const unsigned short* pa = lds + buf * BUF;
         const unsigned short* pw = pa + TBM * TLP;
 #pragma unroll
         for (int ks = 0; ks < TBK / 16; ++ks) {
@@ -117,7 +116,23 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lds_store((kt + 1) & 1);
+    };
+
+    gload_tile(S0, 0);
+    if (nk > 1) gload_tile(S1, 1);
+    lds_store(S0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even step: tile kt multiplies from buffer 0, tile kt + 1 sits in S1, tile kt + 2 is requested into S0
+        if (kt + 2 < nk) gload_tile(S0, kt + 2);
+        compute(0);
+        if (kt + 1 < nk) lds_store(S1, 1);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd step: tile kt + 1 from buffer 1, tile kt + 2 sits in S0, tile kt + 3 is requested into S1
+        if (kt + 3 < nk) gload_tile(S1, kt + 3);
+        compute(1);
+        if (kt + 2 < nk) lds_store(S0, 0);
         __syncthreads();
     }
 
