@@ -46,6 +46,9 @@ def parse():
     p.add_argument("--eta", type=float, default=0.0)
     p.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                    help="f32 (BASELINE configs[1]) or bf16 multiplies with fp32 accumulation (configs[2]: --batch 32 --num_steps 50 --dtype bf16)")
+    p.add_argument("--edit", action="store_true",
+                   help="editing mode (BASELINE configs[4]: --seconds 30 --num_steps 100 --edit): init_samples + in-betweening mask "
+                        "(middle third regenerated, 4 channels pinned), mask blend with the re-noised init every step")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
     p.add_argument("--cpu_steps", type=int, default=40, help="UNet evaluations in the CPU-baseline sample")
@@ -245,9 +248,18 @@ def run(args):
     proc = model.process_audio(wav).to(dev)
     lat0 = torch.cat([synth.synth_latents(c, (1, T, 32)) for c in clips]).to(dev)
 
+    edit_kw = {}
+    if args.edit:   # init = sigmoid(randn) * 0.5; mask = 1 on the outer thirds (kept) and on channels 0-3
+        init_samples = (torch.sigmoid(torch.cat([synth.synth_latents(1000 + c, (1, T, 32)) for c in clips])) * 0.5).to(dev)
+        mask = torch.zeros(B, T, 32, device=dev)
+        mask[:, : T // 3] = 1.0
+        mask[:, 2 * T // 3:] = 1.0
+        mask[:, :, :4] = 1.0
+        edit_kw = dict(init_samples=init_samples, mask=mask, edit_noise=lat0)
+
     def path_fn(_clips):
         return model.inference(proc, num_inference_steps=args.num_steps, guidance_scale=args.guidance_scale, eta=args.eta,
-                               init_latents=lat0).result
+                               init_latents=lat0, **edit_kw).result
 
     r = shard.timed_sharded_passes(path_fn, rank=rank, world=world, clips_per_rank=B, steps=args.steps, warmup=args.warmup,
                                    dist=dist, device=dev)
@@ -266,7 +278,7 @@ def run(args):
             "realtime_factor": round(frames / elapsed / 60.0, 2),
             "config": {"workload": f"{B} clip(s)/GPU x {args.seconds:g} s synthetic audio (T={T} frames), audio encode + "
                                    f"{args.num_steps} DDIM steps (eta={args.eta:g}), guidance_scale={args.guidance_scale:g} "
-                                   f"(UNet batch {Be}), " + ("fp32; BASELINE.json configs[1]" if args.dtype == "f32" else
+                                   f"(UNet batch {Be}), " + ("editing mode: init_samples + in-betweening mask; " if args.edit else "") + ("fp32; BASELINE.json configs[1]" if args.dtype == "f32" else
                                                               "bf16 mode (UNet: bf16 multiplies, fp32 accumulation and storage; audio encoder: bf16 GEMM operands and activations, fp32 residual stream); BASELINE.json configs[2] shape"),
                        "batch_per_gpu": B, "frames": T, "num_steps": args.num_steps, "guidance_scale": args.guidance_scale,
                        "eta": args.eta, "parallelism": f"clips sharded over {world} GPU(s), one RCCL all-gather" if world > 1 else "single GPU",
@@ -280,7 +292,7 @@ def run(args):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
             model.inference(proc, num_inference_steps=args.num_steps, guidance_scale=args.guidance_scale, eta=args.eta,
-                            init_latents=lat0, audio_embedding=emb)
+                            init_latents=lat0, audio_embedding=emb, **edit_kw)
             ev1.record()
             torch.cuda.synchronize()
             step_ms = ev0.elapsed_time(ev1) / args.num_steps

@@ -68,6 +68,9 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const f
 #pragma unroll
     for (int q = 0; q < NQ; ++q) qf[q] = *reinterpret_cast<const f32x4a*>(qb + (long long)(i0 + lt) * D + 4 * q);
 
+    s16x4a qh[NQ];   // bf16 mode: the query fragments are converted once, not once per key tile
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) qh[q] = pk_bf16(qf[q][0], qf[q][1], qf[q][2], qf[q][3]);
     float m = -1.0e30f, lsum = 0.f;
     f32x16 o[ND];
 #pragma unroll
@@ -98,12 +101,46 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const f
         for (int dp = 0; dp < ND * 16; ++dp) {
             if constexpr (BF) {
                 if ((dp & 3) == 0)
-                    s = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(pk_bf16(kf[dp >> 2][0], kf[dp >> 2][1], kf[dp >> 2][2], kf[dp >> 2][3]),
-                                                                 pk_bf16(qf[dp >> 2][0], qf[dp >> 2][1], qf[dp >> 2][2], qf[dp >> 2][3]), s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(pk_bf16(kf[dp >> 2][0], kf[dp >> 2][1], kf[dp >> 2][2], kf[dp >> 2][3]), qh[dp >> 2], s, 0, 0, 0);
             } else {
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[dp >> 2][dp & 3], qf[dp >> 2][dp & 3], s, 0, 0, 0);
             }
         }
+        if constexpr (BF) {
+            // bf16 mode: the VALU work per score bounds this kernel once the products are 8x cheaper, so it is trimmed: the
+            // running maximum is kept in RAW score units and the scale is folded into the exponent (one fma + one exp2 per
+            // score), keys past T are masked only in the tile that contains T, and the accumulator rescale is skipped while
+            // no lane's maximum moved.  (The fp32 path below keeps the reference's op order: scale, subtract, exp.)
+            const float c2 = a.scale * 1.4426950408889634f;
+            if (j0 + 32 > T) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    s[r] = (j < T) ? s[r] : -1.0e30f;
+                }
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);   // v_exp_f32: arguments are <= 0, underflow to 0 is the wanted result
+            m = mn;
+            const float off = -mn * c2;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, off));
+                ps += s[r];
+            }
+            lsum = lsum * alpha + ps;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+                for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[nd][r] *= alpha;
+            }
+        } else {
         float mx = -1.0e30f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -126,6 +163,7 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const f
         for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[nd][r] *= alpha;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -183,7 +221,7 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const f
     float L = 0.f;
 #pragma unroll
     for (int w2 = 0; w2 < KS; ++w2) {
-        f[w2] = __expf(ml[(w2 * 2) * 32 + lt] - M);
+        f[w2] = BF ? __builtin_amdgcn_exp2f((ml[(w2 * 2) * 32 + lt] - M) * (a.scale * 1.4426950408889634f)) : __expf(ml[(w2 * 2) * 32 + lt] - M);   // BF: raw-score maxima
         L += ml[(w2 * 2 + 1) * 32 + lt] * f[w2];
     }
     const float invL = 1.0f / L;

@@ -546,10 +546,12 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
         {   // in_layers: GN -> SiLU -> conv3 + emb term   (openaimodel.py:205-225)
             PrepArgs p = mkprep(g, in0.p, 0, c->uPA, T2 * rw.cin, rw.cin, 0);
             prep_gn(c, p, g, in0.st, cpg, 1e-5f, rw.g1, rw.b1, nb, 0, s);
+            if (rw.has_skip) { p.dst2 = c->uPB; p.dst2_bs = (long long)g.T * 2 * MC; p.ldd2 = 2 * MC; p.coff2 = 0; }   // raw copy for the 1x1 skip conv
             do_prep(c, p, nb, s);
             if (in1) {
                 PrepArgs q = mkprep(g, in1->p, 0, c->uPA, T2 * rw.cin, rw.cin, MC);
                 prep_gn(c, q, g, in1->st, cpg, 1e-5f, rw.g1 + MC, rw.b1 + MC, nb, 1, s);
+                if (rw.has_skip) { q.dst2 = c->uPB; q.dst2_bs = (long long)g.T * 2 * MC; q.ldd2 = 2 * MC; q.coff2 = MC; }
                 do_prep(c, q, nb, s);
             }
             TGemmArgs t = mktg(g, c->uPA, T2 * rw.cin, rw.cin, rw.t_conv1, MC, 3 * rw.cin);
@@ -564,8 +566,7 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
             do_prep(c, p, nb, s);
             TGemmArgs t = mktg(g, c->uPA, T2 * MC, MC, rw.t_conv2, MC, 3 * MC);
             if (rw.has_skip) {   // 1x1 conv over the concatenated raw input as a second K segment
-                do_prep(c, mkprep(g, in0.p, 3, c->uPB, (long long)g.T * 2 * MC, 2 * MC, 0), nb, s);
-                do_prep(c, mkprep(g, in1->p, 3, c->uPB, (long long)g.T * 2 * MC, 2 * MC, MC), nb, s);
+                // (the raw copies of the two inputs were written into uPB by the in_layers operand preparation above)
                 t.a2 = c->uPB; t.a2_bs = (long long)g.T * 2 * MC; t.lda2 = 2 * MC; t.K1 = 3 * MC; t.K = 5 * MC;
                 t.bias = rw.bias2;
             } else {

@@ -77,9 +77,10 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
     auto gload_tile = [&](RegTile& R, int kt) {
         const bool first = kt < nk1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            R.a[i] = first ? *reinterpret_cast<const u32x4*>(A + aoff[i] + (long long)kt * TBK)
-                           : *reinterpret_cast<const u32x4*>(A2 + a2off[i] + (long long)(kt - nk1) * TBK);
+        for (int i = 0; i < 4; ++i) {
+            const unsigned short* p = first ? A + aoff[i] + (long long)kt * TBK : A2 + a2off[i] + (long long)(kt - nk1) * TBK;
+            R.a[i] = *reinterpret_cast<const u32x4*>(p);
+        }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) R.w[i] = *reinterpret_cast<const u32x4*>(W + woff[i] + (long long)kt * TBK);
     };
@@ -118,21 +119,28 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
         }
     };
 
+    // Every load and LDS store of the loop is UNCONDITIONAL (steps past the end re-request the last tile and park it in the
+    // buffer nobody reads any more): with memory operations inside run-time branches the compiler's wait-count analysis
+    // gives up at the joins and drains every outstanding load (s_waitcnt vmcnt(0)) before it issues the next tile's — which
+    // is exactly the overlap the second register set exists for.
     gload_tile(S0, 0);
-    if (nk > 1) gload_tile(S1, 1);
+    gload_tile(S1, min(1, nk - 1));
     lds_store(S0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
         // even step: tile kt multiplies from buffer 0, tile kt + 1 sits in S1, tile kt + 2 is requested into S0
-        if (kt + 2 < nk) gload_tile(S0, kt + 2);
-        compute(0);
-        if (kt + 1 < nk) lds_store(S1, 1);
+        gload_tile(S0, min(kt + 2, nk - 1));
+        __builtin_amdgcn_sched_barrier(0);   // keep the order request -> multiply -> park: the scheduler otherwise hoists the
+        compute(0);                          // LDS stores (and the wait for their loads) above the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        lds_store(S1, 1);
         __syncthreads();
-        if (kt + 1 >= nk) break;
         // odd step: tile kt + 1 from buffer 1, tile kt + 2 sits in S0, tile kt + 3 is requested into S1
-        if (kt + 3 < nk) gload_tile(S1, kt + 3);
-        compute(1);
-        if (kt + 2 < nk) lds_store(S0, 0);
+        gload_tile(S1, min(kt + 3, nk - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_store(S0, 0);
         __syncthreads();
     }
 
@@ -300,7 +308,8 @@ void launch_gn_coef(const float* part, long long part_bs, int cpg, int nparts, i
 // bytes are contiguous).  HBM-bound by construction: 24.6 KB in, 12.3 KB out per workgroup.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs a) {
-    __shared__ float tile[192][33];
+    __shared__ float tile[192][33];     // RAW values [channel][token]
+    __shared__ float coefS[192][2];     // GroupNorm (a, b) per channel (modes 0, 1)
     __shared__ float lnp[8][32][2];
     __shared__ float lnst[32][2];
     const int tid = threadIdx.x;
@@ -308,40 +317,37 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs a) {
     const int T = a.T;
     const bool gn = a.mode <= 1, ln = a.mode == 1 || a.mode == 2;
     const float* xb = a.x + (long long)b * a.x_bs;
-    const float* cf = gn ? a.coef + (long long)b * a.coef_bs : nullptr;
-    // ---- load + per-channel transform -> LDS [channel][token]
+    // ---- load the raw tile -> LDS [channel][token]; GroupNorm coefficients -> LDS
     float4 v[6];
-    float2 cc[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int idx = tid + 256 * i, row = idx >> 3, q = idx & 7;
         v[i] = (t0 + 4 * q < a.pitch) ? *reinterpret_cast<const float4*>(xb + (long long)row * a.pitch + t0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        cc[i] = gn ? *reinterpret_cast<const float2*>(cf + 2 * row) : make_float2(1.f, 0.f);
+    }
+    if (gn) {
+        const float* cf = a.coef + (long long)b * a.coef_bs;
+        for (int i = tid; i < 2 * 192; i += 256) (&coefS[0][0])[i] = cf[i];
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int idx = tid + 256 * i, row = idx >> 3, q = idx & 7;
         const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float x = (t0 + 4 * q + k < T) ? e[k] : 0.f;
-            if (a.mode != 2) {   // mode 2 keeps the raw value in LDS (it is also written out as is); LayerNorm is applied at the end
-                if (gn) x = fmaf(x, cc[i].x, cc[i].y);
-                if (a.mode == 0) x = silu_f(x);
-            }
-            tile[row][4 * q + k] = x;
-        }
+        for (int k = 0; k < 4; ++k) tile[row][4 * q + k] = (t0 + 4 * q + k < T) ? e[k] : 0.f;
     }
     __syncthreads();
-    // ---- LayerNorm statistics per token (modes 1, 2)
+    // ---- LayerNorm statistics per token (modes 1, 2), over the GroupNorm'ed values in mode 1
     float mu = 0.f, rs = 1.f;
     if (ln) {
         const int tt = tid & 31, part = tid >> 5;   // 8 parts x 24 channels
-        const float ref = tile[0][tt];
+        const float ref = gn ? fmaf(tile[0][tt], coefS[0][0], coefS[0][1]) : tile[0][tt];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 24; ++i) {
-            const float d = tile[part * 24 + i][tt] - ref;
+            const int c = part * 24 + i;
+            float x = tile[c][tt];
+            if (gn) x = fmaf(x, coefS[c][0], coefS[c][1]);
+            const float d = x - ref;
             s1 += d;
             s2 = fmaf(d, d, s2);
         }
@@ -354,12 +360,13 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs a) {
             for (int p = 0; p < 8; ++p) { S1 += lnp[p][tid][0]; S2 += lnp[p][tid][1]; }
             const float md = S1 * (1.0f / 192.0f);
             const float var = fmaxf(S2 * (1.0f / 192.0f) - md * md, 0.f);
-            lnst[tid][0] = tile[0][tid] + md;
+            const float r0 = gn ? fmaf(tile[0][tid], coefS[0][0], coefS[0][1]) : tile[0][tid];
+            lnst[tid][0] = r0 + md;
             lnst[tid][1] = 1.0f / sqrtf(var + 1e-5f);
         }
         __syncthreads();
     }
-    // ---- write token-major: thread -> (token tid >> 3, 24 channels starting at 24 (tid & 7)) = 48 contiguous bytes
+    // ---- transform + write token-major: thread -> (token tid >> 3, 24 channels starting at 24 (tid & 7)) = 48 contiguous bytes
     const int tt = tid >> 3, part = tid & 7;
     const int t = t0 + tt;
     if (ln) { mu = lnst[tt][0]; rs = lnst[tt][1]; }
@@ -373,6 +380,8 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs a) {
             const int c = part * 24 + i;
             const float raw = tile[c][tt];
             float x = raw;
+            if (gn) x = fmaf(x, coefS[c][0], coefS[c][1]);
+            if (a.mode == 0) x = silu_f(x);
             if (ln) x = fmaf((x - mu) * rs, a.ln_gamma[c], a.ln_beta[c]);
             o[i] = (__bf16)(tv ? x : 0.f);
             r[i] = (__bf16)raw;
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs a) {
         u32x4* d = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.dst) + (long long)b * a.dst_bs + (long long)(t + row_off) * a.ldd + a.coff + part * 24);
         const u32x4* os = reinterpret_cast<const u32x4*>(o);
         d[0] = os[0]; d[1] = os[1]; d[2] = os[2];
-        if (a.dst2 && tv) {
+        if (a.dst2 && tv) {   // raw copy (1x1 skip conv over the ResBlock input; x2 for the folded proj_out)
             u32x4* d2 = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.dst2) + (long long)b * a.dst2_bs + (long long)t * a.ldd2 + a.coff2 + part * 24);
             const u32x4* rs_ = reinterpret_cast<const u32x4*>(r);
             d2[0] = rs_[0]; d2[1] = rs_[1]; d2[2] = rs_[2];
