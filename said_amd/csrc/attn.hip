@@ -50,15 +50,23 @@ struct AttnView {
 // MFMA m of S^T contracts d = lh * D/2 + 4m + (0..3), i.e. the m-th loaded quad of each lane half; MFMA m of O^T
 // contracts keys j0 + 8m + 4lh + (0..3), i.e. accumulator registers 4m..4m+3 and the m-th V quad.  Scores, softmax
 // statistics and accumulation stay fp32.
-template <int ND, int KS, bool BF>
-__global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const float* pv, float* po, int v_bstride, int o_bstride, int ppitch,
+// QW > 1 (large batches, KS == 1): the workgroup's QW waves take QW CONSECUTIVE query tiles of the same (batch, head), each over
+// all keys, instead of splitting the keys of one query tile.  They walk the same K / V tiles in step, so a tile is fetched
+// from L2 once per workgroup and the other waves hit in the CU's L1: at large batch this kernel is bound by the bytes a CU can
+// keep in flight (every 32-query workgroup re-reads all K and V of its head: 62 B per kFLOP), not by MFMA or VALU work.
+template <int ND, int KS, bool BF, int QW = 1>
+__global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, const float* pv, float* po, int v_bstride, int o_bstride, int ppitch,
                                                        int pT, int pheads, int prows, float pscale, int pb0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AttnView a = {pqk, pv, po, v_bstride, o_bstride, ppitch, pT, pheads, prows, pscale, pb0};
     constexpr int D = 32 * ND, NQ = D / 8;   // NQ dwordx4 per lane and operand row
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z + a.b0;
+    static_assert(QW == 1 || KS == 1, "query-tile waves do not split keys");
+    const int w_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = QW > 1 ? 0 : w_all;               // key-split index
+    const int wq = QW > 1 ? w_all : 0;              // query tile of this wave within the workgroup
+    float* const sm_w = smem + wq * (KS * 64 + KS * ND * 16 * 64);   // private merge scratch per query-tile wave
+    const int i0 = (blockIdx.x * QW + wq) * 32, h = blockIdx.y, b = blockIdx.z + a.b0;
     const int T = a.T, pitch = a.pitch, H = a.heads, rows = a.rows;
     const float* qb = a.qk + (((long long)b * 2 * H + h) * rows) * D + lh * (D / 2);
     const float* kb = a.qk + (((long long)b * 2 * H + H + h) * rows) * D + lh * (D / 2);
@@ -66,7 +74,7 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const f
 
     f32x4a qf[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) qf[q] = *reinterpret_cast<const f32x4a*>(qb + (long long)(i0 + lt) * D + 4 * q);
+    for (int q = 0; q < NQ; ++q) qf[q] = *reinterpret_cast<const f32x4a*>(qb + (long long)min(i0 + lt, rows - 1) * D + 4 * q);
 
     s16x4a qh[NQ];   // bf16 mode: the query fragments are converted once, not once per key tile
 #pragma unroll
@@ -203,8 +211,8 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const f
     lsum += __shfl_xor(lsum, 32);
 
     // ---- merge the KS partial states ----
-    float* ml = smem;                 // [KS][2][32]
-    float* ob = smem + KS * 64;       // [KS][ND][16][64]
+    float* ml = sm_w;                 // [KS][2][32]
+    float* ob = sm_w + KS * 64;       // [KS][ND][16][64]
     if (lh == 0) {
         ml[(w * 2 + 0) * 32 + lt] = m;
         ml[(w * 2 + 1) * 32 + lt] = lsum;
@@ -241,25 +249,30 @@ __global__ __launch_bounds__(64 * KS) void attn_kernel(const float* pqk, const f
     }
 }
 
-template <int ND, int KS, bool BF>
+template <int ND, int KS, bool BF, int QW = 1>
 static void launch_attn_one(const AttnArgs& a, int batch, hipStream_t s) {
-    const int smem = (KS * 64 + KS * ND * 16 * 64) * (int)sizeof(float);
-    dim3 grid((a.T + 31) / 32, a.heads, batch);
+    const int smem = QW * (KS * 64 + KS * ND * 16 * 64) * (int)sizeof(float);
+    dim3 grid(((a.T + 31) / 32 + QW - 1) / QW, a.heads, batch);
     if (a.v_bstride > 0x7fffffffLL || a.o_bstride > 0x7fffffffLL) { fprintf(stderr, "said: attention batch stride exceeds 31 bits\n"); abort(); }
-    hipLaunchKernelGGL((attn_kernel<ND, KS, BF>), grid, dim3(64 * KS), smem, s, a.qk, a.v, a.o, (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T,
+    hipLaunchKernelGGL((attn_kernel<ND, KS, BF, QW>), grid, dim3(64 * KS * QW), smem, s, a.qk, a.v, a.o, (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T,
                        a.heads, a.rows, a.scale, a.b0);
 }
-template <int ND, int KS, bool BF>
+template <int ND, int KS, bool BF, int QW = 1>
 static void configure_attn_one() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<ND, KS, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<ND, KS, BF, QW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
 }
 void configure_attn_kernels() {
     configure_attn_one<1, 8, false>(); configure_attn_one<1, 8, true>(); configure_attn_one<1, 4, false>(); configure_attn_one<1, 4, true>(); configure_attn_one<1, 1, false>(); configure_attn_one<1, 1, true>();
+    configure_attn_one<1, 1, false, 4>(); configure_attn_one<1, 1, true, 4>(); configure_attn_one<2, 1, false, 4>(); configure_attn_one<2, 1, true, 4>();
     configure_attn_one<2, 8, false>(); configure_attn_one<2, 8, true>(); configure_attn_one<2, 4, false>(); configure_attn_one<2, 4, true>(); configure_attn_one<2, 1, false>(); configure_attn_one<2, 1, true>();
 }
 
 void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s, bool bf16) {
+    if (KS == -4) {   // four query tiles per workgroup, no key split (large batches)
+        if (head_dim == 32) return bf16 ? launch_attn_one<1, 1, true, 4>(a, batch, s) : launch_attn_one<1, 1, false, 4>(a, batch, s);
+        if (head_dim == 64) return bf16 ? launch_attn_one<2, 1, true, 4>(a, batch, s) : launch_attn_one<2, 1, false, 4>(a, batch, s);
+    }
     if (head_dim == 32 && KS == 8) return bf16 ? launch_attn_one<1, 8, true>(a, batch, s) : launch_attn_one<1, 8, false>(a, batch, s);
     if (head_dim == 32 && KS == 4) return bf16 ? launch_attn_one<1, 4, true>(a, batch, s) : launch_attn_one<1, 4, false>(a, batch, s);
     if (head_dim == 32 && KS == 1) return bf16 ? launch_attn_one<1, 1, true>(a, batch, s) : launch_attn_one<1, 1, false>(a, batch, s);

@@ -672,7 +672,9 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         static const int attn_ks_env = getenv("SAID_ATTN_KS") ? atoi(getenv("SAID_ATTN_KS")) : 0;   // experiment knob
         // waves per workgroup = ways the key tiles are split: 8 only pays while a wave would otherwise hold a single
         // tile (T <= 256); from there 4 waves with ~5 tiles each merge half as many partial states (B=1: -0.5 % per step)
-        const int attn_ks = (tt1 * HEADS > 8192) ? 1 : ((g.T <= 256 && tt1 * HEADS <= 2048) ? 8 : 4);
+        // large batches: four query tiles per workgroup sharing each K / V tile through the CU's L1 (-4), see attn.hip
+        static const bool no_qw = getenv("SAID_NO_ATTN_QW") != nullptr;
+        const int attn_ks = (!no_qw && tt1 * HEADS >= 2048) ? -4 : ((tt1 * HEADS > 8192) ? 1 : ((g.T <= 256 && tt1 * HEADS <= 2048) ? 8 : 4));
         do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s);
     }
     // small batches: attn1.to_out + norm2 + to_q + banded cross-attention + attn2.to_out as ONE launch (xattn.hip); the
@@ -1844,7 +1846,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     a.qk = ctx->aQK; a.v = ctx->aVT; a.o = ctx->aO;
                     a.v_bstride = hs; a.o_bstride = 2 * hs; a.b0 = 0;
                     a.pitch = Fp; a.T = Fr; a.heads = W2V_HEADS; a.rows = Fp; a.scale = 0.125f;
-                    launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : (tt * W2V_HEADS <= 8192 ? 4 : 1), s, true);
+                    launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : -4, s, true);
                 }
                 launch_cm_to_tm_bf16(ctx->aO, 2 * hs, Fp, ctx->bO, hsT, nb, Fr, W2V_H, s);
                 {   // out_proj + residual, then layer_norm
