@@ -508,6 +508,9 @@ void do_tgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     }
     if (dbg_go(c)) launch_tgemm(a, batch, s);
 }
+// per-sample row pitch of the token-major operands: a multiple of 32 that holds the T tokens plus the two Conv1d padding rows, so
+// that all samples form ONE row axis for the 256-row GEMM tiles (tgemm.h: seg_rows) and 32-row MFMA tiles never straddle samples
+inline int tg_rows(const UGeo& g) { return rup(g.T + 2, 32); }
 PrepArgs mkprep(const UGeo& g, const float* x, int mode, void* dst, long long dst_bs, int ldd, int coff) {
     PrepArgs p;
     memset(&p, 0, sizeof p);
@@ -524,10 +527,10 @@ void prep_gn(said_ctx* c, PrepArgs& p, const UGeo& g, const float* part, int cpg
     if (dbg_go(c)) launch_gn_coef(part, g.sts, cpg, g.np, g.T, eps, gamma, beta, co, 2 * MC, nb, s);
     p.coef = co; p.coef_bs = 2 * MC;
 }
-TGemmArgs mktg(const UGeo& g, const void* a, long long a_bs, int lda, const void* w, int N, int K) {
+TGemmArgs mktg(const UGeo& g, const void* a, int lda, const void* w, int N, int K) {
     TGemmArgs t;
     memset(&t, 0, sizeof t);
-    t.a = a; t.a_bs = a_bs; t.lda = lda; t.w = w; t.M = g.T; t.N = N; t.K = K;
+    t.a = a; t.a_bs = 0; t.lda = lda; t.w = w; t.M = g.T; t.N = N; t.K = K; t.seg_rows = tg_rows(g);
     return t;
 }
 void tg_cm_out(TGemmArgs& t, const UGeo& g, const ActBuf& out) {
@@ -542,19 +545,19 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
     const int nb = shared ? g.Bc : g.Be;
     const long long tt = (long long)nb * ((g.T + 31) / 32);
     if (use_tg(c, g, nb)) {
-        const long long T2 = g.T + 2;
+        const long long T2 = tg_rows(g);
         {   // in_layers: GN -> SiLU -> conv3 + emb term   (openaimodel.py:205-225)
             PrepArgs p = mkprep(g, in0.p, 0, c->uPA, T2 * rw.cin, rw.cin, 0);
             prep_gn(c, p, g, in0.st, cpg, 1e-5f, rw.g1, rw.b1, nb, 0, s);
-            if (rw.has_skip) { p.dst2 = c->uPB; p.dst2_bs = (long long)g.T * 2 * MC; p.ldd2 = 2 * MC; p.coff2 = 0; }   // raw copy for the 1x1 skip conv
+            if (rw.has_skip) { p.dst2 = c->uPB; p.dst2_bs = T2 * 2 * MC; p.ldd2 = 2 * MC; p.coff2 = 0; }   // raw copy for the 1x1 skip conv
             do_prep(c, p, nb, s);
             if (in1) {
                 PrepArgs q = mkprep(g, in1->p, 0, c->uPA, T2 * rw.cin, rw.cin, MC);
                 prep_gn(c, q, g, in1->st, cpg, 1e-5f, rw.g1 + MC, rw.b1 + MC, nb, 1, s);
-                if (rw.has_skip) { q.dst2 = c->uPB; q.dst2_bs = (long long)g.T * 2 * MC; q.ldd2 = 2 * MC; q.coff2 = MC; }
+                if (rw.has_skip) { q.dst2 = c->uPB; q.dst2_bs = T2 * 2 * MC; q.ldd2 = 2 * MC; q.coff2 = MC; }
                 do_prep(c, q, nb, s);
             }
-            TGemmArgs t = mktg(g, c->uPA, T2 * rw.cin, rw.cin, rw.t_conv1, MC, 3 * rw.cin);
+            TGemmArgs t = mktg(g, c->uPA, rw.cin, rw.t_conv1, MC, 3 * rw.cin);
             t.bias = rw.conv1.bias;
             t.emb = c->EO + (long long)rb_index * MC * c->maxNp; t.emb_pitch = c->maxNp; t.step_ptr = g.step_ptr; t.emb_b_stride = g.emb_b_stride;
             tg_cm_out(t, g, c->M);
@@ -564,10 +567,10 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
             PrepArgs p = mkprep(g, c->M.p, 0, c->uPA, T2 * MC, MC, 0);
             prep_gn(c, p, g, c->M.st, 6, 1e-5f, rw.g2, rw.b2, nb, 0, s);
             do_prep(c, p, nb, s);
-            TGemmArgs t = mktg(g, c->uPA, T2 * MC, MC, rw.t_conv2, MC, 3 * MC);
+            TGemmArgs t = mktg(g, c->uPA, MC, rw.t_conv2, MC, 3 * MC);
             if (rw.has_skip) {   // 1x1 conv over the concatenated raw input as a second K segment
                 // (the raw copies of the two inputs were written into uPB by the in_layers operand preparation above)
-                t.a2 = c->uPB; t.a2_bs = (long long)g.T * 2 * MC; t.lda2 = 2 * MC; t.K1 = 3 * MC; t.K = 5 * MC;
+                t.a2 = c->uPB; t.a2_bs = 0; t.lda2 = 2 * MC; t.K1 = 3 * MC; t.K = 5 * MC;
                 t.bias = rw.bias2;
             } else {
                 t.bias = rw.conv2.bias;
@@ -637,11 +640,11 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     const long long obs = 2LL * MC * g.Tp;   // batch stride of O (shared with QK so attention uses one stride)
     const bool tg = use_tg(c, g, n1);
     if (tg) {   // q, k, v on the bf16 token-major GEMM: operand = LayerNorm(GroupNorm(x)) prepared once
-        PrepArgs p = mkprep(g, in.p, 1, c->uPL, (long long)g.T * MC, MC, 0);
+        PrepArgs p = mkprep(g, in.p, 1, c->uPL, (long long)tg_rows(g) * MC, MC, 0);
         prep_gn(c, p, g, in.st, 6, 1e-6f, sw.gn_g, sw.gn_b, n1, 0, s);
         p.ln_gamma = sw.l1g; p.ln_beta = sw.l1b;
         do_prep(c, p, n1, s);
-        TGemmArgs t = mktg(g, c->uPL, (long long)g.T * MC, MC, sw.t_qkv, 3 * MC, MC);
+        TGemmArgs t = mktg(g, c->uPL, MC, sw.t_qkv, 3 * MC, MC);
         t.qk = c->QK; t.vt = c->VT; t.v_bs = (long long)MC * g.Tp; t.qk_n = 2 * MC; t.head_dim = HD; t.rows = vt_rows; t.heads2 = 2 * HEADS; t.v_pitch = g.Tp;
         do_tgemm(c, t, n1, s);
     } else
@@ -746,18 +749,19 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
 geglu:
     if (use_tg(c, g, g.Be)) {
         {   // GEGLU: operand norm3(x2) (and raw x2 for the folded proj_out), value/gate pairs multiplied in the epilogue
-            PrepArgs p = mkprep(g, c->X2, 2, c->uPL, (long long)g.T * MC, MC, 0);
+            const long long P = tg_rows(g);
+            PrepArgs p = mkprep(g, c->X2, 2, c->uPL, P * MC, MC, 0);
             p.ln_gamma = sw.l3g; p.ln_beta = sw.l3b;
-            p.dst2 = c->uPX; p.dst2_bs = (long long)g.T * MC; p.ldd2 = MC; p.coff2 = 0;
+            p.dst2 = c->uPX; p.dst2_bs = P * MC; p.ldd2 = MC; p.coff2 = 0;
             do_prep(c, p, g.Be, s);
-            TGemmArgs t = mktg(g, c->uPL, (long long)g.T * MC, MC, sw.t_ff1, 2 * FFI, MC);
+            TGemmArgs t = mktg(g, c->uPL, MC, sw.t_ff1, 2 * FFI, MC);
             t.bias = sw.t_ff1_bias; t.geglu = 1;
-            t.yb = c->uPH; t.y_bs = (long long)g.T * FFI; t.ldy = FFI;
+            t.yb = c->uPH; t.y_bs = P * FFI; t.ldy = FFI;
             do_tgemm(c, t, g.Be, s);
         }
         {   // proj_out o ff.net.2 over [h ; x2] + x_in, channel-major result + GroupNorm partials
-            TGemmArgs t = mktg(g, c->uPH, (long long)g.T * FFI, FFI, sw.t_ffproj, MC, FFI + MC);
-            t.a2 = c->uPX; t.a2_bs = (long long)g.T * MC; t.lda2 = MC; t.K1 = FFI;
+            TGemmArgs t = mktg(g, c->uPH, FFI, sw.t_ffproj, MC, FFI + MC);
+            t.a2 = c->uPX; t.a2_bs = 0; t.lda2 = MC; t.K1 = FFI;
             t.bias = sw.ffproj.bias;
             t.res_cm = in.p; t.res_cm_bs = g.hs;
             tg_cm_out(t, g, out);
@@ -1030,8 +1034,8 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     rc |= dalloc(ctx, &ctx->rescale_part, Be * 2 * 64 * 3);
     rc |= dalloc(ctx, &ctx->freqs, MC / 2);
     {   // bf16 operand buffers of the large-batch bf16 path (2 bytes per element; zero-initialised, so padding rows start at 0)
-        const size_t Tm = (size_t)max_frames;
-        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPA), Be * (Tm + 2) * 2 * MC + 4096);
+        const size_t Tm = (size_t)rup(max_frames + 2, 32);   // tg_rows(): per-sample row pitch
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPA), Be * Tm * 2 * MC + 4096);
         rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPB), Be * Tm * 2 * MC + 4096);
         rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPL), Be * Tm * MC + 4096);
         rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPH), Be * Tm * FFI + 4096);
@@ -1236,15 +1240,11 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
                 const HostTensor* f1b = getw(ctx, b + ".ff.net.0.proj.bias", {2 * FFI});
                 if (!f1 || !f1b) return -1;
                 std::vector<float> pw((size_t)2 * FFI * MC), pb((size_t)2 * FFI);
-                for (int tile = 0; tile < 2 * FFI / 128; ++tile)
-                    for (int wn = 0; wn < 2; ++wn)
-                        for (int j = 0; j < 2; ++j)
-                            for (int i = 0; i < 32; ++i) {
-                                const int np = tile * 128 + wn * 64 + j * 32 + i;
-                                const int src = (j == 0 ? 0 : FFI) + tile * 64 + wn * 32 + i;
-                                std::copy(f1->data.begin() + (size_t)src * MC, f1->data.begin() + (size_t)(src + 1) * MC, pw.begin() + (size_t)np * MC);
-                                pb[np] = f1b->data[src];
-                            }
+                for (int np = 0; np < 2 * FFI; ++np) {   // tile-interleaved (value, gate) rows for tgemm.hip's 256-wide tile
+                    const int src = tgemm_geglu_src_row(np, 2 * FFI);
+                    std::copy(f1->data.begin() + (size_t)src * MC, f1->data.begin() + (size_t)(src + 1) * MC, pw.begin() + (size_t)np * MC);
+                    pb[np] = f1b->data[src];
+                }
                 if (upload_bf16(ctx, &sw.t_ff1, pw.data(), 2 * FFI, MC, 1) || upload(ctx, &sw.t_ff1_bias, pb.data(), pb.size())) return -1;
                 const HostTensor& w0 = ctx->host_w["__ffproj.w0"];
                 const HostTensor& w1 = ctx->host_w["__ffproj.w1"];

@@ -48,7 +48,14 @@ struct TGemmArgs {
     // ---- GEGLU epilogue (geglu != 0): the weight rows are tile-interleaved on the host so that a wave's two 32-column MFMA
     // tiles are (value, gate) of the same 32 channels; out[m][c] = value * gelu(gate) -> yb (bf16 token-major, N / 2 channels)
     int geglu;
+    // ---- batch as rows (UNet): the A operand of ALL samples is one row axis, sample b's rows starting at b * seg_rows
+    // (seg_rows % 32 == 0, >= M); row R is sample R / seg_rows, token R % seg_rows; tokens >= M are padding.  0: per-sample
+    // operands addressed through a_bs (audio encoder).
+    int seg_rows;
+    // value channel of the first column of a GEGLU value tile starting at permuted column n (see tgemm_geglu_src_row)
+    __host__ __device__ int geglu_c0(int n) const { return (n / 256) * 128 + ((n % 256) / 128) * 64 + ((n % 128) / 64) * 32; }
 };
+int tgemm_geglu_src_row(int n, int N);
 bool tgemm_supports(const TGemmArgs& a);
 void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s);   // N % 128 == 0: 128-wide tiles, else N % 64 == 0: 64-wide
 void configure_tgemm_kernel();

@@ -13,6 +13,7 @@
 // registers).  Operand tiles are staged through LDS with register double-buffering (global -> registers for tile k+1
 // while tile k multiplies, one barrier per tile); LDS rows are padded to 72 halfs so that the 16-byte fragment reads of
 // 8 consecutive lanes fall on distinct banks.  72 KB of LDS per workgroup: two workgroups share a CU.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -25,6 +26,130 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TBM = 128, TBN = 128, TBK = 64, TLP = 72;   // tile, LDS row pitch in halfs
+
+// ------------------------------------------------------------------------------------------------------------------
+// Epilogues shared by the two tile shapes.  D[i = row][j = output]: lane -> output n (l & 31), register r -> row
+// (r & 3) + 8 (r >> 2) + 4 (l >> 5) of a 32 x 32 MFMA tile.  A row tile starts at global row `row0 + 32 i`; with
+// seg_rows > 0 (UNet: all samples of the batch are one row axis with a per-sample pitch of seg_rows rows, a multiple of 32)
+// the sample is row / seg_rows and the token row % seg_rows, else the sample is `b_grid` and the token is the row itself.
+// Tokens >= M are never stored.  n_of(j) gives the first output column of column tile j.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NJ, typename NOf>
+__device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ], int b_grid, int rt, NOf n_of, int l) {
+    const int lh = l >> 5;
+    if (a.seg_rows > 0 && rt >= a.batch * a.seg_rows) return;   // row tile past the last sample (wave-uniform)
+    if (a.geglu) {   // column tiles (2p, 2p + 1) = (value, gate) of the same 32 channels (host tile-interleaving): out = value * gelu(gate)
+        if constexpr (NJ % 2 == 0) {
+#pragma unroll
+            for (int p = 0; p < NJ / 2; ++p) {
+                const int nv = n_of(2 * p) + (l & 31), ng = n_of(2 * p + 1) + (l & 31);
+                const int c = a.geglu_c0(n_of(2 * p)) + (l & 31);
+                const float bv = a.bias ? a.bias[nv] : 0.f, bg = a.bias ? a.bias[ng] : 0.f;
+                {
+                    const int b = a.seg_rows > 0 ? rt / a.seg_rows : b_grid;
+                    const int mt = a.seg_rows > 0 ? rt - b * a.seg_rows : rt;
+                    __bf16* yb = reinterpret_cast<__bf16*>(a.yb) + (long long)b * a.y_bs;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (m < a.M) yb[(long long)m * a.ldy + c] = (__bf16)((acc[2 * p][r] + bv) * gelu_f(acc[2 * p + 1][r] + bg));
+                    }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n_of(j) + (l & 31);
+        const float bias = a.bias ? a.bias[n] : 0.f;
+        {
+            const int b = a.seg_rows > 0 ? rt / a.seg_rows : b_grid;
+            const int mt = a.seg_rows > 0 ? rt - b * a.seg_rows : rt;
+            if (mt >= a.M) continue;
+            if (a.y_cm) {
+                // channel-major fp32 result: 4 consecutive tokens per register quadruple -> one 16-byte store per lane
+                float add = bias;
+                if (a.emb) add += a.emb[(long long)n * a.emb_pitch + (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride];
+                float* yp = a.y_cm + (long long)b * a.cm_bs + (long long)n * a.cm_pitch;
+                const float* rp = a.res_cm ? a.res_cm + (long long)b * a.res_cm_bs + (long long)n * a.cm_pitch : nullptr;
+                float* y2p = a.y2_cm ? a.y2_cm + (long long)b * a.y2_bs + (long long)n * a.cm_pitch : nullptr;
+                float sum = 0.f;
+                float vals[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mt + 8 * q + 4 * lh;
+                    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (rp && m < a.M) rv = *reinterpret_cast<const float4*>(rp + m);   // pitch >= roundup(M, 32): in-bounds
+                    const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[j][4 * q + e] + add + r4[e];
+                        vals[4 * q + e] = v;
+                        sum += (m + e < a.M) ? v : 0.f;
+                    }
+                    if (m < a.M) {   // tokens in [M, roundup(M, 4)) land in the row's padding
+                        const float4 v4 = make_float4(vals[4 * q], vals[4 * q + 1], vals[4 * q + 2], vals[4 * q + 3]);
+                        *reinterpret_cast<float4*>(yp + m) = v4;
+                        if (y2p) *reinterpret_cast<float4*>(y2p + m) = v4;
+                    }
+                }
+                if (a.stats) {   // Welford partial of this channel over the 32-token tile (lanes l and l ^ 32 hold it)
+                    const float cnt = (float)min(32, a.M - mt);
+                    sum += __shfl_xor(sum, 32);
+                    const float mean = sum / cnt;
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = (mt + 8 * q + 4 * lh + e < a.M) ? vals[4 * q + e] - mean : 0.f;
+                            m2 = fmaf(d, d, m2);
+                        }
+                    m2 += __shfl_xor(m2, 32);
+                    if (lh == 0) {
+                        float* so = a.stats + (long long)b * a.stats_bs + ((long long)n * ((a.M + 31) >> 5) + (mt >> 5)) * 2;
+                        so[0] = mean;
+                        so[1] = m2;
+                    }
+                }
+                continue;
+            }
+            if (a.qk && n >= a.qk_n) {
+                // v rows channel-major [c][t] for the attention kernel: 4 consecutive tokens per register quadruple
+                const int c = n - a.qk_n;
+                float* vp = a.vt + (long long)b * a.v_bs + (long long)c * a.v_pitch;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mt + 8 * q + 4 * lh;
+                    if (m + 3 < a.M) {
+                        float4 v4 = make_float4(acc[j][4 * q] + bias, acc[j][4 * q + 1] + bias, acc[j][4 * q + 2] + bias, acc[j][4 * q + 3] + bias);
+                        *reinterpret_cast<float4*>(vp + m) = v4;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (m + e < a.M) vp[m + e] = acc[j][4 * q + e] + bias;
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                float v = acc[j][r] + bias;
+                if (a.act == 1) v = gelu_f(v);
+                if (a.res) v += a.res[(long long)b * a.res_bs + (long long)m * a.ldr + n];
+                if (a.qk) {   // q / k heads token-major [b][2 heads][rows][head_dim]
+                    const int h = n / a.head_dim, d = n - h * a.head_dim;
+                    a.qk[(((long long)b * a.heads2 + h) * a.rows + m) * a.head_dim + d] = v;
+                } else {
+                    if (a.yf) a.yf[(long long)b * a.y_bs + (long long)m * a.ldy + n] = v;
+                    if (a.yb) reinterpret_cast<__bf16*>(a.yb)[(long long)b * a.y_bs + (long long)m * a.ldy + n] = (__bf16)v;
+                }
+            }
+        }
+    }
+}
 
 // BN = 128: wave grid 2 x 2, each wave 64 tokens x 64 outputs; BN = 64 (N = 192, 576): each wave 64 tokens x 32 outputs
 template <int BN>
@@ -93,13 +218,11 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
         for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(pw + lwoff[i]) = R.w[i];
     };
 
-    f32x16 acc[2][NJ];
+    f32x16 acc0[NJ], acc1[NJ];   // two row tiles per wave (separate arrays: one [2][NJ] array of this size is not promoted to registers)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
 
     const int frow = l & 31, fk = 8 * (l >> 5);
     auto compute = [&](int buf) {
@@ -113,9 +236,10 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(pw + (wn * (32 * NJ) + j * 32 + frow) * TLP + ks * 16 + fk);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) {
+                acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[j], acc0[j], 0, 0, 0);
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[j], acc1[j], 0, 0, 0);
+            }
         }
     };
 
@@ -144,130 +268,170 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogues.  D[i = token][j = output]: lane -> output n (l & 31), register r -> token (r & 3) + 8 (r >> 2) + 4 (l >> 5)
-    const int lh = l >> 5;
-    if constexpr (NJ == 2) {
-        if (a.geglu) {   // columns j = 0: value, j = 1: gate of channel c (host tile-interleaving): out = value * gelu(gate)
-            const int c = (n0 >> 1) + wn * 32 + (l & 31);
-            const float bv = a.bias ? a.bias[n0 + wn * 64 + (l & 31)] : 0.f, bg = a.bias ? a.bias[n0 + wn * 64 + 32 + (l & 31)] : 0.f;
-            __bf16* yb = reinterpret_cast<__bf16*>(a.yb) + (long long)b * a.y_bs;
+    auto n_of = [&](int j) { return n0 + wn * (32 * NJ) + j * 32; };
+    tg_epilogue<NJ>(a, acc0, b, m0 + wm * 64, n_of, l);
+    tg_epilogue<NJ>(a, acc1, b, m0 + wm * 64 + 32, n_of, l);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 256-row tile (large M): 8 waves as 4 (rows) x 2 (columns), each 64 rows x BN / 2 columns, BN = 256 (N % 256 == 0: the audio
+// encoder's 512 / 768 / 2304 / 3072-wide outputs, GEGLU) or 192 (the UNet's 192 / 576-wide outputs).  The 128-row kernel
+// above was bound by operand bytes per FLOP, not by MFMA: 15.6-24 B per kFLOP from L2 with two tiles in flight per workgroup
+// left the MFMA pipes 11-22 % busy and the waves 45 % parked on s_waitcnt (profiles/r02c_pmc_sq_b32_bf16.txt).  This shape moves
+// 7.8 (256 x 256) / 9.1 (256 x 192) B per kFLOP and gives each wave 32 / 24 MFMAs per k-tile to hide the next tile's loads.
+// With seg_rows > 0 the row axis is the whole batch (per-sample pitch seg_rows), so M = 600 does not cost tile padding.
+// ------------------------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(512) void tgemm256_kernel(const TGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [2 buffers][A 256 x 72 | W BN x 72]
+    constexpr int BM2 = 256;
+    constexpr int NJ = BN / 64;                 // MFMA column tiles per wave (4 or 3)
+    constexpr int WCH = BN * 8 / 512;           // 16-byte W chunks per thread and tile (4 or 3)
+    constexpr int BUF = (BM2 + BN) * TLP;
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int rows_tot = a.seg_rows > 0 ? a.batch * a.seg_rows : a.M;   // rows of the A operand per grid batch entry
+    const int nbatch = a.seg_rows > 0 ? 1 : a.batch;
+    const int NT = a.N / BN, MT = (rows_tot + BM2 - 1) / BM2;
+    const unsigned L = blockIdx.x, xcd = L & 7u, slot = L >> 3;   // XCD-aware order, as in tgemm_kernel
+    const int nt = (int)(slot % (unsigned)NT);
+    const int mg = (int)(slot / (unsigned)NT) * 8 + (int)xcd;
+    const int b = mg / MT, mt_ = mg - b * MT;
+    if (b >= nbatch) return;
+    const int m0 = mt_ * BM2, n0 = nt * BN;
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.a) + (long long)b * a.a_bs;
+    const unsigned short* A2 = reinterpret_cast<const unsigned short*>(a.a2) + (long long)b * a.a2_bs;
+    const unsigned short* W = reinterpret_cast<const unsigned short*>(a.w);
+    const int nk = a.K / TBK;
+    const int nk1 = (a.a2 ? a.K1 : a.K) / TBK;
+
+    struct RegTile { u32x4 a[4]; u32x4 w[WCH]; };
+    RegTile S0, S1;
+    int aoff[4], a2off[4], woff[WCH];   // element offsets within one sample's operand / the weight matrix: < 2^31 (host-checked)
+    int loff[4], lwoff[WCH];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < a.M) yb[(long long)m * a.ldy + c] = (__bf16)((acc[i][0][r] + bv) * gelu_f(acc[i][1][r] + bg));
-                }
-            return;
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 512 * i, row = c >> 3, kp = c & 7;
+        const int m = min(m0 + row, rows_tot - 1);
+        aoff[i] = m * a.lda + kp * 8;
+        a2off[i] = m * a.lda2 + kp * 8;
+        loff[i] = row * TLP + kp * 8;
     }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + wn * (32 * NJ) + j * 32 + (l & 31);
-        const float bias = a.bias ? a.bias[n] : 0.f;
+    for (int i = 0; i < WCH; ++i) {
+        const int c = tid + 512 * i, row = c >> 3, kp = c & 7;
+        woff[i] = (n0 + row) * a.K + kp * 8;
+        lwoff[i] = row * TLP + kp * 8;
+    }
+    auto gload_tile = [&](RegTile& R, int kt) {
+        const bool first = kt < nk1;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int mt = m0 + wm * 64 + i * 32;
-            if (a.y_cm) {
-                // channel-major fp32 result: 4 consecutive tokens per register quadruple -> one 16-byte store per lane
-                float add = bias;
-                if (a.emb) add += a.emb[(long long)n * a.emb_pitch + (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride];
-                float* yp = a.y_cm + (long long)b * a.cm_bs + (long long)n * a.cm_pitch;
-                const float* rp = a.res_cm ? a.res_cm + (long long)b * a.res_cm_bs + (long long)n * a.cm_pitch : nullptr;
-                float* y2p = a.y2_cm ? a.y2_cm + (long long)b * a.y2_bs + (long long)n * a.cm_pitch : nullptr;
-                float sum = 0.f;
-                float vals[16];
+        for (int i = 0; i < 4; ++i) {
+            const unsigned short* p = first ? A + (aoff[i] + kt * TBK) : A2 + (a2off[i] + (kt - nk1) * TBK);
+            R.a[i] = *reinterpret_cast<const u32x4*>(p);
+        }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = mt + 8 * q + 4 * lh;
-                    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (rp && m < a.M) rv = *reinterpret_cast<const float4*>(rp + m);   // pitch >= roundup(M, 32): in-bounds
-                    const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
+        for (int i = 0; i < WCH; ++i) R.w[i] = *reinterpret_cast<const u32x4*>(W + (woff[i] + kt * TBK));
+    };
+    auto lds_store = [&](const RegTile& R, int buf) {
+        unsigned short* pa = lds + buf * BUF;
+        unsigned short* pw = pa + BM2 * TLP;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = acc[i][j][4 * q + e] + add + r4[e];
-                        vals[4 * q + e] = v;
-                        sum += (m + e < a.M) ? v : 0.f;
-                    }
-                    if (m < a.M) {   // tokens in [M, roundup(M, 4)) land in the row's padding
-                        const float4 v4 = make_float4(vals[4 * q], vals[4 * q + 1], vals[4 * q + 2], vals[4 * q + 3]);
-                        *reinterpret_cast<float4*>(yp + m) = v4;
-                        if (y2p) *reinterpret_cast<float4*>(y2p + m) = v4;
-                    }
-                }
-                if (a.stats && mt < a.M) {   // Welford partial of this channel over the 32-token tile (lanes l and l ^ 32 hold it)
-                    const float cnt = (float)min(32, a.M - mt);
-                    sum += __shfl_xor(sum, 32);
-                    const float mean = sum / cnt;
-                    float m2 = 0.f;
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(pa + loff[i]) = R.a[i];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+        for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(pw + lwoff[i]) = R.w[i];
+    };
+    f32x16 acc0[NJ], acc1[NJ];   // two row tiles per wave (separate arrays: one [2][NJ] array of this size is not promoted to registers)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float d = (mt + 8 * q + 4 * lh + e < a.M) ? vals[4 * q + e] - mean : 0.f;
-                            m2 = fmaf(d, d, m2);
-                        }
-                    m2 += __shfl_xor(m2, 32);
-                    if (lh == 0) {
-                        float* so = a.stats + (long long)b * a.stats_bs + ((long long)n * ((a.M + 31) >> 5) + (mt >> 5)) * 2;
-                        so[0] = mean;
-                        so[1] = m2;
-                    }
-                }
-                continue;
-            }
-            if (a.qk && n >= a.qk_n) {
-                // v rows channel-major [c][t] for the attention kernel: 4 consecutive tokens per register quadruple
-                const int c = n - a.qk_n;
-                float* vp = a.vt + (long long)b * a.v_bs + (long long)c * a.v_pitch;
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = mt + 8 * q + 4 * lh;
-                    if (m + 3 < a.M) {
-                        float4 v4 = make_float4(acc[i][j][4 * q] + bias, acc[i][j][4 * q + 1] + bias, acc[i][j][4 * q + 2] + bias, acc[i][j][4 * q + 3] + bias);
-                        *reinterpret_cast<float4*>(vp + m) = v4;
-                    } else {
+        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
+    const int frow = l & 31, fk = 8 * (l >> 5);
+    auto compute = [&](int buf) {
+        const unsigned short* pa = lds + buf * BUF;
+        const unsigned short* pw = pa + BM2 * TLP;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (m + e < a.M) vp[m + e] = acc[i][j][4 * q + e] + bias;
-                    }
-                }
-                continue;
-            }
+        for (int ks = 0; ks < TBK / 16; ++ks) {
+            bf16x8 fa[2], fb[NJ];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= a.M) continue;
-                float v = acc[i][j][r] + bias;
-                if (a.act == 1) v = gelu_f(v);
-                if (a.res) v += a.res[(long long)b * a.res_bs + (long long)m * a.ldr + n];
-                if (a.qk) {   // q / k heads token-major [b][2 heads][rows][head_dim]
-                    const int h = n / a.head_dim, d = n - h * a.head_dim;
-                    a.qk[(((long long)b * a.heads2 + h) * a.rows + m) * a.head_dim + d] = v;
-                } else {
-                    if (a.yf) a.yf[(long long)b * a.y_bs + (long long)m * a.ldy + n] = v;
-                    if (a.yb) reinterpret_cast<__bf16*>(a.yb)[(long long)b * a.y_bs + (long long)m * a.ldy + n] = (__bf16)v;
-                }
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(pa + (wm * 64 + i * 32 + frow) * TLP + ks * 16 + fk);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(pw + (wn * (32 * NJ) + j * 32 + frow) * TLP + ks * 16 + fk);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[j], acc0[j], 0, 0, 0);
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[j], acc1[j], 0, 0, 0);
             }
         }
+    };
+    gload_tile(S0, 0);
+    gload_tile(S1, min(1, nk - 1));
+    lds_store(S0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        gload_tile(S0, min(kt + 2, nk - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_store(S1, 1);
+        __syncthreads();
+        gload_tile(S1, min(kt + 3, nk - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_store(S0, 0);
+        __syncthreads();
     }
+    auto n_of = [&](int j) { return n0 + wn * (32 * NJ) + j * 32; };
+    tg_epilogue<NJ>(a, acc0, b, m0 + wm * 64, n_of, l);
+    tg_epilogue<NJ>(a, acc1, b, m0 + wm * 64 + 32, n_of, l);
 }
 
 bool tgemm_supports(const TGemmArgs& a) {
     if (!(a.M >= 1 && a.N >= 64 && a.N % 64 == 0 && a.K >= TBK && a.K % TBK == 0 && a.lda % 8 == 0 && a.a_bs % 8 == 0)) return false;
     if (a.qk && (a.qk_n % 32 || a.head_dim % 32)) return false;
     if (a.a2 && (a.K1 % TBK || a.K1 <= 0 || a.K1 >= a.K || a.lda2 % 8 || a.a2_bs % 8)) return false;
-    if (a.geglu && (a.N % 128 || !a.yb)) return false;
+    if (a.geglu && (a.N % 256 || !a.yb)) return false;   // the GEGLU row interleaving is the 256-wide tile's (tgemm_geglu_src_row)
     if (a.y_cm && (a.cm_pitch % 4 || a.cm_pitch < ((a.M + 3) & ~3))) return false;
+    if (a.seg_rows && (a.seg_rows % 32 || a.seg_rows < a.M)) return false;
+    if ((long long)a.N * a.K > 0x7fffffffLL) return false;   // 32-bit element offsets in the 256-row kernel
     return true;
+}
+// GEGLU weight-row interleaving for the 256-wide tile: tile-local column tile pairs (2p, 2p + 1) of each wave are (value, gate)
+// of the same 32 channels.  Returns the source row (value rows [0, N/2), gate rows [N/2, N)) of permuted row n.
+int tgemm_geglu_src_row(int n, int N) {
+    const int tile = n / 256, wn = (n % 256) / 128, j = (n % 128) / 32, i = n % 32;
+    const int c = tile * 128 + wn * 64 + (j >> 1) * 32 + i;
+    return (j & 1) ? N / 2 + c : c;
 }
 void configure_tgemm_kernel() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TBM + 128) * TLP * 2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TBM + 64) * TLP * 2);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm256_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * TLP * 2);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm256_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 192) * TLP * 2);
 }
 void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
     if (!tgemm_supports(a)) { fprintf(stderr, "said: tgemm shape M=%d N=%d K=%d unsupported\n", a.M, a.N, a.K); abort(); }
     TGemmArgs a2 = a;
     a2.batch = batch;
+    static const bool no256 = getenv("SAID_NO_TGEMM256") != nullptr;
+    const long long rows_tot = a.seg_rows > 0 ? (long long)batch * a.seg_rows : a.M;
+    const int nb = a.seg_rows > 0 ? 1 : batch;
+    const bool big = !no256 && (a.N % 256 == 0 || a.N % 192 == 0) && rows_tot * nb >= 4096 &&
+                     (rows_tot + 2) * (long long)std::max(a.lda, a.lda2) < 0x7fffffffLL;
+    if (a.geglu && !big) { fprintf(stderr, "said: the GEGLU epilogue needs the 256-wide tile\n"); abort(); }
+    if (big) {
+        const long long mt8 = ((long long)nb * ((rows_tot + 255) / 256) + 7) / 8 * 8;
+        if (a.N % 256 == 0) {
+            dim3 grid((unsigned)(mt8 * (a.N / 256)));
+            hipLaunchKernelGGL(tgemm256_kernel<256>, grid, dim3(512), 2 * (256 + 256) * TLP * 2, s, a2);
+        } else {
+            dim3 grid((unsigned)(mt8 * (a.N / 192)));
+            hipLaunchKernelGGL(tgemm256_kernel<192>, grid, dim3(512), 2 * (256 + 192) * TLP * 2, s, a2);
+        }
+        return;
+    }
+    if (a.seg_rows > 0) { fprintf(stderr, "said: batch-as-rows addressing needs the 256-row tile\n"); abort(); }
     const long long mtiles8 = ((long long)batch * ((a.M + TBM - 1) / TBM) + 7) / 8 * 8;   // (sample, M tile) pairs padded to the 8 XCDs
     if (a.N % 128 == 0) {
         dim3 grid((unsigned)(mtiles8 * (a.N / 128)));
