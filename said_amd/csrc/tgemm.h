@@ -52,6 +52,7 @@ struct TGemmArgs {
     // (seg_rows % 32 == 0, >= M); row R is sample R / seg_rows, token R % seg_rows; tokens >= M are padding.  0: per-sample
     // operands addressed through a_bs (audio encoder).
     int seg_rows;
+    int dbg;               // timing experiments (SAID_TG_DBG): bit 0 = skip the epilogue, bit 1 = skip the K loop
     // value channel of the first column of a GEGLU value tile starting at permuted column n (see tgemm_geglu_src_row)
     __host__ __device__ int geglu_c0(int n) const { return (n / 256) * 128 + ((n % 256) / 128) * 64 + ((n % 128) / 64) * 32; }
 };

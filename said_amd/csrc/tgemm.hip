@@ -24,131 +24,139 @@ namespace said {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4t __attribute__((ext_vector_type(4)));
 
 constexpr int TBM = 128, TBN = 128, TBK = 64, TLP = 72;   // tile, LDS row pitch in halfs
 
 // ------------------------------------------------------------------------------------------------------------------
-// Epilogues shared by the two tile shapes.  D[i = row][j = output]: lane -> output n (l & 31), register r -> row
-// (r & 3) + 8 (r >> 2) + 4 (l >> 5) of a 32 x 32 MFMA tile.  A row tile starts at global row `row0 + 32 i`; with
-// seg_rows > 0 (UNet: all samples of the batch are one row axis with a per-sample pitch of seg_rows rows, a multiple of 32)
-// the sample is row / seg_rows and the token row % seg_rows, else the sample is `b_grid` and the token is the row itself.
-// Tokens >= M are never stored.  n_of(j) gives the first output column of column tile j.
+// Epilogues shared by the two tile shapes, one 32-row tile of a wave at a time.
+//
+// The MFMA result layout is D[row][n]: lane -> output column n (l & 31 within a 32-column tile), register r -> row
+// (r & 3) + 8 (r >> 2) + 4 (l >> 5).  Storing straight from that layout makes every store instruction touch up to 64
+// different cache lines (channel-major results: one 16-byte piece per lane; token-major bf16: 2-byte elements), and the
+// knock-out experiment of round 2 (SAID_TG_DBG, scripts/gpu_r2_j.sh) measured the epilogue at 53-57 % of the kernels' time.
+// So the tile goes through a wave-private LDS scratch [32 rows][32 NJ + 4] first (the operand buffers are free after the K
+// loop) — bias / timestep-embedding term / activation / GEGLU product are applied on the way in, where lane == column —
+// and is read back in the layout the destination wants:
+//   * token-major (audio encoder, GEGLU, q / k heads): 16 bytes of consecutive columns per lane, a row = 32 NJ / 4 lanes;
+//   * channel-major (UNet results, v rows): 16 bytes of consecutive TOKENS per lane, 8 lanes per channel row — full 128-byte
+//     lines; residual loads use the same mapping, GroupNorm partials reduce over the 8 lanes of a row.
+// A row tile starts at global row rt; with seg_rows > 0 (UNet: all samples form one row axis, per-sample pitch seg_rows, a
+// multiple of 32) the sample is rt / seg_rows and the first token rt % seg_rows, else sample b_grid and token rt.
+// n0w = first output column of this wave's 32 NJ columns.  No workgroup barrier inside (waves may return early): LDS
+// operations of one wave execute in order, so its own writes are visible to its later reads.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NJ, typename NOf>
-__device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ], int b_grid, int rt, NOf n_of, int l) {
-    const int lh = l >> 5;
+template <int NJ>
+__device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ], int b_grid, int rt, int n0w, int l, float* sc) {
+    constexpr int CW = 32 * NJ, CP = CW + 4;   // columns of this wave, scratch row pitch (floats)
+    const int lh = l >> 5, lc = l & 31;
     if (a.seg_rows > 0 && rt >= a.batch * a.seg_rows) return;   // row tile past the last sample (wave-uniform)
-    if (a.geglu) {   // column tiles (2p, 2p + 1) = (value, gate) of the same 32 channels (host tile-interleaving): out = value * gelu(gate)
-        if constexpr (NJ % 2 == 0) {
-#pragma unroll
-            for (int p = 0; p < NJ / 2; ++p) {
-                const int nv = n_of(2 * p) + (l & 31), ng = n_of(2 * p + 1) + (l & 31);
-                const int c = a.geglu_c0(n_of(2 * p)) + (l & 31);
-                const float bv = a.bias ? a.bias[nv] : 0.f, bg = a.bias ? a.bias[ng] : 0.f;
-                {
-                    const int b = a.seg_rows > 0 ? rt / a.seg_rows : b_grid;
-                    const int mt = a.seg_rows > 0 ? rt - b * a.seg_rows : rt;
-                    __bf16* yb = reinterpret_cast<__bf16*>(a.yb) + (long long)b * a.y_bs;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (m < a.M) yb[(long long)m * a.ldy + c] = (__bf16)((acc[2 * p][r] + bv) * gelu_f(acc[2 * p + 1][r] + bg));
-                    }
-                }
-            }
-        }
+    const int b = a.seg_rows > 0 ? rt / a.seg_rows : b_grid;
+    const int mt = a.seg_rows > 0 ? rt - b * a.seg_rows : rt;
+    if (mt >= a.M) return;
+    if (a.dbg & 1) {   // timing experiment (SAID_TG_DBG=1): no epilogue memory traffic — results are WRONG, never used in tests
+        if (acc[0][0] == 12345.678f && a.yf) a.yf[0] = acc[0][1];
         return;
     }
+    const int nrows = min(32, a.M - mt);
+    // ---- phase 1: registers -> scratch, elementwise work where lane == column
+    const bool geglu = a.geglu != 0;
+    constexpr int NJO = NJ;   // (GEGLU writes NJ / 2 column tiles; the scratch keeps the full pitch)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int n = n_of(j) + (l & 31);
-        const float bias = a.bias ? a.bias[n] : 0.f;
-        {
-            const int b = a.seg_rows > 0 ? rt / a.seg_rows : b_grid;
-            const int mt = a.seg_rows > 0 ? rt - b * a.seg_rows : rt;
-            if (mt >= a.M) continue;
-            if (a.y_cm) {
-                // channel-major fp32 result: 4 consecutive tokens per register quadruple -> one 16-byte store per lane
-                float add = bias;
-                if (a.emb) add += a.emb[(long long)n * a.emb_pitch + (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride];
-                float* yp = a.y_cm + (long long)b * a.cm_bs + (long long)n * a.cm_pitch;
-                const float* rp = a.res_cm ? a.res_cm + (long long)b * a.res_cm_bs + (long long)n * a.cm_pitch : nullptr;
-                float* y2p = a.y2_cm ? a.y2_cm + (long long)b * a.y2_bs + (long long)n * a.cm_pitch : nullptr;
+        if (geglu && (j & 1)) continue;   // gate tiles are consumed with their value tile
+        const int n = n0w + j * 32 + lc;
+        float add = a.bias ? a.bias[n] : 0.f;
+        float gadd = 0.f;
+        if (geglu) gadd = a.bias ? a.bias[n + 32] : 0.f;
+        if (a.emb) add += a.emb[(long long)n * a.emb_pitch + (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride];
+        const int col = geglu ? (j >> 1) * 32 + lc : j * 32 + lc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float v = acc[j][r] + add;
+            if (geglu) {
+                if constexpr (NJ % 2 == 0) v *= gelu_f(acc[(j + 1) % NJ][r] + gadd);
+            } else if (a.act == 1) {
+                v = gelu_f(v);
+            }
+            sc[row * CP + col] = v;
+        }
+    }
+    (void)NJO;
+    __builtin_amdgcn_wave_barrier();
+    const int cw = geglu ? CW / 2 : CW;                 // live columns in the scratch
+    const int n_first = geglu ? a.geglu_c0(n0w) : n0w;   // first destination column
+    const bool v_rows = a.qk && n0w >= a.qk_n;          // this wave holds v columns (channel-major) of a q/k/v projection
+    if (a.y_cm || v_rows) {
+        // ---- phase 2b: channel-major destination: lane -> (channel l >> 3 of the pass, token quad l & 7)
+        const int tq = l & 7;
+        const int pitch = a.y_cm ? a.cm_pitch : a.v_pitch;
+        float* const ybase = a.y_cm ? a.y_cm + (long long)b * a.cm_bs : a.vt + (long long)b * a.v_bs - (long long)a.qk_n * a.v_pitch;
+        const int nparts = (a.M + 31) >> 5;
+        for (int c0 = 0; c0 < cw; c0 += 8) {
+            const int c = c0 + (l >> 3);
+            const int n = n_first + c;
+            float v4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] = sc[(4 * tq + e) * CP + c];
+            const int m = mt + 4 * tq;
+            if (a.res_cm && m < a.M) {   // pitch >= roundup(M, 32): the whole quad is in bounds
+                const float4 rv = *reinterpret_cast<const float4*>(a.res_cm + (long long)b * a.res_cm_bs + (long long)n * pitch + m);
+                v4[0] += rv.x; v4[1] += rv.y; v4[2] += rv.z; v4[3] += rv.w;
+            }
+            if (m < a.M) {   // tokens in [M, roundup(M, 4)) land in the row's padding
+                const float4 o = make_float4(v4[0], v4[1], v4[2], v4[3]);
+                *reinterpret_cast<float4*>(ybase + (long long)n * pitch + m) = o;
+                if (a.y2_cm) *reinterpret_cast<float4*>(a.y2_cm + (long long)b * a.y2_bs + (long long)n * pitch + m) = o;
+            }
+            if (a.stats) {   // Welford partial of channel n over this 32-token tile: reduce over the row's 8 lanes
                 float sum = 0.f;
-                float vals[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = mt + 8 * q + 4 * lh;
-                    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (rp && m < a.M) rv = *reinterpret_cast<const float4*>(rp + m);   // pitch >= roundup(M, 32): in-bounds
-                    const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
+                for (int e = 0; e < 4; ++e) sum += (m + e < a.M) ? v4[e] : 0.f;
+                sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+                const float mean = sum / (float)nrows;
+                float m2 = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = acc[j][4 * q + e] + add + r4[e];
-                        vals[4 * q + e] = v;
-                        sum += (m + e < a.M) ? v : 0.f;
-                    }
-                    if (m < a.M) {   // tokens in [M, roundup(M, 4)) land in the row's padding
-                        const float4 v4 = make_float4(vals[4 * q], vals[4 * q + 1], vals[4 * q + 2], vals[4 * q + 3]);
-                        *reinterpret_cast<float4*>(yp + m) = v4;
-                        if (y2p) *reinterpret_cast<float4*>(y2p + m) = v4;
-                    }
+                for (int e = 0; e < 4; ++e) { const float d = (m + e < a.M) ? v4[e] - mean : 0.f; m2 = fmaf(d, d, m2); }
+                m2 += __shfl_xor(m2, 1); m2 += __shfl_xor(m2, 2); m2 += __shfl_xor(m2, 4);
+                if (tq == 0) {
+                    float* so = a.stats + (long long)b * a.stats_bs + ((long long)n * nparts + (mt >> 5)) * 2;
+                    so[0] = mean;
+                    so[1] = m2;
                 }
-                if (a.stats) {   // Welford partial of this channel over the 32-token tile (lanes l and l ^ 32 hold it)
-                    const float cnt = (float)min(32, a.M - mt);
-                    sum += __shfl_xor(sum, 32);
-                    const float mean = sum / cnt;
-                    float m2 = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float d = (mt + 8 * q + 4 * lh + e < a.M) ? vals[4 * q + e] - mean : 0.f;
-                            m2 = fmaf(d, d, m2);
-                        }
-                    m2 += __shfl_xor(m2, 32);
-                    if (lh == 0) {
-                        float* so = a.stats + (long long)b * a.stats_bs + ((long long)n * ((a.M + 31) >> 5) + (mt >> 5)) * 2;
-                        so[0] = mean;
-                        so[1] = m2;
-                    }
-                }
-                continue;
             }
-            if (a.qk && n >= a.qk_n) {
-                // v rows channel-major [c][t] for the attention kernel: 4 consecutive tokens per register quadruple
-                const int c = n - a.qk_n;
-                float* vp = a.vt + (long long)b * a.v_bs + (long long)c * a.v_pitch;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = mt + 8 * q + 4 * lh;
-                    if (m + 3 < a.M) {
-                        float4 v4 = make_float4(acc[j][4 * q] + bias, acc[j][4 * q + 1] + bias, acc[j][4 * q + 2] + bias, acc[j][4 * q + 3] + bias);
-                        *reinterpret_cast<float4*>(vp + m) = v4;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (m + e < a.M) vp[m + e] = acc[j][4 * q + e] + bias;
-                    }
-                }
-                continue;
+        }
+    } else {
+        // ---- phase 2a: token-major destination: lane -> 4 consecutive columns of a row; rows_pp rows per pass
+        const int lanes_per_row = cw / 4;                // 32, 24, 16 or 8
+        const int rows_pp = 64 / lanes_per_row;          // 2, 2 (48 lanes active), 4 or 8
+        const int rr = l / lanes_per_row, cq = l - rr * lanes_per_row;
+        const bool lane_on = rr < rows_pp;
+        for (int r0 = 0; r0 < nrows; r0 += rows_pp) {
+            const int row = r0 + rr;
+            if (!lane_on || row >= nrows) continue;
+            const int m = mt + row;
+            const int n = n_first + 4 * cq;
+            f32x4t v = *reinterpret_cast<const f32x4t*>(sc + row * CP + 4 * cq);
+            if (a.res) {
+                const f32x4t rv = *reinterpret_cast<const f32x4t*>(a.res + (long long)b * a.res_bs + (long long)m * a.ldr + n);
+                v += rv;
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= a.M) continue;
-                float v = acc[j][r] + bias;
-                if (a.act == 1) v = gelu_f(v);
-                if (a.res) v += a.res[(long long)b * a.res_bs + (long long)m * a.ldr + n];
-                if (a.qk) {   // q / k heads token-major [b][2 heads][rows][head_dim]
-                    const int h = n / a.head_dim, d = n - h * a.head_dim;
-                    a.qk[(((long long)b * a.heads2 + h) * a.rows + m) * a.head_dim + d] = v;
-                } else {
-                    if (a.yf) a.yf[(long long)b * a.y_bs + (long long)m * a.ldy + n] = v;
-                    if (a.yb) reinterpret_cast<__bf16*>(a.yb)[(long long)b * a.y_bs + (long long)m * a.ldy + n] = (__bf16)v;
+            if (a.qk) {   // q / k heads token-major [b][2 heads][rows][head_dim]; head_dim % 4 == 0
+                const int h = n / a.head_dim, d = n - h * a.head_dim;
+                *reinterpret_cast<f32x4t*>(a.qk + (((long long)b * a.heads2 + h) * a.rows + m) * a.head_dim + d) = v;
+            } else {
+                if (a.yf) *reinterpret_cast<f32x4t*>(a.yf + (long long)b * a.y_bs + (long long)m * a.ldy + n) = v;
+                if (a.yb) {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.yb) + (long long)b * a.y_bs + (long long)m * a.ldy + n) = o;
                 }
             }
         }
     }
+    __builtin_amdgcn_wave_barrier();   // the scratch is reused for the wave's next row tile
 }
 
 // BN = 128: wave grid 2 x 2, each wave 64 tokens x 64 outputs; BN = 64 (N = 192, 576): each wave 64 tokens x 32 outputs
@@ -268,9 +276,10 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
         __syncthreads();
     }
 
-    auto n_of = [&](int j) { return n0 + wn * (32 * NJ) + j * 32; };
-    tg_epilogue<NJ>(a, acc0, b, m0 + wm * 64, n_of, l);
-    tg_epilogue<NJ>(a, acc1, b, m0 + wm * 64 + 32, n_of, l);
+    // the K loop ended with a barrier: the operand buffers are free and serve as per-wave transposition scratch
+    float* sc = reinterpret_cast<float*>(lds) + w * (32 * (32 * NJ + 4));
+    tg_epilogue<NJ>(a, acc0, b, m0 + wm * 64, n0 + wn * (32 * NJ), l, sc);
+    tg_epilogue<NJ>(a, acc1, b, m0 + wm * 64 + 32, n0 + wn * (32 * NJ), l, sc);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(512) void tgemm256_kernel(const TGemmArgs a) {
     gload_tile(S1, min(1, nk - 1));
     lds_store(S0, 0);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
+    for (int kt = 0; kt < ((a.dbg & 2) ? 0 : nk); kt += 2) {
         gload_tile(S0, min(kt + 2, nk - 1));
         __builtin_amdgcn_sched_barrier(0);
         compute(0);
@@ -382,9 +391,10 @@ __global__ __launch_bounds__(512) void tgemm256_kernel(const TGemmArgs a) {
         lds_store(S0, 0);
         __syncthreads();
     }
-    auto n_of = [&](int j) { return n0 + wn * (32 * NJ) + j * 32; };
-    tg_epilogue<NJ>(a, acc0, b, m0 + wm * 64, n_of, l);
-    tg_epilogue<NJ>(a, acc1, b, m0 + wm * 64 + 32, n_of, l);
+    // the K loop ended with a barrier: the operand buffers are free and serve as per-wave transposition scratch
+    float* sc = reinterpret_cast<float*>(lds) + w * (32 * (32 * NJ + 4));
+    tg_epilogue<NJ>(a, acc0, b, m0 + wm * 64, n0 + wn * (32 * NJ), l, sc);
+    tg_epilogue<NJ>(a, acc1, b, m0 + wm * 64 + 32, n0 + wn * (32 * NJ), l, sc);
 }
 
 bool tgemm_supports(const TGemmArgs& a) {
@@ -414,6 +424,8 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
     if (!tgemm_supports(a)) { fprintf(stderr, "said: tgemm shape M=%d N=%d K=%d unsupported\n", a.M, a.N, a.K); abort(); }
     TGemmArgs a2 = a;
     a2.batch = batch;
+    static const int dbg = getenv("SAID_TG_DBG") ? atoi(getenv("SAID_TG_DBG")) : 0;
+    a2.dbg = dbg;
     static const bool no256 = getenv("SAID_NO_TGEMM256") != nullptr;
     const long long rows_tot = a.seg_rows > 0 ? (long long)batch * a.seg_rows : a.M;
     const int nb = a.seg_rows > 0 ? 1 : batch;
