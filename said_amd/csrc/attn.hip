@@ -185,7 +185,64 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
                 }
             }
     };
-    if constexpr (ND == 1) {
+    if constexpr (QW > 1) {
+        // K / V tiles staged ONCE per workgroup through LDS and shared by its QW query-tile waves.  Fetching fragments straight
+        // from global memory costs one cache line per lane and instruction (a token-major K row / a channel-major V row is a
+        // line of its own, read in four 16-byte pieces): 256 line transactions per key tile and wave for 8 KB of data, times
+        // QW waves — the kernel sat on the CU's L1 path (73 % issue stall, 13 % MFMA busy: profiles/r02c_pmc_sq_b32_bf16.txt).
+        // Here 256 threads move the 2 x (32 x D) floats of a tile with one or two coalesced 16-byte loads each, one tile ahead
+        // (registers -> the other LDS buffer after the current tile's products), one barrier per tile.
+        constexpr int KP = D + 4, VP = 36;                      // LDS row pitches (floats): conflict-free 16-byte fragment reads
+        constexpr int TILE_F = 32 * KP + D * VP;
+        constexpr int NLD = (32 * D / 4) / (64 * QW);           // float4 per thread and operand (1 for D = 32, 2 for D = 64)
+        float* kv = smem + QW * (KS * 64 + KS * ND * 16 * 64);  // [2][K 32 x KP | V D x VP] behind the merge scratch
+        const float* kg = a.qk + (((long long)b * 2 * H + H + h) * rows) * D;
+        const float* vg = a.v + (long long)b * a.v_bstride + (long long)(h * D) * pitch;
+        f32x4a rk[NLD], rv[NLD];
+        auto gload = [&](int kt) {
+            const int j0 = min(kt, nkt - 1) * 32;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = tid + 64 * QW * i;
+                const int krow = idx / (D / 4), kq = idx - krow * (D / 4);     // K: 32 rows of D floats
+                rk[i] = *reinterpret_cast<const f32x4a*>(kg + (long long)(j0 + krow) * D + 4 * kq);
+                const int vrow = idx >> 3, vq = idx & 7;                      // V: D rows of 32 floats
+                rv[i] = *reinterpret_cast<const f32x4a*>(vg + (long long)vrow * pitch + j0 + 4 * vq);
+            }
+        };
+        auto lstore = [&](int buf) {
+            float* ks = kv + buf * TILE_F;
+            float* vs = ks + 32 * KP;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = tid + 64 * QW * i;
+                const int krow = idx / (D / 4), kq = idx - krow * (D / 4);
+                *reinterpret_cast<f32x4a*>(ks + krow * KP + 4 * kq) = rk[i];
+                const int vrow = idx >> 3, vq = idx & 7;
+                *reinterpret_cast<f32x4a*>(vs + vrow * VP + 4 * vq) = rv[i];
+            }
+        };
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            gload(kt + 1);
+            const float* ks = kv + (kt & 1) * TILE_F;
+            const float* vs = ks + 32 * KP;
+            f32x4a kA[NQ], vA[ND][4];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) kA[q] = *reinterpret_cast<const f32x4a*>(ks + lt * KP + lh * (D / 2) + 4 * q);
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vA[nd][q] = *reinterpret_cast<const f32x4a*>(vs + (nd * 32 + lt) * VP + 8 * q + 4 * lh);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(kt, kA, vA);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore((kt + 1) & 1);
+            __syncthreads();
+        }
+    } else if constexpr (ND == 1) {
         f32x4a kA[NQ], vA[ND][4], kB[NQ], vB[ND][4];
         // sched_barrier: without it the machine scheduler sinks the prefetch loads down between the MFMAs that consume
         // them (s_waitcnt vmcnt(0) in front of every fourth MFMA) and the double buffer hides nothing
@@ -251,7 +308,8 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 
 template <int ND, int KS, bool BF, int QW = 1>
 static void launch_attn_one(const AttnArgs& a, int batch, hipStream_t s) {
-    const int smem = QW * (KS * 64 + KS * ND * 16 * 64) * (int)sizeof(float);
+    constexpr int D_ = 32 * ND;
+    const int smem = (QW * (KS * 64 + KS * ND * 16 * 64) + (QW > 1 ? 2 * (32 * (D_ + 4) + D_ * 36) : 0)) * (int)sizeof(float);
     dim3 grid(((a.T + 31) / 32 + QW - 1) / QW, a.heads, batch);
     if (a.v_bstride > 0x7fffffffLL || a.o_bstride > 0x7fffffffLL) { fprintf(stderr, "said: attention batch stride exceeds 31 bits\n"); abort(); }
     hipLaunchKernelGGL((attn_kernel<ND, KS, BF, QW>), grid, dim3(64 * KS * QW), smem, s, a.qk, a.v, a.o, (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T,
