@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * CI_W) void conv_in_kernel(const float* x, cons
             const long long bo = (long long)(b + k * B);
             if (nok && t < T) y[(bo * Cout + n) * pitch + t] = val;
             if (stats && nok && lt == 0) {
-                float* so = stats + ((bo * Cout + n) * np + blockIdx.x) * 2;
+                float* so = stats + ((bo * np + blockIdx.x) * Cout + n) * 2;   // [sample][tile][channel][2]
                 so[0] = mean;
                 so[1] = m2;
             }

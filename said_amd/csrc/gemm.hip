@@ -320,7 +320,7 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
         const rsrc_t rp = make_rsrc(part, (unsigned)(a.groups * a.N) * (unsigned)a.res_gn_nparts * 8u);
         const int c_begin = tile0 * 32, c_end = min(a.N, (tile0 + NB) * 32);
         const int g_first = c_begin / a.res_gn_cpg, g_last = (c_end - 1) / a.res_gn_cpg;
-        const GnP fake = {a.res_gn_cpg, a.res_gn_nparts, a.T, a.res_gn_eps, a.res_gn_gamma, a.res_gn_beta};
+        const GnP fake = {a.res_gn_cpg, a.res_gn_nparts, a.T, a.res_gn_eps, a.res_gn_gamma, a.res_gn_beta, a.groups * a.N};
         for (int gb = g_first; gb <= g_last; gb += KS) {
             const int grp = min(gb + w, g_last);
             GnLoads L;
@@ -551,7 +551,7 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
             const float d = (t < a.T) ? (val - mean) : 0.f;
             const float m2 = half32_sum(d * d);
             if (lt == 0 && nl < a.N) {
-                float* so = a.stats_out + (long long)b * a.stats_bstride + ((long long)ng * nparts_out + blockIdx.x) * 2;
+                float* so = a.stats_out + (long long)b * a.stats_bstride + ((long long)blockIdx.x * (a.groups * a.N) + ng) * 2;   // [tile][channel][2]
                 so[0] = mean;
                 so[1] = m2;
             }

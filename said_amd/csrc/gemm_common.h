@@ -163,8 +163,12 @@ __host__ __device__ inline int epi_scratch_floats(int epi, int KS) {
 // scratch: 64*3 + 16*2 floats per wave.
 // ------------------------------------------------------------------------------------------------
 struct GnLoads { float2 v[10]; float ref; float gamma, beta; };
-struct GnP { int gn_cpg, gn_nparts, Tin; float gn_eps; const float* gn_gamma; const float* gn_beta; };
-__device__ __forceinline__ GnP gnp_of(const Seg& sg) { return {sg.gn_cpg, sg.gn_nparts, sg.Tin, sg.gn_eps, sg.gn_gamma, sg.gn_beta}; }
+// GroupNorm partial statistics are stored TILE-major: part[b][tile][channel][2] (mean, M2), `ct` channels per tile row.  A
+// consuming wave reads them with lane <-> channel, so one load instruction touches the 1-4 cache lines that hold its 24-64
+// consecutive channels of one tile; the channel-major layout of round 1 ([channel][tile]) put every lane on a cache line of
+// its own — 10+ loads x 64 lines per wave in 17 kernels of every step.
+struct GnP { int gn_cpg, gn_nparts, Tin; float gn_eps; const float* gn_gamma; const float* gn_beta; int ct; };
+__device__ __forceinline__ GnP gnp_of(const Seg& sg) { return {sg.gn_cpg, sg.gn_nparts, sg.Tin, sg.gn_eps, sg.gn_gamma, sg.gn_beta, sg.C}; }
 
 __device__ __forceinline__ void gn_issue(const GnP sg, rsrc_t rp, int c_lo, int cw, int lane, GnLoads& L) {
     const int nph = (cw <= 32) ? 2 : 1;
@@ -175,14 +179,14 @@ __device__ __forceinline__ void gn_issue(const GnP sg, rsrc_t rp, int c_lo, int 
     // c / cpg for small non-negative ints through one float multiply (exact: the +0.5 keeps the quotient clear of
     // rounding at multiples of cpg); an integer division is ~25 dependent instructions per lane
     const int gfirst = (int)(((float)c + 0.5f) * __builtin_amdgcn_rcpf((float)sg.gn_cpg)) * sg.gn_cpg;
-    L.ref = bload(rp, gfirst * sg.gn_nparts * 8, 0);
+    L.ref = bload(rp, gfirst * 8, 0);   // tile 0 of the group's first channel
     L.gamma = gload(sg.gn_gamma, c);
     L.beta = gload(sg.gn_beta, c);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const int pi = ph + nph * r;
         const bool ok = chok && (pi < sg.gn_nparts);
-        L.v[r] = bload2(rp, ok ? (c * sg.gn_nparts + pi) * 8 : (int)0x80000000, 0);
+        L.v[r] = bload2(rp, ok ? (pi * sg.ct + c) * 8 : (int)0x80000000, 0);
     }
 }
 
@@ -212,7 +216,7 @@ __device__ __forceinline__ void gn_finish(const GnP sg, rsrc_t rp, int c_lo, int
         for (int r = 0; r < 10; ++r) {
             const int pi = ph + nph * (r0 + r);
             const bool ok = chok && (pi < nparts);
-            v[r] = bload2(rp, ok ? (c * nparts + pi) * 8 : (int)0x80000000, 0);
+            v[r] = bload2(rp, ok ? (pi * sg.ct + c) * 8 : (int)0x80000000, 0);
         }
 #pragma unroll
         for (int r = 0; r < 10; ++r) {

@@ -213,10 +213,10 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     // block, the operands, and last the weights, which are not needed before the MFMA loop
     GnLoads gl0, gl1, glr;
     rsrc_t grp_rsrc0 = u0.rx, grp_rsrc1 = u0.rx, grp_rsrcr = u0.rx;
-    GnP gp0 = {1, 1, hd.T, 1e-5f, nullptr, nullptr};
+    GnP gp0 = {1, 1, hd.T, 1e-5f, nullptr, nullptr, 0};
     if constexpr (GN0) {
         const float* gb = hd.w4 + (long long)w_tiles * taps0 * (C0 >> 3) * (WB / 4);   // gamma[C0], beta[C0] behind the weights
-        gp0 = {hd.gn_cfg & 0xffff, hd.gn_cfg >> 16, hd.T, ((hd.pack >> 26) & 1) ? 1e-6f : 1e-5f, gb, gb + C0};
+        gp0 = {hd.gn_cfg & 0xffff, hd.gn_cfg >> 16, hd.T, ((hd.pack >> 26) & 1) ? 1e-6f : 1e-5f, gb, gb + C0, C0};
         const int sb = b;
         grp_rsrc0 = make_rsrc(hd.gn_part + (long long)sb * hd.gn_bstride, (unsigned)C0 * (unsigned)gp0.gn_nparts * 8u);
         gn_issue(gp0, grp_rsrc0, w * (C0 / KS), C0 / KS, l, gl0);
@@ -273,7 +273,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     };
     auto seg_gnp = [&](int s) {
         const unsigned sv = SV(s);
-        GnP p = {AS(sv, gn_cpg), AS(sv, gn_nparts), AS(sv, Tin), AS(sv, gn_eps), AS(sv, gn_gamma), AS(sv, gn_beta)};
+        GnP p = {AS(sv, gn_cpg), AS(sv, gn_nparts), AS(sv, Tin), AS(sv, gn_eps), AS(sv, gn_gamma), AS(sv, gn_beta), AS(sv, C)};
         return p;
     };
     GnP gp1 = gp0, gpr = gp0;
@@ -298,7 +298,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         rg_first = (int)(((float)c_begin + 0.5f) * rcp_rcpg);
         rg_last = (int)(((float)(c_end - 1) + 0.5f) * rcp_rcpg);   // host guarantees rg_last - rg_first < KS
         rg_grp = min(rg_first + w, rg_last);
-        gpr = {rcpg, rnp, aT, AH(res_gn_eps), AH(res_gn_gamma), AH(res_gn_beta)};
+        gpr = {rcpg, rnp, aT, AH(res_gn_eps), AH(res_gn_gamma), AH(res_gn_beta), aN};
         gn_issue(gpr, grp_rsrcr, rg_grp * rcpg, rcpg, l, glr);
     }
     float ln_g = 0.f, ln_b = 0.f;
@@ -888,7 +888,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             const float d = (t < aT) ? (val - mean) : 0.f;
             const float m2 = half32_sum(d * d);
             if (lt == 0 && nl < aN) {
-                float* so = statsp + (long long)b * AH(stats_bstride) + ((long long)ng * nparts_out + (t0 >> 5)) * 2;
+                float* so = statsp + (long long)b * AH(stats_bstride) + ((long long)(t0 >> 5) * aN + ng) * 2;   // [tile][channel][2]
                 gstore(so, 0, mean);
                 gstore(so, 1, m2);
             }

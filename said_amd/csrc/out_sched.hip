@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
     float* red = mainS;                                    // [KS][NH][16][64] after the MFMA loop
 
     // ---- requests: statistics partials first (head of the dependent chain), then operands, weights last ----
-    const GnP gp = {OS_C / 32, a.gn_nparts, T, 1e-5f, a.gn_gamma, a.gn_beta};
+    const GnP gp = {OS_C / 32, a.gn_nparts, T, 1e-5f, a.gn_gamma, a.gn_beta, OS_C};
     GnLoads gl[NH];
     rsrc_t rp[NH], rx[NH];
     f32x4 xv[NH][3];

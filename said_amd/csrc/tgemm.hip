@@ -121,7 +121,7 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
                 for (int e = 0; e < 4; ++e) { const float d = (m + e < a.M) ? v4[e] - mean : 0.f; m2 = fmaf(d, d, m2); }
                 m2 += __shfl_xor(m2, 1); m2 += __shfl_xor(m2, 2); m2 += __shfl_xor(m2, 4);
                 if (tq == 0) {
-                    float* so = a.stats + (long long)b * a.stats_bs + ((long long)n * nparts + (mt >> 5)) * 2;
+                    float* so = a.stats + (long long)b * a.stats_bs + ((long long)(mt >> 5) * a.N + n) * 2;   // [tile][channel][2]
                     so[0] = mean;
                     so[1] = m2;
                 }
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(const float* __restrict__ 
     __shared__ float coef[2 * 192];
     __shared__ float gns[4 * GN_SCRATCH];
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, b = blockIdx.x;
-    const GnP gp = {cpg, nparts, T, eps, gamma, beta};
+    const GnP gp = {cpg, nparts, T, eps, gamma, beta, 192};
     const rsrc_t rp = make_rsrc(part + (long long)b * part_bs, 192u * (unsigned)nparts * 8u);
     GnLoads gl;
     gn_issue(gp, rp, w * 48, 48, l, gl);

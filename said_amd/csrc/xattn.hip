@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * XW) void xattn_kernel(const XAttnArgs a) {
     WFrag wf, wn;
     load_w(a.w1, w, l, wf);
     GnLoads gl;
-    const GnP gp = {6, a.gn_nparts, T, a.gn_eps, a.gn_gamma, a.gn_beta};
+    const GnP gp = {6, a.gn_nparts, T, a.gn_eps, a.gn_gamma, a.gn_beta, XC};
     const rsrc_t rgn = make_rsrc(a.gn_part + (long long)s * a.gn_part_bs, (unsigned)XC * (unsigned)a.gn_nparts * 8u);
     gn_issue(gp, rgn, w * 24, 24, l, gl);
     // o and x_in tiles: thread -> (row = tid >> 2 [+ 128], token quad tid & 3)
