@@ -152,7 +152,7 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0):
     for st in stages:
         name = (f"attn_kernel<D{32 * st['NB']},KS{st['KS']}>" if st["kind"] == 1 else
                 "xattn_kernel" if st["kind"] == 3 else
-                f"tgemm_kernel<{st['NB']},{EPI_NAMES[st['epi']]}>" if st["kind"] == 4 else
+                f"{'fgemm' if st['KS'] == 32 else 'tgemm'}_kernel<{st['NB']},{EPI_NAMES[st['epi']]}>" if st["kind"] == 4 else
                 "prep_kernel" if st["kind"] == 5 else
                 f"{'ugemm' if st['kind'] == 2 else 'cgemm'}_kernel<NB{st['NB']},KS{st['KS']},{EPI_NAMES[st['epi']]}>")
         a = agg.setdefault(name, dict(us=0.0, bytes=0.0, flops=0.0, launches=0))

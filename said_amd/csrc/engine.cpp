@@ -48,10 +48,12 @@ struct PW {  // packed GEMM weight (up to 2 K-segments) + bias
     bool ln_tail = false;                // ... and then by the LayerNorm gamma[C] and beta[C]
 };
 struct ResW { float *g1, *b1, *g2, *b2; PW conv1, conv2, skip; int cin; bool has_skip; float* bias2;
-              void *t_conv1 = nullptr, *t_conv2 = nullptr; /* bf16 [192][taps * cin] (conv2: [576 | 384 skip]) for tgemm.hip */ };
+              void *t_conv1 = nullptr, *t_conv2 = nullptr; /* bf16 [192][taps * cin] (conv2: [576 | 384 skip]) for tgemm.hip */
+              void *tf_conv1 = nullptr, *tf_conv2 = nullptr; /* the same matrices in fp32 (fgemm_kernel) */ };
 struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj, ffproj;
              float *x_w1, *x_wq, *x_w2; /* pack16 copies of out1 / q2 / out2 for the fused chain kernel (xattn.hip) */
-             void *t_qkv = nullptr, *t_ff1 = nullptr, *t_ffproj = nullptr; float* t_ff1_bias = nullptr; /* bf16 weights for tgemm.hip */ };
+             void *t_qkv = nullptr, *t_ff1 = nullptr, *t_ffproj = nullptr; float* t_ff1_bias = nullptr; /* bf16 weights for tgemm.hip */
+             void *tf_qkv = nullptr, *tf_ff1 = nullptr, *tf_ffproj = nullptr; /* fp32 copies (fgemm_kernel) */ };
 struct W2VLayer { PW qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln2g, *ln2b; };
 
 struct ActBuf {  // channel-major activation + its GroupNorm partial statistics
@@ -130,6 +132,7 @@ struct said_ctx {
     void *uPA = nullptr, *uPB = nullptr, *uPL = nullptr, *uPH = nullptr, *uPX = nullptr;   // conv operand [Be][T+2][384], raw cat input
                                                                                             // [Be][T][384], LN'd [Be][T][192], GEGLU out [Be][T][768], raw x2 [Be][T][192]
     bool unet_tgemm = true;   // SAID_NO_UNET_TGEMM=1 keeps the channel-major kernels in bf16 mode at every batch size
+    bool unet_fgemm = true;   // SAID_NO_UNET_FGEMM=1: the same for the fp32 mode's token-major path (fgemm_kernel)
     long long unet_tgemm_min_tokens = 8192;
 
     // ---- audio workspace (lazily sized) ----
@@ -301,6 +304,18 @@ int upload_bf16(said_ctx* ctx, void** out, const float* W, size_t N, size_t C, s
     if (dalloc(ctx, &d, h.size(), false)) return -1;
     HIPCHK(hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     *out = d;
+    return 0;
+}
+// the same matrix in bf16 AND fp32 (UNet operands of the token-major GEMMs: the precision mode is chosen per call)
+int upload_tm_pair(said_ctx* ctx, void** out_bf, void** out_f32, const float* W, size_t N, size_t C, size_t taps) {
+    if (upload_bf16(ctx, out_bf, W, N, C, taps)) return -1;
+    std::vector<float> h(N * C * taps);
+    for (size_t n = 0; n < N; ++n)
+        for (size_t t = 0; t < taps; ++t)
+            for (size_t c = 0; c < C; ++c) h[(n * taps + t) * C + c] = W[(n * C + c) * taps + t];
+    float* d = nullptr;
+    if (upload(ctx, &d, h.data(), h.size())) return -1;
+    *out_f32 = d;
     return 0;
 }
 std::vector<int> rows_dense(int N, int row0 = 0) {
@@ -494,19 +509,28 @@ void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hi
 // what changes is the GEMM itself: a prep kernel applies the fused operand transform once and writes the operand token-major
 // in bf16, and the GEMM runs as 128-token tiles on v_mfma_f32_32x32x16_bf16 without any split-K reduction.
 bool use_tg(said_ctx* c, const UGeo& g, int nsamples) {
-    return c->bf16_mode && c->unet_tgemm && !c->clk_on && (long long)nsamples * g.T >= c->unet_tgemm_min_tokens;
+    return (c->bf16_mode ? c->unet_tgemm : c->unet_fgemm) && !c->clk_on && (long long)nsamples * g.T >= c->unet_tgemm_min_tokens;
 }
+// weight of the token-major GEMM in the context's precision mode
+inline const void* tw(const said_ctx* c, const void* bf, const void* f32) { return c->bf16_mode ? bf : f32; }
 void do_prep(said_ctx* c, const PrepArgs& a, int batch, hipStream_t s) {
-    if (c->log_on) c->stage_log.push_back({5, -2, 0, 0, (double)batch * a.C * a.T * (4.0 + 2.0), 0.0});
-    if (dbg_go(c)) launch_prep(a, batch, s);
+    if (c->log_on) c->stage_log.push_back({5, -2, 0, 0, (double)batch * a.C * a.T * (4.0 + (c->bf16_mode ? 2.0 : 4.0)) * (a.dst2 ? 1.5 : 1.0), 0.0});
+    PrepArgs a2 = a;
+    a2.f32 = c->bf16_mode ? 0 : 1;
+    if (dbg_go(c)) launch_prep(a2, batch, s);
 }
 void do_tgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     if (c->log_on) {
-        const double out_b = a.geglu ? a.N / 2 * 2.0 : (a.y_cm ? 4.0 * a.N * (a.res_cm ? 2 : 1) : 4.0 * a.N);
-        c->stage_log.push_back({4, a.geglu ? EPI_GEGLU : (a.qk ? EPI_QKV : EPI_STORE), a.N % 128 == 0 ? 128 : 64, 4,
-                                2.0 * a.N * a.K + (double)batch * a.M * (2.0 * a.K + out_b), 2.0 * batch * (double)a.M * a.N * a.K});
+        const double eb = c->bf16_mode ? 2.0 : 4.0;   // operand element size; KS = 32 marks the fp32 kernel (fgemm_kernel) in the log
+        const double out_b = a.geglu ? a.N / 2 * eb : (a.y_cm ? 4.0 * a.N * (a.res_cm ? 2 : 1) : 4.0 * a.N);
+        const int tile_n = c->bf16_mode ? (a.N % 128 == 0 ? 128 : 64) : ((a.N % 128 == 0 && (a.geglu || a.N % 96)) ? 128 : 96);
+        c->stage_log.push_back({4, a.geglu ? EPI_GEGLU : (a.qk ? EPI_QKV : EPI_STORE), tile_n, c->bf16_mode ? 4 : 32,
+                                eb * a.N * a.K + (double)batch * a.M * (eb * a.K + out_b), 2.0 * batch * (double)a.M * a.N * a.K});
     }
-    if (dbg_go(c)) launch_tgemm(a, batch, s);
+    TGemmArgs a2 = a;
+    a2.f32 = c->bf16_mode ? 0 : 1;
+    if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }   // token-major intermediate (GEGLU product) in fp32
+    if (dbg_go(c)) launch_tgemm(a2, batch, s);
 }
 // per-sample row pitch of the token-major operands: a multiple of 32 that holds the T tokens plus the two Conv1d padding rows, so
 // that all samples form ONE row axis for the 256-row GEMM tiles (tgemm.h: seg_rows) and 32-row MFMA tiles never straddle samples
@@ -557,7 +581,7 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
                 if (rw.has_skip) { q.dst2 = c->uPB; q.dst2_bs = T2 * 2 * MC; q.ldd2 = 2 * MC; q.coff2 = MC; }
                 do_prep(c, q, nb, s);
             }
-            TGemmArgs t = mktg(g, c->uPA, rw.cin, rw.t_conv1, MC, 3 * rw.cin);
+            TGemmArgs t = mktg(g, c->uPA, rw.cin, tw(c, rw.t_conv1, rw.tf_conv1), MC, 3 * rw.cin);
             t.bias = rw.conv1.bias;
             t.emb = c->EO + (long long)rb_index * MC * c->maxNp; t.emb_pitch = c->maxNp; t.step_ptr = g.step_ptr; t.emb_b_stride = g.emb_b_stride;
             tg_cm_out(t, g, c->M);
@@ -567,7 +591,7 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
             PrepArgs p = mkprep(g, c->M.p, 0, c->uPA, T2 * MC, MC, 0);
             prep_gn(c, p, g, c->M.st, 6, 1e-5f, rw.g2, rw.b2, nb, 0, s);
             do_prep(c, p, nb, s);
-            TGemmArgs t = mktg(g, c->uPA, MC, rw.t_conv2, MC, 3 * MC);
+            TGemmArgs t = mktg(g, c->uPA, MC, tw(c, rw.t_conv2, rw.tf_conv2), MC, 3 * MC);
             if (rw.has_skip) {   // 1x1 conv over the concatenated raw input as a second K segment
                 // (the raw copies of the two inputs were written into uPB by the in_layers operand preparation above)
                 t.a2 = c->uPB; t.a2_bs = 0; t.lda2 = 2 * MC; t.K1 = 3 * MC; t.K = 5 * MC;
@@ -644,7 +668,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         prep_gn(c, p, g, in.st, 6, 1e-6f, sw.gn_g, sw.gn_b, n1, 0, s);
         p.ln_gamma = sw.l1g; p.ln_beta = sw.l1b;
         do_prep(c, p, n1, s);
-        TGemmArgs t = mktg(g, c->uPL, MC, sw.t_qkv, 3 * MC, MC);
+        TGemmArgs t = mktg(g, c->uPL, MC, tw(c, sw.t_qkv, sw.tf_qkv), 3 * MC, MC);
         t.qk = c->QK; t.vt = c->VT; t.v_bs = (long long)MC * g.Tp; t.qk_n = 2 * MC; t.head_dim = HD; t.rows = vt_rows; t.heads2 = 2 * HEADS; t.v_pitch = g.Tp;
         do_tgemm(c, t, n1, s);
     } else
@@ -754,13 +778,13 @@ geglu:
             p.ln_gamma = sw.l3g; p.ln_beta = sw.l3b;
             p.dst2 = c->uPX; p.dst2_bs = P * MC; p.ldd2 = MC; p.coff2 = 0;
             do_prep(c, p, g.Be, s);
-            TGemmArgs t = mktg(g, c->uPL, MC, sw.t_ff1, 2 * FFI, MC);
+            TGemmArgs t = mktg(g, c->uPL, MC, tw(c, sw.t_ff1, sw.tf_ff1), 2 * FFI, MC);
             t.bias = sw.t_ff1_bias; t.geglu = 1;
             t.yb = c->uPH; t.y_bs = P * FFI; t.ldy = FFI;
             do_tgemm(c, t, g.Be, s);
         }
         {   // proj_out o ff.net.2 over [h ; x2] + x_in, channel-major result + GroupNorm partials
-            TGemmArgs t = mktg(g, c->uPH, FFI, sw.t_ffproj, MC, FFI + MC);
+            TGemmArgs t = mktg(g, c->uPH, FFI, tw(c, sw.t_ffproj, sw.tf_ffproj), MC, FFI + MC);
             t.a2 = c->uPX; t.a2_bs = 0; t.lda2 = MC; t.K1 = FFI;
             t.bias = sw.ffproj.bias;
             t.res_cm = in.p; t.res_cm_bs = g.hs;
@@ -1001,6 +1025,7 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     ctx->use_xattn = getenv("SAID_XATTN") != nullptr;
     ctx->audio_bf16 = getenv("SAID_NO_AUDIO_BF16") == nullptr;
     ctx->unet_tgemm = getenv("SAID_NO_UNET_TGEMM") == nullptr;
+    ctx->unet_fgemm = getenv("SAID_NO_UNET_FGEMM") == nullptr;
     if (getenv("SAID_UNET_TGEMM_MIN")) ctx->unet_tgemm_min_tokens = atoll(getenv("SAID_UNET_TGEMM_MIN"));
     configure_tgemm_kernel();
     configure_xattn_kernel();   // parallel graph branches measured no faster on ROCm 7.2: off by default
@@ -1033,13 +1058,13 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     rc |= dalloc(ctx, &ctx->init_cm, Be * 32 * Tp); rc |= dalloc(ctx, &ctx->enoise_cm, Be * 32 * Tp); rc |= dalloc(ctx, &ctx->mask_cm, Be * 32 * Tp);
     rc |= dalloc(ctx, &ctx->rescale_part, Be * 2 * 64 * 3);
     rc |= dalloc(ctx, &ctx->freqs, MC / 2);
-    {   // bf16 operand buffers of the large-batch bf16 path (2 bytes per element; zero-initialised, so padding rows start at 0)
+    {   // operand buffers of the large-batch token-major path (sized for fp32 elements; zero-initialised, so padding rows start at 0)
         const size_t Tm = (size_t)rup(max_frames + 2, 32);   // tg_rows(): per-sample row pitch
-        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPA), Be * Tm * 2 * MC + 4096);
-        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPB), Be * Tm * 2 * MC + 4096);
-        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPL), Be * Tm * MC + 4096);
-        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPH), Be * Tm * FFI + 4096);
-        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPX), Be * Tm * MC + 4096);
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPA), 2 * (Be * Tm * 2 * MC + 4096));
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPB), 2 * (Be * Tm * 2 * MC + 4096));
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPL), 2 * (Be * Tm * MC + 4096));
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPH), 2 * (Be * Tm * FFI + 4096));
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPX), 2 * (Be * Tm * MC + 4096));
         rc |= dalloc(ctx, &ctx->gn_coef, 2 * Be * 2 * MC);
     }
     if (rc) { g_create_err = ctx->err; said_destroy(ctx); return -1; }
@@ -1112,7 +1137,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
         if (upvec(ctx, &rw.g2, p + ".out_layers.0.weight", MC) || upvec(ctx, &rw.b2, p + ".out_layers.0.bias", MC)) return -1;
         if (make_pw(ctx, &rw.conv2, p + ".out_layers.3.weight", p + ".out_layers.3.bias", MC, MC, 3, 1, p + ".out_layers.0.weight", p + ".out_layers.0.bias")) return -1;
         {   // tgemm.hip operands: conv1 [192][3 * cin] tap-major; conv2 [192][576 (+ 384 skip columns)]
-            if (upload_bf16(ctx, &rw.t_conv1, ctx->host_w[p + ".in_layers.2.weight"].data.data(), MC, (size_t)rw.cin, 3)) return -1;
+            if (upload_tm_pair(ctx, &rw.t_conv1, &rw.tf_conv1, ctx->host_w[p + ".in_layers.2.weight"].data.data(), MC, (size_t)rw.cin, 3)) return -1;
             const HostTensor& c2w = ctx->host_w[p + ".out_layers.3.weight"];
             std::vector<float> cat((size_t)MC * (3 * MC + (rw.has_skip ? 2 * MC : 0)));
             const size_t Kc = 3 * MC + (rw.has_skip ? 2 * MC : 0);
@@ -1123,7 +1148,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
                     for (int cc = 0; cc < MC; ++cc) cat[n * Kc + t * MC + cc] = c2w.data[((size_t)n * MC + cc) * 3 + t];
                 if (sk) for (int cc = 0; cc < 2 * MC; ++cc) cat[n * Kc + 3 * MC + cc] = sk->data[(size_t)n * 2 * MC + cc];
             }
-            if (upload_bf16(ctx, &rw.t_conv2, cat.data(), MC, Kc, 1)) return -1;
+            if (upload_tm_pair(ctx, &rw.t_conv2, &rw.tf_conv2, cat.data(), MC, Kc, 1)) return -1;
         }
         const HostTensor* ew = getw(ctx, p + ".emb_layers.1.weight", {MC, TE});
         const HostTensor* eb = getw(ctx, p + ".emb_layers.1.bias", {MC});
@@ -1235,7 +1260,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
             PW t0, t1;
             if (make_pw(ctx, &t0, "__ffproj.w0", "__ffproj.b", MC, FFI, 0) || make_pw(ctx, &t1, "__ffproj.w1", "", MC, MC, 0)) return -1;
             {   // tgemm.hip operands of this block: q/k/v rows, GEGLU rows tile-interleaved (value, gate), [P F2 | P]
-                if (upload_bf16(ctx, &sw.t_qkv, qkv.data(), 3 * MC, MC, 1)) return -1;
+                if (upload_tm_pair(ctx, &sw.t_qkv, &sw.tf_qkv, qkv.data(), 3 * MC, MC, 1)) return -1;
                 const HostTensor* f1 = getw(ctx, b + ".ff.net.0.proj.weight", {2 * FFI, MC});
                 const HostTensor* f1b = getw(ctx, b + ".ff.net.0.proj.bias", {2 * FFI});
                 if (!f1 || !f1b) return -1;
@@ -1245,7 +1270,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
                     std::copy(f1->data.begin() + (size_t)src * MC, f1->data.begin() + (size_t)(src + 1) * MC, pw.begin() + (size_t)np * MC);
                     pb[np] = f1b->data[src];
                 }
-                if (upload_bf16(ctx, &sw.t_ff1, pw.data(), 2 * FFI, MC, 1) || upload(ctx, &sw.t_ff1_bias, pb.data(), pb.size())) return -1;
+                if (upload_tm_pair(ctx, &sw.t_ff1, &sw.tf_ff1, pw.data(), 2 * FFI, MC, 1) || upload(ctx, &sw.t_ff1_bias, pb.data(), pb.size())) return -1;
                 const HostTensor& w0 = ctx->host_w["__ffproj.w0"];
                 const HostTensor& w1 = ctx->host_w["__ffproj.w1"];
                 std::vector<float> cat((size_t)MC * (FFI + MC));
@@ -1253,7 +1278,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
                     std::copy(w0.data.begin() + (size_t)n * FFI, w0.data.begin() + (size_t)(n + 1) * FFI, cat.begin() + (size_t)n * (FFI + MC));
                     std::copy(w1.data.begin() + (size_t)n * MC, w1.data.begin() + (size_t)(n + 1) * MC, cat.begin() + (size_t)n * (FFI + MC) + FFI);
                 }
-                if (upload_bf16(ctx, &sw.t_ffproj, cat.data(), MC, FFI + MC, 1)) return -1;
+                if (upload_tm_pair(ctx, &sw.t_ffproj, &sw.tf_ffproj, cat.data(), MC, FFI + MC, 1)) return -1;
             }
             PW& fp = sw.ffproj;
             fp.N = MC; fp.taps = 1; fp.nseg = 2; fp.bias = t0.bias;

@@ -1,4 +1,5 @@
-// tgemm.h — launch interface of the bf16 token-major GEMM and its companion kernels (tgemm.hip).
+// tgemm.h — launch interface of the token-major GEMMs (bf16: tgemm_kernel / tgemm256_kernel, fp32: fgemm_kernel) and their
+// companion kernels (tgemm.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -52,6 +53,7 @@ struct TGemmArgs {
     // (seg_rows % 32 == 0, >= M); row R is sample R / seg_rows, token R % seg_rows; tokens >= M are padding.  0: per-sample
     // operands addressed through a_bs (audio encoder).
     int seg_rows;
+    int f32;               // 1: A and W are fp32 (fgemm_kernel on v_mfma_f32_32x32x2_f32; fp32 mode, large batches); K % 32 == 0
     int dbg;               // timing experiments (SAID_TG_DBG): bit 0 = skip the epilogue, bit 1 = skip the K loop
     // value channel of the first column of a GEGLU value tile starting at permuted column n (see tgemm_geglu_src_row)
     __host__ __device__ int geglu_c0(int n) const { return (n / 256) * 128 + ((n % 256) / 128) * 64 + ((n % 128) / 64) * 32; }
@@ -70,6 +72,7 @@ struct PrepArgs {
     void* dst; long long dst_bs; int ldd, coff;
     void* dst2; long long dst2_bs; int ldd2, coff2;
     int mode;
+    int f32;               // 1: dst / dst2 are fp32 (operands of the fp32 token-major GEMM), else bf16
 };
 void launch_prep(const PrepArgs& a, int batch, hipStream_t s);
 // GroupNorm coefficients of a 192-channel tensor from its Welford partials [b][192][nparts][2] -> coef_out[b][192][2]

@@ -397,11 +397,182 @@ __global__ __launch_bounds__(512) void tgemm256_kernel(const TGemmArgs a) {
     tg_epilogue<NJ>(a, acc1, b, m0 + wm * 64 + 32, n0 + wn * (32 * NJ), l, sc);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// fp32 token-major GEMM (fp32 mode, large batches: BASELINE configs[3]'s per-GPU work) on v_mfma_f32_32x32x2_f32.
+// Same operand geometry in BYTES as the bf16 kernels — a k-tile is 128 bytes per row (32 floats), LDS rows 144 bytes, 16-byte
+// fragment reads — and the same epilogue.  A lane's 16-byte fragment holds k = 8 s + 4 (l >> 5) + {0..3}; MFMA i of step s
+// multiplies element i of the A and W fragments, i.e. the k pair (8 s + i, 8 s + 4 + i) — a permutation of k both operands share.
+//
+// Workgroup: tile 64 rows x 32 NJ columns, ONE LDS operand buffer (23-28 KB), FOUR waves = 2 row halves x 2 K HALVES: wave
+// (r, kh) multiplies rows 32 r .. 32 r + 31 by k = 16 kh .. 16 kh + 15 of every 32-k tile; the two K halves are added through
+// LDS once, after the loop (12-16 KB per pair), and wave (r, 0) runs the epilogue.  3-4 workgroups share a CU, each in its own
+// phase, so one's prologue / barriers / epilogue hide under the others' MFMAs.
+//
+// Why this shape (every step measured on the MI355X, scripts/gpu_r2_m.sh ... gpu_r2_u.sh):
+//  * the channel-major ugemm family splits K over the 8 waves of a 32-token tile and pays a 64 KB LDS reduction per tile: 40 % of
+//    the fp32 MFMA roof at Be = 64.  A first token-major shape (64 x 192 tile, 4 waves, each 32 x 96 over the whole K, double-
+//    buffered) ran the 192-wide convolutions at 144 us where the MFMAs alone need 55.
+//  * these GEMMs are MFMA-bound, and an MFMA-bound launch is a bin-packing of indivisible wave-tiles onto 1024 SIMDs: 38912 rows
+//    x 192 columns in 32 x 96 wave-tiles over the whole K are 2432 units = 2.375 per SIMD -> 3 on the busiest, 79 % at best,
+//    whatever the workgroup shape.  Halving K per wave halves the unit (4.75 -> 5 per SIMD: 95 %) WITHOUT extra operand traffic
+//    — all four waves read the same LDS tiles.  (Smaller output tiles would also balance, but cost L2 bandwidth, see below.)
+//  * knock-outs of this kernel's loop: no barriers -0 %, no LDS stores -3 %, no global loads -22 %.  The loads are not waited
+//    for (average L2 latency seen by the L1 is 219 clocks, TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ; a second register set,
+//    PF = 2, buys 5 %); what they cost is CLOCK: scripts/ubench/mfma_with_loads.hip — pure fp32 MFMA loops on all CUs — sustains
+//    150 TFLOP/s alone, 135 with 3.2 TB/s of independent L2 loads beside them, 114 with 5.4 TB/s, 112 with 10.5 TB/s.  A 64 x 96
+//    tile needs 20 KB per 48 MFMA-times: ~5 TB/s at the rate it runs.  So ~115 TFLOP/s is the practical roof of an fp32 GEMM at
+//    these tile sizes, and this kernel's 93-98 (convolutions), 87 (q/k/v, K = 192) and 93 (GEGLU) sit at 75-85 % of it.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int FBK = 32, FLP = 36;   // k per tile, LDS row pitch (floats)
+template <int NJ>
+__host__ __device__ constexpr int fgemm_lds_bytes() {
+    const int tiles = (64 + 32 * NJ) * FLP * 4, scratch = 2 * 32 * (32 * NJ + 4) * 4;
+    return tiles > scratch ? tiles : scratch;
+}
+// NJ = 3: 64 x 96 tile (N = 192 / 576), NJ = 4: 64 x 128 (GEGLU, value / gate column tiles interleaved as for the bf16 kernel).
+// PF = 2: two register sets, the tile two k-steps ahead is in flight while the current one multiplies.
+template <int NJ, int PF>
+__global__ __launch_bounds__(256, NJ == 3 ? 4 : 3) void fgemm_kernel(const TGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [A 64 x 36 | W BN x 36] floats
+    float* const ldsf = reinterpret_cast<float*>(lds);
+    constexpr int BM = 64, BN = 32 * NJ, NTH = 256;
+    constexpr int ACH = BM * 8 / NTH, WCH = BN * 8 / NTH;   // 16-byte chunks per thread and tile: 2, NJ
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int wr = w & 1, kh = w >> 1;
+    const int rows_tot = a.batch * a.seg_rows;   // batch-as-rows addressing only (tgemm_supports)
+    const int NT = a.N / BN, MT = (rows_tot + BM - 1) / BM;
+    const unsigned L = blockIdx.x, xcd = L & 7u, slot = L >> 3;   // XCD-aware order, as in tgemm_kernel
+    const int nt = (int)(slot % (unsigned)NT);
+    const int mg = (int)(slot / (unsigned)NT) * 8 + (int)xcd;
+    if (mg >= MT) return;   // padding of the tile count to a multiple of 8 (the whole workgroup exits together)
+    const int m0 = mg * BM, n0 = nt * BN;
+    const float* A = reinterpret_cast<const float*>(a.a);
+    const float* A2 = reinterpret_cast<const float*>(a.a2);
+    const float* W = reinterpret_cast<const float*>(a.w);
+    const int nk = a.K / FBK;
+    const int nk1 = (a.a2 ? a.K1 : a.K) / FBK;
+
+    f32x4t ra[ACH], rw[WCH], ra1[PF == 2 ? ACH : 1], rw1[PF == 2 ? WCH : 1];
+    int aoff[ACH], a2off[ACH], woff[WCH];   // element offsets: < 2^31 (host-checked)
+    int loff[ACH], lwoff[WCH];
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+        const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
+        const int m = min(m0 + row, rows_tot - 1);
+        aoff[i] = m * a.lda + kp * 4;
+        a2off[i] = m * a.lda2 + kp * 4;
+        loff[i] = row * FLP + kp * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
+        woff[i] = (n0 + row) * a.K + kp * 4;
+        lwoff[i] = BM * FLP + row * FLP + kp * 4;
+    }
+    auto gload_tile = [&](f32x4t* xa, f32x4t* xw, int kt) {
+        const bool first = kt < nk1;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const float* p = first ? A + (aoff[i] + kt * FBK) : A2 + (a2off[i] + (kt - nk1) * FBK);
+            xa[i] = *reinterpret_cast<const f32x4t*>(p);
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) xw[i] = *reinterpret_cast<const f32x4t*>(W + (woff[i] + kt * FBK));
+    };
+    auto lds_store = [&](const f32x4t* xa, const f32x4t* xw) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4t*>(ldsf + loff[i]) = xa[i];
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) *reinterpret_cast<f32x4t*>(ldsf + lwoff[i]) = xw[i];
+    };
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int frow = l & 31, fk = 4 * (l >> 5) + 16 * kh;
+    const float* const pa = ldsf + (wr * 32 + frow) * FLP + fk;
+    const float* const pw = ldsf + BM * FLP + frow * FLP + fk;
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f32x4t fa = *reinterpret_cast<const f32x4t*>(pa + ks * 8);
+            f32x4t fb[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const f32x4t*>(pw + j * 32 * FLP + ks * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j][i], acc[j], 0, 0, 0);
+        }
+    };
+    // Every load and LDS store of the loop is unconditional, as in tgemm_kernel (steps past the end re-request the last tile).
+    // One k-step: request a later tile -> multiply the tile in LDS -> barrier (all four waves have read it) -> park the next
+    // tile -> barrier.
+    const int nloop = (a.dbg & 2) ? 0 : nk;
+    gload_tile(ra, rw, 0);
+    if constexpr (PF == 2) gload_tile(ra1, rw1, min(1, nk - 1));
+    lds_store(ra, rw);
+    __syncthreads();
+    if constexpr (PF == 2) {
+        for (int kt = 0; kt < nloop; kt += 2) {
+            gload_tile(ra, rw, min(kt + 2, nk - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            compute();
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            lds_store(ra1, rw1);
+            __syncthreads();
+            gload_tile(ra1, rw1, min(kt + 3, nk - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) compute();
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            lds_store(ra, rw);
+            __syncthreads();
+        }
+    } else {
+        for (int kt = 0; kt < nloop; ++kt) {
+            gload_tile(ra, rw, min(kt + 1, nk - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            compute();
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            lds_store(ra, rw);
+            __syncthreads();
+        }
+    }
+    // ---- add the two K halves: wave (r, 1) parks its accumulators in region r (lane-linear), wave (r, 0) adds them and runs the
+    // epilogue with the same region as its transposition scratch (the operand tile is dead after the loop's last barrier)
+    float* sc = ldsf + wr * (32 * (32 * NJ + 4));
+    if (kh == 1) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[(j * 16 + r) * 64 + l] = acc[j][r];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] += sc[(j * 16 + r) * 64 + l];
+    __builtin_amdgcn_wave_barrier();
+    tg_epilogue<NJ>(a, acc, 0, m0 + wr * 32, n0, l, sc);
+}
+
 bool tgemm_supports(const TGemmArgs& a) {
+    if (a.f32) {   // fp32 kernel: 4-float chunks, 32-float k-tiles; 96- or 128-wide column tiles; batch-as-rows addressing only
+        if (!(a.M >= 1 && (a.N % 96 == 0 || a.N % 128 == 0) && a.K >= FBK && a.K % FBK == 0 && a.lda % 4 == 0 && a.seg_rows > 0)) return false;
+        if (a.geglu && a.N % 128) return false;
+        if (a.a2 && (a.K1 % FBK || a.K1 <= 0 || a.K1 >= a.K || a.lda2 % 4)) return false;
+        if (a.geglu && (a.N % 256 || !a.yf)) return false;
+        if (a.yb) return false;
+    } else
     if (!(a.M >= 1 && a.N >= 64 && a.N % 64 == 0 && a.K >= TBK && a.K % TBK == 0 && a.lda % 8 == 0 && a.a_bs % 8 == 0)) return false;
     if (a.qk && (a.qk_n % 32 || a.head_dim % 32)) return false;
     if (a.a2 && (a.K1 % TBK || a.K1 <= 0 || a.K1 >= a.K || a.lda2 % 8 || a.a2_bs % 8)) return false;
-    if (a.geglu && (a.N % 256 || !a.yb)) return false;   // the GEGLU row interleaving is the 256-wide tile's (tgemm_geglu_src_row)
+    if (!a.f32 && a.geglu && (a.N % 256 || !a.yb)) return false;   // the GEGLU row interleaving is the 256-wide tile's (tgemm_geglu_src_row)
     if (a.y_cm && (a.cm_pitch % 4 || a.cm_pitch < ((a.M + 3) & ~3))) return false;
     if (a.seg_rows && (a.seg_rows % 32 || a.seg_rows < a.M)) return false;
     if ((long long)a.N * a.K > 0x7fffffffLL) return false;   // 32-bit element offsets in the 256-row kernel
@@ -419,6 +590,8 @@ void configure_tgemm_kernel() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TBM + 64) * TLP * 2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm256_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * TLP * 2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm256_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 192) * TLP * 2);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<4>());
 }
 void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
     if (!tgemm_supports(a)) { fprintf(stderr, "said: tgemm shape M=%d N=%d K=%d unsupported\n", a.M, a.N, a.K); abort(); }
@@ -429,6 +602,14 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
     static const bool no256 = getenv("SAID_NO_TGEMM256") != nullptr;
     const long long rows_tot = a.seg_rows > 0 ? (long long)batch * a.seg_rows : a.M;
     const int nb = a.seg_rows > 0 ? 1 : batch;
+    if (a.f32) {
+        if ((rows_tot + 2) * (long long)std::max(a.lda, a.lda2) >= 0x7fffffffLL) { fprintf(stderr, "said: fgemm operand too large for 32-bit offsets\n"); abort(); }
+        const long long mt8 = ((rows_tot + 63) / 64 + 7) / 8 * 8;   // 64-row tiles, padded to the 8 XCDs
+        constexpr int LDS3 = fgemm_lds_bytes<3>(), LDS4 = fgemm_lds_bytes<4>();
+        if (a.N % 128 == 0 && (a.geglu || a.N % 96)) hipLaunchKernelGGL((fgemm_kernel<4, 1>), dim3((unsigned)(mt8 * (a.N / 128))), dim3(256), LDS4, s, a2);
+        else hipLaunchKernelGGL((fgemm_kernel<3, 2>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
+        return;
+    }
     const bool big = !no256 && (a.N % 256 == 0 || a.N % 192 == 0) && rows_tot * nb >= 4096 &&
                      (rows_tot + 2) * (long long)std::max(a.lda, a.lda2) < 0x7fffffffLL;
     if (a.geglu && !big) { fprintf(stderr, "said: the GEGLU epilogue needs the 256-wide tile\n"); abort(); }
@@ -548,6 +729,40 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs a) {
     if (ln) { mu = lnst[tt][0]; rs = lnst[tt][1]; }
     const int row_off = a.mode == 0 ? 1 : 0;   // conv operand: row 0 is the left padding
     const bool tv = t < T;
+    if (a.f32) {   // fp32 operands (fgemm_kernel): the same mapping, 96 contiguous bytes per thread
+        if (tv || (a.mode == 0 && t == T)) {
+            __attribute__((aligned(16))) float o[24];
+            __attribute__((aligned(16))) float r[24];
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const int c = part * 24 + i;
+                const float raw = tile[c][tt];
+                float x = raw;
+                if (gn) x = fmaf(x, coefS[c][0], coefS[c][1]);
+                if (a.mode == 0) x = silu_f(x);
+                if (ln) x = fmaf((x - mu) * rs, a.ln_gamma[c], a.ln_beta[c]);
+                o[i] = tv ? x : 0.f;
+                r[i] = raw;
+            }
+            f32x4t* d = reinterpret_cast<f32x4t*>(reinterpret_cast<float*>(a.dst) + (long long)b * a.dst_bs + (long long)(t + row_off) * a.ldd + a.coff + part * 24);
+            const f32x4t* os = reinterpret_cast<const f32x4t*>(o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i] = os[i];
+            if (a.dst2 && tv) {
+                f32x4t* d2 = reinterpret_cast<f32x4t*>(reinterpret_cast<float*>(a.dst2) + (long long)b * a.dst2_bs + (long long)t * a.ldd2 + a.coff2 + part * 24);
+                const f32x4t* rs_ = reinterpret_cast<const f32x4t*>(r);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) d2[i] = rs_[i];
+            }
+        }
+        if (a.mode == 0 && t0 == 0 && tt == 0) {   // left padding row
+            f32x4t* z = reinterpret_cast<f32x4t*>(reinterpret_cast<float*>(a.dst) + (long long)b * a.dst_bs + a.coff + part * 24);
+            const f32x4t zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) z[i] = zero;
+        }
+        return;
+    }
     if (tv || (a.mode == 0 && t == T)) {   // the conv operand's right padding row (token T) is written as zeros
         __attribute__((aligned(16))) __bf16 o[24];
         __attribute__((aligned(16))) __bf16 r[24];

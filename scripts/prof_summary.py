@@ -27,7 +27,7 @@ print(f"{len(rows)} dispatches, {tot/1e3:.2f} ms of kernel time")
 print(f"{'total ms':>10} {'calls':>7} {'avg us':>9} {'%':>6}  kernel")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
     print(f"{v[1]/1e3:10.3f} {v[0]:7d} {v[1]/v[0]:9.2f} {100*v[1]/tot:6.1f}  {k}")
-idx = [i for i, r in enumerate(rows) if "sched_step" in r[0]]   # last kernel of a denoise step
+idx = [i for i, r in enumerate(rows) if "sched_step" in r[0] or "out_sched" in r[0]]   # last kernel of a denoise step
 if len(idx) > 3:
     gaps = collections.Counter(b - a for a, b in zip(idx, idx[1:]))
     step_len = gaps.most_common(1)[0][0]
