@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "gemm_common.h"
 #include "tgemm.h"
@@ -423,18 +424,25 @@ __global__ __launch_bounds__(512) void tgemm256_kernel(const TGemmArgs a) {
 //    tile needs 20 KB per 48 MFMA-times: ~5 TB/s at the rate it runs.  So ~115 TFLOP/s is the practical roof of an fp32 GEMM at
 //    these tile sizes, and this kernel's 93-98 (convolutions), 87 (q/k/v, K = 192) and 93 (GEGLU) sit at 75-85 % of it.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int FBK = 32, FLP = 36;   // k per tile, LDS row pitch (floats)
+constexpr int FBK = 32;   // k per tile of the fp32 kernel (host-side checks)
 template <int NJ>
 __host__ __device__ constexpr int fgemm_lds_bytes() {
-    const int tiles = (64 + 32 * NJ) * FLP * 4, scratch = 2 * 32 * (32 * NJ + 4) * 4;
+    const int tiles = (64 + 32 * NJ) * 144, scratch = 2 * 32 * (32 * NJ + 4) * 4;
     return tiles > scratch ? tiles : scratch;
 }
 // NJ = 3: 64 x 96 tile (N = 192 / 576), NJ = 4: 64 x 128 (GEGLU, value / gate column tiles interleaved as for the bf16 kernel).
 // PF = 2: two register sets, the tile two k-steps ahead is in flight while the current one multiplies.
-template <int NJ, int PF>
+// BF: the same workgroup on bf16 operands (bf16 mode's UNet GEMMs): a k-tile is again 128 bytes per row (64 halfs), each K half
+// two v_mfma_f32_32x32x16_bf16 per column tile.  There the point is not MFMA balance but spread: the 256-row bf16 tiles put a
+// 192-wide convolution on 152 workgroups of a 256-CU chip, and its time is the fp32 epilogue traffic (§7.3).
+template <int NJ, int PF, bool BF>
 __global__ __launch_bounds__(256, NJ == 3 ? 4 : 3) void fgemm_kernel(const TGemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [A 64 x 36 | W BN x 36] floats
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [A 64 rows | W BN rows] x 144 bytes
     float* const ldsf = reinterpret_cast<float*>(lds);
+    typedef typename std::conditional<BF, unsigned short, float>::type elt_t;
+    constexpr int EPC = BF ? 8 : 4;              // elements per 16-byte chunk
+    constexpr int FBK = 8 * EPC, FLP = 9 * EPC;  // k per tile (128 bytes), LDS row pitch (144 bytes), in elements
+    elt_t* const ldse = reinterpret_cast<elt_t*>(lds);
     constexpr int BM = 64, BN = 32 * NJ, NTH = 256;
     constexpr int ACH = BM * 8 / NTH, WCH = BN * 8 / NTH;   // 16-byte chunks per thread and tile: 2, NJ
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
@@ -446,9 +454,9 @@ __global__ __launch_bounds__(256, NJ == 3 ? 4 : 3) void fgemm_kernel(const TGemm
     const int mg = (int)(slot / (unsigned)NT) * 8 + (int)xcd;
     if (mg >= MT) return;   // padding of the tile count to a multiple of 8 (the whole workgroup exits together)
     const int m0 = mg * BM, n0 = nt * BN;
-    const float* A = reinterpret_cast<const float*>(a.a);
-    const float* A2 = reinterpret_cast<const float*>(a.a2);
-    const float* W = reinterpret_cast<const float*>(a.w);
+    const elt_t* A = reinterpret_cast<const elt_t*>(a.a);
+    const elt_t* A2 = reinterpret_cast<const elt_t*>(a.a2);
+    const elt_t* W = reinterpret_cast<const elt_t*>(a.w);
     const int nk = a.K / FBK;
     const int nk1 = (a.a2 ? a.K1 : a.K) / FBK;
 
@@ -459,21 +467,21 @@ __global__ __launch_bounds__(256, NJ == 3 ? 4 : 3) void fgemm_kernel(const TGemm
     for (int i = 0; i < ACH; ++i) {
         const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
         const int m = min(m0 + row, rows_tot - 1);
-        aoff[i] = m * a.lda + kp * 4;
-        a2off[i] = m * a.lda2 + kp * 4;
-        loff[i] = row * FLP + kp * 4;
+        aoff[i] = m * a.lda + kp * EPC;
+        a2off[i] = m * a.lda2 + kp * EPC;
+        loff[i] = row * FLP + kp * EPC;
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
         const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
-        woff[i] = (n0 + row) * a.K + kp * 4;
-        lwoff[i] = BM * FLP + row * FLP + kp * 4;
+        woff[i] = (n0 + row) * a.K + kp * EPC;
+        lwoff[i] = BM * FLP + row * FLP + kp * EPC;
     }
     auto gload_tile = [&](f32x4t* xa, f32x4t* xw, int kt) {
         const bool first = kt < nk1;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
-            const float* p = first ? A + (aoff[i] + kt * FBK) : A2 + (a2off[i] + (kt - nk1) * FBK);
+            const elt_t* p = first ? A + (aoff[i] + kt * FBK) : A2 + (a2off[i] + (kt - nk1) * FBK);
             xa[i] = *reinterpret_cast<const f32x4t*>(p);
         }
 #pragma unroll
@@ -481,29 +489,39 @@ __global__ __launch_bounds__(256, NJ == 3 ? 4 : 3) void fgemm_kernel(const TGemm
     };
     auto lds_store = [&](const f32x4t* xa, const f32x4t* xw) {
 #pragma unroll
-        for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4t*>(ldsf + loff[i]) = xa[i];
+        for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4t*>(ldse + loff[i]) = xa[i];
 #pragma unroll
-        for (int i = 0; i < WCH; ++i) *reinterpret_cast<f32x4t*>(ldsf + lwoff[i]) = xw[i];
+        for (int i = 0; i < WCH; ++i) *reinterpret_cast<f32x4t*>(ldse + lwoff[i]) = xw[i];
     };
     f32x16 acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    const int frow = l & 31, fk = 4 * (l >> 5) + 16 * kh;
-    const float* const pa = ldsf + (wr * 32 + frow) * FLP + fk;
-    const float* const pw = ldsf + BM * FLP + frow * FLP + fk;
+    // fragment of step ks: bytes 64 kh + 32 ks + 16 (l >> 5) of the row — the same byte offsets for both element types
+    const int frow = l & 31, fk = EPC * (l >> 5) + 4 * EPC * kh;
+    const elt_t* const pa = ldse + (wr * 32 + frow) * FLP + fk;
+    const elt_t* const pw = ldse + BM * FLP + frow * FLP + fk;
     auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const f32x4t fa = *reinterpret_cast<const f32x4t*>(pa + ks * 8);
-            f32x4t fb[NJ];
+            if constexpr (BF) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(pa + ks * 16);
+                bf16x8 fb[NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const f32x4t*>(pw + j * 32 * FLP + ks * 8);
+                for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(pw + j * 32 * FLP + ks * 16);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[j], 0, 0, 0);
+            } else {
+                const f32x4t fa = *reinterpret_cast<const f32x4t*>(pa + ks * 8);
+                f32x4t fb[NJ];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j][i], acc[j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const f32x4t*>(pw + j * 32 * FLP + ks * 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j][i], acc[j], 0, 0, 0);
+            }
         }
     };
     // Every load and LDS store of the loop is unconditional, as in tgemm_kernel (steps past the end re-request the last tile).
@@ -590,8 +608,10 @@ void configure_tgemm_kernel() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TBM + 64) * TLP * 2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm256_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * TLP * 2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm256_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 192) * TLP * 2);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<4>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<4, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<4>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<4, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<4>());
 }
 void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
     if (!tgemm_supports(a)) { fprintf(stderr, "said: tgemm shape M=%d N=%d K=%d unsupported\n", a.M, a.N, a.K); abort(); }
@@ -606,9 +626,20 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
         if ((rows_tot + 2) * (long long)std::max(a.lda, a.lda2) >= 0x7fffffffLL) { fprintf(stderr, "said: fgemm operand too large for 32-bit offsets\n"); abort(); }
         const long long mt8 = ((rows_tot + 63) / 64 + 7) / 8 * 8;   // 64-row tiles, padded to the 8 XCDs
         constexpr int LDS3 = fgemm_lds_bytes<3>(), LDS4 = fgemm_lds_bytes<4>();
-        if (a.N % 128 == 0 && (a.geglu || a.N % 96)) hipLaunchKernelGGL((fgemm_kernel<4, 1>), dim3((unsigned)(mt8 * (a.N / 128))), dim3(256), LDS4, s, a2);
-        else hipLaunchKernelGGL((fgemm_kernel<3, 2>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
+        if (a.N % 128 == 0 && (a.geglu || a.N % 96)) hipLaunchKernelGGL((fgemm_kernel<4, 1, false>), dim3((unsigned)(mt8 * (a.N / 128))), dim3(256), LDS4, s, a2);
+        else hipLaunchKernelGGL((fgemm_kernel<3, 2, false>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
         return;
+    }
+    static const int small_bf = getenv("SAID_TGEMM_SMALL") ? atoi(getenv("SAID_TGEMM_SMALL")) : 0;   // experiment: bit 0 = N % 96 shapes, bit 1 = GEGLU
+    if (a.seg_rows > 0 && small_bf && a.K % 64 == 0 && (!a.a2 || a.K1 % 64 == 0)) {
+        const bool wide_n = a.N % 128 == 0 && (a.geglu || a.N % 96);
+        if (wide_n ? (small_bf & 2) : ((small_bf & 1) && a.N % 96 == 0)) {
+            const long long mt8 = ((rows_tot + 63) / 64 + 7) / 8 * 8;
+            constexpr int LDS3 = fgemm_lds_bytes<3>(), LDS4 = fgemm_lds_bytes<4>();
+            if (wide_n) hipLaunchKernelGGL((fgemm_kernel<4, 1, true>), dim3((unsigned)(mt8 * (a.N / 128))), dim3(256), LDS4, s, a2);
+            else hipLaunchKernelGGL((fgemm_kernel<3, 2, true>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
+            return;
+        }
     }
     const bool big = !no256 && (a.N % 256 == 0 || a.N % 192 == 0) && rows_tot * nb >= 4096 &&
                      (rows_tot + 2) * (long long)std::max(a.lda, a.lda2) < 0x7fffffffLL;
