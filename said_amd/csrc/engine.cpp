@@ -133,7 +133,9 @@ struct said_ctx {
                                                                                             // [Be][T][384], LN'd [Be][T][192], GEGLU out [Be][T][768], raw x2 [Be][T][192]
     bool unet_tgemm = true;   // SAID_NO_UNET_TGEMM=1 keeps the channel-major kernels in bf16 mode at every batch size
     bool unet_fgemm = true;   // SAID_NO_UNET_FGEMM=1: the same for the fp32 mode's token-major path (fgemm_kernel)
-    long long unet_tgemm_min_tokens = 8192;
+    // tokens per launch from which the token-major GEMM path is taken (measured crossovers, scripts/gpu_r2_w.sh: bf16 between 7200
+    // and 9600 tokens, fp32 between 9600 and 14400); SAID_UNET_TGEMM_MIN overrides both
+    long long unet_tgemm_min_tokens = 8192, unet_fgemm_min_tokens = 12000;
 
     // ---- audio workspace (lazily sized) ----
     float *abufA = nullptr, *abufB = nullptr; size_t abuf_elems[2] = {0, 0};
@@ -509,7 +511,8 @@ void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hi
 // what changes is the GEMM itself: a prep kernel applies the fused operand transform once and writes the operand token-major
 // in bf16, and the GEMM runs as 128-token tiles on v_mfma_f32_32x32x16_bf16 without any split-K reduction.
 bool use_tg(said_ctx* c, const UGeo& g, int nsamples) {
-    return (c->bf16_mode ? c->unet_tgemm : c->unet_fgemm) && !c->clk_on && (long long)nsamples * g.T >= c->unet_tgemm_min_tokens;
+    return (c->bf16_mode ? c->unet_tgemm : c->unet_fgemm) && !c->clk_on &&
+           (long long)nsamples * g.T >= (c->bf16_mode ? c->unet_tgemm_min_tokens : c->unet_fgemm_min_tokens);
 }
 // weight of the token-major GEMM in the context's precision mode
 inline const void* tw(const said_ctx* c, const void* bf, const void* f32) { return c->bf16_mode ? bf : f32; }
@@ -546,6 +549,11 @@ PrepArgs mkprep(const UGeo& g, const float* x, int mode, void* dst, long long ds
 // concatenated input can be prepared back to back)
 void prep_gn(said_ctx* c, PrepArgs& p, const UGeo& g, const float* part, int cpg, float eps, const float* gamma, const float* beta, int nb,
              int slot, hipStream_t s) {
+    static const bool separate = getenv("SAID_PREP_GN_SEPARATE") != nullptr;   // A/B: coefficients by their own launch (gn_coef_kernel)
+    if (!separate) {   // finalised inside the preparation kernel from the producer's partials
+        p.part = part; p.part_bs = g.sts; p.gn_cpg = cpg; p.gn_nparts = g.np; p.gn_eps = eps; p.gn_gamma = gamma; p.gn_beta = beta;
+        return;
+    }
     float* co = c->gn_coef + (size_t)slot * c->maxBe * 2 * MC;
     if (c->log_on) c->stage_log.push_back({5, -2, 0, 0, (double)nb * MC * g.np * 8.0, 0.0});
     if (dbg_go(c)) launch_gn_coef(part, g.sts, cpg, g.np, g.T, eps, gamma, beta, co, 2 * MC, nb, s);
@@ -1026,7 +1034,7 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     ctx->audio_bf16 = getenv("SAID_NO_AUDIO_BF16") == nullptr;
     ctx->unet_tgemm = getenv("SAID_NO_UNET_TGEMM") == nullptr;
     ctx->unet_fgemm = getenv("SAID_NO_UNET_FGEMM") == nullptr;
-    if (getenv("SAID_UNET_TGEMM_MIN")) ctx->unet_tgemm_min_tokens = atoll(getenv("SAID_UNET_TGEMM_MIN"));
+    if (getenv("SAID_UNET_TGEMM_MIN")) ctx->unet_tgemm_min_tokens = ctx->unet_fgemm_min_tokens = atoll(getenv("SAID_UNET_TGEMM_MIN"));
     configure_tgemm_kernel();
     configure_xattn_kernel();   // parallel graph branches measured no faster on ROCm 7.2: off by default
     if (hipStreamCreateWithFlags(&ctx->cap_stream2, hipStreamNonBlocking) != hipSuccess ||

@@ -67,7 +67,10 @@ void configure_tgemm_kernel();
 // LayerNorm(GroupNorm(x)) -> dst[b][t][ldd], mode 2: LayerNorm(x) -> dst and raw x -> dst2 (both [b][t][*]), mode 3: raw x.
 struct PrepArgs {
     const float* x; long long x_bs; int pitch, T, C;
-    const float* coef; long long coef_bs;        // GroupNorm (a, b) per (sample, channel) from launch_gn_coef (modes 0, 1)
+    const float* coef; long long coef_bs;        // GroupNorm (a, b) per (sample, channel) from launch_gn_coef (modes 0, 1) — or,
+    const float* part; long long part_bs;        // when part != null, the producer's Welford partials [b][tile][192][2]: every workgroup
+    int gn_cpg, gn_nparts; float gn_eps;         // finalises the coefficients itself (same code as gn_coef_kernel; its loads fly with
+    const float* gn_gamma; const float* gn_beta; // the tile's), which saves the 5 us dependent launch in front of each preparation
     const float* ln_gamma; const float* ln_beta;
     void* dst; long long dst_bs; int ldd, coff;
     void* dst2; long long dst2_bs; int ldd2, coff2;

@@ -630,10 +630,16 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
         else hipLaunchKernelGGL((fgemm_kernel<3, 2, false>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
         return;
     }
-    static const int small_bf = getenv("SAID_TGEMM_SMALL") ? atoi(getenv("SAID_TGEMM_SMALL")) : 0;   // experiment: bit 0 = N % 96 shapes, bit 1 = GEGLU
-    if (a.seg_rows > 0 && small_bf && a.K % 64 == 0 && (!a.a2 || a.K1 % 64 == 0)) {
+    // bf16, batch-as-rows (UNet): when the 256-row tiles would not even give every CU one workgroup (192-wide outputs at Be = 64:
+    // 152), the 64-row K-split tile spreads the same work over 4-8x as many workgroups — the kernel's time is its fp32 epilogue
+    // traffic, which then comes from all 256 CUs (192-wide convolution 42.0 -> 35.8 us; q/k/v and GEGLU, 456 / 912 workgroups of
+    // 256 rows, are faster as they are: 29.5 vs 33.2, 75 vs 84 us).  SAID_TGEMM_SMALL=0 / 3 forces never / always.
+    static const int small_bf = getenv("SAID_TGEMM_SMALL") ? atoi(getenv("SAID_TGEMM_SMALL")) : -1;
+    if (a.seg_rows > 0 && small_bf != 0 && a.K % 64 == 0 && (!a.a2 || a.K1 % 64 == 0) && (a.N % 96 == 0 || a.N % 128 == 0)) {
         const bool wide_n = a.N % 128 == 0 && (a.geglu || a.N % 96);
-        if (wide_n ? (small_bf & 2) : ((small_bf & 1) && a.N % 96 == 0)) {
+        const long long big_grid = ((rows_tot + 255) / 256) * (a.N / (wide_n ? 256 : 192));
+        const bool can_big = !no256 && (a.N % 256 == 0 || a.N % 192 == 0) && rows_tot >= 4096;
+        if (small_bf == 3 || big_grid < 256 || !can_big) {
             const long long mt8 = ((rows_tot + 63) / 64 + 7) / 8 * 8;
             constexpr int LDS3 = fgemm_lds_bytes<3>(), LDS4 = fgemm_lds_bytes<4>();
             if (wide_n) hipLaunchKernelGGL((fgemm_kernel<4, 1, true>), dim3((unsigned)(mt8 * (a.N / 128))), dim3(256), LDS4, s, a2);
@@ -700,6 +706,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs a) {
     __shared__ float coefS[192][2];     // GroupNorm (a, b) per channel (modes 0, 1)
     __shared__ float lnp[8][32][2];
     __shared__ float lnst[32][2];
+    __shared__ float gns[4 * GN_SCRATCH];
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * 32, b = blockIdx.y;
     const int T = a.T;
@@ -712,7 +719,14 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs a) {
         const int idx = tid + 256 * i, row = idx >> 3, q = idx & 7;
         v[i] = (t0 + 4 * q < a.pitch) ? *reinterpret_cast<const float4*>(xb + (long long)row * a.pitch + t0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (gn) {
+    if (gn && a.part) {   // finalise the GroupNorm coefficients here: 4 waves x 48 channels, as gn_coef_kernel
+        const int l = tid & 63, w = tid >> 6;
+        const GnP gp = {a.gn_cpg, a.gn_nparts, T, a.gn_eps, a.gn_gamma, a.gn_beta, 192};
+        const rsrc_t rp = make_rsrc(a.part + (long long)b * a.part_bs, 192u * (unsigned)a.gn_nparts * 8u);
+        GnLoads gl;
+        gn_issue(gp, rp, w * 48, 48, l, gl);
+        gn_finish(gp, rp, w * 48, 48, l, gl, gns + w * GN_SCRATCH, &coefS[0][0]);
+    } else if (gn) {
         const float* cf = a.coef + (long long)b * a.coef_bs;
         for (int i = tid; i < 2 * 192; i += 256) (&coefS[0][0])[i] = cf[i];
     }
@@ -829,7 +843,8 @@ void launch_prep(const PrepArgs& a, int batch, hipStream_t s) {
         abort();
     }
     dim3 grid(a.T / 32 + 1, batch);   // one tile past ceil(T / 32) when T % 32 == 0: the conv operand's right padding row
-    hipLaunchKernelGGL(prep_kernel, grid, dim3(256), 0, s, a);
+    static const int pad = getenv("SAID_PREP_PAD_LDS") ? atoi(getenv("SAID_PREP_PAD_LDS")) : 0;   // occupancy experiment: unused dynamic LDS
+    hipLaunchKernelGGL(prep_kernel, grid, dim3(256), pad, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
