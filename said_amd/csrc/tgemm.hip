@@ -47,9 +47,11 @@ constexpr int TBM = 128, TBN = 128, TBK = 64, TLP = 72;   // tile, LDS row pitch
 // n0w = first output column of this wave's 32 NJ columns.  No workgroup barrier inside (waves may return early): LDS
 // operations of one wave execute in order, so its own writes are visible to its later reads.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NJ>
+// (J0, NJE): the epilogue covers column tiles J0 .. J0 + NJE - 1 of the wave's NJ accumulator tiles, n0w = first column of tile J0
+// (fgemm_kernel splits a tile's epilogue between the two K-half waves).
+template <int NJ, int J0 = 0, int NJE = NJ>
 __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ], int b_grid, int rt, int n0w, int l, float* sc) {
-    constexpr int CW = 32 * NJ, CP = CW + 4;   // columns of this wave, scratch row pitch (floats)
+    constexpr int CW = 32 * NJE, CP = CW + 4;   // columns of this call, scratch row pitch (floats)
     const int lh = l >> 5, lc = l & 31;
     if (a.seg_rows > 0 && rt >= a.batch * a.seg_rows) return;   // row tile past the last sample (wave-uniform)
     const int b = a.seg_rows > 0 ? rt / a.seg_rows : b_grid;
@@ -62,9 +64,9 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
     const int nrows = min(32, a.M - mt);
     // ---- phase 1: registers -> scratch, elementwise work where lane == column
     const bool geglu = a.geglu != 0;
-    constexpr int NJO = NJ;   // (GEGLU writes NJ / 2 column tiles; the scratch keeps the full pitch)
+    constexpr int NJO = NJE;   // (GEGLU writes NJ / 2 column tiles; the scratch keeps the full pitch)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int j = 0; j < NJE; ++j) {
         if (geglu && (j & 1)) continue;   // gate tiles are consumed with their value tile
         const int n = n0w + j * 32 + lc;
         float add = a.bias ? a.bias[n] : 0.f;
@@ -75,9 +77,9 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float v = acc[j][r] + add;
+            float v = acc[J0 + j][r] + add;
             if (geglu) {
-                if constexpr (NJ % 2 == 0) v *= gelu_f(acc[(j + 1) % NJ][r] + gadd);
+                if constexpr (NJE % 2 == 0 && J0 % 2 == 0) v *= gelu_f(acc[J0 + (j + 1) % NJE][r] + gadd);
             } else if (a.act == 1) {
                 v = gelu_f(v);
             }
@@ -106,7 +108,10 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
                 const float4 rv = *reinterpret_cast<const float4*>(a.res_cm + (long long)b * a.res_cm_bs + (long long)n * pitch + m);
                 v4[0] += rv.x; v4[1] += rv.y; v4[2] += rv.z; v4[3] += rv.w;
             }
-            if (m < a.M) {   // tokens in [M, roundup(M, 4)) land in the row's padding
+            if (m < a.M) {   // tokens in [M, roundup(M, 4)) land in the row's padding: written as ZEROS (they come from operand rows
+                             // nobody prepared; attention multiplies V's padding columns by p = 0, and 0 x NaN is NaN)
+#pragma unroll
+                for (int e = 1; e < 4; ++e) v4[e] = (m + e < a.M) ? v4[e] : 0.f;
                 const float4 o = make_float4(v4[0], v4[1], v4[2], v4[3]);
                 *reinterpret_cast<float4*>(ybase + (long long)n * pitch + m) = o;
                 if (a.y2_cm) *reinterpret_cast<float4*>(a.y2_cm + (long long)b * a.y2_bs + (long long)n * pitch + m) = o;
@@ -427,8 +432,9 @@ __global__ __launch_bounds__(512) void tgemm256_kernel(const TGemmArgs a) {
 constexpr int FBK = 32;   // k per tile of the fp32 kernel (host-side checks)
 template <int NJ>
 __host__ __device__ constexpr int fgemm_lds_bytes() {
-    const int tiles = (64 + 32 * NJ) * 144, scratch = 2 * 32 * (32 * NJ + 4) * 4;
-    return tiles > scratch ? tiles : scratch;
+    const int tiles = (64 + 32 * NJ) * 144, exch = 2 * NJ * 16 * 64 * 4,
+              scratch = NJ == 4 ? 4 * 32 * (32 * 2 + 4) * 4 : 2 * 32 * (32 * NJ + 4) * 4;
+    return tiles > scratch ? (tiles > exch ? tiles : exch) : (scratch > exch ? scratch : exch);
 }
 // NJ = 3: 64 x 96 tile (N = 192 / 576), NJ = 4: 64 x 128 (GEGLU, value / gate column tiles interleaved as for the bf16 kernel).
 // PF = 2: two register sets, the tile two k-steps ahead is in flight while the current one multiplies.
@@ -560,23 +566,40 @@ __global__ __launch_bounds__(256, NJ == 3 ? 4 : 3) void fgemm_kernel(const TGemm
             __syncthreads();
         }
     }
-    // ---- add the two K halves: wave (r, 1) parks its accumulators in region r (lane-linear), wave (r, 0) adds them and runs the
-    // epilogue with the same region as its transposition scratch (the operand tile is dead after the loop's last barrier)
-    float* sc = ldsf + wr * (32 * (32 * NJ + 4));
-    if (kh == 1) {
+    // ---- add the two K halves.  NJ = 4 (GEGLU: the epilogue is 18 % of the kernel, mostly erf) splits the epilogue as well: wave
+    // (r, 0) finishes column tiles [0, 2), wave (r, 1) tiles [2, 4) — each parks the tiles the OTHER one finishes in the exchange
+    // area (lane-linear, region r), a barrier, each adds its partner's half to its own; a second barrier frees the area, which
+    // then serves as the waves' transposition scratch (245 -> 235 us).  NJ = 3: wave (r, 1) parks everything, wave (r, 0) finishes
+    // all three tiles (the 2 : 1 split measured slower: 122.5 -> 126.7 us).
+    constexpr int NJ0 = NJ == 4 ? 2 : NJ, NJ1 = NJ - NJ0;
+    // (unsplit: region r is also wave (r, 0)'s scratch, so the regions are spaced by the scratch size and never overlap)
+    float* const xr = ldsf + wr * (NJ1 > 0 ? NJ * 16 * 64 : 32 * (32 * NJ + 4));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ; ++j) {
+        if ((kh == 1) == (j < NJ0)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[(j * 16 + r) * 64 + l] = acc[j][r];
+            for (int r = 0; r < 16; ++r) xr[(j * 16 + r) * 64 + l] = acc[j][r];
+        }
     }
     __syncthreads();
-    if (kh == 1) return;
+    if (NJ1 == 0 && kh == 1) return;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ; ++j) {
+        if ((kh == 0) == (j < NJ0)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] += sc[(j * 16 + r) * 64 + l];
-    __builtin_amdgcn_wave_barrier();
-    tg_epilogue<NJ>(a, acc, 0, m0 + wr * 32, n0, l, sc);
+            for (int r = 0; r < 16; ++r) acc[j][r] += xr[(j * 16 + r) * 64 + l];
+        }
+    }
+    if constexpr (NJ1 > 0) {
+        __syncthreads();
+        float* sc = ldsf + w * (32 * (32 * NJ0 + 4));
+        if (kh == 0) tg_epilogue<NJ, 0, NJ0>(a, acc, 0, m0 + wr * 32, n0, l, sc);
+        else tg_epilogue<NJ, NJ0, (NJ1 > 0 ? NJ1 : 1)>(a, acc, 0, m0 + wr * 32, n0 + 32 * NJ0, l, sc);
+    } else {
+        // region r holds only this wave's partner data, which it has just consumed: its own transposition scratch (in-order LDS)
+        __builtin_amdgcn_wave_barrier();
+        tg_epilogue<NJ>(a, acc, 0, m0 + wr * 32, n0, l, xr);
+    }
 }
 
 bool tgemm_supports(const TGemmArgs& a) {

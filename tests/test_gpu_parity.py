@@ -688,3 +688,29 @@ def test_fp32_unet_large_batch_token_major_gemm_path(model, unet_sd, dev):
         print(f"fp32 large-batch UNet sample {i}: max err {e:.2e} of range vs oracle, {es:.2e} vs the small-batch path")
         worst = max(worst, e)
     assert worst <= 1e-4
+
+
+@pytest.mark.parametrize("T", [333, 350])
+def test_token_major_path_ragged_length(model, unet_sd, dev, T):
+    """The token-major GEMM path (both precisions) at a sequence length that is not a multiple of the 32-token tile and whose
+    two Conv1d padding rows do (T=350: 352 rows) / do not (T=333) end on a tile boundary: per-sample row pitch, padding rows,
+    partial last tiles of the preparation kernel, GroupNorm partials of a short last tile."""
+    B = 40                                   # 40 x 333 = 13320 tokens >= both thresholds
+    x = synth.synth_latents(81, (B, T, 32))
+    c = synth.synth_latents(82, (B, T, 768))
+    ts = (torch.arange(B) * 53 + 11) % 1000
+    pick = (0, 21, 39)
+    refs = [ou.unet1d_forward(unet_sd, x[i:i + 1], ts[i:i + 1], c[i:i + 1]) for i in pick]
+    out32 = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+    try:
+        model.set_mfma_dtype("bf16")
+        out16 = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+    finally:
+        model.set_mfma_dtype("fp32")
+    for i, ref in zip(pick, refs):
+        scale = float(ref.abs().max())
+        e32 = float((out32[i:i + 1] - ref).abs().max()) / scale
+        e16 = float((out16[i:i + 1] - ref).abs().max()) / scale
+        print(f"T={T} sample {i}: fp32 {e32:.2e}, bf16 {e16:.2e} of range")
+        assert e32 <= 1e-4
+        assert e16 <= 2e-2
