@@ -714,3 +714,27 @@ def test_token_major_path_ragged_length(model, unet_sd, dev, T):
         print(f"T={T} sample {i}: fp32 {e32:.2e}, bf16 {e16:.2e} of range")
         assert e32 <= 1e-4
         assert e16 <= 2e-2
+
+
+def test_loop_large_batch_ragged_length_matches_single_clip_runs(model, dev):
+    """Guidance loop at a batch where the full-batch launches take the token-major path and the guidance-shared prefix (half
+    the samples) stays on the channel-major kernels, at a length that is not a multiple of 4 or 32: every clip must come out
+    as if run alone, in both precision modes (bf16: same rounding points, different summation order and tile shapes)."""
+    B, T, N = 24, 333, 2
+    ctx = synth.synth_latents(130, (B, T, 768)).to(dev)
+    lat = synth.synth_latents(131, (B, T, 32)).to(dev)
+    wav = torch.zeros(B, T * 16000 // 60, device=dev)   # only its shape is used when the embedding is injected
+    for mode, tol in (("fp32", 5e-5), ("bf16", 6e-2)):
+        try:
+            model.set_mfma_dtype(mode)
+            big = model.inference(wav, audio_embedding=ctx, num_inference_steps=N, guidance_scale=2.0, init_latents=lat).result
+            worst = 0.0
+            for i in (0, 11, 23):
+                one = model.inference(wav[i:i + 1], audio_embedding=ctx[i:i + 1], num_inference_steps=N, guidance_scale=2.0,
+                                      init_latents=lat[i:i + 1]).result
+                assert bool(torch.isfinite(big[i]).all())
+                worst = max(worst, float((big[i:i + 1] - one).abs().max()))
+        finally:
+            model.set_mfma_dtype("fp32")
+        print(f"{mode}: batch of {B} vs single-clip runs at T={T}: max abs diff {worst:.2e}")
+        assert worst <= tol
