@@ -121,6 +121,11 @@ struct said_ctx {
     // ---- bf16 audio encoder (tgemm.hip): bf16 weights [N][K] (convs: K = tap-major), token-major workspace ----
     void* bw_conv[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *bw_fproj = nullptr, *bw_aproj = nullptr;
+    void* bw_pos = nullptr;       // positional conv as 16 GEMMs: bf16 [16][64 (48 + 16 zero rows)][taps * 48], tap-major
+    float* pos_bias_pad = nullptr; // its bias, 16 zeros appended (the last group's 64-wide tile reads past 768)
+    void* bXg = nullptr;          // per-group operand [clips][16][R][48] bf16
+    size_t bXg_elems = 0;
+    bool pos_tgemm = true;        // SAID_NO_POSCONV_TGEMM=1: the grouped fp32 channel-major kernel also in bf16 mode
     struct BLayer { void *qkv, *out, *ff1, *ff2; };
     std::vector<BLayer> blayers;
     void *bA0 = nullptr, *bA1 = nullptr, *bX = nullptr, *bHb = nullptr, *bF = nullptr, *bO = nullptr;
@@ -1032,6 +1037,7 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     ctx->cfg_share = getenv("SAID_NO_CFG_SHARE") == nullptr;
     ctx->use_xattn = getenv("SAID_XATTN") != nullptr;
     ctx->audio_bf16 = getenv("SAID_NO_AUDIO_BF16") == nullptr;
+    ctx->pos_tgemm = getenv("SAID_NO_POSCONV_TGEMM") == nullptr;
     ctx->unet_tgemm = getenv("SAID_NO_UNET_TGEMM") == nullptr;
     ctx->unet_fgemm = getenv("SAID_NO_UNET_FGEMM") == nullptr;
     if (getenv("SAID_UNET_TGEMM_MIN")) ctx->unet_tgemm_min_tokens = ctx->unet_fgemm_min_tokens = atoll(getenv("SAID_UNET_TGEMM_MIN"));
@@ -1357,6 +1363,20 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
             }
             if (upload(ctx, &pw.w[0], packed.data(), packed.size())) return -1;
             if (upvec(ctx, &pw.bias, A + "encoder.pos_conv_embed.conv.bias", W2V_H)) return -1;
+            if (CG % 8 == 0 && CG <= 64 && (K * CG) % 64 == 0) {   // bf16 mode: group g as a GEMM, rows padded to one 64-wide tile
+                std::vector<float> wg64((size_t)G * 64 * K * CG, 0.f);
+                for (int g = 0; g < G; ++g)
+                    for (int n = 0; n < CG; ++n)
+                        for (int c = 0; c < CG; ++c)
+                            for (int k = 0; k < K; ++k)
+                                wg64[(((size_t)g * 64 + n) * K + k) * CG + c] = wfull[((size_t)(g * CG + n) * CG + c) * K + k];
+                if (upload_bf16(ctx, &ctx->bw_pos, wg64.data(), (size_t)G * 64, (size_t)K * CG, 1)) return -1;
+                std::vector<float> bp(W2V_H + 64, 0.f);
+                const HostTensor* pb = getw(ctx, A + "encoder.pos_conv_embed.conv.bias", {W2V_H});
+                if (!pb) return -1;
+                std::copy(pb->data.begin(), pb->data.end(), bp.begin());
+                if (upload(ctx, &ctx->pos_bias_pad, bp.data(), bp.size())) return -1;
+            }
         }
         if (upvec(ctx, &ctx->enc_lng, A + "encoder.layer_norm.weight", W2V_H) || upvec(ctx, &ctx->enc_lnb, A + "encoder.layer_norm.bias", W2V_H)) return -1;
         int L = 0;
@@ -1805,7 +1825,8 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
     const bool bfa = ctx->bf16_mode && ctx->audio_bf16 && (!apply_proj || ctx->ctx_dim % 128 == 0) && (int)ctx->blayers.size() == ctx->w2v_layers;
     if (bfa) {
         const size_t e0 = (size_t)chunk * L[0] * W2V_CONV, e1 = (size_t)chunk * L[1] * W2V_CONV, tk = (size_t)chunk * Fr;
-        if (e0 > ctx->b_conv_elems[0] || e1 > ctx->b_conv_elems[1] || tk > ctx->b_tok) {
+        const size_t xg = (size_t)chunk * 16 * (size_t)rup(Fr + ctx->posconv.taps, 8) * (W2V_H / 16) + 4096;   // per-group positional-conv operand
+        if (e0 > ctx->b_conv_elems[0] || e1 > ctx->b_conv_elems[1] || tk > ctx->b_tok || xg > ctx->bXg_elems) {
             HIPCHK(hipStreamSynchronize(s));
             uint16_t** u;
             if (e0 > ctx->b_conv_elems[0]) { u = reinterpret_cast<uint16_t**>(&ctx->bA0); if (drealloc(ctx, u, e0 + 64)) return -1; ctx->b_conv_elems[0] = e0; }
@@ -1817,6 +1838,10 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     drealloc(ctx, &ctx->bPosT, tk * W2V_H))
                     return -1;
                 ctx->b_tok = tk;
+            }
+            if (xg > ctx->bXg_elems) {
+                if (drealloc(ctx, reinterpret_cast<uint16_t**>(&ctx->bXg), xg)) return -1;
+                ctx->bXg_elems = xg;
             }
         }
         for (int b0 = 0; b0 < B; b0 += chunk) {
@@ -1850,6 +1875,26 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                 a.yf = ctx->bH; a.y_bs = hsT; a.ldy = W2V_H; a.M = Fr; a.N = W2V_H; a.K = W2V_CONV;
                 launch_tgemm(a, nb, s);
             }
+            const int PK = ctx->posconv.taps, PG = 16, PCG = W2V_H / PG;
+            if (ctx->pos_tgemm && ctx->bw_pos && PK % 2 == 0) {
+                // positional conv embedding (wav2vec2: Conv1d(768, 768, k=128, padding=64, groups=16), last output dropped, GELU) as 16
+                // GEMMs on the bf16 token-major kernel: group g's input channels laid out [R][48] with 64 zero rows in front, so
+                // that output token t is row t's 128 x 48 contiguous elements times W_g (tap-major) — 150 GFLOP per 32 clips that
+                // the grouped fp32 kernel ran at 40 TFLOP/s (7.5 of the encoder's 21 ms).  Epilogue: + bias, GELU, + hidden state.
+                const int R = rup(Fr + PK, 8);
+                launch_tm_to_group_bf16(ctx->bH, hsT, ctx->bXg, nb, Fr, PG, PCG, R, PK / 2, s);
+                for (int g = 0; g < PG; ++g) {
+                    TGemmArgs a;
+                    memset(&a, 0, sizeof a);
+                    a.a = reinterpret_cast<uint16_t*>(ctx->bXg) + (size_t)g * R * PCG; a.a_bs = (long long)PG * R * PCG; a.lda = PCG;
+                    a.w = reinterpret_cast<uint16_t*>(ctx->bw_pos) + (size_t)g * 64 * PK * PCG; a.bias = ctx->pos_bias_pad + g * PCG; a.act = 1;
+                    a.res = ctx->bH + g * PCG; a.res_bs = hsT; a.ldr = W2V_H;
+                    a.yf = ctx->bT + g * PCG; a.y_bs = hsT; a.ldy = W2V_H; a.n_store = PCG;
+                    a.M = Fr; a.N = 64; a.K = PK * PCG;
+                    launch_tgemm(a, nb, s);
+                }
+                launch_ln_tm(ctx->bT, nullptr, ctx->bH, ctx->bHb, ctx->enc_lng, ctx->enc_lnb, (long long)nb * Fr, W2V_H, 1e-5f, s);
+            } else {
             {   // positional conv embedding (grouped, fp32 channel-major kernel) on the projected features
                 launch_tm_to_cm(ctx->bH, ctx->aH, nb, Fr, W2V_H, Fp, hs, s);
                 GemmArgs a = mkargs(Fr, W2V_H / 16);
@@ -1863,6 +1908,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                 launch_cm_to_tm(ctx->aPOS, ctx->bPosT, nb, Fr, W2V_H, Fp, hs, s);
             }
             launch_ln_tm(ctx->bH, ctx->bPosT, ctx->bH, ctx->bHb, ctx->enc_lng, ctx->enc_lnb, (long long)nb * Fr, W2V_H, 1e-5f, s);
+            }
             for (int l = 0; l < ctx->w2v_layers; ++l) {
                 const W2VLayer& ly = ctx->layers[l];
                 const said_ctx::BLayer& bl = ctx->blayers[l];

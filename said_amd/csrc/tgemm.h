@@ -53,6 +53,7 @@ struct TGemmArgs {
     // (seg_rows % 32 == 0, >= M); row R is sample R / seg_rows, token R % seg_rows; tokens >= M are padding.  0: per-sample
     // operands addressed through a_bs (audio encoder).
     int seg_rows;
+    int n_store;           // token-major outputs: columns n >= n_store are not written (0: all N) — a column count padded to the tile
     int f32;               // 1: A and W are fp32 (fgemm_kernel on v_mfma_f32_32x32x2_f32; fp32 mode, large batches); K % 32 == 0
     int dbg;               // timing experiments (SAID_TG_DBG): bit 0 = skip the epilogue, bit 1 = skip the K loop
     // value channel of the first column of a GEGLU value tile starting at permuted column n (see tgemm_geglu_src_row)
@@ -81,6 +82,9 @@ void launch_prep(const PrepArgs& a, int batch, hipStream_t s);
 // GroupNorm coefficients of a 192-channel tensor from its Welford partials [b][192][nparts][2] -> coef_out[b][192][2]
 void launch_gn_coef(const float* part, long long part_bs, int cpg, int nparts, int T, float eps, const float* gamma, const float* beta,
                     float* coef_out, long long coef_bs, int batch, hipStream_t s);
+// token-major fp32 [b][T][G * CG] -> per-group bf16 [b][G][R][CG] with `lpad` zero rows in front and zeros behind (R >= lpad + T): the
+// operand of a grouped Conv1d run as G GEMMs with overlapping rows (Wav2Vec2's positional convolution)
+void launch_tm_to_group_bf16(const float* src, long long src_bs, void* dst, int B, int T, int G, int CG, int R, int lpad, hipStream_t s);
 void launch_cm_to_tm_bf16(const float* src, long long src_bs, int pitch, void* dst, long long dst_bs, int B, int T, int C, hipStream_t s);
 void launch_ln_tm(const float* x, const float* add, float* yf, void* yb, const float* gamma, const float* beta, long long ntok, int C, float eps,
                   hipStream_t s);

@@ -144,6 +144,7 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
             if (!lane_on || row >= nrows) continue;
             const int m = mt + row;
             const int n = n_first + 4 * cq;
+            if (a.n_store && n >= a.n_store) continue;
             f32x4t v = *reinterpret_cast<const f32x4t*>(sc + row * CP + 4 * cq);
             if (a.res) {
                 const f32x4t rv = *reinterpret_cast<const f32x4t*>(a.res + (long long)b * a.res_bs + (long long)m * a.ldr + n);
@@ -888,6 +889,21 @@ __global__ void cm_to_tm_bf16_kernel(const float* __restrict__ src, long long sr
         const int t = t0 + r, c = c0 + tx;
         if (c < C && t < T) d[(long long)t * C + c] = (__bf16)tile[tx][r];
     }
+}
+__global__ void tm_to_group_bf16_kernel(const float* __restrict__ src, long long src_bs, unsigned short* __restrict__ dst, int T, int G, int CG, int R,
+                                        int lpad) {
+    const int r = blockIdx.x, b = blockIdx.y, C = G * CG;
+    const int t = r - lpad;
+    const bool live = t >= 0 && t < T;
+    __bf16* d = reinterpret_cast<__bf16*>(dst);
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        const int g = i / CG, c = i - g * CG;
+        const float v = live ? src[(long long)b * src_bs + (long long)t * C + i] : 0.f;
+        d[(((long long)b * G + g) * R + r) * CG + c] = (__bf16)v;
+    }
+}
+void launch_tm_to_group_bf16(const float* src, long long src_bs, void* dst, int B, int T, int G, int CG, int R, int lpad, hipStream_t s) {
+    hipLaunchKernelGGL(tm_to_group_bf16_kernel, dim3(R, B), dim3(256), 0, s, src, src_bs, reinterpret_cast<unsigned short*>(dst), T, G, CG, R, lpad);
 }
 void launch_cm_to_tm_bf16(const float* src, long long src_bs, int pitch, void* dst, long long dst_bs, int B, int T, int C, hipStream_t s) {
     dim3 grid((T + 31) / 32, (C + 31) / 32, B);
