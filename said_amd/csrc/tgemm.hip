@@ -133,6 +133,22 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
                 }
             }
         }
+    } else if (a.yb && !a.yf && !a.qk && !a.res && !a.n_store) {
+        // ---- phase 2a', bf16-only token-major destination (GEGLU product, the audio encoder's conv / FFN activations): lane -> 8
+        // consecutive columns = one 16-byte store (8-byte stores run at 0.54-0.70x the 16-byte rate)
+        typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+        const int lanes_per_row = cw / 8;                // 16, 12, 8 or 4
+        const int rows_pp = 64 / lanes_per_row;          // 4, 5 (60 lanes active), 8 or 16
+        const int rr = l / lanes_per_row, cq = l - rr * lanes_per_row;
+        const bool lane_on = rr < rows_pp;
+        for (int r0 = 0; r0 < nrows; r0 += rows_pp) {
+            const int row = r0 + rr;
+            if (!lane_on || row >= nrows) continue;
+            const f32x4t v0 = *reinterpret_cast<const f32x4t*>(sc + row * CP + 8 * cq);
+            const f32x4t v1 = *reinterpret_cast<const f32x4t*>(sc + row * CP + 8 * cq + 4);
+            const bf16x8s o = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3], (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
+            *reinterpret_cast<bf16x8s*>(reinterpret_cast<__bf16*>(a.yb) + (long long)b * a.y_bs + (long long)(mt + row) * a.ldy + n_first + 8 * cq) = o;
+        }
     } else {
         // ---- phase 2a: token-major destination: lane -> 4 consecutive columns of a row; rows_pp rows per pass
         const int lanes_per_row = cw / 4;                // 32, 24, 16 or 8
@@ -617,6 +633,7 @@ bool tgemm_supports(const TGemmArgs& a) {
     if (!a.f32 && a.geglu && (a.N % 256 || !a.yb)) return false;   // the GEGLU row interleaving is the 256-wide tile's (tgemm_geglu_src_row)
     if (a.y_cm && (a.cm_pitch % 4 || a.cm_pitch < ((a.M + 3) & ~3))) return false;
     if (a.seg_rows && (a.seg_rows % 32 || a.seg_rows < a.M)) return false;
+    if (a.yb && (a.ldy % 8 || a.y_bs % 8)) return false;   // 16-byte bf16 stores
     if ((long long)a.N * a.K > 0x7fffffffLL) return false;   // 32-bit element offsets in the 256-row kernel
     return true;
 }
