@@ -164,8 +164,18 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0):
     unet_bytes = _engine.unet_algorithmic_bytes(Be, T, 4)   # activations are stored in fp32 in both modes
     unet_flops = _engine.unet_algorithmic_flops(Be, T)
     sum_us = sum(a["us"] for a in agg.values())
-    out = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
+    # which roof binds the dominant kernel: its arithmetic intensity against the ridge point peak FLOP/s : 8 TB/s (fp32 MFMA: 19.7
+    # FLOP/B, bf16: 312).  Both fractions are always reported (hbm_frac / kernel_mfma_frac); `bound` / `achieved` / `peak` /
+    # `frac` are the binding roof's.
+    k_tf = d["flops"] / (d["us"] * 1e-6) / 1e12
+    mfma_bound = d["flops"] / max(d["bytes"], 1.0) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+    out = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom,
+           "achieved": round(k_tf, 3) if mfma_bound else round(achieved, 2), "peak": peak_tf if mfma_bound else HBM_PEAK_GBS,
+           "unit": "TFLOP/s" if mfma_bound else "GB/s",
+           "frac": round(k_tf / peak_tf, 5) if mfma_bound else round(achieved / HBM_PEAK_GBS, 5),
+           "arithmetic_intensity": round(d["flops"] / max(d["bytes"], 1.0), 1),
+           "hbm_GBps": round(achieved, 2), "hbm_frac": round(achieved / HBM_PEAK_GBS, 5),
+           "traffic": None, "traffic_source": None,
            "launches_per_unet": d["launches"], "avg_launch_us": round(d["us"] / d["launches"], 3),
            "alg_bytes_per_launch": round(d["bytes"] / d["launches"]),
            "kernel_tflops": round(d["flops"] / (d["us"] * 1e-6) / 1e12, 3),
