@@ -149,12 +149,23 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
                     for (int r = 0; r < 16; ++r) o[nd][r] *= alpha;
             }
         } else {
+        // fp32 path: the reference's op order (scale, subtract the maximum, exp).  Two value-preserving trims: keys past T are
+        // masked only in the tile that contains T, and the accumulator rescale is skipped while no lane's maximum moved
+        // (alpha == 1 exactly: multiplying by it changes nothing).
         float mx = -1.0e30f;
+        if (j0 + 32 > T) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            s[r] = (j < T) ? s[r] * a.scale : -1.0e30f;
-            mx = fmaxf(mx, s[r]);
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                s[r] = (j < T) ? s[r] * a.scale : -1.0e30f;
+                mx = fmaxf(mx, s[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = s[r] * a.scale;
+                mx = fmaxf(mx, s[r]);
+            }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mn = fmaxf(m, mx);
@@ -167,10 +178,12 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
             ps += s[r];
         }
         lsum = lsum * alpha + ps;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
 #pragma unroll
-        for (int nd = 0; nd < ND; ++nd)
+            for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[nd][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[nd][r] *= alpha;
+        }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
