@@ -30,12 +30,11 @@ namespace said {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4a __attribute__((ext_vector_type(4)));
-typedef short s16x4a __attribute__((ext_vector_type(4)));
-// four floats -> four bf16 (round to nearest even), as the 32x32x8 bf16 MFMA operand of one lane
-static __device__ __forceinline__ s16x4a pk_bf16(float a, float b, float c, float d) {
-    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-    const bf4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
-    return __builtin_bit_cast(s16x4a, v);
+typedef __bf16 bf16x8a __attribute__((ext_vector_type(8)));
+// eight floats (two loaded quads) -> eight bf16 (round to nearest even): the v_mfma_f32_32x32x16_bf16 operand of one lane
+static __device__ __forceinline__ bf16x8a pk_bf16x8(const f32x4a a, const f32x4a b) {
+    const bf16x8a v = {(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+    return v;
 }
 
 // The arguments are 14 scalar kernel parameters — exactly what the hardware preloads into SGPRs (build.py compiles this
@@ -46,10 +45,11 @@ struct AttnView {
     float scale;
     int b0;
 };
-// BF: both products run on v_mfma_f32_32x32x8_bf16_1k (said_set_precision).  The operand registers are the same ones:
-// MFMA m of S^T contracts d = lh * D/2 + 4m + (0..3), i.e. the m-th loaded quad of each lane half; MFMA m of O^T
-// contracts keys j0 + 8m + 4lh + (0..3), i.e. accumulator registers 4m..4m+3 and the m-th V quad.  Scores, softmax
-// statistics and accumulation stay fp32.
+// BF: both products run on v_mfma_f32_32x32x16_bf16 (said_set_precision; round 2: CDNA4's 16-deep opcode, half the MFMA count of
+// the 32x32x8 form).  The operand registers are the same ones: MFMA m of S^T contracts d = lh * D/2 + 8m + (0..7), i.e. the
+// loaded quads 2m, 2m+1 of each lane half (a permutation of d that K and Q share); MFMA m of O^T contracts keys
+// j0 + 16m + {0..3, 8..11} + 4lh, i.e. accumulator registers 8m..8m+7 and V quads 2m, 2m+1.  Scores, softmax statistics and
+// accumulation stay fp32.
 // QW > 1 (large batches, KS == 1): the workgroup's QW waves take QW CONSECUTIVE query tiles of the same (batch, head), each over
 // all keys, instead of splitting the keys of one query tile.  They walk the same K / V tiles in step, so a tile is fetched
 // from L2 once per workgroup and the other waves hit in the CU's L1: at large batch this kernel is bound by the bytes a CU can
@@ -76,9 +76,9 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
     for (int q = 0; q < NQ; ++q) qf[q] = *reinterpret_cast<const f32x4a*>(qb + (long long)min(i0 + lt, rows - 1) * D + 4 * q);
 
-    s16x4a qh[NQ];   // bf16 mode: the query fragments are converted once, not once per key tile
+    bf16x8a qh[NQ / 2];   // bf16 mode: the query fragments are converted once, not once per key tile
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) qh[q] = pk_bf16(qf[q][0], qf[q][1], qf[q][2], qf[q][3]);
+    for (int q = 0; q < NQ / 2; ++q) qh[q] = pk_bf16x8(qf[2 * q], qf[2 * q + 1]);
     float m = -1.0e30f, lsum = 0.f;
     f32x16 o[ND];
 #pragma unroll
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
         for (int dp = 0; dp < ND * 16; ++dp) {
             if constexpr (BF) {
-                if ((dp & 3) == 0)
-                    s = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(pk_bf16(kf[dp >> 2][0], kf[dp >> 2][1], kf[dp >> 2][2], kf[dp >> 2][3]), qh[dp >> 2], s, 0, 0, 0);
+                if ((dp & 7) == 0)
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pk_bf16x8(kf[dp >> 2], kf[(dp >> 2) + 1]), qh[dp >> 3], s, 0, 0, 0);
             } else {
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[dp >> 2][dp & 3], qf[dp >> 2][dp & 3], s, 0, 0, 0);
             }
@@ -190,9 +190,10 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
             for (int nd = 0; nd < ND; ++nd) {
                 if constexpr (BF) {
-                    if ((r & 3) == 0)
-                        o[nd] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(pk_bf16(vf[nd][r >> 2][0], vf[nd][r >> 2][1], vf[nd][r >> 2][2], vf[nd][r >> 2][3]),
-                                                                         pk_bf16(s[r], s[r + 1], s[r + 2], s[r + 3]), o[nd], 0, 0, 0);
+                    if ((r & 7) == 0) {
+                        const f32x4a p0 = {s[r], s[r + 1], s[r + 2], s[r + 3]}, p1 = {s[r + 4], s[r + 5], s[r + 6], s[r + 7]};
+                        o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pk_bf16x8(vf[nd][r >> 2], vf[nd][(r >> 2) + 1]), pk_bf16x8(p0, p1), o[nd], 0, 0, 0);
+                    }
                 } else {
                     o[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[nd][r >> 2][r & 3], s[r], o[nd], 0, 0, 0);
                 }
