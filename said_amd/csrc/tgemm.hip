@@ -745,9 +745,13 @@ void launch_gn_coef(const float* part, long long part_bs, int cpg, int nparts, i
 __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs a) {
     __shared__ float tile[192][33];     // RAW values [channel][token]
     __shared__ float coefS[192][2];     // GroupNorm (a, b) per channel (modes 0, 1)
-    __shared__ float lnp[8][32][2];
-    __shared__ float lnst[32][2];
+    // one scratch area: first the GroupNorm finalisation's per-wave scratch, then (after the tile barrier) the LayerNorm partials —
+    // 31.4 KB of LDS in all, so FIVE workgroups share a CU and the 1216 workgroups of a Be = 64 launch are resident at once
+    // (with the two areas separate it was four: a second round of 0.75 workgroups per CU, 12 -> 21 us)
     __shared__ float gns[4 * GN_SCRATCH];
+    float (*lnp)[32][2] = reinterpret_cast<float (*)[32][2]>(gns);          // [8][32][2]
+    float (*lnst)[2] = reinterpret_cast<float (*)[2]>(gns + 8 * 32 * 2);     // [32][2]
+    static_assert(4 * GN_SCRATCH >= 8 * 32 * 2 + 32 * 2, "LayerNorm partials alias the GroupNorm scratch");
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * 32, b = blockIdx.y;
     const int T = a.T;
