@@ -671,16 +671,18 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
         else hipLaunchKernelGGL((fgemm_kernel<3, 2, false>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
         return;
     }
-    // bf16, batch-as-rows (UNet): when the 256-row tiles would not even give every CU one workgroup (192-wide outputs at Be = 64:
-    // 152), the 64-row K-split tile spreads the same work over 4-8x as many workgroups — the kernel's time is its fp32 epilogue
-    // traffic, which then comes from all 256 CUs (192-wide convolution 42.0 -> 35.8 us; q/k/v and GEGLU, 456 / 912 workgroups of
-    // 256 rows, are faster as they are: 29.5 vs 33.2, 75 vs 84 us).  SAID_TGEMM_SMALL=0 / 3 forces never / always.
+    // bf16, batch-as-rows (UNet): the 64-row K-split tile of the fp32 path on bf16 operands.  The kernels' time is their fp32
+    // epilogue traffic, and the 256-row tiles give a 192-wide output 152 workgroups on 256 CUs (42.0 -> 35.8 us on the small tile).
+    // For q/k/v and GEGLU (456 / 912 big workgroups) the isolated replays of said_profile_unet favour the big tile (29.8 vs 32.7,
+    // 69.7 vs 75.0 us) but the real step does not: 122.1 vs 120.3 ms per 32 clips x 50 steps, three alternating runs on one box
+    // (scripts/gpu_r2_ak.sh) — one 147 KB-LDS workgroup per CU starts and drains badly between neighbours of other shapes.  So
+    // the small tile is the rule; SAID_TGEMM_SMALL=0 restores the 256-row tiles, =1 uses them only where they fill the chip.
     static const int small_bf = getenv("SAID_TGEMM_SMALL") ? atoi(getenv("SAID_TGEMM_SMALL")) : -1;
     if (a.seg_rows > 0 && small_bf != 0 && a.K % 64 == 0 && (!a.a2 || a.K1 % 64 == 0) && (a.N % 96 == 0 || a.N % 128 == 0)) {
         const bool wide_n = a.N % 128 == 0 && (a.geglu || a.N % 96);
         const long long big_grid = ((rows_tot + 255) / 256) * (a.N / (wide_n ? 256 : 192));
         const bool can_big = !no256 && (a.N % 256 == 0 || a.N % 192 == 0) && rows_tot >= 4096;
-        if (small_bf == 3 || big_grid < 256 || !can_big) {
+        if (small_bf != 1 || big_grid < 256 || !can_big) {
             const long long mt8 = ((rows_tot + 63) / 64 + 7) / 8 * 8;
             constexpr int LDS3 = fgemm_lds_bytes<3>(), LDS4 = fgemm_lds_bytes<4>();
             if (wide_n) hipLaunchKernelGGL((fgemm_kernel<4, 1, true>), dim3((unsigned)(mt8 * (a.N / 128))), dim3(256), LDS4, s, a2);
