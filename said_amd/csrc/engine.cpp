@@ -138,9 +138,9 @@ struct said_ctx {
                                                                                             // [Be][T][384], LN'd [Be][T][192], GEGLU out [Be][T][768], raw x2 [Be][T][192]
     bool unet_tgemm = true;   // SAID_NO_UNET_TGEMM=1 keeps the channel-major kernels in bf16 mode at every batch size
     bool unet_fgemm = true;   // SAID_NO_UNET_FGEMM=1: the same for the fp32 mode's token-major path (fgemm_kernel)
-    // tokens per launch from which the token-major GEMM path is taken (measured crossovers, scripts/gpu_r2_w.sh: bf16 between 7200
-    // and 9600 tokens, fp32 between 9600 and 14400); SAID_UNET_TGEMM_MIN overrides both
-    long long unet_tgemm_min_tokens = 8192, unet_fgemm_min_tokens = 12000;
+    // tokens per launch from which the token-major GEMM path is taken (measured crossovers, scripts/gpu_r2_w.sh: bf16 between 4800
+    // and 6000 tokens, fp32 between 9600 and 10800); SAID_UNET_TGEMM_MIN overrides both
+    long long unet_tgemm_min_tokens = 5800, unet_fgemm_min_tokens = 10000;
 
     // ---- audio workspace (lazily sized) ----
     float *abufA = nullptr, *abufB = nullptr; size_t abuf_elems[2] = {0, 0};

@@ -644,7 +644,7 @@ def test_fused_chain_kernel_opt_in(unet_sd, sd_full, dev, monkeypatch):
 
 
 def test_bf16_unet_large_batch_token_major_gemm_path(model, unet_sd, dev):
-    """bf16 mode at >= 8192 tokens per launch: the ResBlock convolutions, q/k/v, GEGLU and the folded proj_out run on the
+    """bf16 mode at >= 5800 tokens per launch: the ResBlock convolutions, q/k/v, GEGLU and the folded proj_out run on the
     token-major bf16 GEMM (tgemm.hip: prep kernel + v_mfma_f32_32x32x16_bf16, channel-major fp32 results with GroupNorm
     partials).  Error against the FP32 ORACLE on the first, a middle and the last sample, and against the small-batch bf16
     path (same rounding points, different summation order)."""
@@ -670,7 +670,7 @@ def test_bf16_unet_large_batch_token_major_gemm_path(model, unet_sd, dev):
 
 
 def test_fp32_unet_large_batch_token_major_gemm_path(model, unet_sd, dev):
-    """fp32 mode at >= 12000 tokens per launch: the ResBlock convolutions, q/k/v, GEGLU and the folded proj_out run on the
+    """fp32 mode at >= 10000 tokens per launch: the ResBlock convolutions, q/k/v, GEGLU and the folded proj_out run on the
     token-major fp32 GEMM (tgemm.hip: prep kernel + fgemm_kernel on v_mfma_f32_32x32x2_f32).  Same bound as every other fp32
     UNet evaluation (1e-4 of range against the oracle); also against the small-batch channel-major path (summation order)."""
     B, T = 24, 600
