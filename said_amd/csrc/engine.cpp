@@ -516,7 +516,9 @@ void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hi
 // what changes is the GEMM itself: a prep kernel applies the fused operand transform once and writes the operand token-major
 // in bf16, and the GEMM runs as 128-token tiles on v_mfma_f32_32x32x16_bf16 without any split-K reduction.
 bool use_tg(said_ctx* c, const UGeo& g, int nsamples) {
-    return (c->bf16_mode ? c->unet_tgemm : c->unet_fgemm) && !c->clk_on &&
+    // (the token-major kernels address their operands with 32-bit element offsets: beyond that the channel-major kernels run)
+    const long long widest = ((long long)nsamples * rup(g.T + 2, 32) + 2) * FFI;
+    return (c->bf16_mode ? c->unet_tgemm : c->unet_fgemm) && !c->clk_on && widest < 0x7fffffffLL &&
            (long long)nsamples * g.T >= (c->bf16_mode ? c->unet_tgemm_min_tokens : c->unet_fgemm_min_tokens);
 }
 // weight of the token-major GEMM in the context's precision mode
