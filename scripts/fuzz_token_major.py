@@ -1,6 +1,6 @@
 """GPU fuzz (not a test): the token-major GEMM path forced ON for every launch against the channel-major kernels forced on for
 every launch, random (B, T) incl. tiny and ragged shapes, both precision modes.  Run on the GPU box:
-    python scripts/fuzz_token_major.py [n_cases] [seed]
+    python scripts/fuzz_token_major.py [n_cases] [seed] [BxT,BxT,...]     (explicit shapes replace the first cases)
 """
 import os
 import sys
@@ -25,6 +25,7 @@ def make(min_tokens):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    shapes = [tuple(int(v) for v in sh.split("x")) for sh in sys.argv[3].split(",")] if len(sys.argv) > 3 else []
     g = torch.Generator().manual_seed(seed)
     dev = torch.device("cuda:0")
     worst = {"fp32": 0.0, "bf16": 0.0}
@@ -34,7 +35,9 @@ def main():
         edge = (5, 30, 31, 32, 33, 62, 63, 64, 65, 94, 127, 129)   # tile / padding-row boundaries first
         if case < len(edge):
             T = edge[case]
-        if B * T > 45000:
+        if case < len(shapes):
+            B, T = shapes[case]
+        if B * T > 45000 and case >= len(shapes):
             B = max(1, 45000 // T)
         x = synth.synth_latents(1000 + case, (B, T, 32)).to(dev)
         c = synth.synth_latents(2000 + case, (B, T, 768)).to(dev)
