@@ -3,6 +3,7 @@
     python bench.py --gpus N --steps K --warmup W            (N >= 1: spawns N ranks itself when not under torchrun)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     python bench.py --gpus 2 --dry_run_gloo                  (CPU: launch / shard / gather plumbing only, stand-in path)
+    python bench.py --rccl_at_one                             (1 GPU: the RCCL collectives of the sharded run on a one-rank group)
     BASELINE configs[3] (8 GPUs, 256 clips): python bench.py --gpus 8 --batch 32 --steps 1 --warmup 1
 
 One "step" = one pass of the hot path over one batch: Wav2Vec2 audio encode of B synthetic
@@ -52,6 +53,8 @@ def parse():
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
     p.add_argument("--cpu_steps", type=int, default=40, help="UNet evaluations in the CPU-baseline sample")
+    p.add_argument("--rccl_at_one", action="store_true",
+                   help="N=1 only: create a ONE-rank 'nccl' (= RCCL) process group and run the sharded run's collectives on it")
     p.add_argument("--dry_run_gloo", action="store_true",
                    help="no GPU: run the launch / shard / all-gather / timing plumbing on CPU over gloo with a stand-in path")
     return p.parse_args()
@@ -261,7 +264,11 @@ def run(args):
         raise SystemExit("bench.py needs an MI355X: said_amd has no CPU path (use --dry_run_gloo for the launch plumbing)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = shard.init_process_group("nccl", rank, world, dev) if world > 1 else None   # "nccl" IS RCCL on ROCm
+    if args.rccl_at_one and world == 1:
+        os.environ.setdefault("MASTER_PORT", str(shard.free_port()))
+    # "nccl" IS RCCL on ROCm.  --rccl_at_one: a one-rank process group, so that the collectives of the sharded run (all-gather,
+    # barriers, max-reduce of the time) execute on RCCL on a single-GPU box as well
+    dist = shard.init_process_group("nccl", rank, world, dev) if (world > 1 or args.rccl_at_one) else None
 
     from said_amd.model.diffusion import SAID_UNet1D
     from said_amd.util import synth
@@ -308,7 +315,7 @@ def run(args):
                                    f"(UNet batch {Be}), " + ("editing mode: init_samples + in-betweening mask; " if args.edit else "") + ("fp32; BASELINE.json configs[1]" if args.dtype == "f32" else
                                                               "bf16 mode (UNet: bf16 multiplies, fp32 accumulation and storage; audio encoder: bf16 GEMM operands and activations, fp32 residual stream); BASELINE.json configs[2] shape"),
                        "batch_per_gpu": B, "frames": T, "num_steps": args.num_steps, "guidance_scale": args.guidance_scale,
-                       "eta": args.eta, "parallelism": f"clips sharded over {world} GPU(s), one RCCL all-gather" if world > 1 else "single GPU",
+                       "eta": args.eta, "parallelism": f"clips sharded over {world} GPU(s), one RCCL all-gather" if world > 1 else ("single GPU, one-rank RCCL group (all-gather + barriers executed)" if dist is not None else "single GPU"),
                        "clip_ranges": r.clip_ranges, "gathered_checksum": r.checksum,
                        "graph_nodes_per_step": model._eng.graph_num_nodes()},
         }
@@ -328,7 +335,7 @@ def run(args):
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only: other ranks would sit in the final barrier
             line["cpu_baseline"] = cpu_baseline(args, T, Ta)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -57,7 +57,7 @@ class ShardedRun:
 def gather_clips(dist, local: torch.Tensor, world: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One all-gather of the per-rank (B_local, T, C) results into (world * B_local, T, C): rank r's clips land at
     rows [r * B_local, (r + 1) * B_local) — the contiguous partition of clip_range()."""
-    if world == 1:
+    if world == 1 and dist is None:
         return local
     if out is None:
         out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
@@ -69,7 +69,9 @@ def timed_sharded_passes(path_fn: Callable[[range], torch.Tensor], *, rank: int,
                          steps: int, warmup: int, dist=None, device: Optional[torch.device] = None) -> ShardedRun:
     """The bench contract: `warmup` untimed passes, then EXACTLY `steps` passes bracketed by a barrier +
     device synchronisation on both sides; elapsed = MAX over ranks.  One pass = path_fn(own clip ids) +
-    (world > 1) the all-gather, both inside the timed region."""
+    (world > 1) the all-gather, both inside the timed region.  With world == 1 and a process group given (`dist`), the
+    collectives run as well — a one-rank RCCL all-gather / barrier / all-reduce: the only form in which the "nccl" code
+    path can be executed on a single-GPU box."""
     clips = clip_range(rank, world, clips_per_rank)
     on_gpu = device is not None and device.type == "cuda"
     sync = (lambda: torch.cuda.synchronize(device)) if on_gpu else (lambda: None)
@@ -80,7 +82,7 @@ def timed_sharded_passes(path_fn: Callable[[range], torch.Tensor], *, rank: int,
         local = path_fn(clips)
         if local.shape[0] != clips_per_rank:
             raise RuntimeError(f"path returned {local.shape[0]} clips for a shard of {clips_per_rank}")
-        if world > 1:
+        if collectives:
             if gathered is None:
                 gathered = torch.empty((world * clips_per_rank,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
             gather_clips(dist, local, world, gathered)
@@ -88,19 +90,20 @@ def timed_sharded_passes(path_fn: Callable[[range], torch.Tensor], *, rank: int,
             gathered = local
         return gathered
 
+    collectives = world > 1 or dist is not None
     for _ in range(warmup):
         one_pass()
-    if world > 1:
+    if collectives:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         one_pass()
     sync()
-    if world > 1:
+    if collectives:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if collectives:
         tt = torch.tensor([elapsed], device=device if on_gpu else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
