@@ -93,3 +93,25 @@ def test_feature_dim_variant_vs_oracle():
     out = m.inference(proc.to("cuda:0"), num_inference_steps=6, guidance_scale=2.0, init_latents=lat.to("cuda:0")).result.cpu()
     ref = op.inference(sd, proc, init_latents=lat, num_inference_steps=6, guidance_scale=2.0, audio_embedding=ref_emb)
     assert float((out - ref.result).abs().max()) <= 1e-3
+
+
+def test_bench_one_rank_rccl_group():
+    """`bench.py --rccl_at_one`: the sharded run's collectives (all-gather, barriers, max-reduce) on a ONE-rank "nccl" (= RCCL)
+    process group — the only form in which that code path runs on a single-GPU box; one JSON line, finite result, the
+    gathered tensor's checksum equal to the plain single-GPU run's."""
+    import json
+    import subprocess
+    import sys
+
+    def run(extra):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--num_steps", "5", "--seconds", "1",
+                              "--no_cpu_baseline", "--no_roofline"] + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    a = run(["--rccl_at_one"])
+    b = run([])
+    assert "one-rank RCCL group" in a["config"]["parallelism"] and b["config"]["parallelism"] == "single GPU"
+    assert a["n_gpus"] == 1 and a["config"]["gathered_checksum"] == b["config"]["gathered_checksum"]
