@@ -693,7 +693,18 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
     const bool big = !no256 && (a.N % 256 == 0 || a.N % 192 == 0) && rows_tot * nb >= 4096 &&
                      (rows_tot + 2) * (long long)std::max(a.lda, a.lda2) < 0x7fffffffLL;
     if (a.geglu && !big) { fprintf(stderr, "said: the GEGLU epilogue needs the 256-wide tile\n"); abort(); }
-    if (big) {
+    // Per-sample operands (audio encoder): a 256-row tile holds one workgroup per CU, so its grid runs in rounds of 256 — the
+    // encoder's 768-wide GEMMs at 32 clips x 600 frames are 288 workgroups = two rounds, the second 12 % full.  Where the
+    // 128 x 128 tile (two per CU, rounds of 512) fills its rounds clearly better, it is used instead (SAID_TGEMM_BALANCE=0: never).
+    static const bool balance = !(getenv("SAID_TGEMM_BALANCE") && atoi(getenv("SAID_TGEMM_BALANCE")) == 0);
+    bool use_big = big;
+    if (big && balance && a.seg_rows == 0 && !a.geglu && a.N % 128 == 0) {
+        const long long g_big = (long long)nb * ((rows_tot + 255) / 256) * (a.N / (a.N % 256 == 0 ? 256 : 192));
+        const long long g_128 = (long long)batch * ((a.M + TBM - 1) / TBM) * (a.N / 128);
+        const double e_big = (double)g_big / (double)(((g_big + 255) / 256) * 256), e_128 = (double)g_128 / (double)(((g_128 + 511) / 512) * 512);
+        if (e_128 > e_big + 0.15) use_big = false;
+    }
+    if (use_big) {
         const long long mt8 = ((long long)nb * ((rows_tot + 255) / 256) + 7) / 8 * 8;
         if (a.N % 256 == 0) {
             dim3 grid((unsigned)(mt8 * (a.N / 256)));
