@@ -696,13 +696,16 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
     // Per-sample operands (audio encoder): a 256-row tile holds one workgroup per CU, so its grid runs in rounds of 256 — the
     // encoder's 768-wide GEMMs at 32 clips x 600 frames are 288 workgroups = two rounds, the second 12 % full.  Where the
     // 128 x 128 tile (two per CU, rounds of 512) fills its rounds clearly better, it is used instead (SAID_TGEMM_BALANCE=0: never).
-    static const bool balance = !(getenv("SAID_TGEMM_BALANCE") && atoi(getenv("SAID_TGEMM_BALANCE")) == 0);
+    static const int balance = getenv("SAID_TGEMM_BALANCE") ? atoi(getenv("SAID_TGEMM_BALANCE")) : 15;   // margin in percent; 0: never
     bool use_big = big;
-    if (big && balance && a.seg_rows == 0 && !a.geglu && a.N % 128 == 0) {
-        const long long g_big = (long long)nb * ((rows_tot + 255) / 256) * (a.N / (a.N % 256 == 0 ? 256 : 192));
-        const long long g_128 = (long long)batch * ((a.M + TBM - 1) / TBM) * (a.N / 128);
-        const double e_big = (double)g_big / (double)(((g_big + 255) / 256) * 256), e_128 = (double)g_128 / (double)(((g_128 + 511) / 512) * 512);
-        if (e_128 > e_big + 0.15) use_big = false;
+    if (big && balance > 0 && a.seg_rows == 0 && !a.geglu && a.N % 128 == 0) {
+        const long long mt_big = (rows_tot + 255) / 256, mt_128 = (a.M + TBM - 1) / TBM;
+        const long long g_big = (long long)nb * mt_big * (a.N / (a.N % 256 == 0 ? 256 : 192));
+        const long long g_128 = (long long)batch * mt_128 * (a.N / 128);
+        // efficiency = how full the rounds are x how full the row tiles are (rows past M repeat the last row: wasted work)
+        const double e_big = (double)g_big / (double)(((g_big + 255) / 256) * 256) * (double)rows_tot / (double)(mt_big * 256);
+        const double e_128 = (double)g_128 / (double)(((g_128 + 511) / 512) * 512) * (double)a.M / (double)(mt_128 * TBM);
+        if (e_128 > e_big + 0.01 * balance) use_big = false;
     }
     if (use_big) {
         const long long mt8 = ((long long)nb * ((rows_tot + 255) / 256) + 7) / 8 * 8;
