@@ -459,7 +459,7 @@ __host__ __device__ constexpr int fgemm_lds_bytes() {
 // two v_mfma_f32_32x32x16_bf16 per column tile.  There the point is not MFMA balance but spread: the 256-row bf16 tiles put a
 // 192-wide convolution on 152 workgroups of a 256-CU chip, and its time is the fp32 epilogue traffic (§7.3).
 template <int NJ, int PF, bool BF>
-__global__ __launch_bounds__(256, NJ == 3 ? 4 : 3) void fgemm_kernel(const TGemmArgs a) {
+__global__ __launch_bounds__(256, (NJ == 3 ? (BF && PF == 1 ? 5 : 4) : 3)) void fgemm_kernel(const TGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [A 64 rows | W BN rows] x 144 bytes
     float* const ldsf = reinterpret_cast<float*>(lds);
     typedef typename std::conditional<BF, unsigned short, float>::type elt_t;
@@ -652,6 +652,7 @@ void configure_tgemm_kernel() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<4, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<4>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<4, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<4>());
 }
 void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
@@ -668,7 +669,8 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
         const long long mt8 = ((rows_tot + 63) / 64 + 7) / 8 * 8;   // 64-row tiles, padded to the 8 XCDs
         constexpr int LDS3 = fgemm_lds_bytes<3>(), LDS4 = fgemm_lds_bytes<4>();
         if (a.N % 128 == 0 && (a.geglu || a.N % 96)) hipLaunchKernelGGL((fgemm_kernel<4, 1, false>), dim3((unsigned)(mt8 * (a.N / 128))), dim3(256), LDS4, s, a2);
-        else hipLaunchKernelGGL((fgemm_kernel<3, 2, false>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
+        else hipLaunchKernelGGL((fgemm_kernel<3, 2, false>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);   // (one register
+        // set at five workgroups per CU — the bf16 variant's choice — spills and measured 344 vs 328 ms here)
         return;
     }
     // bf16, batch-as-rows (UNet): the 64-row K-split tile of the fp32 path on bf16 operands.  The kernels' time is their fp32
@@ -686,7 +688,14 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
             const long long mt8 = ((rows_tot + 63) / 64 + 7) / 8 * 8;
             constexpr int LDS3 = fgemm_lds_bytes<3>(), LDS4 = fgemm_lds_bytes<4>();
             if (wide_n) hipLaunchKernelGGL((fgemm_kernel<4, 1, true>), dim3((unsigned)(mt8 * (a.N / 128))), dim3(256), LDS4, s, a2);
-            else hipLaunchKernelGGL((fgemm_kernel<3, 2, true>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
+            else {
+                // one register set at FIVE workgroups per CU (96 VGPRs): the 1216 workgroups of a 192-wide launch at Be = 64 are all
+                // resident at once instead of 1024 + a tail of 192 — 124.5 -> 121.0 ms per 32 clips x 50 steps, three alternating
+                // runs on one box (scripts/gpu_r2_ar.sh).  SAID_BF_OCC5=0: two register sets at four per CU.
+                static const int occ5 = getenv("SAID_BF_OCC5") ? atoi(getenv("SAID_BF_OCC5")) : 1;
+                if (occ5) hipLaunchKernelGGL((fgemm_kernel<3, 1, true>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
+                else hipLaunchKernelGGL((fgemm_kernel<3, 2, true>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
+            }
             return;
         }
     }
