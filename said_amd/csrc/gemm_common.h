@@ -162,9 +162,7 @@ __host__ __device__ inline int epi_scratch_floats(int epi, int KS) {
 // channels of a group are then combined through a small per-wave LDS scratch (no shuffle chains).
 // scratch: 64*3 + 16*2 floats per wave.
 // ------------------------------------------------------------------------------------------------
-// NL loads per lane are issued up front (all in flight together); tiles beyond nph * NL come in further rounds of 10 inside gn_finish
-template <int NL> struct GnLoadsT { float2 v[NL]; float ref; float gamma, beta; };
-typedef GnLoadsT<10> GnLoads;
+struct GnLoads { float2 v[10]; float ref; float gamma, beta; };
 // GroupNorm partial statistics are stored TILE-major: part[b][tile][channel][2] (mean, M2), `ct` channels per tile row.  A
 // consuming wave reads them with lane <-> channel, so one load instruction touches the 1-4 cache lines that hold its 24-64
 // consecutive channels of one tile; the channel-major layout of round 1 ([channel][tile]) put every lane on a cache line of
@@ -172,8 +170,7 @@ typedef GnLoadsT<10> GnLoads;
 struct GnP { int gn_cpg, gn_nparts, Tin; float gn_eps; const float* gn_gamma; const float* gn_beta; int ct; };
 __device__ __forceinline__ GnP gnp_of(const Seg& sg) { return {sg.gn_cpg, sg.gn_nparts, sg.Tin, sg.gn_eps, sg.gn_gamma, sg.gn_beta, sg.C}; }
 
-template <int NL>
-__device__ __forceinline__ void gn_issue(const GnP sg, rsrc_t rp, int c_lo, int cw, int lane, GnLoadsT<NL>& L) {
+__device__ __forceinline__ void gn_issue(const GnP sg, rsrc_t rp, int c_lo, int cw, int lane, GnLoads& L) {
     const int nph = (cw <= 32) ? 2 : 1;
     const int ch = (nph == 2) ? (lane & 31) : lane;
     const int ph = (nph == 2) ? (lane >> 5) : 0;
@@ -186,15 +183,14 @@ __device__ __forceinline__ void gn_issue(const GnP sg, rsrc_t rp, int c_lo, int 
     L.gamma = gload(sg.gn_gamma, c);
     L.beta = gload(sg.gn_beta, c);
 #pragma unroll
-    for (int r = 0; r < NL; ++r) {
+    for (int r = 0; r < 10; ++r) {
         const int pi = ph + nph * r;
         const bool ok = chok && (pi < sg.gn_nparts);
         L.v[r] = bload2(rp, ok ? (pi * sg.ct + c) * 8 : (int)0x80000000, 0);
     }
 }
 
-template <int NL>
-__device__ __forceinline__ void gn_finish(const GnP sg, rsrc_t rp, int c_lo, int cw, int lane, const GnLoadsT<NL>& L, float* scratch,
+__device__ __forceinline__ void gn_finish(const GnP sg, rsrc_t rp, int c_lo, int cw, int lane, const GnLoads& L, float* scratch,
                                           float* cA /* interleaved (a,b), indexed by segment channel */) {
     const int nph = (cw <= 32) ? 2 : 1;
     const int ch = (nph == 2) ? (lane & 31) : lane;
@@ -205,7 +201,7 @@ __device__ __forceinline__ void gn_finish(const GnP sg, rsrc_t rp, int c_lo, int
     const int tail = sg.Tin - (nparts - 1) * 32;
     float s1 = 0.f, s2 = 0.f, sm = 0.f;
 #pragma unroll
-    for (int r = 0; r < NL; ++r) {
+    for (int r = 0; r < 10; ++r) {
         const int pi = ph + nph * r;
         const bool ok = chok && (pi < nparts);
         const float cnt = ok ? ((pi == nparts - 1) ? (float)tail : 32.f) : 0.f;
@@ -214,7 +210,7 @@ __device__ __forceinline__ void gn_finish(const GnP sg, rsrc_t rp, int c_lo, int
         s2 = fmaf(cnt * d, d, s2);
         sm += ok ? L.v[r].y : 0.f;
     }
-    for (int r0 = NL; ph + nph * r0 < nparts; r0 += 10) {  // long sequences: further rounds of 10 tiles
+    for (int r0 = 10; ph + nph * r0 < nparts; r0 += 10) {  // long sequences: further rounds of 10 tiles
         float2 v[10];
 #pragma unroll
         for (int r = 0; r < 10; ++r) {

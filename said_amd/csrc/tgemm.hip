@@ -767,8 +767,7 @@ void launch_gn_coef(const float* part, long long part_bs, int cpg, int nparts, i
 // LayerNorm over channels), transposed through LDS and written token-major in bf16 with 16-byte stores (a token's 384
 // bytes are contiguous).  HBM-bound by construction: 24.6 KB in, 12.3 KB out per workgroup.
 // ------------------------------------------------------------------------------------------------------------------
-template <int GNL>   // GroupNorm partial loads issued up front per lane (10: T <= 320 in one round trip, 20: T <= 640)
-__global__ __launch_bounds__(256, 5) void prep_kernel(const PrepArgs a) {   // five workgroups per CU: <= 96 VGPRs, 31 KB LDS
+__global__ __launch_bounds__(256, 5) void prep_kernel(const PrepArgs a) {   // five workgroups per CU: 84 VGPRs, 31 KB LDS
     __shared__ float tile[192][33];     // RAW values [channel][token]
     __shared__ float coefS[192][2];     // GroupNorm (a, b) per channel (modes 0, 1)
     // one scratch area: first the GroupNorm finalisation's per-wave scratch, then (after the tile barrier) the LayerNorm partials —
@@ -794,7 +793,7 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(const PrepArgs a) {   // f
         const int l = tid & 63, w = tid >> 6;
         const GnP gp = {a.gn_cpg, a.gn_nparts, T, a.gn_eps, a.gn_gamma, a.gn_beta, 192};
         const rsrc_t rp = make_rsrc(a.part + (long long)b * a.part_bs, 192u * (unsigned)a.gn_nparts * 8u);
-        GnLoadsT<GNL> gl;   // 48 channels per wave = one tile per load
+        GnLoads gl;   // (20 loads up front — one round trip instead of two at T = 600 — cost 96 VGPRs + spills: 118.5 vs 116.4 ms in situ)
         gn_issue(gp, rp, w * 48, 48, l, gl);
         gn_finish(gp, rp, w * 48, 48, l, gl, gns + w * GN_SCRATCH, &coefS[0][0]);
     } else if (gn) {
@@ -915,9 +914,7 @@ void launch_prep(const PrepArgs& a, int batch, hipStream_t s) {
     }
     dim3 grid(a.T / 32 + 1, batch);   // one tile past ceil(T / 32) when T % 32 == 0: the conv operand's right padding row
     static const int pad = getenv("SAID_PREP_PAD_LDS") ? atoi(getenv("SAID_PREP_PAD_LDS")) : 0;   // occupancy experiment: unused dynamic LDS
-    static const int gnl = getenv("SAID_PREP_NL") ? atoi(getenv("SAID_PREP_NL")) : 10;
-    if (gnl == 20) hipLaunchKernelGGL(prep_kernel<20>, grid, dim3(256), pad, s, a);
-    else hipLaunchKernelGGL(prep_kernel<10>, grid, dim3(256), pad, s, a);
+    hipLaunchKernelGGL(prep_kernel, grid, dim3(256), pad, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
