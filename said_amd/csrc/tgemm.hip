@@ -458,8 +458,9 @@ __host__ __device__ constexpr int fgemm_lds_bytes() {
 // BF: the same workgroup on bf16 operands (bf16 mode's UNet GEMMs): a k-tile is again 128 bytes per row (64 halfs), each K half
 // two v_mfma_f32_32x32x16_bf16 per column tile.  There the point is not MFMA balance but spread: the 256-row bf16 tiles put a
 // 192-wide convolution on 152 workgroups of a 256-CU chip, and its time is the fp32 epilogue traffic (§7.3).
-template <int NJ, int PF, bool BF>
-__global__ __launch_bounds__(256, (NJ == 3 ? (BF && PF == 1 ? 5 : 4) : 3)) void fgemm_kernel(const TGemmArgs a) {
+constexpr int fgemm_occ(int NJ, int PF, bool BF) { return NJ == 3 ? (BF && PF == 1 ? 5 : 4) : 3; }   // workgroups per CU the registers are budgeted for
+template <int NJ, int PF, bool BF, int OCC = fgemm_occ(NJ, PF, BF)>
+__global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [A 64 rows | W BN rows] x 144 bytes
     float* const ldsf = reinterpret_cast<float*>(lds);
     typedef typename std::conditional<BF, unsigned short, float>::type elt_t;
@@ -687,6 +688,7 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
         if (small_bf != 1 || big_grid < 256 || !can_big) {
             const long long mt8 = ((rows_tot + 63) / 64 + 7) / 8 * 8;
             constexpr int LDS3 = fgemm_lds_bytes<3>(), LDS4 = fgemm_lds_bytes<4>();
+            // (the GEGLU tile squeezed to 128 VGPRs for four per CU spills five registers and measured no better: 121.7 vs 120.1 ms)
             if (wide_n) hipLaunchKernelGGL((fgemm_kernel<4, 1, true>), dim3((unsigned)(mt8 * (a.N / 128))), dim3(256), LDS4, s, a2);
             else {
                 // one register set at FIVE workgroups per CU (96 VGPRs): the 1216 workgroups of a 192-wide launch at Be = 64 are all
