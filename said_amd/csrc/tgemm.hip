@@ -441,7 +441,8 @@ __global__ __launch_bounds__(512) void tgemm256_kernel(const TGemmArgs a) {
 //    — all four waves read the same LDS tiles.  (Smaller output tiles would also balance, but cost L2 bandwidth, see below.)
 //  * knock-outs of this kernel's loop: no barriers -0 %, no LDS stores -3 %, no global loads -22 %.  The loads are not waited
 //    for (average L2 latency seen by the L1 is 219 clocks, TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ; a second register set,
-//    PF = 2, buys 5 %); what they cost is CLOCK: scripts/ubench/mfma_with_loads.hip — pure fp32 MFMA loops on all CUs — sustains
+//    PF = 2, buys 5 %); what they cost is the MFMA RATE itself (power-managed clock, or register-file / issue contention — not
+//    separated): scripts/ubench/mfma_with_loads.hip — pure fp32 MFMA loops on all CUs — sustains
 //    150 TFLOP/s alone, 135 with 3.2 TB/s of independent L2 loads beside them, 114 with 5.4 TB/s, 112 with 10.5 TB/s.  A 64 x 96
 //    tile needs 20 KB per 48 MFMA-times: ~5 TB/s at the rate it runs.  So ~115 TFLOP/s is the practical roof of an fp32 GEMM at
 //    these tile sizes, and this kernel's 93-98 (convolutions), 87 (q/k/v, K = 192) and 93 (GEGLU) sit at 75-85 % of it.
