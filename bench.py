@@ -55,6 +55,7 @@ def parse():
     p.add_argument("--cpu_steps", type=int, default=40, help="UNet evaluations in the CPU-baseline sample")
     p.add_argument("--rccl_at_one", action="store_true",
                    help="N=1 only: create a ONE-rank 'nccl' (= RCCL) process group and run the sharded run's collectives on it")
+    p.add_argument("--dry_run_fail_rank", type=int, default=-1, help="with --dry_run_gloo: the stand-in path raises on this rank (failure-handling test)")
     p.add_argument("--dry_run_gloo", action="store_true",
                    help="no GPU: run the launch / shard / all-gather / timing plumbing on CPU over gloo with a stand-in path")
     return p.parse_args()
@@ -246,6 +247,8 @@ def run(args):
         dist = shard.init_process_group("gloo", rank, world) if world > 1 else None
 
         def path_fn(clips):
+            if rank == args.dry_run_fail_rank:
+                raise RuntimeError(f"stand-in path failure on rank {rank}")
             return torch.stack([torch.full((T, 32), float(c)) for c in clips])
 
         r = shard.timed_sharded_passes(path_fn, rank=rank, world=world, clips_per_rank=B, steps=args.steps, warmup=args.warmup,
@@ -342,6 +345,16 @@ def run(args):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit(f"--gpus {args.gpus}: need at least one GPU")
+    if not args.dry_run_gloo:
+        # fail fast, before any rank is spawned: one process per GPU, HIP_VISIBLE_DEVICES (if set) already narrowed the
+        # devices this process sees, and rank r uses visible device LOCAL_RANK = r
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} MI355X device(s) visible to this process "
+                             f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')}); said_amd has no CPU path "
+                             "(--dry_run_gloo exercises the launch plumbing on CPU)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as a plain `python bench.py --gpus N`: launch the N ranks here (one process per GPU)
         from said_amd import shard

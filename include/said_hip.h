@@ -44,6 +44,12 @@ enum { SAID_PRED_EPSILON = 0, SAID_PRED_SAMPLE = 1, SAID_PRED_V = 2 };
  * (768, or feature_dim when > 0); `in_channels` the coefficient width (32). */
 int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, int in_channels, int ctx_dim);
 int said_destroy(said_ctx* ctx);
+/* Grow the workspace to hold `max_batch_eff` samples of `max_frames` frames (never shrinks; no-op when both already fit).
+ * Only the (batch, frames)-sized activation buffers are re-allocated: the packed weights stay on the device, so a
+ * caller that meets a longer clip or a larger batch (script/test_inference.py:160-186 walks clips of varying length
+ * with ONE model) does not pay load_state_dict + .to(device) again.  Synchronises the device. */
+int said_reserve(said_ctx* ctx, int max_batch_eff, int max_frames);
+int said_capacity(const said_ctx* ctx, int* max_batch_eff, int* max_frames);
 const char* said_last_error(const said_ctx* ctx);
 /* ABI version of this library (bumped on any signature change). */
 int said_abi_version(void);
@@ -97,7 +103,9 @@ typedef struct said_loop_params {
     float guidance_scale;    /* CFG active iff > 1.0 (diffusion.py:358) */
     float guidance_rescale;  /* rescale_noise_cfg phi, active iff > 0 (diffusion.py:436-439) */
     float latent_scale;      /* diffusion.py:370, 470 */
-    int use_step_noise;      /* eta > 0: add sigma_t * step_noise[k] (scheduler.step) */
+    int use_step_noise;      /* eta > 0: add sigma_t * noise_k (scheduler.step).  1: noise_k = step_noise_dev[k] (injected by the
+                              * caller); 2: generated inside the step's last kernel from `noise_seed` — counter-based Philox4x32-10,
+                              * one standard normal per (step, element), nothing materialised (see said_philox_normal) */
     int use_mask;            /* editing: blend with re-noised init each step (diffusion.py:446-456) */
     int save_intermediate;   /* write pre-step latents / latent_scale per step (diffusion.py:417-419) */
     /* host tables, num_steps entries each, produced by the host scheduler in fp32 */
@@ -112,6 +120,7 @@ typedef struct said_loop_params {
     const float* mask_dev;           /* (B, T, C) or NULL */
     float* intermediates_dev;        /* (num_steps, B, T, C) or NULL */
     float* result_dev;               /* (B, T, C): clamp(latents / latent_scale, 0, 1) (diffusion.py:470) */
+    uint64_t noise_seed;             /* use_step_noise == 2: Philox key of this call's eta noise */
 } said_loop_params;
 
 /* columns of coef_host (all fp32, computed on the host in the scheduler's op order) */
@@ -129,6 +138,11 @@ enum {
 /* Runs the whole loop: per step one hipGraph replay covering the UNet, the CFG
  * combine, the scheduler update and the mask blend.  Asynchronous on `stream`. */
 int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream);
+
+/* The standard normals the loop generates with use_step_noise == 2: out_dev (nsteps, B*T*C) <- noise of steps
+ * step0 .. step0 + nsteps - 1 for `seed` (element index = ((b*T + t)*C + c)).  Replaces the `randn` drawn inside
+ * DDIMScheduler.step for eta > 0 (diffusion.py:441-443); lets a test feed the identical noise to the CPU oracle. */
+int said_philox_normal(said_ctx* ctx, uint64_t seed, int step0, int nsteps, int64_t n_per_step, float* out_dev, void* stream);
 
 /* ---- scheduler arithmetic on its own (bit-exactness tests) -------------- */
 
@@ -180,6 +194,15 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
 
 /* ---- debugging aids (used by tests/ only) ---------------------------------- */
 
+/* Test-only switches of one context (the shipped library reads no environment variables):
+ *   "unet_tgemm_min_tokens"  tokens per launch from which the UNet takes the token-major GEMM path, both precisions
+ *                            (< 0: restore the measured defaults 5800 bf16 / 10000 fp32)
+ *   "audio_chunk"            clips per audio-encoder pass (default 32)
+ *   "steps_per_graph"        denoise steps captured per hipGraph (default 10)
+ *   "bf16_tm_acts"           0: bf16 mode keeps fp32 channel-major activations between the UNet kernels at large batch (default 1)
+ * said_debug_get additionally knows "n_set_weight" (said_set_weight calls so far). */
+int said_debug_option(said_ctx* ctx, const char* name, long long value);
+long long said_debug_get(const said_ctx* ctx, const char* name);
 /* Stop the UNet schedule after `n_launches` kernel launches (< 0: run everything). */
 int said_debug_stop_after(said_ctx* ctx, int n_launches);
 /* Enable/disable per-phase shader-clock stamps in the GEMM kernels of the next UNet evaluations and

@@ -18,6 +18,7 @@ _lib = None
 
 PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 NCOEF = 8
+ABI_VERSION = 4   # include/said_hip.h as bound below; a stale libsaid_hip.so is refused at load time
 
 
 class EngineError(RuntimeError):
@@ -32,7 +33,7 @@ class LoopParams(ctypes.Structure):
         ("timesteps_host", POINTER(c_int64)), ("coef_host", POINTER(c_float)),
         ("context_dev", c_void_p), ("latents_dev", c_void_p), ("step_noise_dev", c_void_p),
         ("init_latents_dev", c_void_p), ("edit_noise_dev", c_void_p), ("mask_dev", c_void_p),
-        ("intermediates_dev", c_void_p), ("result_dev", c_void_p),
+        ("intermediates_dev", c_void_p), ("result_dev", c_void_p), ("noise_seed", ctypes.c_uint64),
     ]
 
 
@@ -40,6 +41,8 @@ EXPORTS = {
     "said_abi_version": (c_int, []),
     "said_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int]),
     "said_destroy": (c_int, [c_void_p]),
+    "said_reserve": (c_int, [c_void_p, c_int, c_int]),
+    "said_capacity": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "said_last_error": (c_char_p, [c_void_p]),
     "said_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
     "said_finalize_weights": (c_int, [c_void_p, c_void_p]),
@@ -55,6 +58,9 @@ EXPORTS = {
     "said_get_precision": (c_int, [c_void_p]),
     "said_profile_unet": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, POINTER(c_int), c_void_p]),
+    "said_philox_normal": (c_int, [c_void_p, ctypes.c_uint64, c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "said_debug_option": (c_int, [c_void_p, c_char_p, ctypes.c_longlong]),
+    "said_debug_get": (ctypes.c_longlong, [c_void_p, c_char_p]),
     "said_debug_stop_after": (c_int, [c_void_p, c_int]),
     "said_debug_clocks": (c_int, [c_void_p, c_int, c_void_p]),
     "said_debug_read": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
@@ -87,6 +93,10 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    got = lib.said_abi_version()
+    if got != ABI_VERSION:
+        raise EngineError(f"{_LIB_PATH} has ABI version {got}, this binding expects {ABI_VERSION}: rebuild it with "
+                          "`python -m said_amd.build --force`")
     _lib = lib
     return lib
 
@@ -142,6 +152,14 @@ class Engine:
         if rc != 0:
             raise EngineError(f"{what}: " + (self.lib.said_last_error(self.h) or b"?").decode())
 
+    def reserve(self, max_batch_eff: int, max_frames: int) -> None:
+        """Grow the workspace (never shrinks); the packed weights stay on the device (said_reserve)."""
+        with torch.cuda.device(self.index):
+            self._chk(self.lib.said_reserve(self.h, int(max_batch_eff), int(max_frames)), "said_reserve")
+        b, t = c_int(0), c_int(0)
+        self._chk(self.lib.said_capacity(self.h, ctypes.byref(b), ctypes.byref(t)), "said_capacity")
+        self.max_batch_eff, self.max_frames = b.value, t.value
+
     # ---- weights ----
     def load_weights(self, state_dict: Dict[str, torch.Tensor]):
         """`state_dict` uses the reference's SAID key layout."""
@@ -196,8 +214,9 @@ class Engine:
                      prediction_type: str, guidance_scale: float, guidance_rescale: float, latent_scale: float,
                      step_noise: Optional[torch.Tensor] = None, init_latents: Optional[torch.Tensor] = None,
                      edit_noise: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-                     save_intermediate: bool = False):
-        """Returns (result, final_latents, intermediates or None)."""
+                     save_intermediate: bool = False, noise_seed: Optional[int] = None):
+        """Returns (result, final_latents, intermediates or None).  `noise_seed` (with step_noise None): the eta noise is
+        generated inside the step's last kernel (Philox4x32-10 keyed by the seed) instead of being read from a tensor."""
         latents = _check_dev(latents, "latents").clone()
         context = _check_dev(context, "audio_embedding")
         B, T, C = latents.shape
@@ -223,6 +242,9 @@ class Engine:
             assert tuple(step_noise.shape) == (N, B, T, C), step_noise.shape
             p.step_noise_dev = step_noise.data_ptr()
             keep.append(step_noise)
+        elif noise_seed is not None:
+            p.use_step_noise = 2
+            p.noise_seed = int(noise_seed) & 0xFFFFFFFFFFFFFFFF
         if use_mask:
             init_latents = _check_dev(init_latents, "init_latents")
             edit_noise = _check_dev(edit_noise, "edit_noise")
@@ -280,7 +302,22 @@ class Engine:
         return [dict(us=float(us[i]), bytes=float(by[i]), flops=float(fl[i]), kind=int(kind[i]), epi=int(epi[i]), NB=int(nb[i]), KS=int(ks[i]))
                 for i in range(k)]
 
+    def philox_normal(self, seed: int, step0: int, nsteps: int, shape) -> torch.Tensor:
+        """(nsteps, *shape) standard normals: exactly what denoise_loop(noise_seed=seed) adds at steps step0 .. step0 + nsteps - 1."""
+        n = int(np.prod(shape))
+        out = torch.empty((nsteps,) + tuple(shape), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.index):
+            self._chk(self.lib.said_philox_normal(self.h, int(seed) & 0xFFFFFFFFFFFFFFFF, int(step0), int(nsteps), n, _ptr(out), _stream()),
+                      "said_philox_normal")
+        return out
+
     # ---- debugging aids (tests only) ----
+    def debug_option(self, name: str, value: int) -> None:
+        self._chk(self.lib.said_debug_option(self.h, name.encode(), int(value)), "said_debug_option")
+
+    def debug_get(self, name: str) -> int:
+        return int(self.lib.said_debug_get(self.h, name.encode()))
+
     def debug_stop_after(self, n: int):
         self._chk(self.lib.said_debug_stop_after(self.h, int(n)), "said_debug_stop_after")
 
@@ -348,6 +385,8 @@ class VaeEngine:
     def encode(self, coeffs: torch.Tensor, n_windows: int, window_stride: int, want_logvar: bool = True):
         """`coeffs`: contiguous fp32 device tensor holding the windows at `window_stride` floats apart."""
         coeffs = _check_dev(coeffs, "coeffs")
+        if coeffs.device.index != self.index:
+            raise EngineError(f"coeffs live on cuda:{coeffs.device.index}, this VAE engine on cuda:{self.index}")
         need = (n_windows - 1) * window_stride + self.seq_len * self.in_channels if n_windows > 0 else 0
         if coeffs.numel() < need:
             raise EngineError(f"coeffs holds {coeffs.numel()} floats, {n_windows} windows at stride {window_stride} need {need}")

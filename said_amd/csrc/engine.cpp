@@ -16,7 +16,6 @@
 #include "../../include/said_hip.h"
 #include "kernels.h"
 #include "tgemm.h"
-#include "xattn.h"
 
 using namespace said;
 
@@ -51,7 +50,6 @@ struct ResW { float *g1, *b1, *g2, *b2; PW conv1, conv2, skip; int cin; bool has
               void *t_conv1 = nullptr, *t_conv2 = nullptr; /* bf16 [192][taps * cin] (conv2: [576 | 384 skip]) for tgemm.hip */
               void *tf_conv1 = nullptr, *tf_conv2 = nullptr; /* the same matrices in fp32 (fgemm_kernel) */ };
 struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj, ffproj;
-             float *x_w1, *x_wq, *x_w2; /* pack16 copies of out1 / q2 / out2 for the fused chain kernel (xattn.hip) */
              void *t_qkv = nullptr, *t_ff1 = nullptr, *t_ffproj = nullptr; float* t_ff1_bias = nullptr; /* bf16 weights for tgemm.hip */
              void *tf_qkv = nullptr, *tf_ff1 = nullptr, *tf_ffproj = nullptr; /* fp32 copies (fgemm_kernel) */ };
 struct W2VLayer { PW qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln2g, *ln2b; };
@@ -67,10 +65,14 @@ struct said_ctx {
     int device = 0, maxBe = 0, maxT = 0, cin = 32, ctx_dim = 768;
     int maxTp = 0, maxNp = 0;
     std::string err;
+    std::string launch_err;          // set by a schedule function whose kernel refused its shape; reported by the C-ABI entry point
     std::map<std::string, HostTensor> host_w;
-    std::vector<void*> allocs;
+    std::vector<void*> allocs;       // weights, tables and lazily grown buffers: live as long as the context
+    std::vector<void*> ws_allocs;    // the (max_batch_eff, max_frames)-sized workspace: replaced as a whole by said_reserve
+    std::vector<void*>* alloc_list = &allocs;
     bool finalized = false, has_audio = false, has_audio_proj = false;
     int w2v_layers = 0;
+    int n_set_weight = 0;   // said_set_weight calls so far (tests: capacity growth must not re-upload the weights)
     int w2v_kernel[7] = {0}, w2v_stride[7] = {5, 2, 2, 2, 2, 2, 2};
 
     // ---- UNet weights ----
@@ -102,12 +104,11 @@ struct said_ctx {
     int* step_dev = nullptr;
     int *band_lo = nullptr, *band_hi = nullptr;
     int band_T = -1, band_S = -1, band_wmax = 0;
-    bool band_tile16_ok = false;   // every 16-query tile's windows fit XA_KW key columns (fused chain kernel)
-    bool use_xattn = false;        // SAID_XATTN=1: the fused chain kernel (xattn.hip) at small batches — measured no faster than the
-                                   // three launches it replaces (18.4 vs 17.9 us at B = 1), so it is opt-in
     float *init_cm = nullptr, *enoise_cm = nullptr, *mask_cm = nullptr, *rescale_part = nullptr;
     float* noise_cm = nullptr; size_t noise_cm_elems = 0;
     float* coef1_dev = nullptr;  // one row for said_ddim_step
+    unsigned seed_host[2] = {0, 0};
+    unsigned* seed_dev = nullptr;  // [2] Philox key of the loop's eta noise (said_loop_params::noise_seed)
     float* axpby_coef = nullptr;
     long long* clk_dev = nullptr;  // [64 launches][8 waves][8 slots]
     bool clk_on = false;
@@ -136,11 +137,14 @@ struct said_ctx {
     float* gn_coef = nullptr;   // [2 slots][maxBe][192][2] GroupNorm coefficients for prep_kernel
     void *uPA = nullptr, *uPB = nullptr, *uPL = nullptr, *uPH = nullptr, *uPX = nullptr;   // conv operand [Be][T+2][384], raw cat input
                                                                                             // [Be][T][384], LN'd [Be][T][192], GEGLU out [Be][T][768], raw x2 [Be][T][192]
+    bool bf16_tm_acts = true; // bf16 mode at large batch: bf16 token-major activations BETWEEN the UNet kernels (round 3)
     bool unet_tgemm = true;   // SAID_NO_UNET_TGEMM=1 keeps the channel-major kernels in bf16 mode at every batch size
     bool unet_fgemm = true;   // SAID_NO_UNET_FGEMM=1: the same for the fp32 mode's token-major path (fgemm_kernel)
     // tokens per launch from which the token-major GEMM path is taken (measured crossovers, scripts/gpu_r2_w.sh: bf16 between 4800
     // and 6000 tokens, fp32 between 9600 and 10800); SAID_UNET_TGEMM_MIN overrides both
     long long unet_tgemm_min_tokens = 5800, unet_fgemm_min_tokens = 10000;
+    int spg_limit = 10;      // denoise steps captured per graph
+    int audio_chunk = 32;    // clips per audio-encoder pass
 
     // ---- audio workspace (lazily sized) ----
     float *abufA = nullptr, *abufB = nullptr; size_t abuf_elems[2] = {0, 0};
@@ -172,13 +176,19 @@ int fail(said_ctx* c, const char* fmt, ...) {
     return -1;
 }
 
-static bool trace_on() { static int v = -1; if (v < 0) v = getenv("SAID_TRACE") ? 1 : 0; return v == 1; }
+static bool trace_on() { static int v = -1; if (v < 0) v = dev_env("SAID_TRACE") ? 1 : 0; return v == 1; }
 #define TRACE(msg) do { if (trace_on()) { fprintf(stderr, "[said] %s:%d %s\n", __FILE__, __LINE__, msg); fflush(stderr); } } while (0)
 
 #define HIPCHK(expr)                                                                                  \
     do {                                                                                              \
         hipError_t _e = (expr);                                                                       \
         if (_e != hipSuccess) return fail(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// a schedule function's kernel refused its shape (nothing was launched for it): report instead of continuing
+#define LAUNCHCHK()                                                                                   \
+    do {                                                                                              \
+        if (!ctx->launch_err.empty()) { const std::string m_ = ctx->launch_err; ctx->launch_err.clear(); return fail(ctx, "%s", m_.c_str()); } \
     } while (0)
 
 inline int rup(int v, int m) { return (v + m - 1) / m * m; }
@@ -195,7 +205,7 @@ int dalloc(said_ctx* ctx, T** out, size_t n, bool zero = true) {
     void* p = nullptr;
     HIPCHK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
     if (zero) HIPCHK(hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)));
-    ctx->allocs.push_back(p);
+    ctx->alloc_list->push_back(p);
     *out = static_cast<T*>(p);
     return 0;
 }
@@ -262,17 +272,6 @@ std::vector<float> pack_rows4(const float* W, int Ctot, int taps, const std::vec
                         const int c = c_begin + 8 * cq + 2 * j + (l >> 5);
                         out[o++] = row < 0 ? 0.f : W[((size_t)row * Ctot + c) * taps + tap];
                     }
-    return out;
-}
-// v_mfma_f32_16x16x4_f32 A-fragment packing of a [N][C] matrix (xattn.hip): Wp[row tile][C/16][lane][4], value e of lane l =
-// W[16 * tile + (l & 15)][16 * kq + 4 * e + (l >> 4)]
-std::vector<float> pack16(const float* W, int N, int C) {
-    std::vector<float> out((size_t)(N / 16) * (C / 16) * 256);
-    size_t o = 0;
-    for (int rt = 0; rt < N / 16; ++rt)
-        for (int kq = 0; kq < C / 16; ++kq)
-            for (int l = 0; l < 64; ++l)
-                for (int e = 0; e < 4; ++e) out[o++] = W[(size_t)(rt * 16 + (l & 15)) * C + 16 * kq + 4 * e + (l >> 4)];
     return out;
 }
 // round-to-nearest-even fp32 -> bf16 (finite inputs)
@@ -381,7 +380,7 @@ int make_pw(said_ctx* ctx, PW* pw, const std::string& wname, const std::string& 
 
 struct LaunchCfg { int NB, KS; };
 // experiment knob: SAID_BIG=cgemm restores the generic kernel's large-batch tile shapes
-static bool big_cgemm() { static const bool v = getenv("SAID_BIG") && !strcmp(getenv("SAID_BIG"), "cgemm"); return v; }
+static bool big_cgemm() { static const bool v = dev_env("SAID_BIG") && !strcmp(dev_env("SAID_BIG"), "cgemm"); return v; }
 LaunchCfg pick_cfg(long long t_tiles_total, int ntiles, bool allow6 = true) {
     // small problems: maximise workgroups (split K over 8 waves, one tile each);
     // large problems: amortise the operand transform over more tiles per workgroup.
@@ -399,7 +398,7 @@ LaunchCfg pick_unet(long long t_tiles_total) {
     if (big_cgemm()) return pick_cfg(t_tiles_total, 6);
     // experiment knob SAID_BIG_NB=1: one n-tile per workgroup also at large batch — those multi-tile kernels are compiled for
     // two workgroups per CU (gemm_lds.hip)
-    static const int big_nb = getenv("SAID_BIG_NB") ? atoi(getenv("SAID_BIG_NB")) : 2;
+    static const int big_nb = dev_env("SAID_BIG_NB") ? atoi(dev_env("SAID_BIG_NB")) : 2;
     if (big_nb == 1 && t_tiles_total >= 640) return LaunchCfg{1, 8};
     return t_tiles_total * 3 >= 192 ? LaunchCfg{2, 8} : LaunchCfg{1, 8};
 }
@@ -454,13 +453,13 @@ inline bool dbg_go(said_ctx* c) {
 // over `tt` consecutive token tiles instead, keeping its weights in registers; tt is chosen so that ~4 workgroups per
 // CU remain.  Returns 1 when the launch is not eligible.
 static int pick_tt(said_ctx* c, const GemmArgs& a, int epi, int batch, int& NB, int KS, bool bf) {
-    static const bool mt_off = getenv("SAID_NO_MT") != nullptr;
+    static const bool mt_off = dev_env("SAID_NO_MT") != nullptr;
     if (mt_off || !c->use_ugemm || a.step_inc) return 1;
     if (epi == EPI_GEGLU || epi == EPI_BAND) return 1;   // measured slower multi-tile (B=32: GEGLU NB=2 x tt vs NB=4, band)
     int nb = NB;
     const long long ntt = (a.T + 31) / 32;
     const long long wgs = ntt * (a.ntiles_per_group / nb) * batch;
-    static const long long wgs_per_tile = getenv("SAID_MT_WGS") ? std::max(64, atoi(getenv("SAID_MT_WGS"))) : 1024;   // experiment knob
+    static const long long wgs_per_tile = dev_env("SAID_MT_WGS") ? std::max(64, atoi(dev_env("SAID_MT_WGS"))) : 1024;   // experiment knob
     int tt = (int)std::min<long long>(std::min<long long>(8, wgs / wgs_per_tile), ntt);
     if (tt <= 1 || !ugemm_supports(a, epi, nb, KS, bf, tt)) return 1;
     NB = nb;
@@ -527,7 +526,7 @@ void do_prep(said_ctx* c, const PrepArgs& a, int batch, hipStream_t s) {
     if (c->log_on) c->stage_log.push_back({5, -2, 0, 0, (double)batch * a.C * a.T * (4.0 + (c->bf16_mode ? 2.0 : 4.0)) * (a.dst2 ? 1.5 : 1.0), 0.0});
     PrepArgs a2 = a;
     a2.f32 = c->bf16_mode ? 0 : 1;
-    if (dbg_go(c)) launch_prep(a2, batch, s);
+    if (dbg_go(c) && !launch_prep(a2, batch, s)) c->launch_err = "operand preparation kernel: unsupported shape";
 }
 void do_tgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     if (c->log_on) {
@@ -540,7 +539,10 @@ void do_tgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     TGemmArgs a2 = a;
     a2.f32 = c->bf16_mode ? 0 : 1;
     if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }   // token-major intermediate (GEGLU product) in fp32
-    if (dbg_go(c)) launch_tgemm(a2, batch, s);
+    if (dbg_go(c) && !launch_tgemm(a2, batch, s)) {
+        char b[160]; snprintf(b, sizeof b, "token-major GEMM: shape M=%d N=%d K=%d (batch %d) is not served by any kernel", a.M, a.N, a.K, batch);
+        c->launch_err = b;
+    }
 }
 // per-sample row pitch of the token-major operands: a multiple of 32 that holds the T tokens plus the two Conv1d padding rows, so
 // that all samples form ONE row axis for the 256-row GEMM tiles (tgemm.h: seg_rows) and 32-row MFMA tiles never straddle samples
@@ -556,7 +558,7 @@ PrepArgs mkprep(const UGeo& g, const float* x, int mode, void* dst, long long ds
 // concatenated input can be prepared back to back)
 void prep_gn(said_ctx* c, PrepArgs& p, const UGeo& g, const float* part, int cpg, float eps, const float* gamma, const float* beta, int nb,
              int slot, hipStream_t s) {
-    static const bool separate = getenv("SAID_PREP_GN_SEPARATE") != nullptr;   // A/B: coefficients by their own launch (gn_coef_kernel)
+    static const bool separate = dev_env("SAID_PREP_GN_SEPARATE") != nullptr;   // A/B: coefficients by their own launch (gn_coef_kernel)
     if (!separate) {   // finalised inside the preparation kernel from the producer's partials
         p.part = part; p.part_bs = g.sts; p.gn_cpg = cpg; p.gn_nparts = g.np; p.gn_eps = eps; p.gn_gamma = gamma; p.gn_beta = beta;
         return;
@@ -674,7 +676,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     const long long tt1 = (long long)n1 * ((g.T + 31) / 32), tt2 = (long long)n2 * ((g.T + 31) / 32);
     const long long tt = (long long)g.Be * ((g.T + 31) / 32);
     const bool big = big_cgemm() && tt * 6 > 1536;
-    const bool big_qkv = tt1 * 6 > 1536 && getenv("SAID_NO_MT") && !c->bf16_mode;   // without multi-tile workgroups the generic NB=6 shape wins in fp32
+    const bool big_qkv = tt1 * 6 > 1536 && dev_env("SAID_NO_MT") && !c->bf16_mode;   // without multi-tile workgroups the generic NB=6 shape wins in fp32
     const int vt_rows = rup(g.T, 32);
     const long long obs = 2LL * MC * g.Tp;   // batch stride of O (shared with QK so attention uses one stride)
     const bool tg = use_tg(c, g, n1);
@@ -700,7 +702,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.y = c->VT - (long long)a.tm_tiles * 32 * g.Tp; a.y_bstride = (long long)MC * g.Tp; a.y_pitch = g.Tp;
         // tiles per workgroup: the largest shape that still gives every CU a workgroup in ONE round (at Be=2, T=600:
         // NB=3 -> 228 workgroups, 27.5 -> 13.8 us per launch against NB=1's 684 workgroups in 2.7 rounds)
-        static const int qkv_env = getenv("SAID_QKV_NB") ? atoi(getenv("SAID_QKV_NB")) : 0;
+        static const int qkv_env = dev_env("SAID_QKV_NB") ? atoi(dev_env("SAID_QKV_NB")) : 0;
         const int qkv_nb = qkv_env ? qkv_env : (tt1 * 6 >= 192 ? 3 : (tt1 * 9 >= 192 ? 2 : 1));
         const LaunchCfg lc = big_qkv ? LaunchCfg{6, 4} : LaunchCfg{qkv_nb, 8};
         do_gemm(c, a, EPI_QKV, n1, lc.NB, lc.KS, s);
@@ -711,40 +713,13 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.v_bstride = (long long)MC * g.Tp; a.o_bstride = obs;
         a.pitch = g.Tp; a.T = g.T; a.heads = HEADS; a.rows = vt_rows; a.b0 = 0;
         a.scale = 0.17677669529663687f;  // 32 ** -0.5
-        static const int attn_ks_env = getenv("SAID_ATTN_KS") ? atoi(getenv("SAID_ATTN_KS")) : 0;   // experiment knob
+        static const int attn_ks_env = dev_env("SAID_ATTN_KS") ? atoi(dev_env("SAID_ATTN_KS")) : 0;   // experiment knob
         // waves per workgroup = ways the key tiles are split: 8 only pays while a wave would otherwise hold a single
         // tile (T <= 256); from there 4 waves with ~5 tiles each merge half as many partial states (B=1: -0.5 % per step)
         // large batches: four query tiles per workgroup sharing each K / V tile through the CU's L1 (-4), see attn.hip
-        static const bool no_qw = getenv("SAID_NO_ATTN_QW") != nullptr;
+        static const bool no_qw = dev_env("SAID_NO_ATTN_QW") != nullptr;
         const int attn_ks = (!no_qw && tt1 * HEADS >= 2048) ? -4 : ((tt1 * HEADS > 8192) ? 1 : ((g.T <= 256 && tt1 * HEADS <= 2048) ? 8 : 4));
         do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s);
-    }
-    // small batches: attn1.to_out + norm2 + to_q + banded cross-attention + attn2.to_out as ONE launch (xattn.hip); the
-    // weights are re-fetched by every 16-token workgroup, so beyond a few hundred workgroups the three GEMM launches win
-    static const long long xattn_max_wgs = getenv("SAID_XATTN_MAX_WGS") ? atoll(getenv("SAID_XATTN_MAX_WGS")) : 512;
-    const int xs_n = shared ? g.Bc : g.Be;
-    if (c->use_xattn && !c->bf16_mode && c->band_tile16_ok && !c->clk_on && (long long)xs_n * ((g.T + 15) / 16) <= xattn_max_wgs) {
-        XAttnArgs x;
-        memset(&x, 0, sizeof x);
-        x.o = c->O; x.o_bs = obs; x.res = in.p; x.res_bs = g.hs;
-        x.gn_part = in.st; x.gn_part_bs = g.sts; x.gn_gamma = sw.gn_g; x.gn_beta = sw.gn_b; x.gn_nparts = g.np; x.gn_eps = 1e-6f;
-        x.w1 = sw.x_w1; x.b1 = sw.out1.bias; x.ln_g = sw.l2g; x.ln_b = sw.l2b; x.wq = sw.x_wq;
-        x.k = c->KV + (long long)(blk * 2 * MC) * g.Sp; x.v = c->KV + (long long)(blk * 2 * MC + MC) * g.Sp;
-        x.kv_bs = (long long)NST * 2 * MC * g.Sp; x.kv_pitch = g.Sp;
-        x.lo = c->band_lo; x.hi = c->band_hi; x.wmax = c->band_wmax; x.scale = 0.17677669529663687f;
-        x.w2 = sw.x_w2; x.b2 = sw.out2.bias; x.c2 = c->c2[blk];
-        x.x2 = c->X2; x.x2_bs = g.hs; x.pitch = g.Tp; x.T = g.T;
-        x.mode = g.Bc > 0 ? (shared ? 2 : 1) : 0; x.Bc = g.Bc;
-        if (xattn_supports(x, xs_n)) {
-            if (c->log_on) {
-                const double tok = (double)g.T;
-                const double nfull = g.Bc > 0 ? g.Bc : g.Be;
-                c->stage_log.push_back({3, EPI_STORE, 1, 8, 4.0 * (3.0 * MC * MC + (double)xs_n * MC * tok * 2 + (double)g.Be * MC * tok + nfull * 2 * MC * tok),
-                                        2.0 * MC * MC * tok * (xs_n + 2.0 * nfull) + 2.0 * nfull * tok * MC * 2 * c->band_wmax});
-            }
-            if (dbg_go(c)) launch_xattn(x, xs_n, s);
-            goto geglu;
-        }
     }
     {   // x1 = to_out(attn) + x, with x = GroupNorm(in) recomputed on the fly   (attention.py:127, 168)
         GemmArgs a = mkargs(g.T, MC);
@@ -785,7 +760,6 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         const LaunchCfg lc = pick_unet(tt2);
         do_gemm(c, a, EPI_STORE, n2, lc.NB, lc.KS, s);
     }
-geglu:
     if (use_tg(c, g, g.Be)) {
         {   // GEGLU: operand norm3(x2) (and raw x2 for the folded proj_out), value/gate pairs multiplied in the epilogue
             const long long P = tg_rows(g);
@@ -815,11 +789,11 @@ geglu:
         a.seg[0].ln_gamma = sw.l3g; a.seg[0].ln_beta = sw.l3b; a.seg[0].ln_eps = 1e-5f;
         a.bias = sw.ff1.bias; a.geglu_gate_tiles = FFI / 32;
         a.y = c->F; a.y_bstride = (long long)FFI * g.Tp; a.y_pitch = g.Tp;
-        static const int geglu_env = getenv("SAID_GEGLU_NB") ? atoi(getenv("SAID_GEGLU_NB")) : 0;
+        static const int geglu_env = dev_env("SAID_GEGLU_NB") ? atoi(dev_env("SAID_GEGLU_NB")) : 0;
         const int geglu_nb = geglu_env ? geglu_env : (tt * 6 >= 192 ? 4 : (tt * 12 >= 192 ? 2 : 1));   // one round of workgroups, as for qkv
         do_gemm(c, a, EPI_GEGLU, g.Be, big ? 3 : geglu_nb, big ? 4 : 8, s);
     }
-    static const bool no_fold = getenv("SAID_NO_FFPROJ_FOLD") != nullptr;   // A/B knob: the two unfused launches
+    static const bool no_fold = dev_env("SAID_NO_FFPROJ_FOLD") != nullptr;   // A/B knob: the two unfused launches
     if (!no_fold) {
         // x3 = net.2(h) + x2 and out = proj_out(x3) + x_in as ONE GEMM over the K segments [h ; x2] with the host-folded
         // weights (P F2 | P) — both maps are per-token linear, so nothing but rounding order changes
@@ -863,7 +837,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
     c->cur_b0 = g.b0;
     const long long tt = (long long)g.Be * ((g.T + 31) / 32);
     const int in_copies = (g.B_lat > 0 && g.Be % g.B_lat == 0) ? g.Be / g.B_lat : 0;   // samples sharing one clip's latents
-    static const bool no_conv_in = getenv("SAID_NO_CONV_IN") != nullptr;
+    static const bool no_conv_in = dev_env("SAID_NO_CONV_IN") != nullptr;
     if (!no_conv_in && g.b0 == 0 && in_copies >= 1 && c->conv_in.w4[0] && !c->clk_on &&
         conv_in_supports(c->cin, MC, c->conv_in.taps, g.T, g.Tp, in_copies)) {
         // input_blocks.0: Conv1d(32 -> 192, k3), computed once per clip (conv_in.hip)
@@ -970,13 +944,6 @@ int set_band(said_ctx* ctx, int T, int S, hipStream_t s) {
     HIPCHK(hipMemcpy(ctx->band_lo, lo.data(), T * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->band_hi, hi.data(), T * sizeof(int), hipMemcpyHostToDevice));
     ctx->band_T = T; ctx->band_S = S; ctx->band_wmax = wmax;
-    bool ok16 = true;
-    for (int t0 = 0; t0 < T; t0 += 16) {
-        const int tl = std::min(t0 + 15, T - 1);
-        if (hi[tl] - lo[t0] > XA_KW) ok16 = false;
-        for (int t = t0; t < tl; ++t) if (lo[t + 1] < lo[t]) ok16 = false;
-    }
-    ctx->band_tile16_ok = ok16;
     return 0;
 }
 
@@ -986,6 +953,58 @@ UGeo make_geo(said_ctx* c, int Be, int B_lat, int T, int S) {
     g.hs = (long long)MC * g.Tp; g.sts = (long long)MC * g.np * 2;
     g.step_ptr = nullptr; g.emb_b_stride = 0; g.b0 = 0; g.step_inc = nullptr; g.out_sched = nullptr; g.Bc = 0;
     return g;
+}
+
+// The workspace of a context: every buffer whose size depends on (max_batch_eff, max_frames).  Allocated by said_create and
+// replaced as a whole by said_reserve; weights, packed tables and the lazily grown audio / noise buffers are not touched.
+int alloc_workspace(said_ctx* ctx, int max_batch_eff, int max_frames) {
+    ctx->maxBe = max_batch_eff; ctx->maxT = max_frames;
+    ctx->maxTp = rup(max_frames, 32);
+    ctx->maxNp = rup(std::max(1024, max_batch_eff), 32);
+    ctx->alloc_list = &ctx->ws_allocs;
+    const size_t Be = max_batch_eff, Tp = ctx->maxTp, np = Tp / 32;
+    const int ctx_dim = ctx->ctx_dim;
+    int rc = 0;
+    const size_t act = Be * MC * Tp, stt = Be * MC * np * 2;
+    rc |= dalloc(ctx, &ctx->x_cm, Be * 32 * Tp);
+    rc |= dalloc(ctx, &ctx->eps_cm, Be * 32 * Tp);
+    for (ActBuf* a : {&ctx->H0, &ctx->H1, &ctx->P, &ctx->Q, &ctx->M}) { rc |= dalloc(ctx, &a->p, act); rc |= dalloc(ctx, &a->st, stt); }
+    rc |= dalloc(ctx, &ctx->X1, act); rc |= dalloc(ctx, &ctx->X2, act); rc |= dalloc(ctx, &ctx->X3, act);
+    rc |= dalloc(ctx, &ctx->O, 2 * act);  // same batch stride as QK so attention can share one stride
+    rc |= dalloc(ctx, &ctx->QK, 2 * act);
+    rc |= dalloc(ctx, &ctx->VT, Be * HEADS * Tp * HD);
+    rc |= dalloc(ctx, &ctx->F, Be * FFI * Tp);
+    rc |= dalloc(ctx, &ctx->KV, Be * NST * 2 * MC * Tp);
+    rc |= dalloc(ctx, &ctx->CTX, Be * (size_t)ctx_dim * Tp);
+    const size_t Np = ctx->maxNp;
+    rc |= dalloc(ctx, &ctx->E0, MC * Np); rc |= dalloc(ctx, &ctx->E1, TE * Np); rc |= dalloc(ctx, &ctx->E2, TE * Np);
+    rc |= dalloc(ctx, &ctx->EO, NRES * MC * Np);
+    rc |= dalloc(ctx, &ctx->ts_dev, Np); rc |= dalloc(ctx, &ctx->coef_dev, Np * 8);
+    rc |= dalloc(ctx, &ctx->axpby_coef, 2 * Np);
+    rc |= dalloc(ctx, &ctx->band_lo, Tp); rc |= dalloc(ctx, &ctx->band_hi, Tp);
+    rc |= dalloc(ctx, &ctx->init_cm, Be * 32 * Tp); rc |= dalloc(ctx, &ctx->enoise_cm, Be * 32 * Tp); rc |= dalloc(ctx, &ctx->mask_cm, Be * 32 * Tp);
+    rc |= dalloc(ctx, &ctx->rescale_part, Be * 2 * 64 * 3);
+    {   // operand buffers of the large-batch token-major path (sized for fp32 elements; zero-initialised, so padding rows start at 0)
+        const size_t Tm = (size_t)rup(max_frames + 2, 32);   // tg_rows(): per-sample row pitch
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPA), 2 * (Be * Tm * 2 * MC + 4096));
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPB), 2 * (Be * Tm * 2 * MC + 4096));
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPL), 2 * (Be * Tm * MC + 4096));
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPH), 2 * (Be * Tm * FFI + 4096));
+        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPX), 2 * (Be * Tm * MC + 4096));
+        rc |= dalloc(ctx, &ctx->gn_coef, 2 * Be * 2 * MC);
+    }
+    ctx->alloc_list = &ctx->allocs;
+    ctx->band_T = ctx->band_S = -1;   // the band tables are part of the workspace
+    return rc;
+}
+
+void drop_graphs(said_ctx* ctx) {
+    if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
+    if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+    if (ctx->gexec_rem) { (void)hipGraphExecDestroy(ctx->gexec_rem); ctx->gexec_rem = nullptr; }
+    if (ctx->graph_rem) { (void)hipGraphDestroy(ctx->graph_rem); ctx->graph_rem = nullptr; }
+    ctx->gkey.clear();
+    ctx->gnodes = 0;
 }
 
 int check_ready(said_ctx* ctx) {
@@ -1001,7 +1020,7 @@ int check_ready(said_ctx* ctx) {
 // ============================================================================================
 extern "C" {
 
-int said_abi_version(void) { return 3; }   // 3: said_vae_*, said_profile_unet(cfg_clips)
+int said_abi_version(void) { return 4; }   // 4: said_reserve, said_loop_params::noise_seed, said_philox_normal, said_debug_option
 
 const char* said_last_error(const said_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -1027,62 +1046,32 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
             return fail(nullptr, "said_create: device is %s; this library is built for gfx950 only", prop.gcnArchName);
     }
     ctx = new said_ctx();
-    ctx->device = device; ctx->maxBe = max_batch_eff; ctx->maxT = max_frames; ctx->cin = in_channels; ctx->ctx_dim = ctx_dim;
-    ctx->maxTp = rup(max_frames, 32);
-    ctx->maxNp = rup(std::max(1024, max_batch_eff), 32);
+    ctx->device = device; ctx->cin = in_channels; ctx->ctx_dim = ctx_dim;
     configure_gemm_kernels();
     configure_ugemm_kernels();
     configure_attn_kernels();
     configure_out_sched_kernel();
-    ctx->use_ugemm = getenv("SAID_NO_UGEMM") == nullptr;
-    ctx->use_branches = getenv("SAID_BRANCHES") != nullptr;
-    ctx->cfg_share = getenv("SAID_NO_CFG_SHARE") == nullptr;
-    ctx->use_xattn = getenv("SAID_XATTN") != nullptr;
-    ctx->audio_bf16 = getenv("SAID_NO_AUDIO_BF16") == nullptr;
-    ctx->pos_tgemm = getenv("SAID_NO_POSCONV_TGEMM") == nullptr;
-    ctx->unet_tgemm = getenv("SAID_NO_UNET_TGEMM") == nullptr;
-    ctx->unet_fgemm = getenv("SAID_NO_UNET_FGEMM") == nullptr;
-    if (getenv("SAID_UNET_TGEMM_MIN")) ctx->unet_tgemm_min_tokens = ctx->unet_fgemm_min_tokens = atoll(getenv("SAID_UNET_TGEMM_MIN"));
+    ctx->use_ugemm = dev_env("SAID_NO_UGEMM") == nullptr;
+    ctx->use_branches = dev_env("SAID_BRANCHES") != nullptr;
+    ctx->cfg_share = dev_env("SAID_NO_CFG_SHARE") == nullptr;
+    ctx->audio_bf16 = dev_env("SAID_NO_AUDIO_BF16") == nullptr;
+    ctx->pos_tgemm = dev_env("SAID_NO_POSCONV_TGEMM") == nullptr;
+    ctx->unet_tgemm = dev_env("SAID_NO_UNET_TGEMM") == nullptr;
+    ctx->unet_fgemm = dev_env("SAID_NO_UNET_FGEMM") == nullptr;
+    if (dev_env("SAID_UNET_TGEMM_MIN")) ctx->unet_tgemm_min_tokens = ctx->unet_fgemm_min_tokens = atoll(dev_env("SAID_UNET_TGEMM_MIN"));
     configure_tgemm_kernel();
-    configure_xattn_kernel();   // parallel graph branches measured no faster on ROCm 7.2: off by default
     if (hipStreamCreateWithFlags(&ctx->cap_stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return fail(nullptr, "stream/event creation failed"); }
     if (hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, "hipStreamCreateWithFlags failed"); }
 
-    const size_t Be = max_batch_eff, Tp = ctx->maxTp, np = Tp / 32;
-    const size_t act = Be * MC * Tp, stt = Be * MC * np * 2;
     int rc = 0;
-    rc |= dalloc(ctx, &ctx->x_cm, Be * 32 * Tp);
-    rc |= dalloc(ctx, &ctx->eps_cm, Be * 32 * Tp);
-    for (ActBuf* a : {&ctx->H0, &ctx->H1, &ctx->P, &ctx->Q, &ctx->M}) { rc |= dalloc(ctx, &a->p, act); rc |= dalloc(ctx, &a->st, stt); }
-    rc |= dalloc(ctx, &ctx->X1, act); rc |= dalloc(ctx, &ctx->X2, act); rc |= dalloc(ctx, &ctx->X3, act);
-    rc |= dalloc(ctx, &ctx->O, 2 * act);  // same batch stride as QK so attention can share one stride
-    rc |= dalloc(ctx, &ctx->QK, 2 * act);
-    rc |= dalloc(ctx, &ctx->VT, Be * HEADS * Tp * HD);
-    rc |= dalloc(ctx, &ctx->F, Be * FFI * Tp);
-    rc |= dalloc(ctx, &ctx->KV, Be * NST * 2 * MC * Tp);
-    rc |= dalloc(ctx, &ctx->CTX, Be * (size_t)ctx_dim * Tp);
-    const size_t Np = ctx->maxNp;
-    rc |= dalloc(ctx, &ctx->E0, MC * Np); rc |= dalloc(ctx, &ctx->E1, TE * Np); rc |= dalloc(ctx, &ctx->E2, TE * Np);
-    rc |= dalloc(ctx, &ctx->EO, NRES * MC * Np);
-    rc |= dalloc(ctx, &ctx->ts_dev, Np); rc |= dalloc(ctx, &ctx->coef_dev, Np * 8); rc |= dalloc(ctx, &ctx->coef1_dev, 8);
+    rc |= dalloc(ctx, &ctx->coef1_dev, 8);
     rc |= dalloc(ctx, &ctx->step_dev, 4);
-    rc |= dalloc(ctx, &ctx->axpby_coef, 2 * Np);
+    rc |= dalloc(ctx, &ctx->seed_dev, 4);
     rc |= dalloc(ctx, &ctx->clk_dev, 64 * 128);
-    rc |= dalloc(ctx, &ctx->band_lo, Tp); rc |= dalloc(ctx, &ctx->band_hi, Tp);
-    rc |= dalloc(ctx, &ctx->init_cm, Be * 32 * Tp); rc |= dalloc(ctx, &ctx->enoise_cm, Be * 32 * Tp); rc |= dalloc(ctx, &ctx->mask_cm, Be * 32 * Tp);
-    rc |= dalloc(ctx, &ctx->rescale_part, Be * 2 * 64 * 3);
     rc |= dalloc(ctx, &ctx->freqs, MC / 2);
-    {   // operand buffers of the large-batch token-major path (sized for fp32 elements; zero-initialised, so padding rows start at 0)
-        const size_t Tm = (size_t)rup(max_frames + 2, 32);   // tg_rows(): per-sample row pitch
-        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPA), 2 * (Be * Tm * 2 * MC + 4096));
-        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPB), 2 * (Be * Tm * 2 * MC + 4096));
-        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPL), 2 * (Be * Tm * MC + 4096));
-        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPH), 2 * (Be * Tm * FFI + 4096));
-        rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPX), 2 * (Be * Tm * MC + 4096));
-        rc |= dalloc(ctx, &ctx->gn_coef, 2 * Be * 2 * MC);
-    }
+    rc |= alloc_workspace(ctx, max_batch_eff, max_frames);
     if (rc) { g_create_err = ctx->err; said_destroy(ctx); return -1; }
     *out = ctx;
     return 0;
@@ -1092,22 +1081,45 @@ int said_destroy(said_ctx* ctx) {
     if (!ctx) return 0;
     DeviceRestore restore_device;
     (void)hipSetDevice(ctx->device);
-    if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
-    if (ctx->graph) (void)hipGraphDestroy(ctx->graph);
-    if (ctx->gexec_rem) (void)hipGraphExecDestroy(ctx->gexec_rem);
-    if (ctx->graph_rem) (void)hipGraphDestroy(ctx->graph_rem);
+    drop_graphs(ctx);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     if (ctx->cap_stream2) (void)hipStreamDestroy(ctx->cap_stream2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (void* p : ctx->allocs) (void)hipFree(p);
+    for (void* p : ctx->ws_allocs) (void)hipFree(p);
     delete ctx;
+    return 0;
+}
+
+int said_reserve(said_ctx* ctx, int max_batch_eff, int max_frames) {
+    if (!ctx) return -1;
+    if (max_batch_eff < 1 || max_frames < 1) return fail(ctx, "said_reserve: bad sizes");
+    if (max_batch_eff <= ctx->maxBe && max_frames <= ctx->maxT) return 0;
+    DeviceRestore restore_device;
+    HIPCHK(hipSetDevice(ctx->device));
+    // earlier calls may still be running on any stream: the buffers they use are about to be freed
+    HIPCHK(hipDeviceSynchronize());
+    drop_graphs(ctx);   // the captured step graphs hold the old buffers' addresses
+    for (void* p : ctx->ws_allocs) (void)hipFree(p);
+    ctx->ws_allocs.clear();
+    if (alloc_workspace(ctx, std::max(max_batch_eff, ctx->maxBe), std::max(max_frames, ctx->maxT))) return -1;
+    return 0;
+}
+
+int said_capacity(const said_ctx* ctx, int* max_batch_eff, int* max_frames) {
+    if (!ctx) return -1;
+    if (max_batch_eff) *max_batch_eff = ctx->maxBe;
+    if (max_frames) *max_frames = ctx->maxT;
     return 0;
 }
 
 int said_set_weight(said_ctx* ctx, const char* name, const float* data_host, const int64_t* shape, int ndim) {
     if (!ctx) return -1;
     if (ctx->finalized) return fail(ctx, "said_set_weight after finalize");
+    if (!name || !data_host || !shape || ndim < 1 || ndim > 8) return fail(ctx, "said_set_weight: bad arguments");
+    for (int i = 0; i < ndim; ++i) if (shape[i] < 0) return fail(ctx, "said_set_weight(%s): negative dimension", name);
+    ++ctx->n_set_weight;
     HostTensor t;
     t.shape.assign(shape, shape + ndim);
     t.data.assign(data_host, data_host + t.numel());
@@ -1214,14 +1226,6 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
         std::copy(k2->data.begin(), k2->data.end(), kv_w.begin() + (size_t)(i * 2) * MC * CD);
         std::copy(v2->data.begin(), v2->data.end(), kv_w.begin() + (size_t)(i * 2 + 1) * MC * CD);
         if (make_pw(ctx, &sw.out2, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", MC, MC, 0)) return -1;
-        {   // 16x16x4 fragment packings for the fused chain kernel
-            const HostTensor* w1 = getw(ctx, b + ".attn1.to_out.0.weight", {MC, MC});
-            const HostTensor* wq2 = getw(ctx, b + ".attn2.to_q.weight", {MC, MC});
-            const HostTensor* w2 = getw(ctx, b + ".attn2.to_out.0.weight", {MC, MC});
-            if (!w1 || !wq2 || !w2) return -1;
-            auto p1 = pack16(w1->data.data(), MC, MC), pq = pack16(wq2->data.data(), MC, MC), p2 = pack16(w2->data.data(), MC, MC);
-            if (upload(ctx, &sw.x_w1, p1.data(), p1.size()) || upload(ctx, &sw.x_wq, pq.data(), pq.size()) || upload(ctx, &sw.x_w2, p2.data(), p2.size())) return -1;
-        }
         {   // attn2 output for the unconditional context (null_cond_emb repeated: every key / value identical, softmax
             // uniform => output = to_v(null)), pushed through to_out: c2 = W_out (W_v null) + b_out, in double
             const HostTensor* nc = getw(ctx, "null_cond_emb", {1, 1, CD});
@@ -1463,6 +1467,7 @@ int said_unet_forward(said_ctx* ctx, const float* sample_dev, const int64_t* tim
     launch_tm_to_cm(sample_dev, ctx->x_cm, Be, T, ctx->cin, g.Tp, (long long)ctx->cin * g.Tp, s);
     run_unet(ctx, g, s);
     launch_cm_to_tm(ctx->eps_cm, out_dev, Be, T, ctx->cin, g.Tp, (long long)ctx->cin * g.Tp, s);
+    LAUNCHCHK();
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1483,7 +1488,8 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     if (p->prediction_type < 0 || p->prediction_type > 2) return fail(ctx, "bad prediction_type %d", p->prediction_type);
     if (!p->latents_dev || !p->context_dev) return fail(ctx, "latents_dev/context_dev must not be null");
     if (p->use_mask && !(p->init_latents_dev && p->edit_noise_dev && p->mask_dev)) return fail(ctx, "use_mask needs init_latents_dev, edit_noise_dev and mask_dev");
-    if (p->use_step_noise && !p->step_noise_dev) return fail(ctx, "use_step_noise needs step_noise_dev");
+    if (p->use_step_noise == 1 && !p->step_noise_dev) return fail(ctx, "use_step_noise = 1 needs step_noise_dev");
+    if (p->use_step_noise < 0 || p->use_step_noise > 2) return fail(ctx, "bad use_step_noise %d", p->use_step_noise);
     if (p->save_intermediate && !p->intermediates_dev) return fail(ctx, "save_intermediate needs intermediates_dev");
     if (set_band(ctx, T, T, s)) return -1;
     UGeo g = make_geo(ctx, Be, cfg ? B : 0, T, T);
@@ -1514,7 +1520,11 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
         launch_tm_to_cm(p->edit_noise_dev, ctx->enoise_cm, B, T, C, g.Tp, xs, s);
         launch_tm_to_cm(p->mask_dev, ctx->mask_cm, B, T, C, g.Tp, xs, s);
     }
-    if (p->use_step_noise && N > 0) {
+    if (p->use_step_noise == 2) {   // Philox key of this call's eta noise (the graph reads it from device memory)
+        ctx->seed_host[0] = (unsigned)(p->noise_seed & 0xffffffffu); ctx->seed_host[1] = (unsigned)(p->noise_seed >> 32);
+        HIPCHK(hipMemcpyAsync(ctx->seed_dev, ctx->seed_host, 2 * sizeof(unsigned), hipMemcpyHostToDevice, s));
+    }
+    if (p->use_step_noise == 1 && N > 0) {
         const size_t need = (size_t)N * B * xs;
         if (need > ctx->noise_cm_elems) {
             HIPCHK(hipStreamSynchronize(s));
@@ -1532,7 +1542,8 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     sa.guidance_scale = p->guidance_scale; sa.guidance_rescale = (cfg && p->guidance_rescale > 0.f) ? p->guidance_rescale : 0.f;
     sa.rescale_part = ctx->rescale_part; sa.rescale_nblk = 16; sa.prediction_type = p->prediction_type;
     sa.coef = ctx->coef_dev; sa.step_ptr = ctx->step_dev; sa.x = ctx->x_cm; sa.x_bstride = xs;
-    sa.step_noise = p->use_step_noise ? ctx->noise_cm : nullptr;
+    sa.step_noise = p->use_step_noise == 1 ? ctx->noise_cm : nullptr;
+    sa.noise_seed = p->use_step_noise == 2 ? ctx->seed_dev : nullptr;
     sa.init = p->use_mask ? ctx->init_cm : nullptr; sa.edit_noise = p->use_mask ? ctx->enoise_cm : nullptr;
     sa.mask = p->use_mask ? ctx->mask_cm : nullptr;
     sa.inter = p->save_intermediate ? p->intermediates_dev : nullptr; sa.latent_scale = p->latent_scale;
@@ -1541,12 +1552,12 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     memset(&osa, 0, sizeof osa);
     osa.x = ctx->P.p; osa.gn_part = ctx->P.st; osa.gn_gamma = ctx->out_g; osa.gn_beta = ctx->out_b;
     osa.w4 = ctx->conv_out.w4[0]; osa.bias = ctx->conv_out.bias; osa.coef = ctx->coef_dev; osa.step_ptr = ctx->step_dev;
-    osa.lat = ctx->x_cm; osa.step_noise = sa.step_noise; osa.init = sa.init; osa.edit_noise = sa.edit_noise; osa.mask = sa.mask;
+    osa.lat = ctx->x_cm; osa.step_noise = sa.step_noise; osa.noise_seed = sa.noise_seed; osa.init = sa.init; osa.edit_noise = sa.edit_noise; osa.mask = sa.mask;
     osa.inter = sa.inter; osa.x_bstride = g.hs; osa.gn_part_bstride = g.sts; osa.lat_bstride = xs;
     osa.pitch = g.Tp; osa.T = T; osa.B = B; osa.Cin = MC; osa.Cout = C; osa.gn_nparts = g.np; osa.cfg = cfg ? 1 : 0;
     osa.prediction_type = p->prediction_type; osa.guidance_scale = p->guidance_scale; osa.guidance_rescale = sa.guidance_rescale;
     osa.latent_scale = p->latent_scale;
-    static const bool no_fuse = getenv("SAID_NO_FUSE_SCHED") != nullptr;
+    static const bool no_fuse = dev_env("SAID_NO_FUSE_SCHED") != nullptr;
     const bool fused = !no_fuse && !ctx->use_branches && ctx->conv_out.w4[0] && out_sched_supports(osa);
     if (fused) g.out_sched = &osa;
 
@@ -1557,17 +1568,13 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
         // steps per graph: consecutive denoise steps captured back to back in ONE graph (the device-side step counter
         // makes the copies distinct): N / spg launches of the spg-step graph cover the loop, and a second graph holding
         // the N % spg remaining steps finishes it (prime N, e.g. 997 = 99 x 10 + 7)
-        static const int spg_limit = getenv("SAID_SPG") ? std::max(1, atoi(getenv("SAID_SPG"))) : 10;   // measured: ~6 us per graph launch boundary; 10 steps per graph recover 1.2 % at B=1
-        int spg = std::min(spg_limit, N);
+        int spg = std::min(ctx->spg_limit, N);   // measured: ~6 us per graph launch boundary; 10 steps per graph recover 1.2 % at B=1
         if (ctx->use_branches) spg = 1;
         const int rem = N % spg;
-        std::vector<long long> key = {spg, rem, B, T, cfg, gsi, gri, lsi, p->prediction_type, p->use_mask, p->use_step_noise,
+        std::vector<long long> key = {spg, rem, B, T, cfg, gsi, gri, lsi, p->prediction_type, p->use_mask, p->use_step_noise, ctx->bf16_mode,
                                       (long long)(uintptr_t)sa.inter, (long long)(uintptr_t)sa.step_noise};
         if (!ctx->gexec || key != ctx->gkey) {
-            if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
-            if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
-            if (ctx->gexec_rem) { (void)hipGraphExecDestroy(ctx->gexec_rem); ctx->gexec_rem = nullptr; }
-            if (ctx->graph_rem) { (void)hipGraphDestroy(ctx->graph_rem); ctx->graph_rem = nullptr; }
+            drop_graphs(ctx);
             const bool fold_step = !(ctx->use_branches && Be >= 2);   // conv_in advances the step counter itself
             // Eager warm-up of the exact step sequence first: the first launch of a kernel inside a
             // stream capture hangs on ROCm 7.2 (lazy per-kernel initialisation is not capturable).
@@ -1632,6 +1639,7 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     }
     TRACE("loop: graphs launched");
     launch_finish(ctx->x_cm, xs, g.Tp, B, T, C, p->latent_scale, p->latents_dev, p->result_dev, s);
+    LAUNCHCHK();
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1677,6 +1685,50 @@ int said_debug_clocks(said_ctx* ctx, int enable, long long* out_host /* [64][8][
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMemcpy(out_host, ctx->clk_dev, 64 * 128 * sizeof(long long), hipMemcpyDeviceToHost));
     }
+    return 0;
+}
+
+int said_debug_option(said_ctx* ctx, const char* name, long long value) {
+    if (!ctx || !name) return -1;
+    const std::string k = name;
+    if (k == "unet_tgemm_min_tokens") {
+        ctx->unet_tgemm_min_tokens = value < 0 ? 5800 : value;
+        ctx->unet_fgemm_min_tokens = value < 0 ? 10000 : value;
+    } else if (k == "audio_chunk") {
+        if (value < 1) return fail(ctx, "audio_chunk must be >= 1");
+        ctx->audio_chunk = (int)value;
+    } else if (k == "steps_per_graph") {
+        if (value < 1) return fail(ctx, "steps_per_graph must be >= 1");
+        ctx->spg_limit = (int)value;
+    } else if (k == "bf16_tm_acts") {
+        ctx->bf16_tm_acts = value != 0;
+    } else {
+        return fail(ctx, "said_debug_option: unknown option %s", name);
+    }
+    ctx->gkey.clear();   // the captured step graph may hold the other schedule
+    return 0;
+}
+
+long long said_debug_get(const said_ctx* ctx, const char* name) {
+    if (!ctx || !name) return -1;
+    const std::string k = name;
+    if (k == "n_set_weight") return ctx->n_set_weight;
+    if (k == "unet_tgemm_min_tokens") return ctx->bf16_mode ? ctx->unet_tgemm_min_tokens : ctx->unet_fgemm_min_tokens;
+    if (k == "audio_chunk") return ctx->audio_chunk;
+    if (k == "steps_per_graph") return ctx->spg_limit;
+    if (k == "bf16_tm_acts") return ctx->bf16_tm_acts ? 1 : 0;
+    return -1;
+}
+
+int said_philox_normal(said_ctx* ctx, uint64_t seed, int step0, int nsteps, int64_t n_per_step, float* out_dev, void* stream) {
+    if (!ctx) return -1;
+    if (nsteps < 0 || n_per_step < 0 || n_per_step > 0xffffffffLL || !out_dev) return fail(ctx, "said_philox_normal: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->seed_host[0] = (unsigned)(seed & 0xffffffffu); ctx->seed_host[1] = (unsigned)(seed >> 32);
+    HIPCHK(hipMemcpyAsync(ctx->seed_dev, ctx->seed_host, 2 * sizeof(unsigned), hipMemcpyHostToDevice, s));
+    launch_philox_normal(ctx->seed_dev, step0, nsteps, n_per_step, out_dev, s);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -1805,8 +1857,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
     // workspace: ping-pong conv buffers + token-domain buffers, for `chunk` clips at a time
     // clips per pass: the 65 MB/clip conv0 activation is what bounds it (32 clips = 2.1 GB of 288 GB); larger launches
     // amortise the 377 MB of encoder weights over more tokens
-    static const int chunk_max = getenv("SAID_AUDIO_CHUNK") ? std::max(1, atoi(getenv("SAID_AUDIO_CHUNK"))) : 32;
-    const int chunk = std::min(B, chunk_max);
+    const int chunk = std::min(B, ctx->audio_chunk);
     const size_t eA = (size_t)chunk * W2V_CONV * rup(L[0], 32), eB = (size_t)chunk * W2V_CONV * rup(L[1], 32);
     const size_t tok = (size_t)chunk * Fp;
     const size_t tw = std::max<size_t>(W2V_H, (size_t)ctx->ctx_dim);   // aT also receives the audio_proj_layer output (ctx_dim wide)
@@ -1862,7 +1913,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                 a.w = ctx->bw_conv[i]; a.act = 1;
                 a.yb = dst; a.y_bs = (long long)L[i] * W2V_CONV; a.ldy = W2V_CONV;
                 a.M = L[i]; a.N = W2V_CONV; a.K = ctx->w2v_kernel[i] * W2V_CONV;
-                launch_tgemm(a, nb, s);
+                if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 std::swap(src, dst);
             }
             // interpolation to the frame count (wav2vec2.py:41-44) + feature_projection.layer_norm
@@ -1875,7 +1926,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                 memset(&a, 0, sizeof a);
                 a.a = ctx->bX; a.a_bs = (long long)Fr * W2V_CONV; a.lda = W2V_CONV; a.w = ctx->bw_fproj; a.bias = ctx->fproj.bias;
                 a.yf = ctx->bH; a.y_bs = hsT; a.ldy = W2V_H; a.M = Fr; a.N = W2V_H; a.K = W2V_CONV;
-                launch_tgemm(a, nb, s);
+                if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
             }
             const int PK = ctx->posconv.taps, PG = 16, PCG = W2V_H / PG;
             if (ctx->pos_tgemm && ctx->bw_pos && PK % 2 == 0) {
@@ -1893,7 +1944,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     a.res = ctx->bH + g * PCG; a.res_bs = hsT; a.ldr = W2V_H;
                     a.yf = ctx->bT + g * PCG; a.y_bs = hsT; a.ldy = W2V_H; a.n_store = PCG;
                     a.M = Fr; a.N = 64; a.K = PK * PCG;
-                    launch_tgemm(a, nb, s);
+                    if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 launch_ln_tm(ctx->bT, nullptr, ctx->bH, ctx->bHb, ctx->enc_lng, ctx->enc_lnb, (long long)nb * Fr, W2V_H, 1e-5f, s);
             } else {
@@ -1920,7 +1971,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     a.a = ctx->bHb; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.qkv; a.bias = ly.qkv.bias;
                     a.qk = ctx->aQK; a.vt = ctx->aVT; a.v_bs = hs; a.qk_n = 2 * W2V_H; a.head_dim = W2V_HD; a.rows = Fp; a.heads2 = 2 * W2V_HEADS;
                     a.v_pitch = Fp; a.M = Fr; a.N = 3 * W2V_H; a.K = W2V_H;
-                    launch_tgemm(a, nb, s);
+                    if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 {
                     AttnArgs a;
@@ -1936,7 +1987,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     a.a = ctx->bO; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.out; a.bias = ly.out.bias;
                     a.res = ctx->bH; a.res_bs = hsT; a.ldr = W2V_H;
                     a.yf = ctx->bT; a.y_bs = hsT; a.ldy = W2V_H; a.M = Fr; a.N = W2V_H; a.K = W2V_H;
-                    launch_tgemm(a, nb, s);
+                    if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 launch_ln_tm(ctx->bT, nullptr, ctx->bH, ctx->bHb, ly.ln1g, ly.ln1b, (long long)nb * Fr, W2V_H, 1e-5f, s);
                 {   // feed_forward.intermediate_dense + GELU
@@ -1944,7 +1995,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     memset(&a, 0, sizeof a);
                     a.a = ctx->bHb; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.ff1; a.bias = ly.ff1.bias; a.act = 1;
                     a.yb = ctx->bF; a.y_bs = (long long)Fr * W2V_FFN; a.ldy = W2V_FFN; a.M = Fr; a.N = W2V_FFN; a.K = W2V_H;
-                    launch_tgemm(a, nb, s);
+                    if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 {   // feed_forward.output_dense + residual, then final_layer_norm
                     TGemmArgs a;
@@ -1952,7 +2003,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     a.a = ctx->bF; a.a_bs = (long long)Fr * W2V_FFN; a.lda = W2V_FFN; a.w = bl.ff2; a.bias = ly.ff2.bias;
                     a.res = ctx->bH; a.res_bs = hsT; a.ldr = W2V_H;
                     a.yf = ctx->bT; a.y_bs = hsT; a.ldy = W2V_H; a.M = Fr; a.N = W2V_H; a.K = W2V_FFN;
-                    launch_tgemm(a, nb, s);
+                    if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 const bool last = l + 1 == ctx->w2v_layers && !apply_proj;   // the last LayerNorm writes the (B, frames, 768) result itself
                 launch_ln_tm(ctx->bT, nullptr, last ? out_dev + (long long)b0 * Fr * W2V_H : ctx->bH, ctx->bHb, ly.ln2g, ly.ln2b, (long long)nb * Fr, W2V_H, 1e-5f, s);
@@ -1962,11 +2013,12 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                 memset(&a, 0, sizeof a);
                 a.a = ctx->bHb; a.a_bs = hsT; a.lda = W2V_H; a.w = ctx->bw_aproj; a.bias = ctx->aproj.bias;
                 a.yf = out_dev + (long long)b0 * Fr * out_dim; a.y_bs = (long long)Fr * out_dim; a.ldy = out_dim; a.M = Fr; a.N = out_dim; a.K = W2V_H;
-                launch_tgemm(a, nb, s);
+                if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
             } else if (ctx->w2v_layers == 0) {
                 HIPCHK(hipMemcpyAsync(out_dev + (long long)b0 * Fr * W2V_H, ctx->bH, (size_t)nb * Fr * W2V_H * sizeof(float), hipMemcpyDeviceToDevice, s));
             }
         }
+        LAUNCHCHK();
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -2086,6 +2138,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
         }
         launch_cm_to_tm(fin, out_dev + (long long)b0 * Fr * out_dim, nb, Fr, out_dim, Fp, fin_bs, s);
     }
+    LAUNCHCHK();
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2173,6 +2226,8 @@ int said_vae_set_weight(said_vae* v, const char* name, const float* data_host, c
     if (!v) return -1;
     said_ctx* ctx = &v->c;
     if (v->finalized) return fail(ctx, "said_vae_set_weight after finalize");
+    if (!name || !data_host || !shape || ndim < 1 || ndim > 8) return fail(ctx, "said_vae_set_weight: bad arguments");
+    for (int i = 0; i < ndim; ++i) if (shape[i] < 0) return fail(ctx, "said_vae_set_weight(%s): negative dimension", name);
     HostTensor t;
     t.shape.assign(shape, shape + ndim);
     t.data.assign(data_host, data_host + t.numel());

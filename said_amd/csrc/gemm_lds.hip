@@ -1016,7 +1016,7 @@ constexpr int kMaxLds = 160 * 1024;
 template <int NB, int KS, int EPI, int VAR, bool BF, bool MT>
 static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s, int tt) {
     int smem = ugemm_smem_floats<NB, EPI>(a, KS, MT) * (int)sizeof(float);
-    static const int min_lds = getenv("SAID_MIN_LDS") ? atoi(getenv("SAID_MIN_LDS")) : 0;   // experiment: force one workgroup per CU
+    static const int min_lds = dev_env("SAID_MIN_LDS") ? atoi(dev_env("SAID_MIN_LDS")) : 0;   // experiment: force one workgroup per CU
     if (smem < min_lds) smem = min_lds;
     if (smem > kMaxLds) { fprintf(stderr, "said: ugemm needs %d B of LDS\n", smem); abort(); }
     const int ntt = (a.T + 31) / 32;

@@ -8,8 +8,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace said {
+
+// Development knobs (A/B switches, experiment sizes) are environment variables that ONLY a build compiled with
+// -DSAID_DEV_KNOBS reads (SAID_EXTRA_DEFS=-DSAID_DEV_KNOBS python -m said_amd.build --force; scripts/README.md).  The
+// shipped library ignores the environment: every dev_env() below is a null pointer there.
+inline const char* dev_env(const char* name) {
+#ifdef SAID_DEV_KNOBS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // operand transforms applied while loading X (fused producer-side elementwise work)
 enum XForm : int {
@@ -179,6 +192,7 @@ struct SchedArgs {
     const float* mask;
     float* inter;              // token-major (nsteps, B, T, C) or null: pre-step latents / latent_scale
     float latent_scale;
+    const unsigned* noise_seed;   // device [2] Philox key: the eta noise is generated in the kernel (sched_math.h), or null
 };
 void launch_sched_step(const SchedArgs& a, hipStream_t s);
 
@@ -203,6 +217,7 @@ struct OutSchedArgs {
     int cfg;                   // 1: samples [0, B) unconditional, [B, 2B) conditional
     int prediction_type;
     float guidance_scale, guidance_rescale, latent_scale;
+    const unsigned* noise_seed;   // device [2] Philox key: eta noise generated in the kernel (sched_math.h), or null
 };
 bool out_sched_supports(const OutSchedArgs& a);
 void launch_out_sched(const OutSchedArgs& a, hipStream_t s);
@@ -216,6 +231,8 @@ void launch_ddim_flat(const float* eps, const float* eps_u, float gs, const floa
 // out[b][i] = a[b]*x[b][i] + c[b]*y[b][i] (explicitly rounded mul, mul, add); coefficients live in device memory
 void launch_axpby(const float* a_dev, const float* x, const float* c_dev, const float* y, float* out, int B, long long n,
                   hipStream_t s);
+// out (nsteps, B, T, C) token-major <- the standard normals the loop's kernels generate for (seed, step0 + k, element)
+void launch_philox_normal(const unsigned* seed_dev, int step0, int nsteps, long long n_per_step, float* out, hipStream_t s);
 // result = clamp(x / latent_scale, 0, 1), channel-major -> token-major; also copies latents out
 void launch_finish(const float* x_cm, long long x_bstride, int pitch, int B, int T, int C, float latent_scale,
                    float* latents_tm, float* result_tm, hipStream_t s);

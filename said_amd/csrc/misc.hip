@@ -231,6 +231,8 @@ __global__ void sched_step_kernel(const SchedArgs a) {
     if (a.step_noise) {
         const float nz = a.step_noise[((long long)step * a.B + b) * a.x_bstride + off];
         prev = __fadd_rn(prev, __fmul_rn(cf[4], nz));
+    } else if (a.noise_seed) {
+        prev = __fadd_rn(prev, __fmul_rn(cf[4], philox_normal(a.noise_seed[0], a.noise_seed[1], (unsigned)step, (unsigned)((b * a.T + t) * a.C + c))));
     }
     if (a.mask) {
         const long long o2 = (long long)b * a.x_bstride + off;
@@ -241,6 +243,16 @@ __global__ void sched_step_kernel(const SchedArgs a) {
 void launch_sched_step(const SchedArgs& a, hipStream_t s) {
     dim3 grid((a.T + 63) / 64, a.C, a.B);
     hipLaunchKernelGGL(sched_step_kernel, grid, dim3(64), 0, s, a);
+}
+
+__global__ void philox_normal_kernel(const unsigned* __restrict__ seed, int step0, long long n_per_step, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = philox_normal(seed[0], seed[1], (unsigned)(step0 + (int)(i / n_per_step)), (unsigned)(i % n_per_step));
+}
+void launch_philox_normal(const unsigned* seed_dev, int step0, int nsteps, long long n_per_step, float* out, hipStream_t s) {
+    const long long n = n_per_step * nsteps;
+    if (n > 0) hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, seed_dev, step0, n_per_step, n, out);
 }
 
 __global__ void ddim_flat_kernel(const float* __restrict__ eps, const float* __restrict__ eps_u, float gs,

@@ -36,4 +36,32 @@ __device__ __forceinline__ float mask_blend(float prev, float init, float enoise
     return __fadd_rn(__fmul_rn(noisy, mask), __fmul_rn(prev, __fsub_rn(1.0f, mask)));
 }
 
+
+// ------------------------------------------------------------------------------------------
+// eta > 0 variance noise generated on the device (said_loop_params::use_step_noise == 2): the reference draws
+// `randn(model_output.shape)` inside DDIMScheduler.step once per step (diffusion.py:441-443) — a stream no other
+// implementation reproduces bit for bit — so the product path draws its own standard normals, counter-based:
+// Philox4x32-10 (Salmon et al., SC'11) with key = the call's 64-bit seed and counter = (element index in (B, T, C)
+// order, step, 0, 0); the first two output words make one Box-Muller normal.  Layout- and launch-shape-independent,
+// nothing is stored: no (N, B, T, C) buffer exists.  said_philox_normal fills a tensor with exactly these values.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float philox_normal(unsigned seed_lo, unsigned seed_hi, unsigned step, unsigned elem) {
+    unsigned r[4];
+    philox4x32_10(elem, step, 0u, 0u, seed_lo, seed_hi, r);
+    const float u1 = ((float)(r[0] >> 8) + 1.0f) * 5.9604644775390625e-8f;    // (0, 1], 24 bits
+    const float u2 = (float)(r[1] >> 8) * 5.9604644775390625e-8f;             // [0, 1)
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
 }  // namespace said

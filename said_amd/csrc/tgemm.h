@@ -61,7 +61,8 @@ struct TGemmArgs {
 };
 int tgemm_geglu_src_row(int n, int N);
 bool tgemm_supports(const TGemmArgs& a);
-void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s);   // N % 128 == 0: 128-wide tiles, else N % 64 == 0: 64-wide
+// false: shape not served by any instantiation (nothing launched) — the caller reports it through the C ABI
+bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s);   // N % 128 == 0: 128-wide tiles, else N % 64 == 0: 64-wide
 void configure_tgemm_kernel();
 // UNet operand preparation (bf16 mode, large batches): channel-major fp32 x[b][C][pitch] -> transform -> token-major bf16.
 // mode 0: silu(GroupNorm(x)) into dst[b][1 + t][ldd] at column `coff` (rows 0 and T + 1 zero: Conv1d padding), mode 1:
@@ -78,7 +79,7 @@ struct PrepArgs {
     int mode;
     int f32;               // 1: dst / dst2 are fp32 (operands of the fp32 token-major GEMM), else bf16
 };
-void launch_prep(const PrepArgs& a, int batch, hipStream_t s);
+bool launch_prep(const PrepArgs& a, int batch, hipStream_t s);
 // GroupNorm coefficients of a 192-channel tensor from its Welford partials [b][192][nparts][2] -> coef_out[b][192][2]
 void launch_gn_coef(const float* part, long long part_bs, int cpg, int nparts, int T, float eps, const float* gamma, const float* beta,
                     float* coef_out, long long coef_bs, int batch, hipStream_t s);

@@ -657,23 +657,23 @@ void configure_tgemm_kernel() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<4, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<4>());
 }
-void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
-    if (!tgemm_supports(a)) { fprintf(stderr, "said: tgemm shape M=%d N=%d K=%d unsupported\n", a.M, a.N, a.K); abort(); }
+bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
+    if (!tgemm_supports(a)) return false;
     TGemmArgs a2 = a;
     a2.batch = batch;
-    static const int dbg = getenv("SAID_TG_DBG") ? atoi(getenv("SAID_TG_DBG")) : 0;
+    static const int dbg = dev_env("SAID_TG_DBG") ? atoi(dev_env("SAID_TG_DBG")) : 0;
     a2.dbg = dbg;
-    static const bool no256 = getenv("SAID_NO_TGEMM256") != nullptr;
+    static const bool no256 = dev_env("SAID_NO_TGEMM256") != nullptr;
     const long long rows_tot = a.seg_rows > 0 ? (long long)batch * a.seg_rows : a.M;
     const int nb = a.seg_rows > 0 ? 1 : batch;
     if (a.f32) {
-        if ((rows_tot + 2) * (long long)std::max(a.lda, a.lda2) >= 0x7fffffffLL) { fprintf(stderr, "said: fgemm operand too large for 32-bit offsets\n"); abort(); }
+        if ((rows_tot + 2) * (long long)std::max(a.lda, a.lda2) >= 0x7fffffffLL) return false;   // 32-bit operand offsets
         const long long mt8 = ((rows_tot + 63) / 64 + 7) / 8 * 8;   // 64-row tiles, padded to the 8 XCDs
         constexpr int LDS3 = fgemm_lds_bytes<3>(), LDS4 = fgemm_lds_bytes<4>();
         if (a.N % 128 == 0 && (a.geglu || a.N % 96)) hipLaunchKernelGGL((fgemm_kernel<4, 1, false>), dim3((unsigned)(mt8 * (a.N / 128))), dim3(256), LDS4, s, a2);
         else hipLaunchKernelGGL((fgemm_kernel<3, 2, false>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);   // (one register
         // set at five workgroups per CU — the bf16 variant's choice — spills and measured 344 vs 328 ms here)
-        return;
+        return true;
     }
     // bf16, batch-as-rows (UNet): the 64-row K-split tile of the fp32 path on bf16 operands.  The kernels' time is their fp32
     // epilogue traffic, and the 256-row tiles give a 192-wide output 152 workgroups on 256 CUs (42.0 -> 35.8 us on the small tile).
@@ -681,7 +681,7 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
     // 69.7 vs 75.0 us) but the real step does not: 122.1 vs 120.3 ms per 32 clips x 50 steps, three alternating runs on one box
     // (scripts/gpu_r2_ak.sh) — one 147 KB-LDS workgroup per CU starts and drains badly between neighbours of other shapes.  So
     // the small tile is the rule; SAID_TGEMM_SMALL=0 restores the 256-row tiles, =1 uses them only where they fill the chip.
-    static const int small_bf = getenv("SAID_TGEMM_SMALL") ? atoi(getenv("SAID_TGEMM_SMALL")) : -1;
+    static const int small_bf = dev_env("SAID_TGEMM_SMALL") ? atoi(dev_env("SAID_TGEMM_SMALL")) : -1;
     if (a.seg_rows > 0 && small_bf != 0 && a.K % 64 == 0 && (!a.a2 || a.K1 % 64 == 0) && (a.N % 96 == 0 || a.N % 128 == 0)) {
         const bool wide_n = a.N % 128 == 0 && (a.geglu || a.N % 96);
         const long long big_grid = ((rows_tot + 255) / 256) * (a.N / (wide_n ? 256 : 192));
@@ -695,20 +695,20 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
                 // one register set at FIVE workgroups per CU (96 VGPRs): the 1216 workgroups of a 192-wide launch at Be = 64 are all
                 // resident at once instead of 1024 + a tail of 192 — 124.5 -> 121.0 ms per 32 clips x 50 steps, three alternating
                 // runs on one box (scripts/gpu_r2_ar.sh).  SAID_BF_OCC5=0: two register sets at four per CU.
-                static const int occ5 = getenv("SAID_BF_OCC5") ? atoi(getenv("SAID_BF_OCC5")) : 1;
+                static const int occ5 = dev_env("SAID_BF_OCC5") ? atoi(dev_env("SAID_BF_OCC5")) : 1;
                 if (occ5) hipLaunchKernelGGL((fgemm_kernel<3, 1, true>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
                 else hipLaunchKernelGGL((fgemm_kernel<3, 2, true>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
             }
-            return;
+            return true;
         }
     }
     const bool big = !no256 && (a.N % 256 == 0 || a.N % 192 == 0) && rows_tot * nb >= 4096 &&
                      (rows_tot + 2) * (long long)std::max(a.lda, a.lda2) < 0x7fffffffLL;
-    if (a.geglu && !big) { fprintf(stderr, "said: the GEGLU epilogue needs the 256-wide tile\n"); abort(); }
+    if (a.geglu && !big) return false;   // the GEGLU epilogue needs the 256-wide tile
     // Per-sample operands (audio encoder): a 256-row tile holds one workgroup per CU, so its grid runs in rounds of 256 — the
     // encoder's 768-wide GEMMs at 32 clips x 600 frames are 288 workgroups = two rounds, the second 12 % full.  Where the
     // 128 x 128 tile (two per CU, rounds of 512) fills its rounds clearly better, it is used instead (SAID_TGEMM_BALANCE=0: never).
-    static const int balance = getenv("SAID_TGEMM_BALANCE") ? atoi(getenv("SAID_TGEMM_BALANCE")) : 15;   // margin in percent; 0: never
+    static const int balance = dev_env("SAID_TGEMM_BALANCE") ? atoi(dev_env("SAID_TGEMM_BALANCE")) : 15;   // margin in percent; 0: never
     bool use_big = big;
     if (big && balance > 0 && a.seg_rows == 0 && !a.geglu && a.N % 128 == 0) {
         const long long mt_big = (rows_tot + 255) / 256, mt_128 = (a.M + TBM - 1) / TBM;
@@ -728,9 +728,9 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
             dim3 grid((unsigned)(mt8 * (a.N / 192)));
             hipLaunchKernelGGL(tgemm256_kernel<192>, grid, dim3(512), 2 * (256 + 192) * TLP * 2, s, a2);
         }
-        return;
+        return true;
     }
-    if (a.seg_rows > 0) { fprintf(stderr, "said: batch-as-rows addressing needs the 256-row tile\n"); abort(); }
+    if (a.seg_rows > 0) return false;   // batch-as-rows addressing needs the 256-row tile
     const long long mtiles8 = ((long long)batch * ((a.M + TBM - 1) / TBM) + 7) / 8 * 8;   // (sample, M tile) pairs padded to the 8 XCDs
     if (a.N % 128 == 0) {
         dim3 grid((unsigned)(mtiles8 * (a.N / 128)));
@@ -739,6 +739,7 @@ void launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
         dim3 grid((unsigned)(mtiles8 * (a.N / 64)));
         hipLaunchKernelGGL(tgemm_kernel<64>, grid, dim3(256), 2 * (TBM + 64) * TLP * 2, s, a2);
     }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -910,14 +911,12 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(const PrepArgs a) {   // f
         z[0] = zero; z[1] = zero; z[2] = zero;
     }
 }
-void launch_prep(const PrepArgs& a, int batch, hipStream_t s) {
-    if (a.C != 192 || a.T < 1 || a.ldd % 8 || a.coff % 8 || a.dst_bs % 8 || (a.dst2 && (a.ldd2 % 8 || a.coff2 % 8 || a.dst2_bs % 8)) || a.pitch % 4) {
-        fprintf(stderr, "said: prep kernel: unsupported shape (C=%d ldd=%d coff=%d)\n", a.C, a.ldd, a.coff);
-        abort();
-    }
+bool launch_prep(const PrepArgs& a, int batch, hipStream_t s) {
+    if (a.C != 192 || a.T < 1 || a.ldd % 8 || a.coff % 8 || a.dst_bs % 8 || (a.dst2 && (a.ldd2 % 8 || a.coff2 % 8 || a.dst2_bs % 8)) || a.pitch % 4) return false;
     dim3 grid(a.T / 32 + 1, batch);   // one tile past ceil(T / 32) when T % 32 == 0: the conv operand's right padding row
-    static const int pad = getenv("SAID_PREP_PAD_LDS") ? atoi(getenv("SAID_PREP_PAD_LDS")) : 0;   // occupancy experiment: unused dynamic LDS
+    static const int pad = dev_env("SAID_PREP_PAD_LDS") ? atoi(dev_env("SAID_PREP_PAD_LDS")) : 0;   // occupancy experiment: unused dynamic LDS
     hipLaunchKernelGGL(prep_kernel, grid, dim3(256), pad, s, a);
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

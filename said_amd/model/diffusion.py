@@ -78,22 +78,43 @@ class SAID(ABC, nn.Module):
             self.null_cond_emb = nn.Parameter(torch.randn(1, 1, hidden))
         self._eng: Optional[_engine.Engine] = None
         self._eng_key = None
+        self._eng_stale = True
+        self._param_list = None
         self.mfma_dtype = "fp32"   # "bf16": bf16 multiplies in the UNet GEMMs (BASELINE.json configs[2]); set_mfma_dtype()
         self.audio_encoder._owner = weakref.ref(self)
 
     # ---- engine management ---------------------------------------------------
+    # The engine holds its own packed copy of the weights.  It is rebuilt when the module's parameters are replaced or
+    # moved — load_state_dict(), .to() / .cuda() / .float() (all go through nn.Module._apply) mark it stale — and when the
+    # cheap per-call check below sees an in-place update that bumps a parameter's version counter (optimizer steps,
+    # `p.copy_()` under no_grad).  Writes through `p.data` bypass both: call refresh_engine() after them.
+    def _apply(self, fn, *args, **kwargs):
+        self._eng_stale = True
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._eng_stale = True
+        return super().load_state_dict(*args, **kwargs)
+
+    def refresh_engine(self) -> "SAID":
+        """Re-upload the weights at the next call (after in-place edits of `param.data`).  Not part of the reference surface."""
+        self._eng_stale = True
+        return self
+
     def _weights_key(self):
-        ps = list(self.parameters())
-        return (str(ps[0].device), sum(p._version for p in ps), sum(p.data_ptr() for p in ps) & 0xFFFFFFFFFFFF)
+        ps = self._param_list
+        if ps is None:
+            ps = self._param_list = list(self.parameters())
+        return (str(ps[0].device), sum(p._version for p in ps))
 
     def _get_engine(self, batch_eff: int, frames: int) -> _engine.Engine:
-        dev = next(self.parameters()).device
-        if dev.type != "cuda":
-            raise _engine.EngineError(f"model is on {dev}: said_amd runs on MI355X only — call .to('cuda:N') "
-                                      "(the CPU restatement lives in oracle/ and is test infrastructure)")
-        key = self._weights_key()
         e = self._eng
-        if e is None or key != self._eng_key or e.max_batch_eff < batch_eff or e.max_frames < frames:
+        if e is None or getattr(self, "_eng_stale", True) or self._weights_key() != self._eng_key:
+            self._param_list = None
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise _engine.EngineError(f"model is on {dev}: said_amd runs on MI355X only — call .to('cuda:N') "
+                                          "(the CPU restatement lives in oracle/ and is test infrastructure)")
             cap_b = max(batch_eff, e.max_batch_eff if e else 2)
             cap_t = max((frames + 63) // 64 * 64, e.max_frames if e else 64)
             if e is not None:
@@ -101,8 +122,11 @@ class SAID(ABC, nn.Module):
             ctx_dim = self.feature_dim if self.feature_dim > 0 else self.audio_config.hidden_size
             e = _engine.Engine(dev, cap_b, cap_t, self.denoiser.in_channels, ctx_dim)
             e.load_weights(self.state_dict())
-            self._eng, self._eng_key = e, key
+            self._eng, self._eng_key, self._eng_stale = e, self._weights_key(), False
             self.noise_scheduler._engine = e
+        elif e.max_batch_eff < batch_eff or e.max_frames < frames:
+            # a larger batch or a longer clip: only the workspace grows, the packed weights stay where they are
+            e.reserve(max(batch_eff, e.max_batch_eff), max((frames + 63) // 64 * 64, e.max_frames))
         e.set_precision(self.mfma_dtype == "bf16")
         return e
 
@@ -201,19 +225,21 @@ class SAID(ABC, nn.Module):
         ts = sch.timesteps[t_start:].cpu().numpy().astype(np.int64)
         n_run = len(ts)
         coef = sch.coef_table(ts, float(eta))
-        noise_steps = None
+        noise_steps, noise_seed = None, None
         if eta > 0 and n_run > 0:
-            if step_noise is not None:
+            if step_noise is not None:   # injected by the caller (tests: the CPU oracle is fed the same draws)
                 noise_steps = step_noise.to(device)
-            else:  # one draw per step, in step order, as scheduler.step does
-                noise_steps = torch.empty(n_run, batch_size, window_size, in_channels, device=device)
-                for k in range(n_run):
-                    noise_steps[k] = torch.randn(batch_size, window_size, in_channels, device=device)
+            else:
+                # The reference draws randn(model_output.shape) inside scheduler.step, once per step (diffusion.py:441-443).
+                # Here the step's last kernel generates its own standard normals from a counter-based generator keyed by
+                # ONE 64-bit seed taken from torch's default generator (so torch.manual_seed still fixes the run): no
+                # (N, B, T, 32) noise tensor exists — 2.46 GB at B = 32, N = 1000.
+                noise_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
         use_mask = init_samples is not None and mask is not None
         result, _, inter = eng.denoise_loop(
             latents=latents, context=audio_embedding, timesteps=ts, coef=coef,
             prediction_type=sch.config.prediction_type, guidance_scale=guidance_scale, guidance_rescale=guidance_rescale,
-            latent_scale=self.latent_scale, step_noise=noise_steps,
+            latent_scale=self.latent_scale, step_noise=noise_steps, noise_seed=noise_seed,
             init_latents=init_lat if use_mask else None, edit_noise=noise if use_mask else None,
             mask=mask.to(device) if use_mask else None, save_intermediate=save_intermediate)
         intermediates = [inter[k] for k in range(n_run)] if save_intermediate else []

@@ -103,10 +103,26 @@ class BCVAE(nn.Module):
                 nn.init.zeros_(p)
         self._eng: Optional[_engine.VaeEngine] = None
         self._eng_key = None
+        self._eng_stale = True
+
+    # The engine holds folded copies of the weights (BatchNorm folded into the preceding layer).  load_state_dict() and
+    # .to() / .cuda() (nn.Module._apply) mark them stale, as does an in-place update that bumps a tensor's version counter;
+    # writes through `.data` bypass both: call refresh_engine() after them.
+    def _apply(self, fn, *args, **kwargs):
+        self._eng_stale = True
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._eng_stale = True
+        return super().load_state_dict(*args, **kwargs)
+
+    def refresh_engine(self) -> "BCVAE":
+        self._eng_stale = True
+        return self
 
     def _weights_key(self):
         ts = list(self.parameters()) + list(self.buffers())
-        return (str(ts[0].device), sum(t._version for t in ts), sum(t.data_ptr() for t in ts) & 0xFFFFFFFFFFFF)
+        return (str(ts[0].device), tuple(t._version for t in ts))
 
     def _get_engine(self) -> _engine.VaeEngine:
         dev = next(self.parameters()).device
@@ -115,12 +131,12 @@ class BCVAE(nn.Module):
         if self.training:
             raise _engine.EngineError("BCVAE.encode on the HIP engine is eval-mode only (BatchNorm uses running statistics): call .eval()")
         key = self._weights_key()
-        if self._eng is None or key != self._eng_key:
+        if self._eng is None or self._eng_stale or key != self._eng_key:
             if self._eng is not None:
                 self._eng.close()
             e = _engine.VaeEngine(dev, self.channels, self.seq_len, self.z_dim)
             e.load_weights({k: v for k, v in self.state_dict().items() if k.startswith("encoder.")})
-            self._eng, self._eng_key = e, key
+            self._eng, self._eng_key, self._eng_stale = e, key, False
         return self._eng
 
     def encode(self, coeffs: torch.Tensor) -> BCLatent:

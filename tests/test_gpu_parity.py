@@ -293,7 +293,7 @@ def test_loop_is_deterministic_and_graph_replayed(model, dev):
     a = model.inference(proc, num_inference_steps=12, guidance_scale=2.0, init_latents=lat).result
     b = model.inference(proc, num_inference_steps=12, guidance_scale=2.0, init_latents=lat).result
     assert torch.equal(a, b)
-    assert model._eng.graph_num_nodes() >= 30  # one captured graph covers the whole step (40 launches; 32 with the opt-in chain kernel)
+    assert model._eng.graph_num_nodes() >= 30  # one captured graph covers the whole step (40 launches at this batch)
 
 
 def test_idempotent_clamp_and_linearity_properties_full_size(model, dev):
@@ -462,8 +462,9 @@ def test_loop_1000_steps_teacher_forced_vs_oracle(model, sd_full, dev):
 
 
 def test_loop_1000_steps_eta1_teacher_forced_vs_oracle(model, sd_full, dev):
-    """Same with eta = 1 (ancestral sampling, one injected noise draw per step)."""
-    worst = _teacher_forced(model, sd_full, dev, N=1000, eta=1.0, seg_lens=[1, 10])
+    """Same with eta = 1 (ancestral sampling, one injected noise draw per step); single steps sampled at every 4th step of the
+    chain (the eta = 0 test above walks all 1000; this keeps the suite inside its time limit)."""
+    worst = _teacher_forced(model, sd_full, dev, N=1000, eta=1.0, seg_lens=[1, 10], starts={1: range(0, 1000, 4)})
     print(f"N=1000 eta=1 teacher-forced: worst single-step err {worst[1]:.3e}, worst 10-step-segment err {worst[10]:.3e}")
     assert worst[1] <= 2e-4 and worst[10] <= 1e-3
 
@@ -616,31 +617,6 @@ def test_bf16_audio_encoder_vs_fp32_oracle(model, w2v_sd, dev, Ta, frames):
     assert b16.shape == ref.shape and torch.isfinite(b16).all()
     assert not torch.equal(b16, f32)
     assert float(e.max()) <= BF16_AUDIO_TOL and rms <= 5e-2
-
-
-def test_fused_chain_kernel_opt_in(unet_sd, sd_full, dev, monkeypatch):
-    """xattn.hip (attn1.to_out -> norm2 -> to_q -> banded cross-attention -> attn2.to_out in one launch on 16-token tiles,
-    v_mfma_f32_16x16x4_f32) is opt-in (SAID_XATTN=1: measured no faster than the three launches).  All three of its modes
-    against the oracle: plain forward (mode 0), the guided loop's shared first block (mode 2) and other blocks (mode 1)."""
-    from said_amd.model.diffusion import SAID_UNet1D
-    monkeypatch.setenv("SAID_XATTN", "1")
-    m = SAID_UNet1D()
-    m.load_state_dict(synth.said_state_dict(), strict=True)
-    m.to(dev).eval()
-    x = synth.synth_latents(24, (2, 600, 32))
-    c = synth.synth_latents(124, (2, 600, 768))
-    ts = torch.tensor([999, 17])
-    out = m(x.to(dev), ts.to(dev), c.to(dev)).cpu()
-    ref = ou.unet1d_forward(unet_sd, x, ts, c)
-    assert float((out - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
-    x = synth.synth_latents(300 + 7, (1, 7, 32))                     # fewer tokens than one tile, S != T
-    c = synth.synth_latents(400 + 10, (1, 10, 768))
-    out = m(x.to(dev), torch.tensor([11]).to(dev), c.to(dev)).cpu()
-    ref = ou.unet1d_forward(unet_sd, x, torch.tensor([11]), c)
-    assert float((out - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
-    _loop_case(m, sd_full, dev, B=2, Ta=16000, N=20, gs=2.0)
-    assert m._eng.graph_num_nodes() == 32
-    m._eng.close()
 
 
 def test_bf16_unet_large_batch_token_major_gemm_path(model, unet_sd, dev):

@@ -1,0 +1,339 @@
+"""Round-3 GPU parity tests: the large-batch schedules the bench runs (BASELINE configs[2]/[3]) against the ORACLE (not
+against another HIP run), the reference's batched caller at its real shape (script/test_inference.py:90, 167-186: 64 clips
+per chunk -> UNet batch 128), configs[0] through the CLI, the token-major path on edge shapes, workspace growth without a
+weight reload, and the device-generated eta noise.  All through the C ABI."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from scipy.io import wavfile
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import philox_ref  # noqa: E402
+from oracle import pipeline as op  # noqa: E402
+from oracle import scheduler as osch  # noqa: E402
+from oracle import unet as ou  # noqa: E402
+from oracle import wav2vec2 as ow  # noqa: E402
+from said_amd.util import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+AUDIO_TOL = 4e-6          # x max(1, |ref|max): the B = 1 bound of test_gpu_parity.py
+BF16_AUDIO_TOL = 0.11     # the B = 1 bf16 bound of test_gpu_parity.py
+BF16_STEP_MAX = 0.13      # teacher-forced bf16 single step, as in test_gpu_parity.py
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    from said_amd.model.diffusion import SAID_UNet1D
+    m = SAID_UNet1D()
+    m.load_state_dict(synth.said_state_dict(), strict=True)
+    m.to(dev).eval()
+    return m
+
+
+@pytest.fixture(scope="module")
+def sd_full():
+    return synth.said_state_dict()
+
+
+def _load_script(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "script", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _write_wav(path, n, seed):
+    w = (synth.synth_waveform(seed, n).numpy() * 32767 * 3).clip(-32768, 32767).astype(np.int16)
+    wavfile.write(path, 16000, w)
+    return w.astype(np.float32) / 32768.0
+
+
+# ---------------------------------------------------------------- (a), (b): the audio encoder at the bench's batch sizes
+def test_audio_encoder_batch32_10s_vs_oracle_both_precisions(model, w2v_sd, dev):
+    """configs[2]/[3] encode 32 clips per pass: launch_tgemm's tile choice by round fill x row fill (bf16) and the
+    cgemm<6,4,*> / <4,4,0> shapes (fp32) that no B <= 2 call reaches.  Clips 0, 17, 31 against the oracle."""
+    B, Ta, F = 32, 160000, 600
+    proc = op.process_audio([synth.synth_waveform(200 + i, Ta).numpy() for i in range(B)])
+    pick = (0, 17, 31)
+    refs = {i: ow.wav2vec2_forward(w2v_sd, proc[i:i + 1], F)[0][0] for i in pick}
+    f32 = model.get_audio_embedding(proc.to(dev), F).cpu()
+    try:
+        model.set_mfma_dtype("bf16")
+        b16 = model.get_audio_embedding(proc.to(dev), F).cpu()
+    finally:
+        model.set_mfma_dtype("fp32")
+    assert f32.shape == b16.shape == (B, F, 768) and torch.isfinite(b16).all()
+    for i in pick:
+        ref = refs[i]
+        e32 = float((f32[i] - ref).abs().max())
+        e16 = float((b16[i] - ref).abs().max())
+        rms16 = float((b16[i] - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        print(f"audio B=32 clip {i}: fp32 max abs err {e32:.3e}, bf16 {e16:.3e} (rms rel {rms16:.3e}), |ref| max {float(ref.abs().max()):.2f}")
+        assert e32 <= AUDIO_TOL * max(1.0, float(ref.abs().max()))
+        assert e16 <= BF16_AUDIO_TOL and rms16 <= 5e-2
+
+
+def test_audio_encoder_batch40_two_chunks_vs_oracle(model, w2v_sd, dev):
+    """More clips than one engine pass holds (32): 40 x 1 s = a 32-clip and an 8-clip chunk; the clips on both sides of the
+    chunk boundary against the oracle, in both precisions; and the same result with 16-clip passes (16 + 16 + 8)."""
+    B, Ta, F = 40, 16000, 60
+    proc = op.process_audio([synth.synth_waveform(300 + i, Ta).numpy() for i in range(B)])
+    pick = (0, 31, 32, 39)
+    refs = {i: ow.wav2vec2_forward(w2v_sd, proc[i:i + 1], F)[0][0] for i in pick}
+    f32 = model.get_audio_embedding(proc.to(dev), F).cpu()
+    try:
+        model._eng.debug_option("audio_chunk", 16)
+        f32_c16 = model.get_audio_embedding(proc.to(dev), F).cpu()
+    finally:
+        model._eng.debug_option("audio_chunk", 32)
+    try:
+        model.set_mfma_dtype("bf16")
+        b16 = model.get_audio_embedding(proc.to(dev), F).cpu()
+    finally:
+        model.set_mfma_dtype("fp32")
+    for i in pick:
+        ref = refs[i]
+        e32, e16 = float((f32[i] - ref).abs().max()), float((b16[i] - ref).abs().max())
+        ec = float((f32_c16[i] - ref).abs().max())
+        print(f"audio B=40 clip {i}: fp32 {e32:.3e} (16-clip passes {ec:.3e}), bf16 {e16:.3e}")
+        assert max(e32, ec) <= AUDIO_TOL * max(1.0, float(ref.abs().max()))
+        assert e16 <= BF16_AUDIO_TOL
+
+
+# ---------------------------------------------------------------- (c): the guided loop at B = 32, T = 600 against the oracle
+def _oracle_cfg_step(sd_full, lat, emb, t, sch, gs=2.0):
+    """One guided step of diffusion.py:411-443 for ONE clip from given latents."""
+    _, sd_u, null = op.split_state_dict(sd_full)
+    T = lat.shape[1]
+    ctx = torch.cat([null.repeat(1, T, 1), emb])
+    pred = ou.unet1d_forward(sd_u, torch.cat([lat] * 2), torch.tensor([t, t]), ctx)
+    e_u, e_c = pred.chunk(2)
+    return sch.step(e_c + gs * (e_c - e_u), t, lat)
+
+
+def test_loop_batch32_teacher_forced_vs_oracle_both_precisions(model, sd_full, dev):
+    """configs[2]/[3]'s schedule — token-major GEMMs, guidance-shared prefix at half batch, duplicate-store epilogue, constant
+    unconditional cross-attention — met the oracle only transitively through B = 1 so far.  Two single steps of the
+    50-step schedule (k = 0: t = 980, k = 25: t = 480) at B = 32, T = 600, clips 0 / 17 / 31 against the oracle's step from the
+    same latents, in fp32 (bound of the B = 1 teacher-forced test) and bf16 (ditto)."""
+    B, T, N = 32, 600, 50
+    emb = synth.synth_latents(520, (B, T, 768))
+    lat = synth.synth_latents(521, (B, T, 32))
+    eng = model._get_engine(2 * B, T)
+    sch = model.noise_scheduler
+    sch.set_timesteps(N)
+    ts = sch.timesteps.numpy()
+    coef = sch.coef_table(ts, 0.0)
+    o = osch.OracleDDIM()
+    o.set_timesteps(N)
+    pick = (0, 17, 31)
+    for k in (0, 25):
+        refs = {i: _oracle_cfg_step(sd_full, lat[i:i + 1], emb[i:i + 1], int(ts[k]), o) for i in pick}
+        out = {}
+        for mode in ("fp32", "bf16"):
+            try:
+                model.set_mfma_dtype(mode)
+                eng = model._get_engine(2 * B, T)
+                _, latf, _ = eng.denoise_loop(latents=lat.to(dev), context=emb.to(dev), timesteps=ts[k:k + 1], coef=coef[k:k + 1],
+                                              prediction_type="epsilon", guidance_scale=2.0, guidance_rescale=0.0, latent_scale=1.0)
+                out[mode] = latf.cpu()
+            finally:
+                model.set_mfma_dtype("fp32")
+        for i in pick:
+            e32 = float((out["fp32"][i:i + 1] - refs[i]).abs().max())
+            e16 = float((out["bf16"][i:i + 1] - refs[i]).abs().max())
+            print(f"B=32 guided step k={k} (t={int(ts[k])}) clip {i}: fp32 {e32:.3e}, bf16 {e16:.3e} vs oracle")
+            assert e32 <= 2e-4
+            assert e16 <= BF16_STEP_MAX
+
+
+# ---------------------------------------------------------------- (d): the reference's batched caller at its real shape
+def test_batch_driver_64_clips_per_chunk_unet_batch_128(tmp_path, sd_full):
+    """script/test_inference.py with the reference's default --batch_size 64: one clip repeated 64 times -> audio batch 64 (two
+    32-clip encoder passes), UNet batch 128 (15,360 tokens at T = 120: the token-major fp32 path).  Samples 0 and 63 of the
+    chunk against the oracle fed the same start noise (drawn on the device after torch.manual_seed(seed), as the driver does)."""
+    drv = _load_script("test_inference")
+    adir, odir = tmp_path / "audio", tmp_path / "out"
+    pid = drv.PERSON_IDS_TEST[0]
+    os.makedirs(adir / pid)
+    wav = _write_wav(str(adir / pid / "sentence01.wav"), 32000, 11)
+    drv.main(["--weights_path", "synthetic", "--audio_dir", str(adir), "--output_dir", str(odir), "--num_steps", "2",
+              "--num_repeats", "64", "--batch_size", "64", "--seed", "7"])
+    from said_amd.util.blendshape import load_blendshape_coeffs
+    assert len(os.listdir(odir / pid)) == 64
+    wf, window = op.fit_audio_unet(torch.from_numpy(wav), 16000, 60, 1)
+    T = int(wf.shape[0] / 16000 * 60)
+    assert T == window == 120
+    torch.manual_seed(7)
+    lat = torch.randn(64, T, 32, device="cuda:0").cpu()
+    proc = op.process_audio(wf)
+    for k in (0, 63):
+        got = load_blendshape_coeffs(str(odir / pid / f"sentence01-{k}.csv"))
+        ref = op.inference(sd_full, proc, init_latents=lat[k:k + 1], num_inference_steps=2, guidance_scale=2.0).result[0]
+        err = float((got - ref[:window]).abs().max())
+        print(f"batch driver, sample {k} of a 64-clip chunk (UNet batch 128): max abs err {err:.3e}")
+        assert got.shape == (window, 32) and err <= 1e-3
+
+
+# ---------------------------------------------------------------- (e): BASELINE configs[0] through the CLI
+def test_inference_cli_3s_wav_50_steps_configs0(tmp_path, sd_full):
+    """BASELINE.json configs[0] as written (script/inference.py:17-214): one 3 s WAV, 50 DDIM steps, guidance 2 -> 32-column
+    CSV ("pretrained SAiD" is hub-only: the seeded synthetic weights stand in), against the oracle run on the same start noise."""
+    cli = _load_script("inference")
+    wav_path, out_csv = str(tmp_path / "a.wav"), str(tmp_path / "o.csv")
+    wav = _write_wav(wav_path, 48000, 5)
+    torch.manual_seed(321)
+    cli.main(["--weights_path", "synthetic", "--audio_path", wav_path, "--output_path", out_csv, "--num_steps", "50", "--device", "cuda:0"])
+    from said_amd.util.blendshape import DEFAULT_BLENDSHAPE_CLASSES, load_blendshape_coeffs
+    assert open(out_csv).read().splitlines()[0].split(",") == DEFAULT_BLENDSHAPE_CLASSES
+    got = load_blendshape_coeffs(out_csv)
+    wf, window = op.fit_audio_unet(torch.from_numpy(wav), 16000, 60, 1)
+    T = int(wf.shape[0] / 16000 * 60)
+    assert got.shape == (window, 32) == (180, 32)
+    torch.manual_seed(321)
+    lat = torch.randn(1, T, 32, device="cuda:0").cpu()
+    ref = op.inference(sd_full, op.process_audio(wf), init_latents=lat, num_inference_steps=50, guidance_scale=2.0)
+    err = float((got - ref.result[0, :window]).abs().max())
+    print(f"configs[0] (3 s WAV, 50 steps) CLI vs oracle: max abs err {err:.3e}")
+    assert err <= 1e-3
+
+
+# ---------------------------------------------------------------- (f): token-major path on edge shapes (was scripts/fuzz_token_major.py)
+@pytest.mark.parametrize("B,T", [(1, 5), (3, 31), (2, 32), (5, 33), (7, 63), (4, 64), (3, 65), (9, 94), (2, 127), (40, 129)])
+def test_token_major_path_forced_on_edge_shapes(model, unet_sd, dev, B, T):
+    """The token-major GEMM path forced on for EVERY launch (tile / padding-row boundaries, fewer tokens than one tile, a single
+    sample) against the oracle and against the channel-major kernels forced on for every launch, both precision modes."""
+    x = synth.synth_latents(1000 + T, (B, T, 32))
+    c = synth.synth_latents(2000 + T, (B, T, 768))
+    ts = (torch.arange(B) * 37 + T) % 1000
+    eng = model._get_engine(B, T)
+    out = {}
+    try:
+        for name, min_tokens in (("tm", 0), ("cm", 10 ** 12)):
+            eng.debug_option("unet_tgemm_min_tokens", min_tokens)
+            for mode in ("fp32", "bf16"):
+                model.set_mfma_dtype(mode)
+                out[(name, mode)] = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+    finally:
+        model.set_mfma_dtype("fp32")
+        eng.debug_option("unet_tgemm_min_tokens", -1)
+    ref = ou.unet1d_forward(unet_sd, x[:1], ts[:1], c[:1])
+    scale = float(ref.abs().max())
+    e_or = float((out[("tm", "fp32")][:1] - ref).abs().max()) / scale
+    assert e_or <= 1e-4, f"token-major fp32 vs oracle: {e_or:.2e} of range"
+    for mode, tol in (("fp32", 2e-5), ("bf16", 3e-2)):
+        a, b = out[("tm", mode)], out[("cm", mode)]
+        e = float((a - b).abs().max()) / float(b.abs().max())
+        print(f"B={B} T={T} {mode}: token-major vs channel-major {e:.2e} of range (fp32 vs oracle {e_or:.2e})")
+        assert bool(torch.isfinite(a).all()) and e <= tol
+
+
+# ---------------------------------------------------------------- workspace growth without a weight reload (said_reserve)
+def test_capacity_grows_without_weight_reload(dev):
+    """script/test_inference.py:160-186 walks clips of varying length with ONE model: a larger batch or a longer clip must only
+    re-allocate the workspace.  Grow B 1 -> 8 -> 32 and T 60 -> 600: said_set_weight is called 372 times in total, every
+    result equals a fresh context's bit for bit, and the small shape still gives its first answer afterwards."""
+    from said_amd.model.diffusion import SAID_UNet1D
+
+    def fresh():
+        m = SAID_UNet1D()
+        m.load_state_dict(synth.said_state_dict(), strict=True)
+        return m.to(dev).eval()
+
+    def run(m, B, T, N=2):
+        ctx = synth.synth_latents(700 + B, (B, T, 768)).to(dev)
+        lat = synth.synth_latents(800 + B, (B, T, 32)).to(dev)
+        wav = torch.zeros(B, T * 16000 // 60, device=dev)   # only its shape is used when the embedding is injected
+        return m.inference(wav, audio_embedding=ctx, num_inference_steps=N, guidance_scale=2.0, init_latents=lat).result
+
+    m = fresh()
+    proc = op.process_audio(synth.synth_waveform(3, 16000)).to(dev)
+    a1 = m.get_audio_embedding(proc, 60)
+    r1 = run(m, 1, 60)
+    eng = m._eng
+    assert eng.debug_get("n_set_weight") == 372 and (eng.max_batch_eff, eng.max_frames) == (2, 64)
+    r8 = run(m, 8, 60)
+    assert (eng.max_batch_eff, eng.max_frames) == (16, 64)
+    r32 = run(m, 32, 600)
+    assert m._eng is eng and eng.debug_get("n_set_weight") == 372 and (eng.max_batch_eff, eng.max_frames) == (64, 640)
+    assert torch.equal(run(m, 1, 60), r1) and torch.equal(run(m, 8, 60), r8)
+    assert torch.equal(m.get_audio_embedding(proc, 60), a1)
+    m2 = fresh()
+    assert torch.equal(run(m2, 32, 600), r32)
+    m2._eng.close()
+    m3 = fresh()
+    assert torch.equal(run(m3, 8, 60), r8)
+    m3._eng.close()
+    # load_state_dict / .to() invalidate the packed copy: the next call uploads again
+    m.load_state_dict(synth.said_state_dict(salt=1), strict=True)
+    r_new = run(m, 1, 60)
+    assert m._eng is not eng and not torch.equal(r_new, r1)
+    m._eng.close()
+
+
+# ---------------------------------------------------------------- eta > 0: noise generated inside the step's last kernel
+def test_device_eta_noise_matches_numpy_philox(model, dev):
+    eng = model._get_engine(2, 64)
+    seed = 0x1234_5678_9ABC_DEF1
+    got = eng.philox_normal(seed, 3, 5, (2, 37, 32)).cpu().numpy().reshape(5, -1)
+    ref = philox_ref.normals(seed, 3, 5, 2 * 37 * 32)
+    assert np.abs(got - ref).max() <= 2e-5
+    big = eng.philox_normal(99, 0, 4, (250000,)).cpu().numpy()
+    assert abs(big.mean()) < 5e-3 and abs(big.var() - 1.0) < 1e-2
+    assert abs(np.corrcoef(big[0], big[1])[0, 1]) < 5e-3 and abs(np.corrcoef(big[0, :-1], big[0, 1:])[0, 1]) < 5e-3
+    assert not np.array_equal(eng.philox_normal(100, 0, 1, (64,)).cpu().numpy(), big[:1, :64])
+
+
+@pytest.mark.parametrize("rescale", [0.0, 0.7])
+def test_loop_device_eta_noise_equals_injected_noise(model, sd_full, dev, rescale):
+    """use_step_noise = 2 (no noise tensor) must add exactly what said_philox_normal reports — fused out+scheduler kernel
+    (rescale 0) and the unfused scheduler kernel (guidance_rescale > 0) — and that loop meets the oracle fed the same noise."""
+    B, Ta, N = 2, 8000, 13
+    T = int(Ta / 16000 * 60)
+    proc = op.process_audio([synth.synth_waveform(40 + i, Ta).numpy() for i in range(B)])
+    lat = synth.synth_latents(41, (B, T, 32))
+    emb = model.get_audio_embedding(proc.to(dev), T)
+    eng = model._get_engine(2 * B, T)
+    sch = model.noise_scheduler
+    sch.set_timesteps(N)
+    ts = sch.timesteps.numpy()
+    coef = sch.coef_table(ts, 1.0)
+    seed = 2 ** 61 + 12345
+    kw = dict(latents=lat.to(dev), context=emb, timesteps=ts, coef=coef, prediction_type="epsilon", guidance_scale=2.5,
+              guidance_rescale=rescale, latent_scale=1.0)
+    r_dev, _, _ = eng.denoise_loop(noise_seed=seed, **kw)
+    sn = eng.philox_normal(seed, 0, N, (B, T, 32))
+    r_inj, _, _ = eng.denoise_loop(step_noise=sn, **kw)
+    assert torch.equal(r_dev, r_inj)
+    ref = op.inference(sd_full, proc, init_latents=lat, num_inference_steps=N, guidance_scale=2.5, guidance_rescale=rescale, eta=1.0,
+                       step_noise=sn.cpu(), audio_embedding=emb.cpu())
+    err = float((r_dev.cpu() - ref.result).abs().max())
+    print(f"device eta noise, rescale {rescale}: max abs err vs oracle {err:.3e}")
+    assert err <= 2e-3
+
+
+def test_inference_eta_seeded_by_torch_generator(model, dev):
+    """SAID.inference(eta > 0) without injected noise: one 64-bit key from torch's default generator, so torch.manual_seed fixes
+    the run; different seeds give different samples."""
+    proc = op.process_audio(synth.synth_waveform(3, 8000)).to(dev)
+
+    def run(seed):
+        torch.manual_seed(seed)
+        return model.inference(proc, num_inference_steps=9, guidance_scale=2.0, eta=1.0).result
+
+    a, b, c = run(5), run(5), run(6)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert torch.isfinite(a).all() and float(a.min()) >= 0 and float(a.max()) <= 1

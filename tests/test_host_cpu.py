@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/said_hip.h but not exported"
     assert declared == set(_engine.EXPORTS), (declared ^ set(_engine.EXPORTS))
-    assert lib.said_abi_version() == 3
+    assert lib.said_abi_version() == _engine.ABI_VERSION == 4
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -241,3 +241,17 @@ def test_vae_state_dict_layout_and_cpu_refusal():
         m.encode(torch.zeros(1, 120, 32))
     with pytest.raises(NotImplementedError):
         m.decode(torch.zeros(1, 64))
+
+
+def test_philox_reference_matches_random123_known_answers():
+    """The eta-noise generator (sched_math.h: Philox4x32-10) is checked on the GPU against tests/philox_ref.py; that numpy
+    restatement is pinned here against Random123's published known-answer vectors, and its normals are sane."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import philox_ref as pr
+    for ctr, key, want in pr.KAT:
+        got = pr.philox4x32_10(*[np.uint32(v) for v in ctr], *[np.uint32(v) for v in key])
+        assert tuple(int(v) for v in got) == want
+    z = pr.normals(12345, 0, 4, 200000)
+    assert abs(z.mean()) < 5e-3 and abs(z.var() - 1) < 1e-2 and abs(np.corrcoef(z[0], z[1])[0, 1]) < 1e-2
+    assert np.array_equal(pr.normals(7, 3, 1, 10), pr.normals(7, 0, 4, 10)[3:4])      # counter-based: step k alone == step k of a run

@@ -41,14 +41,7 @@ def _worker(rank, world, port, B_local, T, out_q):
 
 def test_shard_and_gather_world2():
     world, B_local, T = 2, 3, 7
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = shard.free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, B_local, T, q)) for r in range(world)]
-    for p in procs: p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
-    for p in procs: p.join(timeout=60)
-    assert all(p.exitcode == 0 for p in procs)
+    res = _run_world(world, B_local, T)
     want = torch.stack([_clip_tensor(c, T) for c in range(world * B_local)])
     for rank, gathered, elapsed, ranges, checksum, calls in res:
         assert torch.equal(gathered, want)                               # global clip order, on every rank
@@ -57,6 +50,61 @@ def test_shard_and_gather_world2():
         assert len(calls) == 5 and all(c == list(shard.clip_range(rank, world, B_local)) for c in calls)   # 2 warm-up + exactly 3 timed
     # elapsed is the MAX over ranks: both ranks report the slow rank's time (3 timed passes x 50 ms)
     assert res[0][2] == res[1][2] and res[0][2] >= 0.15
+
+
+def _run_world(world, B_local, T):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = shard.free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B_local, T, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    return res
+
+
+def test_shard_and_gather_world4_and_world8():
+    """BASELINE configs[3]'s world size (8) and the 4-GPU point of the scaling curve, on the gloo stand-in: contiguous global
+    clip order on every rank, identical max-over-ranks time everywhere, exactly warm-up + K passes per rank."""
+    for world, B_local, T in ((4, 2, 5), (8, 2, 3)):
+        res = _run_world(world, B_local, T)
+        want = torch.stack([_clip_tensor(c, T) for c in range(world * B_local)])
+        for rank, gathered, elapsed, ranges, checksum, calls in res:
+            assert torch.equal(gathered, want)
+            assert ranges == [[r * B_local, (r + 1) * B_local - 1] for r in range(world)]
+            assert checksum == float(want.double().sum())
+            assert len(calls) == 5 and all(c == list(shard.clip_range(rank, world, B_local)) for c in calls)
+        assert len({r[2] for r in res}) == 1 and res[0][2] >= 0.15     # the slow rank's time, reported by all
+
+
+def test_bench_rank_failure_ends_every_rank_no_hang():
+    """One rank raising inside its path must take the whole job down promptly (non-zero exit, no rank left waiting in the
+    all-gather): bench.py's self-launch over 4 gloo ranks with the stand-in path failing on rank 2."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--batch", "1", "--steps", "2", "--warmup", "1",
+                          "--seconds", "0.5", "--dry_run_gloo", "--dry_run_fail_rank", "2"], capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode != 0
+    assert "stand-in path failure on rank 2" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]     # no result line from a failed job
+    assert time.time() - t0 < 200
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` with fewer than N visible devices fails fast with a clear message instead of spawning ranks that die
+    one by one (here: no GPU at all, or a single one)."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        import pytest
+        pytest.skip("8 GPUs visible")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], capture_output=True,
+                         text=True, timeout=240, env=env)
+    assert out.returncode != 0 and "--gpus 8" in out.stderr and "visible" in out.stderr
 
 
 def test_clip_range_partitions_without_overlap():
