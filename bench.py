@@ -51,6 +51,9 @@ def parse():
                    help="editing mode (BASELINE configs[4]: --seconds 30 --num_steps 100 --edit): init_samples + in-betweening mask "
                         "(middle third regenerated, 4 channels pinned), mask blend with the re-noised init every step")
     p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--no_secondary", action="store_true",
+                   help="skip the secondary configurations (BASELINE configs[2], [3] per GPU, [4], and the headline with eta = 1) that the "
+                        "default single-GPU headline run measures after the headline and attaches as `secondary`")
     p.add_argument("--no_roofline", action="store_true")
     p.add_argument("--cpu_steps", type=int, default=40, help="UNet evaluations in the CPU-baseline sample")
     p.add_argument("--rccl_at_one", action="store_true",
@@ -146,7 +149,20 @@ def cpu_baseline(args, T, Ta):
             "clips_per_s": round(1.0 / total, 5)}
 
 
-def roofline(model, Be, T, step_ms, dtype, cfg_clips=0):
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel and engine sources: what a committed PMC traffic figure was measured on.
+    (The GPU box has no .git; the sources identify the build.)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "said_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1"):
     """Per-kernel HIP-event timing of one UNet evaluation (said_profile_unet: every launch of the schedule replayed
     back to back in a graph on the caller's stream and timed with hipEvents) + the whole-step figures."""
     eng = model._eng
@@ -168,6 +184,12 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0):
     unet_bytes = _engine.unet_algorithmic_bytes(Be, T, 4)   # activations are stored in fp32 in both modes
     unet_flops = _engine.unet_algorithmic_flops(Be, T)
     sum_us = sum(a["us"] for a in agg.values())
+    # work the schedule actually EXECUTES (sum over its launches).  Under guidance the prefix shared by the two halves runs
+    # once per clip and the unconditional half's cross-attention is a constant, so this is less than the reference-equivalent
+    # (algorithmic) work of a 2B-sample UNet evaluation: `mfma_frac` / `hbm_frac` below are EFFECTIVE rates (reference work /
+    # time), `*_executed` the hardware's.
+    exec_flops = sum(st["flops"] for st in stages)
+    exec_bytes = sum(st["bytes"] for st in stages)
     # which roof binds the dominant kernel: its arithmetic intensity against the ridge point peak FLOP/s : 8 TB/s (fp32 MFMA: 19.7
     # FLOP/B, bf16: 312).  Both fractions are always reported (hbm_frac / kernel_mfma_frac); `bound` / `achieved` / `peak` /
     # `frac` are the binding roof's.
@@ -188,7 +210,10 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0):
            "unet_step": {"ms_loop_per_step": round(step_ms, 4), "sum_kernel_us": round(sum_us, 2), "launches": len(stages),
                          "alg_bytes": round(unet_bytes), "alg_gflop": round(unet_flops / 1e9, 3),
                          "hbm_frac": round(unet_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "mfma_frac": round(unet_flops / (step_ms * 1e-3) / 1e12 / peak_tf, 5)},
+                         "mfma_frac": round(unet_flops / (step_ms * 1e-3) / 1e12 / peak_tf, 5),
+                         "fracs_are": "effective: reference-equivalent (algorithmic) work of the full UNet batch / loop time",
+                         "executed_gflop": round(exec_flops / 1e9, 3), "executed_bytes_per_launch_sum": round(exec_bytes),
+                         "mfma_frac_executed": round(exec_flops / (step_ms * 1e-3) / 1e12 / peak_tf, 5)},
            "by_kernel": {k: {"us": round(v["us"], 2), "launches": v["launches"],
                              "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1),
                              "TFLOPs": round(v["flops"] / (v["us"] * 1e-6) / 1e12, 2)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"])}}
@@ -197,10 +222,13 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0):
     tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tf):
         try:
-            tr = json.load(open(tf))
-            if tr.get("kernel") == dom:
+            tr = json.load(open(tf)).get("configs", {}).get(traffic_key)
+            if tr and tr.get("kernel") == dom:
                 out["traffic"] = tr.get("hbm_bytes_per_launch")
-                out["traffic_source"] = "profiles/traffic_latest.json (" + str(tr.get("source", "separate rocprofv3 --pmc pass")) + ")"
+                out["traffic_source"] = "profiles/traffic_latest.json[" + traffic_key + "] (" + str(tr.get("source", "separate rocprofv3 --pmc passes")) + ")"
+                # the figure is only as current as the sources it was measured on
+                out["traffic_stale"] = tr.get("source_hash") != source_hash()
+                out["traffic_git_sha"] = tr.get("git_sha")
         except Exception:
             pass
     return out
@@ -228,6 +256,92 @@ def audio_encode_block(model, proc, T, B, dtype):
             "tflops": round(2 * mac * B / (ms * 1e-3) / 1e12, 2),
             "mfma_dtype": dtype, "mfma_frac": round(2 * mac * B / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[dtype], 4),
             "alg_bytes": round(weights_b + B * act_b), "alg_GBps": round((weights_b + B * act_b) / (ms * 1e-3) / 1e9, 1)}
+
+
+
+def make_inputs(model, dev, clips, seconds, edit):
+    """Synthetic inputs of SURVEY.md 8d for the given GLOBAL clip ids, resident in HBM: processed waveform, start latents, and
+    (editing) init_samples = sigmoid(randn) * 0.5 with the in-betweening mask (outer thirds kept, channels 0-3 pinned)."""
+    from said_amd.util import synth
+    Ta = int(round(seconds * 16000))
+    T = int(Ta / 16000 * 60)
+    wav = [synth.synth_waveform(c, Ta).numpy() for c in clips]
+    proc = model.process_audio(wav).to(dev)
+    lat0 = torch.cat([synth.synth_latents(c, (1, T, 32)) for c in clips]).to(dev)
+    edit_kw = {}
+    if edit:
+        B = len(clips)
+        init_samples = (torch.sigmoid(torch.cat([synth.synth_latents(1000 + c, (1, T, 32)) for c in clips])) * 0.5).to(dev)
+        mask = torch.zeros(B, T, 32, device=dev)
+        mask[:, : T // 3] = 1.0
+        mask[:, 2 * T // 3:] = 1.0
+        mask[:, :, :4] = 1.0
+        edit_kw = dict(init_samples=init_samples, mask=mask, edit_noise=lat0)
+    return proc, lat0, edit_kw, T, Ta
+
+
+def loop_step_ms(model, proc, lat0, edit_kw, T, num_steps, gs, eta):
+    """Denoising loop alone (audio embedding precomputed), HIP events on the stream the engine launches on: ms per step."""
+    emb = model.get_audio_embedding(proc, T)
+    model.inference(proc, num_inference_steps=min(num_steps, 10), guidance_scale=gs, eta=eta, init_latents=lat0, audio_embedding=emb, **edit_kw)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = min(num_steps, 200)
+    ev0.record()
+    model.inference(proc, num_inference_steps=n, guidance_scale=gs, eta=eta, init_latents=lat0, audio_embedding=emb, **edit_kw)
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / n
+
+
+# Secondary configurations measured by the default single-GPU headline run (after the headline; N = 1 only).  Each is
+# `python bench.py <flags>` in its own right; here they run for `passes` timed passes after one short warm-up pass.
+SECONDARY = {
+    "cfg2_bf16": dict(batch=32, seconds=10.0, num_steps=50, dtype="bf16", eta=0.0, edit=False, passes=2,
+                      flags="--batch 32 --num_steps 50 --dtype bf16",
+                      workload="BASELINE.json configs[2]: 32 clips x 10 s (T=600), audio encode + 50 DDIM steps, guidance 2 (UNet batch 64), bf16 mode"),
+    "cfg3_per_gpu_f32": dict(batch=32, seconds=10.0, num_steps=1000, dtype="f32", eta=0.0, edit=False, passes=1,
+                             flags="--batch 32 --steps 1 --warmup 1",
+                             workload="BASELINE.json configs[3], ONE GPU's share: 32 clips x 10 s, audio encode + 1000 DDIM steps, guidance 2, fp32 (no all-gather at N = 1)"),
+    "cfg4_edit": dict(batch=1, seconds=30.0, num_steps=100, dtype="f32", eta=0.0, edit=True, passes=2,
+                      flags="--seconds 30 --num_steps 100 --edit",
+                      workload="BASELINE.json configs[4]: editing mode, 1 clip x 30 s (T=1800), init_samples + in-betweening mask, 100 DDIM steps, guidance 2, fp32"),
+    "cfg1_eta1": dict(batch=1, seconds=10.0, num_steps=1000, dtype="f32", eta=1.0, edit=False, passes=2,
+                      flags="--eta 1",
+                      workload="BASELINE.json configs[1] with eta = 1 (ancestral / DDPM-variance sampling, noise generated in the step's last kernel): 1 clip x 10 s, 1000 steps, guidance 2, fp32"),
+}
+
+
+def run_secondary(model, dev, gs):
+    """The secondary configurations on the SAME model object (its engine workspace grows; the weights are uploaded once)."""
+    out = {}
+    for name, c in SECONDARY.items():
+        B = c["batch"]
+        proc, lat0, edit_kw, T, Ta = make_inputs(model, dev, range(B), c["seconds"], c["edit"])
+        model.set_mfma_dtype("bf16" if c["dtype"] == "bf16" else "fp32")
+
+        def one(n_steps):
+            return model.inference(proc, num_inference_steps=n_steps, guidance_scale=gs, eta=c["eta"], init_latents=lat0, **edit_kw).result
+
+        one(min(c["num_steps"], 10))   # warm-up: workspace growth, graph capture (the graph does not depend on the step count)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(c["passes"]):
+            res = one(c["num_steps"])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / c["passes"]
+        assert torch.isfinite(res).all()
+        Be = 2 * B if gs > 1.0 else B
+        step_ms = loop_step_ms(model, proc, lat0, edit_kw, T, c["num_steps"], gs, c["eta"])
+        rf = roofline(model, Be, T, step_ms, c["dtype"], cfg_clips=B if gs > 1.0 else 0, traffic_key=name)
+        rf["audio_encode"] = audio_encode_block(model, proc, T, B, c["dtype"])
+        rf.pop("by_kernel", None)      # the headline's roofline carries the per-kernel table; keep the line readable
+        out[name] = {"value": round(B * T / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "passes": c["passes"],
+                     "clips_per_s": round(B / dt, 4), "realtime_factor": round(B * T / dt / 60.0, 2),
+                     "ms_per_denoise_step": round(step_ms, 4), "dtype": c["dtype"], "workload": c["workload"],
+                     "command": "python bench.py " + c["flags"], "graph_nodes_per_step": model._eng.graph_num_nodes(), "roofline": rf}
+    model.set_mfma_dtype("fp32")
+    return out
 
 
 def run(args):
@@ -281,18 +395,7 @@ def run(args):
     model.set_mfma_dtype("bf16" if args.dtype == "bf16" else "fp32")
     # synthetic inputs, resident in HBM before the timed region; keyed by GLOBAL clip id
     clips = shard.clip_range(rank, world, B)
-    wav = [synth.synth_waveform(c, Ta).numpy() for c in clips]
-    proc = model.process_audio(wav).to(dev)
-    lat0 = torch.cat([synth.synth_latents(c, (1, T, 32)) for c in clips]).to(dev)
-
-    edit_kw = {}
-    if args.edit:   # init = sigmoid(randn) * 0.5; mask = 1 on the outer thirds (kept) and on channels 0-3
-        init_samples = (torch.sigmoid(torch.cat([synth.synth_latents(1000 + c, (1, T, 32)) for c in clips])) * 0.5).to(dev)
-        mask = torch.zeros(B, T, 32, device=dev)
-        mask[:, : T // 3] = 1.0
-        mask[:, 2 * T // 3:] = 1.0
-        mask[:, :, :4] = 1.0
-        edit_kw = dict(init_samples=init_samples, mask=mask, edit_noise=lat0)
+    proc, lat0, edit_kw, T, Ta = make_inputs(model, dev, clips, args.seconds, args.edit)
 
     def path_fn(_clips):
         return model.inference(proc, num_inference_steps=args.num_steps, guidance_scale=args.guidance_scale, eta=args.eta,
@@ -323,18 +426,16 @@ def run(args):
                        "graph_nodes_per_step": model._eng.graph_num_nodes()},
         }
         if not args.no_roofline:
-            # denoising loop alone (audio embedding precomputed), HIP events on the stream the engine launches on
-            emb = model.get_audio_embedding(proc, T)
-            torch.cuda.synchronize()
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            model.inference(proc, num_inference_steps=args.num_steps, guidance_scale=args.guidance_scale, eta=args.eta,
-                            init_latents=lat0, audio_embedding=emb, **edit_kw)
-            ev1.record()
-            torch.cuda.synchronize()
-            step_ms = ev0.elapsed_time(ev1) / args.num_steps
-            line["roofline"] = roofline(model, Be, T, step_ms, args.dtype, cfg_clips=B if args.guidance_scale > 1.0 else 0)
+            step_ms = loop_step_ms(model, proc, lat0, edit_kw, T, args.num_steps, args.guidance_scale, args.eta)
+            headline = (B == 1 and args.seconds == 10.0 and args.num_steps == 1000 and args.dtype == "f32" and not args.edit and args.eta == 0.0)
+            key = ("cfg1" if headline else
+                   "cfg2_bf16" if (B == 32 and args.num_steps == 50 and args.dtype == "bf16") else
+                   "cfg3_per_gpu_f32" if (B == 32 and args.dtype == "f32" and not args.edit) else
+                   "cfg4_edit" if args.edit else "other")
+            line["roofline"] = roofline(model, Be, T, step_ms, args.dtype, cfg_clips=B if args.guidance_scale > 1.0 else 0, traffic_key=key)
             line["roofline"]["audio_encode"] = audio_encode_block(model, proc, T, B, args.dtype)
+            if headline and world == 1 and not args.no_secondary:
+                line["secondary"] = run_secondary(model, dev, args.guidance_scale)
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only: other ranks would sit in the final barrier
             line["cpu_baseline"] = cpu_baseline(args, T, Ta)
         print(json.dumps(line), flush=True)
