@@ -174,6 +174,7 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1"):
                 "xattn_kernel" if st["kind"] == 3 else
                 f"{'fgemm' if st['KS'] == 32 else 'tgemm'}_kernel<{st['NB']},{EPI_NAMES[st['epi']]}>" if st["kind"] == 4 else
                 "prep_kernel" if st["kind"] == 5 else
+                f"xgemm_kernel<{st['NB']},{'f32' if st['KS'] == 32 else 'bf16'},{EPI_NAMES[st['epi']]}>" if st["kind"] == 6 else
                 f"{'ugemm' if st['kind'] == 2 else 'cgemm'}_kernel<NB{st['NB']},KS{st['KS']},{EPI_NAMES[st['epi']]}>")
         a = agg.setdefault(name, dict(us=0.0, bytes=0.0, flops=0.0, launches=0))
         a["us"] += st["us"]; a["bytes"] += st["bytes"]; a["flops"] += st["flops"]; a["launches"] += 1

@@ -199,7 +199,9 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
  *                            (< 0: restore the measured defaults 5800 bf16 / 10000 fp32)
  *   "audio_chunk"            clips per audio-encoder pass (default 32)
  *   "steps_per_graph"        denoise steps captured per hipGraph (default 10)
- *   "bf16_tm_acts"           0: bf16 mode keeps fp32 channel-major activations between the UNet kernels at large batch (default 1)
+ *   "tm_acts"                0: large batches keep round 2's schedule (fp32 channel-major activations between the UNet kernels, a
+ *                            preparation kernel in front of every token-major GEMM); default 1: token-major activations
+ *   "xgemm_ntw"              column tiles per workgroup of the resident-source GEMMs (0: chosen per launch)
  * said_debug_get additionally knows "n_set_weight" (said_set_weight calls so far). */
 int said_debug_option(said_ctx* ctx, const char* name, long long value);
 long long said_debug_get(const said_ctx* ctx, const char* name);

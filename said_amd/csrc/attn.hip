@@ -44,6 +44,8 @@ struct AttnView {
     int v_bstride, o_bstride, pitch, T, heads, rows;
     float scale;
     int b0;
+    int o_mode;   // 0: o channel-major fp32 [b][h * D + d][pitch]; 1 / 2: TOKEN-major fp32 / bf16 [b * o_bstride + i][h * D + d] (o_bstride =
+                  // sample pitch in tokens) — the layout of the round-3 token-major activation path (tgemm.hip: xgemm_kernel)
 };
 // BF: both products run on v_mfma_f32_32x32x16_bf16 (said_set_precision; round 2: CDNA4's 16-deep opcode, half the MFMA count of
 // the 32x32x8 form).  The operand registers are the same ones: MFMA m of S^T contracts d = lh * D/2 + 8m + (0..7), i.e. the
@@ -56,9 +58,9 @@ struct AttnView {
 // keep in flight (every 32-query workgroup re-reads all K and V of its head: 62 B per kFLOP), not by MFMA or VALU work.
 template <int ND, int KS, bool BF, int QW = 1>
 __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, const float* pv, float* po, int v_bstride, int o_bstride, int ppitch,
-                                                       int pT, int pheads, int prows, float pscale, int pb0) {
+                                                       int pT, int pheads, int prows, float pscale, int pb0, int po_mode) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const AttnView a = {pqk, pv, po, v_bstride, o_bstride, ppitch, pT, pheads, prows, pscale, pb0};
+    const AttnView a = {pqk, pv, po, v_bstride, o_bstride, ppitch, pT, pheads, prows, pscale, pb0, po_mode};
     constexpr int D = 32 * ND, NQ = D / 8;   // NQ dwordx4 per lane and operand row
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     static_assert(QW == 1 || KS == 1, "query-tile waves do not split keys");
@@ -306,6 +308,32 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
     const float invL = 1.0f / L;
     constexpr int NV = ND * 16;
     static_assert(NV % KS == 0, "");
+    if (a.o_mode != 0) {
+        // token-major destination (KS == 1 only: every register of this wave is final).  Registers 4 q .. 4 q + 3 are channels
+        // 8 q + 4 lh + (0 .. 3) of the head: four consecutive elements of the query's row
+        if constexpr (KS == 1) {
+            const int i = i0 + lt;
+            if (i < T) {
+                const long long row = ((long long)b * a.o_bstride + i) * (H * D) + h * D;
+#pragma unroll
+                for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v0 = o[nd][4 * q] * invL, v1 = o[nd][4 * q + 1] * invL, v2 = o[nd][4 * q + 2] * invL, v3 = o[nd][4 * q + 3] * invL;
+                        const long long off = row + nd * 32 + 8 * q + 4 * lh;
+                        if (a.o_mode == 2) {
+                            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                            const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.o) + off) = ov;
+                        } else {
+                            const f32x4a ov = {v0, v1, v2, v3};
+                            *reinterpret_cast<f32x4a*>(a.o + off) = ov;
+                        }
+                    }
+            }
+        }
+        return;
+    }
     float* ob_out = a.o + (long long)b * a.o_bstride + (long long)(h * D) * pitch;
 #pragma unroll
     for (int jv = 0; jv < NV / KS; ++jv) {
@@ -327,7 +355,7 @@ static void launch_attn_one(const AttnArgs& a, int batch, hipStream_t s) {
     dim3 grid(((a.T + 31) / 32 + QW - 1) / QW, a.heads, batch);
     if (a.v_bstride > 0x7fffffffLL || a.o_bstride > 0x7fffffffLL) { fprintf(stderr, "said: attention batch stride exceeds 31 bits\n"); abort(); }
     hipLaunchKernelGGL((attn_kernel<ND, KS, BF, QW>), grid, dim3(64 * KS * QW), smem, s, a.qk, a.v, a.o, (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T,
-                       a.heads, a.rows, a.scale, a.b0);
+                       a.heads, a.rows, a.scale, a.b0, a.o_mode);
 }
 template <int ND, int KS, bool BF, int QW = 1>
 static void configure_attn_one() {

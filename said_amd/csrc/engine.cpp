@@ -51,12 +51,14 @@ struct ResW { float *g1, *b1, *g2, *b2; PW conv1, conv2, skip; int cin; bool has
               void *tf_conv1 = nullptr, *tf_conv2 = nullptr; /* the same matrices in fp32 (fgemm_kernel) */ };
 struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj, ffproj;
              void *t_qkv = nullptr, *t_ff1 = nullptr, *t_ffproj = nullptr; float* t_ff1_bias = nullptr; /* bf16 weights for tgemm.hip */
-             void *tf_qkv = nullptr, *tf_ff1 = nullptr, *tf_ffproj = nullptr; /* fp32 copies (fgemm_kernel) */ };
+             void *tf_qkv = nullptr, *tf_ff1 = nullptr, *tf_ffproj = nullptr; /* fp32 copies (fgemm_kernel) */
+             void *t_out1 = nullptr, *t_q2 = nullptr, *t_out2 = nullptr, *tf_out1 = nullptr, *tf_q2 = nullptr, *tf_out2 = nullptr; /* [192][192] (xgemm_kernel) */ };
 struct W2VLayer { PW qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln2g, *ln2b; };
 
 struct ActBuf {  // channel-major activation + its GroupNorm partial statistics
     float* p = nullptr;
     float* st = nullptr;
+    void* t = nullptr;   // token-major twin [sample][seg rows][192] in the precision mode's element type (round 3, large batches)
 };
 
 }  // namespace
@@ -137,7 +139,11 @@ struct said_ctx {
     float* gn_coef = nullptr;   // [2 slots][maxBe][192][2] GroupNorm coefficients for prep_kernel
     void *uPA = nullptr, *uPB = nullptr, *uPL = nullptr, *uPH = nullptr, *uPX = nullptr;   // conv operand [Be][T+2][384], raw cat input
                                                                                             // [Be][T][384], LN'd [Be][T][192], GEGLU out [Be][T][768], raw x2 [Be][T][192]
-    bool bf16_tm_acts = true; // bf16 mode at large batch: bf16 token-major activations BETWEEN the UNet kernels (round 3)
+    bool tm_acts = true;      // large batches: token-major activations BETWEEN the UNet kernels, operand transforms inside the GEMMs
+                              // (round 3: no preparation kernels); false = round 2's schedule (prep_kernel + channel-major fp32 interface)
+    int xgemm_dbg = 0;
+    int xgemm_ntw = 0;        // test / measurement: column tiles per workgroup of the resident-source GEMMs (0: launch_xgemm decides)
+    void *tX1 = nullptr, *tX2 = nullptr, *tO = nullptr, *tF = nullptr;   // token-major x1, x2, attention output [.][192], GEGLU product [.][768]
     bool unet_tgemm = true;   // SAID_NO_UNET_TGEMM=1 keeps the channel-major kernels in bf16 mode at every batch size
     bool unet_fgemm = true;   // SAID_NO_UNET_FGEMM=1: the same for the fp32 mode's token-major path (fgemm_kernel)
     // tokens per launch from which the token-major GEMM path is taken (measured crossovers, scripts/gpu_r2_w.sh: bf16 between 4800
@@ -578,6 +584,140 @@ void tg_cm_out(TGemmArgs& t, const UGeo& g, const ActBuf& out) {
     t.y_cm = out.p; t.cm_bs = g.hs; t.cm_pitch = g.Tp; t.stats = out.st; t.stats_bs = g.sts;
 }
 
+// ---- round 3, large batches: token-major activations between the kernels, operand transforms inside the GEMMs (xgemm_kernel) ----
+inline int tm_seg(const UGeo& g) { return rup(g.T, 64); }   // sample pitch in tokens: a 64-row tile never straddles samples
+inline bool use_tm(said_ctx* c, const UGeo& g) { return c->tm_acts && use_tg(c, g, g.Be) && g.b0 == 0; }
+// `rows` tokens further into a token-major tensor of row width `ld` (element size by precision mode)
+inline void* tm_at(const said_ctx* c, void* base, long long rows, int ld) { return static_cast<char*>(base) + rows * ld * (c->bf16_mode ? 2 : 4); }
+void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
+    if (c->log_on) {
+        const double eb = c->bf16_mode ? 2.0 : 4.0;
+        const double out_n = a.geglu ? a.N / 2 : a.N;
+        const double out_b = a.y_cm ? 4.0 * out_n : (a.qk ? 4.0 * out_n : eb * out_n * (a.y2_tm ? 2 : 1));
+        const double in_k = (a.ra[0] ? (a.ra[1] ? 384.0 : 192.0) : 0.0) + a.sk[0] + a.sk[1] + a.sk[2];   // source channels read per token (a conv reads its tile once)
+        const double res_b = a.res_tm ? eb * a.N : 0.0;
+        const double band_b = a.band_k ? 2.0 * 4.0 * a.N : 0.0;
+        c->stage_log.push_back({6, a.geglu ? EPI_GEGLU : (a.qk ? EPI_QKV : (a.band_k ? EPI_BAND : EPI_STORE)), a.N % 128 == 0 && (a.geglu || a.N % 96) ? 128 : 96, c->bf16_mode ? 4 : 32,
+                                eb * a.N * a.K + (double)batch * a.M * (eb * in_k + out_b + res_b + band_b), 2.0 * batch * (double)a.M * a.N * a.K});
+    }
+    TGemmArgs a2 = a;
+    a2.f32 = c->bf16_mode ? 0 : 1;
+    if (c->xgemm_ntw > 0 && a2.ra[0]) a2.ntw = c->xgemm_ntw;
+    a2.dbg = c->xgemm_dbg;
+    if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }
+    if (dbg_go(c) && !launch_xgemm(a2, batch, s)) {
+        char b[160]; snprintf(b, sizeof b, "token-major activation GEMM: shape M=%d N=%d K=%d (batch %d) is not served by any kernel", a.M, a.N, a.K, batch);
+        c->launch_err = b;
+    }
+}
+TGemmArgs mkx(const UGeo& g, const void* w, int N, int K) {
+    TGemmArgs t;
+    memset(&t, 0, sizeof t);
+    t.w = w; t.M = g.T; t.N = N; t.K = K; t.seg_rows = tm_seg(g);
+    t.gn_part_bs = g.sts; t.gn_nparts = g.np; t.stats_bs = g.sts; t.ldy = MC; t.ldr_tm = MC;
+    return t;
+}
+void run_resblock_tm(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, const ActBuf& in0, const ActBuf* in1, const ActBuf& out, hipStream_t s, bool shared) {
+    const int nb = shared ? g.Bc : g.Be;
+    {   // in_layers: GN -> SiLU -> conv3 + emb term   (openaimodel.py:205-225)
+        TGemmArgs t = mkx(g, tw(c, rw.t_conv1, rw.tf_conv1), MC, 3 * rw.cin);
+        t.ra[0] = in0.t; t.ra[1] = in1 ? in1->t : nullptr; t.rmode = 1; t.rtaps = 3;
+        t.gn_part[0] = in0.st; t.gn_part[1] = in1 ? in1->st : nullptr; t.gn_cpg = rw.cin / 32; t.gn_eps = 1e-5f; t.gn_gamma = rw.g1; t.gn_beta = rw.b1;
+        t.bias = rw.conv1.bias;
+        t.emb = c->EO + (long long)rb_index * MC * c->maxNp; t.emb_pitch = c->maxNp; t.step_ptr = g.step_ptr; t.emb_b_stride = g.emb_b_stride;
+        t.y_tm = c->M.t; t.stats = c->M.st;
+        do_xgemm(c, t, nb, s);
+    }
+    {   // out_layers: GN -> SiLU -> conv3 ; + skip(x)   (openaimodel.py:226-227)
+        TGemmArgs t = mkx(g, tw(c, rw.t_conv2, rw.tf_conv2), MC, 3 * MC + (rw.has_skip ? 2 * MC : 0));
+        t.ra[0] = c->M.t; t.rmode = 1; t.rtaps = 3;
+        t.gn_part[0] = c->M.st; t.gn_cpg = 6; t.gn_eps = 1e-5f; t.gn_gamma = rw.g2; t.gn_beta = rw.b2;
+        if (rw.has_skip) {   // 1x1 conv over the concatenated raw input: two streamed K segments behind the resident one
+            t.sa[0] = in0.t; t.sld[0] = MC; t.sk[0] = MC;
+            t.sa[1] = in1->t; t.sld[1] = MC; t.sk[1] = MC;
+            t.bias = rw.bias2;
+        } else {
+            t.bias = rw.conv2.bias;
+            t.res_tm = in0.t;
+        }
+        t.y_tm = out.t; t.stats = out.st;
+        if (shared) { t.y2_tm = out.t; t.y2_row_off = (long long)g.Bc * tm_seg(g); }
+        do_xgemm(c, t, nb, s);
+    }
+}
+// last: this block feeds the `out` convolution, which reads channel-major fp32 + GroupNorm partials (out_sched.hip)
+void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, const ActBuf& in, const ActBuf& out, hipStream_t s, bool shared, bool last) {
+    const int n1 = shared ? g.Bc : g.Be;
+    const int n2 = g.Bc > 0 ? g.Bc : g.Be;
+    const int x_off = (g.Bc > 0 && !shared) ? g.Bc : 0;
+    const int kv_off = g.Bc > 0 ? g.Bc : 0;
+    const long long seg = tm_seg(g);
+    const int vt_rows = rup(g.T, 32);
+    {   // x = norm(x); q, k, v = to_{q,k,v}(norm1(x)) into attn.hip's operand layout   (attention.py:227, 168, 93-97)
+        TGemmArgs t = mkx(g, tw(c, sw.t_qkv, sw.tf_qkv), 3 * MC, MC);
+        t.ra[0] = in.t; t.rmode = 3; t.rtaps = 1;
+        t.gn_part[0] = in.st; t.gn_cpg = 6; t.gn_eps = 1e-6f; t.gn_gamma = sw.gn_g; t.gn_beta = sw.gn_b;
+        t.ln_gamma = sw.l1g; t.ln_beta = sw.l1b;
+        t.qk = c->QK; t.vt = c->VT; t.v_bs = (long long)MC * g.Tp; t.qk_n = 2 * MC; t.head_dim = HD; t.rows = vt_rows; t.heads2 = 2 * HEADS; t.v_pitch = g.Tp;
+        do_xgemm(c, t, n1, s);
+    }
+    {   // softmax(q k^T * scale) v -> token-major   (attention.py:99-126)
+        AttnArgs a;
+        a.qk = c->QK; a.v = c->VT; a.o = static_cast<float*>(c->tO);
+        a.v_bstride = (long long)MC * g.Tp; a.o_bstride = seg; a.o_mode = c->bf16_mode ? 2 : 1;
+        a.pitch = g.Tp; a.T = g.T; a.heads = HEADS; a.rows = vt_rows; a.b0 = 0;
+        a.scale = 0.17677669529663687f;
+        do_attn(c, a, n1, HD, -4, s);
+    }
+    {   // x1 = to_out(attn) + GroupNorm(x_in)   (attention.py:127, 168); under guidance also x2 of the unconditional half = x1 + c2
+        TGemmArgs t = mkx(g, tw(c, sw.t_out1, sw.tf_out1), MC, MC);
+        t.sa[0] = c->tO; t.sld[0] = MC; t.sk[0] = MC;
+        t.bias = sw.out1.bias;
+        t.res_tm = in.t; t.res_gn = 1; t.res_part = in.st; t.res_gamma = sw.gn_g; t.res_beta = sw.gn_b; t.res_eps = 1e-6f; t.gn_cpg = 6;
+        t.y_tm = c->tX1;
+        if (g.Bc > 0) { t.y2_tm = c->tX2; t.y2_row_off = 0; t.y2_add = c->c2[blk]; }
+        do_xgemm(c, t, n1, s);
+    }
+    {   // attn2: q = to_q(norm2(x1)); banded softmax over the precomputed audio K/V   (attention.py:170-191)
+        TGemmArgs t = mkx(g, tw(c, sw.t_q2, sw.tf_q2), MC, MC);
+        t.ra[0] = tm_at(c, c->tX1, x_off * seg, MC); t.rmode = 2; t.rtaps = 1;
+        t.ln_gamma = sw.l2g; t.ln_beta = sw.l2b;
+        const long long kvbs = (long long)NST * 2 * MC * g.Sp;
+        t.band_k = c->KV + (long long)(blk * 2 * MC) * g.Sp + (long long)kv_off * kvbs;
+        t.band_v = c->KV + (long long)(blk * 2 * MC + MC) * g.Sp + (long long)kv_off * kvbs;
+        t.band_kv_bs = kvbs; t.band_kv_pitch = g.Sp; t.band_lo = c->band_lo; t.band_hi = c->band_hi; t.band_wmax = c->band_wmax;
+        t.band_scale = 0.17677669529663687f;
+        t.y_tm = tm_at(c, c->tO, x_off * seg, MC);
+        do_xgemm(c, t, n2, s);
+    }
+    {   // x2 = to_out(attn2) + x1   (conditional half only under guidance: its rows are [Bc, 2 Bc) of X2)
+        TGemmArgs t = mkx(g, tw(c, sw.t_out2, sw.tf_out2), MC, MC);
+        t.sa[0] = tm_at(c, c->tO, x_off * seg, MC); t.sld[0] = MC; t.sk[0] = MC;
+        t.bias = sw.out2.bias;
+        t.res_tm = tm_at(c, c->tX1, x_off * seg, MC);
+        t.y_tm = tm_at(c, c->tX2, kv_off * seg, MC);
+        do_xgemm(c, t, n2, s);
+    }
+    {   // GEGLU: proj(norm3(x2)) -> a * gelu(gate)   (attention.py:25-32)
+        TGemmArgs t = mkx(g, tw(c, sw.t_ff1, sw.tf_ff1), 2 * FFI, MC);
+        t.ra[0] = c->tX2; t.rmode = 2; t.rtaps = 1;
+        t.ln_gamma = sw.l3g; t.ln_beta = sw.l3b;
+        t.bias = sw.t_ff1_bias; t.geglu = 1;
+        t.yb = c->tF; t.y_bs = seg * FFI; t.ldy = FFI;
+        do_xgemm(c, t, g.Be, s);
+    }
+    {   // proj_out o ff.net.2 over [h ; x2] + x_in   (attention.py:193, 232-234)
+        TGemmArgs t = mkx(g, tw(c, sw.t_ffproj, sw.tf_ffproj), MC, FFI + MC);
+        t.sa[0] = c->tF; t.sld[0] = FFI; t.sk[0] = FFI;
+        t.sa[1] = c->tX2; t.sld[1] = MC; t.sk[1] = MC;
+        t.bias = sw.ffproj.bias;
+        t.res_tm = in.t;
+        if (last) { t.y_cm = out.p; t.cm_bs = g.hs; t.cm_pitch = g.Tp; t.stats = out.st; }
+        else { t.y_tm = out.t; t.stats = out.st; }
+        do_xgemm(c, t, g.Be, s);
+    }
+}
+
 // shared: guidance-shared prefix — only the first g.Bc samples are computed, and the result is ALSO written into the
 // conditional half's slots (values only; its statistics are consumed by kernels that run on the first half alone)
 void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, const ActBuf& in0, const ActBuf* in1, const ActBuf& out, hipStream_t s,
@@ -857,6 +997,21 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     const bool sh = g.Bc > 0;   // guidance-shared prefix: the two halves first differ at input_blocks.1.1's cross-attention
+    if (use_tm(c, g)) {
+        {   // conv_in's result (channel-major fp32 + GroupNorm partials) -> token-major, raw
+            PrepArgs p = mkprep(g, c->H0.p, 3, c->H0.t, (long long)tm_seg(g) * MC, MC, 0);
+            do_prep(c, p, g.Be, s);
+        }
+        run_resblock_tm(c, g, c->res[0], 0, c->H0, nullptr, c->P, s, sh);            // input_blocks.1.0
+        run_transformer_tm(c, g, c->st[0], 0, c->P, c->H1, s, sh, false);           // input_blocks.1.1
+        run_resblock_tm(c, g, c->res[1], 1, c->H1, nullptr, c->P, s, false);         // middle_block.0
+        run_transformer_tm(c, g, c->st[1], 1, c->P, c->Q, s, false, false);         // middle_block.1
+        run_resblock_tm(c, g, c->res[2], 2, c->Q, nullptr, c->P, s, false);          // middle_block.2
+        run_resblock_tm(c, g, c->res[3], 3, c->P, &c->H1, c->Q, s, false);           // output_blocks.0.0  cat([h, H1])
+        run_transformer_tm(c, g, c->st[2], 2, c->Q, c->P, s, false, false);         // output_blocks.0.1
+        run_resblock_tm(c, g, c->res[4], 4, c->P, &c->H0, c->Q, s, false);           // output_blocks.1.0  cat([h, H0])
+        run_transformer_tm(c, g, c->st[3], 3, c->Q, c->P, s, false, true);          // output_blocks.1.1 -> channel-major for `out`
+    } else {
     run_resblock(c, g, c->res[0], 0, c->H0, nullptr, c->P, s, sh);   // input_blocks.1.0
     run_transformer(c, g, c->st[0], 0, c->P, c->H1, s, sh);          // input_blocks.1.1   (hs: H0, H1)
     run_resblock(c, g, c->res[1], 1, c->H1, nullptr, c->P, s);       // middle_block.0
@@ -866,6 +1021,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
     run_transformer(c, g, c->st[2], 2, c->Q, c->P, s);               // output_blocks.0.1
     run_resblock(c, g, c->res[4], 4, c->P, &c->H0, c->Q, s);         // output_blocks.1.0  cat([h, H0])
     run_transformer(c, g, c->st[3], 3, c->Q, c->P, s);               // output_blocks.1.1
+    }
     if (g.out_sched) {   // out conv + guidance + DDIM update in one kernel (out_sched.hip)
         if (dbg_go(c)) launch_out_sched(*g.out_sched, s);
     } else {   // out: GN -> SiLU -> Conv1d(192 -> 32, k3)
@@ -992,6 +1148,14 @@ int alloc_workspace(said_ctx* ctx, int max_batch_eff, int max_frames) {
         rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPH), 2 * (Be * Tm * FFI + 4096));
         rc |= dalloc(ctx, reinterpret_cast<uint16_t**>(&ctx->uPX), 2 * (Be * Tm * MC + 4096));
         rc |= dalloc(ctx, &ctx->gn_coef, 2 * Be * 2 * MC);
+    }
+    {   // token-major activations of the round-3 large-batch path: sample pitch = frames rounded up to 64 tokens, fp32-sized
+        const size_t seg = (size_t)rup(max_frames, 64), tm = Be * seg * MC + 4096;
+        for (ActBuf* a : {&ctx->H0, &ctx->H1, &ctx->P, &ctx->Q, &ctx->M}) rc |= dalloc(ctx, reinterpret_cast<float**>(&a->t), tm);
+        rc |= dalloc(ctx, reinterpret_cast<float**>(&ctx->tX1), tm);
+        rc |= dalloc(ctx, reinterpret_cast<float**>(&ctx->tX2), tm);
+        rc |= dalloc(ctx, reinterpret_cast<float**>(&ctx->tO), tm);
+        rc |= dalloc(ctx, reinterpret_cast<float**>(&ctx->tF), Be * seg * FFI + 4096);
     }
     ctx->alloc_list = &ctx->allocs;
     ctx->band_T = ctx->band_S = -1;   // the band tables are part of the workspace
@@ -1226,6 +1390,15 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
         std::copy(k2->data.begin(), k2->data.end(), kv_w.begin() + (size_t)(i * 2) * MC * CD);
         std::copy(v2->data.begin(), v2->data.end(), kv_w.begin() + (size_t)(i * 2 + 1) * MC * CD);
         if (make_pw(ctx, &sw.out2, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", MC, MC, 0)) return -1;
+        {   // the three 192 x 192 projections around the banded cross-attention as token-major GEMM operands (xgemm_kernel)
+            const HostTensor* w1 = getw(ctx, b + ".attn1.to_out.0.weight", {MC, MC});
+            const HostTensor* wq2 = getw(ctx, b + ".attn2.to_q.weight", {MC, MC});
+            const HostTensor* w2 = getw(ctx, b + ".attn2.to_out.0.weight", {MC, MC});
+            if (!w1 || !wq2 || !w2) return -1;
+            if (upload_tm_pair(ctx, &sw.t_out1, &sw.tf_out1, w1->data.data(), MC, MC, 1) || upload_tm_pair(ctx, &sw.t_q2, &sw.tf_q2, wq2->data.data(), MC, MC, 1) ||
+                upload_tm_pair(ctx, &sw.t_out2, &sw.tf_out2, w2->data.data(), MC, MC, 1))
+                return -1;
+        }
         {   // attn2 output for the unconditional context (null_cond_emb repeated: every key / value identical, softmax
             // uniform => output = to_v(null)), pushed through to_out: c2 = W_out (W_v null) + b_out, in double
             const HostTensor* nc = getw(ctx, "null_cond_emb", {1, 1, CD});
@@ -1700,8 +1873,13 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
     } else if (k == "steps_per_graph") {
         if (value < 1) return fail(ctx, "steps_per_graph must be >= 1");
         ctx->spg_limit = (int)value;
-    } else if (k == "bf16_tm_acts") {
-        ctx->bf16_tm_acts = value != 0;
+    } else if (k == "xgemm_ntw") {
+        ctx->xgemm_ntw = (int)value;
+    } else if (k == "xgemm_dbg") {   // knock-out timing experiments (1: no epilogue, 2: no k loop, 4: no residual, 8: no source tile): WRONG results,
+        if (!dev_env("SAID_DEV")) return fail(ctx, "xgemm_dbg needs a -DSAID_DEV_KNOBS build with SAID_DEV=1");   // so refused by the shipped library
+        ctx->xgemm_dbg = (int)value;
+    } else if (k == "tm_acts") {
+        ctx->tm_acts = value != 0;
     } else {
         return fail(ctx, "said_debug_option: unknown option %s", name);
     }
@@ -1716,7 +1894,7 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "unet_tgemm_min_tokens") return ctx->bf16_mode ? ctx->unet_tgemm_min_tokens : ctx->unet_fgemm_min_tokens;
     if (k == "audio_chunk") return ctx->audio_chunk;
     if (k == "steps_per_graph") return ctx->spg_limit;
-    if (k == "bf16_tm_acts") return ctx->bf16_tm_acts ? 1 : 0;
+    if (k == "tm_acts") return ctx->tm_acts ? 1 : 0;
     return -1;
 }
 

@@ -147,6 +147,8 @@ struct AttnArgs {
     int rows;              // padded T of the token-major buffer
     float scale;
     int b0;                // batch offset
+    int o_mode = 0;        // 0: o channel-major fp32; 1 / 2: token-major fp32 / bf16 [b * o_bstride + i][h * D + d], o_bstride = sample
+                           // pitch in tokens (key-split-free shapes only: KS == 1 or -4)
 };
 
 // tile shape selection: NB 32-row tiles per workgroup, KS waves splitting K

@@ -56,6 +56,37 @@ struct TGemmArgs {
     int n_store;           // token-major outputs: columns n >= n_store are not written (0: all N) — a column count padded to the tile
     int f32;               // 1: A and W are fp32 (fgemm_kernel on v_mfma_f32_32x32x2_f32; fp32 mode, large batches); K % 32 == 0
     int dbg;               // timing experiments (SAID_TG_DBG): bit 0 = skip the epilogue, bit 1 = skip the K loop
+    // ==== token-major ACTIVATION interface (round 3; xgemm_kernel only; large batches, both precisions) ====================
+    // Between the UNet kernels the activations are token-major [sample][token][192] in the context's element type ET (bf16 in
+    // bf16 mode, fp32 else), sample pitch seg_rows tokens (a multiple of 64, so a 64-row tile never straddles samples), plus
+    // the producer's fp32 GroupNorm partials [sample][32-token tile][192][2].  Nothing prepares operands any more: the consuming
+    // GEMM applies GroupNorm + SiLU / LayerNorm itself.
+    // -- resident first K segment (ra[0] != null): the workgroup's source tile — 64 tokens (+ 2 halo tokens for taps == 3) x 192
+    // channels of ra[0], then of ra[1] (concatenated input) — is loaded ONCE, transformed once per element and parked in LDS;
+    // only the weights stream.  k order of W for this segment: [tap][source][channel] (Conv1d weight, tap-major).
+    int ntw;               // column tiles per workgroup (0: chosen by launch_xgemm)
+    const void* ra[2];     // sources (row pitch 192), or null
+    int rmode;             // 0: raw, 1: silu(GroupNorm(x)), 2: LayerNorm(x), 3: LayerNorm(GroupNorm(x))
+    int rtaps;             // 1, or 3: output token t reads tokens t - 1 + tap, zero outside [0, M)
+    const float* gn_part[2];       // GroupNorm partials of ra[0] / ra[1]
+    long long gn_part_bs;
+    int gn_cpg, gn_nparts; float gn_eps;
+    const float* gn_gamma; const float* gn_beta;     // [192 per source]
+    const float* ln_gamma; const float* ln_beta;     // [192]
+    // -- streamed raw K segments AFTER the resident one (or the whole K when ra[0] == null): up to three sources, source i holding
+    // sk[i] channels with row pitch sld[i]; row R (= sample * seg_rows + token) of source i starts at sa[i] + R * sld[i]
+    const void* sa[3]; int sld[3]; int sk[3];
+    // -- token-major activation epilogue (y_tm != null): y_tm[R][n] (ET, row pitch ldy) = acc + bias + emb + residual; `stats` then
+    // receives the GroupNorm partials of the STORED (rounded) values
+    void* y_tm;
+    const void* res_tm; int ldr_tm;      // residual rows R (ET); with res_gn: GroupNorm'ed first (attention.py:227: x = norm(x))
+    int res_gn; const float* res_part; const float* res_gamma; const float* res_beta; float res_eps;
+    void* y2_tm; long long y2_row_off; const float* y2_add;   // second copy at rows R + y2_row_off (+ per-channel constant)
+    // -- banded cross-attention epilogue (band_k != null; needs the transposed product: xgemm_kernel<.., TR = true>): the N = 192
+    // outputs are the queries of 6 heads; softmax over keys [lo[t], hi[t]) of the precomputed K / V, result -> y_tm
+    const float* band_k; const float* band_v;   // [b][192][kv_pitch] channel-major fp32
+    const int* band_lo; const int* band_hi;
+    long long band_kv_bs; int band_kv_pitch, band_wmax; float band_scale;
     // value channel of the first column of a GEGLU value tile starting at permuted column n (see tgemm_geglu_src_row)
     __host__ __device__ int geglu_c0(int n) const { return (n / 256) * 128 + ((n % 256) / 128) * 64 + ((n % 128) / 64) * 32; }
 };
@@ -64,6 +95,9 @@ bool tgemm_supports(const TGemmArgs& a);
 // false: shape not served by any instantiation (nothing launched) — the caller reports it through the C ABI
 bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s);   // N % 128 == 0: 128-wide tiles, else N % 64 == 0: 64-wide
 void configure_tgemm_kernel();
+// GEMMs on token-major activations with the operand transform inside (TGemmArgs fields of round 3)
+bool xgemm_supports(const TGemmArgs& a);
+bool launch_xgemm(const TGemmArgs& a, int batch, hipStream_t s);
 // UNet operand preparation (bf16 mode, large batches): channel-major fp32 x[b][C][pitch] -> transform -> token-major bf16.
 // mode 0: silu(GroupNorm(x)) into dst[b][1 + t][ldd] at column `coff` (rows 0 and T + 1 zero: Conv1d padding), mode 1:
 // LayerNorm(GroupNorm(x)) -> dst[b][t][ldd], mode 2: LayerNorm(x) -> dst and raw x -> dst2 (both [b][t][*]), mode 3: raw x.

@@ -49,8 +49,13 @@ constexpr int TBM = 128, TBN = 128, TBK = 64, TLP = 72;   // tile, LDS row pitch
 // ------------------------------------------------------------------------------------------------------------------
 // (J0, NJE): the epilogue covers column tiles J0 .. J0 + NJE - 1 of the wave's NJ accumulator tiles, n0w = first column of tile J0
 // (fgemm_kernel splits a tile's epilogue between the two K-half waves).
+// round 3 (token-major activations, xgemm_kernel): `res_tm` adds a token-major residual in phase 1 (optionally GroupNorm'ed with the
+// per-channel coefficients coefR[2 n], coefR[2 n + 1] in LDS), `y_tm` selects the token-major activation destination: values are
+// rounded to the element type in phase 1, the GroupNorm partials of the ROUNDED values are taken there too (lane == column: 16
+// rows in registers + the other lane half), and phase 2c stores 8 consecutive columns per lane.
 template <int NJ, int J0 = 0, int NJE = NJ>
-__device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ], int b_grid, int rt, int n0w, int l, float* sc) {
+__device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ], int b_grid, int rt, int n0w, int l, float* sc,
+                                            const float* coefR = nullptr) {
     constexpr int CW = 32 * NJE, CP = CW + 4;   // columns of this call, scratch row pitch (floats)
     const int lh = l >> 5, lc = l & 31;
     if (a.seg_rows > 0 && rt >= a.batch * a.seg_rows) return;   // row tile past the last sample (wave-uniform)
@@ -62,6 +67,8 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
         return;
     }
     const int nrows = min(32, a.M - mt);
+    const long long R0 = (long long)b * a.seg_rows + mt;   // global row of the tile's first token (token-major activation tensors)
+    const bool tm_out = a.y_tm != nullptr;
     // ---- phase 1: registers -> scratch, elementwise work where lane == column
     const bool geglu = a.geglu != 0;
     constexpr int NJO = NJE;   // (GEGLU writes NJ / 2 column tiles; the scratch keeps the full pitch)
@@ -74,16 +81,42 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
         if (geglu) gadd = a.bias ? a.bias[n + 32] : 0.f;
         if (a.emb) add += a.emb[(long long)n * a.emb_pitch + (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride];
         const int col = geglu ? (j >> 1) * 32 + lc : j * 32 + lc;
+        float rca = 1.f, rcb = 0.f;
+        if (a.res_tm && a.res_gn) { rca = coefR[2 * n]; rcb = coefR[2 * n + 1]; }
+        float vals[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
             float v = acc[J0 + j][r] + add;
+            if (a.res_tm && !(a.dbg & 4)) {   // token-major residual: lanes = 32 consecutive channels of one row
+                const long long ro = (R0 + min(row, nrows - 1)) * a.ldr_tm + n;
+                const float rv = a.f32 ? reinterpret_cast<const float*>(a.res_tm)[ro] : (float)reinterpret_cast<const __bf16*>(a.res_tm)[ro];
+                v += fmaf(rv, rca, rcb);
+            }
             if (geglu) {
                 if constexpr (NJE % 2 == 0 && J0 % 2 == 0) v *= gelu_f(acc[J0 + (j + 1) % NJE][r] + gadd);
             } else if (a.act == 1) {
                 v = gelu_f(v);
             }
+            if (tm_out && !a.f32) v = (float)(__bf16)v;   // what the consumers will read
+            vals[r] = v;
             sc[row * CP + col] = v;
+        }
+        if (tm_out && a.stats) {   // Welford partial of channel n over this tile's rows (of the stored values)
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += ((r & 3) + 8 * (r >> 2) + 4 * lh < nrows) ? vals[r] : 0.f;
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum / (float)nrows;
+            float m2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = ((r & 3) + 8 * (r >> 2) + 4 * lh < nrows) ? vals[r] - mean : 0.f; m2 = fmaf(d, d, m2); }
+            m2 += __shfl_xor(m2, 32);
+            if (lh == 0) {
+                float* so = a.stats + (long long)b * a.stats_bs + ((long long)(mt >> 5) * a.N + n) * 2;   // [tile][channel][2]
+                so[0] = mean;
+                so[1] = m2;
+            }
         }
     }
     (void)NJO;
@@ -130,6 +163,44 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
                     float* so = a.stats + (long long)b * a.stats_bs + ((long long)(mt >> 5) * a.N + n) * 2;   // [tile][channel][2]
                     so[0] = mean;
                     so[1] = m2;
+                }
+            }
+        }
+    } else if (tm_out) {
+        // ---- phase 2c: token-major ACTIVATION destination (element type ET): lane -> 8 consecutive columns of a row
+        const int lanes_per_row = cw / 8;                // 16 or 12
+        const int rows_pp = 64 / lanes_per_row;          // 4 or 5 (60 lanes active)
+        const int rr = l / lanes_per_row, cq = l - rr * lanes_per_row;
+        const bool lane_on = rr < rows_pp;
+        const int n = n_first + 8 * cq;
+        float add2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) add2[e] = (a.y2_tm && a.y2_add && lane_on) ? a.y2_add[n + e] : 0.f;
+        for (int r0 = 0; r0 < nrows; r0 += rows_pp) {
+            const int row = r0 + rr;
+            if (!lane_on || row >= nrows) continue;
+            const f32x4t v0 = *reinterpret_cast<const f32x4t*>(sc + row * CP + 8 * cq);
+            const f32x4t v1 = *reinterpret_cast<const f32x4t*>(sc + row * CP + 8 * cq + 4);
+            const long long o = (R0 + row) * a.ldy + n;
+            if (a.f32) {
+                float* y = reinterpret_cast<float*>(a.y_tm) + o;
+                *reinterpret_cast<f32x4t*>(y) = v0;
+                *reinterpret_cast<f32x4t*>(y + 4) = v1;
+                if (a.y2_tm) {
+                    float* y2 = reinterpret_cast<float*>(a.y2_tm) + o + a.y2_row_off * a.ldy;
+                    const f32x4t w0 = {v0[0] + add2[0], v0[1] + add2[1], v0[2] + add2[2], v0[3] + add2[3]};
+                    const f32x4t w1 = {v1[0] + add2[4], v1[1] + add2[5], v1[2] + add2[6], v1[3] + add2[7]};
+                    *reinterpret_cast<f32x4t*>(y2) = w0;
+                    *reinterpret_cast<f32x4t*>(y2 + 4) = w1;
+                }
+            } else {
+                typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+                const bf16x8s ov = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3], (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
+                *reinterpret_cast<bf16x8s*>(reinterpret_cast<__bf16*>(a.y_tm) + o) = ov;
+                if (a.y2_tm) {
+                    const bf16x8s o2 = {(__bf16)(v0[0] + add2[0]), (__bf16)(v0[1] + add2[1]), (__bf16)(v0[2] + add2[2]), (__bf16)(v0[3] + add2[3]),
+                                        (__bf16)(v1[0] + add2[4]), (__bf16)(v1[1] + add2[5]), (__bf16)(v1[2] + add2[6]), (__bf16)(v1[3] + add2[7])};
+                    *reinterpret_cast<bf16x8s*>(reinterpret_cast<__bf16*>(a.y2_tm) + o + a.y2_row_off * a.ldy) = o2;
                 }
             }
         }
@@ -621,6 +692,524 @@ __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// xgemm_kernel (round 3) — GEMMs on TOKEN-MAJOR ACTIVATIONS with the operand transform inside.
+//
+// Round 2's large-batch path kept fp32 channel-major activations between kernels and ran a preparation kernel in front of every
+// GEMM (20 launches, 17 % of the bf16 step, and the GEMM epilogues wrote 59 MB of fp32 per 192-wide convolution against 14.8 MB
+// of bf16 operand).  Here the activations between the UNet kernels ARE token-major [sample][token][192] in the element type
+// (bf16 / fp32), and the consuming GEMM does the normalisation itself:
+//   * RS (resident source): the workgroup's source tile — its 64 tokens (+ the two Conv1d halo tokens) x 192 channels — is
+//     loaded once, transformed once per element (silu(GroupNorm) / LayerNorm / LayerNorm(GroupNorm); the GroupNorm coefficients
+//     are finalised from the producer's partials in the prologue, the LayerNorm statistics taken over the row's four threads)
+//     and parked in LDS [66][192 + pad]; the three taps of a convolution are three row offsets into it, a concatenated input
+//     (384 channels) is two passes over the same 26 / 52 KB buffer.  Only the weights stream through the k loop.
+//   * SS (streamed sources): raw operands (attention output, GEGLU product, x2, the 1x1 skip over the concatenated input) go
+//     through the k-tile pipeline of fgemm_kernel; up to three sources are chained along K.
+//   * TR: the product is formed transposed (D[channel][token]: operand roles swapped) for the banded cross-attention epilogue,
+//     where a lane owns one query token and a head's 32 channels sit in 16 registers of the two lane halves.
+// Workgroup, wave roles (2 row halves x 2 K halves), k-tile geometry and the K-half exchange are fgemm_kernel's.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int XRR = 66;                       // resident rows: 64 tokens + 2 halo
+template <bool BF> __host__ __device__ constexpr int x_rp_bytes() { return 192 * (BF ? 2 : 4) + 16; }   // resident row pitch: 400 / 784 bytes (conflict-free 16-byte fragment reads)
+constexpr int X_COEF_BYTES = 2 * 192 * 4;     // GroupNorm (a, b) of ONE 192-channel source at a time; after the prologue the region carries the
+                                              // epilogue's statistics exchange (a kernel never needs both at once)
+template <int NJ, bool BF>
+__host__ __device__ constexpr int xgemm_lds_bytes(bool resident) {
+    return fgemm_lds_bytes<NJ>() + X_COEF_BYTES + (resident ? XRR * x_rp_bytes<BF>() : 0);
+}
+static __device__ __forceinline__ f32x4t xbload4(rsrc_t r, int voff) {
+    return __builtin_bit_cast(f32x4t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+
+// banded cross-attention on the transposed q tile of one head: acc[r] = q[d = (r & 3) + 8 (r >> 2) + 4 lh][token lt]
+template <bool BF>
+__device__ __forceinline__ void band_head(const TGemmArgs& a, const f32x16& q, int b, int t, bool tv, int lo, int hi, int head, int l) {
+    const int lh = l >> 5;
+    const int kvp = a.band_kv_pitch;
+    const long long kvo = (long long)b * a.band_kv_bs + (long long)(head * 32) * kvp;
+    const rsrc_t rk = make_rsrc(a.band_k + kvo, 32u * (unsigned)kvp * 4u);
+    const rsrc_t rv = make_rsrc(a.band_v + kvo, 32u * (unsigned)kvp * 4u);
+    const int nh = a.band_wmax > 4 ? 2 : 1;
+    float sc[8];
+#pragma unroll
+    for (int wi = 0; wi < 8; ++wi) sc[wi] = 0.f;
+    for (int hf = 0; hf < nh; ++hf) {
+        f32x4t kq[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kq[r] = xbload4(rk, (((r & 3) + 8 * (r >> 2) + 4 * lh) * kvp + lo + 4 * hf) * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (hf == 0) sc[e] = fmaf(q[r], kq[r][e], sc[e]); else sc[4 + e] = fmaf(q[r], kq[r][e], sc[4 + e]);
+            }
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int wi = 0; wi < 8; ++wi) {
+        sc[wi] += __shfl_xor(sc[wi], 32);
+        const bool vis = (wi < a.band_wmax) && (lo + wi < hi);
+        sc[wi] = vis ? sc[wi] * a.band_scale : -3.0e38f;   // scale after QK^T (ldm/attention.py:101), masked keys at -max
+        mx = fmaxf(mx, sc[wi]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int wi = 0; wi < 8; ++wi) {
+        const bool vis = (wi < a.band_wmax) && (lo + wi < hi);
+        sc[wi] = vis ? __expf(sc[wi] - mx) : 0.f;
+        den += sc[wi];
+    }
+    const float inv = 1.0f / den;
+    float o[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    for (int hf = 0; hf < nh; ++hf) {
+        f32x4t vq[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vq[r] = xbload4(rv, (((r & 3) + 8 * (r >> 2) + 4 * lh) * kvp + lo + 4 * hf) * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int wi = 4 * hf + e;
+                const bool vis = (wi < a.band_wmax) && (lo + wi < hi);   // invisible slots may hold another row's data
+                o[r] = fmaf((hf == 0 ? sc[e] : sc[4 + e]) * inv, vis ? vq[r][e] : 0.f, o[r]);
+            }
+    }
+    if (!tv) return;
+    // registers 4 q .. 4 q + 3 are channels 8 q + 4 lh + (0 .. 3) of the head: four consecutive elements of the token's row
+    const long long row = (long long)b * a.seg_rows + t;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        const long long off = row * a.ldy + head * 32 + 8 * qd + 4 * lh;
+        if constexpr (BF) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            const bf16x4 ov = {(__bf16)o[4 * qd], (__bf16)o[4 * qd + 1], (__bf16)o[4 * qd + 2], (__bf16)o[4 * qd + 3]};
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y_tm) + off) = ov;
+        } else {
+            const f32x4t ov = {o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};
+            *reinterpret_cast<f32x4t*>(reinterpret_cast<float*>(a.y_tm) + off) = ov;
+        }
+    }
+}
+
+template <int NJ, bool BF, bool RS, bool SS, bool TR, int OCC>
+__global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
+    static_assert(RS || SS, "a GEMM needs an operand");
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [stream A 64 rows | W BN rows] x 144 bytes | coefficients | resident tile
+    float* const ldsf = reinterpret_cast<float*>(lds);
+    typedef typename std::conditional<BF, unsigned short, float>::type elt_t;
+    constexpr int EPC = BF ? 8 : 4;              // elements per 16-byte chunk
+    constexpr int FBK = 8 * EPC, FLP = 9 * EPC;  // k per tile (128 bytes), LDS row pitch of the streamed tiles (144 bytes), in elements
+    constexpr int CT = 192 / FBK;                // k-tiles per source and tap of the resident segment (3 bf16, 6 fp32)
+    constexpr int RP = x_rp_bytes<BF>() / (int)sizeof(elt_t);   // resident row pitch in elements
+    elt_t* const ldse = reinterpret_cast<elt_t*>(lds);
+    float* const coefS = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + fgemm_lds_bytes<NJ>());
+    elt_t* const ares = reinterpret_cast<elt_t*>(reinterpret_cast<char*>(lds) + fgemm_lds_bytes<NJ>() + X_COEF_BYTES);
+    constexpr int BM = 64, BN = 32 * NJ, NTH = 256;
+    constexpr int ACH = BM * 8 / NTH, WCH = BN * 8 / NTH;   // 16-byte chunks per thread and tile: 2, NJ
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int wr = w & 1, kh = w >> 1;
+    const int rows_tot = a.batch * a.seg_rows;
+    const int NT = a.N / (BN * (a.ntw > 0 ? a.ntw : 1)), MT = rows_tot / BM;   // seg_rows % 64 == 0 (host-checked): a tile never straddles samples
+    const unsigned L = blockIdx.x, xcd = L & 7u, slot = L >> 3;   // XCD-aware order, as in tgemm_kernel
+    const int nt = (int)(slot % (unsigned)NT);
+    const int mg = (int)(slot / (unsigned)NT) * 8 + (int)xcd;
+    if (mg >= MT) return;
+    const int m0 = mg * BM, n0 = nt * BN * (a.ntw > 0 ? a.ntw : 1);
+    const int b = m0 / a.seg_rows, t0 = m0 - b * a.seg_rows;
+    if (t0 >= a.M) return;                                    // a tile of padding tokens only
+    const elt_t* W = reinterpret_cast<const elt_t*>(a.w);
+    const int nsrc = RS ? (a.ra[1] ? 2 : 1) : 0;
+    const int ntap = RS ? a.rtaps : 0;
+    const int nkr = ntap * nsrc * CT;                          // resident k-tiles
+    const int nk = a.K / FBK;
+    const int nst = nk - nkr;                                  // streamed k-tiles
+    const int sk0 = a.sk[0] / FBK, sk1 = a.sk[1] / FBK;
+
+    // ---- GroupNorm coefficients from a producer's partials -> coefS (4 waves x 48 channels; per-wave scratch inside the tile area,
+    // which is idle at both call sites: kernel entry, and the source switch of a concatenated input)
+    auto gn_coefs = [&](const float* part, float eps, const float* gamma, const float* beta) {
+        const GnP gp = {a.gn_cpg, a.gn_nparts, a.M, eps, gamma, beta, 192};
+        const rsrc_t rp = make_rsrc(part + (long long)b * a.gn_part_bs, 192u * (unsigned)a.gn_nparts * 8u);
+        GnLoads gl;
+        gn_issue(gp, rp, w * 48, 48, l, gl);
+        gn_finish(gp, rp, w * 48, 48, l, gl, ldsf + w * GN_SCRATCH, coefS);
+        __syncthreads();
+    };
+    if (!RS && a.res_gn) gn_coefs(a.res_part, a.res_eps, a.res_gamma, a.res_beta);
+    // ---- resident tile of source `ph`: 8 threads per row (24 channels each), 32 rows per pass; a convolution's two halo rows
+    // (resident rows 64, 65) by the first 16 threads in a third pass.  Few live registers on purpose: this prologue must not
+    // cost the k loop its occupancy.
+    auto load_resident = [&](int ph) {
+        if (a.rmode == 1 || a.rmode == 3) gn_coefs(a.gn_part[ph], a.gn_eps, a.gn_gamma + ph * 192, a.gn_beta + ph * 192);
+        const elt_t* src = reinterpret_cast<const elt_t*>(a.ra[ph]);
+        const int halo = a.rtaps == 3 ? 1 : 0;
+        const int q8 = tid & 7;
+        const float* cf = coefS + 48 * q8;
+        for (int pass = 0; pass < 2 + halo; ++pass) {
+            const int r = pass * 32 + (tid >> 3);
+            if (pass == 2 && tid >= 16) break;
+            const int tt = t0 + r - halo;
+            const bool valid = tt >= 0 && tt < a.M;
+            const elt_t* p = src + ((long long)b * a.seg_rows + min(max(tt, 0), a.M - 1)) * 192 + 24 * q8;
+            float x[24];
+            if constexpr (BF) {
+                u32x4 raw[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) raw[i] = *reinterpret_cast<const u32x4*>(p + 8 * i);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[8 * i + 2 * e] = __builtin_bit_cast(float, raw[i][e] << 16);
+                        x[8 * i + 2 * e + 1] = __builtin_bit_cast(float, raw[i][e] & 0xffff0000u);
+                    }
+            } else {
+                f32x4t raw[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) raw[i] = *reinterpret_cast<const f32x4t*>(p + 4 * i);
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[4 * i + e] = raw[i][e];
+            }
+            if (a.rmode == 1 || a.rmode == 3) {
+#pragma unroll
+                for (int i = 0; i < 24; ++i) x[i] = fmaf(x[i], cf[2 * i], cf[2 * i + 1]);
+            }
+            if (a.rmode == 1) {
+#pragma unroll
+                for (int i = 0; i < 24; ++i) x[i] = silu_f(x[i]);
+            }
+            if (a.rmode >= 2) {   // LayerNorm over the row's 192 channels: sums over this thread's 24, then over the row's eight threads
+                const float ref = __shfl(x[0], l & ~7);
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 24; ++i) { const float d = x[i] - ref; s1 += d; s2 = fmaf(d, d, s2); }
+                s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
+                s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+                s1 += __shfl_xor(s1, 4); s2 += __shfl_xor(s2, 4);
+                const float md = s1 * (1.0f / 192.0f);
+                const float var = fmaxf(s2 * (1.0f / 192.0f) - md * md, 0.f);
+                const float mu = ref + md, rs = 1.0f / sqrtf(var + 1e-5f);
+                const float* lg = a.ln_gamma + 24 * q8;
+                const float* lb = a.ln_beta + 24 * q8;
+#pragma unroll
+                for (int i = 0; i < 24; ++i) x[i] = fmaf((x[i] - mu) * rs, lg[i], lb[i]);
+            }
+            if (!valid) {
+#pragma unroll
+                for (int i = 0; i < 24; ++i) x[i] = 0.f;
+            }
+            elt_t* d = ares + r * RP + 24 * q8;
+            if constexpr (BF) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const bf16x8 o = {(__bf16)x[8 * i], (__bf16)x[8 * i + 1], (__bf16)x[8 * i + 2], (__bf16)x[8 * i + 3],
+                                      (__bf16)x[8 * i + 4], (__bf16)x[8 * i + 5], (__bf16)x[8 * i + 6], (__bf16)x[8 * i + 7]};
+                    *reinterpret_cast<bf16x8*>(d + 8 * i) = o;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const f32x4t o = {x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]};
+                    *reinterpret_cast<f32x4t*>(d + 4 * i) = o;
+                }
+            }
+        }
+    };
+
+    // ---- k-tile pipeline: weights always, streamed A tiles when SS
+    f32x4t ra_[ACH], rw[WCH];
+    int woff[WCH], lwoff[WCH], loff[ACH], arow[ACH], akp[ACH];
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+        const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
+        arow[i] = min(m0 + row, rows_tot - 1);
+        akp[i] = kp * EPC;
+        loff[i] = row * FLP + kp * EPC;
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
+        woff[i] = (n0 + row) * a.K + kp * EPC;
+        lwoff[i] = BM * FLP + row * FLP + kp * EPC;
+    }
+    // W k-offset of tile kt: the resident segment runs source-major ([source][tap][channel tile]) over a tap-major weight
+    auto wk_of = [&](int kt) -> int {
+        if (RS && kt < nkr) {
+            const int per = ntap * CT;
+            const int ph = kt / per, rem = kt - ph * per;
+            const int tap = rem / CT, ct = rem - tap * CT;
+            return tap * (nsrc * 192) + ph * 192 + ct * FBK;
+        }
+        return kt * FBK;
+    };
+    auto lds_store = [&](const f32x4t* xa, const f32x4t* xw) {
+        if constexpr (SS) {
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4t*>(ldse + loff[i]) = xa[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) *reinterpret_cast<f32x4t*>(ldse + lwoff[i]) = xw[i];
+    };
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int frow = l & 31, fk = EPC * (l >> 5) + 4 * EPC * kh;
+    const elt_t* const pa_s = ldse + (wr * 32 + frow) * FLP + fk;
+    const elt_t* const pa_r = ares + (wr * 32 + frow) * RP + fk;
+    const elt_t* const pw = ldse + BM * FLP + frow * FLP + fk;
+    auto compute = [&](int kt) {
+        const elt_t* pa = pa_s;
+        if (RS && kt < nkr) {
+            const int rem = kt % (ntap * CT);
+            const int tap = rem / CT, ct = rem - tap * CT;
+            pa = pa_r + tap * RP + ct * FBK;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if constexpr (BF) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(pa + ks * 16);
+                bf16x8 fb[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(pw + j * 32 * FLP + ks * 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa, acc[j], 0, 0, 0);
+                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[j], 0, 0, 0);
+                }
+            } else {
+                const f32x4t fa = *reinterpret_cast<const f32x4t*>(pa + ks * 8);
+                f32x4t fb[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const f32x4t*>(pw + j * 32 * FLP + ks * 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][i], fa[i], acc[j], 0, 0, 0);
+                        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j][i], acc[j], 0, 0, 0);
+                    }
+            }
+        }
+    };
+    // The workgroup walks over `ntw` consecutive column tiles with its resident source tile (the prologue — GroupNorm finalisation,
+    // tile load, transform, LayerNorm — is paid once per ntw x 32 NJ output columns instead of once per column tile: with one
+    // column tile per workgroup the 12 workgroups of a GEGLU row tile each repeated it, 163 us per launch against 71 for round
+    // 2's GEMM + 19 for its preparation kernel).  (column tile, k-tile) pairs form ONE sequence of steps through the k-tile
+    // pipeline: request the next step's tile -> multiply the tile in LDS -> barrier -> [last k-tile of a column tile: add the K
+    // halves, epilogue] -> park the next tile -> barrier.  The next column tile's first weights are in flight during the epilogue.
+    const int ntw = RS ? (a.ntw > 0 ? a.ntw : 1) : 1;   // (streamed-only GEMMs have no prologue to amortise)
+    const int nsteps = ntw * nk;
+    const int e0 = (RS && nsrc == 2) ? ntap * CT : -1;   // a concatenated input (ntw == 1): the second source takes the resident buffer over
+    constexpr int NJ0 = (NJ == 4 && !TR) ? 2 : NJ, NJ1 = NJ - NJ0;
+    float* const xr = ldsf + wr * (NJ1 > 0 ? NJ * 16 * 64 : 32 * (32 * NJ + 4));
+    auto gload_step = [&](int step) {
+        const int jn = step / nk, kt = step - jn * nk;
+        const int wk = wk_of(kt) + jn * BN * a.K;
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) rw[i] = *reinterpret_cast<const f32x4t*>(W + (woff[i] + wk));
+        if constexpr (SS) {
+            const int st = min(max(kt - nkr, 0), nst - 1);        // (resident steps re-request the first streamed tile: an L1 hit)
+            const elt_t* base; int ld, off;
+            if (st < sk0) { base = reinterpret_cast<const elt_t*>(a.sa[0]); ld = a.sld[0]; off = st * FBK; }
+            else if (st < sk0 + sk1) { base = reinterpret_cast<const elt_t*>(a.sa[1]); ld = a.sld[1]; off = (st - sk0) * FBK; }
+            else { base = reinterpret_cast<const elt_t*>(a.sa[2]); ld = a.sld[2]; off = (st - sk0 - sk1) * FBK; }
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) ra_[i] = *reinterpret_cast<const f32x4t*>(base + ((long long)arow[i] * ld + off + akp[i]));
+        }
+    };
+    gload_step(0);
+    if constexpr (RS) { if (!(a.dbg & 8)) load_resident(0); }
+    lds_store(ra_, rw);
+    __syncthreads();
+    const int nk_loop = (a.dbg & 2) ? 1 : nk;   // (timing experiment: no k loop)
+    for (int jn = 0; jn < ntw; ++jn) {
+        const int s0 = jn * nk;
+        // all k-tiles but the last: request the next tile -> multiply -> barrier -> park the next tile -> barrier
+        for (int kt = 0; kt < nk_loop - 1; ++kt) {
+            gload_step(s0 + kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(kt);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (kt == e0 - 1) load_resident(1);   // all waves are done with the first source's tile (concatenated input)
+            lds_store(ra_, rw);
+            __syncthreads();
+        }
+        // last k-tile: the NEXT column tile's first weights are requested and stay in registers through the epilogue
+        if constexpr (RS) gload_step(min(s0 + nk, nsteps - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        compute(nk - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // ---- add the two K halves (fgemm_kernel's exchange), then the epilogue of column tile jn
+        const int n0j = n0 + jn * BN;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if ((kh == 1) == (j < NJ0)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xr[(j * 16 + r) * 64 + l] = acc[j][r];
+            }
+        }
+        __syncthreads();
+        if (NJ1 > 0 || kh == 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if ((kh == 0) == (j < NJ0)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] += xr[(j * 16 + r) * 64 + l];
+                }
+            }
+        }
+        if constexpr (TR) {
+            if (kh == 0) {   // banded cross-attention: lane -> query token, one head per column tile
+                const int t = t0 + wr * 32 + (l & 31);
+                const bool tv = t < a.M;
+                const int tc = min(t, a.M - 1);
+                const int lo = a.band_lo[tc], hi = a.band_hi[tc];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) band_head<BF>(a, acc[j], b, t, tv, lo, hi, n0j / 32 + j, l);
+            }
+        } else if constexpr (NJ1 > 0) {
+            __syncthreads();
+            float* sc = ldsf + w * (32 * (32 * NJ0 + 4));
+            if (kh == 0) tg_epilogue<NJ, 0, NJ0>(a, acc, 0, m0 + wr * 32, n0j, l, sc, coefS);
+            else tg_epilogue<NJ, NJ0, (NJ1 > 0 ? NJ1 : 1)>(a, acc, 0, m0 + wr * 32, n0j + 32 * NJ0, l, sc, coefS);
+        } else if (a.y_tm) {
+            // ---- token-major activation epilogue on ALL FOUR waves.  (Run by the two K-half-0 waves alone, with the residual gathered
+            // in the MFMA layout — 2-byte loads, lane == column — it was 40-60 % of these kernels: knock-outs, profiles/r03_*.)
+            // phase 1 (K-half-0 waves, lane == column): acc + bias + timestep-embedding term -> scratch [32 rows][CW + 4] of this row half
+            constexpr int CW = 32 * NJ, CP = CW + 4;
+            float* const sc = xr;
+            const int mt = t0 + wr * 32;                       // first token of this row half
+            const int nrows = min(32, a.M - mt);               // <= 0: padding rows only
+            if (kh == 0 && nrows > 0) {
+                const int lc = l & 31, lh = l >> 5;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int n = n0j + j * 32 + lc;
+                    float add = a.bias ? a.bias[n] : 0.f;
+                    if (a.emb) add += a.emb[(long long)n * a.emb_pitch + (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * lh) * CP + j * 32 + lc] = acc[j][r] + add;
+                }
+            }
+            __syncthreads();
+            // phase 2 (all waves): wave (wr, kh) takes rows 16 kh .. 16 kh + 15; 16 lanes per row (CW / 8 of them active), each 8
+            // consecutive columns: residual (16-byte loads, optionally GroupNorm'ed), rounding to the element type, GroupNorm partial
+            // sums of the stored values, 16-byte stores
+            const int rr = l >> 4, cq = l & 15;
+            const bool lane_on = cq < CW / 8;
+            const int n = n0j + 8 * min(cq, CW / 8 - 1);
+            float ref[8], s1[8], s2[8], rca[8], rcb[8], add2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ref[e] = sc[8 * min(cq, CW / 8 - 1) + e];   // any common shift will do: row 0 of the row half, before the residual
+                s1[e] = 0.f; s2[e] = 0.f;
+                rca[e] = a.res_gn ? coefS[2 * (n + e)] : 1.f;
+                rcb[e] = a.res_gn ? coefS[2 * (n + e) + 1] : 0.f;
+                add2[e] = (a.y2_tm && a.y2_add) ? a.y2_add[n + e] : 0.f;
+            }
+            const long long R0 = (long long)b * a.seg_rows + mt;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = 16 * kh + 4 * ps + rr;
+                if (!lane_on || row >= nrows) continue;
+                const f32x4t v0 = *reinterpret_cast<const f32x4t*>(sc + row * CP + 8 * cq);
+                const f32x4t v1 = *reinterpret_cast<const f32x4t*>(sc + row * CP + 8 * cq + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (a.res_tm && !(a.dbg & 4)) {
+                    if constexpr (BF) {
+                        const u32x4 rv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.res_tm) + (R0 + row) * a.ldr_tm + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += fmaf(__builtin_bit_cast(float, rv[e] << 16), rca[2 * e], rcb[2 * e]);
+                            v[2 * e + 1] += fmaf(__builtin_bit_cast(float, rv[e] & 0xffff0000u), rca[2 * e + 1], rcb[2 * e + 1]);
+                        }
+                    } else {
+                        const float* rp = reinterpret_cast<const float*>(a.res_tm) + (R0 + row) * a.ldr_tm + n;
+                        const f32x4t r0 = *reinterpret_cast<const f32x4t*>(rp), r1 = *reinterpret_cast<const f32x4t*>(rp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += fmaf(r0[e], rca[e], rcb[e]); v[4 + e] += fmaf(r1[e], rca[4 + e], rcb[4 + e]); }
+                    }
+                }
+                const long long o = (R0 + row) * a.ldy + n;
+                if constexpr (BF) {
+                    const bf16x8 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3], (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(a.y_tm) + o) = ov;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)ov[e];   // the statistics are those of the stored values
+                    if (a.y2_tm) {
+                        const bf16x8 o2 = {(__bf16)(v[0] + add2[0]), (__bf16)(v[1] + add2[1]), (__bf16)(v[2] + add2[2]), (__bf16)(v[3] + add2[3]),
+                                           (__bf16)(v[4] + add2[4]), (__bf16)(v[5] + add2[5]), (__bf16)(v[6] + add2[6]), (__bf16)(v[7] + add2[7])};
+                        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(a.y2_tm) + o + a.y2_row_off * a.ldy) = o2;
+                    }
+                } else {
+                    float* y = reinterpret_cast<float*>(a.y_tm) + o;
+                    const f32x4t w0 = {v[0], v[1], v[2], v[3]}, w1 = {v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<f32x4t*>(y) = w0;
+                    *reinterpret_cast<f32x4t*>(y + 4) = w1;
+                    if (a.y2_tm) {
+                        float* y2 = reinterpret_cast<float*>(a.y2_tm) + o + a.y2_row_off * a.ldy;
+                        const f32x4t u0 = {v[0] + add2[0], v[1] + add2[1], v[2] + add2[2], v[3] + add2[3]};
+                        const f32x4t u1 = {v[4] + add2[4], v[5] + add2[5], v[6] + add2[6], v[7] + add2[7]};
+                        *reinterpret_cast<f32x4t*>(y2) = u0;
+                        *reinterpret_cast<f32x4t*>(y2 + 4) = u1;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[e] - ref[e]; s1[e] += d; s2[e] = fmaf(d, d, s2[e]); }
+            }
+            if (a.stats) {
+                // sums over the wave's 16 rows (lanes l, l ^ 16, l ^ 32, l ^ 48 share their columns), then over the two waves of the row
+                // half through the statistics exchange [2 row halves][CW columns][2] (the coefficient region: free after the prologue)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1[e] += __shfl_xor(s1[e], 16); s2[e] += __shfl_xor(s2[e], 16);
+                    s1[e] += __shfl_xor(s1[e], 32); s2[e] += __shfl_xor(s2[e], 32);
+                }
+                float* const ex = coefS + wr * (2 * CW);
+                if (kh == 1 && l < CW / 8) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ex[2 * (8 * l + e)] = s1[e]; ex[2 * (8 * l + e) + 1] = s2[e]; }
+                }
+                __syncthreads();
+                if (kh == 0 && l < CW / 8 && nrows > 0) {
+                    float* so = a.stats + (long long)b * a.stats_bs + ((long long)(mt >> 5) * a.N + n) * 2;   // [tile][channel][2]
+                    const float cnt = (float)nrows, inv = 1.0f / cnt;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float S1 = s1[e] + ex[2 * (8 * l + e)], S2 = s2[e] + ex[2 * (8 * l + e) + 1];
+                        const float md = S1 * inv;
+                        so[2 * e] = ref[e] + md;                          // mean
+                        so[2 * e + 1] = fmaxf(S2 - cnt * md * md, 0.f);   // M2 = sum (x - mean)^2
+                    }
+                }
+            }
+        } else {
+            if (kh == 0) {
+                __builtin_amdgcn_wave_barrier();
+                tg_epilogue<NJ>(a, acc, 0, m0 + wr * 32, n0j, l, xr, coefS);
+            }
+        }
+        if (jn + 1 < ntw) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            __syncthreads();   // the tile area served as exchange / transposition scratch
+            lds_store(ra_, rw);
+            __syncthreads();
+        }
+    }
+}
+
 bool tgemm_supports(const TGemmArgs& a) {
     if (a.f32) {   // fp32 kernel: 4-float chunks, 32-float k-tiles; 96- or 128-wide column tiles; batch-as-rows addressing only
         if (!(a.M >= 1 && (a.N % 96 == 0 || a.N % 128 == 0) && a.K >= FBK && a.K % FBK == 0 && a.lda % 4 == 0 && a.seg_rows > 0)) return false;
@@ -738,6 +1327,73 @@ bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
     } else {
         dim3 grid((unsigned)(mtiles8 * (a.N / 64)));
         hipLaunchKernelGGL(tgemm_kernel<64>, grid, dim3(256), 2 * (TBM + 64) * TLP * 2, s, a2);
+    }
+    return true;
+}
+
+// ---- host side of xgemm_kernel ---------------------------------------------------------------------------------------
+bool xgemm_supports(const TGemmArgs& a) {
+    const int fbk = a.f32 ? 32 : 64;
+    if (a.seg_rows <= 0 || a.seg_rows % 64 || a.M < 1 || a.M > a.seg_rows) return false;
+    if (!(a.N % 96 == 0 || a.N % 128 == 0)) return false;
+    if (a.geglu && a.N % 256) return false;
+    int kres = 0;
+    if (a.ra[0]) {
+        if (a.rtaps != 1 && a.rtaps != 3) return false;
+        if (a.rmode < 0 || a.rmode > 3) return false;
+        if ((a.rmode == 1 || a.rmode == 3) && (!a.gn_part[0] || !a.gn_gamma || !a.gn_beta || (a.ra[1] && !a.gn_part[1]))) return false;
+        if (a.rmode >= 2 && (a.ra[1] || !a.ln_gamma || !a.ln_beta)) return false;
+        kres = a.rtaps * (a.ra[1] ? 384 : 192);
+    }
+    int kst = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (a.sk[i] < 0 || a.sk[i] % fbk) return false;
+        if (a.sk[i] > 0 && (!a.sa[i] || a.sld[i] % (a.f32 ? 4 : 8))) return false;
+        if (i > 0 && a.sk[i] > 0 && a.sk[i - 1] == 0) return false;
+        kst += a.sk[i];
+    }
+    if (kres + kst != a.K || a.K < fbk) return false;
+    if (a.band_k && (a.N % 96 || !a.ra[0] || kst || !a.y_tm || !a.band_lo || !a.band_hi || a.band_wmax < 1 || a.band_wmax > 8)) return false;
+    if (a.res_gn && (!a.res_tm || !a.res_part || !a.res_gamma || !a.res_beta || (a.ra[0] && (a.rmode == 1 || a.rmode == 3)))) return false;
+    if ((long long)a.N * a.K > 0x7fffffffLL) return false;
+    if ((long long)a.batch * a.seg_rows > 0x7fffffffLL / 768) return false;   // 32-bit row arithmetic in the epilogue helpers
+    if (a.y_cm && (a.cm_pitch % 4 || a.cm_pitch < ((a.M + 3) & ~3))) return false;
+    return true;
+}
+template <int NJ, bool BF, bool RS, bool SS, bool TR, int OCC>
+static void launch_xgemm_one(const TGemmArgs& a, hipStream_t s) {
+    const long long mt8 = ((long long)a.batch * a.seg_rows / 64 + 7) / 8 * 8;
+    const int smem = xgemm_lds_bytes<NJ, BF>(RS);
+    static bool configured = false;   // (configure_tgemm_kernel raises the limit for every instantiation it lists; this is the safety net)
+    if (!configured) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xgemm_kernel<NJ, BF, RS, SS, TR, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); configured = true; }
+    hipLaunchKernelGGL((xgemm_kernel<NJ, BF, RS, SS, TR, OCC>), dim3((unsigned)(mt8 * (a.N / (32 * NJ * a.ntw)))), dim3(256), smem, s, a);
+}
+bool launch_xgemm(const TGemmArgs& a_in, int batch, hipStream_t s) {
+    TGemmArgs a = a_in;
+    a.batch = batch;
+    if (!xgemm_supports(a)) return false;
+    const bool rs = a.ra[0] != nullptr, ss = a.sk[0] > 0, tr = a.band_k != nullptr;
+    const bool nj4 = a.N % 128 == 0 && (a.geglu || a.N % 96);
+    {   // column tiles per workgroup: with a resident source all of them (the prologue is paid once per row tile) unless the caller
+        // chose; a concatenated input re-uses the resident buffer for its second source, so it stays at one
+        const int ntiles = a.N / (nj4 ? 128 : 96);
+        int ntw = a.ntw > 0 ? a.ntw : ((rs && !a.ra[1]) ? ntiles : 1);
+        if (a.ra[1]) ntw = 1;
+        while (ntiles % ntw) --ntw;
+        a.ntw = ntw;
+    }
+    if (a.f32) {
+        if (tr) launch_xgemm_one<3, false, true, false, true, 2>(a, s);
+        else if (nj4) { if (rs && !ss) launch_xgemm_one<4, false, true, false, false, 2>(a, s); else return false; }
+        else if (rs && ss) launch_xgemm_one<3, false, true, true, false, 2>(a, s);
+        else if (rs) launch_xgemm_one<3, false, true, false, false, 2>(a, s);
+        else launch_xgemm_one<3, false, false, true, false, 3>(a, s);
+    } else {
+        if (tr) launch_xgemm_one<3, true, true, false, true, 2>(a, s);
+        else if (nj4) { if (rs && !ss) launch_xgemm_one<4, true, true, false, false, 2>(a, s); else return false; }
+        else if (rs && ss) launch_xgemm_one<3, true, true, true, false, 2>(a, s);
+        else if (rs) launch_xgemm_one<3, true, true, false, false, 2>(a, s);
+        else launch_xgemm_one<3, true, false, true, false, 3>(a, s);
     }
     return true;
 }
