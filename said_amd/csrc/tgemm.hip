@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -794,39 +795,32 @@ __device__ __forceinline__ void band_head(const TGemmArgs& a, const f32x16& q, i
     }
 }
 
-template <int NJ, bool BF, bool RS, bool SS, bool TR, int OCC>
+template <int NJ, bool BF, bool TR, int OCC>
 __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
-    static_assert(RS || SS, "a GEMM needs an operand");
-    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [stream A 64 rows | W BN rows] x 144 bytes | coefficients | resident tile
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // exchange / transposition scratch | coefficients & statistics | resident tile
     float* const ldsf = reinterpret_cast<float*>(lds);
     typedef typename std::conditional<BF, unsigned short, float>::type elt_t;
     constexpr int EPC = BF ? 8 : 4;              // elements per 16-byte chunk
-    constexpr int FBK = 8 * EPC, FLP = 9 * EPC;  // k per tile (128 bytes), LDS row pitch of the streamed tiles (144 bytes), in elements
-    constexpr int CT = 192 / FBK;                // k-tiles per source and tap of the resident segment (3 bf16, 6 fp32)
+    constexpr int FBK = 8 * EPC;                 // k per k-tile (128 bytes of a row): four MFMA operand steps of 2 EPC
+    constexpr int CT = 192 / FBK;                // k-tiles per tap of a phase (3 bf16, 6 fp32)
     constexpr int RP = x_rp_bytes<BF>() / (int)sizeof(elt_t);   // resident row pitch in elements
-    elt_t* const ldse = reinterpret_cast<elt_t*>(lds);
     float* const coefS = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + fgemm_lds_bytes<NJ>());
     elt_t* const ares = reinterpret_cast<elt_t*>(reinterpret_cast<char*>(lds) + fgemm_lds_bytes<NJ>() + X_COEF_BYTES);
-    constexpr int BM = 64, BN = 32 * NJ, NTH = 256;
-    constexpr int ACH = BM * 8 / NTH, WCH = BN * 8 / NTH;   // 16-byte chunks per thread and tile: 2, NJ
+    constexpr int BM = 64, BN = 32 * NJ;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int wr = w & 1, kh = w >> 1;
     const int rows_tot = a.batch * a.seg_rows;
-    const int NT = a.N / (BN * (a.ntw > 0 ? a.ntw : 1)), MT = rows_tot / BM;   // seg_rows % 64 == 0 (host-checked): a tile never straddles samples
+    const int ntw = a.ntw > 0 ? a.ntw : 1;
+    const int NT = a.N / (BN * ntw), MT = rows_tot / BM;   // seg_rows % 64 == 0 (host-checked): a tile never straddles samples
     const unsigned L = blockIdx.x, xcd = L & 7u, slot = L >> 3;   // XCD-aware order, as in tgemm_kernel
     const int nt = (int)(slot % (unsigned)NT);
     const int mg = (int)(slot / (unsigned)NT) * 8 + (int)xcd;
     if (mg >= MT) return;
-    const int m0 = mg * BM, n0 = nt * BN * (a.ntw > 0 ? a.ntw : 1);
+    const int m0 = mg * BM, n0 = nt * BN * ntw;
     const int b = m0 / a.seg_rows, t0 = m0 - b * a.seg_rows;
     if (t0 >= a.M) return;                                    // a tile of padding tokens only
-    const elt_t* W = reinterpret_cast<const elt_t*>(a.w);
-    const int nsrc = RS ? (a.ra[1] ? 2 : 1) : 0;
-    const int ntap = RS ? a.rtaps : 0;
-    const int nkr = ntap * nsrc * CT;                          // resident k-tiles
-    const int nk = a.K / FBK;
-    const int nst = nk - nkr;                                  // streamed k-tiles
-    const int sk0 = a.sk[0] / FBK, sk1 = a.sk[1] / FBK;
+    const int nph = a.nph;
+    const int nstep_tot = a.K / (2 * EPC);                    // MFMA operand steps along K (16 bf16 / 8 fp32 each)
 
     // ---- GroupNorm coefficients from a producer's partials -> coefS (4 waves x 48 channels; per-wave scratch inside the tile area,
     // which is idle at both call sites: kernel entry, and the source switch of a concatenated input)
@@ -838,14 +832,15 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
         gn_finish(gp, rp, w * 48, 48, l, gl, ldsf + w * GN_SCRATCH, coefS);
         __syncthreads();
     };
-    if (!RS && a.res_gn) gn_coefs(a.res_part, a.res_eps, a.res_gamma, a.res_beta);
     // ---- resident tile of source `ph`: 8 threads per row (24 channels each), 32 rows per pass; a convolution's two halo rows
     // (resident rows 64, 65) by the first 16 threads in a third pass.  Few live registers on purpose: this prologue must not
     // cost the k loop its occupancy.
     auto load_resident = [&](int ph) {
-        if (a.rmode == 1 || a.rmode == 3) gn_coefs(a.gn_part[ph], a.gn_eps, a.gn_gamma + ph * 192, a.gn_beta + ph * 192);
-        const elt_t* src = reinterpret_cast<const elt_t*>(a.ra[ph]);
-        const int halo = a.rtaps == 3 ? 1 : 0;
+        const int rmode = a.pmode[ph];
+        if (rmode == 1 || rmode == 3) gn_coefs(a.ppart[ph], a.gn_eps, a.pgamma[ph], a.pbeta[ph]);
+        const elt_t* src = reinterpret_cast<const elt_t*>(a.pa[ph]) + a.pcoff[ph];
+        const int ld = a.pld[ph];
+        const int halo = a.ptaps[ph] == 3 ? 1 : 0;
         const int q8 = tid & 7;
         const float* cf = coefS + 48 * q8;
         for (int pass = 0; pass < 2 + halo; ++pass) {
@@ -853,7 +848,7 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
             if (pass == 2 && tid >= 16) break;
             const int tt = t0 + r - halo;
             const bool valid = tt >= 0 && tt < a.M;
-            const elt_t* p = src + ((long long)b * a.seg_rows + min(max(tt, 0), a.M - 1)) * 192 + 24 * q8;
+            const elt_t* p = src + ((long long)b * a.seg_rows + min(max(tt, 0), a.M - 1)) * ld + 24 * q8;
             float x[24];
             if constexpr (BF) {
                 u32x4 raw[3];
@@ -875,15 +870,15 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[4 * i + e] = raw[i][e];
             }
-            if (a.rmode == 1 || a.rmode == 3) {
+            if (rmode == 1 || rmode == 3) {
 #pragma unroll
                 for (int i = 0; i < 24; ++i) x[i] = fmaf(x[i], cf[2 * i], cf[2 * i + 1]);
             }
-            if (a.rmode == 1) {
+            if (rmode == 1) {
 #pragma unroll
                 for (int i = 0; i < 24; ++i) x[i] = silu_f(x[i]);
             }
-            if (a.rmode >= 2) {   // LayerNorm over the row's 192 channels: sums over this thread's 24, then over the row's eight threads
+            if (rmode >= 2) {   // LayerNorm over the row's 192 channels: sums over this thread's 24, then over the row's eight threads
                 const float ref = __shfl(x[0], l & ~7);
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -921,39 +916,26 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
         }
     };
 
-    // ---- k-tile pipeline: weights always, streamed A tiles when SS
-    f32x4t ra_[ACH], rw[WCH];
-    int woff[WCH], lwoff[WCH], loff[ACH], arow[ACH], akp[ACH];
+
+    if (a.res_gn && nph == 1 && a.pmode[0] == 0) gn_coefs(a.res_part, a.res_eps, a.res_gamma, a.res_beta);
+
+    // ---- weights: packed on the host in MFMA operand order, wp[column tile][operand step][lane][16 bytes] — a wave's fragment is ONE
+    // coalesced 1 KB read straight into registers: no LDS staging, no barrier in the k loop (the source tile is already in LDS).
+    // k-tile g of the sequence (phases in order, tap-major inside a phase) = operand steps 4 g .. 4 g + 3; K half kh takes 2 kh, 2 kh + 1.
+    const f32x4t* const wpv = reinterpret_cast<const f32x4t*>(a.wp);
+    f32x4t wc[2][NJ], wn[2][NJ];   // current / next k-tile's fragments: [operand step of the K half][column tile]
+    auto wload = [&](int jn, int g) {
+        const long long cbase = (long long)((n0 >> 5) + jn * NJ) * nstep_tot;
 #pragma unroll
-    for (int i = 0; i < ACH; ++i) {
-        const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
-        arow[i] = min(m0 + row, rows_tot - 1);
-        akp[i] = kp * EPC;
-        loff[i] = row * FLP + kp * EPC;
-    }
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-        const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
-        woff[i] = (n0 + row) * a.K + kp * EPC;
-        lwoff[i] = BM * FLP + row * FLP + kp * EPC;
-    }
-    // W k-offset of tile kt: the resident segment runs source-major ([source][tap][channel tile]) over a tap-major weight
-    auto wk_of = [&](int kt) -> int {
-        if (RS && kt < nkr) {
-            const int per = ntap * CT;
-            const int ph = kt / per, rem = kt - ph * per;
-            const int tap = rem / CT, ct = rem - tap * CT;
-            return tap * (nsrc * 192) + ph * 192 + ct * FBK;
-        }
-        return kt * FBK;
+            for (int j = 0; j < NJ; ++j) wn[ks][j] = wpv[((cbase + (long long)j * nstep_tot) + (4 * g + 2 * kh + ks)) * 64 + l];
     };
-    auto lds_store = [&](const f32x4t* xa, const f32x4t* xw) {
-        if constexpr (SS) {
+    auto wshift = [&]() {
 #pragma unroll
-            for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4t*>(ldse + loff[i]) = xa[i];
-        }
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int i = 0; i < WCH; ++i) *reinterpret_cast<f32x4t*>(ldse + lwoff[i]) = xw[i];
+            for (int j = 0; j < NJ; ++j) wc[ks][j] = wn[ks][j];
     };
     f32x16 acc[NJ];
 #pragma unroll
@@ -961,93 +943,61 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int frow = l & 31, fk = EPC * (l >> 5) + 4 * EPC * kh;
-    const elt_t* const pa_s = ldse + (wr * 32 + frow) * FLP + fk;
     const elt_t* const pa_r = ares + (wr * 32 + frow) * RP + fk;
-    const elt_t* const pw = ldse + BM * FLP + frow * FLP + fk;
-    auto compute = [&](int kt) {
-        const elt_t* pa = pa_s;
-        if (RS && kt < nkr) {
-            const int rem = kt % (ntap * CT);
-            const int tap = rem / CT, ct = rem - tap * CT;
-            pa = pa_r + tap * RP + ct * FBK;
-        }
+    auto compute = [&](int tap, int ct) {
+        const elt_t* pa = pa_r + tap * RP + ct * FBK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if constexpr (BF) {
                 const bf16x8 fa = *reinterpret_cast<const bf16x8*>(pa + ks * 16);
-                bf16x8 fb[NJ];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(pw + j * 32 * FLP + ks * 16);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa, acc[j], 0, 0, 0);
-                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[j], 0, 0, 0);
+                    const bf16x8 fb = __builtin_bit_cast(bf16x8, wc[ks][j]);
+                    if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, acc[j], 0, 0, 0);
+                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
                 }
             } else {
                 const f32x4t fa = *reinterpret_cast<const f32x4t*>(pa + ks * 8);
-                f32x4t fb[NJ];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const f32x4t*>(pw + j * 32 * FLP + ks * 8);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][i], fa[i], acc[j], 0, 0, 0);
-                        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j][i], acc[j], 0, 0, 0);
+                        if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[ks][j][i], fa[i], acc[j], 0, 0, 0);
+                        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], wc[ks][j][i], acc[j], 0, 0, 0);
                     }
             }
         }
     };
-    // The workgroup walks over `ntw` consecutive column tiles with its resident source tile (the prologue — GroupNorm finalisation,
-    // tile load, transform, LayerNorm — is paid once per ntw x 32 NJ output columns instead of once per column tile: with one
-    // column tile per workgroup the 12 workgroups of a GEGLU row tile each repeated it, 163 us per launch against 71 for round
-    // 2's GEMM + 19 for its preparation kernel).  (column tile, k-tile) pairs form ONE sequence of steps through the k-tile
-    // pipeline: request the next step's tile -> multiply the tile in LDS -> barrier -> [last k-tile of a column tile: add the K
-    // halves, epilogue] -> park the next tile -> barrier.  The next column tile's first weights are in flight during the epilogue.
-    const int ntw = RS ? (a.ntw > 0 ? a.ntw : 1) : 1;   // (streamed-only GEMMs have no prologue to amortise)
-    const int nsteps = ntw * nk;
-    const int e0 = (RS && nsrc == 2) ? ntap * CT : -1;   // a concatenated input (ntw == 1): the second source takes the resident buffer over
     constexpr int NJ0 = (NJ == 4 && !TR) ? 2 : NJ, NJ1 = NJ - NJ0;
     float* const xr = ldsf + wr * (NJ1 > 0 ? NJ * 16 * 64 : 32 * (32 * NJ + 4));
-    auto gload_step = [&](int step) {
-        const int jn = step / nk, kt = step - jn * nk;
-        const int wk = wk_of(kt) + jn * BN * a.K;
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) rw[i] = *reinterpret_cast<const f32x4t*>(W + (woff[i] + wk));
-        if constexpr (SS) {
-            const int st = min(max(kt - nkr, 0), nst - 1);        // (resident steps re-request the first streamed tile: an L1 hit)
-            const elt_t* base; int ld, off;
-            if (st < sk0) { base = reinterpret_cast<const elt_t*>(a.sa[0]); ld = a.sld[0]; off = st * FBK; }
-            else if (st < sk0 + sk1) { base = reinterpret_cast<const elt_t*>(a.sa[1]); ld = a.sld[1]; off = (st - sk0) * FBK; }
-            else { base = reinterpret_cast<const elt_t*>(a.sa[2]); ld = a.sld[2]; off = (st - sk0 - sk1) * FBK; }
-#pragma unroll
-            for (int i = 0; i < ACH; ++i) ra_[i] = *reinterpret_cast<const f32x4t*>(base + ((long long)arow[i] * ld + off + akp[i]));
-        }
-    };
-    gload_step(0);
-    if constexpr (RS) { if (!(a.dbg & 8)) load_resident(0); }
-    lds_store(ra_, rw);
-    __syncthreads();
-    const int nk_loop = (a.dbg & 2) ? 1 : nk;   // (timing experiment: no k loop)
+    const int nk = a.K / FBK;                                  // k-tiles of one column tile
+
+    // The workgroup walks over `ntw` consecutive column tiles.  With ONE phase the resident tile is loaded once and serves them all
+    // (the prologue — GroupNorm finalisation, tile load, transform, LayerNorm — is paid once per row tile); with several phases
+    // (concatenated inputs, the 1x1 skip behind a convolution, [h ; x2]) every column tile re-walks them.
+    wload(0, 0);
+    wshift();
+    if (nph == 1) { if (!(a.dbg & 8)) load_resident(0); __syncthreads(); }
     for (int jn = 0; jn < ntw; ++jn) {
-        const int s0 = jn * nk;
-        // all k-tiles but the last: request the next tile -> multiply -> barrier -> park the next tile -> barrier
-        for (int kt = 0; kt < nk_loop - 1; ++kt) {
-            gload_step(s0 + kt + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(kt);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            if (kt == e0 - 1) load_resident(1);   // all waves are done with the first source's tile (concatenated input)
-            lds_store(ra_, rw);
-            __syncthreads();
+        int g = 0;                                             // k-tile index within the column tile
+        for (int ph = 0; ph < nph; ++ph) {
+            if (nph > 1) {
+                if (ph > 0) __syncthreads();                   // every wave is done with the previous phase's tile
+                load_resident(ph);
+                __syncthreads();
+            }
+            const int nkp = a.ptaps[ph] * CT;                  // k-tiles of this phase: tap-major
+            for (int gl = 0; gl < nkp; ++gl, ++g) {
+                // request the next k-tile's weights (behind the last one: the next column tile's first), multiply this one's: no barrier
+                const bool last = g == nk - 1;
+                wload(last ? min(jn + 1, ntw - 1) : jn, last ? 0 : g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const int tap = CT == 3 ? (gl * 43) >> 7 : (gl * 43) >> 8;   // gl / CT for gl < 64
+                compute(tap, gl - tap * CT);
+                __builtin_amdgcn_sched_barrier(0);
+                wshift();
+            }
         }
-        // last k-tile: the NEXT column tile's first weights are requested and stay in registers through the epilogue
-        if constexpr (RS) gload_step(min(s0 + nk, nsteps - 1));
-        __builtin_amdgcn_sched_barrier(0);
-        compute(nk - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
         // ---- add the two K halves (fgemm_kernel's exchange), then the epilogue of column tile jn
         const int n0j = n0 + jn * BN;
 #pragma unroll
@@ -1203,9 +1153,7 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-            __syncthreads();   // the tile area served as exchange / transposition scratch
-            lds_store(ra_, rw);
-            __syncthreads();
+            __syncthreads();   // the scratch area is free again
         }
     }
 }
@@ -1333,67 +1281,77 @@ bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
 
 // ---- host side of xgemm_kernel ---------------------------------------------------------------------------------------
 bool xgemm_supports(const TGemmArgs& a) {
-    const int fbk = a.f32 ? 32 : 64;
     if (a.seg_rows <= 0 || a.seg_rows % 64 || a.M < 1 || a.M > a.seg_rows) return false;
     if (!(a.N % 96 == 0 || a.N % 128 == 0)) return false;
     if (a.geglu && a.N % 256) return false;
-    int kres = 0;
-    if (a.ra[0]) {
-        if (a.rtaps != 1 && a.rtaps != 3) return false;
-        if (a.rmode < 0 || a.rmode > 3) return false;
-        if ((a.rmode == 1 || a.rmode == 3) && (!a.gn_part[0] || !a.gn_gamma || !a.gn_beta || (a.ra[1] && !a.gn_part[1]))) return false;
-        if (a.rmode >= 2 && (a.ra[1] || !a.ln_gamma || !a.ln_beta)) return false;
-        kres = a.rtaps * (a.ra[1] ? 384 : 192);
+    if (a.nph < 1 || a.nph > 5 || !a.wp) return false;
+    int k = 0;
+    for (int i = 0; i < a.nph; ++i) {
+        if (!a.pa[i] || (a.ptaps[i] != 1 && a.ptaps[i] != 3) || a.pmode[i] < 0 || a.pmode[i] > 3) return false;
+        if (a.pld[i] % (a.f32 ? 4 : 8) || a.pcoff[i] % (a.f32 ? 4 : 8) || a.pcoff[i] + 192 > a.pld[i]) return false;
+        if ((a.pmode[i] == 1 || a.pmode[i] == 3) && (!a.ppart[i] || !a.pgamma[i] || !a.pbeta[i])) return false;
+        if (a.pmode[i] >= 2 && (a.nph != 1 || !a.ln_gamma || !a.ln_beta)) return false;
+        k += a.ptaps[i] * 192;
     }
-    int kst = 0;
-    for (int i = 0; i < 3; ++i) {
-        if (a.sk[i] < 0 || a.sk[i] % fbk) return false;
-        if (a.sk[i] > 0 && (!a.sa[i] || a.sld[i] % (a.f32 ? 4 : 8))) return false;
-        if (i > 0 && a.sk[i] > 0 && a.sk[i - 1] == 0) return false;
-        kst += a.sk[i];
-    }
-    if (kres + kst != a.K || a.K < fbk) return false;
-    if (a.band_k && (a.N % 96 || !a.ra[0] || kst || !a.y_tm || !a.band_lo || !a.band_hi || a.band_wmax < 1 || a.band_wmax > 8)) return false;
-    if (a.res_gn && (!a.res_tm || !a.res_part || !a.res_gamma || !a.res_beta || (a.ra[0] && (a.rmode == 1 || a.rmode == 3)))) return false;
-    if ((long long)a.N * a.K > 0x7fffffffLL) return false;
+    if (k != a.K) return false;
+    if (a.band_k && (a.N % 96 || a.nph != 1 || !a.y_tm || !a.band_lo || !a.band_hi || a.band_wmax < 1 || a.band_wmax > 8)) return false;
+    if (a.res_gn && (!a.res_tm || !a.res_part || !a.res_gamma || !a.res_beta || a.nph != 1 || a.pmode[0] != 0 || a.stats)) return false;
     if ((long long)a.batch * a.seg_rows > 0x7fffffffLL / 768) return false;   // 32-bit row arithmetic in the epilogue helpers
     if (a.y_cm && (a.cm_pitch % 4 || a.cm_pitch < ((a.M + 3) & ~3))) return false;
     return true;
 }
-template <int NJ, bool BF, bool RS, bool SS, bool TR, int OCC>
+size_t tgemm_packed_bytes(int N, int K, bool bf16) { return (size_t)N * K * (bf16 ? 2 : 4); }
+void tgemm_pack_weights(const float* W, int N, int K, bool bf16, void* out) {
+    const int step = bf16 ? 16 : 8, ns = K / step;
+    for (int jt = 0; jt < N / 32; ++jt)
+        for (int s = 0; s < ns; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const float* src = W + (size_t)(jt * 32 + (l & 31)) * K + (size_t)s * step + (step / 2) * (l >> 5);
+                const size_t frag = ((size_t)jt * ns + s) * 64 + l;
+                if (bf16) {
+                    unsigned short* d = reinterpret_cast<unsigned short*>(out) + frag * 8;
+                    for (int e = 0; e < 8; ++e) {
+                        unsigned x;
+                        memcpy(&x, &src[e], 4);
+                        x += 0x7fffu + ((x >> 16) & 1u);   // round to nearest even (finite inputs)
+                        d[e] = (unsigned short)(x >> 16);
+                    }
+                } else {
+                    float* d = reinterpret_cast<float*>(out) + frag * 4;
+                    for (int e = 0; e < 4; ++e) d[e] = src[e];
+                }
+            }
+}
+template <int NJ, bool BF, bool TR, int OCC>
 static void launch_xgemm_one(const TGemmArgs& a, hipStream_t s) {
     const long long mt8 = ((long long)a.batch * a.seg_rows / 64 + 7) / 8 * 8;
-    const int smem = xgemm_lds_bytes<NJ, BF>(RS);
-    static bool configured = false;   // (configure_tgemm_kernel raises the limit for every instantiation it lists; this is the safety net)
-    if (!configured) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xgemm_kernel<NJ, BF, RS, SS, TR, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); configured = true; }
-    hipLaunchKernelGGL((xgemm_kernel<NJ, BF, RS, SS, TR, OCC>), dim3((unsigned)(mt8 * (a.N / (32 * NJ * a.ntw)))), dim3(256), smem, s, a);
+    const int smem = xgemm_lds_bytes<NJ, BF>(true);
+    static bool configured = false;
+    if (!configured) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xgemm_kernel<NJ, BF, TR, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); configured = true; }
+    hipLaunchKernelGGL((xgemm_kernel<NJ, BF, TR, OCC>), dim3((unsigned)(mt8 * (a.N / (32 * NJ * a.ntw)))), dim3(256), smem, s, a);
 }
 bool launch_xgemm(const TGemmArgs& a_in, int batch, hipStream_t s) {
     TGemmArgs a = a_in;
     a.batch = batch;
     if (!xgemm_supports(a)) return false;
-    const bool rs = a.ra[0] != nullptr, ss = a.sk[0] > 0, tr = a.band_k != nullptr;
+    const bool tr = a.band_k != nullptr;
     const bool nj4 = a.N % 128 == 0 && (a.geglu || a.N % 96);
-    {   // column tiles per workgroup: with a resident source all of them (the prologue is paid once per row tile) unless the caller
-        // chose; a concatenated input re-uses the resident buffer for its second source, so it stays at one
+    {   // column tiles per workgroup: with ONE phase all of them (the prologue is paid once per row tile) unless the caller chose;
+        // with several phases every column tile re-walks the phases, so one tile per workgroup spreads the launch further
         const int ntiles = a.N / (nj4 ? 128 : 96);
-        int ntw = a.ntw > 0 ? a.ntw : ((rs && !a.ra[1]) ? ntiles : 1);
-        if (a.ra[1]) ntw = 1;
+        int ntw = a.ntw > 0 ? a.ntw : (a.nph == 1 ? ntiles : 1);
+        if (ntw > ntiles) ntw = ntiles;
         while (ntiles % ntw) --ntw;
         a.ntw = ntw;
     }
     if (a.f32) {
-        if (tr) launch_xgemm_one<3, false, true, false, true, 2>(a, s);
-        else if (nj4) { if (rs && !ss) launch_xgemm_one<4, false, true, false, false, 2>(a, s); else return false; }
-        else if (rs && ss) launch_xgemm_one<3, false, true, true, false, 2>(a, s);
-        else if (rs) launch_xgemm_one<3, false, true, false, false, 2>(a, s);
-        else launch_xgemm_one<3, false, false, true, false, 3>(a, s);
+        if (tr) launch_xgemm_one<3, false, true, 2>(a, s);
+        else if (nj4) launch_xgemm_one<4, false, false, 2>(a, s);
+        else launch_xgemm_one<3, false, false, 2>(a, s);
     } else {
-        if (tr) launch_xgemm_one<3, true, true, false, true, 2>(a, s);
-        else if (nj4) { if (rs && !ss) launch_xgemm_one<4, true, true, false, false, 2>(a, s); else return false; }
-        else if (rs && ss) launch_xgemm_one<3, true, true, true, false, 2>(a, s);
-        else if (rs) launch_xgemm_one<3, true, true, false, false, 2>(a, s);
-        else launch_xgemm_one<3, true, false, true, false, 3>(a, s);
+        if (tr) launch_xgemm_one<3, true, true, 2>(a, s);
+        else if (nj4) launch_xgemm_one<4, true, false, 2>(a, s);
+        else launch_xgemm_one<3, true, false, 3>(a, s);
     }
     return true;
 }
