@@ -199,8 +199,9 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
  *                            (< 0: restore the measured defaults 5800 bf16 / 10000 fp32)
  *   "audio_chunk"            clips per audio-encoder pass (default 32)
  *   "steps_per_graph"        denoise steps captured per hipGraph (default 10)
- *   "tm_acts"                0: large batches keep round 2's schedule (fp32 channel-major activations between the UNet kernels, a
- *                            preparation kernel in front of every token-major GEMM); default 1: token-major activations
+ *   "tm_acts"                1: large batches run round 3's experimental schedule — token-major activations (bf16 / fp32) between the UNet
+ *                            kernels, GroupNorm / LayerNorm applied inside the consuming GEMM (xgemm_kernel), 41 launches per step, no
+ *                            preparation kernels; parity-green, measured slower than the default (0 = round 2's schedule), DESIGN.md 7.3
  *   "xgemm_ntw"              column tiles per workgroup of the resident-source GEMMs (0: chosen per launch)
  * said_debug_get additionally knows "n_set_weight" (said_set_weight calls so far). */
 int said_debug_option(said_ctx* ctx, const char* name, long long value);

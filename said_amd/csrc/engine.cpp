@@ -48,13 +48,11 @@ struct PW {  // packed GEMM weight (up to 2 K-segments) + bias
 };
 struct ResW { float *g1, *b1, *g2, *b2; PW conv1, conv2, skip; int cin; bool has_skip; float* bias2;
               void *t_conv1 = nullptr, *t_conv2 = nullptr; /* bf16 [192][taps * cin] (conv2: [576 | 384 skip]) for tgemm.hip */
-              void *tf_conv1 = nullptr, *tf_conv2 = nullptr; /* the same matrices in fp32 (fgemm_kernel) */
-              void *x_conv1 = nullptr, *x_conv2 = nullptr, *xf_conv1 = nullptr, *xf_conv2 = nullptr; /* packed for xgemm_kernel (conv1: K source-major) */ };
+              void *tf_conv1 = nullptr, *tf_conv2 = nullptr; /* the same matrices in fp32 (fgemm_kernel) */ };
 struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj, ffproj;
              void *t_qkv = nullptr, *t_ff1 = nullptr, *t_ffproj = nullptr; float* t_ff1_bias = nullptr; /* bf16 weights for tgemm.hip */
              void *tf_qkv = nullptr, *tf_ff1 = nullptr, *tf_ffproj = nullptr; /* fp32 copies (fgemm_kernel) */
-             void *x_qkv = nullptr, *x_ff1 = nullptr, *x_ffproj = nullptr, *x_out1 = nullptr, *x_q2 = nullptr, *x_out2 = nullptr;   /* packed for xgemm_kernel, bf16 */
-             void *xf_qkv = nullptr, *xf_ff1 = nullptr, *xf_ffproj = nullptr, *xf_out1 = nullptr, *xf_q2 = nullptr, *xf_out2 = nullptr; /* ... fp32 */ };
+             void *t_out1 = nullptr, *t_q2 = nullptr, *t_out2 = nullptr, *tf_out1 = nullptr, *tf_q2 = nullptr, *tf_out2 = nullptr; /* [192][192] (xgemm_kernel) */ };
 struct W2VLayer { PW qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln2g, *ln2b; };
 
 struct ActBuf {  // channel-major activation + its GroupNorm partial statistics
@@ -141,8 +139,10 @@ struct said_ctx {
     float* gn_coef = nullptr;   // [2 slots][maxBe][192][2] GroupNorm coefficients for prep_kernel
     void *uPA = nullptr, *uPB = nullptr, *uPL = nullptr, *uPH = nullptr, *uPX = nullptr;   // conv operand [Be][T+2][384], raw cat input
                                                                                             // [Be][T][384], LN'd [Be][T][192], GEGLU out [Be][T][768], raw x2 [Be][T][192]
-    bool tm_acts = true;      // large batches: token-major activations BETWEEN the UNet kernels, operand transforms inside the GEMMs
-                              // (round 3: no preparation kernels); false = round 2's schedule (prep_kernel + channel-major fp32 interface)
+    bool tm_acts = false;     // large batches: token-major activations BETWEEN the UNet kernels, operand transforms inside the GEMMs (round 3:
+                              // 41 launches, no preparation kernels).  Parity-green in both precisions but measured SLOWER than round 2's
+                              // schedule (prep_kernel + channel-major fp32 interface; bf16 2.49 vs 2.37, fp32 5.85 vs 4.92 ms per step at 32 clips:
+                              // DESIGN.md section 7.3), so it is opt-in: said_debug_option("tm_acts", 1)
     int xgemm_dbg = 0;
     int xgemm_ntw = 0;        // test / measurement: column tiles per workgroup of the resident-source GEMMs (0: launch_xgemm decides)
     void *tX1 = nullptr, *tX2 = nullptr, *tO = nullptr, *tF = nullptr;   // token-major x1, x2, attention output [.][192], GEGLU product [.][768]
@@ -318,18 +318,6 @@ int upload_bf16(said_ctx* ctx, void** out, const float* W, size_t N, size_t C, s
     if (dalloc(ctx, &d, h.size(), false)) return -1;
     HIPCHK(hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     *out = d;
-    return 0;
-}
-// xgemm_kernel operands: W [N][K] (K already in the GEMM's phase order) packed in MFMA operand order, bf16 and fp32 copies
-int upload_packed_pair(said_ctx* ctx, void** out_bf, void** out_f32, const float* W, int N, int K) {
-    for (int bf = 0; bf < 2; ++bf) {
-        std::vector<unsigned char> h(tgemm_packed_bytes(N, K, bf != 0));
-        tgemm_pack_weights(W, N, K, bf != 0, h.data());
-        unsigned char* d = nullptr;
-        if (dalloc(ctx, &d, h.size(), false)) return -1;
-        HIPCHK(hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice));
-        *(bf ? out_bf : out_f32) = d;
-    }
     return 0;
 }
 // the same matrix in bf16 AND fp32 (UNet operands of the token-major GEMMs: the precision mode is chosen per call)
@@ -608,7 +596,7 @@ void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
         const double eb = c->bf16_mode ? 2.0 : 4.0;
         const double out_n = a.geglu ? a.N / 2 : a.N;
         const double out_b = a.y_cm ? 4.0 * out_n : (a.qk ? 4.0 * out_n : eb * out_n * (a.y2_tm ? 2 : 1));
-        const double in_k = 192.0 * a.nph;   // source channels read per token (a convolution reads its tile once)
+        const double in_k = (a.ra[0] ? (a.ra[1] ? 384.0 : 192.0) : 0.0) + a.sk[0] + a.sk[1] + a.sk[2];   // source channels read per token (a conv reads its tile once)
         const double res_b = a.res_tm ? eb * a.N : 0.0;
         const double band_b = a.band_k ? 2.0 * 4.0 * a.N : 0.0;
         c->stage_log.push_back({6, a.geglu ? EPI_GEGLU : (a.qk ? EPI_QKV : (a.band_k ? EPI_BAND : EPI_STORE)), a.N % 128 == 0 && (a.geglu || a.N % 96) ? 128 : 96, c->bf16_mode ? 4 : 32,
@@ -616,7 +604,7 @@ void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     }
     TGemmArgs a2 = a;
     a2.f32 = c->bf16_mode ? 0 : 1;
-    if (c->xgemm_ntw > 0) a2.ntw = c->xgemm_ntw;
+    if (c->xgemm_ntw > 0 && a2.ra[0]) a2.ntw = c->xgemm_ntw;
     a2.dbg = c->xgemm_dbg;
     if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }
     if (dbg_go(c) && !launch_xgemm(a2, batch, s)) {
@@ -624,38 +612,31 @@ void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
         c->launch_err = b;
     }
 }
-TGemmArgs mkx(const UGeo& g, const void* wp, int N, int K) {
+TGemmArgs mkx(const UGeo& g, const void* w, int N, int K) {
     TGemmArgs t;
     memset(&t, 0, sizeof t);
-    t.wp = wp; t.M = g.T; t.N = N; t.K = K; t.seg_rows = tm_seg(g);
+    t.w = w; t.M = g.T; t.N = N; t.K = K; t.seg_rows = tm_seg(g);
     t.gn_part_bs = g.sts; t.gn_nparts = g.np; t.stats_bs = g.sts; t.ldy = MC; t.ldr_tm = MC;
     return t;
-}
-// append a phase: 192 channels of `src` (row pitch ld) starting at column coff
-void xphase(TGemmArgs& t, const void* src, int ld, int coff, int mode, int taps, const float* part = nullptr, const float* gamma = nullptr,
-            const float* beta = nullptr) {
-    const int i = t.nph++;
-    t.pa[i] = src; t.pld[i] = ld; t.pcoff[i] = coff; t.pmode[i] = mode; t.ptaps[i] = taps; t.ppart[i] = part; t.pgamma[i] = gamma; t.pbeta[i] = beta;
 }
 void run_resblock_tm(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, const ActBuf& in0, const ActBuf* in1, const ActBuf& out, hipStream_t s, bool shared) {
     const int nb = shared ? g.Bc : g.Be;
     {   // in_layers: GN -> SiLU -> conv3 + emb term   (openaimodel.py:205-225)
-        TGemmArgs t = mkx(g, tw(c, rw.x_conv1, rw.xf_conv1), MC, 3 * rw.cin);
-        t.gn_cpg = rw.cin / 32; t.gn_eps = 1e-5f;
-        xphase(t, in0.t, MC, 0, 1, 3, in0.st, rw.g1, rw.b1);
-        if (in1) xphase(t, in1->t, MC, 0, 1, 3, in1->st, rw.g1 + MC, rw.b1 + MC);
+        TGemmArgs t = mkx(g, tw(c, rw.t_conv1, rw.tf_conv1), MC, 3 * rw.cin);
+        t.ra[0] = in0.t; t.ra[1] = in1 ? in1->t : nullptr; t.rmode = 1; t.rtaps = 3;
+        t.gn_part[0] = in0.st; t.gn_part[1] = in1 ? in1->st : nullptr; t.gn_cpg = rw.cin / 32; t.gn_eps = 1e-5f; t.gn_gamma = rw.g1; t.gn_beta = rw.b1;
         t.bias = rw.conv1.bias;
         t.emb = c->EO + (long long)rb_index * MC * c->maxNp; t.emb_pitch = c->maxNp; t.step_ptr = g.step_ptr; t.emb_b_stride = g.emb_b_stride;
         t.y_tm = c->M.t; t.stats = c->M.st;
         do_xgemm(c, t, nb, s);
     }
     {   // out_layers: GN -> SiLU -> conv3 ; + skip(x)   (openaimodel.py:226-227)
-        TGemmArgs t = mkx(g, tw(c, rw.x_conv2, rw.xf_conv2), MC, 3 * MC + (rw.has_skip ? 2 * MC : 0));
-        t.gn_cpg = 6; t.gn_eps = 1e-5f;
-        xphase(t, c->M.t, MC, 0, 1, 3, c->M.st, rw.g2, rw.b2);
-        if (rw.has_skip) {   // 1x1 conv over the concatenated raw input: two raw one-tap phases behind the convolution's
-            xphase(t, in0.t, MC, 0, 0, 1);
-            xphase(t, in1->t, MC, 0, 0, 1);
+        TGemmArgs t = mkx(g, tw(c, rw.t_conv2, rw.tf_conv2), MC, 3 * MC + (rw.has_skip ? 2 * MC : 0));
+        t.ra[0] = c->M.t; t.rmode = 1; t.rtaps = 3;
+        t.gn_part[0] = c->M.st; t.gn_cpg = 6; t.gn_eps = 1e-5f; t.gn_gamma = rw.g2; t.gn_beta = rw.b2;
+        if (rw.has_skip) {   // 1x1 conv over the concatenated raw input: two streamed K segments behind the resident one
+            t.sa[0] = in0.t; t.sld[0] = MC; t.sk[0] = MC;
+            t.sa[1] = in1->t; t.sld[1] = MC; t.sk[1] = MC;
             t.bias = rw.bias2;
         } else {
             t.bias = rw.conv2.bias;
@@ -675,9 +656,9 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
     const long long seg = tm_seg(g);
     const int vt_rows = rup(g.T, 32);
     {   // x = norm(x); q, k, v = to_{q,k,v}(norm1(x)) into attn.hip's operand layout   (attention.py:227, 168, 93-97)
-        TGemmArgs t = mkx(g, tw(c, sw.x_qkv, sw.xf_qkv), 3 * MC, MC);
-        t.gn_cpg = 6; t.gn_eps = 1e-6f;
-        xphase(t, in.t, MC, 0, 3, 1, in.st, sw.gn_g, sw.gn_b);
+        TGemmArgs t = mkx(g, tw(c, sw.t_qkv, sw.tf_qkv), 3 * MC, MC);
+        t.ra[0] = in.t; t.rmode = 3; t.rtaps = 1;
+        t.gn_part[0] = in.st; t.gn_cpg = 6; t.gn_eps = 1e-6f; t.gn_gamma = sw.gn_g; t.gn_beta = sw.gn_b;
         t.ln_gamma = sw.l1g; t.ln_beta = sw.l1b;
         t.qk = c->QK; t.vt = c->VT; t.v_bs = (long long)MC * g.Tp; t.qk_n = 2 * MC; t.head_dim = HD; t.rows = vt_rows; t.heads2 = 2 * HEADS; t.v_pitch = g.Tp;
         do_xgemm(c, t, n1, s);
@@ -691,8 +672,8 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
         do_attn(c, a, n1, HD, -4, s);
     }
     {   // x1 = to_out(attn) + GroupNorm(x_in)   (attention.py:127, 168); under guidance also x2 of the unconditional half = x1 + c2
-        TGemmArgs t = mkx(g, tw(c, sw.x_out1, sw.xf_out1), MC, MC);
-        xphase(t, c->tO, MC, 0, 0, 1);
+        TGemmArgs t = mkx(g, tw(c, sw.t_out1, sw.tf_out1), MC, MC);
+        t.sa[0] = c->tO; t.sld[0] = MC; t.sk[0] = MC;
         t.bias = sw.out1.bias;
         t.res_tm = in.t; t.res_gn = 1; t.res_part = in.st; t.res_gamma = sw.gn_g; t.res_beta = sw.gn_b; t.res_eps = 1e-6f; t.gn_cpg = 6;
         t.y_tm = c->tX1;
@@ -700,8 +681,8 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
         do_xgemm(c, t, n1, s);
     }
     {   // attn2: q = to_q(norm2(x1)); banded softmax over the precomputed audio K/V   (attention.py:170-191)
-        TGemmArgs t = mkx(g, tw(c, sw.x_q2, sw.xf_q2), MC, MC);
-        xphase(t, tm_at(c, c->tX1, x_off * seg, MC), MC, 0, 2, 1);
+        TGemmArgs t = mkx(g, tw(c, sw.t_q2, sw.tf_q2), MC, MC);
+        t.ra[0] = tm_at(c, c->tX1, x_off * seg, MC); t.rmode = 2; t.rtaps = 1;
         t.ln_gamma = sw.l2g; t.ln_beta = sw.l2b;
         const long long kvbs = (long long)NST * 2 * MC * g.Sp;
         t.band_k = c->KV + (long long)(blk * 2 * MC) * g.Sp + (long long)kv_off * kvbs;
@@ -712,25 +693,25 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
         do_xgemm(c, t, n2, s);
     }
     {   // x2 = to_out(attn2) + x1   (conditional half only under guidance: its rows are [Bc, 2 Bc) of X2)
-        TGemmArgs t = mkx(g, tw(c, sw.x_out2, sw.xf_out2), MC, MC);
-        xphase(t, tm_at(c, c->tO, x_off * seg, MC), MC, 0, 0, 1);
+        TGemmArgs t = mkx(g, tw(c, sw.t_out2, sw.tf_out2), MC, MC);
+        t.sa[0] = tm_at(c, c->tO, x_off * seg, MC); t.sld[0] = MC; t.sk[0] = MC;
         t.bias = sw.out2.bias;
         t.res_tm = tm_at(c, c->tX1, x_off * seg, MC);
         t.y_tm = tm_at(c, c->tX2, kv_off * seg, MC);
         do_xgemm(c, t, n2, s);
     }
     {   // GEGLU: proj(norm3(x2)) -> a * gelu(gate)   (attention.py:25-32)
-        TGemmArgs t = mkx(g, tw(c, sw.x_ff1, sw.xf_ff1), 2 * FFI, MC);
-        xphase(t, c->tX2, MC, 0, 2, 1);
+        TGemmArgs t = mkx(g, tw(c, sw.t_ff1, sw.tf_ff1), 2 * FFI, MC);
+        t.ra[0] = c->tX2; t.rmode = 2; t.rtaps = 1;
         t.ln_gamma = sw.l3g; t.ln_beta = sw.l3b;
         t.bias = sw.t_ff1_bias; t.geglu = 1;
         t.yb = c->tF; t.y_bs = seg * FFI; t.ldy = FFI;
         do_xgemm(c, t, g.Be, s);
     }
-    {   // proj_out o ff.net.2 over [h ; x2] + x_in   (attention.py:193, 232-234): five raw phases
-        TGemmArgs t = mkx(g, tw(c, sw.x_ffproj, sw.xf_ffproj), MC, FFI + MC);
-        for (int q = 0; q < FFI / MC; ++q) xphase(t, c->tF, FFI, q * MC, 0, 1);
-        xphase(t, c->tX2, MC, 0, 0, 1);
+    {   // proj_out o ff.net.2 over [h ; x2] + x_in   (attention.py:193, 232-234)
+        TGemmArgs t = mkx(g, tw(c, sw.t_ffproj, sw.tf_ffproj), MC, FFI + MC);
+        t.sa[0] = c->tF; t.sld[0] = FFI; t.sk[0] = FFI;
+        t.sa[1] = c->tX2; t.sld[1] = MC; t.sk[1] = MC;
         t.bias = sw.ffproj.bias;
         t.res_tm = in.t;
         if (last) { t.y_cm = out.p; t.cm_bs = g.hs; t.cm_pitch = g.Tp; t.stats = out.st; }
@@ -1362,17 +1343,6 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
                 if (sk) for (int cc = 0; cc < 2 * MC; ++cc) cat[n * Kc + 3 * MC + cc] = sk->data[(size_t)n * 2 * MC + cc];
             }
             if (upload_tm_pair(ctx, &rw.t_conv2, &rw.tf_conv2, cat.data(), MC, Kc, 1)) return -1;
-            if (upload_packed_pair(ctx, &rw.x_conv2, &rw.xf_conv2, cat.data(), MC, (int)Kc)) return -1;   // phases: [3 taps x 192 | 192 skip(in0) | 192 skip(in1)]
-            // conv1 for xgemm_kernel: K in PHASE order [source][tap][192 channels] (the Conv1d weight is [n][source * 192 + c][tap])
-            const HostTensor& c1w = ctx->host_w[p + ".in_layers.2.weight"];
-            const int nsrc = rw.cin / MC;
-            std::vector<float> ph((size_t)MC * 3 * rw.cin);
-            for (int n = 0; n < MC; ++n)
-                for (int sidx = 0; sidx < nsrc; ++sidx)
-                    for (int t = 0; t < 3; ++t)
-                        for (int cc = 0; cc < MC; ++cc)
-                            ph[(size_t)n * 3 * rw.cin + (size_t)sidx * 3 * MC + t * MC + cc] = c1w.data[((size_t)n * rw.cin + sidx * MC + cc) * 3 + t];
-            if (upload_packed_pair(ctx, &rw.x_conv1, &rw.xf_conv1, ph.data(), MC, 3 * rw.cin)) return -1;
         }
         const HostTensor* ew = getw(ctx, p + ".emb_layers.1.weight", {MC, TE});
         const HostTensor* eb = getw(ctx, p + ".emb_layers.1.bias", {MC});
@@ -1427,8 +1397,8 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
             const HostTensor* wq2 = getw(ctx, b + ".attn2.to_q.weight", {MC, MC});
             const HostTensor* w2 = getw(ctx, b + ".attn2.to_out.0.weight", {MC, MC});
             if (!w1 || !wq2 || !w2) return -1;
-            if (upload_packed_pair(ctx, &sw.x_out1, &sw.xf_out1, w1->data.data(), MC, MC) || upload_packed_pair(ctx, &sw.x_q2, &sw.xf_q2, wq2->data.data(), MC, MC) ||
-                upload_packed_pair(ctx, &sw.x_out2, &sw.xf_out2, w2->data.data(), MC, MC))
+            if (upload_tm_pair(ctx, &sw.t_out1, &sw.tf_out1, w1->data.data(), MC, MC, 1) || upload_tm_pair(ctx, &sw.t_q2, &sw.tf_q2, wq2->data.data(), MC, MC, 1) ||
+                upload_tm_pair(ctx, &sw.t_out2, &sw.tf_out2, w2->data.data(), MC, MC, 1))
                 return -1;
         }
         {   // attn2 output for the unconditional context (null_cond_emb repeated: every key / value identical, softmax
@@ -1486,7 +1456,6 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
             if (make_pw(ctx, &t0, "__ffproj.w0", "__ffproj.b", MC, FFI, 0) || make_pw(ctx, &t1, "__ffproj.w1", "", MC, MC, 0)) return -1;
             {   // tgemm.hip operands of this block: q/k/v rows, GEGLU rows tile-interleaved (value, gate), [P F2 | P]
                 if (upload_tm_pair(ctx, &sw.t_qkv, &sw.tf_qkv, qkv.data(), 3 * MC, MC, 1)) return -1;
-                if (upload_packed_pair(ctx, &sw.x_qkv, &sw.xf_qkv, qkv.data(), 3 * MC, MC)) return -1;
                 const HostTensor* f1 = getw(ctx, b + ".ff.net.0.proj.weight", {2 * FFI, MC});
                 const HostTensor* f1b = getw(ctx, b + ".ff.net.0.proj.bias", {2 * FFI});
                 if (!f1 || !f1b) return -1;
@@ -1497,7 +1466,6 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
                     pb[np] = f1b->data[src];
                 }
                 if (upload_tm_pair(ctx, &sw.t_ff1, &sw.tf_ff1, pw.data(), 2 * FFI, MC, 1) || upload(ctx, &sw.t_ff1_bias, pb.data(), pb.size())) return -1;
-                if (upload_packed_pair(ctx, &sw.x_ff1, &sw.xf_ff1, pw.data(), 2 * FFI, MC)) return -1;
                 const HostTensor& w0 = ctx->host_w["__ffproj.w0"];
                 const HostTensor& w1 = ctx->host_w["__ffproj.w1"];
                 std::vector<float> cat((size_t)MC * (FFI + MC));
@@ -1506,7 +1474,6 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
                     std::copy(w1.data.begin() + (size_t)n * MC, w1.data.begin() + (size_t)(n + 1) * MC, cat.begin() + (size_t)n * (FFI + MC) + FFI);
                 }
                 if (upload_tm_pair(ctx, &sw.t_ffproj, &sw.tf_ffproj, cat.data(), MC, FFI + MC, 1)) return -1;
-                if (upload_packed_pair(ctx, &sw.x_ffproj, &sw.xf_ffproj, cat.data(), MC, FFI + MC)) return -1;
             }
             PW& fp = sw.ffproj;
             fp.N = MC; fp.taps = 1; fp.nseg = 2; fp.bias = t0.bias;

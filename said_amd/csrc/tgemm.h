@@ -61,21 +61,21 @@ struct TGemmArgs {
     // bf16 mode, fp32 else), sample pitch seg_rows tokens (a multiple of 64, so a 64-row tile never straddles samples), plus
     // the producer's fp32 GroupNorm partials [sample][32-token tile][192][2].  Nothing prepares operands any more: the consuming
     // GEMM applies GroupNorm + SiLU / LayerNorm itself.
-    // -- the K axis is a sequence of up to five PHASES of 192 source channels each.  Per phase the workgroup's source tile — its 64
-    // tokens (+ 2 halo tokens for ptaps == 3) x 192 channels starting at column pcoff of the tensor pa (row pitch pld) — is loaded ONCE,
-    // transformed once per element and parked in LDS; the k loop over the phase (ptaps x 192 weights per output, tap-major) then runs
-    // without a barrier, its weights arriving as packed fragments straight from memory.  Examples: conv3 over concat([h, skip]) = two
-    // GroupNorm + SiLU phases; conv3 + 1x1 skip = one 3-tap phase + two raw 1-tap phases; [h (768) ; x2] = five raw phases.
-    int nph;
+    // -- resident first K segment (ra[0] != null): the workgroup's source tile — 64 tokens (+ 2 halo tokens for taps == 3) x 192
+    // channels of ra[0], then of ra[1] (concatenated input) — is loaded ONCE, transformed once per element and parked in LDS;
+    // only the weights stream.  k order of W for this segment: [tap][source][channel] (Conv1d weight, tap-major).
     int ntw;               // column tiles per workgroup (0: chosen by launch_xgemm)
-    const void* pa[5]; int pld[5]; int pcoff[5];
-    int pmode[5];          // 0: raw, 1: silu(GroupNorm(x)), 2: LayerNorm(x), 3: LayerNorm(GroupNorm(x))
-    int ptaps[5];          // 1, or 3: output token t reads tokens t - 1 + tap, zero outside [0, M)
-    const float* ppart[5]; const float* pgamma[5]; const float* pbeta[5];   // GroupNorm partials / affine of a phase's 192 channels
+    const void* ra[2];     // sources (row pitch 192), or null
+    int rmode;             // 0: raw, 1: silu(GroupNorm(x)), 2: LayerNorm(x), 3: LayerNorm(GroupNorm(x))
+    int rtaps;             // 1, or 3: output token t reads tokens t - 1 + tap, zero outside [0, M)
+    const float* gn_part[2];       // GroupNorm partials of ra[0] / ra[1]
     long long gn_part_bs;
     int gn_cpg, gn_nparts; float gn_eps;
+    const float* gn_gamma; const float* gn_beta;     // [192 per source]
     const float* ln_gamma; const float* ln_beta;     // [192]
-    const void* wp;        // weights in MFMA operand order (tgemm_pack_weights): [N / 32][K / step][64 lanes][16 bytes], K in phase order
+    // -- streamed raw K segments AFTER the resident one (or the whole K when ra[0] == null): up to three sources, source i holding
+    // sk[i] channels with row pitch sld[i]; row R (= sample * seg_rows + token) of source i starts at sa[i] + R * sld[i]
+    const void* sa[3]; int sld[3]; int sk[3];
     // -- token-major activation epilogue (y_tm != null): y_tm[R][n] (ET, row pitch ldy) = acc + bias + emb + residual; `stats` then
     // receives the GroupNorm partials of the STORED (rounded) values
     void* y_tm;
@@ -97,10 +97,6 @@ bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s);   // N % 128 ==
 void configure_tgemm_kernel();
 // GEMMs on token-major activations with the operand transform inside (TGemmArgs fields of round 3)
 bool xgemm_supports(const TGemmArgs& a);
-// host: W [N][K] (K contiguous, fp32) -> MFMA operand order for xgemm_kernel; bf16: 16-k steps, lane l = row 32 jt + (l & 31), elements
-// k = 16 s + 8 (l >> 5) + 0..7 rounded to bf16; fp32: 8-k steps, k = 8 s + 4 (l >> 5) + 0..3.  N % 32 == 0, K % 16 == 0.
-void tgemm_pack_weights(const float* W, int N, int K, bool bf16, void* out);
-size_t tgemm_packed_bytes(int N, int K, bool bf16);
 bool launch_xgemm(const TGemmArgs& a, int batch, hipStream_t s);
 // UNet operand preparation (bf16 mode, large batches): channel-major fp32 x[b][C][pitch] -> transform -> token-major bf16.
 // mode 0: silu(GroupNorm(x)) into dst[b][1 + t][ldd] at column `coff` (rows 0 and T + 1 zero: Conv1d padding), mode 1:

@@ -16,7 +16,6 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -50,13 +49,15 @@ constexpr int TBM = 128, TBN = 128, TBK = 64, TLP = 72;   // tile, LDS row pitch
 // ------------------------------------------------------------------------------------------------------------------
 // (J0, NJE): the epilogue covers column tiles J0 .. J0 + NJE - 1 of the wave's NJ accumulator tiles, n0w = first column of tile J0
 // (fgemm_kernel splits a tile's epilogue between the two K-half waves).
-// round 3 (token-major activations, xgemm_kernel): `res_tm` adds a token-major residual in phase 1 (optionally GroupNorm'ed with the
-// per-channel coefficients coefR[2 n], coefR[2 n + 1] in LDS), `y_tm` selects the token-major activation destination: values are
-// rounded to the element type in phase 1, the GroupNorm partials of the ROUNDED values are taken there too (lane == column: 16
-// rows in registers + the other lane half), and phase 2c stores 8 consecutive columns per lane.
-template <int NJ, int J0 = 0, int NJE = NJ>
+// round 3 (xgemm_kernel): `res_tm` adds a token-major residual in phase 1 (EK == 3 only; the token-major activation destination has
+// its own all-wave epilogue inside xgemm_kernel).
+// EK (xgemm_kernel): the epilogue kind is a compile-time constant there, so the paths a launch cannot take cost it no registers —
+// -1: any (the round-2 kernels), 1: q/k/v split, 2: GEGLU, 3: channel-major fp32 result (+ token-major residual).
+template <int NJ, int J0 = 0, int NJE = NJ, int EK = -1>
 __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ], int b_grid, int rt, int n0w, int l, float* sc,
                                             const float* coefR = nullptr) {
+    constexpr bool ANY = EK < 0, P_CM = ANY || EK == 1 || EK == 3, P_BF = ANY || EK == 2, P_GEN = ANY || EK == 1 || EK == 2,
+                   P_RES = EK == 3, P_GEGLU = ANY || EK == 2;
     constexpr int CW = 32 * NJE, CP = CW + 4;   // columns of this call, scratch row pitch (floats)
     const int lh = l >> 5, lc = l & 31;
     if (a.seg_rows > 0 && rt >= a.batch * a.seg_rows) return;   // row tile past the last sample (wave-uniform)
@@ -69,9 +70,8 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
     }
     const int nrows = min(32, a.M - mt);
     const long long R0 = (long long)b * a.seg_rows + mt;   // global row of the tile's first token (token-major activation tensors)
-    const bool tm_out = a.y_tm != nullptr;
     // ---- phase 1: registers -> scratch, elementwise work where lane == column
-    const bool geglu = a.geglu != 0;
+    const bool geglu = P_GEGLU && a.geglu != 0;
     constexpr int NJO = NJE;   // (GEGLU writes NJ / 2 column tiles; the scratch keeps the full pitch)
 #pragma unroll
     for (int j = 0; j < NJE; ++j) {
@@ -82,42 +82,22 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
         if (geglu) gadd = a.bias ? a.bias[n + 32] : 0.f;
         if (a.emb) add += a.emb[(long long)n * a.emb_pitch + (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride];
         const int col = geglu ? (j >> 1) * 32 + lc : j * 32 + lc;
-        float rca = 1.f, rcb = 0.f;
-        if (a.res_tm && a.res_gn) { rca = coefR[2 * n]; rcb = coefR[2 * n + 1]; }
-        float vals[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
             float v = acc[J0 + j][r] + add;
-            if (a.res_tm && !(a.dbg & 4)) {   // token-major residual: lanes = 32 consecutive channels of one row
-                const long long ro = (R0 + min(row, nrows - 1)) * a.ldr_tm + n;
-                const float rv = a.f32 ? reinterpret_cast<const float*>(a.res_tm)[ro] : (float)reinterpret_cast<const __bf16*>(a.res_tm)[ro];
-                v += fmaf(rv, rca, rcb);
+            if constexpr (P_RES) {
+                if (a.res_tm) {   // token-major residual (the one launch per step that feeds the channel-major `out` convolution)
+                    const long long ro = (R0 + min(row, nrows - 1)) * a.ldr_tm + n;
+                    v += a.f32 ? reinterpret_cast<const float*>(a.res_tm)[ro] : (float)reinterpret_cast<const __bf16*>(a.res_tm)[ro];
+                }
             }
             if (geglu) {
                 if constexpr (NJE % 2 == 0 && J0 % 2 == 0) v *= gelu_f(acc[J0 + (j + 1) % NJE][r] + gadd);
             } else if (a.act == 1) {
                 v = gelu_f(v);
             }
-            if (tm_out && !a.f32) v = (float)(__bf16)v;   // what the consumers will read
-            vals[r] = v;
             sc[row * CP + col] = v;
-        }
-        if (tm_out && a.stats) {   // Welford partial of channel n over this tile's rows (of the stored values)
-            float sum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sum += ((r & 3) + 8 * (r >> 2) + 4 * lh < nrows) ? vals[r] : 0.f;
-            sum += __shfl_xor(sum, 32);
-            const float mean = sum / (float)nrows;
-            float m2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float d = ((r & 3) + 8 * (r >> 2) + 4 * lh < nrows) ? vals[r] - mean : 0.f; m2 = fmaf(d, d, m2); }
-            m2 += __shfl_xor(m2, 32);
-            if (lh == 0) {
-                float* so = a.stats + (long long)b * a.stats_bs + ((long long)(mt >> 5) * a.N + n) * 2;   // [tile][channel][2]
-                so[0] = mean;
-                so[1] = m2;
-            }
         }
     }
     (void)NJO;
@@ -125,7 +105,7 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
     const int cw = geglu ? CW / 2 : CW;                 // live columns in the scratch
     const int n_first = geglu ? a.geglu_c0(n0w) : n0w;   // first destination column
     const bool v_rows = a.qk && n0w >= a.qk_n;          // this wave holds v columns (channel-major) of a q/k/v projection
-    if (a.y_cm || v_rows) {
+    if (P_CM && (a.y_cm || v_rows)) {
         // ---- phase 2b: channel-major destination: lane -> (channel l >> 3 of the pass, token quad l & 7)
         const int tq = l & 7;
         const int pitch = a.y_cm ? a.cm_pitch : a.v_pitch;
@@ -167,45 +147,7 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
                 }
             }
         }
-    } else if (tm_out) {
-        // ---- phase 2c: token-major ACTIVATION destination (element type ET): lane -> 8 consecutive columns of a row
-        const int lanes_per_row = cw / 8;                // 16 or 12
-        const int rows_pp = 64 / lanes_per_row;          // 4 or 5 (60 lanes active)
-        const int rr = l / lanes_per_row, cq = l - rr * lanes_per_row;
-        const bool lane_on = rr < rows_pp;
-        const int n = n_first + 8 * cq;
-        float add2[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) add2[e] = (a.y2_tm && a.y2_add && lane_on) ? a.y2_add[n + e] : 0.f;
-        for (int r0 = 0; r0 < nrows; r0 += rows_pp) {
-            const int row = r0 + rr;
-            if (!lane_on || row >= nrows) continue;
-            const f32x4t v0 = *reinterpret_cast<const f32x4t*>(sc + row * CP + 8 * cq);
-            const f32x4t v1 = *reinterpret_cast<const f32x4t*>(sc + row * CP + 8 * cq + 4);
-            const long long o = (R0 + row) * a.ldy + n;
-            if (a.f32) {
-                float* y = reinterpret_cast<float*>(a.y_tm) + o;
-                *reinterpret_cast<f32x4t*>(y) = v0;
-                *reinterpret_cast<f32x4t*>(y + 4) = v1;
-                if (a.y2_tm) {
-                    float* y2 = reinterpret_cast<float*>(a.y2_tm) + o + a.y2_row_off * a.ldy;
-                    const f32x4t w0 = {v0[0] + add2[0], v0[1] + add2[1], v0[2] + add2[2], v0[3] + add2[3]};
-                    const f32x4t w1 = {v1[0] + add2[4], v1[1] + add2[5], v1[2] + add2[6], v1[3] + add2[7]};
-                    *reinterpret_cast<f32x4t*>(y2) = w0;
-                    *reinterpret_cast<f32x4t*>(y2 + 4) = w1;
-                }
-            } else {
-                typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
-                const bf16x8s ov = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3], (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
-                *reinterpret_cast<bf16x8s*>(reinterpret_cast<__bf16*>(a.y_tm) + o) = ov;
-                if (a.y2_tm) {
-                    const bf16x8s o2 = {(__bf16)(v0[0] + add2[0]), (__bf16)(v0[1] + add2[1]), (__bf16)(v0[2] + add2[2]), (__bf16)(v0[3] + add2[3]),
-                                        (__bf16)(v1[0] + add2[4]), (__bf16)(v1[1] + add2[5]), (__bf16)(v1[2] + add2[6]), (__bf16)(v1[3] + add2[7])};
-                    *reinterpret_cast<bf16x8s*>(reinterpret_cast<__bf16*>(a.y2_tm) + o + a.y2_row_off * a.ldy) = o2;
-                }
-            }
-        }
-    } else if (a.yb && !a.yf && !a.qk && !a.res && !a.n_store) {
+    } else if (P_BF && a.yb && !a.yf && !a.qk && !a.res && !a.n_store) {
         // ---- phase 2a', bf16-only token-major destination (GEGLU product, the audio encoder's conv / FFN activations): lane -> 8
         // consecutive columns = one 16-byte store (8-byte stores run at 0.54-0.70x the 16-byte rate)
         typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
@@ -221,7 +163,7 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
             const bf16x8s o = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3], (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
             *reinterpret_cast<bf16x8s*>(reinterpret_cast<__bf16*>(a.yb) + (long long)b * a.y_bs + (long long)(mt + row) * a.ldy + n_first + 8 * cq) = o;
         }
-    } else {
+    } else if (P_GEN) {
         // ---- phase 2a: token-major destination: lane -> 4 consecutive columns of a row; rows_pp rows per pass
         const int lanes_per_row = cw / 4;                // 32, 24, 16 or 8
         const int rows_pp = 64 / lanes_per_row;          // 2, 2 (48 lanes active), 4 or 8
@@ -712,6 +654,12 @@ __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
 // Workgroup, wave roles (2 row halves x 2 K halves), k-tile geometry and the K-half exchange are fgemm_kernel's.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int XRR = 66;                       // resident rows: 64 tokens + 2 halo
+#ifndef XG_OCC_RS
+#define XG_OCC_RS 2
+#endif
+#ifndef XG_OCC_SS
+#define XG_OCC_SS 3
+#endif
 template <bool BF> __host__ __device__ constexpr int x_rp_bytes() { return 192 * (BF ? 2 : 4) + 16; }   // resident row pitch: 400 / 784 bytes (conflict-free 16-byte fragment reads)
 constexpr int X_COEF_BYTES = 2 * 192 * 4;     // GroupNorm (a, b) of ONE 192-channel source at a time; after the prologue the region carries the
                                               // epilogue's statistics exchange (a kernel never needs both at once)
@@ -795,32 +743,39 @@ __device__ __forceinline__ void band_head(const TGemmArgs& a, const f32x16& q, i
     }
 }
 
-template <int NJ, bool BF, bool TR, int OCC>
+template <int NJ, bool BF, bool RS, bool SS, bool TR, int EK, int OCC>
 __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // exchange / transposition scratch | coefficients & statistics | resident tile
+    static_assert(RS || SS, "a GEMM needs an operand");
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [stream A 64 rows | W BN rows] x 144 bytes | coefficients | resident tile
     float* const ldsf = reinterpret_cast<float*>(lds);
     typedef typename std::conditional<BF, unsigned short, float>::type elt_t;
     constexpr int EPC = BF ? 8 : 4;              // elements per 16-byte chunk
-    constexpr int FBK = 8 * EPC;                 // k per k-tile (128 bytes of a row): four MFMA operand steps of 2 EPC
-    constexpr int CT = 192 / FBK;                // k-tiles per tap of a phase (3 bf16, 6 fp32)
+    constexpr int FBK = 8 * EPC, FLP = 9 * EPC;  // k per tile (128 bytes), LDS row pitch of the streamed tiles (144 bytes), in elements
+    constexpr int CT = 192 / FBK;                // k-tiles per source and tap of the resident segment (3 bf16, 6 fp32)
     constexpr int RP = x_rp_bytes<BF>() / (int)sizeof(elt_t);   // resident row pitch in elements
+    elt_t* const ldse = reinterpret_cast<elt_t*>(lds);
     float* const coefS = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + fgemm_lds_bytes<NJ>());
     elt_t* const ares = reinterpret_cast<elt_t*>(reinterpret_cast<char*>(lds) + fgemm_lds_bytes<NJ>() + X_COEF_BYTES);
-    constexpr int BM = 64, BN = 32 * NJ;
+    constexpr int BM = 64, BN = 32 * NJ, NTH = 256;
+    constexpr int ACH = BM * 8 / NTH, WCH = BN * 8 / NTH;   // 16-byte chunks per thread and tile: 2, NJ
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int wr = w & 1, kh = w >> 1;
     const int rows_tot = a.batch * a.seg_rows;
-    const int ntw = a.ntw > 0 ? a.ntw : 1;
-    const int NT = a.N / (BN * ntw), MT = rows_tot / BM;   // seg_rows % 64 == 0 (host-checked): a tile never straddles samples
+    const int NT = a.N / (BN * (a.ntw > 0 ? a.ntw : 1)), MT = rows_tot / BM;   // seg_rows % 64 == 0 (host-checked): a tile never straddles samples
     const unsigned L = blockIdx.x, xcd = L & 7u, slot = L >> 3;   // XCD-aware order, as in tgemm_kernel
     const int nt = (int)(slot % (unsigned)NT);
     const int mg = (int)(slot / (unsigned)NT) * 8 + (int)xcd;
     if (mg >= MT) return;
-    const int m0 = mg * BM, n0 = nt * BN * ntw;
+    const int m0 = mg * BM, n0 = nt * BN * (a.ntw > 0 ? a.ntw : 1);
     const int b = m0 / a.seg_rows, t0 = m0 - b * a.seg_rows;
     if (t0 >= a.M) return;                                    // a tile of padding tokens only
-    const int nph = a.nph;
-    const int nstep_tot = a.K / (2 * EPC);                    // MFMA operand steps along K (16 bf16 / 8 fp32 each)
+    const elt_t* W = reinterpret_cast<const elt_t*>(a.w);
+    const int nsrc = RS ? (a.ra[1] ? 2 : 1) : 0;
+    const int ntap = RS ? a.rtaps : 0;
+    const int nkr = ntap * nsrc * CT;                          // resident k-tiles
+    const int nk = a.K / FBK;
+    const int nst = nk - nkr;                                  // streamed k-tiles
+    const int sk0 = a.sk[0] / FBK, sk1 = a.sk[1] / FBK;
 
     // ---- GroupNorm coefficients from a producer's partials -> coefS (4 waves x 48 channels; per-wave scratch inside the tile area,
     // which is idle at both call sites: kernel entry, and the source switch of a concatenated input)
@@ -832,23 +787,23 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
         gn_finish(gp, rp, w * 48, 48, l, gl, ldsf + w * GN_SCRATCH, coefS);
         __syncthreads();
     };
+    if (!RS && a.res_gn) gn_coefs(a.res_part, a.res_eps, a.res_gamma, a.res_beta);
     // ---- resident tile of source `ph`: 8 threads per row (24 channels each), 32 rows per pass; a convolution's two halo rows
     // (resident rows 64, 65) by the first 16 threads in a third pass.  Few live registers on purpose: this prologue must not
     // cost the k loop its occupancy.
     auto load_resident = [&](int ph) {
-        const int rmode = a.pmode[ph];
-        if (rmode == 1 || rmode == 3) gn_coefs(a.ppart[ph], a.gn_eps, a.pgamma[ph], a.pbeta[ph]);
-        const elt_t* src = reinterpret_cast<const elt_t*>(a.pa[ph]) + a.pcoff[ph];
-        const int ld = a.pld[ph];
-        const int halo = a.ptaps[ph] == 3 ? 1 : 0;
+        if (a.rmode == 1 || a.rmode == 3) gn_coefs(a.gn_part[ph], a.gn_eps, a.gn_gamma + ph * 192, a.gn_beta + ph * 192);
+        const elt_t* src = reinterpret_cast<const elt_t*>(a.ra[ph]);
+        const int halo = a.rtaps == 3 ? 1 : 0;
         const int q8 = tid & 7;
         const float* cf = coefS + 48 * q8;
+#pragma unroll 1
         for (int pass = 0; pass < 2 + halo; ++pass) {
             const int r = pass * 32 + (tid >> 3);
             if (pass == 2 && tid >= 16) break;
             const int tt = t0 + r - halo;
             const bool valid = tt >= 0 && tt < a.M;
-            const elt_t* p = src + ((long long)b * a.seg_rows + min(max(tt, 0), a.M - 1)) * ld + 24 * q8;
+            const elt_t* p = src + ((long long)b * a.seg_rows + min(max(tt, 0), a.M - 1)) * 192 + 24 * q8;
             float x[24];
             if constexpr (BF) {
                 u32x4 raw[3];
@@ -870,15 +825,15 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[4 * i + e] = raw[i][e];
             }
-            if (rmode == 1 || rmode == 3) {
+            if (a.rmode == 1 || a.rmode == 3) {
 #pragma unroll
                 for (int i = 0; i < 24; ++i) x[i] = fmaf(x[i], cf[2 * i], cf[2 * i + 1]);
             }
-            if (rmode == 1) {
+            if (a.rmode == 1) {
 #pragma unroll
                 for (int i = 0; i < 24; ++i) x[i] = silu_f(x[i]);
             }
-            if (rmode >= 2) {   // LayerNorm over the row's 192 channels: sums over this thread's 24, then over the row's eight threads
+            if (a.rmode >= 2) {   // LayerNorm over the row's 192 channels: sums over this thread's 24, then over the row's eight threads
                 const float ref = __shfl(x[0], l & ~7);
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -916,26 +871,39 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
         }
     };
 
-
-    if (a.res_gn && nph == 1 && a.pmode[0] == 0) gn_coefs(a.res_part, a.res_eps, a.res_gamma, a.res_beta);
-
-    // ---- weights: packed on the host in MFMA operand order, wp[column tile][operand step][lane][16 bytes] — a wave's fragment is ONE
-    // coalesced 1 KB read straight into registers: no LDS staging, no barrier in the k loop (the source tile is already in LDS).
-    // k-tile g of the sequence (phases in order, tap-major inside a phase) = operand steps 4 g .. 4 g + 3; K half kh takes 2 kh, 2 kh + 1.
-    const f32x4t* const wpv = reinterpret_cast<const f32x4t*>(a.wp);
-    f32x4t wc[2][NJ], wn[2][NJ];   // current / next k-tile's fragments: [operand step of the K half][column tile]
-    auto wload = [&](int jn, int g) {
-        const long long cbase = (long long)((n0 >> 5) + jn * NJ) * nstep_tot;
+    // ---- k-tile pipeline: weights always, streamed A tiles when SS
+    f32x4t ra_[ACH], rw[WCH];
+    int woff[WCH], lwoff[WCH], loff[ACH], arow[ACH], akp[ACH];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+    for (int i = 0; i < ACH; ++i) {
+        const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
+        arow[i] = min(m0 + row, rows_tot - 1);
+        akp[i] = kp * EPC;
+        loff[i] = row * FLP + kp * EPC;
+    }
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) wn[ks][j] = wpv[((cbase + (long long)j * nstep_tot) + (4 * g + 2 * kh + ks)) * 64 + l];
+    for (int i = 0; i < WCH; ++i) {
+        const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
+        woff[i] = (n0 + row) * a.K + kp * EPC;
+        lwoff[i] = BM * FLP + row * FLP + kp * EPC;
+    }
+    // W k-offset of tile kt: the resident segment runs source-major ([source][tap][channel tile]) over a tap-major weight
+    auto wk_of = [&](int kt) -> int {
+        if (RS && kt < nkr) {
+            const int per = ntap * CT;
+            const int ph = kt / per, rem = kt - ph * per;
+            const int tap = rem / CT, ct = rem - tap * CT;
+            return tap * (nsrc * 192) + ph * 192 + ct * FBK;
+        }
+        return kt * FBK;
     };
-    auto wshift = [&]() {
+    auto lds_store = [&](const f32x4t* xa, const f32x4t* xw) {
+        if constexpr (SS) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4t*>(ldse + loff[i]) = xa[i];
+        }
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) wc[ks][j] = wn[ks][j];
+        for (int i = 0; i < WCH; ++i) *reinterpret_cast<f32x4t*>(ldse + lwoff[i]) = xw[i];
     };
     f32x16 acc[NJ];
 #pragma unroll
@@ -943,61 +911,93 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int frow = l & 31, fk = EPC * (l >> 5) + 4 * EPC * kh;
+    const elt_t* const pa_s = ldse + (wr * 32 + frow) * FLP + fk;
     const elt_t* const pa_r = ares + (wr * 32 + frow) * RP + fk;
-    auto compute = [&](int tap, int ct) {
-        const elt_t* pa = pa_r + tap * RP + ct * FBK;
+    const elt_t* const pw = ldse + BM * FLP + frow * FLP + fk;
+    auto compute = [&](int kt) {
+        const elt_t* pa = pa_s;
+        if (RS && kt < nkr) {
+            const int rem = kt % (ntap * CT);
+            const int tap = rem / CT, ct = rem - tap * CT;
+            pa = pa_r + tap * RP + ct * FBK;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if constexpr (BF) {
                 const bf16x8 fa = *reinterpret_cast<const bf16x8*>(pa + ks * 16);
+                bf16x8 fb[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(pw + j * 32 * FLP + ks * 16);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const bf16x8 fb = __builtin_bit_cast(bf16x8, wc[ks][j]);
-                    if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, acc[j], 0, 0, 0);
-                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
+                    if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa, acc[j], 0, 0, 0);
+                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[j], 0, 0, 0);
                 }
             } else {
                 const f32x4t fa = *reinterpret_cast<const f32x4t*>(pa + ks * 8);
+                f32x4t fb[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const f32x4t*>(pw + j * 32 * FLP + ks * 8);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[ks][j][i], fa[i], acc[j], 0, 0, 0);
-                        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], wc[ks][j][i], acc[j], 0, 0, 0);
+                        if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][i], fa[i], acc[j], 0, 0, 0);
+                        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j][i], acc[j], 0, 0, 0);
                     }
             }
         }
     };
+    // The workgroup walks over `ntw` consecutive column tiles with its resident source tile (the prologue — GroupNorm finalisation,
+    // tile load, transform, LayerNorm — is paid once per ntw x 32 NJ output columns instead of once per column tile: with one
+    // column tile per workgroup the 12 workgroups of a GEGLU row tile each repeated it, 163 us per launch against 71 for round
+    // 2's GEMM + 19 for its preparation kernel).  (column tile, k-tile) pairs form ONE sequence of steps through the k-tile
+    // pipeline: request the next step's tile -> multiply the tile in LDS -> barrier -> [last k-tile of a column tile: add the K
+    // halves, epilogue] -> park the next tile -> barrier.  The next column tile's first weights are in flight during the epilogue.
+    const int ntw = RS ? (a.ntw > 0 ? a.ntw : 1) : 1;   // (streamed-only GEMMs have no prologue to amortise)
+    const int nsteps = ntw * nk;
+    const int e0 = (RS && nsrc == 2) ? ntap * CT : -1;   // a concatenated input (ntw == 1): the second source takes the resident buffer over
     constexpr int NJ0 = (NJ == 4 && !TR) ? 2 : NJ, NJ1 = NJ - NJ0;
     float* const xr = ldsf + wr * (NJ1 > 0 ? NJ * 16 * 64 : 32 * (32 * NJ + 4));
-    const int nk = a.K / FBK;                                  // k-tiles of one column tile
-
-    // The workgroup walks over `ntw` consecutive column tiles.  With ONE phase the resident tile is loaded once and serves them all
-    // (the prologue — GroupNorm finalisation, tile load, transform, LayerNorm — is paid once per row tile); with several phases
-    // (concatenated inputs, the 1x1 skip behind a convolution, [h ; x2]) every column tile re-walks them.
-    wload(0, 0);
-    wshift();
-    if (nph == 1) { if (!(a.dbg & 8)) load_resident(0); __syncthreads(); }
-    for (int jn = 0; jn < ntw; ++jn) {
-        int g = 0;                                             // k-tile index within the column tile
-        for (int ph = 0; ph < nph; ++ph) {
-            if (nph > 1) {
-                if (ph > 0) __syncthreads();                   // every wave is done with the previous phase's tile
-                load_resident(ph);
-                __syncthreads();
-            }
-            const int nkp = a.ptaps[ph] * CT;                  // k-tiles of this phase: tap-major
-            for (int gl = 0; gl < nkp; ++gl, ++g) {
-                // request the next k-tile's weights (behind the last one: the next column tile's first), multiply this one's: no barrier
-                const bool last = g == nk - 1;
-                wload(last ? min(jn + 1, ntw - 1) : jn, last ? 0 : g + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                const int tap = CT == 3 ? (gl * 43) >> 7 : (gl * 43) >> 8;   // gl / CT for gl < 64
-                compute(tap, gl - tap * CT);
-                __builtin_amdgcn_sched_barrier(0);
-                wshift();
-            }
+    auto gload_step = [&](int step) {
+        const int jn = step / nk, kt = step - jn * nk;
+        const int wk = wk_of(kt) + jn * BN * a.K;
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) rw[i] = *reinterpret_cast<const f32x4t*>(W + (woff[i] + wk));
+        if constexpr (SS) {
+            const int st = min(max(kt - nkr, 0), nst - 1);        // (resident steps re-request the first streamed tile: an L1 hit)
+            const elt_t* base; int ld, off;
+            if (st < sk0) { base = reinterpret_cast<const elt_t*>(a.sa[0]); ld = a.sld[0]; off = st * FBK; }
+            else if (st < sk0 + sk1) { base = reinterpret_cast<const elt_t*>(a.sa[1]); ld = a.sld[1]; off = (st - sk0) * FBK; }
+            else { base = reinterpret_cast<const elt_t*>(a.sa[2]); ld = a.sld[2]; off = (st - sk0 - sk1) * FBK; }
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) ra_[i] = *reinterpret_cast<const f32x4t*>(base + ((long long)arow[i] * ld + off + akp[i]));
         }
+    };
+    gload_step(0);
+    if constexpr (RS) { if (!(a.dbg & 8)) load_resident(0); }
+    lds_store(ra_, rw);
+    __syncthreads();
+    const int nk_loop = (a.dbg & 2) ? 1 : nk;   // (timing experiment: no k loop)
+    for (int jn = 0; jn < ntw; ++jn) {
+        const int s0 = jn * nk;
+        // all k-tiles but the last: request the next tile -> multiply -> barrier -> park the next tile -> barrier
+        for (int kt = 0; kt < nk_loop - 1; ++kt) {
+            gload_step(s0 + kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(kt);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (kt == e0 - 1) load_resident(1);   // all waves are done with the first source's tile (concatenated input)
+            lds_store(ra_, rw);
+            __syncthreads();
+        }
+        // last k-tile: the NEXT column tile's first weights are requested and stay in registers through the epilogue
+        if constexpr (RS) gload_step(min(s0 + nk, nsteps - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        compute(nk - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
         // ---- add the two K halves (fgemm_kernel's exchange), then the epilogue of column tile jn
         const int n0j = n0 + jn * BN;
 #pragma unroll
@@ -1029,9 +1029,9 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
         } else if constexpr (NJ1 > 0) {
             __syncthreads();
             float* sc = ldsf + w * (32 * (32 * NJ0 + 4));
-            if (kh == 0) tg_epilogue<NJ, 0, NJ0>(a, acc, 0, m0 + wr * 32, n0j, l, sc, coefS);
-            else tg_epilogue<NJ, NJ0, (NJ1 > 0 ? NJ1 : 1)>(a, acc, 0, m0 + wr * 32, n0j + 32 * NJ0, l, sc, coefS);
-        } else if (a.y_tm) {
+            if (kh == 0) tg_epilogue<NJ, 0, NJ0, EK>(a, acc, 0, m0 + wr * 32, n0j, l, sc, coefS);
+            else tg_epilogue<NJ, NJ0, (NJ1 > 0 ? NJ1 : 1), EK>(a, acc, 0, m0 + wr * 32, n0j + 32 * NJ0, l, sc, coefS);
+        } else if constexpr (EK == 0) {
             // ---- token-major activation epilogue on ALL FOUR waves.  (Run by the two K-half-0 waves alone, with the residual gathered
             // in the MFMA layout — 2-byte loads, lane == column — it was 40-60 % of these kernels: knock-outs, profiles/r03_*.)
             // phase 1 (K-half-0 waves, lane == column): acc + bias + timestep-embedding term -> scratch [32 rows][CW + 4] of this row half
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
         } else {
             if (kh == 0) {
                 __builtin_amdgcn_wave_barrier();
-                tg_epilogue<NJ>(a, acc, 0, m0 + wr * 32, n0j, l, xr, coefS);
+                tg_epilogue<NJ, 0, NJ, EK>(a, acc, 0, m0 + wr * 32, n0j, l, xr, coefS);
             }
         }
         if (jn + 1 < ntw) {
@@ -1153,7 +1153,9 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-            __syncthreads();   // the scratch area is free again
+            __syncthreads();   // the tile area served as exchange / transposition scratch
+            lds_store(ra_, rw);
+            __syncthreads();
         }
     }
 }
@@ -1281,79 +1283,71 @@ bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
 
 // ---- host side of xgemm_kernel ---------------------------------------------------------------------------------------
 bool xgemm_supports(const TGemmArgs& a) {
+    const int fbk = a.f32 ? 32 : 64;
     if (a.seg_rows <= 0 || a.seg_rows % 64 || a.M < 1 || a.M > a.seg_rows) return false;
     if (!(a.N % 96 == 0 || a.N % 128 == 0)) return false;
     if (a.geglu && a.N % 256) return false;
-    if (a.nph < 1 || a.nph > 5 || !a.wp) return false;
-    int k = 0;
-    for (int i = 0; i < a.nph; ++i) {
-        if (!a.pa[i] || (a.ptaps[i] != 1 && a.ptaps[i] != 3) || a.pmode[i] < 0 || a.pmode[i] > 3) return false;
-        if (a.pld[i] % (a.f32 ? 4 : 8) || a.pcoff[i] % (a.f32 ? 4 : 8) || a.pcoff[i] + 192 > a.pld[i]) return false;
-        if ((a.pmode[i] == 1 || a.pmode[i] == 3) && (!a.ppart[i] || !a.pgamma[i] || !a.pbeta[i])) return false;
-        if (a.pmode[i] >= 2 && (a.nph != 1 || !a.ln_gamma || !a.ln_beta)) return false;
-        k += a.ptaps[i] * 192;
+    int kres = 0;
+    if (a.ra[0]) {
+        if (a.rtaps != 1 && a.rtaps != 3) return false;
+        if (a.rmode < 0 || a.rmode > 3) return false;
+        if ((a.rmode == 1 || a.rmode == 3) && (!a.gn_part[0] || !a.gn_gamma || !a.gn_beta || (a.ra[1] && !a.gn_part[1]))) return false;
+        if (a.rmode >= 2 && (a.ra[1] || !a.ln_gamma || !a.ln_beta)) return false;
+        kres = a.rtaps * (a.ra[1] ? 384 : 192);
     }
-    if (k != a.K) return false;
-    if (a.band_k && (a.N % 96 || a.nph != 1 || !a.y_tm || !a.band_lo || !a.band_hi || a.band_wmax < 1 || a.band_wmax > 8)) return false;
-    if (a.res_gn && (!a.res_tm || !a.res_part || !a.res_gamma || !a.res_beta || a.nph != 1 || a.pmode[0] != 0 || a.stats)) return false;
+    int kst = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (a.sk[i] < 0 || a.sk[i] % fbk) return false;
+        if (a.sk[i] > 0 && (!a.sa[i] || a.sld[i] % (a.f32 ? 4 : 8))) return false;
+        if (i > 0 && a.sk[i] > 0 && a.sk[i - 1] == 0) return false;
+        kst += a.sk[i];
+    }
+    if (kres + kst != a.K || a.K < fbk) return false;
+    if (a.band_k && (a.N % 96 || !a.ra[0] || kst || !a.y_tm || !a.band_lo || !a.band_hi || a.band_wmax < 1 || a.band_wmax > 8)) return false;
+    if (a.res_gn && (!a.res_tm || !a.res_part || !a.res_gamma || !a.res_beta || (a.ra[0] && (a.rmode == 1 || a.rmode == 3)))) return false;
+    if ((long long)a.N * a.K > 0x7fffffffLL) return false;
     if ((long long)a.batch * a.seg_rows > 0x7fffffffLL / 768) return false;   // 32-bit row arithmetic in the epilogue helpers
     if (a.y_cm && (a.cm_pitch % 4 || a.cm_pitch < ((a.M + 3) & ~3))) return false;
     return true;
 }
-size_t tgemm_packed_bytes(int N, int K, bool bf16) { return (size_t)N * K * (bf16 ? 2 : 4); }
-void tgemm_pack_weights(const float* W, int N, int K, bool bf16, void* out) {
-    const int step = bf16 ? 16 : 8, ns = K / step;
-    for (int jt = 0; jt < N / 32; ++jt)
-        for (int s = 0; s < ns; ++s)
-            for (int l = 0; l < 64; ++l) {
-                const float* src = W + (size_t)(jt * 32 + (l & 31)) * K + (size_t)s * step + (step / 2) * (l >> 5);
-                const size_t frag = ((size_t)jt * ns + s) * 64 + l;
-                if (bf16) {
-                    unsigned short* d = reinterpret_cast<unsigned short*>(out) + frag * 8;
-                    for (int e = 0; e < 8; ++e) {
-                        unsigned x;
-                        memcpy(&x, &src[e], 4);
-                        x += 0x7fffu + ((x >> 16) & 1u);   // round to nearest even (finite inputs)
-                        d[e] = (unsigned short)(x >> 16);
-                    }
-                } else {
-                    float* d = reinterpret_cast<float*>(out) + frag * 4;
-                    for (int e = 0; e < 4; ++e) d[e] = src[e];
-                }
-            }
-}
-template <int NJ, bool BF, bool TR, int OCC>
+template <int NJ, bool BF, bool RS, bool SS, bool TR, int EK, int OCC>
 static void launch_xgemm_one(const TGemmArgs& a, hipStream_t s) {
     const long long mt8 = ((long long)a.batch * a.seg_rows / 64 + 7) / 8 * 8;
-    const int smem = xgemm_lds_bytes<NJ, BF>(true);
+    const int smem = xgemm_lds_bytes<NJ, BF>(RS);
     static bool configured = false;
-    if (!configured) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xgemm_kernel<NJ, BF, TR, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); configured = true; }
-    hipLaunchKernelGGL((xgemm_kernel<NJ, BF, TR, OCC>), dim3((unsigned)(mt8 * (a.N / (32 * NJ * a.ntw)))), dim3(256), smem, s, a);
+    if (!configured) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xgemm_kernel<NJ, BF, RS, SS, TR, EK, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); configured = true; }
+    hipLaunchKernelGGL((xgemm_kernel<NJ, BF, RS, SS, TR, EK, OCC>), dim3((unsigned)(mt8 * (a.N / (32 * NJ * a.ntw)))), dim3(256), smem, s, a);
+}
+template <bool BF>
+static bool launch_xgemm_p(const TGemmArgs& a, hipStream_t s) {
+    const bool rs = a.ra[0] != nullptr, ss = a.sk[0] > 0;
+    constexpr int O_RS = XG_OCC_RS, O_SS = XG_OCC_SS;
+    if (a.band_k) { launch_xgemm_one<3, BF, true, false, true, 4, 2>(a, s); return true; }
+    if (a.geglu) { if (rs && !ss) { launch_xgemm_one<4, BF, true, false, false, 2, 2>(a, s); return true; } return false; }
+    if (a.qk) { if (rs && !ss) { launch_xgemm_one<3, BF, true, false, false, 1, O_RS>(a, s); return true; } return false; }
+    if (a.y_cm) { if (!rs && ss) { launch_xgemm_one<3, BF, false, true, false, 3, O_SS>(a, s); return true; } return false; }
+    if (!a.y_tm || a.N % 96) return false;
+    if (rs && ss) launch_xgemm_one<3, BF, true, true, false, 0, O_RS>(a, s);
+    else if (rs) launch_xgemm_one<3, BF, true, false, false, 0, O_RS>(a, s);
+    else launch_xgemm_one<3, BF, false, true, false, 0, O_SS>(a, s);
+    return true;
 }
 bool launch_xgemm(const TGemmArgs& a_in, int batch, hipStream_t s) {
     TGemmArgs a = a_in;
     a.batch = batch;
     if (!xgemm_supports(a)) return false;
-    const bool tr = a.band_k != nullptr;
+    const bool rs = a.ra[0] != nullptr;
     const bool nj4 = a.N % 128 == 0 && (a.geglu || a.N % 96);
-    {   // column tiles per workgroup: with ONE phase all of them (the prologue is paid once per row tile) unless the caller chose;
-        // with several phases every column tile re-walks the phases, so one tile per workgroup spreads the launch further
+    {   // column tiles per workgroup: with a resident source all of them (the prologue is paid once per row tile) unless the caller
+        // chose; a concatenated input re-uses the resident buffer for its second source, so it stays at one
         const int ntiles = a.N / (nj4 ? 128 : 96);
-        int ntw = a.ntw > 0 ? a.ntw : (a.nph == 1 ? ntiles : 1);
+        int ntw = a.ntw > 0 ? a.ntw : ((rs && !a.ra[1]) ? ntiles : 1);
+        if (a.ra[1]) ntw = 1;
         if (ntw > ntiles) ntw = ntiles;
         while (ntiles % ntw) --ntw;
         a.ntw = ntw;
     }
-    if (a.f32) {
-        if (tr) launch_xgemm_one<3, false, true, 2>(a, s);
-        else if (nj4) launch_xgemm_one<4, false, false, 2>(a, s);
-        else launch_xgemm_one<3, false, false, 2>(a, s);
-    } else {
-        if (tr) launch_xgemm_one<3, true, true, 2>(a, s);
-        else if (nj4) launch_xgemm_one<4, true, false, 2>(a, s);
-        else launch_xgemm_one<3, true, false, 3>(a, s);
-    }
-    return true;
+    return a.f32 ? launch_xgemm_p<false>(a, s) : launch_xgemm_p<true>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

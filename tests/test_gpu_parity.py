@@ -722,14 +722,12 @@ def test_token_major_path_ragged_length(model, unet_sd, dev, T):
 def test_loop_large_batch_ragged_length_matches_single_clip_runs(model, dev):
     """Guidance loop at a batch where the full-batch launches take the token-major path and the guidance-shared prefix (half
     the samples) stays on the channel-major kernels, at a length that is not a multiple of 4 or 32: every clip must come out
-    as if run alone, in both precision modes.  bf16 since round 3: the batch keeps bf16 token-major activations between its
-    kernels, a single clip fp32 channel-major ones, so the two differ by the activation rounding as well (measured 6.8e-2 after
-    the two free-running steps; bound = 3x)."""
+    as if run alone, in both precision modes (bf16: same rounding points, different summation order and tile shapes)."""
     B, T, N = 24, 333, 2
     ctx = synth.synth_latents(130, (B, T, 768)).to(dev)
     lat = synth.synth_latents(131, (B, T, 32)).to(dev)
     wav = torch.zeros(B, T * 16000 // 60, device=dev)   # only its shape is used when the embedding is injected
-    for mode, tol in (("fp32", 5e-5), ("bf16", 0.2)):
+    for mode, tol in (("fp32", 5e-5), ("bf16", 6e-2)):
         try:
             model.set_mfma_dtype(mode)
             big = model.inference(wav, audio_embedding=ctx, num_inference_steps=N, guidance_scale=2.0, init_latents=lat).result

@@ -337,3 +337,50 @@ def test_inference_eta_seeded_by_torch_generator(model, dev):
     a, b, c = run(5), run(5), run(6)
     assert torch.equal(a, b) and not torch.equal(a, c)
     assert torch.isfinite(a).all() and float(a.min()) >= 0 and float(a.max()) <= 1
+
+
+# ---------------------------------------------------------------- the experimental token-major activation schedule (opt-in)
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_token_major_activation_schedule_opt_in_vs_oracle(model, unet_sd, sd_full, dev, mode):
+    """said_debug_option("tm_acts", 1): activations stay token-major (bf16 / fp32) between the UNet kernels and the consuming GEMMs
+    apply GroupNorm + SiLU / LayerNorm themselves (xgemm_kernel: 41 launches per step, no preparation kernels).  Measured slower
+    than the default schedule, hence opt-in — but it must stay correct: a plain forward at B = 16 x T = 600 and a ragged B = 40 x
+    T = 333 against the oracle, and one guided step at B = 32 (shared prefix, duplicate stores, constant unconditional
+    cross-attention) against the oracle's step."""
+    tol = 1e-4 if mode == "fp32" else 2e-2
+    try:
+        model.set_mfma_dtype(mode)
+        for B, T in ((16, 600), (40, 333)):
+            x = synth.synth_latents(901 + T, (B, T, 32))
+            c = synth.synth_latents(902 + T, (B, T, 768))
+            ts = (torch.arange(B) * 61 + 5) % 1000
+            eng = model._get_engine(B, T)
+            eng.debug_option("tm_acts", 1)
+            out = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+            for i in (0, B // 2, B - 1):
+                ref = ou.unet1d_forward(unet_sd, x[i:i + 1], ts[i:i + 1], c[i:i + 1])
+                e = float((out[i:i + 1] - ref).abs().max()) / float(ref.abs().max())
+                print(f"tm_acts {mode} B={B} T={T} sample {i}: {e:.2e} of range vs oracle")
+                assert e <= tol
+        B, T, N = 32, 600, 50
+        emb = synth.synth_latents(520, (B, T, 768))
+        lat = synth.synth_latents(521, (B, T, 32))
+        eng = model._get_engine(2 * B, T)
+        eng.debug_option("tm_acts", 1)
+        sch = model.noise_scheduler
+        sch.set_timesteps(N)
+        ts = sch.timesteps.numpy()
+        coef = sch.coef_table(ts, 0.0)
+        o = osch.OracleDDIM()
+        o.set_timesteps(N)
+        _, latf, _ = eng.denoise_loop(latents=lat.to(dev), context=emb.to(dev), timesteps=ts[25:26], coef=coef[25:26], prediction_type="epsilon",
+                                      guidance_scale=2.0, guidance_rescale=0.0, latent_scale=1.0)
+        assert eng.graph_num_nodes() == 41
+        for i in (0, 31):
+            ref = _oracle_cfg_step(sd_full, lat[i:i + 1], emb[i:i + 1], int(ts[25]), o)
+            e = float((latf.cpu()[i:i + 1] - ref).abs().max())
+            print(f"tm_acts {mode} guided step clip {i}: {e:.3e} vs oracle")
+            assert e <= (2e-4 if mode == "fp32" else BF16_STEP_MAX)
+    finally:
+        model._eng.debug_option("tm_acts", 0)
+        model.set_mfma_dtype("fp32")
