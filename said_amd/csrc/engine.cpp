@@ -404,10 +404,6 @@ LaunchCfg pick_cfg(long long t_tiles_total, int ntiles, bool allow6 = true) {
 // as soon as that still fills the chip (measured at Be=32: 47 TFLOP/s against 34 for the generic NB=6 shape)
 LaunchCfg pick_unet(long long t_tiles_total) {
     if (big_cgemm()) return pick_cfg(t_tiles_total, 6);
-    // experiment knob SAID_BIG_NB=1: one n-tile per workgroup also at large batch — those multi-tile kernels are compiled for
-    // two workgroups per CU (gemm_lds.hip)
-    static const int big_nb = dev_env("SAID_BIG_NB") ? atoi(dev_env("SAID_BIG_NB")) : 2;
-    if (big_nb == 1 && t_tiles_total >= 640) return LaunchCfg{1, 8};
     return t_tiles_total * 3 >= 192 ? LaunchCfg{2, 8} : LaunchCfg{1, 8};
 }
 

@@ -1058,7 +1058,8 @@ static void uconfigure_one() {
     X(EPI_BAND, 1, 8, 0)
 #endif
 
-// multi-tile shapes (large batches; single-block launches).  fp32 GEGLU uses NB = 2: with 8 accumulator tiles the
+// multi-tile shapes (large batches; single-block launches).  (Round 2's single-n-tile store shapes at two workgroups per CU — an
+// experiment that measured slower, two of whose instantiations spilled 6 VGPRs — are gone.)  fp32 GEGLU uses NB = 2: with 8 accumulator tiles the
 // weight fragments only fit by rolling them through the registers, which a multi-tile workgroup cannot do.
 #ifdef SAID_DEV_ONE_CONFIG
 #define SAID_UGEMM_MT_CONFIGS(X)
@@ -1066,8 +1067,6 @@ static void uconfigure_one() {
 #define SAID_UGEMM_MT_CONFIGS(X)                                                                   \
     X(EPI_STORE, 2, 8, 0, 0) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0, 0) X(EPI_STORE, 1, 8, UV_RGN, 0)   \
     X(EPI_STORE, 2, 8, 0, 1) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0, 1) X(EPI_STORE, 1, 8, UV_RGN, 1)   \
-    X(EPI_STORE, 1, 8, 0, 0) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0, 0) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_DUP, 0) \
-    X(EPI_STORE, 1, 8, 0, 1) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0, 1) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_DUP, 1) \
     X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_DUP, 0) X(EPI_STORE, 1, 8, UV_RGN | UV_DUP, 0)          \
     X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_DUP, 1) X(EPI_STORE, 1, 8, UV_RGN | UV_DUP, 1)          \
     X(EPI_QKV, 3, 8, UV_GN0, 0) X(EPI_QKV, 3, 8, UV_GN0, 1)                                        \

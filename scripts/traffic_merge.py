@@ -1,0 +1,66 @@
+"""After `gpurun -- bash scripts/gpu_r3_traffic.sh`: per-config dominant-kernel HBM traffic -> profiles/traffic_latest.json.
+
+Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE count
+kilobytes; on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B per lane) coalesced reads, which is what these kernels
+issue, so reads are doubled: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, launch-weighted over the kernel family's variants.
+Stamps the file with bench.source_hash() (what bench.py compares at run time) and the git HEAD it was taken at.
+usage: python scripts/traffic_merge.py <round tag, e.g. r03>
+"""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+# config -> (substring of the rocprof kernel name, bench.py's name of the same kernel family)
+FAMILY = {
+    "cfg1": ("ugemm_kernel<1, 8, 0", "ugemm_kernel<NB1,KS8,store>"),
+    "cfg2_bf16": ("fgemm_kernel<3, 1, true", "tgemm_kernel<64,store>"),
+    "cfg3_per_gpu_f32": ("fgemm_kernel<3, 2, false", "fgemm_kernel<96,store>"),
+    "cfg4_edit": ("ugemm_kernel<2, 8, 0", "ugemm_kernel<NB2,KS8,store>"),
+}
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+sha = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
+out = {"format": "per-config dominant-kernel HBM traffic from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; "
+                 "source_hash = bench.source_hash() of the sources measured", "configs": {}}
+lines = []
+for cfg, (match, name) in FAMILY.items():
+    def load(counter):
+        fs = glob.glob(os.path.join(ROOT, "gpurun_out", "traffic", "**", f"{cfg}_{counter}_summary.json"), recursive=True)
+        return json.load(open(fs[0])) if fs else []
+    f, w = load("FETCH_SIZE"), load("WRITE_SIZE")
+    if not f or not w:
+        print(cfg, "missing counters")
+        continue
+    n = sum(r["launches"] for r in f if match in r["kernel"] and r["counter"] == "FETCH_SIZE")
+    fk = sum(r["sum"] for r in f if match in r["kernel"] and r["counter"] == "FETCH_SIZE")
+    wk = sum(r["sum"] for r in w if match in r["kernel"] and r["counter"] == "WRITE_SIZE")
+    if not n:
+        print(cfg, "kernel family not found:", match)
+        continue
+    per = (2 * fk + wk) * 1024 / n
+    out["configs"][cfg] = {"kernel": name, "rocprof_match": match, "launches": n, "hbm_bytes_per_launch": round(per),
+                           "fetch_kb_per_launch": round(fk / n, 1), "write_kb_per_launch": round(wk / n, 1),
+                           "note": "(2*FETCH_SIZE + WRITE_SIZE) * 1024, launch-weighted over the family's variants; gfx950 half-count correction on reads",
+                           "source": f"profiles/{tag}_pmc_hbm_traffic.txt", "source_hash": bench.source_hash(), "git_sha": sha}
+    lines.append(f"{cfg:18s} {name:32s} launches {n:6d}  FETCH {fk / n:10.1f} KB  WRITE {wk / n:10.1f} KB  HBM {(per) / 1e6:8.2f} MB per launch")
+    # the rest of the step, for the record
+    fam = {}
+    for r in f:
+        fam.setdefault(r["kernel"], [0, 0.0, 0.0])
+        fam[r["kernel"]][0] = r["launches"]; fam[r["kernel"]][1] = r["sum"]
+    for r in w:
+        if r["kernel"] in fam: fam[r["kernel"]][2] = r["sum"]
+    for k, (nn, a, b) in sorted(fam.items(), key=lambda kv: -(2 * kv[1][1] + kv[1][2]))[:10]:
+        lines.append(f"    {nn:6d} x {(2 * a + b) * 1024 / nn / 1e6:9.2f} MB  {k[:90]}")
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
+open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.txt"), "w").write(
+    f"# rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate passes) -- python bench.py --steps 1 --warmup 0 "
+    f"--no_cpu_baseline --no_roofline --no_secondary <config flags>   (scripts/gpu_r3_traffic.sh; git {sha}, sources {bench.source_hash()})\n"
+    "# HBM MB per launch = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 wide-read half-count correction, MI355X_MICROARCH.md); top 10 kernels per config\n"
+    + "\n".join(lines) + "\n")
+print("\n".join(lines))
