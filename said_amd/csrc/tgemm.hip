@@ -825,9 +825,14 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[4 * i + e] = raw[i][e];
             }
+            // (sched_barriers: without them the scheduler hoists all 48 coefficient reads / 48 LayerNorm parameter loads of a row in
+            // front of the arithmetic — 120+ live registers in a prologue, which then set the whole kernel's occupancy)
             if (a.rmode == 1 || a.rmode == 3) {
 #pragma unroll
-                for (int i = 0; i < 24; ++i) x[i] = fmaf(x[i], cf[2 * i], cf[2 * i + 1]);
+                for (int i = 0; i < 24; ++i) {
+                    x[i] = fmaf(x[i], cf[2 * i], cf[2 * i + 1]);
+                    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if (a.rmode == 1) {
 #pragma unroll
@@ -847,7 +852,10 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
                 const float* lg = a.ln_gamma + 24 * q8;
                 const float* lb = a.ln_beta + 24 * q8;
 #pragma unroll
-                for (int i = 0; i < 24; ++i) x[i] = fmaf((x[i] - mu) * rs, lg[i], lb[i]);
+                for (int i = 0; i < 24; ++i) {
+                    x[i] = fmaf((x[i] - mu) * rs, lg[i], lb[i]);
+                    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if (!valid) {
 #pragma unroll
@@ -906,10 +914,6 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
         for (int i = 0; i < WCH; ++i) *reinterpret_cast<f32x4t*>(ldse + lwoff[i]) = xw[i];
     };
     f32x16 acc[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int frow = l & 31, fk = EPC * (l >> 5) + 4 * EPC * kh;
     const elt_t* const pa_s = ldse + (wr * 32 + frow) * FLP + fk;
     const elt_t* const pa_r = ares + (wr * 32 + frow) * RP + fk;
@@ -974,8 +978,12 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
             for (int i = 0; i < ACH; ++i) ra_[i] = *reinterpret_cast<const f32x4t*>(base + ((long long)arow[i] * ld + off + akp[i]));
         }
     };
+    if constexpr (RS) { if (!(a.dbg & 8)) load_resident(0); }   // (before anything of the k loop is live in registers)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     gload_step(0);
-    if constexpr (RS) { if (!(a.dbg & 8)) load_resident(0); }
     lds_store(ra_, rw);
     __syncthreads();
     const int nk_loop = (a.dbg & 2) ? 1 : nk;   // (timing experiment: no k loop)
