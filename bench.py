@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--edit", action="store_true",
                    help="editing mode (BASELINE configs[4]: --seconds 30 --num_steps 100 --edit): init_samples + in-betweening mask "
                         "(middle third regenerated, 4 channels pinned), mask blend with the re-noised init every step")
+    p.add_argument("--tm_acts", action="store_true",
+                   help="experimental large-batch schedule (said_debug_option tm_acts = 1): token-major activations between the UNet kernels, "
+                        "normalisation inside the consuming GEMMs, 41 launches per step")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_secondary", action="store_true",
                    help="skip the secondary configurations (BASELINE configs[2], [3] per GPU, [4], and the headline with eta = 1) that the "
@@ -394,6 +397,8 @@ def run(args):
     model.load_state_dict(synth.said_state_dict(), strict=True)
     model.to(dev).eval()
     model.set_mfma_dtype("bf16" if args.dtype == "bf16" else "fp32")
+    if args.tm_acts:
+        model._get_engine(2 * B if args.guidance_scale > 1.0 else B, T).debug_option("tm_acts", 1)
     # synthetic inputs, resident in HBM before the timed region; keyed by GLOBAL clip id
     clips = shard.clip_range(rank, world, B)
     proc, lat0, edit_kw, T, Ta = make_inputs(model, dev, clips, args.seconds, args.edit)

@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int XRR = 66;                       // resident rows: 64 tokens + 2 halo
 #ifndef XG_OCC_RS
-#define XG_OCC_RS 2
+#define XG_OCC_RS 3
 #endif
 #ifndef XG_OCC_SS
 #define XG_OCC_SS 3
@@ -780,11 +780,18 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
     // ---- GroupNorm coefficients from a producer's partials -> coefS (4 waves x 48 channels; per-wave scratch inside the tile area,
     // which is idle at both call sites: kernel entry, and the source switch of a concatenated input)
     auto gn_coefs = [&](const float* part, float eps, const float* gamma, const float* beta) {
+        // (the lane / wave ids pass through an opaque asm: this lambda is inlined at several call sites, and without it the compiler
+        // shares the dozens of lane-derived offsets and masks between them — i.e. keeps them alive in registers across the whole k loop)
+        int lo_ = l, wo_ = w;
+        asm volatile("" : "+v"(lo_), "+v"(wo_));
         const GnP gp = {a.gn_cpg, a.gn_nparts, a.M, eps, gamma, beta, 192};
         const rsrc_t rp = make_rsrc(part + (long long)b * a.gn_part_bs, 192u * (unsigned)a.gn_nparts * 8u);
         GnLoads gl;
-        gn_issue(gp, rp, w * 48, 48, l, gl);
-        gn_finish(gp, rp, w * 48, 48, l, gl, ldsf + w * GN_SCRATCH, coefS);
+        // per-wave scratch: in the resident tile's region when there is one (empty at kernel entry, dead at the source switch of a
+        // concatenated input — the weight buffers in the tile area are live there), else in the idle tile area
+        float* const gsc = (RS ? reinterpret_cast<float*>(ares) : ldsf) + wo_ * GN_SCRATCH;
+        gn_issue(gp, rp, wo_ * 48, 48, lo_, gl);
+        gn_finish(gp, rp, wo_ * 48, 48, lo_, gl, gsc, coefS);
         __syncthreads();
     };
     if (!RS && a.res_gn) gn_coefs(a.res_part, a.res_eps, a.res_gamma, a.res_beta);
@@ -795,12 +802,14 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
         if (a.rmode == 1 || a.rmode == 3) gn_coefs(a.gn_part[ph], a.gn_eps, a.gn_gamma + ph * 192, a.gn_beta + ph * 192);
         const elt_t* src = reinterpret_cast<const elt_t*>(a.ra[ph]);
         const int halo = a.rtaps == 3 ? 1 : 0;
-        const int q8 = tid & 7;
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));   // (as in gn_coefs: nothing of this prologue is to stay alive through the k loop)
+        const int q8 = tid_ & 7;
         const float* cf = coefS + 48 * q8;
 #pragma unroll 1
         for (int pass = 0; pass < 2 + halo; ++pass) {
-            const int r = pass * 32 + (tid >> 3);
-            if (pass == 2 && tid >= 16) break;
+            const int r = pass * 32 + (tid_ >> 3);
+            if (pass == 2 && tid_ >= 16) break;
             const int tt = t0 + r - halo;
             const bool valid = tt >= 0 && tt < a.M;
             const elt_t* p = src + ((long long)b * a.seg_rows + min(max(tt, 0), a.M - 1)) * 192 + 24 * q8;
@@ -839,7 +848,7 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
                 for (int i = 0; i < 24; ++i) x[i] = silu_f(x[i]);
             }
             if (a.rmode >= 2) {   // LayerNorm over the row's 192 channels: sums over this thread's 24, then over the row's eight threads
-                const float ref = __shfl(x[0], l & ~7);
+                const float ref = __shfl(x[0], (tid_ & 63) & ~7);
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 24; ++i) { const float d = x[i] - ref; s1 += d; s2 = fmaf(d, d, s2); }
@@ -882,19 +891,21 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
     // ---- k-tile pipeline: weights always, streamed A tiles when SS
     f32x4t ra_[ACH], rw[WCH];
     int woff[WCH], lwoff[WCH], loff[ACH], arow[ACH], akp[ACH];
+    auto setup_offsets = [&]() {   // (called AFTER the prologue: these are live through the whole k loop, the prologue's registers are not)
 #pragma unroll
-    for (int i = 0; i < ACH; ++i) {
-        const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
-        arow[i] = min(m0 + row, rows_tot - 1);
-        akp[i] = kp * EPC;
-        loff[i] = row * FLP + kp * EPC;
-    }
+        for (int i = 0; i < ACH; ++i) {
+            const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
+            arow[i] = min(m0 + row, rows_tot - 1);
+            akp[i] = kp * EPC;
+            loff[i] = row * FLP + kp * EPC;
+        }
 #pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-        const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
-        woff[i] = (n0 + row) * a.K + kp * EPC;
-        lwoff[i] = BM * FLP + row * FLP + kp * EPC;
-    }
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
+            woff[i] = (n0 + row) * a.K + kp * EPC;
+            lwoff[i] = BM * FLP + row * FLP + kp * EPC;
+        }
+    };
     // W k-offset of tile kt: the resident segment runs source-major ([source][tap][channel tile]) over a tap-major weight
     auto wk_of = [&](int kt) -> int {
         if (RS && kt < nkr) {
@@ -978,7 +989,257 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
             for (int i = 0; i < ACH; ++i) ra_[i] = *reinterpret_cast<const f32x4t*>(base + ((long long)arow[i] * ld + off + akp[i]));
         }
     };
+    if constexpr (!SS) {
+        // ---- resident source only (convolutions without a skip, q/k/v, banded cross-attention, GEGLU): just the weights stream, so
+        // the tile area holds TWO weight tiles (128-byte rows, 16-byte chunks XOR-swizzled by the row instead of padded) and a k-step
+        // costs ONE barrier: park the next tile in the other buffer, request the one after, multiply the current one.
+        load_resident(0);
+        int wo[WCH], wl[WCH];
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + NTH * i, row = c >> 3, kp = c & 7;
+            wo[i] = (n0 + row) * a.K + kp * EPC;
+            wl[i] = row * FBK + ((kp ^ (row & 7)) * EPC);
+        }
+        auto wload = [&](int jn, int kt) {
+            const int wk = wk_of(kt) + jn * BN * a.K;
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) rw[i] = *reinterpret_cast<const f32x4t*>(W + (wo[i] + wk));
+        };
+        auto wstore = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) *reinterpret_cast<f32x4t*>(ldse + buf * (BN * FBK) + wl[i]) = rw[i];
+        };
+        const int fr = l & 31;
+        const int sw0 = (((l >> 5) + 4 * kh) ^ (fr & 7)) * EPC, sw1 = (((l >> 5) + 4 * kh + 2) ^ (fr & 7)) * EPC;   // the K half's two operand steps
+        const elt_t* const par = ares + (wr * 32 + fr) * RP + EPC * (l >> 5) + 4 * EPC * kh;
+        auto wcompute = [&](int buf, int kt) {
+            const int rem = (nsrc == 2 && kt >= ntap * CT) ? kt - ntap * CT : kt;
+            const int tap = CT == 3 ? (rem * 43) >> 7 : (rem * 43) >> 8;   // rem / CT for rem < 64
+            const elt_t* pa = par + tap * RP + (rem - tap * CT) * FBK;
+            const elt_t* pwb = ldse + buf * (BN * FBK) + fr * FBK;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int sw = ks ? sw1 : sw0;
+                if constexpr (BF) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(pa + ks * 16);
+                    bf16x8 fb[NJ];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(pwb + j * 32 * FBK + sw);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa, acc[j], 0, 0, 0);
+                        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[j], 0, 0, 0);
+                    }
+                } else {
+                    const f32x4t fa = *reinterpret_cast<const f32x4t*>(pa + ks * 8);
+                    f32x4t fb[NJ];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const f32x4t*>(pwb + j * 32 * FBK + sw);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            if constexpr (TR) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][i], fa[i], acc[j], 0, 0, 0);
+                            else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j][i], acc[j], 0, 0, 0);
+                        }
+                }
+            }
+        };
+        const int ntw = a.ntw > 0 ? a.ntw : 1;
+        const int e0 = nsrc == 2 ? ntap * CT : -1;
+        constexpr int NJ0 = (NJ == 4 && !TR) ? 2 : NJ, NJ1 = NJ - NJ0;
+        float* const xr = ldsf + wr * (NJ1 > 0 ? NJ * 16 * 64 : 32 * (32 * NJ + 4));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        wload(0, 0);
+        wstore(0);
+        wload(0, 1);
+        __syncthreads();
+        for (int jn = 0; jn < ntw; ++jn) {
+            const int jnx = min(jn + 1, ntw - 1);
+            // invariant at step kt: buffer kt & 1 holds tile kt, the registers tile kt + 1 (behind the last tile: the next column tile's first)
+            for (int kt = 0; kt < nk - 1; ++kt) {
+                wstore((kt + 1) & 1);
+                { const bool nx = kt + 2 < nk; wload(nx ? jn : jnx, nx ? kt + 2 : 0); }   // (one unconditional request: exact wait counts)
+                __builtin_amdgcn_sched_barrier(0);
+                wcompute(kt & 1, kt);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt == e0 - 1) { __syncthreads(); load_resident(1); }   // every wave is done with the first source's tile
+                __syncthreads();
+            }
+            wcompute((nk - 1) & 1, nk - 1);
+            __syncthreads();   // the tile area becomes exchange / transposition scratch
+            const int n0j = n0 + jn * BN;
+            // ---- add the two K halves (fgemm_kernel's exchange), then the epilogue of column tile jn
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if ((kh == 1) == (j < NJ0)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xr[(j * 16 + r) * 64 + l] = acc[j][r];
+                }
+            }
+            __syncthreads();
+            if (NJ1 > 0 || kh == 0) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if ((kh == 0) == (j < NJ0)) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[j][r] += xr[(j * 16 + r) * 64 + l];
+                    }
+                }
+            }
+            if constexpr (TR) {
+                if (kh == 0) {   // banded cross-attention: lane -> query token, one head per column tile
+                    const int t = t0 + wr * 32 + (l & 31);
+                    const bool tv = t < a.M;
+                    const int tc = min(t, a.M - 1);
+                    const int lo = a.band_lo[tc], hi = a.band_hi[tc];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) band_head<BF>(a, acc[j], b, t, tv, lo, hi, n0j / 32 + j, l);
+                }
+            } else if constexpr (NJ1 > 0) {
+                __syncthreads();
+                float* sc = ldsf + w * (32 * (32 * NJ0 + 4));
+                if (kh == 0) tg_epilogue<NJ, 0, NJ0, EK>(a, acc, 0, m0 + wr * 32, n0j, l, sc, coefS);
+                else tg_epilogue<NJ, NJ0, (NJ1 > 0 ? NJ1 : 1), EK>(a, acc, 0, m0 + wr * 32, n0j + 32 * NJ0, l, sc, coefS);
+            } else if constexpr (EK == 0) {
+                // ---- token-major activation epilogue on ALL FOUR waves.  (Run by the two K-half-0 waves alone, with the residual gathered
+                // in the MFMA layout — 2-byte loads, lane == column — it was 40-60 % of these kernels: knock-outs, profiles/r03_*.)
+                // phase 1 (K-half-0 waves, lane == column): acc + bias + timestep-embedding term -> scratch [32 rows][CW + 4] of this row half
+                constexpr int CW = 32 * NJ, CP = CW + 4;
+                float* const sc = xr;
+                int le = l;
+                asm volatile("" : "+v"(le));   // (keeps this epilogue's lane-derived values out of the k loop: the column-tile loop around both
+                                               // would otherwise have them computed once, up front, and held in registers)
+                const int mt = t0 + wr * 32;                       // first token of this row half
+                const int nrows = min(32, a.M - mt);               // <= 0: padding rows only
+                if (kh == 0 && nrows > 0) {
+                    const int lc = le & 31, lh = le >> 5;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int n = n0j + j * 32 + lc;
+                        float add = a.bias ? a.bias[n] : 0.f;
+                        if (a.emb) add += a.emb[(long long)n * a.emb_pitch + (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * lh) * CP + j * 32 + lc] = acc[j][r] + add;
+                    }
+                }
+                __syncthreads();
+                // phase 2 (all waves): wave (wr, kh) takes rows 16 kh .. 16 kh + 15; 16 lanes per row (CW / 8 of them active), each 8
+                // consecutive columns: residual (16-byte loads, optionally GroupNorm'ed), rounding to the element type, GroupNorm partial
+                // sums of the stored values, 16-byte stores
+                const int rr = le >> 4, cq = le & 15;
+                const bool lane_on = cq < CW / 8;
+                const int n = n0j + 8 * min(cq, CW / 8 - 1);
+                float ref[8], s1[8], s2[8], rca[8], rcb[8], add2[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ref[e] = sc[8 * min(cq, CW / 8 - 1) + e];   // any common shift will do: row 0 of the row half, before the residual
+                    s1[e] = 0.f; s2[e] = 0.f;
+                    rca[e] = a.res_gn ? coefS[2 * (n + e)] : 1.f;
+                    rcb[e] = a.res_gn ? coefS[2 * (n + e) + 1] : 0.f;
+                    add2[e] = (a.y2_tm && a.y2_add) ? a.y2_add[n + e] : 0.f;
+                }
+                const long long R0 = (long long)b * a.seg_rows + mt;
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int row = 16 * kh + 4 * ps + rr;
+                    if (!lane_on || row >= nrows) continue;
+                    const f32x4t v0 = *reinterpret_cast<const f32x4t*>(sc + row * CP + 8 * cq);
+                    const f32x4t v1 = *reinterpret_cast<const f32x4t*>(sc + row * CP + 8 * cq + 4);
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (a.res_tm && !(a.dbg & 4)) {
+                        if constexpr (BF) {
+                            const u32x4 rv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.res_tm) + (R0 + row) * a.ldr_tm + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[2 * e] += fmaf(__builtin_bit_cast(float, rv[e] << 16), rca[2 * e], rcb[2 * e]);
+                                v[2 * e + 1] += fmaf(__builtin_bit_cast(float, rv[e] & 0xffff0000u), rca[2 * e + 1], rcb[2 * e + 1]);
+                            }
+                        } else {
+                            const float* rp = reinterpret_cast<const float*>(a.res_tm) + (R0 + row) * a.ldr_tm + n;
+                            const f32x4t r0 = *reinterpret_cast<const f32x4t*>(rp), r1 = *reinterpret_cast<const f32x4t*>(rp + 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v[e] += fmaf(r0[e], rca[e], rcb[e]); v[4 + e] += fmaf(r1[e], rca[4 + e], rcb[4 + e]); }
+                        }
+                    }
+                    const long long o = (R0 + row) * a.ldy + n;
+                    if constexpr (BF) {
+                        const bf16x8 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3], (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
+                        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(a.y_tm) + o) = ov;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (float)ov[e];   // the statistics are those of the stored values
+                        if (a.y2_tm) {
+                            const bf16x8 o2 = {(__bf16)(v[0] + add2[0]), (__bf16)(v[1] + add2[1]), (__bf16)(v[2] + add2[2]), (__bf16)(v[3] + add2[3]),
+                                               (__bf16)(v[4] + add2[4]), (__bf16)(v[5] + add2[5]), (__bf16)(v[6] + add2[6]), (__bf16)(v[7] + add2[7])};
+                            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(a.y2_tm) + o + a.y2_row_off * a.ldy) = o2;
+                        }
+                    } else {
+                        float* y = reinterpret_cast<float*>(a.y_tm) + o;
+                        const f32x4t w0 = {v[0], v[1], v[2], v[3]}, w1 = {v[4], v[5], v[6], v[7]};
+                        *reinterpret_cast<f32x4t*>(y) = w0;
+                        *reinterpret_cast<f32x4t*>(y + 4) = w1;
+                        if (a.y2_tm) {
+                            float* y2 = reinterpret_cast<float*>(a.y2_tm) + o + a.y2_row_off * a.ldy;
+                            const f32x4t u0 = {v[0] + add2[0], v[1] + add2[1], v[2] + add2[2], v[3] + add2[3]};
+                            const f32x4t u1 = {v[4] + add2[4], v[5] + add2[5], v[6] + add2[6], v[7] + add2[7]};
+                            *reinterpret_cast<f32x4t*>(y2) = u0;
+                            *reinterpret_cast<f32x4t*>(y2 + 4) = u1;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = v[e] - ref[e]; s1[e] += d; s2[e] = fmaf(d, d, s2[e]); }
+                }
+                if (a.stats) {
+                    // sums over the wave's 16 rows (lanes l, l ^ 16, l ^ 32, l ^ 48 share their columns), then over the two waves of the row
+                    // half through the statistics exchange [2 row halves][CW columns][2] (the coefficient region: free after the prologue)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        s1[e] += __shfl_xor(s1[e], 16); s2[e] += __shfl_xor(s2[e], 16);
+                        s1[e] += __shfl_xor(s1[e], 32); s2[e] += __shfl_xor(s2[e], 32);
+                    }
+                    float* const ex = coefS + wr * (2 * CW);
+                    if (kh == 1 && le < CW / 8) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { ex[2 * (8 * le + e)] = s1[e]; ex[2 * (8 * le + e) + 1] = s2[e]; }
+                    }
+                    __syncthreads();
+                    if (kh == 0 && le < CW / 8 && nrows > 0) {
+                        float* so = a.stats + (long long)b * a.stats_bs + ((long long)(mt >> 5) * a.N + n) * 2;   // [tile][channel][2]
+                        const float cnt = (float)nrows, inv = 1.0f / cnt;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float S1 = s1[e] + ex[2 * (8 * le + e)], S2 = s2[e] + ex[2 * (8 * le + e) + 1];
+                            const float md = S1 * inv;
+                            so[2 * e] = ref[e] + md;                          // mean
+                            so[2 * e + 1] = fmaxf(S2 - cnt * md * md, 0.f);   // M2 = sum (x - mean)^2
+                        }
+                    }
+                }
+            } else {
+                if (kh == 0) {
+                    __builtin_amdgcn_wave_barrier();
+                    tg_epilogue<NJ, 0, NJ, EK>(a, acc, 0, m0 + wr * 32, n0j, l, xr, coefS);
+                }
+            }
+            if (jn + 1 < ntw) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+                __syncthreads();   // the tile area is free again
+                wstore(0);
+                wload(jn + 1, 1);
+                __syncthreads();
+            }
+        }
+        return;
+    }
     if constexpr (RS) { if (!(a.dbg & 8)) load_resident(0); }   // (before anything of the k loop is live in registers)
+    setup_offsets();
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -1045,10 +1306,13 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
             // phase 1 (K-half-0 waves, lane == column): acc + bias + timestep-embedding term -> scratch [32 rows][CW + 4] of this row half
             constexpr int CW = 32 * NJ, CP = CW + 4;
             float* const sc = xr;
+            int le = l;
+            asm volatile("" : "+v"(le));   // (keeps this epilogue's lane-derived values out of the k loop: the column-tile loop around both
+                                           // would otherwise have them computed once, up front, and held in registers)
             const int mt = t0 + wr * 32;                       // first token of this row half
             const int nrows = min(32, a.M - mt);               // <= 0: padding rows only
             if (kh == 0 && nrows > 0) {
-                const int lc = l & 31, lh = l >> 5;
+                const int lc = le & 31, lh = le >> 5;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int n = n0j + j * 32 + lc;
@@ -1062,7 +1326,7 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
             // phase 2 (all waves): wave (wr, kh) takes rows 16 kh .. 16 kh + 15; 16 lanes per row (CW / 8 of them active), each 8
             // consecutive columns: residual (16-byte loads, optionally GroupNorm'ed), rounding to the element type, GroupNorm partial
             // sums of the stored values, 16-byte stores
-            const int rr = l >> 4, cq = l & 15;
+            const int rr = le >> 4, cq = le & 15;
             const bool lane_on = cq < CW / 8;
             const int n = n0j + 8 * min(cq, CW / 8 - 1);
             float ref[8], s1[8], s2[8], rca[8], rcb[8], add2[8];
@@ -1133,17 +1397,17 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
                     s1[e] += __shfl_xor(s1[e], 32); s2[e] += __shfl_xor(s2[e], 32);
                 }
                 float* const ex = coefS + wr * (2 * CW);
-                if (kh == 1 && l < CW / 8) {
+                if (kh == 1 && le < CW / 8) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { ex[2 * (8 * l + e)] = s1[e]; ex[2 * (8 * l + e) + 1] = s2[e]; }
+                    for (int e = 0; e < 8; ++e) { ex[2 * (8 * le + e)] = s1[e]; ex[2 * (8 * le + e) + 1] = s2[e]; }
                 }
                 __syncthreads();
-                if (kh == 0 && l < CW / 8 && nrows > 0) {
+                if (kh == 0 && le < CW / 8 && nrows > 0) {
                     float* so = a.stats + (long long)b * a.stats_bs + ((long long)(mt >> 5) * a.N + n) * 2;   // [tile][channel][2]
                     const float cnt = (float)nrows, inv = 1.0f / cnt;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float S1 = s1[e] + ex[2 * (8 * l + e)], S2 = s2[e] + ex[2 * (8 * l + e) + 1];
+                        const float S1 = s1[e] + ex[2 * (8 * le + e)], S2 = s2[e] + ex[2 * (8 * le + e) + 1];
                         const float md = S1 * inv;
                         so[2 * e] = ref[e] + md;                          // mean
                         so[2 * e + 1] = fmaxf(S2 - cnt * md * md, 0.f);   // M2 = sum (x - mean)^2
@@ -1329,7 +1593,7 @@ static void launch_xgemm_one(const TGemmArgs& a, hipStream_t s) {
 template <bool BF>
 static bool launch_xgemm_p(const TGemmArgs& a, hipStream_t s) {
     const bool rs = a.ra[0] != nullptr, ss = a.sk[0] > 0;
-    constexpr int O_RS = XG_OCC_RS, O_SS = XG_OCC_SS;
+    constexpr int O_RS = BF ? XG_OCC_RS : 2, O_SS = XG_OCC_SS;   // (fp32: the 52 KB resident tile allows two workgroups per CU anyway)
     if (a.band_k) { launch_xgemm_one<3, BF, true, false, true, 4, 2>(a, s); return true; }
     if (a.geglu) { if (rs && !ss) { launch_xgemm_one<4, BF, true, false, false, 2, 2>(a, s); return true; } return false; }
     if (a.qk) { if (rs && !ss) { launch_xgemm_one<3, BF, true, false, false, 1, O_RS>(a, s); return true; } return false; }
