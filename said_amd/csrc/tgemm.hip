@@ -53,9 +53,12 @@ constexpr int TBM = 128, TBN = 128, TBK = 64, TLP = 72;   // tile, LDS row pitch
 // its own all-wave epilogue inside xgemm_kernel).
 // EK (xgemm_kernel): the epilogue kind is a compile-time constant there, so the paths a launch cannot take cost it no registers —
 // -1: any (the round-2 kernels), 1: q/k/v split, 2: GEGLU, 3: channel-major fp32 result (+ token-major residual).
-template <int NJ, int J0 = 0, int NJE = NJ, int EK = -1>
+// PH (fgemm_kernel, round 3): 0 = both phases by the calling wave; 1 = phase 1 only; 2 = phase 2 only, on HALF `half` of the work (phase 2b:
+// the lower / upper half of the channels, phases 2a / 2a': rows 0-15 / 16-31) — the two K-half waves of a row half then share the
+// memory-facing phase instead of one of them idling (the scratch is the row half's, a workgroup barrier separates the phases).
+template <int NJ, int J0 = 0, int NJE = NJ, int EK = -1, int PH = 0>
 __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ], int b_grid, int rt, int n0w, int l, float* sc,
-                                            const float* coefR = nullptr) {
+                                            const float* coefR = nullptr, int half = 0) {
     constexpr bool ANY = EK < 0, P_CM = ANY || EK == 1 || EK == 3, P_BF = ANY || EK == 2, P_GEN = ANY || EK == 1 || EK == 2,
                    P_RES = EK == 3, P_GEGLU = ANY || EK == 2;
     constexpr int CW = 32 * NJE, CP = CW + 4;   // columns of this call, scratch row pitch (floats)
@@ -73,6 +76,7 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
     // ---- phase 1: registers -> scratch, elementwise work where lane == column
     const bool geglu = P_GEGLU && a.geglu != 0;
     constexpr int NJO = NJE;   // (GEGLU writes NJ / 2 column tiles; the scratch keeps the full pitch)
+    if constexpr (PH != 2) {
 #pragma unroll
     for (int j = 0; j < NJE; ++j) {
         if (geglu && (j & 1)) continue;   // gate tiles are consumed with their value tile
@@ -100,9 +104,13 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
             sc[row * CP + col] = v;
         }
     }
+    }
     (void)NJO;
+    if constexpr (PH == 1) return;
     __builtin_amdgcn_wave_barrier();
     const int cw = geglu ? CW / 2 : CW;                 // live columns in the scratch
+    const int c_lo = PH == 2 ? half * (cw / 2) : 0, c_hi = PH == 2 ? c_lo + cw / 2 : cw;      // phase 2b's channel range
+    const int r_lo = PH == 2 ? 16 * half : 0, r_hi = PH == 2 ? min(nrows, r_lo + 16) : nrows;   // phase 2a's row range
     const int n_first = geglu ? a.geglu_c0(n0w) : n0w;   // first destination column
     const bool v_rows = a.qk && n0w >= a.qk_n;          // this wave holds v columns (channel-major) of a q/k/v projection
     if (P_CM && (a.y_cm || v_rows)) {
@@ -111,7 +119,7 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
         const int pitch = a.y_cm ? a.cm_pitch : a.v_pitch;
         float* const ybase = a.y_cm ? a.y_cm + (long long)b * a.cm_bs : a.vt + (long long)b * a.v_bs - (long long)a.qk_n * a.v_pitch;
         const int nparts = (a.M + 31) >> 5;
-        for (int c0 = 0; c0 < cw; c0 += 8) {
+        for (int c0 = c_lo; c0 < c_hi; c0 += 8) {
             const int c = c0 + (l >> 3);
             const int n = n_first + c;
             float v4[4];
@@ -155,9 +163,9 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
         const int rows_pp = 64 / lanes_per_row;          // 4, 5 (60 lanes active), 8 or 16
         const int rr = l / lanes_per_row, cq = l - rr * lanes_per_row;
         const bool lane_on = rr < rows_pp;
-        for (int r0 = 0; r0 < nrows; r0 += rows_pp) {
+        for (int r0 = r_lo; r0 < r_hi; r0 += rows_pp) {
             const int row = r0 + rr;
-            if (!lane_on || row >= nrows) continue;
+            if (!lane_on || row >= r_hi) continue;
             const f32x4t v0 = *reinterpret_cast<const f32x4t*>(sc + row * CP + 8 * cq);
             const f32x4t v1 = *reinterpret_cast<const f32x4t*>(sc + row * CP + 8 * cq + 4);
             const bf16x8s o = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3], (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
@@ -169,9 +177,9 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
         const int rows_pp = 64 / lanes_per_row;          // 2, 2 (48 lanes active), 4 or 8
         const int rr = l / lanes_per_row, cq = l - rr * lanes_per_row;
         const bool lane_on = rr < rows_pp;
-        for (int r0 = 0; r0 < nrows; r0 += rows_pp) {
+        for (int r0 = r_lo; r0 < r_hi; r0 += rows_pp) {
             const int row = r0 + rr;
-            if (!lane_on || row >= nrows) continue;
+            if (!lane_on || row >= r_hi) continue;
             const int m = mt + row;
             const int n = n_first + 4 * cq;
             if (a.n_store && n >= a.n_store) continue;
@@ -615,12 +623,13 @@ __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
         }
     }
     __syncthreads();
-    if (NJ1 == 0 && kh == 1) return;
+    if (NJ1 > 0 || kh == 0) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        if ((kh == 0) == (j < NJ0)) {
+        for (int j = 0; j < NJ; ++j) {
+            if ((kh == 0) == (j < NJ0)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] += xr[(j * 16 + r) * 64 + l];
+                for (int r = 0; r < 16; ++r) acc[j][r] += xr[(j * 16 + r) * 64 + l];
+            }
         }
     }
     if constexpr (NJ1 > 0) {
@@ -629,9 +638,16 @@ __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
         if (kh == 0) tg_epilogue<NJ, 0, NJ0>(a, acc, 0, m0 + wr * 32, n0, l, sc);
         else tg_epilogue<NJ, NJ0, (NJ1 > 0 ? NJ1 : 1)>(a, acc, 0, m0 + wr * 32, n0 + 32 * NJ0, l, sc);
     } else {
-        // region r holds only this wave's partner data, which it has just consumed: its own transposition scratch (in-order LDS)
-        __builtin_amdgcn_wave_barrier();
-        tg_epilogue<NJ>(a, acc, 0, m0 + wr * 32, n0, l, xr);
+        // region r holds only wave (r, 0)'s partner data, which it has just consumed: the row half's transposition scratch (in-order
+        // LDS).  Round 3: wave (r, 0) runs phase 1 alone, then BOTH waves of the row half share phase 2 — half the channels (channel-
+        // major results) or half the rows (token-major ones) each; before, wave (r, 1) had exited and two of the workgroup's four
+        // waves carried the whole memory-facing half of the kernel.
+        if (kh == 0) {
+            __builtin_amdgcn_wave_barrier();
+            tg_epilogue<NJ, 0, NJ, -1, 1>(a, acc, 0, m0 + wr * 32, n0, l, xr);
+        }
+        __syncthreads();
+        tg_epilogue<NJ, 0, NJ, -1, 2>(a, acc, 0, m0 + wr * 32, n0, l, xr, nullptr, kh);
     }
 }
 

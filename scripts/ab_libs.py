@@ -1,0 +1,34 @@
+"""Same-box A/B of two builds of the engine: said_amd/lib/ab_old.so vs ab_new.so (each run in its own process).
+    python scripts/ab_libs.py <lib> [B=32] [N=50] [dtype ...]      prints ms per denoise step in situ (audio embedding injected)"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from said_amd import _engine  # noqa: E402
+
+_engine._LIB_PATH = os.path.abspath(sys.argv[1])
+from said_amd.model.diffusion import SAID_UNet1D  # noqa: E402
+from said_amd.util import synth  # noqa: E402
+
+torch.set_grad_enabled(False)
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+T = 600
+dev = torch.device("cuda:0")
+m = SAID_UNet1D()
+m.load_state_dict(synth.said_state_dict(), strict=True)
+m.to(dev).eval()
+ctx = synth.synth_latents(1, (B, T, 768)).to(dev)
+lat = synth.synth_latents(2, (B, T, 32)).to(dev)
+wav = torch.zeros(B, T * 16000 // 60, device=dev)
+for dt in (sys.argv[4:] or ["bf16", "fp32"]):
+    m.set_mfma_dtype(dt)
+    m.inference(wav, audio_embedding=ctx, num_inference_steps=10, guidance_scale=2.0, init_latents=lat)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        r = m.inference(wav, audio_embedding=ctx, num_inference_steps=N, guidance_scale=2.0, init_latents=lat).result
+    torch.cuda.synchronize()
+    print(f"{os.path.basename(sys.argv[1])} B={B} {dt}: {(time.perf_counter() - t0) / 3 / N * 1e3:.4f} ms per step, checksum {float(r.double().sum()):.6f}", flush=True)
