@@ -144,6 +144,7 @@ struct said_ctx {
                               // schedule (prep_kernel + channel-major fp32 interface; bf16 2.49 vs 2.37, fp32 5.85 vs 4.92 ms per step at 32 clips:
                               // DESIGN.md section 7.3), so it is opt-in: said_debug_option("tm_acts", 1)
     int xgemm_dbg = 0;
+    bool xclk_on = false;
     int xgemm_ntw = 0;        // test / measurement: column tiles per workgroup of the resident-source GEMMs (0: launch_xgemm decides)
     void *tX1 = nullptr, *tX2 = nullptr, *tO = nullptr, *tF = nullptr;   // token-major x1, x2, attention output [.][192], GEGLU product [.][768]
     bool unet_tgemm = true;   // SAID_NO_UNET_TGEMM=1 keeps the channel-major kernels in bf16 mode at every batch size
@@ -602,6 +603,7 @@ void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     a2.f32 = c->bf16_mode ? 0 : 1;
     if (c->xgemm_ntw > 0 && a2.ra[0]) a2.ntw = c->xgemm_ntw;
     a2.dbg = c->xgemm_dbg;
+    if (c->xclk_on && c->dbg_count < 64) a2.clk = c->clk_dev + (long long)c->dbg_count * 128;
     if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }
     if (dbg_go(c) && !launch_xgemm(a2, batch, s)) {
         char b[160]; snprintf(b, sizeof b, "token-major activation GEMM: shape M=%d N=%d K=%d (batch %d) is not served by any kernel", a.M, a.N, a.K, batch);
@@ -1871,6 +1873,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
     } else if (k == "steps_per_graph") {
         if (value < 1) return fail(ctx, "steps_per_graph must be >= 1");
         ctx->spg_limit = (int)value;
+    } else if (k == "xgemm_clk") {   // shader-clock stamps of the token-major-activation GEMMs (-DSAID_CLK_STAMPS builds); read with said_debug_clocks
+        ctx->xclk_on = value != 0;
     } else if (k == "xgemm_ntw") {
         ctx->xgemm_ntw = (int)value;
     } else if (k == "xgemm_dbg") {   // knock-out timing experiments (1: no epilogue, 2: no k loop, 4: no residual, 8: no source tile): WRONG results,

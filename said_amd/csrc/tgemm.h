@@ -65,6 +65,7 @@ struct TGemmArgs {
     // channels of ra[0], then of ra[1] (concatenated input) — is loaded ONCE, transformed once per element and parked in LDS;
     // only the weights stream.  k order of W for this segment: [tap][source][channel] (Conv1d weight, tap-major).
     int ntw;               // column tiles per workgroup (0: chosen by launch_xgemm)
+    long long* clk;        // optional [4 waves][16] shader-clock stamps of workgroup 8 (-DSAID_CLK_STAMPS builds; scripts/xgemm_clocks.py)
     const void* ra[2];     // sources (row pitch 192), or null
     int rmode;             // 0: raw, 1: silu(GroupNorm(x)), 2: LayerNorm(x), 3: LayerNorm(GroupNorm(x))
     int rtaps;             // 1, or 3: output token t reads tokens t - 1 + tap, zero outside [0, M)

@@ -1005,11 +1005,13 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
             for (int i = 0; i < ACH; ++i) ra_[i] = *reinterpret_cast<const f32x4t*>(base + ((long long)arow[i] * ld + off + akp[i]));
         }
     };
+    clk_stamp_p(a.clk, w, l, 0);
     if constexpr (!SS) {
         // ---- resident source only (convolutions without a skip, q/k/v, banded cross-attention, GEGLU): just the weights stream, so
         // the tile area holds TWO weight tiles (128-byte rows, 16-byte chunks XOR-swizzled by the row instead of padded) and a k-step
         // costs ONE barrier: park the next tile in the other buffer, request the one after, multiply the current one.
         load_resident(0);
+        clk_stamp_p(a.clk, w, l, 1);
         int wo[WCH], wl[WCH];
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
@@ -1074,6 +1076,7 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
         wstore(0);
         wload(0, 1);
         __syncthreads();
+        clk_stamp_p(a.clk, w, l, 2);
         for (int jn = 0; jn < ntw; ++jn) {
             const int jnx = min(jn + 1, ntw - 1);
             // invariant at step kt: buffer kt & 1 holds tile kt, the registers tile kt + 1 (behind the last tile: the next column tile's first)
@@ -1087,6 +1090,7 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
                 __syncthreads();
             }
             wcompute((nk - 1) & 1, nk - 1);
+            clk_stamp_p(a.clk, w, l, 3 + 2 * min(jn, 5));
             __syncthreads();   // the tile area becomes exchange / transposition scratch
             const int n0j = n0 + jn * BN;
             // ---- add the two K halves (fgemm_kernel's exchange), then the epilogue of column tile jn
@@ -1241,6 +1245,7 @@ __global__ __launch_bounds__(256, OCC) void xgemm_kernel(const TGemmArgs a) {
                     tg_epilogue<NJ, 0, NJ, EK>(a, acc, 0, m0 + wr * 32, n0j, l, xr, coefS);
                 }
             }
+            clk_stamp_p(a.clk, w, l, 4 + 2 * min(jn, 5));
             if (jn + 1 < ntw) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
@@ -1629,7 +1634,9 @@ bool launch_xgemm(const TGemmArgs& a_in, int batch, hipStream_t s) {
     {   // column tiles per workgroup: with a resident source all of them (the prologue is paid once per row tile) unless the caller
         // chose; a concatenated input re-uses the resident buffer for its second source, so it stays at one
         const int ntiles = a.N / (nj4 ? 128 : 96);
-        int ntw = a.ntw > 0 ? a.ntw : ((rs && !a.ra[1]) ? ntiles : 1);
+        // (at most six: a GEGLU row tile's twelve column tiles in ONE workgroup leave 640 heavy workgroups on 512-768 slots — in situ
+        // 2.135 ms per step against 2.037 with six, 32 clips x 50 steps bf16)
+        int ntw = a.ntw > 0 ? a.ntw : ((rs && !a.ra[1]) ? (ntiles > 6 ? 6 : ntiles) : 1);
         if (a.ra[1]) ntw = 1;
         if (ntw > ntiles) ntw = ntiles;
         while (ntiles % ntw) --ntw;
