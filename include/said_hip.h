@@ -203,6 +203,8 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
  *                            kernels, GroupNorm / LayerNorm applied inside the consuming GEMM (xgemm_kernel), 41 launches per step, no
  *                            preparation kernels; parity-green, measured slower than the default (0 = round 2's schedule), DESIGN.md 7.3
  *   "xgemm_ntw"              column tiles per workgroup of the resident-source GEMMs (0: chosen per launch)
+ *   "hybrid"                 0: bf16 mode at large batch keeps round 2's SpatialTransformer schedule throughout (default 1: from the
+ *                            attention output on, the block runs on round 3's token-major kernels — DESIGN.md 7.3)
  * said_debug_get additionally knows "n_set_weight" (said_set_weight calls so far). */
 int said_debug_option(said_ctx* ctx, const char* name, long long value);
 long long said_debug_get(const said_ctx* ctx, const char* name);

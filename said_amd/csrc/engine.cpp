@@ -143,6 +143,7 @@ struct said_ctx {
                               // 41 launches, no preparation kernels).  Parity-green in both precisions but measured SLOWER than round 2's
                               // schedule (prep_kernel + channel-major fp32 interface; bf16 2.49 vs 2.37, fp32 5.85 vs 4.92 ms per step at 32 clips:
                               // DESIGN.md section 7.3), so it is opt-in: said_debug_option("tm_acts", 1)
+    bool hybrid = true;       // bf16 mode at large batch: SpatialTransformers from the attention output on use round 3's token-major kernels
     int xgemm_dbg = 0;
     bool xclk_on = false;
     int xgemm_ntw = 0;        // test / measurement: column tiles per workgroup of the resident-source GEMMs (0: launch_xgemm decides)
@@ -718,6 +719,85 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
     }
 }
 
+// ---- round 3, bf16 mode at large batch (default): the HYBRID SpatialTransformer.  The ResBlocks and q/k/v keep round 2's kernels
+// (channel-major fp32 between them, prep_kernel + token-major GEMM), everything from the attention output on runs on round 3's
+// token-major-activation kernels, where they are faster in situ: attention writes token-major bf16, attn1.to_out / band / attn2.to_out /
+// GEGLU / folded proj_out are xgemm launches (no second preparation kernel: GEGLU applies norm3 itself), and the folded proj_out writes
+// channel-major fp32 + GroupNorm partials again for the next ResBlock.  The token-major copy of the block's input (the residual of
+// attn1.to_out and of proj_out) is a by-product of the q/k/v operand preparation.  8 launches per block instead of 9.
+void run_transformer_hybrid(said_ctx* c, const UGeo& g, const STW& sw, int blk, const ActBuf& in, const ActBuf& out, hipStream_t s, bool shared) {
+    const int n1 = shared ? g.Bc : g.Be;
+    const int n2 = g.Bc > 0 ? g.Bc : g.Be;
+    const int x_off = (g.Bc > 0 && !shared) ? g.Bc : 0;
+    const int kv_off = g.Bc > 0 ? g.Bc : 0;
+    const long long seg = tm_seg(g);
+    const int vt_rows = rup(g.T, 32);
+    {   // q, k, v on round 2's token-major GEMM; the preparation kernel also leaves the raw input token-major (in.t)
+        PrepArgs p = mkprep(g, in.p, 1, c->uPL, (long long)tg_rows(g) * MC, MC, 0);
+        prep_gn(c, p, g, in.st, 6, 1e-6f, sw.gn_g, sw.gn_b, g.Be, 0, s);
+        p.ln_gamma = sw.l1g; p.ln_beta = sw.l1b;
+        p.dst2 = in.t; p.dst2_bs = seg * MC; p.ldd2 = MC; p.coff2 = 0;
+        do_prep(c, p, g.Be, s);   // (all samples: the second half's rows are the residual of proj_out)
+        TGemmArgs t = mktg(g, c->uPL, MC, tw(c, sw.t_qkv, sw.tf_qkv), 3 * MC, MC);
+        t.qk = c->QK; t.vt = c->VT; t.v_bs = (long long)MC * g.Tp; t.qk_n = 2 * MC; t.head_dim = HD; t.rows = vt_rows; t.heads2 = 2 * HEADS; t.v_pitch = g.Tp;
+        do_tgemm(c, t, n1, s);
+    }
+    {   // softmax(q k^T * scale) v -> token-major   (attention.py:99-126)
+        AttnArgs a;
+        a.qk = c->QK; a.v = c->VT; a.o = static_cast<float*>(c->tO);
+        a.v_bstride = (long long)MC * g.Tp; a.o_bstride = seg; a.o_mode = c->bf16_mode ? 2 : 1;
+        a.pitch = g.Tp; a.T = g.T; a.heads = HEADS; a.rows = vt_rows; a.b0 = 0;
+        a.scale = 0.17677669529663687f;
+        do_attn(c, a, n1, HD, -4, s);
+    }
+    {   // x1 = to_out(attn) + GroupNorm(x_in); under guidance also x2 of the unconditional half = x1 + c2
+        TGemmArgs t = mkx(g, tw(c, sw.t_out1, sw.tf_out1), MC, MC);
+        t.sa[0] = c->tO; t.sld[0] = MC; t.sk[0] = MC;
+        t.bias = sw.out1.bias;
+        t.res_tm = in.t; t.res_gn = 1; t.res_part = in.st; t.res_gamma = sw.gn_g; t.res_beta = sw.gn_b; t.res_eps = 1e-6f; t.gn_cpg = 6;
+        t.y_tm = c->tX1;
+        if (g.Bc > 0) { t.y2_tm = c->tX2; t.y2_row_off = 0; t.y2_add = c->c2[blk]; }
+        do_xgemm(c, t, n1, s);
+    }
+    {   // attn2: q = to_q(norm2(x1)); banded softmax over the precomputed audio K/V
+        TGemmArgs t = mkx(g, tw(c, sw.t_q2, sw.tf_q2), MC, MC);
+        t.ra[0] = tm_at(c, c->tX1, x_off * seg, MC); t.rmode = 2; t.rtaps = 1;
+        t.ln_gamma = sw.l2g; t.ln_beta = sw.l2b;
+        const long long kvbs = (long long)NST * 2 * MC * g.Sp;
+        t.band_k = c->KV + (long long)(blk * 2 * MC) * g.Sp + (long long)kv_off * kvbs;
+        t.band_v = c->KV + (long long)(blk * 2 * MC + MC) * g.Sp + (long long)kv_off * kvbs;
+        t.band_kv_bs = kvbs; t.band_kv_pitch = g.Sp; t.band_lo = c->band_lo; t.band_hi = c->band_hi; t.band_wmax = c->band_wmax;
+        t.band_scale = 0.17677669529663687f;
+        t.y_tm = tm_at(c, c->tO, x_off * seg, MC);
+        do_xgemm(c, t, n2, s);
+    }
+    {   // x2 = to_out(attn2) + x1   (conditional half only under guidance: its rows are [Bc, 2 Bc) of X2)
+        TGemmArgs t = mkx(g, tw(c, sw.t_out2, sw.tf_out2), MC, MC);
+        t.sa[0] = tm_at(c, c->tO, x_off * seg, MC); t.sld[0] = MC; t.sk[0] = MC;
+        t.bias = sw.out2.bias;
+        t.res_tm = tm_at(c, c->tX1, x_off * seg, MC);
+        t.y_tm = tm_at(c, c->tX2, kv_off * seg, MC);
+        do_xgemm(c, t, n2, s);
+    }
+    {   // GEGLU: proj(norm3(x2)) -> a * gelu(gate): the GEMM normalises its operand itself
+        TGemmArgs t = mkx(g, tw(c, sw.t_ff1, sw.tf_ff1), 2 * FFI, MC);
+        t.ra[0] = c->tX2; t.rmode = 2; t.rtaps = 1;
+        t.ln_gamma = sw.l3g; t.ln_beta = sw.l3b;
+        t.bias = sw.t_ff1_bias; t.geglu = 1;
+        t.yb = c->tF; t.y_bs = seg * FFI; t.ldy = FFI;
+        do_xgemm(c, t, g.Be, s);
+    }
+    {   // proj_out o ff.net.2 over [h ; x2] + x_in -> channel-major fp32 + GroupNorm partials for the next ResBlock
+        TGemmArgs t = mkx(g, tw(c, sw.t_ffproj, sw.tf_ffproj), MC, FFI + MC);
+        t.sa[0] = c->tF; t.sld[0] = FFI; t.sk[0] = FFI;
+        t.sa[1] = c->tX2; t.sld[1] = MC; t.sk[1] = MC;
+        t.bias = sw.ffproj.bias;
+        t.res_tm = in.t;
+        t.y_cm = out.p; t.cm_bs = g.hs; t.cm_pitch = g.Tp; t.stats = out.st;
+        do_xgemm(c, t, g.Be, s);
+    }
+}
+
 // shared: guidance-shared prefix — only the first g.Bc samples are computed, and the result is ALSO written into the
 // conditional half's slots (values only; its statistics are consumed by kernels that run on the first half alone)
 void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, const ActBuf& in0, const ActBuf* in1, const ActBuf& out, hipStream_t s,
@@ -820,6 +900,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     const int vt_rows = rup(g.T, 32);
     const long long obs = 2LL * MC * g.Tp;   // batch stride of O (shared with QK so attention uses one stride)
     const bool tg = use_tg(c, g, n1);
+    if (c->hybrid && c->bf16_mode && tg && use_tg(c, g, g.Be) && g.b0 == 0) { run_transformer_hybrid(c, g, sw, blk, in, out, s, shared); return; }
     if (tg) {   // q, k, v on the bf16 token-major GEMM: operand = LayerNorm(GroupNorm(x)) prepared once
         PrepArgs p = mkprep(g, in.p, 1, c->uPL, (long long)tg_rows(g) * MC, MC, 0);
         prep_gn(c, p, g, in.st, 6, 1e-6f, sw.gn_g, sw.gn_b, n1, 0, s);
@@ -1873,6 +1954,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
     } else if (k == "steps_per_graph") {
         if (value < 1) return fail(ctx, "steps_per_graph must be >= 1");
         ctx->spg_limit = (int)value;
+    } else if (k == "hybrid") {
+        ctx->hybrid = value != 0;
     } else if (k == "xgemm_clk") {   // shader-clock stamps of the token-major-activation GEMMs (-DSAID_CLK_STAMPS builds); read with said_debug_clocks
         ctx->xclk_on = value != 0;
     } else if (k == "xgemm_ntw") {
