@@ -50,6 +50,11 @@ int said_destroy(said_ctx* ctx);
  * with ONE model) does not pay load_state_dict + .to(device) again.  Synchronises the device. */
 int said_reserve(said_ctx* ctx, int max_batch_eff, int max_frames);
 int said_capacity(const said_ctx* ctx, int* max_batch_eff, int* max_frames);
+/* A second context on the same device that SHARES the parent's packed weights (read-only) and owns its own workspace, capture
+ * streams and step graph: two contexts can run said_denoise_loop concurrently on two streams.  The host wrapper uses it to run the
+ * two halves of a large batch as concurrent clip groups (a launch's phases — tile loads, MFMAs, result stores — then overlap
+ * across the groups: -3 % bf16 / -5 % fp32 per step at 32 clips).  No reference counterpart.  Destroy the clone BEFORE its parent. */
+int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_frames);
 const char* said_last_error(const said_ctx* ctx);
 /* ABI version of this library (bumped on any signature change). */
 int said_abi_version(void);
@@ -121,6 +126,7 @@ typedef struct said_loop_params {
     float* intermediates_dev;        /* (num_steps, B, T, C) or NULL */
     float* result_dev;               /* (B, T, C): clamp(latents / latent_scale, 0, 1) (diffusion.py:470) */
     uint64_t noise_seed;             /* use_step_noise == 2: Philox key of this call's eta noise */
+    int noise_batch_offset;          /* ... and the index of this call's first clip in the batch the noise is drawn for (clip groups) */
 } said_loop_params;
 
 /* columns of coef_host (all fp32, computed on the host in the scheduler's op order) */
@@ -138,6 +144,12 @@ enum {
 /* Runs the whole loop: per step one hipGraph replay covering the UNet, the CFG
  * combine, the scheduler update and the mask blend.  Asynchronous on `stream`. */
 int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream);
+
+/* Builds (warm-up, stream capture, instantiation) the step graph said_denoise_loop(ctx, p, stream) would need and launches
+ * none of the loop; returns at once when that graph exists.  Building synchronises `stream` and captures, which must not run
+ * while another host thread drives a second context: the host wrapper prepares both clip groups' contexts in turn before it
+ * starts their loops from two threads.  Same parameters (same intermediates_dev) as the loop call that follows. */
+int said_loop_prepare(said_ctx* ctx, const said_loop_params* p, void* stream);
 
 /* The standard normals the loop generates with use_step_noise == 2: out_dev (nsteps, B*T*C) <- noise of steps
  * step0 .. step0 + nsteps - 1 for `seed` (element index = ((b*T + t)*C + c)).  Replaces the `randn` drawn inside

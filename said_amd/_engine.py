@@ -18,7 +18,7 @@ _lib = None
 
 PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 NCOEF = 8
-ABI_VERSION = 4   # include/said_hip.h as bound below; a stale libsaid_hip.so is refused at load time
+ABI_VERSION = 5   # include/said_hip.h as bound below; a stale libsaid_hip.so is refused at load time
 
 
 class EngineError(RuntimeError):
@@ -34,6 +34,7 @@ class LoopParams(ctypes.Structure):
         ("context_dev", c_void_p), ("latents_dev", c_void_p), ("step_noise_dev", c_void_p),
         ("init_latents_dev", c_void_p), ("edit_noise_dev", c_void_p), ("mask_dev", c_void_p),
         ("intermediates_dev", c_void_p), ("result_dev", c_void_p), ("noise_seed", ctypes.c_uint64),
+        ("noise_batch_offset", c_int),
     ]
 
 
@@ -43,6 +44,8 @@ EXPORTS = {
     "said_destroy": (c_int, [c_void_p]),
     "said_reserve": (c_int, [c_void_p, c_int, c_int]),
     "said_capacity": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "said_clone": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int]),
+    "said_loop_prepare": (c_int, [c_void_p, POINTER(LoopParams), c_void_p]),
     "said_last_error": (c_char_p, [c_void_p]),
     "said_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
     "said_finalize_weights": (c_int, [c_void_p, c_void_p]),
@@ -120,7 +123,7 @@ def _stream() -> c_void_p:
 class Engine:
     """One engine context on one GPU (one process per GPU)."""
 
-    def __init__(self, device: torch.device, max_batch_eff: int, max_frames: int, in_channels: int = 32, ctx_dim: int = 768):
+    def __init__(self, device: torch.device, max_batch_eff: int, max_frames: int, in_channels: int = 32, ctx_dim: int = 768, _clone_of=None):
         self.lib = load_library()
         device = torch.device(device)
         if device.type != "cuda":
@@ -130,14 +133,31 @@ class Engine:
         self.max_batch_eff, self.max_frames = int(max_batch_eff), int(max_frames)
         self.in_channels, self.ctx_dim = in_channels, ctx_dim
         h = c_void_p()
-        rc = self.lib.said_create(ctypes.byref(h), self.index, self.max_batch_eff, self.max_frames, in_channels, ctx_dim)
-        if rc != 0:
-            raise EngineError("said_create: " + (self.lib.said_last_error(None) or b"?").decode())
+        self._parent = _clone_of   # a clone shares its parent's packed weights: keep the parent alive, destroy the clone first
+        if _clone_of is not None:
+            rc = self.lib.said_clone(_clone_of.h, ctypes.byref(h), self.max_batch_eff, self.max_frames)
+            if rc != 0:
+                raise EngineError("said_clone: " + (self.lib.said_last_error(_clone_of.h) or b"?").decode())
+        else:
+            rc = self.lib.said_create(ctypes.byref(h), self.index, self.max_batch_eff, self.max_frames, in_channels, ctx_dim)
+            if rc != 0:
+                raise EngineError("said_create: " + (self.lib.said_last_error(None) or b"?").decode())
         self.h = h
-        self.has_audio = False
+        self.has_audio = _clone_of.has_audio if _clone_of is not None else False
+        self._clones = []
         self._keep = []  # host buffers referenced by in-flight async copies
 
+    def clone(self, max_batch_eff: int, max_frames: int) -> "Engine":
+        """A context sharing this one's packed weights, with its own workspace and step graph (said_clone): for concurrent
+        denoising loops on a second stream.  Closed together with this engine."""
+        c = Engine(self.device, max_batch_eff, max_frames, self.in_channels, self.ctx_dim, _clone_of=self)
+        self._clones.append(c)
+        return c
+
     def close(self):
+        for c in getattr(self, "_clones", []):
+            c.close()      # clones first: they point into this context's weights
+        self._clones = []
         if getattr(self, "h", None):
             self.lib.said_destroy(self.h)
             self.h = None
@@ -210,13 +230,14 @@ class Engine:
                                                  context.shape[1], _ptr(out), _stream()), "said_unet_forward")
         return out
 
-    def denoise_loop(self, *, latents: torch.Tensor, context: torch.Tensor, timesteps: np.ndarray, coef: np.ndarray,
+    def loop_job(self, *, latents: torch.Tensor, context: torch.Tensor, timesteps: np.ndarray, coef: np.ndarray,
                      prediction_type: str, guidance_scale: float, guidance_rescale: float, latent_scale: float,
                      step_noise: Optional[torch.Tensor] = None, init_latents: Optional[torch.Tensor] = None,
                      edit_noise: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-                     save_intermediate: bool = False, noise_seed: Optional[int] = None):
-        """Returns (result, final_latents, intermediates or None).  `noise_seed` (with step_noise None): the eta noise is
-        generated inside the step's last kernel (Philox4x32-10 keyed by the seed) instead of being read from a tensor."""
+                     save_intermediate: bool = False, noise_seed: Optional[int] = None, noise_batch_offset: int = 0):
+        """Validates the arguments and allocates the outputs of one denoising loop (on the current stream): a job for
+        prepare_loop / run_loop.  `noise_seed` (with step_noise None): the eta noise is generated inside the step's last
+        kernel (Philox4x32-10 keyed by the seed) instead of being read from a tensor."""
         latents = _check_dev(latents, "latents").clone()
         context = _check_dev(context, "audio_embedding")
         B, T, C = latents.shape
@@ -245,6 +266,7 @@ class Engine:
         elif noise_seed is not None:
             p.use_step_noise = 2
             p.noise_seed = int(noise_seed) & 0xFFFFFFFFFFFFFFFF
+            p.noise_batch_offset = int(noise_batch_offset)
         if use_mask:
             init_latents = _check_dev(init_latents, "init_latents")
             edit_noise = _check_dev(edit_noise, "edit_noise")
@@ -254,10 +276,23 @@ class Engine:
         if inter is not None:
             p.intermediates_dev = inter.data_ptr()
         p.result_dev = result.data_ptr()
+        return p, keep, (result, latents, inter)
+
+    def prepare_loop(self, job):
+        """Builds the job's step graph if this context does not hold it yet (said_loop_prepare); launches nothing of the loop."""
         with torch.cuda.device(self.index):
-            self._chk(self.lib.said_denoise_loop(self.h, ctypes.byref(p), _stream()), "said_denoise_loop")
-        self._keep = keep  # alive until the next call (async copies / kernels may still reference them)
-        return result, latents, inter
+            self._chk(self.lib.said_loop_prepare(self.h, ctypes.byref(job[0]), _stream()), "said_loop_prepare")
+
+    def run_loop(self, job):
+        """Enqueues the job's loop on the current stream; returns (result, final_latents, intermediates or None)."""
+        with torch.cuda.device(self.index):
+            self._chk(self.lib.said_denoise_loop(self.h, ctypes.byref(job[0]), _stream()), "said_denoise_loop")
+        self._keep = job[1]  # alive until the next call (async copies / kernels may still reference them)
+        return job[2]
+
+    def denoise_loop(self, **kw):
+        """loop_job + run_loop: returns (result, final_latents, intermediates or None)."""
+        return self.run_loop(self.loop_job(**kw))
 
     def ddim_step(self, eps: torch.Tensor, sample: torch.Tensor, coef_row: np.ndarray, prediction_type: str,
                   eps_uncond: Optional[torch.Tensor] = None, guidance_scale: float = 1.0,

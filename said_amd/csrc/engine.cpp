@@ -73,6 +73,7 @@ struct said_ctx {
     std::vector<void*> ws_allocs;    // the (max_batch_eff, max_frames)-sized workspace: replaced as a whole by said_reserve
     std::vector<void*>* alloc_list = &allocs;
     bool finalized = false, has_audio = false, has_audio_proj = false;
+    bool is_clone = false;           // said_clone: the packed weights and tables belong to the parent context
     int w2v_layers = 0;
     int n_set_weight = 0;   // said_set_weight calls so far (tests: capacity growth must not re-upload the weights)
     int w2v_kernel[7] = {0}, w2v_stride[7] = {5, 2, 2, 2, 2, 2, 2};
@@ -1265,7 +1266,7 @@ int check_ready(said_ctx* ctx) {
 // ============================================================================================
 extern "C" {
 
-int said_abi_version(void) { return 4; }   // 4: said_reserve, said_loop_params::noise_seed, said_philox_normal, said_debug_option
+int said_abi_version(void) { return 5; }   // 5: said_clone, said_loop_params::noise_batch_offset; 4: said_reserve, noise_seed, said_philox_normal, said_debug_option
 
 const char* said_last_error(const said_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -1349,6 +1350,46 @@ int said_reserve(said_ctx* ctx, int max_batch_eff, int max_frames) {
     for (void* p : ctx->ws_allocs) (void)hipFree(p);
     ctx->ws_allocs.clear();
     if (alloc_workspace(ctx, std::max(max_batch_eff, ctx->maxBe), std::max(max_frames, ctx->maxT))) return -1;
+    return 0;
+}
+
+int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_frames) {
+    if (!out) return fail(parent, "said_clone: out is null");
+    *out = nullptr;
+    if (check_ready(parent)) return -1;
+    if (max_batch_eff < 1 || max_frames < 1) return fail(parent, "said_clone: bad sizes");
+    DeviceRestore restore_device;
+    {
+        said_ctx* ctx = parent;
+        HIPCHK(hipSetDevice(parent->device));
+    }
+    // a copy of the parent: every packed weight / table pointer is SHARED (read-only on the device); everything a run writes is its own
+    said_ctx* c = new said_ctx(*parent);
+    c->err.clear(); c->launch_err.clear(); c->host_w.clear();
+    c->allocs.clear(); c->ws_allocs.clear(); c->alloc_list = &c->allocs;
+    c->is_clone = true;
+    c->graph = c->graph_rem = nullptr; c->gexec = c->gexec_rem = nullptr; c->gkey.clear(); c->gnodes = 0;
+    c->cap_stream = c->cap_stream2 = nullptr; c->ev_fork = c->ev_join = nullptr;
+    c->stage_log.clear(); c->log_on = false; c->dbg_stop = -1; c->dbg_only = -1; c->dbg_count = 0; c->clk_on = false; c->xclk_on = false;
+    // lazily grown buffers start empty
+    c->abufA = c->abufB = nullptr; c->abuf_elems[0] = c->abuf_elems[1] = 0;
+    c->aH = c->aT = c->aO = c->aQK = c->aVT = c->aF = c->aPOS = c->aX = nullptr; c->a_tok_elems = 0;
+    c->bA0 = c->bA1 = c->bX = c->bHb = c->bF = c->bO = nullptr; c->bH = c->bT = c->bPosT = nullptr; c->b_conv_elems[0] = c->b_conv_elems[1] = 0; c->b_tok = 0;
+    c->bXg = nullptr; c->bXg_elems = 0;
+    c->noise_cm = nullptr; c->noise_cm_elems = 0;
+    said_ctx* ctx = c;
+    auto bail = [&](const char* what) { parent->err = std::string("said_clone: ") + what + (c->err.empty() ? "" : ": " + c->err); said_destroy(c); return -1; };
+    if (hipStreamCreateWithFlags(&c->cap_stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess)
+        return bail("stream / event creation failed");
+    int rc = 0;
+    rc |= dalloc(ctx, &c->coef1_dev, 8);
+    rc |= dalloc(ctx, &c->step_dev, 4);
+    rc |= dalloc(ctx, &c->seed_dev, 4);
+    rc |= dalloc(ctx, &c->clk_dev, 64 * 128);
+    rc |= alloc_workspace(c, max_batch_eff, max_frames);
+    if (rc) return bail("workspace allocation failed");
+    *out = c;
     return 0;
 }
 
@@ -1729,7 +1770,20 @@ int said_unet_forward(said_ctx* ctx, const float* sample_dev, const int64_t* tim
 // --------------------------------------------------------------------------------------------
 // SAID.inference loop
 // --------------------------------------------------------------------------------------------
-int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
+// What the captured step graph depends on (everything else it reads from device memory at replay time).
+static std::vector<long long> loop_graph_key(const said_ctx* ctx, const said_loop_params* p, const float* noise_cm) {
+    const bool cfg = p->guidance_scale > 1.0f;
+    float gs = p->guidance_scale, gr = (cfg && p->guidance_rescale > 0.f) ? p->guidance_rescale : 0.f, ls = p->latent_scale;
+    int gsi, gri, lsi;
+    memcpy(&gsi, &gs, 4); memcpy(&gri, &gr, 4); memcpy(&lsi, &ls, 4);
+    int spg = std::min(ctx->spg_limit, p->num_steps);
+    if (ctx->use_branches) spg = 1;
+    const int rem = spg > 0 ? p->num_steps % spg : 0;
+    return {spg, rem, p->batch, p->frames, cfg, gsi, gri, lsi, p->prediction_type, p->use_mask, p->use_step_noise, ctx->bf16_mode, p->noise_batch_offset,
+            (long long)(uintptr_t)(p->save_intermediate ? p->intermediates_dev : nullptr), (long long)(uintptr_t)(p->use_step_noise == 1 ? noise_cm : nullptr)};
+}
+
+static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, bool prepare_only) {
     if (check_ready(ctx)) return -1;
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
@@ -1745,6 +1799,11 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     if (p->use_step_noise == 1 && !p->step_noise_dev) return fail(ctx, "use_step_noise = 1 needs step_noise_dev");
     if (p->use_step_noise < 0 || p->use_step_noise > 2) return fail(ctx, "bad use_step_noise %d", p->use_step_noise);
     if (p->save_intermediate && !p->intermediates_dev) return fail(ctx, "save_intermediate needs intermediates_dev");
+    if (prepare_only) {   // nothing to do when the step graph of this configuration exists
+        if (N == 0) return 0;
+        const bool grow = p->use_step_noise == 1 && (size_t)N * B * C * (size_t)rup(T, 32) > ctx->noise_cm_elems;
+        if (!grow && ctx->gexec && loop_graph_key(ctx, p, ctx->noise_cm) == ctx->gkey) return 0;
+    }
     if (set_band(ctx, T, T, s)) return -1;
     UGeo g = make_geo(ctx, Be, cfg ? B : 0, T, T);
     g.step_ptr = ctx->step_dev;
@@ -1798,6 +1857,7 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     sa.coef = ctx->coef_dev; sa.step_ptr = ctx->step_dev; sa.x = ctx->x_cm; sa.x_bstride = xs;
     sa.step_noise = p->use_step_noise == 1 ? ctx->noise_cm : nullptr;
     sa.noise_seed = p->use_step_noise == 2 ? ctx->seed_dev : nullptr;
+    sa.noise_elem0 = (unsigned)((long long)p->noise_batch_offset * T * C);
     sa.init = p->use_mask ? ctx->init_cm : nullptr; sa.edit_noise = p->use_mask ? ctx->enoise_cm : nullptr;
     sa.mask = p->use_mask ? ctx->mask_cm : nullptr;
     sa.inter = p->save_intermediate ? p->intermediates_dev : nullptr; sa.latent_scale = p->latent_scale;
@@ -1806,7 +1866,7 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     memset(&osa, 0, sizeof osa);
     osa.x = ctx->P.p; osa.gn_part = ctx->P.st; osa.gn_gamma = ctx->out_g; osa.gn_beta = ctx->out_b;
     osa.w4 = ctx->conv_out.w4[0]; osa.bias = ctx->conv_out.bias; osa.coef = ctx->coef_dev; osa.step_ptr = ctx->step_dev;
-    osa.lat = ctx->x_cm; osa.step_noise = sa.step_noise; osa.noise_seed = sa.noise_seed; osa.init = sa.init; osa.edit_noise = sa.edit_noise; osa.mask = sa.mask;
+    osa.lat = ctx->x_cm; osa.step_noise = sa.step_noise; osa.noise_seed = sa.noise_seed; osa.noise_elem0 = sa.noise_elem0; osa.init = sa.init; osa.edit_noise = sa.edit_noise; osa.mask = sa.mask;
     osa.inter = sa.inter; osa.x_bstride = g.hs; osa.gn_part_bstride = g.sts; osa.lat_bstride = xs;
     osa.pitch = g.Tp; osa.T = T; osa.B = B; osa.Cin = MC; osa.Cout = C; osa.gn_nparts = g.np; osa.cfg = cfg ? 1 : 0;
     osa.prediction_type = p->prediction_type; osa.guidance_scale = p->guidance_scale; osa.guidance_rescale = sa.guidance_rescale;
@@ -1816,17 +1876,13 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     if (fused) g.out_sched = &osa;
 
     if (N > 0) {
-        float gs = p->guidance_scale, gr = sa.guidance_rescale, ls = p->latent_scale;
-        int gsi, gri, lsi;
-        memcpy(&gsi, &gs, 4); memcpy(&gri, &gr, 4); memcpy(&lsi, &ls, 4);
         // steps per graph: consecutive denoise steps captured back to back in ONE graph (the device-side step counter
         // makes the copies distinct): N / spg launches of the spg-step graph cover the loop, and a second graph holding
         // the N % spg remaining steps finishes it (prime N, e.g. 997 = 99 x 10 + 7)
         int spg = std::min(ctx->spg_limit, N);   // measured: ~6 us per graph launch boundary; 10 steps per graph recover 1.2 % at B=1
         if (ctx->use_branches) spg = 1;
         const int rem = N % spg;
-        std::vector<long long> key = {spg, rem, B, T, cfg, gsi, gri, lsi, p->prediction_type, p->use_mask, p->use_step_noise, ctx->bf16_mode,
-                                      (long long)(uintptr_t)sa.inter, (long long)(uintptr_t)sa.step_noise};
+        const std::vector<long long> key = loop_graph_key(ctx, p, sa.step_noise);
         if (!ctx->gexec || key != ctx->gkey) {
             drop_graphs(ctx);
             const bool fold_step = !(ctx->use_branches && Be >= 2);   // conv_in advances the step counter itself
@@ -1888,6 +1944,7 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
             ctx->gkey = key;
             TRACE("loop: graph instantiated");
         }
+        if (prepare_only) return 0;
         for (int k = 0; k < N / ctx->gspg; ++k) HIPCHK(hipGraphLaunch(ctx->gexec, s));
         if (rem > 0) HIPCHK(hipGraphLaunch(ctx->gexec_rem, s));
     }
@@ -1897,6 +1954,10 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) {
     HIPCHK(hipGetLastError());
     return 0;
 }
+
+int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream) { return loop_impl(ctx, p, stream, false); }
+
+int said_loop_prepare(said_ctx* ctx, const said_loop_params* p, void* stream) { return loop_impl(ctx, p, stream, true); }
 
 int said_ddim_step(said_ctx* ctx, const float* eps_dev, const float* eps_uncond_dev, float guidance_scale,
                    const float* sample_dev, const float* coef_host, int prediction_type, const float* step_noise_dev,

@@ -195,6 +195,7 @@ struct SchedArgs {
     float* inter;              // token-major (nsteps, B, T, C) or null: pre-step latents / latent_scale
     float latent_scale;
     const unsigned* noise_seed;   // device [2] Philox key: the eta noise is generated in the kernel (sched_math.h), or null
+    unsigned noise_elem0;         // element index of this call's first clip in the whole batch (clip groups on concurrent streams draw the noise of ONE batch)
 };
 void launch_sched_step(const SchedArgs& a, hipStream_t s);
 
@@ -220,6 +221,7 @@ struct OutSchedArgs {
     int prediction_type;
     float guidance_scale, guidance_rescale, latent_scale;
     const unsigned* noise_seed;   // device [2] Philox key: eta noise generated in the kernel (sched_math.h), or null
+    unsigned noise_elem0;         // see SchedArgs
 };
 bool out_sched_supports(const OutSchedArgs& a);
 void launch_out_sched(const OutSchedArgs& a, hipStream_t s);

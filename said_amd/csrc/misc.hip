@@ -232,7 +232,7 @@ __global__ void sched_step_kernel(const SchedArgs a) {
         const float nz = a.step_noise[((long long)step * a.B + b) * a.x_bstride + off];
         prev = __fadd_rn(prev, __fmul_rn(cf[4], nz));
     } else if (a.noise_seed) {
-        prev = __fadd_rn(prev, __fmul_rn(cf[4], philox_normal(a.noise_seed[0], a.noise_seed[1], (unsigned)step, (unsigned)((b * a.T + t) * a.C + c))));
+        prev = __fadd_rn(prev, __fmul_rn(cf[4], philox_normal(a.noise_seed[0], a.noise_seed[1], (unsigned)step, a.noise_elem0 + (unsigned)((b * a.T + t) * a.C + c))));
     }
     if (a.mask) {
         const long long o2 = (long long)b * a.x_bstride + off;

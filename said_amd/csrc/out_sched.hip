@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
         if (a.inter) a.inter[(((long long)step * a.B + b) * T + t) * a.Cout + n] = x / a.latent_scale;
         float prev = ddim_prev(e, x, cfv, a.prediction_type);
         if (a.step_noise) prev = __fadd_rn(prev, __fmul_rn(cfv[4], e_nz[j]));
-        else if (a.noise_seed) prev = __fadd_rn(prev, __fmul_rn(cfv[4], philox_normal(a.noise_seed[0], a.noise_seed[1], (unsigned)step, (unsigned)((b * T + t) * a.Cout + n))));
+        else if (a.noise_seed) prev = __fadd_rn(prev, __fmul_rn(cfv[4], philox_normal(a.noise_seed[0], a.noise_seed[1], (unsigned)step, a.noise_elem0 + (unsigned)((b * T + t) * a.Cout + n))));
         if (a.mask) prev = mask_blend(prev, e_in[j], e_en[j], e_mk[j], cfv);
         latp[(long long)n * a.pitch + t] = prev;
     }

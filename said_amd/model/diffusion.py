@@ -15,6 +15,7 @@ so a CPU oracle and the GPU path can be fed identical noise.
 """
 from __future__ import annotations
 
+import threading
 import weakref
 from abc import ABC
 from dataclasses import dataclass
@@ -81,6 +82,9 @@ class SAID(ABC, nn.Module):
         self._eng_stale = True
         self._param_list = None
         self.mfma_dtype = "fp32"   # "bf16": bf16 multiplies in the UNet GEMMs (BASELINE.json configs[2]); set_mfma_dtype()
+        self.clip_groups = None     # None: decided per call (two concurrent groups for large even batches); 1: never split; 2: always
+        self._eng2: Optional[_engine.Engine] = None
+        self._side_stream = None
         self.audio_encoder._owner = weakref.ref(self)
 
     # ---- engine management ---------------------------------------------------
@@ -123,6 +127,7 @@ class SAID(ABC, nn.Module):
             e = _engine.Engine(dev, cap_b, cap_t, self.denoiser.in_channels, ctx_dim)
             e.load_weights(self.state_dict())
             self._eng, self._eng_key, self._eng_stale = e, self._weights_key(), False
+            self._eng2 = None      # (closed with the old engine)
             self.noise_scheduler._engine = e
         elif e.max_batch_eff < batch_eff or e.max_frames < frames:
             # a larger batch or a longer clip: only the workspace grows, the packed weights stay where they are
@@ -236,12 +241,76 @@ class SAID(ABC, nn.Module):
                 # (N, B, T, 32) noise tensor exists — 2.46 GB at B = 32, N = 1000.
                 noise_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
         use_mask = init_samples is not None and mask is not None
-        result, _, inter = eng.denoise_loop(
-            latents=latents, context=audio_embedding, timesteps=ts, coef=coef,
-            prediction_type=sch.config.prediction_type, guidance_scale=guidance_scale, guidance_rescale=guidance_rescale,
-            latent_scale=self.latent_scale, step_noise=noise_steps, noise_seed=noise_seed,
-            init_latents=init_lat if use_mask else None, edit_noise=noise if use_mask else None,
-            mask=mask.to(device) if use_mask else None, save_intermediate=save_intermediate)
+        mask_d = mask.to(device) if use_mask else None
+        if mask_d is not None and mask_d.shape != latents.shape:
+            mask_d = mask_d.expand_as(latents)
+        kw = dict(timesteps=ts, coef=coef, prediction_type=sch.config.prediction_type, guidance_scale=guidance_scale,
+                  guidance_rescale=guidance_rescale, latent_scale=self.latent_scale, save_intermediate=save_intermediate, noise_seed=noise_seed)
+
+        def job(e, lo, hi):
+            sl = slice(lo, hi)
+            return e.loop_job(latents=latents[sl], context=audio_embedding[sl],
+                              step_noise=None if noise_steps is None else noise_steps[:, sl].contiguous(),
+                              init_latents=init_lat[sl] if use_mask else None, edit_noise=noise[sl] if use_mask else None,
+                              mask=mask_d[sl] if use_mask else None, noise_batch_offset=lo, **kw)
+
+        # Clip groups: a large even batch runs as TWO half-batches on two streams (a second engine context sharing the packed
+        # weights: said_clone).  One launch is a single wave of workgroups that load, multiply and store in lockstep; two
+        # concurrent loops interleave those phases: -3 % (bf16) / -5 % (fp32) per step at 32 clips x 600 frames on one MI355X.
+        # The results are those of the half-batches run alone (bit-identical to the whole batch in bf16 mode; fp32's tile choice
+        # depends on the launch size, so there the sums differ in their last bits).  The eta noise is drawn for the whole batch.
+        half = batch_size // 2
+        per_group = (2 if do_cfg else 1) * half * window_size
+        groups = self.clip_groups if self.clip_groups in (1, 2) else (2 if (batch_size % 2 == 0 and per_group >= 16000) else 1)
+        if groups == 2 and batch_size % 2 == 0 and n_run > 0:
+            be = 2 * half if do_cfg else half
+            e2 = self._eng2
+            if e2 is None or e2.h is None or e2.max_batch_eff < be or e2.max_frames < window_size:
+                if e2 is not None and e2.h is not None:
+                    e2.reserve(max(be, e2.max_batch_eff), max((window_size + 63) // 64 * 64, e2.max_frames))
+                else:
+                    e2 = self._eng2 = eng.clone(be, (window_size + 63) // 64 * 64)
+            e2.set_precision(self.mfma_dtype == "bf16")
+            main = torch.cuda.current_stream(device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device)
+            side = self._side_stream
+            side.wait_stream(main)                       # the inputs were produced on the caller's stream
+            # Outputs are allocated and both step graphs built here, in turn (stream capture and the allocator's hipMalloc must
+            # not run beside another thread's launches); then the second group is ENQUEUED from its own host thread: a 1000-step
+            # loop is 100 graph launches, more than a stream's queue takes without blocking the caller, so one thread would
+            # enqueue (and the GPU run) the groups one after the other.  (ctypes releases the GIL inside said_denoise_loop.)
+            j0 = job(eng, 0, half)
+            eng.prepare_loop(j0)
+            with torch.cuda.stream(side):
+                j1 = job(e2, half, batch_size)
+                e2.prepare_loop(j1)
+            box = {}
+
+            def second():
+                try:
+                    with torch.cuda.device(device), torch.cuda.stream(side):
+                        box["r"] = e2.run_loop(j1)
+                except BaseException as ex:   # re-raised on the caller's thread
+                    box["e"] = ex
+
+            th = threading.Thread(target=second, name="said-clip-group-1")
+            th.start()
+            try:
+                r0 = eng.run_loop(j0)
+            finally:
+                th.join()
+            if "e" in box:
+                raise box["e"]
+            r1 = box["r"]
+            main.wait_stream(side)
+            for t in (r1[0], r1[2]):                    # allocated on the side stream, consumed on the caller's
+                if t is not None:
+                    t.record_stream(main)
+            result = torch.cat([r0[0], r1[0]])
+            inter = torch.cat([r0[2], r1[2]], dim=1) if save_intermediate else None
+        else:
+            result, _, inter = eng.run_loop(job(eng, 0, batch_size))
         intermediates = [inter[k] for k in range(n_run)] if save_intermediate else []
         return SAIDInferenceOutput(result=result, intermediates=intermediates)
 

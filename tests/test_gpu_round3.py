@@ -384,3 +384,66 @@ def test_token_major_activation_schedule_opt_in_vs_oracle(model, unet_sd, sd_ful
     finally:
         model._eng.debug_option("tm_acts", 0)
         model.set_mfma_dtype("fp32")
+
+
+# ---------------------------------------------------------------- clip groups: two half-batches on two streams (said_clone)
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_clip_groups_two_streams_equal_whole_batch(model, dev, mode):
+    """SAID.inference splits a large even batch into two concurrent half-batches (second context sharing the weights, second
+    stream).  Same samples as the unsplit batch: eta noise included (the device generator is offset by the group's first clip),
+    intermediates included.  32 clips x 10 s is the size at which the split is the default."""
+    B, Ta, N = 32, 160000, 6
+    T = 600
+    proc = op.process_audio([synth.synth_waveform(300 + i, Ta).numpy() for i in range(B)]).to(dev)
+    lat = synth.synth_latents(77, (B, T, 32)).to(dev)
+    model.set_mfma_dtype(mode)
+    try:
+        emb = model.get_audio_embedding(proc, T)
+        out = {}
+        for g in (1, 2, None):
+            model.clip_groups = g
+            torch.manual_seed(11)
+            out[g] = model.inference(proc, num_inference_steps=N, guidance_scale=2.0, eta=1.0, init_latents=lat, audio_embedding=emb,
+                                     save_intermediate=True)
+        assert model._eng2 is not None and model._eng.debug_get("n_set_weight") > 0 and model._eng2.debug_get("n_set_weight") == model._eng.debug_get("n_set_weight")
+        assert torch.equal(out[2].result, out[None].result)          # the default at this size IS two groups
+        a, b = out[1], out[2]
+        d = float((a.result - b.result).abs().max())
+        di = max(float((x - y).abs().max()) for x, y in zip(a.intermediates, b.intermediates))
+        print(f"clip groups {mode}: max |whole - split| result {d:.3e}, intermediates {di:.3e}")
+        assert len(b.intermediates) == N and b.intermediates[0].shape == (B, T, 32)
+        if mode == "bf16":
+            assert d == 0.0 and di == 0.0
+        else:
+            assert d <= 1e-4 and di <= 5e-4      # fp32's GEMM tile depends on the launch size: other summation order
+    finally:
+        model.clip_groups = None
+        model.set_mfma_dtype("fp32")
+
+
+def test_clip_groups_forced_small_edit_vs_oracle(model, sd_full, dev):
+    """The split forced on a small editing job (mask + init_samples + eta noise): against the oracle fed the same noise."""
+    B, Ta, N = 2, 16000, 7
+    T = 60
+    wav = [synth.synth_waveform(500 + i, Ta).numpy() for i in range(B)]
+    proc = op.process_audio(wav)
+    lat = synth.synth_latents(78, (B, T, 32))
+    init = synth.synth_latents(79, (B, T, 32)).abs().clamp(0, 1)
+    mask = torch.zeros(B, T, 32)
+    mask[:, 20:40] = 1
+    emb = model.get_audio_embedding(proc.to(dev), T)
+    model.clip_groups = 2
+    try:
+        torch.manual_seed(3)
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))   # the one draw SAID.inference makes from torch's generator
+        torch.manual_seed(3)
+        r = model.inference(proc.to(dev), num_inference_steps=N, guidance_scale=2.0, eta=1.0, edit_noise=lat.to(dev), audio_embedding=emb,
+                            init_samples=init.to(dev), mask=mask.to(dev), strength=1.0).result
+    finally:
+        model.clip_groups = None
+    sn = model._eng.philox_normal(seed, 0, N, (B, T, 32)).cpu()
+    ref = op.inference(sd_full, proc, init_latents=lat, edit_noise=lat, num_inference_steps=N, guidance_scale=2.0, eta=1.0, step_noise=sn,
+                       audio_embedding=emb.cpu(), init_samples=init, mask=mask, strength=1.0)
+    err = float((r.cpu() - ref.result).abs().max())
+    print(f"forced clip groups, edit + eta: max abs err vs oracle {err:.3e}")
+    assert err <= 2e-3
