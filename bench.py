@@ -50,9 +50,9 @@ def parse():
     p.add_argument("--edit", action="store_true",
                    help="editing mode (BASELINE configs[4]: --seconds 30 --num_steps 100 --edit): init_samples + in-betweening mask "
                         "(middle third regenerated, 4 channels pinned), mask blend with the re-noised init every step")
-    p.add_argument("--clip_groups", type=int, default=0, choices=[0, 1, 2],
-                   help="0 (default): SAID.inference decides (two concurrent half-batches on two streams for large even batches); "
-                        "1: never split; 2: always split an even batch")
+    p.add_argument("--clip_groups", type=int, default=0,
+                   help="0 (default): SAID.inference decides (two concurrent half-batches on two streams for large batches); "
+                        "n >= 1: run every batch as n concurrent clip groups (1: never split)")
     p.add_argument("--tm_acts", action="store_true",
                    help="experimental large-batch schedule (said_debug_option tm_acts = 1): token-major activations between the UNet kernels, "
                         "normalisation inside the consuming GEMMs, 41 launches per step")
@@ -347,7 +347,7 @@ def run_secondary(model, dev, gs):
                      "clips_per_s": round(B / dt, 4), "realtime_factor": round(B * T / dt / 60.0, 2),
                      "ms_per_denoise_step": round(step_ms, 4), "dtype": c["dtype"], "workload": c["workload"],
                      "command": "python bench.py " + c["flags"], "graph_nodes_per_step": model._eng.graph_num_nodes(), "roofline": rf,
-                     "clip_groups": 2 if (model.clip_groups in (None, 2) and B % 2 == 0 and (model.clip_groups == 2 or Be * T // 2 >= 16000)) else 1}
+                     "clip_groups": model._pick_clip_groups(B, Be // B * T)}
     model.set_mfma_dtype("fp32")
     return out
 

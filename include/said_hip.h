@@ -55,6 +55,10 @@ int said_capacity(const said_ctx* ctx, int* max_batch_eff, int* max_frames);
  * two halves of a large batch as concurrent clip groups (a launch's phases — tile loads, MFMAs, result stores — then overlap
  * across the groups: -3 % bf16 / -5 % fp32 per step at 32 clips).  No reference counterpart.  Destroy the clone BEFORE its parent. */
 int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_frames);
+
+/* The non-blocking stream a clone owns (NULL for a context made by said_create): the clone's loops are meant to run on it.
+ * It is the one extra live stream a clip group costs; a live stream occupies one of the device's few hardware queues. */
+void* said_stream(const said_ctx* ctx);
 const char* said_last_error(const said_ctx* ctx);
 /* ABI version of this library (bumped on any signature change). */
 int said_abi_version(void);

@@ -45,6 +45,7 @@ EXPORTS = {
     "said_reserve": (c_int, [c_void_p, c_int, c_int]),
     "said_capacity": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "said_clone": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int]),
+    "said_stream": (c_void_p, [c_void_p]),
     "said_loop_prepare": (c_int, [c_void_p, POINTER(LoopParams), c_void_p]),
     "said_last_error": (c_char_p, [c_void_p]),
     "said_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
@@ -146,6 +147,8 @@ class Engine:
         self.has_audio = _clone_of.has_audio if _clone_of is not None else False
         self._clones = []
         self._keep = []  # host buffers referenced by in-flight async copies
+        sp = self.lib.said_stream(self.h) if _clone_of is not None else None
+        self.stream = torch.cuda.ExternalStream(sp, device=self.device) if sp else None   # a clone's own stream
 
     def clone(self, max_batch_eff: int, max_frames: int) -> "Engine":
         """A context sharing this one's packed weights, with its own workspace and step graph (said_clone): for concurrent

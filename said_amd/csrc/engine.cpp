@@ -164,6 +164,7 @@ struct said_ctx {
 
     // ---- per-step graph ----
     hipStream_t cap_stream = nullptr;  // private stream used only to capture the per-step graph
+    hipStream_t own_stream = nullptr;  // a clone's stream (said_stream): the one extra live stream a clip group costs
     hipGraph_t graph = nullptr, graph_rem = nullptr;       // `gspg` consecutive steps / the N % gspg remaining steps
     hipGraphExec_t gexec = nullptr, gexec_rem = nullptr;
     std::vector<long long> gkey;
@@ -188,6 +189,7 @@ int fail(said_ctx* c, const char* fmt, ...) {
 }
 
 static bool trace_on() { static int v = -1; if (v < 0) v = dev_env("SAID_TRACE") ? 1 : 0; return v == 1; }
+
 #define TRACE(msg) do { if (trace_on()) { fprintf(stderr, "[said] %s:%d %s\n", __FILE__, __LINE__, msg); fflush(stderr); } } while (0)
 
 #define HIPCHK(expr)                                                                                  \
@@ -195,6 +197,26 @@ static bool trace_on() { static int v = -1; if (v < 0) v = dev_env("SAID_TRACE")
         hipError_t _e = (expr);                                                                       \
         if (_e != hipSuccess) return fail(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
+
+// The capture streams exist only while a graph is being built: a live stream holds one of the device's few hardware queues
+// (four by default), and streams beyond that count share queues, which serialises launches the caller meant to run side by
+// side (the clip groups' loops).
+static int ensure_cap_streams(said_ctx* ctx) {
+    if (!ctx->cap_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
+    if (ctx->use_branches) {
+        if (!ctx->cap_stream2) HIPCHK(hipStreamCreateWithFlags(&ctx->cap_stream2, hipStreamNonBlocking));
+        if (!ctx->ev_fork) HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        if (!ctx->ev_join) HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    return 0;
+}
+static void release_cap_streams(said_ctx* ctx) {
+    if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
+    if (ctx->cap_stream2) (void)hipStreamDestroy(ctx->cap_stream2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    ctx->cap_stream = ctx->cap_stream2 = nullptr; ctx->ev_fork = ctx->ev_join = nullptr;
+}
 
 // a schedule function's kernel refused its shape (nothing was launched for it): report instead of continuing
 #define LAUNCHCHK()                                                                                   \
@@ -1306,10 +1328,6 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     ctx->unet_fgemm = dev_env("SAID_NO_UNET_FGEMM") == nullptr;
     if (dev_env("SAID_UNET_TGEMM_MIN")) ctx->unet_tgemm_min_tokens = ctx->unet_fgemm_min_tokens = atoll(dev_env("SAID_UNET_TGEMM_MIN"));
     configure_tgemm_kernel();
-    if (hipStreamCreateWithFlags(&ctx->cap_stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return fail(nullptr, "stream/event creation failed"); }
-    if (hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, "hipStreamCreateWithFlags failed"); }
 
     int rc = 0;
     rc |= dalloc(ctx, &ctx->coef1_dev, 8);
@@ -1328,10 +1346,8 @@ int said_destroy(said_ctx* ctx) {
     DeviceRestore restore_device;
     (void)hipSetDevice(ctx->device);
     drop_graphs(ctx);
-    if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
-    if (ctx->cap_stream2) (void)hipStreamDestroy(ctx->cap_stream2);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    release_cap_streams(ctx);
     for (void* p : ctx->allocs) (void)hipFree(p);
     for (void* p : ctx->ws_allocs) (void)hipFree(p);
     delete ctx;
@@ -1369,7 +1385,7 @@ int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_fram
     c->allocs.clear(); c->ws_allocs.clear(); c->alloc_list = &c->allocs;
     c->is_clone = true;
     c->graph = c->graph_rem = nullptr; c->gexec = c->gexec_rem = nullptr; c->gkey.clear(); c->gnodes = 0;
-    c->cap_stream = c->cap_stream2 = nullptr; c->ev_fork = c->ev_join = nullptr;
+    c->cap_stream = c->cap_stream2 = nullptr; c->ev_fork = c->ev_join = nullptr; c->own_stream = nullptr;
     c->stage_log.clear(); c->log_on = false; c->dbg_stop = -1; c->dbg_only = -1; c->dbg_count = 0; c->clk_on = false; c->xclk_on = false;
     // lazily grown buffers start empty
     c->abufA = c->abufB = nullptr; c->abuf_elems[0] = c->abuf_elems[1] = 0;
@@ -1379,9 +1395,7 @@ int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_fram
     c->noise_cm = nullptr; c->noise_cm_elems = 0;
     said_ctx* ctx = c;
     auto bail = [&](const char* what) { parent->err = std::string("said_clone: ") + what + (c->err.empty() ? "" : ": " + c->err); said_destroy(c); return -1; };
-    if (hipStreamCreateWithFlags(&c->cap_stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess)
-        return bail("stream / event creation failed");
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreateWithFlags failed");
     int rc = 0;
     rc |= dalloc(ctx, &c->coef1_dev, 8);
     rc |= dalloc(ctx, &c->step_dev, 4);
@@ -1392,6 +1406,8 @@ int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_fram
     *out = c;
     return 0;
 }
+
+void* said_stream(const said_ctx* ctx) { return ctx ? (void*)ctx->own_stream : nullptr; }
 
 int said_capacity(const said_ctx* ctx, int* max_batch_eff, int* max_frames) {
     if (!ctx) return -1;
@@ -1904,6 +1920,7 @@ static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, boo
             TRACE("loop: warmup synced");
             // capture on a private stream: the caller's stream may be the legacy default stream,
             // which cannot be captured; the instantiated graph is then replayed on the caller's stream
+            if (ensure_cap_streams(ctx)) return -1;
             hipStream_t cs = ctx->cap_stream;
             auto capture_steps = [&](int nsteps, hipGraph_t* gr, hipGraphExec_t* ge) -> int {
                 HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
@@ -1942,6 +1959,7 @@ static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, boo
             ctx->gnodes = (int)nn / spg;
             ctx->gspg = spg;
             ctx->gkey = key;
+            release_cap_streams(ctx);
             TRACE("loop: graph instantiated");
         }
         if (prepare_only) return 0;
@@ -2092,6 +2110,7 @@ int said_profile_unet(said_ctx* ctx, int Be, int T, int cfg_clips, int reps, int
     if (cfg_clips > 0 && ctx->cfg_share && !ctx->use_branches) g.Bc = cfg_clips;   // the schedule the guided loop runs
     run_unet(ctx, g, s);  // eager warm-up: kernels must not see their first launch inside a capture
     HIPCHK(hipStreamSynchronize(s));
+    if (ensure_cap_streams(ctx)) return -1;
     // pass 0: log the schedule without launching anything
     ctx->stage_log.clear();
     ctx->log_on = true; ctx->dbg_only = -1; ctx->dbg_stop = 0; ctx->dbg_count = 0;

@@ -82,9 +82,8 @@ class SAID(ABC, nn.Module):
         self._eng_stale = True
         self._param_list = None
         self.mfma_dtype = "fp32"   # "bf16": bf16 multiplies in the UNet GEMMs (BASELINE.json configs[2]); set_mfma_dtype()
-        self.clip_groups = None     # None: decided per call (two concurrent groups for large even batches); 1: never split; 2: always
-        self._eng2: Optional[_engine.Engine] = None
-        self._side_stream = None
+        self.clip_groups = None     # None: decided per call (_pick_clip_groups); n >= 1: that many concurrent clip groups
+        self._clones: List[_engine.Engine] = []
         self.audio_encoder._owner = weakref.ref(self)
 
     # ---- engine management ---------------------------------------------------
@@ -127,7 +126,7 @@ class SAID(ABC, nn.Module):
             e = _engine.Engine(dev, cap_b, cap_t, self.denoiser.in_channels, ctx_dim)
             e.load_weights(self.state_dict())
             self._eng, self._eng_key, self._eng_stale = e, self._weights_key(), False
-            self._eng2 = None      # (closed with the old engine)
+            self._clones = []      # (closed with the old engine)
             self.noise_scheduler._engine = e
         elif e.max_batch_eff < batch_eff or e.max_frames < frames:
             # a larger batch or a longer clip: only the workspace grows, the packed weights stay where they are
@@ -187,6 +186,31 @@ class SAID(ABC, nn.Module):
 
     def decode_latent(self, latent: torch.FloatTensor) -> torch.FloatTensor:
         return latent.clone()
+
+    def _pick_clip_groups(self, batch_size: int, tokens_per_clip: int) -> int:
+        """How many concurrent clip groups SAID.inference runs a batch as (tokens_per_clip: UNet rows per clip, 2 T under
+        guidance).  Measured on one MI355X (scripts/clip_groups_sweep.py, profiles/r03d_clip_groups_sweep.txt): a split pays
+        when every group keeps >= 12000 UNet rows (>= 9000 for two groups in bf16 mode), i.e. stays on the large-batch GEMM
+        kernels with a full wave of workgroups: -4 .. -14 % per step; below that it costs up to +15 %.  Three groups beat two
+        by 1-2 points; four are slower than one (they outnumber the device's hardware queues and serialise)."""
+        if self.clip_groups is not None:
+            return max(1, min(int(self.clip_groups), batch_size))
+        for g, need in ((3, 12000), (2, 9000 if self.mfma_dtype == "bf16" else 12000)):
+            if batch_size >= g and (batch_size // g) * tokens_per_clip >= need:
+                return g
+        return 1
+
+    def _group_engines(self, eng: "_engine.Engine", n: int, max_batch_eff: int, frames: int) -> List["_engine.Engine"]:
+        frames_r = (frames + 63) // 64 * 64
+        self._clones = [c for c in self._clones if c.h is not None]
+        for c in self._clones[:n]:
+            if c.max_batch_eff < max_batch_eff or c.max_frames < frames:
+                c.reserve(max(max_batch_eff, c.max_batch_eff), max(frames_r, c.max_frames))
+        while len(self._clones) < n:
+            self._clones.append(eng.clone(max_batch_eff, frames_r))
+        for c in self._clones[:n]:
+            c.set_precision(self.mfma_dtype == "bf16")
+        return self._clones[:n]
 
     def inference(self, waveform_processed: torch.FloatTensor, init_samples: Optional[torch.FloatTensor] = None,
                   mask: Optional[torch.FloatTensor] = None, num_inference_steps: int = 100, strength: float = 1.0,
@@ -254,61 +278,55 @@ class SAID(ABC, nn.Module):
                               init_latents=init_lat[sl] if use_mask else None, edit_noise=noise[sl] if use_mask else None,
                               mask=mask_d[sl] if use_mask else None, noise_batch_offset=lo, **kw)
 
-        # Clip groups: a large even batch runs as TWO half-batches on two streams (a second engine context sharing the packed
-        # weights: said_clone).  One launch is a single wave of workgroups that load, multiply and store in lockstep; two
-        # concurrent loops interleave those phases: -3 % (bf16) / -5 % (fp32) per step at 32 clips x 600 frames on one MI355X.
-        # The results are those of the half-batches run alone (bit-identical to the whole batch in bf16 mode; fp32's tile choice
-        # depends on the launch size, so there the sums differ in their last bits).  The eta noise is drawn for the whole batch.
-        half = batch_size // 2
-        per_group = (2 if do_cfg else 1) * half * window_size
-        groups = self.clip_groups if self.clip_groups in (1, 2) else (2 if (batch_size % 2 == 0 and per_group >= 16000) else 1)
-        if groups == 2 and batch_size % 2 == 0 and n_run > 0:
-            be = 2 * half if do_cfg else half
-            e2 = self._eng2
-            if e2 is None or e2.h is None or e2.max_batch_eff < be or e2.max_frames < window_size:
-                if e2 is not None and e2.h is not None:
-                    e2.reserve(max(be, e2.max_batch_eff), max((window_size + 63) // 64 * 64, e2.max_frames))
-                else:
-                    e2 = self._eng2 = eng.clone(be, (window_size + 63) // 64 * 64)
-            e2.set_precision(self.mfma_dtype == "bf16")
+        # Clip groups: a large batch runs as G (two or three) concurrent sub-batches, each on its own stream and engine context (the extra
+        # contexts share the packed weights: said_clone).  One launch is a single wave of workgroups that load, multiply and
+        # store in lockstep; concurrent loops interleave those phases: -7 % (bf16) / -5 % (fp32) per step at 32 clips x 600
+        # frames on one MI355X.  The results are those of the sub-batches run alone (bit-identical to the whole batch in bf16
+        # mode; fp32's GEMM tile depends on the launch size, so there sums differ in their last bits: 2e-5 after 6 steps).  The
+        # eta noise is the whole batch's (noise_batch_offset).
+        G = self._pick_clip_groups(batch_size, (2 if do_cfg else 1) * window_size)
+        if G > 1 and n_run > 0:
+            bounds = [batch_size * i // G for i in range(G + 1)]
+            engines = [eng] + self._group_engines(eng, G - 1, (2 if do_cfg else 1) * max(bounds[i + 1] - bounds[i] for i in range(G)), window_size)
             main = torch.cuda.current_stream(device)
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device)
-            side = self._side_stream
-            side.wait_stream(main)                       # the inputs were produced on the caller's stream
-            # Outputs are allocated and both step graphs built here, in turn (stream capture and the allocator's hipMalloc must
-            # not run beside another thread's launches); then the second group is ENQUEUED from its own host thread: a 1000-step
-            # loop is 100 graph launches, more than a stream's queue takes without blocking the caller, so one thread would
-            # enqueue (and the GPU run) the groups one after the other.  (ctypes releases the GIL inside said_denoise_loop.)
-            j0 = job(eng, 0, half)
-            eng.prepare_loop(j0)
-            with torch.cuda.stream(side):
-                j1 = job(e2, half, batch_size)
-                e2.prepare_loop(j1)
-            box = {}
+            streams = [main] + [e.stream for e in engines[1:]]       # each clone owns its stream
+            # Outputs are allocated and the step graphs built here, in turn (stream capture and the allocator's hipMalloc must
+            # not run beside another thread's launches); then every further group is ENQUEUED from its own host thread: a
+            # 1000-step loop is 100 graph launches, more than a stream's queue takes without blocking the caller, so one thread
+            # would enqueue (and the GPU run) the groups one after the other.  (ctypes releases the GIL inside said_denoise_loop.)
+            jobs = []
+            for i in range(G):
+                if i:
+                    streams[i].wait_stream(main)          # the inputs were produced on the caller's stream
+                with torch.cuda.stream(streams[i]):
+                    jobs.append(job(engines[i], bounds[i], bounds[i + 1]))
+                    engines[i].prepare_loop(jobs[i])
+            out, errs = [None] * G, []
 
-            def second():
+            def enqueue(i):
                 try:
-                    with torch.cuda.device(device), torch.cuda.stream(side):
-                        box["r"] = e2.run_loop(j1)
+                    with torch.cuda.device(device), torch.cuda.stream(streams[i]):
+                        out[i] = engines[i].run_loop(jobs[i])
                 except BaseException as ex:   # re-raised on the caller's thread
-                    box["e"] = ex
+                    errs.append(ex)
 
-            th = threading.Thread(target=second, name="said-clip-group-1")
-            th.start()
+            threads = [threading.Thread(target=enqueue, args=(i,), name=f"said-clip-group-{i}") for i in range(1, G)]
+            for th in threads:
+                th.start()
             try:
-                r0 = eng.run_loop(j0)
+                enqueue(0)
             finally:
-                th.join()
-            if "e" in box:
-                raise box["e"]
-            r1 = box["r"]
-            main.wait_stream(side)
-            for t in (r1[0], r1[2]):                    # allocated on the side stream, consumed on the caller's
-                if t is not None:
-                    t.record_stream(main)
-            result = torch.cat([r0[0], r1[0]])
-            inter = torch.cat([r0[2], r1[2]], dim=1) if save_intermediate else None
+                for th in threads:
+                    th.join()
+            if errs:
+                raise errs[0]
+            for i in range(1, G):
+                main.wait_stream(streams[i])
+                for t in (out[i][0], out[i][2]):          # allocated on the side stream, consumed on the caller's
+                    if t is not None:
+                        t.record_stream(main)
+            result = torch.cat([o[0] for o in out])
+            inter = torch.cat([o[2] for o in out], dim=1) if save_intermediate else None
         else:
             result, _, inter = eng.run_loop(job(eng, 0, batch_size))
         intermediates = [inter[k] for k in range(n_run)] if save_intermediate else []

@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 {
 timeout 900 python -m pytest tests/test_gpu_round3.py -m gpu -x -q -s -k "clip_groups or eta" 2>&1 | tail -15
-for g in 0 1; do
+for g in 0 2; do
   echo "== --clip_groups $g"
   timeout 900 python bench.py --steps 2 --warmup 1 --clip_groups $g 2>&1 | tail -1 | python -c "
 import json,sys
