@@ -168,11 +168,17 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1"):
+def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1", groups=1):
     """Per-kernel HIP-event timing of one UNet evaluation (said_profile_unet: every launch of the schedule replayed
-    back to back in a graph on the caller's stream and timed with hipEvents) + the whole-step figures."""
+    back to back in a graph on the caller's stream and timed with hipEvents) + the whole-step figures.  With clip groups
+    (SAID.inference runs the batch as `groups` concurrent sub-batches) the launches are one GROUP's: the per-kernel figures are
+    those of the largest group's UNet evaluation timed alone; the whole-step figures are the whole batch's work / loop time."""
     eng = model._eng
-    stages = eng.profile_unet(Be, T, reps=40, cfg_clips=cfg_clips)
+    B = cfg_clips if cfg_clips else Be
+    per = Be // B                                    # UNet samples per clip (2 under guidance)
+    sizes = [B * (i + 1) // groups - B * i // groups for i in range(groups)]
+    nmax = max(sizes)
+    stages = eng.profile_unet(per * nmax, T, reps=40, cfg_clips=nmax if cfg_clips else 0)
     peak_tf = MFMA_PEAK_TFLOPS[dtype]
     agg = {}
     for st in stages:
@@ -195,8 +201,11 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1"):
     # once per clip and the unconditional half's cross-attention is a constant, so this is less than the reference-equivalent
     # (algorithmic) work of a 2B-sample UNet evaluation: `mfma_frac` / `hbm_frac` below are EFFECTIVE rates (reference work /
     # time), `*_executed` the hardware's.
-    exec_flops = sum(st["flops"] for st in stages)
-    exec_bytes = sum(st["bytes"] for st in stages)
+    exec_flops = exec_bytes = 0.0
+    for n in sorted(set(sizes)):
+        st_n = stages if n == nmax else eng.profile_unet(per * n, T, reps=1, cfg_clips=n if cfg_clips else 0)
+        exec_flops += sizes.count(n) * sum(st["flops"] for st in st_n)
+        exec_bytes += sizes.count(n) * sum(st["bytes"] for st in st_n)
     # which roof binds the dominant kernel: its arithmetic intensity against the ridge point peak FLOP/s : 8 TB/s (fp32 MFMA: 19.7
     # FLOP/B, bf16: 312).  Both fractions are always reported (hbm_frac / kernel_mfma_frac); `bound` / `achieved` / `peak` /
     # `frac` are the binding roof's.
@@ -212,9 +221,9 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1"):
            "launches_per_unet": d["launches"], "avg_launch_us": round(d["us"] / d["launches"], 3),
            "alg_bytes_per_launch": round(d["bytes"] / d["launches"]),
            "kernel_tflops": round(d["flops"] / (d["us"] * 1e-6) / 1e12, 3),
-           "mfma_peak_tflops": peak_tf, "mfma_dtype": dtype,
+           "mfma_peak_tflops": peak_tf, "mfma_dtype": dtype, "clip_groups": groups, "launch_unet_batch": per * nmax,
            "kernel_mfma_frac": round(d["flops"] / (d["us"] * 1e-6) / 1e12 / peak_tf, 5),
-           "unet_step": {"ms_loop_per_step": round(step_ms, 4), "sum_kernel_us": round(sum_us, 2), "launches": len(stages),
+           "unet_step": {"ms_loop_per_step": round(step_ms, 4), "sum_kernel_us": round(sum_us, 2), "launches": len(stages) * groups,
                          "alg_bytes": round(unet_bytes), "alg_gflop": round(unet_flops / 1e9, 3),
                          "hbm_frac": round(unet_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "mfma_frac": round(unet_flops / (step_ms * 1e-3) / 1e12 / peak_tf, 5),
@@ -340,7 +349,8 @@ def run_secondary(model, dev, gs):
         assert torch.isfinite(res).all()
         Be = 2 * B if gs > 1.0 else B
         step_ms = loop_step_ms(model, proc, lat0, edit_kw, T, c["num_steps"], gs, c["eta"])
-        rf = roofline(model, Be, T, step_ms, c["dtype"], cfg_clips=B if gs > 1.0 else 0, traffic_key="cfg1" if name == "cfg1_eta1" else name)   # (eta = 1 runs the headline's kernels)
+        rf = roofline(model, Be, T, step_ms, c["dtype"], cfg_clips=B if gs > 1.0 else 0, traffic_key="cfg1" if name == "cfg1_eta1" else name,   # (eta = 1 runs the headline's kernels)
+                      groups=model._pick_clip_groups(B, Be // B * T))
         rf["audio_encode"] = audio_encode_block(model, proc, T, B, c["dtype"])
         rf.pop("by_kernel", None)      # the headline's roofline carries the per-kernel table; keep the line readable
         out[name] = {"value": round(B * T / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "passes": c["passes"],
@@ -443,7 +453,8 @@ def run(args):
                    "cfg2_bf16" if (B == 32 and args.num_steps == 50 and args.dtype == "bf16") else
                    "cfg3_per_gpu_f32" if (B == 32 and args.dtype == "f32" and not args.edit) else
                    "cfg4_edit" if args.edit else "other")
-            line["roofline"] = roofline(model, Be, T, step_ms, args.dtype, cfg_clips=B if args.guidance_scale > 1.0 else 0, traffic_key=key)
+            line["roofline"] = roofline(model, Be, T, step_ms, args.dtype, cfg_clips=B if args.guidance_scale > 1.0 else 0, traffic_key=key,
+                                        groups=model._pick_clip_groups(B, Be // B * T))
             line["roofline"]["audio_encode"] = audio_encode_block(model, proc, T, B, args.dtype)
             if headline and world == 1 and not args.no_secondary:
                 line["secondary"] = run_secondary(model, dev, args.guidance_scale)
