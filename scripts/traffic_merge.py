@@ -16,19 +16,57 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-# config -> (substring of the rocprof kernel name, bench.py's name of the same kernel family)
-FAMILY = {
-    "cfg1": ("ugemm_kernel<1, 8, 0", "ugemm_kernel<NB1,KS8,store>"),
-    "cfg2_bf16": ("fgemm_kernel<3, 1, true", "tgemm_kernel<64,store>"),
-    "cfg3_per_gpu_f32": ("fgemm_kernel<3, 2, false", "fgemm_kernel<96,store>"),
-    "cfg4_edit": ("ugemm_kernel<2, 8, 0", "ugemm_kernel<NB2,KS8,store>"),
-}
+import re
+
+# Fallback families (config -> bench.py's name of the dominant kernel family) when no bench line is given; normally the names come
+# from the `roofline.kernel` fields of a bench line measured on the same sources (3rd argument, default
+# gpurun_out/final/bench_default.log): the dominant kernel changes when the schedule does.
+FAMILY = {"cfg1": "ugemm_kernel<NB1,KS8,store>", "cfg2_bf16": "xgemm_kernel<96,bf16,store>",
+          "cfg3_per_gpu_f32": "fgemm_kernel<96,store>", "cfg4_edit": "ugemm_kernel<NB2,KS8,store>"}
+EPI = {"store": 0, "qkv": 1, "geglu": 2, "band": 3}
+XGEMM_EK = {"store": ("0", "4"), "qkv": ("1",), "geglu": ("2",), "band": ("3",)}   # xgemm's epilogue-kind template argument
+
+
+def matcher(name):
+    """bench.py's family name -> predicate over rocprofv3's demangled kernel names."""
+    m = re.match(r"(ugemm|cgemm)_kernel<NB(\d+),KS(\d+),(\w+)>", name)
+    if m:
+        pre = f"{m.group(1)}_kernel<{m.group(2)}, {m.group(3)}, {EPI[m.group(4)]}"
+        return lambda k: pre + "," in k or pre + ">" in k
+    m = re.match(r"(fgemm|tgemm)_kernel<(\d+),(\w+)>", name)
+    if m:   # both are instantiations of fgemm_kernel<NJ, KH, BF, ...>: fp32 (K halves) / bf16
+        pre = f"fgemm_kernel<{int(m.group(2)) // 32}, " + ("2, false" if m.group(1) == "fgemm" else "1, true")
+        return lambda k: pre in k
+    m = re.match(r"xgemm_kernel<(\d+),(bf16|f32),(\w+)>", name)
+    if m:
+        pre = f"xgemm_kernel<{int(m.group(1)) // 32}, {'true' if m.group(2) == 'bf16' else 'false'},"
+        eks = XGEMM_EK[m.group(3)]
+        return lambda k: pre in k and k[k.index("xgemm_kernel<"):].rstrip(">").split(", ")[5:6] and k[k.index("xgemm_kernel<"):].split(", ")[5] in eks
+    m = re.match(r"attn_kernel<D(\d+),KS(\d+)>", name)
+    if m:
+        pre = f"attn_kernel<{int(m.group(1)) // 32}, {m.group(2)},"
+        return lambda k: pre in k
+    return lambda k: name.split("<")[0] in k
+
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+bench_log = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "final", "bench_default.log")
+if os.path.exists(bench_log):
+    for ln in open(bench_log):
+        if ln.startswith("{"):
+            d = json.loads(ln)
+            FAMILY["cfg1"] = d["roofline"]["kernel"]
+            for k, v in d.get("secondary", {}).items():
+                if k in FAMILY:
+                    FAMILY[k] = v["roofline"]["kernel"]
+            print("dominant kernels from", bench_log, FAMILY)
 sha = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
 out = {"format": "per-config dominant-kernel HBM traffic from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; "
                  "source_hash = bench.source_hash() of the sources measured", "configs": {}}
 lines = []
-for cfg, (match, name) in FAMILY.items():
+for cfg, name in FAMILY.items():
+    is_fam = matcher(name)
+    match = name
     def load(counter):
         fs = glob.glob(os.path.join(ROOT, "gpurun_out", "traffic", "**", f"{cfg}_{counter}_summary.json"), recursive=True)
         return json.load(open(fs[0])) if fs else []
@@ -36,9 +74,9 @@ for cfg, (match, name) in FAMILY.items():
     if not f or not w:
         print(cfg, "missing counters")
         continue
-    n = sum(r["launches"] for r in f if match in r["kernel"] and r["counter"] == "FETCH_SIZE")
-    fk = sum(r["sum"] for r in f if match in r["kernel"] and r["counter"] == "FETCH_SIZE")
-    wk = sum(r["sum"] for r in w if match in r["kernel"] and r["counter"] == "WRITE_SIZE")
+    n = sum(r["launches"] for r in f if is_fam(r["kernel"]) and r["counter"] == "FETCH_SIZE")
+    fk = sum(r["sum"] for r in f if is_fam(r["kernel"]) and r["counter"] == "FETCH_SIZE")
+    wk = sum(r["sum"] for r in w if is_fam(r["kernel"]) and r["counter"] == "WRITE_SIZE")
     if not n:
         print(cfg, "kernel family not found:", match)
         continue
