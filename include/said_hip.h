@@ -221,6 +221,8 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
  *   "xgemm_ntw"              column tiles per workgroup of the resident-source GEMMs (0: chosen per launch)
  *   "hybrid"                 0: bf16 mode at large batch keeps round 2's SpatialTransformer schedule throughout (default 1: from the
  *                            attention output on, the block runs on round 3's token-major kernels — DESIGN.md 7.3)
+ *   "audio_front_fused"      0: the bf16 audio encoder stores conv0's fp32 activation and runs GroupNorm + GELU and the transpose as separate
+ *                            kernels (round 2); default 1: one recomputing pass writes token-major bf16 directly
  * said_debug_get additionally knows "n_set_weight" (said_set_weight calls so far). */
 int said_debug_option(said_ctx* ctx, const char* name, long long value);
 long long said_debug_get(const said_ctx* ctx, const char* name);

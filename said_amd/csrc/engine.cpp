@@ -163,6 +163,7 @@ struct said_ctx {
     size_t a_tok_elems = 0; int a_chunk = 0;
 
     // ---- per-step graph ----
+    bool audio_front_fused = true;     // bf16 encoder: conv0 + GroupNorm + GELU in one recomputing pass (said_debug_option "audio_front_fused")
     hipStream_t cap_stream = nullptr;  // private stream used only to capture the per-step graph
     hipStream_t own_stream = nullptr;  // a clone's stream (said_stream): the one extra live stream a clip group costs
     hipGraph_t graph = nullptr, graph_rem = nullptr;       // `gspg` consecutive steps / the N % gspg remaining steps
@@ -1174,13 +1175,15 @@ void run_time_embed(said_ctx* c, int n, hipStream_t s) {
 }
 
 // cross-attention K/V of all four transformer blocks from the channel-major context (step-invariant)
-void run_kv(said_ctx* c, int Be, int S, int Sp, hipStream_t s) {
+// for samples [b0, b0 + nb): under guidance with the shared schedule only the conditional half's are ever read
+void run_kv(said_ctx* c, int b0, int nb, int S, int Sp, hipStream_t s) {
     GemmArgs a = mkargs(S, NST * 2 * MC);
     a.nseg = 1;
-    a.seg[0] = with_pw(mkseg(c->CTX, (long long)c->ctx_dim * Sp, Sp, c->ctx_dim, 1, 0, 1, S, XF_NONE, c->kv_all.w[0]), c->kv_all, 0);
-    a.y = c->KV; a.y_bstride = (long long)NST * 2 * MC * Sp; a.y_pitch = Sp;
-    const LaunchCfg lc = pick_cfg((long long)Be * ((S + 31) / 32), NST * 2 * MC / 32);
-    launch_gemm(a, EPI_STORE, Be, lc.NB, lc.KS, s);
+    const long long cbs = (long long)c->ctx_dim * Sp, ybs = (long long)NST * 2 * MC * Sp;
+    a.seg[0] = with_pw(mkseg(c->CTX + b0 * cbs, cbs, Sp, c->ctx_dim, 1, 0, 1, S, XF_NONE, c->kv_all.w[0]), c->kv_all, 0);
+    a.y = c->KV + b0 * ybs; a.y_bstride = ybs; a.y_pitch = Sp;
+    const LaunchCfg lc = pick_cfg((long long)nb * ((S + 31) / 32), NST * 2 * MC / 32);
+    launch_gemm(a, EPI_STORE, nb, lc.NB, lc.KS, s);
 }
 
 // alignment band of ldm/attention.py:170-189 with Python's banker's rounding on doubles
@@ -1774,7 +1777,7 @@ int said_unet_forward(said_ctx* ctx, const float* sample_dev, const int64_t* tim
     ctx->dbg_count = 0;
     run_time_embed(ctx, Be, s);
     launch_tm_to_cm(context_dev, ctx->CTX, Be, S, ctx->ctx_dim, g.Sp, (long long)ctx->ctx_dim * g.Sp, s);
-    run_kv(ctx, Be, S, g.Sp, s);
+    run_kv(ctx, 0, Be, S, g.Sp, s);
     launch_tm_to_cm(sample_dev, ctx->x_cm, Be, T, ctx->cin, g.Tp, (long long)ctx->cin * g.Tp, s);
     run_unet(ctx, g, s);
     launch_cm_to_tm(ctx->eps_cm, out_dev, Be, T, ctx->cin, g.Tp, (long long)ctx->cin * g.Tp, s);
@@ -1834,14 +1837,15 @@ static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, boo
         run_time_embed(ctx, N, s);
     }
     const long long cs = (long long)ctx->ctx_dim * g.Sp;
+    const bool uncond_const = g.Bc > 0;   // the unconditional half's cross-attention is the constant c2[blk]: its context and K/V are never read
     if (cfg) {  // uncond FIRST (diffusion.py:397-400): null_cond_emb repeated over (B, S)
-        launch_fill_cm_vec(ctx->null_cond, ctx->CTX, B, T, ctx->ctx_dim, g.Sp, cs, s);
+        if (!uncond_const) launch_fill_cm_vec(ctx->null_cond, ctx->CTX, B, T, ctx->ctx_dim, g.Sp, cs, s);
         launch_tm_to_cm(p->context_dev, ctx->CTX + (long long)B * cs, B, T, ctx->ctx_dim, g.Sp, cs, s);
     } else {
         launch_tm_to_cm(p->context_dev, ctx->CTX, B, T, ctx->ctx_dim, g.Sp, cs, s);
     }
     TRACE("loop: ctx done");
-    run_kv(ctx, Be, T, g.Sp, s);
+    if (uncond_const) run_kv(ctx, B, B, T, g.Sp, s); else run_kv(ctx, 0, Be, T, g.Sp, s);
     TRACE("loop: kv launched");
     launch_tm_to_cm(p->latents_dev, ctx->x_cm, B, T, C, g.Tp, xs, s);
     if (p->use_mask) {
@@ -2035,6 +2039,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->spg_limit = (int)value;
     } else if (k == "hybrid") {
         ctx->hybrid = value != 0;
+    } else if (k == "audio_front_fused") {   // bf16 encoder: 0 = conv0 -> fp32 activation -> rownorm+GELU -> transpose (round 2's three kernels)
+        ctx->audio_front_fused = value != 0;
     } else if (k == "xgemm_clk") {   // shader-clock stamps of the token-major-activation GEMMs (-DSAID_CLK_STAMPS builds); read with said_debug_clocks
         ctx->xclk_on = value != 0;
     } else if (k == "xgemm_ntw") {
@@ -2244,9 +2250,14 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
             const int nb = std::min(chunk, B - b0);
             const int pitch0 = rup(L[0], 32);
             const long long bs0 = (long long)W2V_CONV * pitch0;
-            launch_conv0(wav_dev + (long long)b0 * Ta, ctx->c0_w, ctx->abufA, nb, Ta, W2V_CONV, ctx->w2v_kernel[0], ctx->w2v_stride[0], L[0], pitch0, bs0, s);
-            launch_rownorm_gelu(ctx->abufA, ctx->c0_g, ctx->c0_b, W2V_CONV, nb, L[0], pitch0, bs0, 1e-5f, s);
-            launch_cm_to_tm_bf16(ctx->abufA, bs0, pitch0, ctx->bA0, (long long)L[0] * W2V_CONV, nb, L[0], W2V_CONV, s);
+            // conv0 + GroupNorm + GELU straight to token-major bf16 (abufA, sized for the fp32 activation, serves as its scratch)
+            if (!ctx->audio_front_fused ||
+                !launch_conv0_gn_gelu_tm_bf16(wav_dev + (long long)b0 * Ta, ctx->c0_w, ctx->c0_g, ctx->c0_b, ctx->abufA, ctx->bA0, nb, Ta, W2V_CONV,
+                                              ctx->w2v_kernel[0], ctx->w2v_stride[0], L[0], 1e-5f, s)) {
+                launch_conv0(wav_dev + (long long)b0 * Ta, ctx->c0_w, ctx->abufA, nb, Ta, W2V_CONV, ctx->w2v_kernel[0], ctx->w2v_stride[0], L[0], pitch0, bs0, s);
+                launch_rownorm_gelu(ctx->abufA, ctx->c0_g, ctx->c0_b, W2V_CONV, nb, L[0], pitch0, bs0, 1e-5f, s);
+                launch_cm_to_tm_bf16(ctx->abufA, bs0, pitch0, ctx->bA0, (long long)L[0] * W2V_CONV, nb, L[0], W2V_CONV, s);
+            }
             void* src = ctx->bA0;
             void* dst = ctx->bA1;
             for (int i = 1; i < 7; ++i) {   // Conv1d(512, 512, k, stride 2, no bias) + GELU as a GEMM with overlapping rows

@@ -259,6 +259,10 @@ void launch_flatten_cm(const float* src, long long src_bstride, int src_pitch, f
 void launch_conv0(const float* wav, const float* w, float* y, int B, int Ta, int C, int K, int S, int Tout, int pitch,
                   long long y_bstride, hipStream_t s);
 // per-row (b, c) mean/rstd over Tout, then y = gelu(gamma*(y-mean)*rstd+beta) in place
+// bf16 encoder front end (conv0 + GroupNorm(512, 512) + GELU -> token-major bf16 [b][Tout][512]); scratch: B * (ceil(Tout / 256) + 1) * 1024 floats.
+// false: shape not served (only wav2vec2-base's conv0: 512 channels, kernel 10, stride 5)
+bool launch_conv0_gn_gelu_tm_bf16(const float* wav, const float* w, const float* gamma, const float* beta, float* scratch, void* dst, int B, int Ta,
+                                  int C, int K, int S, int Tout, float eps, hipStream_t s);
 void launch_rownorm_gelu(float* y, const float* gamma, const float* beta, int rows_per_batch, int B, int T, int pitch,
                          long long bstride, float eps, hipStream_t s);
 // linear interpolation along t with align_corners=True (wav2vec2.py:41-44)

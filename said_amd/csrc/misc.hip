@@ -385,6 +385,117 @@ void launch_rownorm_gelu(float* y, const float* gamma, const float* beta, int ro
     hipLaunchKernelGGL(rownorm_gelu_kernel, dim3(rows_per_batch, B), dim3(256), 0, s, y, gamma, beta, T, pitch, bstride, eps);
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 encoder front end: conv0 + per-channel GroupNorm + GELU -> token-major bf16, WITHOUT storing the fp32 conv0 activation
+// (65 MB per 10 s clip: written, read three times by the normalisation, written, read and transposed = 9.4 GB per 32 clips).
+// conv0 is 10 multiply-adds per output, so it is computed twice instead: once for the per-channel statistics (nothing stored
+// but (sum, sum of squares) per 256-frame tile), once more to normalise, GELU and write the 1 KB bf16 row of every frame.
+//   stats: workgroup = (256-frame tile, clip), thread = channels tid and tid + 256
+//   coef : workgroup = clip, thread = channel: Chan's merge of the tile moments -> (gamma * rstd, beta - mean * gamma * rstd)
+//   apply: workgroup = (256-frame tile, clip), wave = every fourth frame, lane = 8 consecutive channels = one 16-byte store
+// Same multiply-add order per output as conv0_kernel (k ascending); K = 10, S = 5 (wav2vec2-base).
+// ------------------------------------------------------------------------------------------
+constexpr int C0_FT = 256, C0_K = 10, C0_S = 5, C0_C = 512;
+
+__global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restrict__ wav, const float* __restrict__ w, float* __restrict__ part,
+                                                          int Ta, int Tout, int ntile) {
+    __shared__ float seg[C0_FT * C0_S + C0_K];
+    const int tid = threadIdx.x, tile = blockIdx.x, b = blockIdx.y;
+    const int f0 = tile * C0_FT, nf = min(C0_FT, Tout - f0);
+    const float* xp = wav + (long long)b * Ta + (long long)f0 * C0_S;
+    const int nsamp = min(nf * C0_S + C0_K - C0_S, Ta - f0 * C0_S);
+    for (int i = tid; i < C0_FT * C0_S + C0_K; i += 256) seg[i] = i < nsamp ? xp[i] : 0.f;
+    float w0[C0_K], w1[C0_K];
+#pragma unroll
+    for (int k = 0; k < C0_K; ++k) { w0[k] = w[tid * C0_K + k]; w1[k] = w[(tid + 256) * C0_K + k]; }
+    __syncthreads();
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    float x[C0_K];
+#pragma unroll
+    for (int k = 0; k < C0_S; ++k) x[C0_S + k] = seg[k];
+    for (int f = 0; f < nf; ++f) {
+#pragma unroll
+        for (int k = 0; k < C0_S; ++k) { x[k] = x[C0_S + k]; x[C0_S + k] = seg[f * C0_S + C0_S + k]; }
+        float ya = 0.f, yb = 0.f;
+#pragma unroll
+        for (int k = 0; k < C0_K; ++k) { ya = fmaf(w0[k], x[k], ya); yb = fmaf(w1[k], x[k], yb); }
+        a1 += ya; a2 = fmaf(ya, ya, a2);
+        b1 += yb; b2 = fmaf(yb, yb, b2);
+    }
+    float2* pp = reinterpret_cast<float2*>(part) + ((long long)b * ntile + tile) * C0_C;
+    pp[tid] = make_float2(a1, a2);
+    pp[tid + 256] = make_float2(b1, b2);
+}
+
+__global__ __launch_bounds__(512) void conv0_coef_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ coef, int Tout, int ntile, float eps) {
+    const int c = threadIdx.x, b = blockIdx.x;
+    const float2* pp = reinterpret_cast<const float2*>(part) + (long long)b * ntile * C0_C + c;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int t = 0; t < ntile; ++t) {
+        const float2 v = pp[(long long)t * C0_C];
+        const float nb = (float)min(C0_FT, Tout - t * C0_FT);
+        const float mb = v.x / nb, m2b = fmaxf(v.y - v.x * mb, 0.f);
+        const float nn = n + nb, d = mb - mean;
+        mean += d * (nb / nn);
+        m2 += m2b + d * d * (n * nb / nn);
+        n = nn;
+    }
+    const float rstd = 1.0f / sqrtf(m2 / n + eps);
+    coef[((long long)b * C0_C + c) * 2] = gamma[c] * rstd;
+    coef[((long long)b * C0_C + c) * 2 + 1] = beta[c] - mean * gamma[c] * rstd;
+}
+
+__global__ __launch_bounds__(256) void conv0_apply_tm_kernel(const float* __restrict__ wav, const float* __restrict__ w, const float* __restrict__ coef,
+                                                             unsigned short* __restrict__ dst, int Ta, int Tout) {
+    __shared__ float seg[C0_FT * C0_S + C0_K];
+    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, tile = blockIdx.x, b = blockIdx.y;
+    const int f0 = tile * C0_FT, nf = min(C0_FT, Tout - f0);
+    const float* xp = wav + (long long)b * Ta + (long long)f0 * C0_S;
+    const int nsamp = min(nf * C0_S + C0_K - C0_S, Ta - f0 * C0_S);
+    for (int i = tid; i < C0_FT * C0_S + C0_K; i += 256) seg[i] = i < nsamp ? xp[i] : 0.f;
+    float wr[8][C0_K], g[8], bb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int k = 0; k < C0_K; ++k) wr[j][k] = w[(8 * l + j) * C0_K + k];
+        g[j] = coef[((long long)b * C0_C + 8 * l + j) * 2];
+        bb[j] = coef[((long long)b * C0_C + 8 * l + j) * 2 + 1];
+    }
+    __syncthreads();
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    for (int f = wv; f < nf; f += 4) {
+        float x[C0_K];
+#pragma unroll
+        for (int k = 0; k < C0_K; ++k) x[k] = seg[f * C0_S + k];
+        unsigned int o[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float y = 0.f;
+#pragma unroll
+            for (int k = 0; k < C0_K; ++k) y = fmaf(wr[j][k], x[k], y);
+            const float v = gelu_exact(fmaf(y, g[j], bb[j]));
+            const unsigned int u = __builtin_bit_cast(unsigned int, v);
+            const unsigned int r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;     // round to nearest even (finite values)
+            if (j & 1) o[j >> 1] |= r << 16; else o[j >> 1] = r;
+        }
+        u32x4 ov = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<u32x4*>(dst + ((long long)b * Tout + f0 + f) * C0_C + 8 * l) = ov;
+    }
+}
+
+bool launch_conv0_gn_gelu_tm_bf16(const float* wav, const float* w, const float* gamma, const float* beta, float* scratch, void* dst, int B, int Ta,
+                                  int C, int K, int S, int Tout, float eps, hipStream_t s) {
+    if (C != C0_C || K != C0_K || S != C0_S || Tout < 1) return false;
+    const int ntile = (Tout + C0_FT - 1) / C0_FT;
+    float* part = scratch;                                   // [B][ntile][512][2]
+    float* coef = scratch + (size_t)B * ntile * C0_C * 2;    // [B][512][2]
+    hipLaunchKernelGGL(conv0_stats_kernel, dim3(ntile, B), dim3(256), 0, s, wav, w, part, Ta, Tout, ntile);
+    hipLaunchKernelGGL(conv0_coef_kernel, dim3(B), dim3(512), 0, s, part, gamma, beta, coef, Tout, ntile, eps);
+    hipLaunchKernelGGL(conv0_apply_tm_kernel, dim3(ntile, B), dim3(256), 0, s, wav, w, coef, reinterpret_cast<unsigned short*>(dst), Ta, Tout);
+    return true;
+}
+
 // F.interpolate(mode="linear", align_corners=True) along t (wav2vec2.py:41-44)
 __global__ void interp_linear_kernel(const float* __restrict__ src, float* __restrict__ dst, int Tin, int Tout, int src_pitch,
                                      int dst_pitch, long long src_bstride, long long dst_bstride, float scale) {

@@ -1745,73 +1745,68 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(const PrepArgs a) {   // f
         }
         __syncthreads();
     }
-    // ---- transform + write token-major: thread -> (token tid >> 3, 24 channels starting at 24 (tid & 7)) = 48 contiguous bytes
-    const int tt = tid >> 3, part = tid & 7;
-    const int t = t0 + tt;
-    if (ln) { mu = lnst[tt][0]; rs = lnst[tt][1]; }
+    // ---- transform + write token-major.  A token's 192 channels are one contiguous row of the destination (768 B in fp32, 384 B in
+    // bf16) and the tile's 32 rows are 16-byte chunk g = token * (chunks per row) + chunk: thread tid takes chunks tid, tid + 256, ...,
+    // so the 64 lanes of every store instruction write 1 KB of consecutive bytes (with 24 channels per thread each instruction
+    // scattered 64 16-byte pieces at a 96-byte stride: six partial writes per cache line).
     const int row_off = a.mode == 0 ? 1 : 0;   // conv operand: row 0 is the left padding
-    const bool tv = t < T;
-    if (a.f32) {   // fp32 operands (fgemm_kernel): the same mapping, 96 contiguous bytes per thread
-        if (tv || (a.mode == 0 && t == T)) {
-            __attribute__((aligned(16))) float o[24];
-            __attribute__((aligned(16))) float r[24];
+    if (a.f32) {   // fp32 operands (fgemm_kernel): 48 chunks of 4 channels per token
 #pragma unroll
-            for (int i = 0; i < 24; ++i) {
-                const int c = part * 24 + i;
+        for (int i = 0; i < 6; ++i) {
+            const int g = i * 256 + tid, tt = g / 48, c0 = 4 * (g - tt * 48);
+            const int t = t0 + tt;
+            const bool tv = t < T;
+            if (!(tv || (a.mode == 0 && t == T))) continue;   // the conv operand's right padding row (token T) is written as zeros
+            if (ln) { mu = lnst[tt][0]; rs = lnst[tt][1]; }
+            f32x4t o, r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k;
                 const float raw = tile[c][tt];
                 float x = raw;
                 if (gn) x = fmaf(x, coefS[c][0], coefS[c][1]);
                 if (a.mode == 0) x = silu_f(x);
                 if (ln) x = fmaf((x - mu) * rs, a.ln_gamma[c], a.ln_beta[c]);
-                o[i] = tv ? x : 0.f;
-                r[i] = raw;
+                o[k] = tv ? x : 0.f;
+                r[k] = raw;
             }
-            f32x4t* d = reinterpret_cast<f32x4t*>(reinterpret_cast<float*>(a.dst) + (long long)b * a.dst_bs + (long long)(t + row_off) * a.ldd + a.coff + part * 24);
-            const f32x4t* os = reinterpret_cast<const f32x4t*>(o);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) d[i] = os[i];
-            if (a.dst2 && tv) {
-                f32x4t* d2 = reinterpret_cast<f32x4t*>(reinterpret_cast<float*>(a.dst2) + (long long)b * a.dst2_bs + (long long)t * a.ldd2 + a.coff2 + part * 24);
-                const f32x4t* rs_ = reinterpret_cast<const f32x4t*>(r);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) d2[i] = rs_[i];
-            }
+            *reinterpret_cast<f32x4t*>(reinterpret_cast<float*>(a.dst) + (long long)b * a.dst_bs + (long long)(t + row_off) * a.ldd + a.coff + c0) = o;
+            if (a.dst2 && tv)   // raw copy (1x1 skip conv over the ResBlock input; x2 for the folded proj_out)
+                *reinterpret_cast<f32x4t*>(reinterpret_cast<float*>(a.dst2) + (long long)b * a.dst2_bs + (long long)t * a.ldd2 + a.coff2 + c0) = r;
         }
-        if (a.mode == 0 && t0 == 0 && tt == 0) {   // left padding row
-            f32x4t* z = reinterpret_cast<f32x4t*>(reinterpret_cast<float*>(a.dst) + (long long)b * a.dst_bs + a.coff + part * 24);
+        if (a.mode == 0 && t0 == 0 && tid < 48) {   // left padding row
             const f32x4t zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 6; ++i) z[i] = zero;
+            *reinterpret_cast<f32x4t*>(reinterpret_cast<float*>(a.dst) + (long long)b * a.dst_bs + a.coff + 4 * tid) = zero;
         }
         return;
     }
-    if (tv || (a.mode == 0 && t == T)) {   // the conv operand's right padding row (token T) is written as zeros
-        __attribute__((aligned(16))) __bf16 o[24];
-        __attribute__((aligned(16))) __bf16 r[24];
 #pragma unroll
-        for (int i = 0; i < 24; ++i) {
-            const int c = part * 24 + i;
+    for (int i = 0; i < 3; ++i) {   // bf16 operands: 24 chunks of 8 channels per token
+        const int g = i * 256 + tid, tt = g / 24, c0 = 8 * (g - tt * 24);
+        const int t = t0 + tt;
+        const bool tv = t < T;
+        if (!(tv || (a.mode == 0 && t == T))) continue;
+        if (ln) { mu = lnst[tt][0]; rs = lnst[tt][1]; }
+        __attribute__((aligned(16))) __bf16 o[8];
+        __attribute__((aligned(16))) __bf16 r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k;
             const float raw = tile[c][tt];
             float x = raw;
             if (gn) x = fmaf(x, coefS[c][0], coefS[c][1]);
             if (a.mode == 0) x = silu_f(x);
             if (ln) x = fmaf((x - mu) * rs, a.ln_gamma[c], a.ln_beta[c]);
-            o[i] = (__bf16)(tv ? x : 0.f);
-            r[i] = (__bf16)raw;
+            o[k] = (__bf16)(tv ? x : 0.f);
+            r[k] = (__bf16)raw;
         }
-        u32x4* d = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.dst) + (long long)b * a.dst_bs + (long long)(t + row_off) * a.ldd + a.coff + part * 24);
-        const u32x4* os = reinterpret_cast<const u32x4*>(o);
-        d[0] = os[0]; d[1] = os[1]; d[2] = os[2];
-        if (a.dst2 && tv) {   // raw copy (1x1 skip conv over the ResBlock input; x2 for the folded proj_out)
-            u32x4* d2 = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.dst2) + (long long)b * a.dst2_bs + (long long)t * a.ldd2 + a.coff2 + part * 24);
-            const u32x4* rs_ = reinterpret_cast<const u32x4*>(r);
-            d2[0] = rs_[0]; d2[1] = rs_[1]; d2[2] = rs_[2];
-        }
+        *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.dst) + (long long)b * a.dst_bs + (long long)(t + row_off) * a.ldd + a.coff + c0) = *reinterpret_cast<const u32x4*>(o);
+        if (a.dst2 && tv)
+            *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.dst2) + (long long)b * a.dst2_bs + (long long)t * a.ldd2 + a.coff2 + c0) = *reinterpret_cast<const u32x4*>(r);
     }
-    if (a.mode == 0 && t0 == 0 && tt == 0) {   // left padding row
-        u32x4* z = reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.dst) + (long long)b * a.dst_bs + a.coff + part * 24);
+    if (a.mode == 0 && t0 == 0 && tid < 24) {   // left padding row
         const u32x4 zero = {0u, 0u, 0u, 0u};
-        z[0] = zero; z[1] = zero; z[2] = zero;
+        *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.dst) + (long long)b * a.dst_bs + a.coff + 8 * tid) = zero;
     }
 }
 bool launch_prep(const PrepArgs& a, int batch, hipStream_t s) {

@@ -3,6 +3,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 rm -rf gpurun_out/traffic; mkdir -p gpurun_out/traffic
+python -c "import bench; print(bench.source_hash())" > gpurun_out/traffic/source_hash.txt   # of the sources MEASURED (this snapshot)
 run() {  # name, bench flags
   name=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do

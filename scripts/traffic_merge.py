@@ -50,6 +50,8 @@ def matcher(name):
 
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+_hf = os.path.join(ROOT, "gpurun_out", "traffic", "source_hash.txt")     # written on the GPU box by gpu_r3_traffic.sh
+SRC_HASH = open(_hf).read().strip() if os.path.exists(_hf) else bench.source_hash()
 bench_log = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "final", "bench_default.log")
 if os.path.exists(bench_log):
     for ln in open(bench_log):
@@ -84,7 +86,7 @@ for cfg, name in FAMILY.items():
     out["configs"][cfg] = {"kernel": name, "rocprof_match": match, "launches": n, "hbm_bytes_per_launch": round(per),
                            "fetch_kb_per_launch": round(fk / n, 1), "write_kb_per_launch": round(wk / n, 1),
                            "note": "(2*FETCH_SIZE + WRITE_SIZE) * 1024, launch-weighted over the family's variants; gfx950 half-count correction on reads",
-                           "source": f"profiles/{tag}_pmc_hbm_traffic.txt", "source_hash": bench.source_hash(), "git_sha": sha}
+                           "source": f"profiles/{tag}_pmc_hbm_traffic.txt", "source_hash": SRC_HASH, "git_sha": sha}
     lines.append(f"{cfg:18s} {name:32s} launches {n:6d}  FETCH {fk / n:10.1f} KB  WRITE {wk / n:10.1f} KB  HBM {(per) / 1e6:8.2f} MB per launch")
     # the rest of the step, for the record
     fam = {}
@@ -98,7 +100,7 @@ for cfg, name in FAMILY.items():
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
 open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.txt"), "w").write(
     f"# rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace (separate passes) -- python bench.py --steps 1 --warmup 0 "
-    f"--no_cpu_baseline --no_roofline --no_secondary <config flags>   (scripts/gpu_r3_traffic.sh; git {sha}, sources {bench.source_hash()})\n"
+    f"--no_cpu_baseline --no_roofline --no_secondary <config flags>   (scripts/gpu_r3_traffic.sh; git {sha}, sources {SRC_HASH})\n"
     "# HBM MB per launch = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 wide-read half-count correction, MI355X_MICROARCH.md); top 10 kernels per config\n"
     + "\n".join(lines) + "\n")
 print("\n".join(lines))

@@ -86,6 +86,31 @@ def test_audio_encoder_batch32_10s_vs_oracle_both_precisions(model, w2v_sd, dev)
         assert e16 <= BF16_AUDIO_TOL and rms16 <= 5e-2
 
 
+@pytest.mark.parametrize("B,Ta", [(1, 16000), (3, 12345), (4, 160000)])
+def test_bf16_audio_front_end_fused_vs_three_kernels(model, w2v_sd, dev, B, Ta):
+    """bf16 encoder front end: conv0 + GroupNorm(512, 512) + GELU in one recomputing pass (per-tile moments merged with Chan's
+    formula, nothing stored in fp32) against round 2's three kernels (stored fp32 activation, two-pass statistics), and both
+    against the oracle.  Tile edges: 12345 samples = 2467 frames = 9 full tiles + 163 frames."""
+    F = int(Ta / 16000 * 60)
+    proc = op.process_audio([synth.synth_waveform(600 + i, Ta).numpy() for i in range(B)])
+    ref = ow.wav2vec2_forward(w2v_sd, proc[B - 1:B], F)[0][0]
+    eng = model._get_engine(2, 64)
+    try:
+        model.set_mfma_dtype("bf16")
+        new = model.get_audio_embedding(proc.to(dev), F).cpu()
+        eng.debug_option("audio_front_fused", 0)
+        old = model.get_audio_embedding(proc.to(dev), F).cpu()
+    finally:
+        eng.debug_option("audio_front_fused", 1)
+        model.set_mfma_dtype("fp32")
+    d = float((new - old).abs().max())
+    e_new, e_old = float((new[B - 1] - ref).abs().max()), float((old[B - 1] - ref).abs().max())
+    print(f"bf16 audio front end B={B} Ta={Ta}: fused vs three kernels {d:.3e}; vs oracle fused {e_new:.3e}, three kernels {e_old:.3e}")
+    assert torch.isfinite(new).all()
+    assert e_new <= BF16_AUDIO_TOL and e_new <= 1.5 * e_old + 1e-3
+    assert d <= BF16_AUDIO_TOL
+
+
 def test_audio_encoder_batch40_two_chunks_vs_oracle(model, w2v_sd, dev):
     """More clips than one engine pass holds (32): 40 x 1 s = a 32-clip and an 8-clip chunk; the clips on both sides of the
     chunk boundary against the oracle, in both precisions; and the same result with 16-clip passes (16 + 16 + 8)."""
