@@ -353,7 +353,7 @@ static void launch_attn_one(const AttnArgs& a, int batch, hipStream_t s) {
     constexpr int D_ = 32 * ND;
     const int smem = (QW * (KS * 64 + KS * ND * 16 * 64) + (QW > 1 ? 2 * (32 * (D_ + 4) + D_ * 36) : 0)) * (int)sizeof(float);
     dim3 grid(((a.T + 31) / 32 + QW - 1) / QW, a.heads, batch);
-    if (a.v_bstride > 0x7fffffffLL || a.o_bstride > 0x7fffffffLL) { fprintf(stderr, "said: attention batch stride exceeds 31 bits\n"); abort(); }
+    if (a.v_bstride > 0x7fffffffLL || a.o_bstride > 0x7fffffffLL) { launch_fault("attention batch stride exceeds 31 bits"); return; }
     hipLaunchKernelGGL((attn_kernel<ND, KS, BF, QW>), grid, dim3(64 * KS * QW), smem, s, a.qk, a.v, a.o, (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T,
                        a.heads, a.rows, a.scale, a.b0, a.o_mode);
 }
@@ -379,8 +379,7 @@ void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t
     if (head_dim == 64 && KS == 8) return bf16 ? launch_attn_one<2, 8, true>(a, batch, s) : launch_attn_one<2, 8, false>(a, batch, s);
     if (head_dim == 64 && KS == 4) return bf16 ? launch_attn_one<2, 4, true>(a, batch, s) : launch_attn_one<2, 4, false>(a, batch, s);
     if (head_dim == 64 && KS == 1) return bf16 ? launch_attn_one<2, 1, true>(a, batch, s) : launch_attn_one<2, 1, false>(a, batch, s);
-    fprintf(stderr, "said: unsupported attention config D=%d KS=%d\n", head_dim, KS);
-    abort();
+    launch_fault("unsupported attention config D=%d KS=%d", head_dim, KS);
 }
 
 }  // namespace said

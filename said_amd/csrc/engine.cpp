@@ -222,6 +222,7 @@ static void release_cap_streams(said_ctx* ctx) {
 // a schedule function's kernel refused its shape (nothing was launched for it): report instead of continuing
 #define LAUNCHCHK()                                                                                   \
     do {                                                                                              \
+        if (const char* f_ = launch_fault_peek()) { const std::string m_ = f_; launch_fault_clear(); ctx->launch_err.clear(); return fail(ctx, "%s", m_.c_str()); } \
         if (!ctx->launch_err.empty()) { const std::string m_ = ctx->launch_err; ctx->launch_err.clear(); return fail(ctx, "%s", m_.c_str()); } \
     } while (0)
 
@@ -2290,15 +2291,16 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                 // the grouped fp32 kernel ran at 40 TFLOP/s (7.5 of the encoder's 21 ms).  Epilogue: + bias, GELU, + hidden state.
                 const int R = rup(Fr + PK, 8);
                 launch_tm_to_group_bf16(ctx->bH, hsT, ctx->bXg, nb, Fr, PG, PCG, R, PK / 2, s);
-                for (int g = 0; g < PG; ++g) {
+                {   // ONE grouped launch (batch axis = (clip, group)): 16 launches of 160 workgroups left 40 % of the CUs idle (16 x 60 us)
                     TGemmArgs a;
                     memset(&a, 0, sizeof a);
-                    a.a = reinterpret_cast<uint16_t*>(ctx->bXg) + (size_t)g * R * PCG; a.a_bs = (long long)PG * R * PCG; a.lda = PCG;
-                    a.w = reinterpret_cast<uint16_t*>(ctx->bw_pos) + (size_t)g * 64 * PK * PCG; a.bias = ctx->pos_bias_pad + g * PCG; a.act = 1;
-                    a.res = ctx->bH + g * PCG; a.res_bs = hsT; a.ldr = W2V_H;
-                    a.yf = ctx->bT + g * PCG; a.y_bs = hsT; a.ldy = W2V_H; a.n_store = PCG;
+                    a.a = ctx->bXg; a.a_bs = (long long)PG * R * PCG; a.a_gs = (long long)R * PCG; a.lda = PCG;
+                    a.w = ctx->bw_pos; a.w_gs = (long long)64 * PK * PCG; a.bias = ctx->pos_bias_pad; a.act = 1;
+                    a.res = ctx->bH; a.res_bs = hsT; a.ldr = W2V_H;
+                    a.yf = ctx->bT; a.y_bs = hsT; a.ldy = W2V_H; a.n_store = PCG;
+                    a.grp = PG; a.col_gs = PCG;
                     a.M = Fr; a.N = 64; a.K = PK * PCG;
-                    if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
+                    if (!launch_tgemm(a, nb * PG, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 launch_ln_tm(ctx->bT, nullptr, ctx->bH, ctx->bHb, ctx->enc_lng, ctx->enc_lnb, (long long)nb * Fr, W2V_H, 1e-5f, s);
             } else {
@@ -2332,32 +2334,37 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     a.qk = ctx->aQK; a.v = ctx->aVT; a.o = ctx->aO;
                     a.v_bstride = hs; a.o_bstride = 2 * hs; a.b0 = 0;
                     a.pitch = Fp; a.T = Fr; a.heads = W2V_HEADS; a.rows = Fp; a.scale = 0.125f;
-                    launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : -4, s, true);
+                    const int aks = tt * W2V_HEADS <= 2048 ? 8 : -4;
+                    if (aks == -4) {   // the key-split-free variant writes the out_proj operand itself: token-major bf16 [clip][frame][768]
+                        a.o = reinterpret_cast<float*>(ctx->bO); a.o_bstride = Fr; a.o_mode = 2;
+                    }
+                    launch_attn(a, nb, W2V_HD, aks, s, true);
+                    if (aks != -4) launch_cm_to_tm_bf16(ctx->aO, 2 * hs, Fp, ctx->bO, hsT, nb, Fr, W2V_H, s);
                 }
-                launch_cm_to_tm_bf16(ctx->aO, 2 * hs, Fp, ctx->bO, hsT, nb, Fr, W2V_H, s);
                 {   // out_proj + residual, then layer_norm
                     TGemmArgs a;
                     memset(&a, 0, sizeof a);
+                    // (row-wise GEMMs see the pass's clips as ONE [nb * frames][768] matrix: no per-clip tile padding, 600 = 4.7 tiles of 128)
                     a.a = ctx->bO; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.out; a.bias = ly.out.bias;
                     a.res = ctx->bH; a.res_bs = hsT; a.ldr = W2V_H;
-                    a.yf = ctx->bT; a.y_bs = hsT; a.ldy = W2V_H; a.M = Fr; a.N = W2V_H; a.K = W2V_H;
-                    if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
+                    a.yf = ctx->bT; a.y_bs = hsT; a.ldy = W2V_H; a.M = nb * Fr; a.N = W2V_H; a.K = W2V_H;
+                    if (!launch_tgemm(a, 1, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 launch_ln_tm(ctx->bT, nullptr, ctx->bH, ctx->bHb, ly.ln1g, ly.ln1b, (long long)nb * Fr, W2V_H, 1e-5f, s);
                 {   // feed_forward.intermediate_dense + GELU
                     TGemmArgs a;
                     memset(&a, 0, sizeof a);
                     a.a = ctx->bHb; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.ff1; a.bias = ly.ff1.bias; a.act = 1;
-                    a.yb = ctx->bF; a.y_bs = (long long)Fr * W2V_FFN; a.ldy = W2V_FFN; a.M = Fr; a.N = W2V_FFN; a.K = W2V_H;
-                    if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
+                    a.yb = ctx->bF; a.y_bs = (long long)Fr * W2V_FFN; a.ldy = W2V_FFN; a.M = nb * Fr; a.N = W2V_FFN; a.K = W2V_H;
+                    if (!launch_tgemm(a, 1, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 {   // feed_forward.output_dense + residual, then final_layer_norm
                     TGemmArgs a;
                     memset(&a, 0, sizeof a);
                     a.a = ctx->bF; a.a_bs = (long long)Fr * W2V_FFN; a.lda = W2V_FFN; a.w = bl.ff2; a.bias = ly.ff2.bias;
                     a.res = ctx->bH; a.res_bs = hsT; a.ldr = W2V_H;
-                    a.yf = ctx->bT; a.y_bs = hsT; a.ldy = W2V_H; a.M = Fr; a.N = W2V_H; a.K = W2V_FFN;
-                    if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
+                    a.yf = ctx->bT; a.y_bs = hsT; a.ldy = W2V_H; a.M = nb * Fr; a.N = W2V_H; a.K = W2V_FFN;
+                    if (!launch_tgemm(a, 1, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 const bool last = l + 1 == ctx->w2v_layers && !apply_proj;   // the last LayerNorm writes the (B, frames, 768) result itself
                 launch_ln_tm(ctx->bT, nullptr, last ? out_dev + (long long)b0 * Fr * W2V_H : ctx->bH, ctx->bHb, ly.ln2g, ly.ln2b, (long long)nb * Fr, W2V_H, 1e-5f, s);

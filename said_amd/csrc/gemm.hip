@@ -647,8 +647,8 @@ template <int NB, int KS, int EPI>
 static void launch_one(const GemmArgs& a, int batch, hipStream_t s) {
     const int smem = gemm_smem_floats<NB, EPI>(a, KS) * (int)sizeof(float);
     if (smem > kMaxLdsBytes) {
-        fprintf(stderr, "said: gemm needs %d B of LDS (> %d)\n", smem, kMaxLdsBytes);
-        abort();
+        launch_fault("gemm needs %d B of LDS (> %d)", smem, kMaxLdsBytes);
+        return;
     }
     dim3 grid((a.T + 31) / 32, a.groups * (a.ntiles_per_group / NB), batch);
     hipLaunchKernelGGL((cgemm_kernel<NB, KS, EPI>), grid, dim3(64 * KS), smem, s, a);
@@ -680,8 +680,7 @@ void launch_gemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStrea
     // there after all): every epilogue exists as one tile x 8 waves, and the q/k/v token-major split needs
     // tm_tiles % NB == 0, which NB = 1 always satisfies.
     if (!(NB == 1 && KS == 8)) { launch_gemm(a, epi, batch, 1, 8, s); return; }
-    fprintf(stderr, "said: unsupported gemm config epi=%d NB=%d KS=%d\n", epi, NB, KS);
-    abort();
+    launch_fault("unsupported gemm config epi=%d NB=%d KS=%d", epi, NB, KS);
 }
 
 }  // namespace said

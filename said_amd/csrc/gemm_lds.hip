@@ -1018,7 +1018,7 @@ static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s, int tt) {
     int smem = ugemm_smem_floats<NB, EPI>(a, KS, MT) * (int)sizeof(float);
     static const int min_lds = dev_env("SAID_MIN_LDS") ? atoi(dev_env("SAID_MIN_LDS")) : 0;   // experiment: force one workgroup per CU
     if (smem < min_lds) smem = min_lds;
-    if (smem > kMaxLds) { fprintf(stderr, "said: ugemm needs %d B of LDS\n", smem); abort(); }
+    if (smem > kMaxLds) { launch_fault("ugemm needs %d B of LDS", smem); return; }
     const int ntt = (a.T + 31) / 32;
     dim3 grid(((MT ? (ntt + tt - 1) / tt : ntt)) * (a.ntiles_per_group / NB), batch);   // x: decoded XCD-aware in the kernel
     const Seg& s0 = a.seg[0];
@@ -1027,7 +1027,7 @@ static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s, int tt) {
                      ((MT ? tt : 0) << 28);
     const unsigned ny_host = (unsigned)(a.ntiles_per_group / NB), magic = 65536u / ny_host + 1u;
     for (unsigned L = 0; L < grid.x; ++L)   // exactness of the multiply-shift over this launch's range (a few thousand at most)
-        if (((L * magic) >> 16) != L / ny_host) { fprintf(stderr, "said: block decode magic inexact (grid %u, ny %u)\n", grid.x, ny_host); abort(); }
+        if (((L * magic) >> 16) != L / ny_host) { launch_fault("block decode magic inexact (grid %u, ny %u)", grid.x, ny_host); return; }
     const int bmod_b0 = (int)(magic & 0x1ffffu) | (a.b0 << 17);
     const int gate_vft = (EPI == EPI_GEGLU) ? a.geglu_gate_tiles : (EPI == EPI_QKV ? a.tm_tiles : 0);   // tm_tiles shares a union
     hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI, VAR, BF, MT>), grid, dim3(64 * KS), smem, s, s0.x, BF ? s0.w2 : s0.w4, pack,
@@ -1171,8 +1171,7 @@ void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStre
     }
     SAID_UGEMM_CONFIGS(X)
 #undef X
-    fprintf(stderr, "said: unsupported ugemm config epi=%d NB=%d KS=%d\n", epi, NB, KS);
-    abort();
+    launch_fault("unsupported ugemm config epi=%d NB=%d KS=%d", epi, NB, KS);
 }
 
 }  // namespace said

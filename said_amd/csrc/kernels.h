@@ -135,6 +135,13 @@ struct GemmArgs : GemmCommon {
 static_assert(sizeof(GemmCommon) <= 256, "common block must fit 256 bytes");
 static_assert(sizeof(GemmArgs) == 1024, "GemmArgs = 4 blocks of 256 bytes");
 
+// A launch helper that cannot serve its arguments (no instantiation for the shape, LDS budget exceeded, 32-bit stride overflow) records
+// the reason here and launches nothing; the C-ABI entry point that drove it returns the message as its error (engine.cpp: LAUNCHCHK).
+// Thread-local: two contexts may be driven from two host threads.  (Round 2 called abort() at these sites.)
+void launch_fault(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+const char* launch_fault_peek();    // nullptr when nothing is recorded
+void launch_fault_clear();
+
 struct AttnArgs {
     const float* qk;       // token-major [B][2*H][rows][D]: q heads, then k heads
     const float* v;        // channel-major [B][H*D][pitch]

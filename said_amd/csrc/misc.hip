@@ -1,6 +1,7 @@
 // misc.hip — layout changes, timestep embedding, the scheduler update, and the small
 // audio-encoder kernels (conv0, per-row GroupNorm+GELU, linear interpolation, LayerNorm).
 // All are HBM/latency-bound elementwise or row-reduction kernels: coalesced along t.
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 
@@ -8,6 +9,23 @@
 #include "sched_math.h"
 
 namespace said {
+
+// ------------------------------------------------------------------------------------------
+// launch_fault (kernels.h)
+// ------------------------------------------------------------------------------------------
+static thread_local char g_fault[256];
+static thread_local bool g_fault_set = false;
+void launch_fault(const char* fmt, ...) {
+    if (g_fault_set) return;   // keep the first one
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_fault, sizeof g_fault, fmt, ap);
+    va_end(ap);
+    g_fault_set = true;
+}
+const char* launch_fault_peek() { return g_fault_set ? g_fault : nullptr; }
+void launch_fault_clear() { g_fault_set = false; }
+
 
 // ------------------------------------------------------------------------------------------
 // token-major (B,T,C) <-> channel-major [B][C][pitch]
@@ -345,7 +363,7 @@ __global__ void conv0_kernel(const float* __restrict__ wav, const float* __restr
 }
 void launch_conv0(const float* wav, const float* w, float* y, int B, int Ta, int C, int K, int S, int Tout, int pitch,
                   long long y_bstride, hipStream_t s) {
-    if (K > 16) { fprintf(stderr, "said: conv0 kernel size %d > 16 unsupported\n", K); abort(); }
+    if (K > 16) { launch_fault("conv0 kernel size %d > 16 unsupported", K); return; }
     dim3 grid((Tout + 255) / 256, (C + 7) / 8, B);
     hipLaunchKernelGGL(conv0_kernel, grid, dim3(256), 0, s, wav, w, y, Ta, C, K, S, Tout, pitch, y_bstride);
 }

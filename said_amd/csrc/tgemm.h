@@ -53,6 +53,9 @@ struct TGemmArgs {
     // (seg_rows % 32 == 0, >= M); row R is sample R / seg_rows, token R % seg_rows; tokens >= M are padding.  0: per-sample
     // operands addressed through a_bs (audio encoder).
     int seg_rows;
+    int grp;               // tgemm_kernel only: > 1 = grouped launch, the batch axis is (sample, group) [batch = samples x grp]; group g reads A at
+    long long a_gs, w_gs;  //   a + sample a_bs + g a_gs and W at w + g w_gs (elements) and owns the output columns [g col_gs, g col_gs + n_store)
+    int col_gs;            //   of bias / res / y (the wav2vec2 positional convolution: 16 groups of 48 channels)
     int n_store;           // token-major outputs: columns n >= n_store are not written (0: all N) — a column count padded to the tile
     int f32;               // 1: A and W are fp32 (fgemm_kernel on v_mfma_f32_32x32x2_f32; fp32 mode, large batches); K % 32 == 0
     int dbg;               // timing experiments (SAID_TG_DBG): bit 0 = skip the epilogue, bit 1 = skip the K loop

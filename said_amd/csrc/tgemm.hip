@@ -58,7 +58,7 @@ constexpr int TBM = 128, TBN = 128, TBK = 64, TLP = 72;   // tile, LDS row pitch
 // memory-facing phase instead of one of them idling (the scratch is the row half's, a workgroup barrier separates the phases).
 template <int NJ, int J0 = 0, int NJE = NJ, int EK = -1, int PH = 0>
 __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ], int b_grid, int rt, int n0w, int l, float* sc,
-                                            const float* coefR = nullptr, int half = 0) {
+                                            const float* coefR = nullptr, int half = 0, int n_lim = 0) {
     constexpr bool ANY = EK < 0, P_CM = ANY || EK == 1 || EK == 3, P_BF = ANY || EK == 2, P_GEN = ANY || EK == 1 || EK == 2,
                    P_RES = EK == 3, P_GEGLU = ANY || EK == 2;
     constexpr int CW = 32 * NJE, CP = CW + 4;   // columns of this call, scratch row pitch (floats)
@@ -72,6 +72,7 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
         return;
     }
     const int nrows = min(32, a.M - mt);
+    const int n_store = n_lim ? n_lim : a.n_store;   // first column NOT stored (grouped launches: the group's own limit)
     const long long R0 = (long long)b * a.seg_rows + mt;   // global row of the tile's first token (token-major activation tensors)
     // ---- phase 1: registers -> scratch, elementwise work where lane == column
     const bool geglu = P_GEGLU && a.geglu != 0;
@@ -155,7 +156,7 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
                 }
             }
         }
-    } else if (P_BF && a.yb && !a.yf && !a.qk && !a.res && !a.n_store) {
+    } else if (P_BF && a.yb && !a.yf && !a.qk && !a.res && !n_store) {
         // ---- phase 2a', bf16-only token-major destination (GEGLU product, the audio encoder's conv / FFN activations): lane -> 8
         // consecutive columns = one 16-byte store (8-byte stores run at 0.54-0.70x the 16-byte rate)
         typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
@@ -182,7 +183,7 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
             if (!lane_on || row >= r_hi) continue;
             const int m = mt + row;
             const int n = n_first + 4 * cq;
-            if (a.n_store && n >= a.n_store) continue;
+            if (n_store && n >= n_store) continue;
             f32x4t v = *reinterpret_cast<const f32x4t*>(sc + row * CP + 4 * cq);
             if (a.res) {
                 const f32x4t rv = *reinterpret_cast<const f32x4t*>(a.res + (long long)b * a.res_bs + (long long)m * a.ldr + n);
@@ -225,9 +226,13 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
     const int b = mg / MT, mt_ = mg - b * MT;
     if (b >= a.batch) return;   // padding of the tile count to a multiple of 8 (the whole workgroup exits together)
     const int m0 = mt_ * TBM, n0 = nt * BN;
-    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.a) + (long long)b * a.a_bs;
-    const unsigned short* A2 = reinterpret_cast<const unsigned short*>(a.a2) + (long long)b * a.a2_bs;
-    const unsigned short* W = reinterpret_cast<const unsigned short*>(a.w);
+    // grouped launch (a.grp > 1: the positional convolution's 16 groups): the grid's batch axis is (sample, group); a group has its own
+    // A columns / weights and writes columns [g col_gs, g col_gs + n_store) of the sample's output rows
+    int bs = b, g = 0;
+    if (a.grp > 1) { bs = b / a.grp; g = b - bs * a.grp; }
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.a) + (long long)bs * a.a_bs + (long long)g * a.a_gs;
+    const unsigned short* A2 = reinterpret_cast<const unsigned short*>(a.a2) + (long long)bs * a.a2_bs;
+    const unsigned short* W = reinterpret_cast<const unsigned short*>(a.w) + (long long)g * a.w_gs;
     const int nk = a.K / TBK;
     const int nk1 = (a.a2 ? a.K1 : a.K) / TBK;   // K tiles served by the first A segment
 
@@ -323,8 +328,9 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
 
     // the K loop ended with a barrier: the operand buffers are free and serve as per-wave transposition scratch
     float* sc = reinterpret_cast<float*>(lds) + w * (32 * (32 * NJ + 4));
-    tg_epilogue<NJ>(a, acc0, b, m0 + wm * 64, n0 + wn * (32 * NJ), l, sc);
-    tg_epilogue<NJ>(a, acc1, b, m0 + wm * 64 + 32, n0 + wn * (32 * NJ), l, sc);
+    const int ncol = n0 + g * a.col_gs + wn * (32 * NJ), nlim = a.grp > 1 ? g * a.col_gs + a.n_store : 0;
+    tg_epilogue<NJ>(a, acc0, bs, m0 + wm * 64, ncol, l, sc, nullptr, 0, nlim);
+    tg_epilogue<NJ>(a, acc1, bs, m0 + wm * 64 + 32, ncol, l, sc, nullptr, 0, nlim);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1499,6 +1505,7 @@ bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
     const long long rows_tot = a.seg_rows > 0 ? (long long)batch * a.seg_rows : a.M;
     const int nb = a.seg_rows > 0 ? 1 : batch;
     if (a.f32) {
+        if (a.grp > 1) return false;
         if ((rows_tot + 2) * (long long)std::max(a.lda, a.lda2) >= 0x7fffffffLL) return false;   // 32-bit operand offsets
         const long long mt8 = ((rows_tot + 63) / 64 + 7) / 8 * 8;   // 64-row tiles, padded to the 8 XCDs
         constexpr int LDS3 = fgemm_lds_bytes<3>(), LDS4 = fgemm_lds_bytes<4>();
@@ -1534,7 +1541,8 @@ bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
             return true;
         }
     }
-    const bool big = !no256 && (a.N % 256 == 0 || a.N % 192 == 0) && rows_tot * nb >= 4096 &&
+    if (a.grp > 1 && (a.seg_rows > 0 || a.a2 || a.n_store < 1 || a.col_gs < a.n_store)) return false;   // grouped launches: tgemm_kernel only
+    const bool big = a.grp <= 1 && !no256 && (a.N % 256 == 0 || a.N % 192 == 0) && rows_tot * nb >= 4096 &&
                      (rows_tot + 2) * (long long)std::max(a.lda, a.lda2) < 0x7fffffffLL;
     if (a.geglu && !big) return false;   // the GEGLU epilogue needs the 256-wide tile
     // Per-sample operands (audio encoder): a 256-row tile holds one workgroup per CU, so its grid runs in rounds of 256 — the
@@ -1893,7 +1901,7 @@ void launch_ln_tm(const float* x, const float* add, float* yf, void* yb, const f
     const dim3 grid((unsigned)((ntok + 3) / 4));
     if (C == 768) hipLaunchKernelGGL(ln_tm_kernel<768>, grid, dim3(256), 0, s, x, add, yf, reinterpret_cast<unsigned short*>(yb), gamma, beta, ntok, eps);
     else if (C == 512) hipLaunchKernelGGL(ln_tm_kernel<512>, grid, dim3(256), 0, s, x, add, yf, reinterpret_cast<unsigned short*>(yb), gamma, beta, ntok, eps);
-    else { fprintf(stderr, "said: ln_tm for C=%d not instantiated\n", C); abort(); }
+    else launch_fault("ln_tm for C=%d not instantiated", C);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1933,7 +1941,7 @@ __global__ __launch_bounds__(256) void interp_ln_tm_kernel(const unsigned short*
 }
 void launch_interp_ln_tm(const void* src, long long src_bs, int Tin, void* dst, long long dst_bs, int Tout, int B, int C, const float* gamma,
                          const float* beta, float eps, hipStream_t s) {
-    if (C != 512) { fprintf(stderr, "said: interp_ln_tm for C=%d not instantiated\n", C); abort(); }
+    if (C != 512) { launch_fault("interp_ln_tm for C=%d not instantiated", C); return; }
     const float scale = (Tout > 1) ? (float)(Tin - 1) / (float)(Tout - 1) : 0.f;
     dim3 grid((Tout + 3) / 4, B);
     hipLaunchKernelGGL(interp_ln_tm_kernel<512>, grid, dim3(256), 0, s, reinterpret_cast<const unsigned short*>(src), src_bs, Tin,
