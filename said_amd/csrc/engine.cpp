@@ -144,6 +144,7 @@ struct said_ctx {
                               // 41 launches, no preparation kernels).  Parity-green in both precisions but measured SLOWER than round 2's
                               // schedule (prep_kernel + channel-major fp32 interface; bf16 2.49 vs 2.37, fp32 5.85 vs 4.92 ms per step at 32 clips:
                               // DESIGN.md section 7.3), so it is opt-in: said_debug_option("tm_acts", 1)
+    bool hybrid_f32 = false;  // (experiment: the hybrid schedule in fp32 mode too — said_debug_option "hybrid_f32")
     bool hybrid = true;       // bf16 mode at large batch: SpatialTransformers from the attention output on use round 3's token-major kernels
     int xgemm_dbg = 0;
     bool xclk_on = false;
@@ -925,7 +926,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     const int vt_rows = rup(g.T, 32);
     const long long obs = 2LL * MC * g.Tp;   // batch stride of O (shared with QK so attention uses one stride)
     const bool tg = use_tg(c, g, n1);
-    if (c->hybrid && c->bf16_mode && tg && use_tg(c, g, g.Be) && g.b0 == 0) { run_transformer_hybrid(c, g, sw, blk, in, out, s, shared); return; }
+    if (c->hybrid && (c->bf16_mode || c->hybrid_f32) && tg && use_tg(c, g, g.Be) && g.b0 == 0) { run_transformer_hybrid(c, g, sw, blk, in, out, s, shared); return; }
     if (tg) {   // q, k, v on the bf16 token-major GEMM: operand = LayerNorm(GroupNorm(x)) prepared once
         PrepArgs p = mkprep(g, in.p, 1, c->uPL, (long long)tg_rows(g) * MC, MC, 0);
         prep_gn(c, p, g, in.st, 6, 1e-6f, sw.gn_g, sw.gn_b, n1, 0, s);
@@ -2040,6 +2041,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->spg_limit = (int)value;
     } else if (k == "hybrid") {
         ctx->hybrid = value != 0;
+    } else if (k == "hybrid_f32") {
+        ctx->hybrid_f32 = value != 0;
     } else if (k == "audio_front_fused") {   // bf16 encoder: 0 = conv0 -> fp32 activation -> rownorm+GELU -> transpose (round 2's three kernels)
         ctx->audio_front_fused = value != 0;
     } else if (k == "xgemm_clk") {   // shader-clock stamps of the token-major-activation GEMMs (-DSAID_CLK_STAMPS builds); read with said_debug_clocks
