@@ -53,6 +53,8 @@ def parse():
     p.add_argument("--clip_groups", type=int, default=0,
                    help="0 (default): SAID.inference decides (two concurrent half-batches on two streams for large batches); "
                         "n >= 1: run every batch as n concurrent clip groups (1: never split)")
+    p.add_argument("--debug_option", action="append", default=[], metavar="NAME=VALUE",
+                   help="development: said_debug_option(NAME, VALUE) on the engine before the first run (scripts/ A/B drivers)")
     p.add_argument("--tm_acts", action="store_true",
                    help="experimental large-batch schedule (said_debug_option tm_acts = 1): token-major activations between the UNet kernels, "
                         "normalisation inside the consuming GEMMs, 41 launches per step")
@@ -412,6 +414,9 @@ def run(args):
     model.to(dev).eval()
     model.set_mfma_dtype("bf16" if args.dtype == "bf16" else "fp32")
     model.clip_groups = args.clip_groups or None
+    for kv in args.debug_option:
+        k, v = kv.split("=")
+        model._get_engine(2 * B if args.guidance_scale > 1.0 else B, T).debug_option(k, int(v))
     if args.tm_acts:
         model._get_engine(2 * B if args.guidance_scale > 1.0 else B, T).debug_option("tm_acts", 1)
     # synthetic inputs, resident in HBM before the timed region; keyed by GLOBAL clip id

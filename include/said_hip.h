@@ -56,8 +56,9 @@ int said_capacity(const said_ctx* ctx, int* max_batch_eff, int* max_frames);
  * across the groups: -3 % bf16 / -5 % fp32 per step at 32 clips).  No reference counterpart.  Destroy the clone BEFORE its parent. */
 int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_frames);
 
-/* The non-blocking stream a clone owns (NULL for a context made by said_create): the clone's loops are meant to run on it.
- * It is the one extra live stream a clip group costs; a live stream occupies one of the device's few hardware queues. */
+/* The non-blocking stream a clone's loops are meant to run on (NULL for a context made by said_create).  It comes from a pool of three
+ * streams per device shared by every clone in the process and is never destroyed: a live stream occupies one of the device's few
+ * hardware queues, and streams beyond their number share queues and serialise. */
 void* said_stream(const said_ctx* ctx);
 const char* said_last_error(const said_ctx* ctx);
 /* ABI version of this library (bumped on any signature change). */

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -144,6 +145,7 @@ struct said_ctx {
                               // 41 launches, no preparation kernels).  Parity-green in both precisions but measured SLOWER than round 2's
                               // schedule (prep_kernel + channel-major fp32 interface; bf16 2.49 vs 2.37, fp32 5.85 vs 4.92 ms per step at 32 clips:
                               // DESIGN.md section 7.3), so it is opt-in: said_debug_option("tm_acts", 1)
+    bool f32_out1_tm = true;  // fp32 large batch: attn1.to_out on the token-major fp32 GEMM (said_debug_option "f32_out1_tm")
     bool hybrid_f32 = false;  // (experiment: the hybrid schedule in fp32 mode too — said_debug_option "hybrid_f32")
     bool hybrid = true;       // bf16 mode at large batch: SpatialTransformers from the attention output on use round 3's token-major kernels
     int xgemm_dbg = 0;
@@ -166,7 +168,8 @@ struct said_ctx {
     // ---- per-step graph ----
     bool audio_front_fused = true;     // bf16 encoder: conv0 + GroupNorm + GELU in one recomputing pass (said_debug_option "audio_front_fused")
     hipStream_t cap_stream = nullptr;  // private stream used only to capture the per-step graph
-    hipStream_t own_stream = nullptr;  // a clone's stream (said_stream): the one extra live stream a clip group costs
+    hipStream_t own_stream = nullptr;  // a clone's stream (said_stream): from the process-wide pool below, never destroyed
+    int n_clones = 0;                  // clones made of this context so far (picks the pool slot)
     hipGraph_t graph = nullptr, graph_rem = nullptr;       // `gspg` consecutive steps / the N % gspg remaining steps
     hipGraphExec_t gexec = nullptr, gexec_rem = nullptr;
     std::vector<long long> gkey;
@@ -927,10 +930,14 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     const long long obs = 2LL * MC * g.Tp;   // batch stride of O (shared with QK so attention uses one stride)
     const bool tg = use_tg(c, g, n1);
     if (c->hybrid && (c->bf16_mode || c->hybrid_f32) && tg && use_tg(c, g, g.Be) && g.b0 == 0) { run_transformer_hybrid(c, g, sw, blk, in, out, s, shared); return; }
+    // fp32 mode: attn1.to_out on the token-major fp32 GEMM too (the attention kernel writes its operand token-major into the free q/k/v
+    // operand buffer; the GroupNorm'ed residual uses the coefficients the q/k/v preparation finalised): 59 -> ~30 us per launch at Be = 64
+    const bool out1_tm = tg && !c->bf16_mode && c->f32_out1_tm && tt1 * HEADS >= 2048 && sw.tf_out1;
     if (tg) {   // q, k, v on the bf16 token-major GEMM: operand = LayerNorm(GroupNorm(x)) prepared once
         PrepArgs p = mkprep(g, in.p, 1, c->uPL, (long long)tg_rows(g) * MC, MC, 0);
         prep_gn(c, p, g, in.st, 6, 1e-6f, sw.gn_g, sw.gn_b, n1, 0, s);
         p.ln_gamma = sw.l1g; p.ln_beta = sw.l1b;
+        if (out1_tm && p.part) { p.coef_out = c->gn_coef; p.coef_out_bs = 2 * MC; }
         do_prep(c, p, n1, s);
         TGemmArgs t = mktg(g, c->uPL, MC, tw(c, sw.t_qkv, sw.tf_qkv), 3 * MC, MC);
         t.qk = c->QK; t.vt = c->VT; t.v_bs = (long long)MC * g.Tp; t.qk_n = 2 * MC; t.head_dim = HD; t.rows = vt_rows; t.heads2 = 2 * HEADS; t.v_pitch = g.Tp;
@@ -954,6 +961,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         const LaunchCfg lc = big_qkv ? LaunchCfg{6, 4} : LaunchCfg{qkv_nb, 8};
         do_gemm(c, a, EPI_QKV, n1, lc.NB, lc.KS, s);
     }
+    bool out1_done = false;
     {   // softmax(q k^T * scale) v   (attention.py:99-126)
         AttnArgs a;
         a.qk = c->QK; a.v = c->VT; a.o = c->O;
@@ -966,8 +974,18 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         // large batches: four query tiles per workgroup sharing each K / V tile through the CU's L1 (-4), see attn.hip
         static const bool no_qw = dev_env("SAID_NO_ATTN_QW") != nullptr;
         const int attn_ks = (!no_qw && tt1 * HEADS >= 2048) ? -4 : ((tt1 * HEADS > 8192) ? 1 : ((g.T <= 256 && tt1 * HEADS <= 2048) ? 8 : 4));
+        if (out1_tm && !attn_ks_env && attn_ks == -4) { a.o = static_cast<float*>(c->uPL); a.o_bstride = tg_rows(g); a.o_mode = 1; }
         do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s);
+        out1_done = a.o_mode == 1;
     }
+    if (out1_done) {   // x1 = to_out(attn) + GroupNorm(x_in) on fgemm_kernel; under guidance also x2 of the unconditional half = x1 + c2
+        TGemmArgs t = mktg(g, c->uPL, MC, sw.tf_out1, MC, MC);
+        t.bias = sw.out1.bias;
+        t.res_cm = in.p; t.res_cm_bs = g.hs; t.res_cm_coef = c->gn_coef; t.res_cm_coef_bs = 2 * MC;
+        t.y_cm = c->X1; t.cm_bs = g.hs; t.cm_pitch = g.Tp;
+        if (g.Bc > 0) { t.y2_cm = c->X2; t.y2_bs = g.hs; t.y2_add_cm = c->c2[blk]; }
+        do_tgemm(c, t, n1, s);
+    } else
     {   // x1 = to_out(attn) + x, with x = GroupNorm(in) recomputed on the fly   (attention.py:127, 168)
         GemmArgs a = mkargs(g.T, MC);
         a.nseg = 1;
@@ -1351,8 +1369,7 @@ int said_destroy(said_ctx* ctx) {
     DeviceRestore restore_device;
     (void)hipSetDevice(ctx->device);
     drop_graphs(ctx);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
-    release_cap_streams(ctx);
+    release_cap_streams(ctx);   // (own_stream belongs to the pool)
     for (void* p : ctx->allocs) (void)hipFree(p);
     for (void* p : ctx->ws_allocs) (void)hipFree(p);
     delete ctx;
@@ -1372,6 +1389,20 @@ int said_reserve(said_ctx* ctx, int max_batch_eff, int max_frames) {
     ctx->ws_allocs.clear();
     if (alloc_workspace(ctx, std::max(max_batch_eff, ctx->maxBe), std::max(max_frames, ctx->maxT))) return -1;
     return 0;
+}
+
+// The clones' streams come from ONE pool per device for the whole process (three streams, created on first use, never destroyed): a live
+// stream pins one of the device's hardware queues (four by default), and streams beyond that share queues and serialise — two models with
+// their own clone streams were enough for that (the second model's clip groups ran 16 % SLOWER than its unsplit batch).  Clones of
+// different parents therefore share streams; they only run side by side if the caller drives two models from two threads.
+constexpr int POOL_STREAMS = 3, POOL_DEVICES = 64;
+static std::mutex g_pool_mu;
+static hipStream_t g_pool[POOL_DEVICES][POOL_STREAMS];
+static hipStream_t pool_stream(int dev, int idx) {
+    if (dev < 0 || dev >= POOL_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!g_pool[dev][idx] && hipStreamCreateWithFlags(&g_pool[dev][idx], hipStreamNonBlocking) != hipSuccess) g_pool[dev][idx] = nullptr;
+    return g_pool[dev][idx];
 }
 
 int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_frames) {
@@ -1400,7 +1431,9 @@ int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_fram
     c->noise_cm = nullptr; c->noise_cm_elems = 0;
     said_ctx* ctx = c;
     auto bail = [&](const char* what) { parent->err = std::string("said_clone: ") + what + (c->err.empty() ? "" : ": " + c->err); said_destroy(c); return -1; };
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreateWithFlags failed");
+    c->own_stream = pool_stream(parent->device, parent->n_clones++ % POOL_STREAMS);
+    if (!c->own_stream) return bail("hipStreamCreateWithFlags failed");
+    c->n_clones = 0;
     int rc = 0;
     rc |= dalloc(ctx, &c->coef1_dev, 8);
     rc |= dalloc(ctx, &c->step_dev, 4);
@@ -2043,6 +2076,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->hybrid = value != 0;
     } else if (k == "hybrid_f32") {
         ctx->hybrid_f32 = value != 0;
+    } else if (k == "f32_out1_tm") {
+        ctx->f32_out1_tm = value != 0;
     } else if (k == "audio_front_fused") {   // bf16 encoder: 0 = conv0 -> fp32 activation -> rownorm+GELU -> transpose (round 2's three kernels)
         ctx->audio_front_fused = value != 0;
     } else if (k == "xgemm_clk") {   // shader-clock stamps of the token-major-activation GEMMs (-DSAID_CLK_STAMPS builds); read with said_debug_clocks

@@ -42,10 +42,13 @@ struct TGemmArgs {
     int emb_pitch, emb_b_stride;
     const float* res_cm;   // channel-major fp32 residual [b][n][cm_pitch] (or null)
     long long res_cm_bs;
+    const float* res_cm_coef;   // != null: the residual is GroupNorm(res_cm) = res_cm * a + b with (a, b) = res_cm_coef[b][n][0..1] (prep_kernel's coef_out)
+    long long res_cm_coef_bs;
     float* stats;          // [b][N][ceil(M/32)][2] (mean, M2) or null
     long long stats_bs;
     float* y2_cm;          // second copy of the result (or null)
     long long y2_bs;
+    const float* y2_add_cm;     // != null: ... plus this per-channel constant (guidance: x2 of the unconditional half = x1 + c2, kernels.h y2_add)
     // ---- GEGLU epilogue (geglu != 0): the weight rows are tile-interleaved on the host so that a wave's two 32-column MFMA
     // tiles are (value, gate) of the same 32 channels; out[m][c] = value * gelu(gate) -> yb (bf16 token-major, N / 2 channels)
     int geglu;
@@ -114,6 +117,7 @@ struct PrepArgs {
     const float* ln_gamma; const float* ln_beta;
     void* dst; long long dst_bs; int ldd, coff;
     void* dst2; long long dst2_bs; int ldd2, coff2;
+    float* coef_out; long long coef_out_bs;      // != null: the first tile's workgroup of every sample also stores the finalised (a, b) [b][192][2]
     int mode;
     int f32;               // 1: dst / dst2 are fp32 (operands of the fp32 token-major GEMM), else bf16
 };

@@ -129,7 +129,12 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
             const int m = mt + 4 * tq;
             if (a.res_cm && m < a.M) {   // pitch >= roundup(M, 32): the whole quad is in bounds
                 const float4 rv = *reinterpret_cast<const float4*>(a.res_cm + (long long)b * a.res_cm_bs + (long long)n * pitch + m);
-                v4[0] += rv.x; v4[1] += rv.y; v4[2] += rv.z; v4[3] += rv.w;
+                if (a.res_cm_coef) {   // GroupNorm'ed residual (attn1.to_out: + norm(x_in), attention.py:168)
+                    const float2 cf = *reinterpret_cast<const float2*>(a.res_cm_coef + (long long)b * a.res_cm_coef_bs + 2 * n);
+                    v4[0] += fmaf(rv.x, cf.x, cf.y); v4[1] += fmaf(rv.y, cf.x, cf.y); v4[2] += fmaf(rv.z, cf.x, cf.y); v4[3] += fmaf(rv.w, cf.x, cf.y);
+                } else {
+                    v4[0] += rv.x; v4[1] += rv.y; v4[2] += rv.z; v4[3] += rv.w;
+                }
             }
             if (m < a.M) {   // tokens in [M, roundup(M, 4)) land in the row's padding: written as ZEROS (they come from operand rows
                              // nobody prepared; attention multiplies V's padding columns by p = 0, and 0 x NaN is NaN)
@@ -137,7 +142,11 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
                 for (int e = 1; e < 4; ++e) v4[e] = (m + e < a.M) ? v4[e] : 0.f;
                 const float4 o = make_float4(v4[0], v4[1], v4[2], v4[3]);
                 *reinterpret_cast<float4*>(ybase + (long long)n * pitch + m) = o;
-                if (a.y2_cm) *reinterpret_cast<float4*>(a.y2_cm + (long long)b * a.y2_bs + (long long)n * pitch + m) = o;
+                if (a.y2_cm) {
+                    const float ad = a.y2_add_cm ? a.y2_add_cm[n] : 0.f;
+                    *reinterpret_cast<float4*>(a.y2_cm + (long long)b * a.y2_bs + (long long)n * pitch + m) =
+                        make_float4(v4[0] + ad, (m + 1 < a.M) ? v4[1] + ad : 0.f, (m + 2 < a.M) ? v4[2] + ad : 0.f, (m + 3 < a.M) ? v4[3] + ad : 0.f);
+                }
             }
             if (a.stats) {   // Welford partial of channel n over this 32-token tile: reduce over the row's 8 lanes
                 float sum = 0.f;
@@ -1711,6 +1720,11 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(const PrepArgs a) {   // f
         GnLoads gl;   // (20 loads up front — one round trip instead of two at T = 600 — cost 96 VGPRs + spills: 118.5 vs 116.4 ms in situ)
         gn_issue(gp, rp, w * 48, 48, l, gl);
         gn_finish(gp, rp, w * 48, 48, l, gl, gns + w * GN_SCRATCH, &coefS[0][0]);
+        if (a.coef_out && blockIdx.x == 0) {   // the tensor's coefficients for a later consumer (the GroupNorm'ed residual of attn1.to_out)
+            __syncthreads();
+            float* co = a.coef_out + (long long)b * a.coef_out_bs;
+            for (int i = tid; i < 2 * 192; i += 256) co[i] = (&coefS[0][0])[i];
+        }
     } else if (gn) {
         const float* cf = a.coef + (long long)b * a.coef_bs;
         for (int i = tid; i < 2 * 192; i += 256) (&coefS[0][0])[i] = cf[i];
