@@ -51,9 +51,10 @@ int said_destroy(said_ctx* ctx);
 int said_reserve(said_ctx* ctx, int max_batch_eff, int max_frames);
 int said_capacity(const said_ctx* ctx, int* max_batch_eff, int* max_frames);
 /* A second context on the same device that SHARES the parent's packed weights (read-only) and owns its own workspace, capture
- * streams and step graph: two contexts can run said_denoise_loop concurrently on two streams.  The host wrapper uses it to run the
- * two halves of a large batch as concurrent clip groups (a launch's phases — tile loads, MFMAs, result stores — then overlap
- * across the groups: -3 % bf16 / -5 % fp32 per step at 32 clips).  No reference counterpart.  Destroy the clone BEFORE its parent. */
+ * streams and step graph: contexts can run said_denoise_loop concurrently on different streams.  The host wrapper uses it to run a
+ * large batch as two or three concurrent clip groups (a launch's phases — tile loads, MFMAs, result stores — then overlap across
+ * the groups: -7 % bf16 / -8 % fp32 per step at 32 clips x 600 frames).  The clone inherits the parent's precision
+ * mode and debug options as they are at this call.  No reference counterpart.  Destroy the clone BEFORE its parent. */
 int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_frames);
 
 /* The non-blocking stream a clone's loops are meant to run on (NULL for a context made by said_create).  It comes from a pool of three
