@@ -145,6 +145,8 @@ struct said_ctx {
                               // 41 launches, no preparation kernels).  Parity-green in both precisions but measured SLOWER than round 2's
                               // schedule (prep_kernel + channel-major fp32 interface; bf16 2.49 vs 2.37, fp32 5.85 vs 4.92 ms per step at 32 clips:
                               // DESIGN.md section 7.3), so it is opt-in: said_debug_option("tm_acts", 1)
+    int unet_nb = 0;          // > 0: forces pick_unet's column tiles per workgroup (said_debug_option "unet_nb")
+    bool unet_nb_model = true; // pick_unet by the busiest-CU model (0: round 2's rule; said_debug_option "unet_nb_model")
     bool f32_out1_tm = true;  // fp32 large batch: attn1.to_out on the token-major fp32 GEMM (said_debug_option "f32_out1_tm")
     bool hybrid_f32 = false;  // (experiment: the hybrid schedule in fp32 mode too — said_debug_option "hybrid_f32")
     bool hybrid = true;       // bf16 mode at large batch: SpatialTransformers from the attention output on use round 3's token-major kernels
@@ -433,9 +435,22 @@ LaunchCfg pick_cfg(long long t_tiles_total, int ntiles, bool allow6 = true) {
 
 // UNet GEMMs with 6 output tiles (192 channels): the LDS-staged kernel at every batch size — two tiles per workgroup
 // as soon as that still fills the chip (measured at Be=32: 47 TFLOP/s against 34 for the generic NB=6 shape)
-LaunchCfg pick_unet(long long t_tiles_total) {
+// Column tiles per workgroup (NB) of the UNet's 192-wide channel-major GEMMs.  A launch is t_tiles x 6 / NB workgroups on 256 CUs; its
+// time is that of the busiest CU: ceil(workgroups / 256) workgroups of (F + NB) units each, F = 0.45 the per-workgroup fixed part
+// (GroupNorm finalisation, operand tile; fitted on T = 1800: NB = 1 14.8 us, NB = 2 25.0 us at 342 workgroups each).  Round 2's rule
+// (NB = 2 from 64 tiles) put 342 workgroups on 256 CUs at T = 1800: two rounds of three units where NB = 3 is one round of 3.45.
+LaunchCfg pick_unet(const said_ctx* c, long long t_tiles_total) {
     if (big_cgemm()) return pick_cfg(t_tiles_total, 6);
-    return t_tiles_total * 3 >= 192 ? LaunchCfg{2, 8} : LaunchCfg{1, 8};
+    if (c->unet_nb > 0) return LaunchCfg{c->unet_nb, 8};
+    if (!c->unet_nb_model || t_tiles_total * 6 > 1024) return t_tiles_total * 3 >= 192 ? LaunchCfg{2, 8} : LaunchCfg{1, 8};   // (large launches: multi-tile NB = 2 shapes)
+    int best = 1;
+    double cost = 1e30;
+    for (int nb = 1; nb <= 3; ++nb) {
+        const long long wgs = t_tiles_total * (6 / nb);
+        const double k = (double)((wgs + 255) / 256) * (0.45 + nb);
+        if (k < cost - 1e-9) { cost = k; best = nb; }
+    }
+    return LaunchCfg{best, 8};
 }
 
 Seg mkseg(const float* x, long long bstride, int pitch, int C, int taps, int pad, int stride, int Tin, int xform, const float* w) {
@@ -505,6 +520,7 @@ void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS,
     GemmArgs a2 = a;
     a2.b0 = c->cur_b0;
     const bool bf = c->bf16_mode;
+    if (NB == 3 && epi == EPI_STORE && c->use_ugemm && !ugemm_supports(a2, epi, 3, KS, bf)) NB = 2;   // (the two-segment fp32 shapes spill at NB = 3: not built)
     const int tt = pick_tt(c, a2, epi, batch, NB, KS, bf);
     if (c->log_on) {
         double w = 0, in = 0, fl = 0;
@@ -885,7 +901,7 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
         a.emb = c->EO + (long long)rb_index * MC * c->maxNp; a.emb_pitch = c->maxNp; a.step_ptr = g.step_ptr; a.emb_b_stride = g.emb_b_stride;
         a.y = c->M.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         a.stats_out = c->M.st; a.stats_bstride = g.sts;
-        const LaunchCfg lc = pick_unet(tt);
+        const LaunchCfg lc = pick_unet(c, tt);
         do_gemm(c, a, EPI_STORE, nb, lc.NB, lc.KS, s);
     }
     {   // out_layers: GN -> SiLU -> conv3 ; + skip(x)   (openaimodel.py:226-227)
@@ -905,7 +921,7 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
         a.y = out.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         a.stats_out = out.st; a.stats_bstride = g.sts;
         if (shared) { a.y2 = out.p + (long long)g.Bc * g.hs; a.y2_bstride = g.hs; a.y2_add = nullptr; }
-        const LaunchCfg lc = pick_unet(tt);
+        const LaunchCfg lc = pick_unet(c, tt);
         do_gemm(c, a, EPI_STORE, nb, lc.NB, lc.KS, s);
     }
 }
@@ -999,7 +1015,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
                           // conditional slots — when this launch covers them — are overwritten by attn2's to_out below)
             a.y2 = c->X2; a.y2_bstride = g.hs; a.y2_add = c->c2[blk];
         }
-        const LaunchCfg lc = big_cgemm() ? pick_unet(tt1) : LaunchCfg{1, 8};   // the GroupNorm'ed-residual variant exists for NB = 1
+        const LaunchCfg lc = big_cgemm() ? pick_unet(c, tt1) : LaunchCfg{1, 8};   // the GroupNorm'ed-residual variant exists for NB = 1
         do_gemm(c, a, EPI_STORE, n1, lc.NB, lc.KS, s);
     }
     {   // attn2: q = to_q(norm2(x1)); banded softmax over the precomputed audio K/V   (attention.py:170-191)
@@ -1022,7 +1038,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.bias = sw.out2.bias;
         a.res_kind = RES_PLAIN; a.res = c->X1 + (long long)x_off * g.hs; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = c->X2 + (long long)kv_off * g.hs; a.y_bstride = g.hs; a.y_pitch = g.Tp;
-        const LaunchCfg lc = pick_unet(tt2);
+        const LaunchCfg lc = pick_unet(c, tt2);
         do_gemm(c, a, EPI_STORE, n2, lc.NB, lc.KS, s);
     }
     if (use_tg(c, g, g.Be)) {
@@ -1070,7 +1086,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.res_kind = RES_PLAIN; a.res = in.p; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = out.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         a.stats_out = out.st; a.stats_bstride = g.sts;
-        const LaunchCfg lc = pick_unet(tt);
+        const LaunchCfg lc = pick_unet(c, tt);
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
         return;
     }
@@ -1081,7 +1097,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.bias = sw.ff2.bias;
         a.res_kind = RES_PLAIN; a.res = c->X2; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = c->X3; a.y_bstride = g.hs; a.y_pitch = g.Tp;
-        const LaunchCfg lc = pick_unet(tt);
+        const LaunchCfg lc = pick_unet(c, tt);
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     {   // proj_out (1x1 conv) + x_in   (attention.py:232-234)
@@ -1092,7 +1108,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.res_kind = RES_PLAIN; a.res = in.p; a.res_bstride = g.hs; a.res_pitch = g.Tp;
         a.y = out.p; a.y_bstride = g.hs; a.y_pitch = g.Tp;
         a.stats_out = out.st; a.stats_bstride = g.sts;
-        const LaunchCfg lc = pick_unet(tt);
+        const LaunchCfg lc = pick_unet(c, tt);
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
 }
@@ -1118,7 +1134,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
         a.step_inc = g.step_inc;   // the loop's device step counter is advanced by the first kernel of the step
         a.bias = c->conv_in.bias;
         a.y = c->H0.p; a.y_bstride = g.hs; a.y_pitch = g.Tp; a.stats_out = c->H0.st; a.stats_bstride = g.sts;
-        const LaunchCfg lc = pick_unet(tt);
+        const LaunchCfg lc = pick_unet(c, tt);
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     const bool sh = g.Bc > 0;   // guidance-shared prefix: the two halves first differ at input_blocks.1.1's cross-attention
@@ -2076,6 +2092,10 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->hybrid = value != 0;
     } else if (k == "hybrid_f32") {
         ctx->hybrid_f32 = value != 0;
+    } else if (k == "unet_nb") {
+        ctx->unet_nb = (int)value;
+    } else if (k == "unet_nb_model") {
+        ctx->unet_nb_model = value != 0;
     } else if (k == "f32_out1_tm") {
         ctx->f32_out1_tm = value != 0;
     } else if (k == "audio_front_fused") {   // bf16 encoder: 0 = conv0 -> fp32 activation -> rownorm+GELU -> transpose (round 2's three kernels)

@@ -1053,6 +1053,8 @@ static void uconfigure_one() {
     X(EPI_STORE, 2, 8, 0) X(EPI_STORE, 2, 8, UV_DEEP) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0)                         \
     X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_MULTI)                                                                \
     X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_GN1 | UV_MULTI)                                                       \
+    X(EPI_STORE, 3, 8, 0) X(EPI_STORE, 3, 8, UV_DEEP) X(EPI_STORE, 3, 8, UV_T3 | UV_GN0) X(EPI_STORE, 3, 8, UV_MULTI) \
+    X(EPI_STORE, 3, 8, UV_T3 | UV_GN0 | UV_DUP)                                                                  \
     X(EPI_QKV, 1, 8, UV_GN0) X(EPI_QKV, 2, 8, UV_GN0) X(EPI_QKV, 3, 8, UV_GN0)                                   \
     X(EPI_GEGLU, 1, 8, 0) X(EPI_GEGLU, 2, 8, 0) X(EPI_GEGLU, 4, 8, 0)                                            \
     X(EPI_BAND, 1, 8, 0)
