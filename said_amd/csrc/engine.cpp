@@ -973,7 +973,14 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         // tiles per workgroup: the largest shape that still gives every CU a workgroup in ONE round (at Be=2, T=600:
         // NB=3 -> 228 workgroups, 27.5 -> 13.8 us per launch against NB=1's 684 workgroups in 2.7 rounds)
         static const int qkv_env = dev_env("SAID_QKV_NB") ? atoi(dev_env("SAID_QKV_NB")) : 0;
-        const int qkv_nb = qkv_env ? qkv_env : (tt1 * 6 >= 192 ? 3 : (tt1 * 9 >= 192 ? 2 : 1));
+        int qkv_nb = qkv_env ? qkv_env : (tt1 * 6 >= 192 ? 3 : (tt1 * 9 >= 192 ? 2 : 1));
+        if (!qkv_env && c->unet_nb_model && tt1 * 18 <= 1024) {   // pick_unet's busiest-CU model over the 18 column tiles (19 tiles: NB 1 -> 2, 342 -> 171 workgroups)
+            double cost = 1e30;
+            for (int nb = 1; nb <= 3; ++nb) {
+                const double k = (double)((tt1 * (18 / nb) + 255) / 256) * (0.45 + nb);
+                if (k < cost - 1e-9) { cost = k; qkv_nb = nb; }
+            }
+        }
         const LaunchCfg lc = big_qkv ? LaunchCfg{6, 4} : LaunchCfg{qkv_nb, 8};
         do_gemm(c, a, EPI_QKV, n1, lc.NB, lc.KS, s);
     }
