@@ -225,6 +225,10 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
  *                            attention output on, the block runs on round 3's token-major kernels — DESIGN.md 7.3)
  *   "audio_front_fused"      0: the bf16 audio encoder stores conv0's fp32 activation and runs GroupNorm + GELU and the transpose as separate
  *                            kernels (round 2); default 1: one recomputing pass writes token-major bf16 directly
+ *   "f32_out1_tm"            0: fp32 mode at large batch runs attn1.to_out on the channel-major kernel (round 2); default 1: on the token-major fp32 GEMM
+ *   "unet_nb_model"          0: round 2's rule for the column tiles per workgroup of the 192-wide channel-major GEMMs (default 1: busiest-CU model)
+ *   "unet_nb"                > 0: forces that number of column tiles per workgroup (1, 2 or 3)
+ *   "hybrid_f32"             1: the hybrid SpatialTransformer schedule in fp32 mode too (measured slower: default 0)
  * said_debug_get additionally knows "n_set_weight" (said_set_weight calls so far). */
 int said_debug_option(said_ctx* ctx, const char* name, long long value);
 long long said_debug_get(const said_ctx* ctx, const char* name);
