@@ -13,7 +13,7 @@ python scripts/prof_summary.py gpurun_out/prof/r01_results.db > gpurun_out/prof_
 grep '^{' gpurun_out/bench_default.log | tail -1 > profiles/r01_bench_default.json
 [ -f gpurun_out/bench_cfg3_bf16.log ] && grep '^{' gpurun_out/bench_cfg3_bf16.log | tail -1 > profiles/r01_bench_cfg3_b32_n50_bf16.json
 [ -f gpurun_out/bench_cfg3_f32.log ] && grep '^{' gpurun_out/bench_cfg3_f32.log | tail -1 > profiles/r01_bench_cfg3_b32_n50_f32.json
-( echo "# tests/debug_clocks.py on MI355X, library built with -DSAID_CLK_STAMPS (shader-clock stamps of workgroup 8 of every GEMM launch of one UNet evaluation, Be=2, T=600)"
+( echo "# scripts/debug_clocks.py on MI355X, library built with -DSAID_CLK_STAMPS (shader-clock stamps of workgroup 8 of every GEMM launch of one UNet evaluation, Be=2, T=600)"
   echo "# columns: request issue | GroupNorm finalize | LayerNorm stats | band loads | stage->LDS | MFMA | barrier skew | LDS reduce | epilogue"
   grep -E "^launch" gpurun_out/clk.log ) > profiles/r01c_phase_clocks_variants.txt
 python -c "

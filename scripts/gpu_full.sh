@@ -15,4 +15,4 @@ cp profiles/traffic_latest.json gpurun_out/traffic_latest.json
 timeout 500 python bench.py > gpurun_out/bench_default.log 2>&1; echo exit=$? >> gpurun_out/bench_default.log; tail -2 gpurun_out/bench_default.log | cut -c1-900
 # phase clocks need the stamp sites compiled in (the product library has none); the box is discarded afterwards
 touch said_amd/csrc/gemm_common.h; SAID_EXTRA_DEFS=-DSAID_CLK_STAMPS python -m said_amd.build > /dev/null 2>&1
-timeout 200 python tests/debug_clocks.py > gpurun_out/clk.log 2>&1; grep -c "^launch" gpurun_out/clk.log
+timeout 200 python scripts/debug_clocks.py > gpurun_out/clk.log 2>&1; grep -c "^launch" gpurun_out/clk.log
