@@ -225,6 +225,8 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
  *                            attention output on, the block runs on round 3's token-major kernels — DESIGN.md 7.3)
  *   "audio_front_fused"      0: the bf16 audio encoder stores conv0's fp32 activation and runs GroupNorm + GELU and the transpose as separate
  *                            kernels (round 2); default 1: one recomputing pass writes token-major bf16 directly
+ *   "tgemm_sb"               0: the bf16 audio encoder's 128 x 128 GEMM tiles keep two LDS operand buffers (two workgroups per CU; round 2); default 1: one
+ *                            buffer, three workgroups per CU (11.12 -> 10.90 ms per 32 clips, bit-identical)
  *   "f32_out1_tm"            0: fp32 mode at large batch runs attn1.to_out on the channel-major kernel (round 2); default 1: on the token-major fp32 GEMM
  *   "unet_nb_model"          0: round 2's rule for the column tiles per workgroup of the 192-wide channel-major GEMMs (default 1: busiest-CU model)
  *   "unet_nb"                > 0: forces that number of column tiles per workgroup (1, 2 or 3)

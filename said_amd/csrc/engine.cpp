@@ -145,6 +145,7 @@ struct said_ctx {
                               // 41 launches, no preparation kernels).  Parity-green in both precisions but measured SLOWER than round 2's
                               // schedule (prep_kernel + channel-major fp32 interface; bf16 2.49 vs 2.37, fp32 5.85 vs 4.92 ms per step at 32 clips:
                               // DESIGN.md section 7.3), so it is opt-in: said_debug_option("tm_acts", 1)
+    int tgemm_sb = 1;         // audio encoder (bf16): the single-LDS-buffer 128 x 128 GEMM variant, three workgroups per CU (said_debug_option "tgemm_sb"; 0: double buffer, two per CU)
     int unet_nb = 0;          // > 0: forces pick_unet's column tiles per workgroup (said_debug_option "unet_nb")
     bool unet_nb_model = true; // pick_unet by the busiest-CU model (0: round 2's rule; said_debug_option "unet_nb_model")
     bool f32_out1_tm = true;  // fp32 large batch: attn1.to_out on the token-major fp32 GEMM (said_debug_option "f32_out1_tm")
@@ -2099,6 +2100,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->hybrid = value != 0;
     } else if (k == "hybrid_f32") {
         ctx->hybrid_f32 = value != 0;
+    } else if (k == "tgemm_sb") {
+        ctx->tgemm_sb = value != 0;
     } else if (k == "unet_nb") {
         ctx->unet_nb = (int)value;
     } else if (k == "unet_nb_model") {
@@ -2392,6 +2395,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     a.a = ctx->bHb; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.qkv; a.bias = ly.qkv.bias;
                     a.qk = ctx->aQK; a.vt = ctx->aVT; a.v_bs = hs; a.qk_n = 2 * W2V_H; a.head_dim = W2V_HD; a.rows = Fp; a.heads2 = 2 * W2V_HEADS;
                     a.v_pitch = Fp; a.M = Fr; a.N = 3 * W2V_H; a.K = W2V_H;
+                    a.sb = ctx->tgemm_sb;
                     if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 {
@@ -2413,6 +2417,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     a.a = ctx->bO; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.out; a.bias = ly.out.bias;
                     a.res = ctx->bH; a.res_bs = hsT; a.ldr = W2V_H;
                     a.yf = ctx->bT; a.y_bs = hsT; a.ldy = W2V_H; a.M = nb * Fr; a.N = W2V_H; a.K = W2V_H;
+                    a.sb = ctx->tgemm_sb;
                     if (!launch_tgemm(a, 1, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 launch_ln_tm(ctx->bT, nullptr, ctx->bH, ctx->bHb, ly.ln1g, ly.ln1b, (long long)nb * Fr, W2V_H, 1e-5f, s);
@@ -2421,6 +2426,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     memset(&a, 0, sizeof a);
                     a.a = ctx->bHb; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.ff1; a.bias = ly.ff1.bias; a.act = 1;
                     a.yb = ctx->bF; a.y_bs = (long long)Fr * W2V_FFN; a.ldy = W2V_FFN; a.M = nb * Fr; a.N = W2V_FFN; a.K = W2V_H;
+                    a.sb = ctx->tgemm_sb;
                     if (!launch_tgemm(a, 1, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 {   // feed_forward.output_dense + residual, then final_layer_norm
@@ -2429,6 +2435,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     a.a = ctx->bF; a.a_bs = (long long)Fr * W2V_FFN; a.lda = W2V_FFN; a.w = bl.ff2; a.bias = ly.ff2.bias;
                     a.res = ctx->bH; a.res_bs = hsT; a.ldr = W2V_H;
                     a.yf = ctx->bT; a.y_bs = hsT; a.ldy = W2V_H; a.M = nb * Fr; a.N = W2V_H; a.K = W2V_FFN;
+                    a.sb = ctx->tgemm_sb;
                     if (!launch_tgemm(a, 1, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 const bool last = l + 1 == ctx->w2v_layers && !apply_proj;   // the last LayerNorm writes the (B, frames, 768) result itself

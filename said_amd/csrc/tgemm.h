@@ -56,6 +56,7 @@ struct TGemmArgs {
     // (seg_rows % 32 == 0, >= M); row R is sample R / seg_rows, token R % seg_rows; tokens >= M are padding.  0: per-sample
     // operands addressed through a_bs (audio encoder).
     int seg_rows;
+    int sb;                // tgemm_kernel<128> only: 1 = single-LDS-buffer variant (four workgroups per CU)
     int grp;               // tgemm_kernel only: > 1 = grouped launch, the batch axis is (sample, group) [batch = samples x grp]; group g reads A at
     long long a_gs, w_gs;  //   a + sample a_bs + g a_gs and W at w + g w_gs (elements) and owns the output columns [g col_gs, g col_gs + n_store)
     int col_gs;            //   of bias / res / y (the wav2vec2 positional convolution: 16 groups of 48 channels)

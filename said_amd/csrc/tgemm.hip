@@ -215,7 +215,9 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
 }
 
 // BN = 128: wave grid 2 x 2, each wave 64 tokens x 64 outputs; BN = 64 (N = 192, 576): each wave 64 tokens x 32 outputs
-template <int BN>
+// SB (single LDS buffer): one operand buffer and one register set instead of two of each — 36.9 KB of LDS and ~84 VGPRs, so FOUR
+// workgroups share a CU (two with the double buffer); a k-tile then costs two barriers, which the other three workgroups fill.
+template <int BN, bool SB = false>
 __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [2 buffers][A 128 x 72 | W BN x 72]
     constexpr int NJ = BN / 64;                 // MFMA column tiles per wave
@@ -314,6 +316,21 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
     // buffer nobody reads any more): with memory operations inside run-time branches the compiler's wait-count analysis
     // gives up at the joins and drains every outstanding load (s_waitcnt vmcnt(0)) before it issues the next tile's — which
     // is exactly the overlap the second register set exists for.
+    if constexpr (SB) {
+        gload_tile(S0, 0);
+        lds_store(S0, 0);
+        gload_tile(S0, min(1, nk - 1));
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {   // LDS holds tile kt, S0 tile kt + 1 (in flight)
+            __builtin_amdgcn_sched_barrier(0);
+            compute(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                 // every wave has read tile kt
+            lds_store(S0, 0);
+            gload_tile(S0, min(kt + 2, nk - 1));
+            __syncthreads();
+        }
+    } else {
     gload_tile(S0, 0);
     gload_tile(S1, min(1, nk - 1));
     lds_store(S0, 0);
@@ -333,6 +350,7 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         lds_store(S0, 0);
         __syncthreads();
+    }
     }
 
     // the K loop ended with a barrier: the operand buffers are free and serve as per-wave transposition scratch
@@ -1494,6 +1512,7 @@ int tgemm_geglu_src_row(int n, int N) {
     return (j & 1) ? N / 2 + c : c;
 }
 void configure_tgemm_kernel() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (TBM + 128) * TLP * 2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TBM + 128) * TLP * 2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TBM + 64) * TLP * 2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm256_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * TLP * 2);
@@ -1568,6 +1587,7 @@ bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
         const double e_128 = (double)g_128 / (double)(((g_128 + 511) / 512) * 512) * (double)a.M / (double)(mt_128 * TBM);
         if (e_128 > e_big + 0.01 * balance) use_big = false;
     }
+    if (a.sb && a.seg_rows == 0 && !a.geglu && a.N % 128 == 0) use_big = false;   // the single-buffer 128 x 128 variant was asked for
     if (use_big) {
         const long long mt8 = ((long long)nb * ((rows_tot + 255) / 256) + 7) / 8 * 8;
         if (a.N % 256 == 0) {
@@ -1583,7 +1603,8 @@ bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
     const long long mtiles8 = ((long long)batch * ((a.M + TBM - 1) / TBM) + 7) / 8 * 8;   // (sample, M tile) pairs padded to the 8 XCDs
     if (a.N % 128 == 0) {
         dim3 grid((unsigned)(mtiles8 * (a.N / 128)));
-        hipLaunchKernelGGL(tgemm_kernel<128>, grid, dim3(256), 2 * (TBM + 128) * TLP * 2, s, a2);
+        if (a.sb) hipLaunchKernelGGL((tgemm_kernel<128, true>), grid, dim3(256), (TBM + 128) * TLP * 2, s, a2);
+        else hipLaunchKernelGGL(tgemm_kernel<128>, grid, dim3(256), 2 * (TBM + 128) * TLP * 2, s, a2);
     } else {
         dim3 grid((unsigned)(mtiles8 * (a.N / 64)));
         hipLaunchKernelGGL(tgemm_kernel<64>, grid, dim3(256), 2 * (TBM + 64) * TLP * 2, s, a2);
