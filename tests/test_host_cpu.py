@@ -255,3 +255,21 @@ def test_philox_reference_matches_random123_known_answers():
     z = pr.normals(12345, 0, 4, 200000)
     assert abs(z.mean()) < 5e-3 and abs(z.var() - 1) < 1e-2 and abs(np.corrcoef(z[0], z[1])[0, 1]) < 1e-2
     assert np.array_equal(pr.normals(7, 3, 1, 10), pr.normals(7, 0, 4, 10)[3:4])      # counter-based: step k alone == step k of a run
+
+
+def test_clip_group_policy():
+    """SAID._pick_clip_groups (host logic, no GPU): groups only where every group keeps the large-batch kernels busy."""
+    from said_amd.model.diffusion import SAID_UNet1D
+    m = SAID_UNet1D()
+    assert m.mfma_dtype == "fp32"
+    pick = m._pick_clip_groups
+    assert pick(1, 1200) == 1 and pick(2, 1200) == 1                     # the headline never splits
+    assert pick(16, 1200) == 1 and pick(24, 1200) == 2 and pick(32, 1200) == 3 and pick(64, 1200) == 3
+    assert pick(32, 600) == 1                                           # no guidance: half the rows per clip
+    assert pick(8, 3600) == 2 and pick(12, 3600) == 3                   # 30 s clips
+    m.mfma_dtype = "bf16"
+    assert pick(12, 1200) == 1 and pick(16, 1200) == 2 and pick(32, 1200) == 3
+    m.clip_groups = 1
+    assert pick(64, 1200) == 1
+    m.clip_groups = 5
+    assert pick(3, 1200) == 3 and pick(64, 1200) == 5                   # forced, capped by the batch
