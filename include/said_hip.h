@@ -225,6 +225,9 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
  *                            attention output on, the block runs on round 3's token-major kernels — DESIGN.md 7.3)
  *   "audio_front_fused"      0: the bf16 audio encoder stores conv0's fp32 activation and runs GroupNorm + GELU and the transpose as separate
  *                            kernels (round 2); default 1: one recomputing pass writes token-major bf16 directly
+ *   "mt_mid"                 0: multi-tile workgroups (several token tiles per workgroup, weights kept in registers) only from 1024 workgroups per
+ *                            launch on (round 2); default 1: also for launches of 2-4 rounds of one workgroup per CU
+ *   "mt_wgs"                 > 0: workgroups per token tile from which a launch goes multi-tile (overrides both rules)
  *   "tgemm_sb"               0: the bf16 audio encoder's 128 x 128 GEMM tiles keep two LDS operand buffers (two workgroups per CU; round 2); default 1: one
  *                            buffer, three workgroups per CU (11.12 -> 10.90 ms per 32 clips, bit-identical)
  *   "f32_out1_tm"            0: fp32 mode at large batch runs attn1.to_out on the channel-major kernel (round 2); default 1: on the token-major fp32 GEMM

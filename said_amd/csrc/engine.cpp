@@ -145,6 +145,8 @@ struct said_ctx {
                               // 41 launches, no preparation kernels).  Parity-green in both precisions but measured SLOWER than round 2's
                               // schedule (prep_kernel + channel-major fp32 interface; bf16 2.49 vs 2.37, fp32 5.85 vs 4.92 ms per step at 32 clips:
                               // DESIGN.md section 7.3), so it is opt-in: said_debug_option("tm_acts", 1)
+    bool mt_mid = true;       // multi-tile workgroups for mid-size launches too (said_debug_option "mt_mid")
+    int mt_wgs = 0;           // > 0: multi-tile workgroups from this many workgroups per token tile on (said_debug_option "mt_wgs"; default 1024)
     int tgemm_sb = 1;         // audio encoder (bf16): the single-LDS-buffer 128 x 128 GEMM variant, three workgroups per CU (said_debug_option "tgemm_sb"; 0: double buffer, two per CU)
     int unet_nb = 0;          // > 0: forces pick_unet's column tiles per workgroup (said_debug_option "unet_nb")
     bool unet_nb_model = true; // pick_unet by the busiest-CU model (0: round 2's rule; said_debug_option "unet_nb_model")
@@ -510,8 +512,13 @@ static int pick_tt(said_ctx* c, const GemmArgs& a, int epi, int batch, int& NB, 
     int nb = NB;
     const long long ntt = (a.T + 31) / 32;
     const long long wgs = ntt * (a.ntiles_per_group / nb) * batch;
-    static const long long wgs_per_tile = dev_env("SAID_MT_WGS") ? std::max(64, atoi(dev_env("SAID_MT_WGS"))) : 1024;   // experiment knob
-    int tt = (int)std::min<long long>(std::min<long long>(8, wgs / wgs_per_tile), ntt);
+    static const long long wgs_env = dev_env("SAID_MT_WGS") ? std::max(64, atoi(dev_env("SAID_MT_WGS"))) : 1024;   // experiment knob
+    const long long wgs_per_tile = c->mt_wgs > 0 ? c->mt_wgs : wgs_env;
+    long long want = wgs / wgs_per_tile;
+    // mid-size launches (one to four rounds of one workgroup per CU, e.g. q/k/v at T = 1800: 684 workgroups): as many token tiles per
+    // workgroup as there would be rounds, so that ONE round of <= 256 workgroups remains (configs[4]: 16.87k -> 17.34k frames/s)
+    if (want <= 1 && c->mt_mid && c->mt_wgs <= 0) want = wgs / 228;
+    int tt = (int)std::min<long long>(std::min<long long>(8, want), ntt);
     if (tt <= 1 || !ugemm_supports(a, epi, nb, KS, bf, tt)) return 1;
     NB = nb;
     return tt;
@@ -2100,6 +2107,10 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->hybrid = value != 0;
     } else if (k == "hybrid_f32") {
         ctx->hybrid_f32 = value != 0;
+    } else if (k == "mt_mid") {
+        ctx->mt_mid = value != 0;
+    } else if (k == "mt_wgs") {
+        ctx->mt_wgs = (int)value;
     } else if (k == "tgemm_sb") {
         ctx->tgemm_sb = value != 0;
     } else if (k == "unet_nb") {

@@ -477,3 +477,23 @@ def test_clip_groups_forced_small_edit_vs_oracle(model, sd_full, dev):
     err = float((r.cpu() - ref.result).abs().max())
     print(f"forced clip groups, edit + eta: max abs err vs oracle {err:.3e}")
     assert err <= 2e-3
+
+
+def test_clip_groups_clone_workspace_grows(model, dev):
+    """The clones' workspaces grow with the clips (said_reserve on a clone: weights stay shared): a short batch, then a longer and
+    larger one through the same model, each equal to its unsplit run (fp32: up to the kernels' launch-size-dependent summation order)."""
+    try:
+        for B, T in ((12, 192), (20, 420)):
+            wav = torch.zeros(B, T * 16000 // 60, device=dev)
+            emb = synth.synth_latents(300 + B, (B, T, 768)).to(dev)
+            lat = synth.synth_latents(301 + B, (B, T, 32)).to(dev)
+            res = {}
+            for g in (1, 3):
+                model.clip_groups = g
+                res[g] = model.inference(wav, num_inference_steps=3, guidance_scale=2.0, init_latents=lat, audio_embedding=emb).result
+            d = float((res[1] - res[3]).abs().max())
+            print(f"clone growth B={B} T={T}: max |whole - split| {d:.3e}")
+            assert d <= 1e-4 and len(model._clones) == 2
+            assert all(c.max_frames >= T and c.max_batch_eff >= 2 * ((B + 2) // 3) for c in model._clones)
+    finally:
+        model.clip_groups = None
