@@ -133,6 +133,9 @@ typedef struct said_loop_params {
     float* result_dev;               /* (B, T, C): clamp(latents / latent_scale, 0, 1) (diffusion.py:470) */
     uint64_t noise_seed;             /* use_step_noise == 2: Philox key of this call's eta noise */
     int noise_batch_offset;          /* ... and the index of this call's first clip in the batch the noise is drawn for (clip groups) */
+    int concurrent;                  /* 1: this loop runs beside other contexts' loops (clip groups): launches that would under-fill the chip
+                                      * alone overlap with the neighbours', so the fp32 token-major GEMM path starts at 6000 rows per launch
+                                      * instead of 10000 (measured: 4.457 -> 4.41 ms per step at 32 clips in three groups) */
 } said_loop_params;
 
 /* columns of coef_host (all fp32, computed on the host in the scheduler's op order) */

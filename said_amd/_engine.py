@@ -34,7 +34,7 @@ class LoopParams(ctypes.Structure):
         ("context_dev", c_void_p), ("latents_dev", c_void_p), ("step_noise_dev", c_void_p),
         ("init_latents_dev", c_void_p), ("edit_noise_dev", c_void_p), ("mask_dev", c_void_p),
         ("intermediates_dev", c_void_p), ("result_dev", c_void_p), ("noise_seed", ctypes.c_uint64),
-        ("noise_batch_offset", c_int),
+        ("noise_batch_offset", c_int), ("concurrent", c_int),
     ]
 
 
@@ -237,7 +237,7 @@ class Engine:
                      prediction_type: str, guidance_scale: float, guidance_rescale: float, latent_scale: float,
                      step_noise: Optional[torch.Tensor] = None, init_latents: Optional[torch.Tensor] = None,
                      edit_noise: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-                     save_intermediate: bool = False, noise_seed: Optional[int] = None, noise_batch_offset: int = 0):
+                     save_intermediate: bool = False, noise_seed: Optional[int] = None, noise_batch_offset: int = 0, concurrent: bool = False):
         """Validates the arguments and allocates the outputs of one denoising loop (on the current stream): a job for
         prepare_loop / run_loop.  `noise_seed` (with step_noise None): the eta noise is generated inside the step's last
         kernel (Philox4x32-10 keyed by the seed) instead of being read from a tensor."""
@@ -257,6 +257,7 @@ class Engine:
         p.use_step_noise = int(step_noise is not None)
         p.use_mask = int(use_mask)
         p.save_intermediate = int(save_intermediate)
+        p.concurrent = int(bool(concurrent))
         p.timesteps_host = ts.ctypes.data_as(POINTER(c_int64))
         p.coef_host = cf.ctypes.data_as(POINTER(c_float))
         p.context_dev = context.data_ptr()

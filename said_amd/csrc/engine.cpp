@@ -162,6 +162,8 @@ struct said_ctx {
     // tokens per launch from which the token-major GEMM path is taken (measured crossovers, scripts/gpu_r2_w.sh: bf16 between 4800
     // and 6000 tokens, fp32 between 9600 and 10800); SAID_UNET_TGEMM_MIN overrides both
     long long unet_tgemm_min_tokens = 5800, unet_fgemm_min_tokens = 10000;
+    long long unet_fgemm_min_concurrent = 6000;   // fp32 threshold while other contexts' loops run beside this one (said_loop_params::concurrent)
+    bool cur_concurrent = false;
     int spg_limit = 10;      // denoise steps captured per graph
     int audio_chunk = 32;    // clips per audio-encoder pass
 
@@ -577,7 +579,7 @@ bool use_tg(said_ctx* c, const UGeo& g, int nsamples) {
     // (the token-major kernels address their operands with 32-bit element offsets: beyond that the channel-major kernels run)
     const long long widest = ((long long)nsamples * rup(g.T + 2, 32) + 2) * FFI;
     return (c->bf16_mode ? c->unet_tgemm : c->unet_fgemm) && !c->clk_on && widest < 0x7fffffffLL &&
-           (long long)nsamples * g.T >= (c->bf16_mode ? c->unet_tgemm_min_tokens : c->unet_fgemm_min_tokens);
+           (long long)nsamples * g.T >= (c->bf16_mode ? c->unet_tgemm_min_tokens : (c->cur_concurrent ? std::min(c->unet_fgemm_min_tokens, c->unet_fgemm_min_concurrent) : c->unet_fgemm_min_tokens));
 }
 // weight of the token-major GEMM in the context's precision mode
 inline const void* tw(const said_ctx* c, const void* bf, const void* f32) { return c->bf16_mode ? bf : f32; }
@@ -1830,6 +1832,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
 int said_unet_forward(said_ctx* ctx, const float* sample_dev, const int64_t* timesteps_host, const float* context_dev,
                       int Be, int T, int S, float* out_dev, void* stream) {
     if (check_ready(ctx)) return -1;
+    ctx->cur_concurrent = false;
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
     if (Be < 1 || Be > ctx->maxBe) return fail(ctx, "batch %d exceeds the context's max_batch_eff %d", Be, ctx->maxBe);
@@ -1864,7 +1867,7 @@ static std::vector<long long> loop_graph_key(const said_ctx* ctx, const said_loo
     int spg = std::min(ctx->spg_limit, p->num_steps);
     if (ctx->use_branches) spg = 1;
     const int rem = spg > 0 ? p->num_steps % spg : 0;
-    return {spg, rem, p->batch, p->frames, cfg, gsi, gri, lsi, p->prediction_type, p->use_mask, p->use_step_noise, ctx->bf16_mode, p->noise_batch_offset,
+    return {spg, rem, p->batch, p->frames, cfg, gsi, gri, lsi, p->prediction_type, p->use_mask, p->use_step_noise, ctx->bf16_mode, p->noise_batch_offset, p->concurrent != 0,
             (long long)(uintptr_t)(p->save_intermediate ? p->intermediates_dev : nullptr), (long long)(uintptr_t)(p->use_step_noise == 1 ? noise_cm : nullptr)};
 }
 
@@ -1872,6 +1875,7 @@ static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, boo
     if (check_ready(ctx)) return -1;
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
+    ctx->cur_concurrent = p->concurrent != 0;
     const int B = p->batch, T = p->frames, N = p->num_steps, C = ctx->cin;
     const bool cfg = p->guidance_scale > 1.0f;
     const int Be = cfg ? 2 * B : B;

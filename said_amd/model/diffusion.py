@@ -273,7 +273,7 @@ class SAID(ABC, nn.Module):
 
         def job(e, lo, hi):
             sl = slice(lo, hi)
-            return e.loop_job(latents=latents[sl], context=audio_embedding[sl],
+            return e.loop_job(concurrent=(hi - lo) < batch_size, latents=latents[sl], context=audio_embedding[sl],
                               step_noise=None if noise_steps is None else noise_steps[:, sl].contiguous(),
                               init_latents=init_lat[sl] if use_mask else None, edit_noise=noise[sl] if use_mask else None,
                               mask=mask_d[sl] if use_mask else None, noise_batch_offset=lo, **kw)

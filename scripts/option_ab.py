@@ -1,4 +1,4 @@
-"""Same-box A/B of a said_debug_option value on the in-situ denoising loop: python scripts/option_ab.py <option> <dtype> [B=32] [N=50]
+"""Same-box A/B of a said_debug_option value on the in-situ denoising loop: python scripts/option_ab.py <option> <dtype> [B=32] [N=50] [value0 value1]
 One model per value (the option is set before the first inference, so clip-group clones inherit it); alternating timed runs; the
 results of the two settings are compared.  Only ONE model is alive at a time: two models with three clip groups each hold more
 streams than the device has hardware queues, and the second model's groups then serialise (+16 % - that artefact was measured
@@ -15,6 +15,7 @@ from said_amd.util import synth  # noqa: E402
 opt, dt = sys.argv[1], sys.argv[2]
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 N = int(sys.argv[4]) if len(sys.argv) > 4 else 50
+VALS = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (0, 1)
 T = 600
 dev = torch.device("cuda:0")
 torch.set_grad_enabled(False)
@@ -32,7 +33,7 @@ def make(v):
 
 res = {}
 for rep in range(3):
-    for v in (0, 1):
+    for v in VALS:
         m = make(v)
         m.inference(wav, audio_embedding=ctx, num_inference_steps=10, guidance_scale=2.0, init_latents=lat)
         torch.cuda.synchronize()
@@ -47,4 +48,4 @@ for rep in range(3):
         m._eng.close()
         del m
         torch.cuda.synchronize()
-print(f"max |result(1) - result(0)| = {float((res[1] - res[0]).abs().max()):.3e}")
+print(f"max |result({VALS[1]}) - result({VALS[0]})| = {float((res[VALS[1]] - res[VALS[0]]).abs().max()):.3e}")
