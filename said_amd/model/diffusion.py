@@ -198,6 +198,12 @@ class SAID(ABC, nn.Module):
         for g, need in ((3, 12000), (2, 9000 if self.mfma_dtype == "bf16" else 12000)):
             if batch_size >= g and (batch_size // g) * tokens_per_clip >= need:
                 return g
+        # Small batches (below ~the token-major threshold as a whole) are chains of short, latency-bound launches: two such chains side
+        # by side overlap almost freely: -6 .. -14 % per step at 4-8 clips x 600 frames in fp32 mode, -5 .. -14 % at 4-6 clips in bf16
+        # mode (profiles/r03g_clip_groups_small_batches.txt).  At least two clips per group (single short clips side by side: +5 %);
+        # bf16 from 8000 rows on loses (8 clips x 600: +4 %).
+        if batch_size >= 4 and batch_size * tokens_per_clip < (8000 if self.mfma_dtype == "bf16" else 10000):
+            return 2
         return 1
 
     def _group_engines(self, eng: "_engine.Engine", n: int, max_batch_eff: int, frames: int) -> List["_engine.Engine"]:

@@ -263,11 +263,13 @@ def test_clip_group_policy():
     m = SAID_UNet1D()
     assert m.mfma_dtype == "fp32"
     pick = m._pick_clip_groups
-    assert pick(1, 1200) == 1 and pick(2, 1200) == 1                     # the headline never splits
+    assert pick(1, 1200) == 1 and pick(2, 1200) == 1 and pick(3, 1200) == 1   # the headline never splits; no single-clip groups
+    assert pick(4, 1200) == 2 and pick(8, 1200) == 2 and pick(10, 1200) == 1    # small batches: two chains of short launches
     assert pick(16, 1200) == 1 and pick(24, 1200) == 2 and pick(32, 1200) == 3 and pick(64, 1200) == 3
     assert pick(32, 600) == 1                                           # no guidance: half the rows per clip
-    assert pick(8, 3600) == 2 and pick(12, 3600) == 3                   # 30 s clips
+    assert pick(2, 3600) == 1 and pick(8, 3600) == 2 and pick(12, 3600) == 3   # 30 s clips
     m.mfma_dtype = "bf16"
+    assert pick(4, 1200) == 2 and pick(6, 1200) == 2 and pick(8, 1200) == 1
     assert pick(12, 1200) == 1 and pick(16, 1200) == 2 and pick(32, 1200) == 3
     m.clip_groups = 1
     assert pick(64, 1200) == 1
