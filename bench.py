@@ -55,9 +55,9 @@ def parse():
                         "n >= 1: run every batch as n concurrent clip groups (1: never split)")
     p.add_argument("--debug_option", action="append", default=[], metavar="NAME=VALUE",
                    help="development: said_debug_option(NAME, VALUE) on the engine before the first run (scripts/ A/B drivers)")
-    p.add_argument("--tm_acts", action="store_true",
-                   help="experimental large-batch schedule (said_debug_option tm_acts = 1): token-major activations between the UNet kernels, "
-                        "normalisation inside the consuming GEMMs, 41 launches per step")
+    p.add_argument("--tm_acts", type=int, nargs="?", const=1, default=-1, choices=[-1, 0, 1],
+                   help="large-batch schedule with token-major activations between the UNet kernels and the normalisations inside the consuming "
+                        "GEMMs (41 launches per step): -1 (default) = on in bf16 mode, off in fp32 mode; 0 / 1 force it (said_debug_option tm_acts)")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_secondary", action="store_true",
                    help="skip the secondary configurations (BASELINE configs[2], [3] per GPU, [4], and the headline with eta = 1) that the "
@@ -417,8 +417,8 @@ def run(args):
     for kv in args.debug_option:
         k, v = kv.split("=")
         model._get_engine(2 * B if args.guidance_scale > 1.0 else B, T).debug_option(k, int(v))
-    if args.tm_acts:
-        model._get_engine(2 * B if args.guidance_scale > 1.0 else B, T).debug_option("tm_acts", 1)
+    if args.tm_acts >= 0:
+        model._get_engine(2 * B if args.guidance_scale > 1.0 else B, T).debug_option("tm_acts", args.tm_acts)
     # synthetic inputs, resident in HBM before the timed region; keyed by GLOBAL clip id
     clips = shard.clip_range(rank, world, B)
     proc, lat0, edit_kw, T, Ta = make_inputs(model, dev, clips, args.seconds, args.edit)

@@ -220,9 +220,9 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
  *                            (< 0: restore the measured defaults 5800 bf16 / 10000 fp32)
  *   "audio_chunk"            clips per audio-encoder pass (default 32)
  *   "steps_per_graph"        denoise steps captured per hipGraph (default 10)
- *   "tm_acts"                1: large batches run round 3's experimental schedule — token-major activations (bf16 / fp32) between the UNet
- *                            kernels, GroupNorm / LayerNorm applied inside the consuming GEMM (xgemm_kernel), 41 launches per step, no
- *                            preparation kernels; parity-green, measured slower than the default (0 = round 2's schedule), DESIGN.md 7.3
+ *   "tm_acts"                large batches: token-major activations (bf16 / fp32) between the UNet kernels, GroupNorm / LayerNorm applied inside
+ *                            the consuming GEMM (xgemm_kernel), 41 launches per step, no preparation kernels.  -1 (default): on
+ *                            in bf16 mode, off in fp32 mode (measured slower there); 0 / 1 force it
  *   "xgemm_ntw"              column tiles per workgroup of the resident-source GEMMs (0: chosen per launch)
  *   "hybrid"                 0: bf16 mode at large batch keeps round 2's SpatialTransformer schedule throughout (default 1: from the
  *                            attention output on, the block runs on round 3's token-major kernels — DESIGN.md 7.3)

@@ -141,10 +141,9 @@ struct said_ctx {
     float* gn_coef = nullptr;   // [2 slots][maxBe][192][2] GroupNorm coefficients for prep_kernel
     void *uPA = nullptr, *uPB = nullptr, *uPL = nullptr, *uPH = nullptr, *uPX = nullptr;   // conv operand [Be][T+2][384], raw cat input
                                                                                             // [Be][T][384], LN'd [Be][T][192], GEGLU out [Be][T][768], raw x2 [Be][T][192]
-    bool tm_acts = false;     // large batches: token-major activations BETWEEN the UNet kernels, operand transforms inside the GEMMs (round 3:
-                              // 41 launches, no preparation kernels).  Parity-green in both precisions but measured SLOWER than round 2's
-                              // schedule (prep_kernel + channel-major fp32 interface; bf16 2.49 vs 2.37, fp32 5.85 vs 4.92 ms per step at 32 clips:
-                              // DESIGN.md section 7.3), so it is opt-in: said_debug_option("tm_acts", 1)
+    int tm_acts = -1;         // large batches: token-major activations BETWEEN the UNet kernels, operand transforms inside the GEMMs (round 3: 41
+                              // launches per step, no preparation kernels).  -1 = by precision mode: ON in bf16 mode (1.774 vs 1.841 ms per step at
+                              // 32 clips once its kernels stopped spilling), off in fp32 mode (4.78 vs 4.41); 0 / 1 force it (said_debug_option "tm_acts")
     bool mt_mid = true;       // multi-tile workgroups for mid-size launches too (said_debug_option "mt_mid")
     int mt_wgs = 0;           // > 0: multi-tile workgroups from this many workgroups per token tile on (said_debug_option "mt_wgs"; default 1024)
     int tgemm_sb = 1;         // audio encoder (bf16): the single-LDS-buffer 128 x 128 GEMM variant, three workgroups per CU (said_debug_option "tgemm_sb"; 0: double buffer, two per CU)
@@ -641,7 +640,7 @@ void tg_cm_out(TGemmArgs& t, const UGeo& g, const ActBuf& out) {
 
 // ---- round 3, large batches: token-major activations between the kernels, operand transforms inside the GEMMs (xgemm_kernel) ----
 inline int tm_seg(const UGeo& g) { return rup(g.T, 64); }   // sample pitch in tokens: a 64-row tile never straddles samples
-inline bool use_tm(said_ctx* c, const UGeo& g) { return c->tm_acts && use_tg(c, g, g.Be) && g.b0 == 0; }
+inline bool use_tm(said_ctx* c, const UGeo& g) { return (c->tm_acts < 0 ? c->bf16_mode : c->tm_acts != 0) && use_tg(c, g, g.Be) && g.b0 == 0; }
 // `rows` tokens further into a token-major tensor of row width `ld` (element size by precision mode)
 inline void* tm_at(const said_ctx* c, void* base, long long rows, int ld) { return static_cast<char*>(base) + rows * ld * (c->bf16_mode ? 2 : 4); }
 void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
@@ -2133,7 +2132,7 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         if (!dev_env("SAID_DEV")) return fail(ctx, "xgemm_dbg needs a -DSAID_DEV_KNOBS build with SAID_DEV=1");   // so refused by the shipped library
         ctx->xgemm_dbg = (int)value;
     } else if (k == "tm_acts") {
-        ctx->tm_acts = value != 0;
+        ctx->tm_acts = value < 0 ? -1 : (value != 0);
     } else {
         return fail(ctx, "said_debug_option: unknown option %s", name);
     }
@@ -2148,7 +2147,7 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "unet_tgemm_min_tokens") return ctx->bf16_mode ? ctx->unet_tgemm_min_tokens : ctx->unet_fgemm_min_tokens;
     if (k == "audio_chunk") return ctx->audio_chunk;
     if (k == "steps_per_graph") return ctx->spg_limit;
-    if (k == "tm_acts") return ctx->tm_acts ? 1 : 0;
+    if (k == "tm_acts") return ctx->tm_acts;
     return -1;
 }
 

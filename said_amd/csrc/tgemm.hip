@@ -514,7 +514,7 @@ __host__ __device__ constexpr int fgemm_lds_bytes() {
 // BF: the same workgroup on bf16 operands (bf16 mode's UNet GEMMs): a k-tile is again 128 bytes per row (64 halfs), each K half
 // two v_mfma_f32_32x32x16_bf16 per column tile.  There the point is not MFMA balance but spread: the 256-row bf16 tiles put a
 // 192-wide convolution on 152 workgroups of a 256-CU chip, and its time is the fp32 epilogue traffic (§7.3).
-constexpr int fgemm_occ(int NJ, int PF, bool BF) { return NJ == 3 ? (BF && PF == 1 ? 5 : 4) : 3; }   // workgroups per CU the registers are budgeted for
+constexpr int fgemm_occ(int NJ, int PF, bool BF) { return NJ == 3 ? 4 : 3; }   // workgroups per CU the registers are budgeted for
 template <int NJ, int PF, bool BF, int OCC = fgemm_occ(NJ, PF, BF)>
 __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [A 64 rows | W BN rows] x 144 bytes
@@ -703,8 +703,11 @@ __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
 // Workgroup, wave roles (2 row halves x 2 K halves), k-tile geometry and the K-half exchange are fgemm_kernel's.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int XRR = 66;                       // resident rows: 64 tokens + 2 halo
+// Workgroups per CU the registers are budgeted for.  The resident-source variants at THREE per CU (168 VGPRs) spilled 56-128 bytes per lane
+// — outside the k loop, and still enough to turn the token-major-activation schedule from 3 % faster than the default into 3 % slower
+// (1.768 vs 1.892 ms per step, bf16, 32 clips): two per CU (196-212 VGPRs, scratch 0).
 #ifndef XG_OCC_RS
-#define XG_OCC_RS 3
+#define XG_OCC_RS 2
 #endif
 #ifndef XG_OCC_SS
 #define XG_OCC_SS 3
@@ -1653,7 +1656,7 @@ template <bool BF>
 static bool launch_xgemm_p(const TGemmArgs& a, hipStream_t s) {
     const bool rs = a.ra[0] != nullptr, ss = a.sk[0] > 0;
     constexpr int O_RS = BF ? XG_OCC_RS : 2, O_SS = XG_OCC_SS;   // (fp32: the 52 KB resident tile allows two workgroups per CU anyway)
-    if (a.band_k) { launch_xgemm_one<3, BF, true, false, true, 4, 2>(a, s); return true; }
+    if (a.band_k) { launch_xgemm_one<3, BF, true, false, true, 4, 1>(a, s); return true; }
     if (a.geglu) { if (rs && !ss) { launch_xgemm_one<4, BF, true, false, false, 2, 2>(a, s); return true; } return false; }
     if (a.qk) { if (rs && !ss) { launch_xgemm_one<3, BF, true, false, false, 1, O_RS>(a, s); return true; } return false; }
     if (a.y_cm) { if (!rs && ss) { launch_xgemm_one<3, BF, false, true, false, 3, O_SS>(a, s); return true; } return false; }

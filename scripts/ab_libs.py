@@ -23,6 +23,9 @@ m.to(dev).eval()
 ctx = synth.synth_latents(1, (B, T, 768)).to(dev)
 lat = synth.synth_latents(2, (B, T, 32)).to(dev)
 wav = torch.zeros(B, T * 16000 // 60, device=dev)
+for kv in os.environ.get("AB_OPTS", "").split():      # e.g. AB_OPTS="tm_acts=1": said_debug_option before the first inference
+    k, v = kv.split("=")
+    m._get_engine(2 * B, T).debug_option(k, int(v))
 for dt in (sys.argv[4:] or ["bf16", "fp32"]):
     m.set_mfma_dtype(dt)
     m.inference(wav, audio_embedding=ctx, num_inference_steps=10, guidance_scale=2.0, init_latents=lat)

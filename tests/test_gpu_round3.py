@@ -364,14 +364,14 @@ def test_inference_eta_seeded_by_torch_generator(model, dev):
     assert torch.isfinite(a).all() and float(a.min()) >= 0 and float(a.max()) <= 1
 
 
-# ---------------------------------------------------------------- the experimental token-major activation schedule (opt-in)
+# ---------------------------------------------------------------- the token-major activation schedule (default in bf16 mode, opt-in in fp32 mode)
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_token_major_activation_schedule_opt_in_vs_oracle(model, unet_sd, sd_full, dev, mode):
     """said_debug_option("tm_acts", 1): activations stay token-major (bf16 / fp32) between the UNet kernels and the consuming GEMMs
-    apply GroupNorm + SiLU / LayerNorm themselves (xgemm_kernel: 41 launches per step, no preparation kernels).  Measured slower
-    than the default schedule, hence opt-in — but it must stay correct: a plain forward at B = 16 x T = 600 and a ragged B = 40 x
-    T = 333 against the oracle, and one guided step at B = 32 (shared prefix, duplicate stores, constant unconditional
-    cross-attention) against the oracle's step."""
+    apply GroupNorm + SiLU / LayerNorm themselves (xgemm_kernel: 41 launches per step, no preparation kernels).  The default at
+    large batch in bf16 mode (-1 = by precision mode), measured slower in fp32 mode — correct in both: a plain forward at B = 16 x
+    T = 600 and a ragged B = 40 x T = 333 against the oracle, and one guided step at B = 32 (shared prefix, duplicate stores,
+    constant unconditional cross-attention) against the oracle's step."""
     tol = 1e-4 if mode == "fp32" else 2e-2
     try:
         model.set_mfma_dtype(mode)
@@ -407,7 +407,7 @@ def test_token_major_activation_schedule_opt_in_vs_oracle(model, unet_sd, sd_ful
             print(f"tm_acts {mode} guided step clip {i}: {e:.3e} vs oracle")
             assert e <= (2e-4 if mode == "fp32" else BF16_STEP_MAX)
     finally:
-        model._eng.debug_option("tm_acts", 0)
+        model._eng.debug_option("tm_acts", -1)
         model.set_mfma_dtype("fp32")
 
 
