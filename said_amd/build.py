@@ -52,8 +52,28 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             # leading scalar kernel parameters arrive in SGPRs (14 is what the hardware has room for): see gemm_lds.hip, attn.hip
             extra = ["-mllvm", "-amdgpu-kernarg-preload-count=14"] if (src in ("gemm_lds.hip", "attn.hip", "conv_in.hip") and not os.environ.get("SAID_NO_PRELOAD")) else []
             extra += os.environ.get("SAID_EXTRA_DEFS", "").split()   # development: -D switches for A/B builds (scripts/gpu_ab_build.sh)
-            cmd = [hipcc] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
+            # the register allocator's report: a kernel that uses scratch (spills) fails the build — see check_scratch below
+            cmd = [hipcc] + FLAGS + extra + ["-Rpass-analysis=kernel-resource-usage"] + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
             jobs.append(cmd)
+
+    def check_scratch(cmd, stderr):
+        """Round 3 lost most of its work on the bf16 large-batch path to 56-204 bytes of scratch per lane in kernels whose k loops were
+        clean: no kernel of this library may spill.  SAID_ALLOW_SCRATCH=1 turns the check into a report."""
+        import re
+        bad, name = [], None
+        for ln in stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", ln)
+            if m:
+                name = m.group(1)
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", ln)
+            if m and int(m.group(1)) > 0:
+                bad.append(f"{name}: {m.group(1)} bytes of scratch per lane")
+        if bad:
+            msg = "kernels that spill (" + os.path.basename(cmd[-3]) + "):\n  " + "\n  ".join(bad)
+            if os.environ.get("SAID_ALLOW_SCRATCH"):
+                print(msg, file=sys.stderr)
+            else:
+                raise RuntimeError(msg + "\n(set SAID_ALLOW_SCRATCH=1 to build anyway)")
 
     def run(cmd):
         if verbose:
@@ -61,6 +81,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stderr[-8000:])
+        if "-c" in cmd:
+            check_scratch(cmd, r.stderr)
         return r
 
     if jobs:
