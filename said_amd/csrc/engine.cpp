@@ -2237,6 +2237,7 @@ int said_profile_unet(said_ctx* ctx, int Be, int T, int cfg_clips, int reps, int
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    release_cap_streams(ctx);   // a live stream pins a hardware queue (the clip groups need them): DESIGN.md 5.1
     return 0;
 }
 

@@ -493,7 +493,7 @@ def test_clip_groups_clone_workspace_grows(model, dev):
                 res[g] = model.inference(wav, num_inference_steps=3, guidance_scale=2.0, init_latents=lat, audio_embedding=emb).result
             d = float((res[1] - res[3]).abs().max())
             print(f"clone growth B={B} T={T}: max |whole - split| {d:.3e}")
-            assert d <= 1e-4 and len(model._clones) == 2
+            assert d <= 1e-4 and len(model._clones) >= 2
             assert all(c.max_frames >= T and c.max_batch_eff >= 2 * ((B + 2) // 3) for c in model._clones)
     finally:
         model.clip_groups = None
