@@ -58,8 +58,9 @@ int said_capacity(const said_ctx* ctx, int* max_batch_eff, int* max_frames);
 int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_frames);
 
 /* The non-blocking stream a clone's loops are meant to run on (NULL for a context made by said_create).  It comes from a pool of three
- * streams per device shared by every clone in the process and is never destroyed: a live stream occupies one of the device's few
- * hardware queues, and streams beyond their number share queues and serialise. */
+ * streams per device shared by every clone in the process and never destroyed.  Streams that share one of the device's few hardware queues
+ * serialise and the mapping cannot be queried, so the pool is picked by a one-off timing probe (about 5 ms, synchronises the device) at the
+ * first said_clone: three streams that run beside the default stream and beside each other. */
 void* said_stream(const said_ctx* ctx);
 const char* said_last_error(const said_ctx* ctx);
 /* ABI version of this library (bumped on any signature change). */

@@ -1423,17 +1423,61 @@ int said_reserve(said_ctx* ctx, int max_batch_eff, int max_frames) {
     return 0;
 }
 
-// The clones' streams come from ONE pool per device for the whole process (three streams, created on first use, never destroyed): a live
-// stream pins one of the device's hardware queues (four by default), and streams beyond that share queues and serialise — two models with
-// their own clone streams were enough for that (the second model's clip groups ran 16 % SLOWER than its unsplit batch).  Clones of
-// different parents therefore share streams; they only run side by side if the caller drives two models from two threads.
-constexpr int POOL_STREAMS = 3, POOL_DEVICES = 64;
+// The clones' streams come from ONE pool per device for the whole process (three streams, chosen on first use, never destroyed): a live
+// stream is mapped onto one of the device's few hardware queues (four by default), streams on the same queue serialise, and the mapping
+// follows creation order — with two other streams alive in the application the pool's second stream landed on the CALLER's queue and a
+// three-group loop ran 37 % slower (2.43 vs 1.77 ms per step), while with four others it was fine again.  There is no API to ask which
+// queue a stream sits on, so the pool is chosen by measurement: candidates are created one by one and probed with a 0.3 ms spinning wave —
+// two streams that finish two such waves in the time of one are on different queues — until three are found that run beside the default
+// stream and beside each other; the other candidates are destroyed.  Two models with a stream per clone were enough to exhaust the queues
+// (the second model's groups ran 16 % SLOWER than its unsplit batch): clones of different parents share the pool.
+constexpr int POOL_STREAMS = 3, POOL_DEVICES = 64, POOL_CANDIDATES = 12;
 static std::mutex g_pool_mu;
 static hipStream_t g_pool[POOL_DEVICES][POOL_STREAMS];
+static bool g_pool_ready[POOL_DEVICES];
+static int g_pool_probed[POOL_DEVICES];   // candidates looked at (said_debug_get "pool_probed")
+
+// true when a wave on `b` runs beside one on `a` (a == nullptr: the default stream)
+static bool streams_overlap(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1) {
+    const long long ticks = 30000;   // 0.3 ms of the 100 MHz wall clock
+    if (hipEventRecord(e0, a) != hipSuccess) return false;
+    launch_spin(ticks, a);
+    launch_spin(ticks, b);
+    if (hipEventRecord(e1, b) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return false;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return false;
+    return ms < 0.48f;               // serialised: >= 0.6 ms
+}
+static void pool_init(int dev) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int found = 0;
+    if (hipDeviceSynchronize() == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        launch_spin(1, nullptr);     // first launch of the probe kernel (module load) outside the measurements
+        (void)hipDeviceSynchronize();
+        hipStream_t rejected[POOL_CANDIDATES];
+        int nrej = 0;
+        for (int c = 0; c < POOL_CANDIDATES && found < POOL_STREAMS; ++c) {
+            hipStream_t s = nullptr;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+            ++g_pool_probed[dev];
+            bool ok = streams_overlap(nullptr, s, e0, e1);
+            for (int k = 0; ok && k < found; ++k) ok = streams_overlap(g_pool[dev][k], s, e0, e1);
+            if (ok) g_pool[dev][found++] = s;
+            else rejected[nrej++] = s;   // kept alive until the end: a destroyed candidate's queue is the next candidate's again
+        }
+        for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipGetLastError();
+    for (; found < POOL_STREAMS; ++found)   // fewer independent queues than groups (or the probe failed): any stream will do
+        if (hipStreamCreateWithFlags(&g_pool[dev][found], hipStreamNonBlocking) != hipSuccess) g_pool[dev][found] = nullptr;
+    g_pool_ready[dev] = true;
+}
 static hipStream_t pool_stream(int dev, int idx) {
     if (dev < 0 || dev >= POOL_DEVICES) return nullptr;
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    if (!g_pool[dev][idx] && hipStreamCreateWithFlags(&g_pool[dev][idx], hipStreamNonBlocking) != hipSuccess) g_pool[dev][idx] = nullptr;
+    if (!g_pool_ready[dev]) pool_init(dev);
     return g_pool[dev][idx];
 }
 
@@ -2148,6 +2192,7 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "audio_chunk") return ctx->audio_chunk;
     if (k == "steps_per_graph") return ctx->spg_limit;
     if (k == "tm_acts") return ctx->tm_acts;
+    if (k == "pool_probed") return (ctx->device >= 0 && ctx->device < POOL_DEVICES) ? g_pool_probed[ctx->device] : -1;
     return -1;
 }
 

@@ -177,6 +177,7 @@ void launch_fill_cm_vec(const float* vec, float* dst, int B, int T, int C, int p
 // freqs_dev: the context's own [dim/2] frequency table (no process-global state: several contexts may coexist)
 void launch_timestep_embedding(const long long* timesteps_dev, const float* freqs_dev, float* dst, int n, int dim, int pitch, hipStream_t s);
 void launch_step_advance(int* step_ptr, hipStream_t s);
+void launch_spin(long long ticks_100mhz, hipStream_t s);   // one wave busy for that long (stream-concurrency probe)
 void configure_gemm_kernels();   // raise the dynamic-LDS limit of every instantiation (call once, outside capture)
 void configure_attn_kernels();
 

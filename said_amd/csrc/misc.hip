@@ -11,6 +11,16 @@
 namespace said {
 
 // ------------------------------------------------------------------------------------------
+// spin_kernel: one wave busy for `ticks` of the 100 MHz wall clock — the probe behind the clip groups' stream pool (engine.cpp:
+// two streams run side by side only if they sit on different hardware queues, and that can only be found out by timing)
+// ------------------------------------------------------------------------------------------
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+void launch_spin(long long ticks, hipStream_t s) { hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, ticks); }
+
+// ------------------------------------------------------------------------------------------
 // launch_fault (kernels.h)
 // ------------------------------------------------------------------------------------------
 static thread_local char g_fault[256];

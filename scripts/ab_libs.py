@@ -23,6 +23,13 @@ m.to(dev).eval()
 ctx = synth.synth_latents(1, (B, T, 768)).to(dev)
 lat = synth.synth_latents(2, (B, T, 32)).to(dev)
 wav = torch.zeros(B, T * 16000 // 60, device=dev)
+extra = [torch.cuda.Stream(dev) for _ in range(int(os.environ.get("AB_EXTRA_STREAMS", "0")))]   # other live streams of the application
+for st in extra:
+    with torch.cuda.stream(st):
+        torch.zeros(16, device=dev).add_(1)
+torch.cuda.synchronize()
+if os.environ.get("AB_GROUPS"):
+    m.clip_groups = int(os.environ["AB_GROUPS"])
 for kv in os.environ.get("AB_OPTS", "").split():      # e.g. AB_OPTS="tm_acts=1": said_debug_option before the first inference
     k, v = kv.split("=")
     m._get_engine(2 * B, T).debug_option(k, int(v))
@@ -34,4 +41,5 @@ for dt in (sys.argv[4:] or ["bf16", "fp32"]):
     for _ in range(3):
         r = m.inference(wav, audio_embedding=ctx, num_inference_steps=N, guidance_scale=2.0, init_latents=lat).result
     torch.cuda.synchronize()
-    print(f"{os.path.basename(sys.argv[1])} B={B} {dt}: {(time.perf_counter() - t0) / 3 / N * 1e3:.4f} ms per step, checksum {float(r.double().sum()):.6f}", flush=True)
+    probed = m._eng.debug_get("pool_probed")
+    print(f"[pool candidates probed: {probed}] {os.path.basename(sys.argv[1])} B={B} {dt}: {(time.perf_counter() - t0) / 3 / N * 1e3:.4f} ms per step, checksum {float(r.double().sum()):.6f}", flush=True)

@@ -430,8 +430,9 @@ def test_clip_groups_two_streams_equal_whole_batch(model, dev, mode):
             torch.manual_seed(11)
             out[g] = model.inference(proc, num_inference_steps=N, guidance_scale=2.0, eta=1.0, init_latents=lat, audio_embedding=emb,
                                      save_intermediate=True)
-        assert model._pick_clip_groups(B, 2 * T) == 3      # the default at this size: three groups (10 + 11 + 11 clips)
-        assert len(model._clones) == 2 and model._eng.debug_get("n_set_weight") > 0
+        G = model._pick_clip_groups(B, 2 * T)
+        assert G == (4 if mode == "bf16" else 3)             # the default at this size: 10 + 11 + 11 clips (fp32), 4 x 8 (bf16)
+        assert len(model._clones) == G - 1 and model._eng.debug_get("n_set_weight") > 0
         assert all(c.debug_get("n_set_weight") == model._eng.debug_get("n_set_weight") for c in model._clones)   # weights shared, never re-sent
         if mode == "bf16":
             assert torch.equal(out[2].result, out[None].result)
