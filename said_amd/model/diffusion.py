@@ -198,7 +198,7 @@ class SAID(ABC, nn.Module):
         bf = self.mfma_dtype == "bf16"
         # (bf16 mode: four groups of >= 9000 rows beat three: 199.5k vs 194.0k frames/s at 32 clips x 50 steps, three alternating pairs;
         # fp32 mode: 36.5k vs 36.7k — stays at three.  Four groups = the caller's stream + the pool's three = every hardware queue.)
-        for g, need in ((4, 9000 if bf else 1 << 60), (3, 12000), (2, 9000 if bf else 12000)):
+        for g, need in ((4, 9000 if bf else 1 << 60), (3, 9000 if bf else 12000), (2, 9000 if bf else 12000)):
             if batch_size >= g and (batch_size // g) * tokens_per_clip >= need:
                 return g
         # Small batches (below ~the token-major threshold as a whole) are chains of short, latency-bound launches: two such chains side

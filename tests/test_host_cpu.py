@@ -270,7 +270,7 @@ def test_clip_group_policy():
     assert pick(2, 3600) == 1 and pick(8, 3600) == 2 and pick(12, 3600) == 3   # 30 s clips
     m.mfma_dtype = "bf16"
     assert pick(4, 1200) == 2 and pick(6, 1200) == 2 and pick(8, 1200) == 1
-    assert pick(12, 1200) == 1 and pick(16, 1200) == 2 and pick(24, 1200) == 2 and pick(32, 1200) == 4 and pick(64, 1200) == 4
+    assert pick(12, 1200) == 1 and pick(16, 1200) == 2 and pick(24, 1200) == 3 and pick(32, 1200) == 4 and pick(64, 1200) == 4
     m.clip_groups = 1
     assert pick(64, 1200) == 1
     m.clip_groups = 5
