@@ -434,6 +434,7 @@ def test_clip_groups_two_streams_equal_whole_batch(model, dev, mode):
         assert G == (4 if mode == "bf16" else 3)             # the default at this size: 10 + 11 + 11 clips (fp32), 4 x 8 (bf16)
         assert len(model._clones) == G - 1 and model._eng.debug_get("n_set_weight") > 0
         assert all(c.debug_get("n_set_weight") == model._eng.debug_get("n_set_weight") for c in model._clones)   # weights shared, never re-sent
+        assert 3 <= model._eng.debug_get("pool_probed") <= 12        # the groups' streams were picked by the timing probe (engine.cpp pool_init)
         if mode == "bf16":
             assert torch.equal(out[2].result, out[None].result)
         else:
