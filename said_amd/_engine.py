@@ -178,10 +178,13 @@ class Engine:
     def reserve(self, max_batch_eff: int, max_frames: int) -> None:
         """Grow the workspace (never shrinks); the packed weights stay on the device (said_reserve)."""
         with torch.cuda.device(self.index):
-            self._chk(self.lib.said_reserve(self.h, int(max_batch_eff), int(max_frames)), "said_reserve")
+            rc = self.lib.said_reserve(self.h, int(max_batch_eff), int(max_frames))
+        msg = (self.lib.said_last_error(self.h) or b"?").decode() if rc != 0 else ""
         b, t = c_int(0), c_int(0)
         self._chk(self.lib.said_capacity(self.h, ctypes.byref(b), ctypes.byref(t)), "said_capacity")
-        self.max_batch_eff, self.max_frames = b.value, t.value
+        self.max_batch_eff, self.max_frames = b.value, t.value   # (0, 0) after a failed growth: the context refuses every size
+        if rc != 0:
+            raise EngineError("said_reserve: " + msg)
 
     # ---- weights ----
     def load_weights(self, state_dict: Dict[str, torch.Tensor]):

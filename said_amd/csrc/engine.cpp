@@ -154,6 +154,9 @@ struct said_ctx {
     bool hybrid = true;       // bf16 mode at large batch: SpatialTransformers from the attention output on use round 3's token-major kernels
     int xgemm_dbg = 0;
     bool xclk_on = false;
+    int pgemm = -1;           // round 4: the token-major-activation GEMMs as persistent weight-stationary workgroups (pgemm.hip).  -1: wherever
+                              // launch_pgemm serves the shape (bf16 mode), 0: round 3's xgemm_kernel only (said_debug_option "pgemm")
+    long long n_pgemm = 0, n_xgemm = 0;   // launches issued through either kernel family (said_debug_get)
     int xgemm_ntw = 0;        // test / measurement: column tiles per workgroup of the resident-source GEMMs (0: launch_xgemm decides)
     void *tX1 = nullptr, *tX2 = nullptr, *tO = nullptr, *tF = nullptr;   // token-major x1, x2, attention output [.][192], GEGLU product [.][768]
     bool unet_tgemm = true;   // SAID_NO_UNET_TGEMM=1 keeps the channel-major kernels in bf16 mode at every batch size
@@ -640,7 +643,11 @@ void tg_cm_out(TGemmArgs& t, const UGeo& g, const ActBuf& out) {
 
 // ---- round 3, large batches: token-major activations between the kernels, operand transforms inside the GEMMs (xgemm_kernel) ----
 inline int tm_seg(const UGeo& g) { return rup(g.T, 64); }   // sample pitch in tokens: a 64-row tile never straddles samples
-inline bool use_tm(said_ctx* c, const UGeo& g) { return (c->tm_acts < 0 ? c->bf16_mode : c->tm_acts != 0) && use_tg(c, g, g.Be) && g.b0 == 0; }
+// (32-bit element offsets inside the kernels: the widest token-major tensor here is the GEGLU product, sample pitch tm_seg — up to 4/3 of
+// the rup(T + 2, 32) pitch use_tg's guard is written for)
+inline bool use_tm(said_ctx* c, const UGeo& g) {
+    return (c->tm_acts < 0 ? c->bf16_mode : c->tm_acts != 0) && use_tg(c, g, g.Be) && g.b0 == 0 && ((long long)g.Be * tm_seg(g) + 2) * FFI < 0x7fffffffLL;
+}
 // `rows` tokens further into a token-major tensor of row width `ld` (element size by precision mode)
 inline void* tm_at(const said_ctx* c, void* base, long long rows, int ld) { return static_cast<char*>(base) + rows * ld * (c->bf16_mode ? 2 : 4); }
 void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
@@ -660,6 +667,11 @@ void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     a2.dbg = c->xgemm_dbg;
     if (c->xclk_on && c->dbg_count < 64) a2.clk = c->clk_dev + (long long)c->dbg_count * 128;
     if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }
+    if (c->pgemm != 0 && !a2.f32 && pgemm_supports(a2, batch)) {
+        if (dbg_go(c)) { launch_pgemm(a2, batch, s); ++c->n_pgemm; }
+        return;
+    }
+    ++c->n_xgemm;
     if (dbg_go(c) && !launch_xgemm(a2, batch, s)) {
         char b[160]; snprintf(b, sizeof b, "token-major activation GEMM: shape M=%d N=%d K=%d (batch %d) is not served by any kernel", a.M, a.N, a.K, batch);
         c->launch_err = b;
@@ -1383,6 +1395,8 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     ctx->unet_fgemm = dev_env("SAID_NO_UNET_FGEMM") == nullptr;
     if (dev_env("SAID_UNET_TGEMM_MIN")) ctx->unet_tgemm_min_tokens = ctx->unet_fgemm_min_tokens = atoll(dev_env("SAID_UNET_TGEMM_MIN"));
     configure_tgemm_kernel();
+    configure_xgemm_kernels();
+    configure_pgemm_kernels();
 
     int rc = 0;
     rc |= dalloc(ctx, &ctx->coef1_dev, 8);
@@ -1419,7 +1433,20 @@ int said_reserve(said_ctx* ctx, int max_batch_eff, int max_frames) {
     drop_graphs(ctx);   // the captured step graphs hold the old buffers' addresses
     for (void* p : ctx->ws_allocs) (void)hipFree(p);
     ctx->ws_allocs.clear();
-    if (alloc_workspace(ctx, std::max(max_batch_eff, ctx->maxBe), std::max(max_frames, ctx->maxT))) return -1;
+    const int want_be = std::max(max_batch_eff, ctx->maxBe), want_t = std::max(max_frames, ctx->maxT);
+    if (alloc_workspace(ctx, want_be, want_t)) {
+        // Out of memory part-way through: the old workspace is gone and some members still hold its (freed) addresses.  Release what was
+        // obtained and advertise NO capacity — every entry point then refuses its sizes instead of running on freed memory — until a
+        // later said_reserve (e.g. with a smaller batch) succeeds and re-assigns every workspace pointer.
+        const std::string why = ctx->err;
+        for (void* p : ctx->ws_allocs) (void)hipFree(p);
+        ctx->ws_allocs.clear();
+        (void)hipGetLastError();
+        ctx->maxBe = 0; ctx->maxT = 0; ctx->maxTp = 0;
+        ctx->band_T = ctx->band_S = -1;
+        return fail(ctx, "said_reserve(%d, %d): workspace allocation failed (%s); the context has no workspace until a smaller said_reserve succeeds",
+                    want_be, want_t, why.c_str());
+    }
     return 0;
 }
 
@@ -2035,6 +2062,11 @@ static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, boo
             HIPCHK(hipMemsetAsync(ctx->step_dev, 0xFF, sizeof(int), s));
             HIPCHK(hipStreamSynchronize(s));
             TRACE("loop: warmup synced");
+            // A launch helper that refused a shape launched NOTHING (launch_fault / launch_err): a graph captured from the same schedule would be
+            // missing that kernel and — cached under this key — replay silently wrong on every later call.  So the faults of the warm-up and of
+            // each capture are consumed HERE, on the thread that drove them, in the prepare-only path too, and nothing is cached.
+            auto loop_fault = [&]() -> bool { return launch_fault_peek() != nullptr || !ctx->launch_err.empty(); };
+            if (loop_fault()) { drop_graphs(ctx); LAUNCHCHK(); }
             // capture on a private stream: the caller's stream may be the legacy default stream,
             // which cannot be captured; the instantiated graph is then replayed on the caller's stream
             if (ensure_cap_streams(ctx)) return -1;
@@ -2069,8 +2101,10 @@ static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, boo
                 HIPCHK(hipGraphInstantiate(ge, *gr, nullptr, nullptr, 0));
                 return 0;
             };
-            if (capture_steps(spg, &ctx->graph, &ctx->gexec)) return -1;
-            if (rem > 0 && capture_steps(rem, &ctx->graph_rem, &ctx->gexec_rem)) return -1;
+            if (capture_steps(spg, &ctx->graph, &ctx->gexec)) { drop_graphs(ctx); release_cap_streams(ctx); return -1; }
+            if (loop_fault()) { drop_graphs(ctx); release_cap_streams(ctx); LAUNCHCHK(); }
+            if (rem > 0 && capture_steps(rem, &ctx->graph_rem, &ctx->gexec_rem)) { drop_graphs(ctx); release_cap_streams(ctx); return -1; }
+            if (loop_fault()) { drop_graphs(ctx); release_cap_streams(ctx); LAUNCHCHK(); }
             size_t nn = 0;
             (void)hipGraphGetNodes(ctx->graph, nullptr, &nn);
             ctx->gnodes = (int)nn / spg;
@@ -2177,6 +2211,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->xgemm_dbg = (int)value;
     } else if (k == "tm_acts") {
         ctx->tm_acts = value < 0 ? -1 : (value != 0);
+    } else if (k == "pgemm") {
+        ctx->pgemm = value < 0 ? -1 : (value != 0);
     } else {
         return fail(ctx, "said_debug_option: unknown option %s", name);
     }
@@ -2192,6 +2228,9 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "audio_chunk") return ctx->audio_chunk;
     if (k == "steps_per_graph") return ctx->spg_limit;
     if (k == "tm_acts") return ctx->tm_acts;
+    if (k == "pgemm") return ctx->pgemm;
+    if (k == "n_pgemm") return ctx->n_pgemm;
+    if (k == "n_xgemm") return ctx->n_xgemm;
     if (k == "pool_probed") return (ctx->device >= 0 && ctx->device < POOL_DEVICES) ? g_pool_probed[ctx->device] : -1;
     return -1;
 }

@@ -72,6 +72,7 @@ struct TGemmArgs {
     // channels of ra[0], then of ra[1] (concatenated input) — is loaded ONCE, transformed once per element and parked in LDS;
     // only the weights stream.  k order of W for this segment: [tap][source][channel] (Conv1d weight, tap-major).
     int ntw;               // column tiles per workgroup (0: chosen by launch_xgemm)
+    int pg_s, pg_per;      // pgemm_kernel (filled in by launch_pgemm): column slices of the launch, row tiles per row group
     long long* clk;        // optional [4 waves][16] shader-clock stamps of workgroup 8 (-DSAID_CLK_STAMPS builds; scripts/xgemm_clocks.py)
     const void* ra[2];     // sources (row pitch 192), or null
     int rmode;             // 0: raw, 1: silu(GroupNorm(x)), 2: LayerNorm(x), 3: LayerNorm(GroupNorm(x))
@@ -106,6 +107,11 @@ void configure_tgemm_kernel();
 // GEMMs on token-major activations with the operand transform inside (TGemmArgs fields of round 3)
 bool xgemm_supports(const TGemmArgs& a);
 bool launch_xgemm(const TGemmArgs& a, int batch, hipStream_t s);
+void configure_xgemm_kernels();
+// round 4 (pgemm.hip): the same launches as persistent weight-stationary workgroups (bf16 mode); false: not served (nothing launched)
+bool pgemm_supports(const TGemmArgs& a, int batch);
+bool launch_pgemm(const TGemmArgs& a, int batch, hipStream_t s);
+void configure_pgemm_kernels();
 // UNet operand preparation (bf16 mode, large batches): channel-major fp32 x[b][C][pitch] -> transform -> token-major bf16.
 // mode 0: silu(GroupNorm(x)) into dst[b][1 + t][ldd] at column `coff` (rows 0 and T + 1 zero: Conv1d padding), mode 1:
 // LayerNorm(GroupNorm(x)) -> dst[b][t][ldd], mode 2: LayerNorm(x) -> dst and raw x -> dst2 (both [b][t][*]), mode 3: raw x.

@@ -104,11 +104,21 @@ class SAID(ABC, nn.Module):
         self._eng_stale = True
         return self
 
+    def __setattr__(self, name, value):
+        # a parameter or submodule replaced on the model (`model.null_cond_emb = nn.Parameter(..)`, `model.denoiser = ...`): the cached
+        # parameter list below would keep pointing at the old tensors
+        if isinstance(value, (torch.nn.Parameter, torch.nn.Module)):
+            self.__dict__["_eng_stale"] = True
+            self.__dict__["_param_list"] = None
+        super().__setattr__(name, value)
+
     def _weights_key(self):
         ps = self._param_list
         if ps is None:
             ps = self._param_list = list(self.parameters())
-        return (str(ps[0].device), sum(p._version for p in ps))
+        # versions: in-place updates; data pointers: `.to()` / `.half()` / `.data = ...` on a SUBMODULE (they replace param.data without
+        # bumping the version counter and do not pass through this module's _apply)
+        return (str(ps[0].device), sum(p._version for p in ps), sum(p.data_ptr() for p in ps))
 
     def _get_engine(self, batch_eff: int, frames: int) -> _engine.Engine:
         e = self._eng
@@ -130,7 +140,16 @@ class SAID(ABC, nn.Module):
             self.noise_scheduler._engine = e
         elif e.max_batch_eff < batch_eff or e.max_frames < frames:
             # a larger batch or a longer clip: only the workspace grows, the packed weights stay where they are
-            e.reserve(max(batch_eff, e.max_batch_eff), max((frames + 63) // 64 * 64, e.max_frames))
+            try:
+                e.reserve(max(batch_eff, e.max_batch_eff), max((frames + 63) // 64 * 64, e.max_frames))
+            except _engine.EngineError:
+                # out of memory while growing: the context has lost its workspace (said_reserve) — drop it, the next call builds a fresh one
+                for c in self._clones:
+                    c.close()
+                self._clones = []
+                e.close()
+                self._eng = None
+                raise
         e.set_precision(self.mfma_dtype == "bf16")
         return e
 
