@@ -154,7 +154,10 @@ struct said_ctx {
     bool hybrid = true;       // bf16 mode at large batch: SpatialTransformers from the attention output on use round 3's token-major kernels
     int xgemm_dbg = 0;
     bool xclk_on = false;
-    int pgemm = -1;           // round 4: the token-major-activation GEMMs as persistent weight-stationary workgroups (pgemm.hip).  -1: wherever
+    int rgemm = -1;           // round 4: register-stationary, wave-specialised persistent GEMMs (rgemm.hip) wherever launch_rgemm serves the shape
+                              // (bf16 mode: 192-wide GEMMs with K <= 576, q/k/v); 0: off (said_debug_option "rgemm")
+    long long n_rgemm = 0;
+    int pgemm = 0;            // round 4: the token-major-activation GEMMs as persistent weight-stationary workgroups (pgemm.hip).  -1: wherever
                               // launch_pgemm serves the shape (bf16 mode), 0: round 3's xgemm_kernel only (said_debug_option "pgemm")
     long long n_pgemm = 0, n_xgemm = 0;   // launches issued through either kernel family (said_debug_get)
     int xgemm_ntw = 0;        // test / measurement: column tiles per workgroup of the resident-source GEMMs (0: launch_xgemm decides)
@@ -667,6 +670,10 @@ void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     a2.dbg = c->xgemm_dbg;
     if (c->xclk_on && c->dbg_count < 64) a2.clk = c->clk_dev + (long long)c->dbg_count * 128;
     if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }
+    if (c->rgemm != 0 && !a2.f32 && rgemm_supports(a2, batch)) {
+        if (dbg_go(c)) { launch_rgemm(a2, batch, s); ++c->n_rgemm; }
+        return;
+    }
     if (c->pgemm != 0 && !a2.f32 && pgemm_supports(a2, batch)) {
         if (dbg_go(c)) { launch_pgemm(a2, batch, s); ++c->n_pgemm; }
         return;
@@ -1397,6 +1404,7 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     configure_tgemm_kernel();
     configure_xgemm_kernels();
     configure_pgemm_kernels();
+    configure_rgemm_kernels();
 
     int rc = 0;
     rc |= dalloc(ctx, &ctx->coef1_dev, 8);
@@ -2213,6 +2221,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->tm_acts = value < 0 ? -1 : (value != 0);
     } else if (k == "pgemm") {
         ctx->pgemm = value < 0 ? -1 : (value != 0);
+    } else if (k == "rgemm") {
+        ctx->rgemm = value < 0 ? -1 : (value != 0);
     } else {
         return fail(ctx, "said_debug_option: unknown option %s", name);
     }
@@ -2230,6 +2240,8 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "tm_acts") return ctx->tm_acts;
     if (k == "pgemm") return ctx->pgemm;
     if (k == "n_pgemm") return ctx->n_pgemm;
+    if (k == "rgemm") return ctx->rgemm;
+    if (k == "n_rgemm") return ctx->n_rgemm;
     if (k == "n_xgemm") return ctx->n_xgemm;
     if (k == "pool_probed") return (ctx->device >= 0 && ctx->device < POOL_DEVICES) ? g_pool_probed[ctx->device] : -1;
     return -1;

@@ -1,0 +1,580 @@
+// rgemm.hip — REGISTER-STATIONARY weights, WAVE-SPECIALISED persistent GEMMs on token-major activations (round 4; bf16 mode,
+// large batches): the 192-wide GEMMs with K <= 576 — the ResBlock convolutions 192 -> 192 (k = 3), attn1.to_out, attn2.to_out,
+// the banded cross-attention's q projection — and q/k/v (N = 576, K = 192).
+//
+// What pgemm.hip (weights resident in LDS, one 4-wave workgroup per CU walking over row tiles) taught, by its shader-clock stamps
+// (profiles/r04a_pgemm_clocks.txt): with ONE wave per SIMD every phase of a row tile is a latency chain — 5.0k clocks of MFMA phase
+// against 1.7k of MFMA, 5.7k for the GroupNorm + SiLU transform of a 66 x 192 tile, 7.7k for the epilogue — and the 112 KB weight slice of a
+// 3-tap convolution leaves no LDS for a second set of waves.  So the weights move to where a CU has most room, the register file:
+//
+//   * waves 0-5 are MFMA waves: wave j owns output columns [32 j, 32 j + 32) (q/k/v: head j of q, k and v) and keeps THEIR weight
+//     fragments — 32 rows x K bf16 = 144 VGPRs at K = 576 — in registers for the whole launch (fetched once in full 128-byte lines
+//     through a wave-private LDS staging area: fragment-shaped loads straight from memory took 25k clocks).  Per 32-token row tile it reads
+//     the A fragments from an LDS tile (conflict-free 16-byte reads, 400-byte rows; the three taps of a convolution are three row
+//     offsets; six fragments in flight, two accumulators), issues K / 16 MFMAs and finishes ITS 32 x 32 output tile itself: bias +
+//     timestep-embedding term in the MFMA layout (lane == column), a transposition through a wave-private 4.6 KB scratch, residual (16-byte
+//     loads issued before the MFMAs; optionally GroupNorm'ed), rounding, 16-byte stores, duplicate store, GroupNorm partials of the stored
+//     values (read back lane == column: in-lane sums) — or direct stores where the MFMA layout is already coalesced (q / k: 128-byte rows
+//     of a head; v: transposed product, 128 bytes of consecutive tokens per channel) — or the banded cross-attention of head j;
+//   * waves 6-7 are helper waves (lane = (row slot, 6 consecutive channels = 12 bytes)): they load the source rows two tiles ahead, apply
+//     the operand transform once per element (GroupNorm coefficients of the sample in registers; LayerNorm sums over the 32 lanes of a row
+//     by DPP) and park the tile in the other LDS buffer, as STRAIGHT-LINE code (compile-time transform, clamped addresses instead of
+//     branches: with loads inside run-time branches hipcc's wait counts fall back to vmcnt(0) and every use of a prefetched register
+//     also waits for the loads issued after it);
+//   * ONE workgroup barrier per tile (LDS data only: s_waitcnt lgkmcnt(0) + s_barrier, global loads stay in flight across it).
+//
+// One workgroup of 8 waves per CU (<= 256 VGPRs each), 64 KB of LDS, <= 256 workgroups for the whole batch, each walking over its
+// contiguous share of the 32-token tiles.  All 192 columns of a row tile are produced by ONE workgroup: the operand transform runs once
+// per tile.  Reference semantics: /root/reference/said/model/ldm/openaimodel.py:116-227 (ResBlock: in_layers, emb_layers, out_layers,
+// skip), ldm/attention.py:86-128, 131-193 (to_q/k/v, to_out, norm1-3 and the residuals around them).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "gemm_common.h"
+#include "tgemm.h"
+#include "tgemm_dev.h"
+
+namespace said {
+
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int RG_AP = 200;                        // A tile row pitch in elements (192 + 8: 400 bytes)
+constexpr int RG_AROWS = 34;                      // 32 tokens + 2 halo
+constexpr int RG_A_ELEMS = RG_AROWS * RG_AP;
+constexpr int RG_WS_FLOATS = 32 * 36;             // wave-private scratch: [32 rows][32 + 4] floats = 4608 bytes (= [32 rows][144 bytes] of weight staging)
+constexpr int RG_COEF_FLOATS = 2 * 4 * 384;        // GroupNorm (a, b) tables [kind: source / residual][slot = sample & 3][192][2]
+constexpr int RG_LDS_BYTES = 2 * RG_A_ELEMS * 2 + 6 * RG_WS_FLOATS * 4 + RG_COEF_FLOATS * 4 + 2 * GN_SCRATCH * 4;
+
+// GroupNorm coefficients of a 48-channel slice (lane <-> channel, 48 lanes active) with up to TWENTY partial tiles in flight per lane
+// (T <= 640: one memory round trip; gemm_common.h's gn_issue / gn_finish take ten per round).  Same combination order as there.
+struct GnL20 { float2 v[20]; float ref, gamma, beta; };
+__device__ __forceinline__ void gn20_issue(const GnP sg, rsrc_t rp, int c_lo, int lane, GnL20& L) {
+    const bool chok = lane < 48;
+    const int c = c_lo + (chok ? lane : 0);
+    const int gfirst = (int)(((float)c + 0.5f) * __builtin_amdgcn_rcpf((float)sg.gn_cpg)) * sg.gn_cpg;
+    L.ref = bload(rp, gfirst * 8, 0);
+    L.gamma = gload(sg.gn_gamma, c);
+    L.beta = gload(sg.gn_beta, c);
+#pragma unroll
+    for (int r = 0; r < 20; ++r) {
+        const bool ok = chok && (r < sg.gn_nparts);
+        L.v[r] = bload2(rp, ok ? (r * sg.ct + c) * 8 : (int)0x80000000, 0);
+    }
+}
+__device__ __forceinline__ void gn20_finish(const GnP sg, rsrc_t rp, int c_lo, int lane, const GnL20& L, float* scratch, float* cA) {
+    const bool chok = lane < 48;
+    const int c = c_lo + (chok ? lane : 0);
+    const int nparts = sg.gn_nparts;
+    const int tail = sg.Tin - (nparts - 1) * 32;
+    float s1 = 0.f, s2 = 0.f, sm = 0.f;
+#pragma unroll
+    for (int r = 0; r < 20; ++r) {
+        const bool ok = chok && (r < nparts);
+        const float cnt = ok ? ((r == nparts - 1) ? (float)tail : 32.f) : 0.f;
+        const float d = L.v[r].x - L.ref;
+        s1 = fmaf(cnt, d, s1);
+        s2 = fmaf(cnt * d, d, s2);
+        sm += ok ? L.v[r].y : 0.f;
+    }
+    for (int r0 = 20; r0 < nparts; r0 += 10) {   // long sequences: further rounds of 10 tiles
+        float2 v[10];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const bool ok = chok && (r0 + r < nparts);
+            v[r] = bload2(rp, ok ? ((r0 + r) * sg.ct + c) * 8 : (int)0x80000000, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const int pi = r0 + r;
+            const bool ok = chok && (pi < nparts);
+            const float cnt = ok ? ((pi == nparts - 1) ? (float)tail : 32.f) : 0.f;
+            const float d = v[r].x - L.ref;
+            s1 = fmaf(cnt, d, s1);
+            s2 = fmaf(cnt * d, d, s2);
+            sm += ok ? v[r].y : 0.f;
+        }
+    }
+    float* sc = scratch;            // [64][3]
+    float* gs = scratch + 64 * 3;   // [16][2] (mean, rstd) per group of this slice
+    if (chok) { sc[lane * 3] = s1; sc[lane * 3 + 1] = s2; sc[lane * 3 + 2] = sm; }
+    const float rcp_cpg = __builtin_amdgcn_rcpf((float)sg.gn_cpg);
+    const int gpw = (int)((48.0f + 0.5f) * rcp_cpg);
+    if (lane < gpw) {
+        float S1 = 0.f, S2 = 0.f, SM = 0.f;
+        for (int q = 0; q < sg.gn_cpg; ++q) {
+            const int cc = lane * sg.gn_cpg + q;
+            S1 += sc[cc * 3]; S2 += sc[cc * 3 + 1]; SM += sc[cc * 3 + 2];
+        }
+        const float total = (float)sg.gn_cpg * (float)sg.Tin;
+        const float inv_total = __builtin_amdgcn_rcpf(total);
+        const float md = S1 * inv_total;
+        const float var = fmaxf((SM + S2 - total * md * md) * inv_total, 0.f);
+        gs[lane * 2] = md;
+        gs[lane * 2 + 1] = __builtin_amdgcn_rsqf(var + sg.gn_eps);
+    }
+    if (chok) {
+        const int gi = (int)(((float)lane + 0.5f) * rcp_cpg);
+        const float mean = L.ref + gs[gi * 2];
+        const float av = gs[gi * 2 + 1] * L.gamma;
+        cA[2 * c] = av;
+        cA[2 * c + 1] = L.beta - mean * av;
+    }
+}
+
+// Workgroup barrier for data exchanged through LDS only: the LDS counter is drained, global loads and stores stay in flight across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const bf16x2 p = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// EK: 0 token-major activation out, 1 q/k/v split (direct stores), 4 banded cross-attention (transposed product)
+// MODE: operand transform (0 raw, 1 silu(GroupNorm), 2 LayerNorm, 3 LayerNorm(GroupNorm)); RES: 0 none, 1 plain, 2 GroupNorm'ed residual;
+// DUP: second copy of the result (+ per-channel constant); STATS: GroupNorm partials of the stored values
+template <int NTAP, int EK, int MODE, int RES, bool DUP, bool STATS>
+__global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    typedef unsigned short elt_t;
+    constexpr int NCT = EK == 1 ? 3 : 1;          // column tiles per MFMA wave
+    constexpr int NACC = NCT == 1 ? 2 : 1;        // accumulators per column tile (one tile: two interleaved chains)
+    constexpr int NTS = NTAP * 12;                // k16 steps
+    constexpr int HALO = NTAP == 3 ? 1 : 0;
+    constexpr int NR = 32 + 2 * HALO;             // rows of an A tile
+    constexpr int RPW = NR / 2;                   // rows per helper wave
+    constexpr int NPASS = (RPW + 1) / 2;          // two rows per helper wave and pass
+    constexpr int AP = RG_AP;
+    elt_t* const Abuf = lds;
+    float* const wscr = reinterpret_cast<float*>(lds + 2 * RG_A_ELEMS);   // [6 MFMA waves][RG_WS_FLOATS]
+    float* const coefS = wscr + 6 * RG_WS_FLOATS; // [source / residual][sample & 3][192][2]
+    float* const gnscr = coefS + RG_COEF_FLOATS;  // [helper wave][GN_SCRATCH]
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int ntv = (a.M + 31) >> 5;              // valid 32-token tiles per sample
+    const int total = a.batch * ntv;
+    const int tb = (int)blockIdx.x * a.pg_per;
+    const int n = min(total, tb + a.pg_per) - tb;
+    if (n <= 0) return;
+    const int t_last = tb + n - 1;
+
+    if (w < 6) {
+        // =================================================================== MFMA waves
+        const int j = w, fr = l & 31, lh = l >> 5;
+        float* const ws = wscr + j * RG_WS_FLOATS;
+        const elt_t* W = reinterpret_cast<const elt_t*>(a.w);
+        bf16x8 wf[NCT][NTS];
+        {   // ---- weights: rounds of four k16 steps = 128 bytes of each of the wave's 32 rows: four 16-byte loads per lane that cover eight
+            // full rows each -> the staging area [32][144 bytes] -> this lane's four fragments
+            const int srow = l >> 3, spc = l & 7;           // staging: lane -> (row within 8, 16-byte piece)
+            u32x4* const st = reinterpret_cast<u32x4*>(ws);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const elt_t* wbase = W + (long long)(ct * 192 + 32 * j) * a.K;
+#pragma unroll
+                for (int r4 = 0; r4 < NTS / 4; ++r4) {
+                    u32x4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4*>(wbase + (long long)(8 * q + srow) * a.K + 64 * r4 + 8 * spc);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) st[(8 * q + srow) * 9 + spc] = v[q];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) wf[ct][4 * r4 + s4] = __builtin_bit_cast(bf16x8, st[fr * 9 + 2 * s4 + lh]);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        float bias_n[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) bias_n[ct] = a.bias ? a.bias[ct * 192 + 32 * j + fr] : 0.f;
+        // epilogue mapping (EK 0): lane -> (row 16 q + (l >> 2), columns 8 (l & 3) .. + 7 of the wave's 32)
+        const int er = l >> 2, ec = l & 3;
+        float rca[8], rcb[8], add2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { rca[e] = 1.f; rcb[e] = 0.f; add2[e] = (EK == 0 && DUP && a.y2_add) ? a.y2_add[32 * j + 8 * ec + e] : 0.f; }
+        int cur_b = -1;
+        const rsrc_t rsrc_res = make_rsrc((EK == 0 && RES != 0) ? a.res_tm : a.w, 0x7ffffff0u);
+        const rsrc_t rsrc_y = make_rsrc(EK == 0 ? a.y_tm : (void*)a.w, 0x7ffffff0u);
+        const rsrc_t rsrc_y2 = make_rsrc((EK == 0 && DUP) ? a.y2_tm : (void*)a.w, 0x7ffffff0u);
+        clk_stamp_p(a.clk, w, l, 0);
+        lds_barrier();                            // (the helpers' coefficient tables of the first samples are published)
+        lds_barrier();                            // the first tile is parked
+        clk_stamp_p(a.clk, w, l, 1);
+        for (int k = 0; k < n; ++k) {
+            const int ti = tb + k;
+            const int b = ti / ntv, t0 = (ti - b * ntv) * 32;
+            const int nrows = min(32, a.M - t0);
+            const int R0 = b * a.seg_rows + t0;
+            float add = bias_n[0];
+            u32x4 rres[2];
+            if constexpr (EK == 0) {
+                if (a.emb) add += a.emb[(long long)(32 * j + fr) * a.emb_pitch + (a.step_ptr ? *a.step_ptr : 0) + b * a.emb_b_stride];
+                if constexpr (RES != 0) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int row = min(16 * q + er, nrows - 1);
+                        rres[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, ((R0 + row) * a.ldr_tm + 32 * j + 8 * ec) * 2, 0, 0));
+                    }
+                }
+                if constexpr (RES == 2) {
+                    if (b != cur_b) {   // (the helpers published this sample's table at least one barrier ago)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { rca[e] = coefS[(4 + (b & 3)) * 384 + 2 * (32 * j + 8 * ec + e)]; rcb[e] = coefS[(4 + (b & 3)) * 384 + 2 * (32 * j + 8 * ec + e) + 1]; }
+                        cur_b = b;
+                    }
+                }
+            }
+            // ---- K / 16 MFMAs: A fragments six at a time, one group ahead
+            f32x16 acc[NCT][NACC];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int x = 0; x < NACC; ++x)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ct][x][r] = 0.f;
+            const elt_t* pa = Abuf + (k & 1) * RG_A_ELEMS + fr * AP + 8 * lh;
+            constexpr int GS = NCT == 3 ? 3 : 6;   // fragments per group (q/k/v: three MFMAs per fragment, and 144 + 48 registers already taken)
+            constexpr int NG = NTS / GS;
+            bf16x8 fa[2][GS];
+#pragma unroll
+            for (int s = 0; s < GS; ++s) fa[0][s] = *reinterpret_cast<const bf16x8*>(pa + 16 * s);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) {
+                    const int ts0 = (g + 1) * GS, tap = ts0 / 12, s0 = ts0 - 12 * tap;
+#pragma unroll
+                    for (int s = 0; s < GS; ++s) fa[(g + 1) & 1][s] = *reinterpret_cast<const bf16x8*>(pa + tap * AP + 16 * (s0 + s));
+                }
+#pragma unroll
+                for (int s = 0; s < GS; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        const bool tr = EK == 4 || (EK == 1 && ct == 2);
+                        f32x16& ac = acc[ct][NACC == 2 ? (s & 1) : 0];
+                        if (tr) ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ct][GS * g + s], fa[g & 1][s], ac, 0, 0, 0);
+                        else ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][s], wf[ct][GS * g + s], ac, 0, 0, 0);
+                    }
+            }
+            if constexpr (NACC == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] += acc[0][1][r];
+            }
+            if (k < 3) clk_stamp_p(a.clk, w, l, 2 + 3 * k);
+            if constexpr (EK == 1) {
+                // q, k: D[token][d] (lane == d); v: the transposed product D[channel][token] (lane == token).  Straight from the MFMA layout a
+                // store instruction moves 4 bytes per lane — 48 of them per tile and wave, and the stamps showed the store issue, not the
+                // MFMAs, setting the period (6.5k clocks).  Through the wave's scratch every lane stores 16 bytes: rows of [tokens][32 d]
+                // (q, k: 128 contiguous bytes per token and head) / [channels][32 tokens] (v: 128 bytes per channel).
+                const rsrc_t rq = make_rsrc(a.qk, 0x7ffffff0u), rv = make_rsrc(a.vt, 0x7ffffff0u);
+                const int prow = l >> 3, pc4 = (l & 7) * 4;
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        float bv = bias_n[ct];
+                        if (ct == 2) bv = a.bias ? a.bias[384 + 32 * j + row] : 0.f;
+                        ws[row * 36 + fr] = acc[ct][0][r] + bv;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int p4 = 0; p4 < 4; ++p4) {
+                        const int row = 8 * p4 + prow;
+                        f32x4t v = *reinterpret_cast<const f32x4t*>(ws + row * 36 + pc4);
+                        int off;
+                        if (ct < 2) {
+                            off = row < nrows ? (((b * a.heads2 + ct * 6 + j) * a.rows + t0 + row) * 32 + pc4) * 4 : (int)0x80000000;
+                        } else {   // (padding tokens of the tile: zeros — attention multiplies them by p = 0)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = pc4 + e < nrows ? v[e] : 0.f;
+                            off = (int)(((long long)b * a.v_bs + (long long)(32 * j + row) * a.v_pitch + t0 + pc4) * 4);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ct < 2 ? rq : rv, off, 0, 0);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else if constexpr (EK == 4) {
+                const int t = t0 + fr;
+                const bool tv = t < a.M;
+                const int tc = min(t, a.M - 1);
+                band_head<true>(a, acc[0][0], b, t, tv, a.band_lo[tc], a.band_hi[tc], j, l);
+            } else {
+                // ---- this wave's 32 x 32 tile: MFMA layout (lane == column) -> scratch -> rows (lane == 8 consecutive columns of a row)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + fr] = acc[0][0][r] + add;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int row = 16 * q + er;
+                    const bool on = row < nrows;
+                    const f32x4t v0 = *reinterpret_cast<const f32x4t*>(ws + row * 36 + 8 * ec);
+                    const f32x4t v1 = *reinterpret_cast<const f32x4t*>(ws + row * 36 + 8 * ec + 4);
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if constexpr (RES != 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float r0 = bf_lo(rres[q][e]), r1 = bf_hi(rres[q][e]);
+                            v[2 * e] += RES == 2 ? fmaf(r0, rca[2 * e], rcb[2 * e]) : r0;
+                            v[2 * e + 1] += RES == 2 ? fmaf(r1, rca[2 * e + 1], rcb[2 * e + 1]) : r1;
+                        }
+                    }
+                    const u32x4 ov = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+                    const int off = on ? ((R0 + row) * a.ldy + 32 * j + 8 * ec) * 2 : (int)0x80000000;   // (out of range: the hardware drops the store)
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, off, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(ov[e]); v[2 * e + 1] = bf_hi(ov[e]); }   // the stored values
+                    if constexpr (DUP) {
+                        const u32x4 o2 = {pack_bf16(v[0] + add2[0], v[1] + add2[1]), pack_bf16(v[2] + add2[2], v[3] + add2[3]),
+                                          pack_bf16(v[4] + add2[4], v[5] + add2[5]), pack_bf16(v[6] + add2[6], v[7] + add2[7])};
+                        __builtin_amdgcn_raw_buffer_store_b128(o2, rsrc_y2, on ? off + (int)(a.y2_row_off * a.ldy * 2) : (int)0x80000000, 0, 0);
+                    }
+                    if constexpr (STATS) {   // back into the scratch for the column sums (lane == column again)
+                        const f32x4t w0 = {v[0], v[1], v[2], v[3]}, w1 = {v[4], v[5], v[6], v[7]};
+                        *reinterpret_cast<f32x4t*>(ws + row * 36 + 8 * ec) = w0;
+                        *reinterpret_cast<f32x4t*>(ws + row * 36 + 8 * ec + 4) = w1;
+                    }
+                }
+                if constexpr (STATS) {
+                    __builtin_amdgcn_wave_barrier();
+                    const float ref = ws[fr];                       // row 0 of the column (always a valid row)
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float d = row < nrows ? ws[row * 36 + fr] - ref : 0.f;
+                        s1 += d; s2 = fmaf(d, d, s2);
+                    }
+                    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                    if (lh == 0) {
+                        float* so = a.stats + (long long)b * a.stats_bs + ((long long)(t0 >> 5) * a.N + 32 * j + fr) * 2;   // [tile][channel][2]
+                        const float cnt = (float)nrows, md = s1 / cnt;
+                        so[0] = ref + md;
+                        so[1] = fmaxf(s2 - cnt * md * md, 0.f);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (k < 3) clk_stamp_p(a.clk, w, l, 3 + 3 * k);
+            lds_barrier();
+            if (k < 3) clk_stamp_p(a.clk, w, l, 4 + 3 * k);
+        }
+        return;
+    }
+
+    // ======================================================================= helper waves
+    const int hw = w - 6, slot = l >> 5, c6 = l & 31;
+    constexpr bool GN_SRC = MODE == 1 || MODE == 3;
+    const elt_t* src = reinterpret_cast<const elt_t*>(MODE != 0 ? a.ra[0] : a.sa[0]);
+    const rsrc_t rsrc_src = make_rsrc(src, 0x7ffffff0u);
+    float ga[6], gb[6], lg[6], lb[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        ga[e] = 1.f; gb[e] = 0.f;
+        lg[e] = MODE >= 2 ? a.ln_gamma[6 * c6 + e] : 1.f;
+        lb[e] = MODE >= 2 ? a.ln_beta[6 * c6 + e] : 0.f;
+    }
+    // GroupNorm (a, b) tables of sample b -> coefS[kind][b & 3]: helper wave hw finalises channels [96 hw, 96 hw + 96) — two 48-channel
+    // slices, all partial tiles of a slice in flight together — for the source (GN_SRC) and for the GroupNorm'ed residual (RES 2).  Tables are
+    // published by the NEXT workgroup barrier: they are computed one period before the first tile of the sample is parked (prologue: before
+    // an extra barrier).  Four slots: a slot is rewritten three samples later, when nothing of its sample is in flight any more.
+    auto sample_tables = [&](int b) __attribute__((always_inline)) {
+        float* const gs = gnscr + hw * GN_SCRATCH;
+        if constexpr (GN_SRC) {
+            const GnP gp = {a.gn_cpg, a.gn_nparts, a.M, a.gn_eps, a.gn_gamma, a.gn_beta, 192};
+            const rsrc_t rp = make_rsrc(a.gn_part[0] + (long long)b * a.gn_part_bs, 192u * (unsigned)a.gn_nparts * 8u);
+#pragma unroll 1
+            for (int q = 0; q < 2; ++q) {   // (one slice at a time: 43 registers of loads; both at once spilled in the K = 576 kernels)
+                GnL20 g0;
+                gn20_issue(gp, rp, 96 * hw + 48 * q, l, g0);
+                gn20_finish(gp, rp, 96 * hw + 48 * q, l, g0, gs, coefS + (b & 3) * 384);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if constexpr (EK == 0 && RES == 2) {
+            const GnP gp = {a.gn_cpg, a.gn_nparts, a.M, a.res_eps, a.res_gamma, a.res_beta, 192};
+            const rsrc_t rp = make_rsrc(a.res_part + (long long)b * a.gn_part_bs, 192u * (unsigned)a.gn_nparts * 8u);
+#pragma unroll 1
+            for (int q = 0; q < 2; ++q) {   // (one slice at a time: 43 registers of loads; both at once spilled in the K = 576 kernels)
+                GnL20 g0;
+                gn20_issue(gp, rp, 96 * hw + 48 * q, l, g0);
+                gn20_finish(gp, rp, 96 * hw + 48 * q, l, g0, gs, coefS + (4 + (b & 3)) * 384);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
+    constexpr bool TABLES = GN_SRC || (EK == 0 && RES == 2);
+    int cur_b_src = -1;
+
+    u32x3 raw[NPASS];
+    auto issue_tile = [&](int ti_) __attribute__((always_inline)) {
+        const int ti = min(ti_, t_last);          // (tiles past the workgroup's range: clamped, their work is done and discarded)
+        const int b = ti / ntv, t0 = (ti - b * ntv) * 32;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int rl = 2 * p + slot;
+            const int tt = t0 + hw * RPW + rl - HALO;
+            const int row = b * a.seg_rows + min(max(tt, 0), a.M - 1);
+            raw[p] = __builtin_bit_cast(u32x3, __builtin_amdgcn_raw_buffer_load_b96(rsrc_src, (row * 192 + 6 * c6) * 2, 0, 0));
+        }
+    };
+    auto park_tile = [&](int ti_, int buf) __attribute__((always_inline)) {
+        const int ti = min(ti_, t_last);
+        const int b = ti / ntv, t0 = (ti - b * ntv) * 32;
+        if constexpr (GN_SRC) {
+            if (b != cur_b_src) {   // (published at least one barrier ago)
+                const float* const tab = coefS + (b & 3) * 384;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) { ga[e] = tab[2 * (6 * c6 + e)]; gb[e] = tab[2 * (6 * c6 + e) + 1]; }
+                cur_b_src = b;
+            }
+        }
+        unsigned* const A32 = reinterpret_cast<unsigned*>(Abuf + buf * RG_A_ELEMS);
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int rl = min(2 * p + slot, RPW - 1);      // (the odd pass of a 17-row share: slot 1 repeats the share's last row)
+            const int r = hw * RPW + rl;
+            const int tt = t0 + r - HALO;
+            const bool valid = tt >= 0 && tt < a.M;
+            const u32x3 rw = (2 * p + 1 < RPW) ? raw[p] : u32x3{(unsigned)__shfl((int)raw[p][0], l & 31), (unsigned)__shfl((int)raw[p][1], l & 31), (unsigned)__shfl((int)raw[p][2], l & 31)};
+            unsigned o0, o1, o2;
+            if constexpr (MODE == 0) {
+                o0 = rw[0]; o1 = rw[1]; o2 = rw[2];
+            } else {
+                float x[6] = {bf_lo(rw[0]), bf_hi(rw[0]), bf_lo(rw[1]), bf_hi(rw[1]), bf_lo(rw[2]), bf_hi(rw[2])};
+                if constexpr (GN_SRC) {
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) x[e] = fmaf(x[e], ga[e], gb[e]);
+                }
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) x[e] = silu_f(x[e]);
+                }
+                if constexpr (MODE >= 2) {   // LayerNorm over the row's 192 channels = the 32 lanes of this half-wave
+                    const float ref = __shfl(x[0], l & 32);
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) { const float d = x[e] - ref; s1 += d; s2 = fmaf(d, d, s2); }
+                    s1 = half32_sum(s1); s2 = half32_sum(s2);
+                    const float md = s1 * (1.0f / 192.0f);
+                    const float var = fmaxf(s2 * (1.0f / 192.0f) - md * md, 0.f);
+                    const float mu = ref + md, rs = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) x[e] = fmaf((x[e] - mu) * rs, lg[e], lb[e]);
+                }
+                o0 = pack_bf16(x[0], x[1]); o1 = pack_bf16(x[2], x[3]); o2 = pack_bf16(x[4], x[5]);
+            }
+            o0 = valid ? o0 : 0u; o1 = valid ? o1 : 0u; o2 = valid ? o2 : 0u;
+            unsigned* d = A32 + r * (AP / 2) + 3 * c6;
+            d[0] = o0; d[1] = o1; d[2] = o2;
+        }
+    };
+
+    // ---- prologue
+    clk_stamp_p(a.clk, w, l, 0);
+    issue_tile(tb);
+    if constexpr (TABLES) {
+        const int b0 = tb / ntv, b1 = min(tb + 1, t_last) / ntv;
+        sample_tables(b0);
+        if (b1 != b0) sample_tables(b1);
+    }
+    lds_barrier();
+    park_tile(tb, 0);
+    issue_tile(tb + 1);
+    lds_barrier();
+    clk_stamp_p(a.clk, w, l, 1);
+    for (int k = 0; k < n; ++k) {
+        park_tile(tb + k + 1, (k + 1) & 1);
+        if (k < 3) clk_stamp_p(a.clk, w, l, 2 + 3 * k);
+        issue_tile(tb + k + 2);
+        if constexpr (TABLES) {   // a new sample two tiles ahead: its tables now, published by this period's barrier (rare: a self-contained block)
+            const int b1 = min(tb + k + 1, t_last) / ntv, b2 = min(tb + k + 2, t_last) / ntv;
+            if (b2 != b1) sample_tables(b2);
+        }
+        if (k < 3) clk_stamp_p(a.clk, w, l, 3 + 3 * k);
+        lds_barrier();
+        if (k < 3) clk_stamp_p(a.clk, w, l, 4 + 3 * k);
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+struct RgPlan { int ntap, ek, mode, res, dup, stats, per, grid; };
+static bool rg_plan(const TGemmArgs& a, RgPlan& p) {
+    if (a.f32 || a.seg_rows <= 0 || a.seg_rows % 32 || a.M < 1 || a.M > a.seg_rows) return false;
+    if (a.ra[1] || a.sk[1] || a.sk[2] || a.geglu || a.y_cm) return false;
+    if (a.ra[0]) {
+        if (a.sk[0] || (a.rtaps != 1 && a.rtaps != 3) || a.K != a.rtaps * 192) return false;
+        if (a.rmode < 1 || a.rmode > 3) return false;
+        if ((a.rmode == 1 || a.rmode == 3) && (!a.gn_part[0] || !a.gn_gamma || !a.gn_beta || a.res_gn)) return false;
+        if (a.rmode >= 2 && (!a.ln_gamma || !a.ln_beta || a.rtaps != 1)) return false;
+        p.ntap = a.rtaps; p.mode = a.rmode;
+    } else {
+        if (!a.sa[0] || a.sk[0] != 192 || a.sld[0] != 192 || a.K != 192) return false;
+        p.ntap = 1; p.mode = 0;
+    }
+    p.res = 0; p.dup = 0; p.stats = 0;
+    if (a.band_k) {
+        if (a.N != 192 || !a.ra[0] || !a.y_tm || !a.band_lo || !a.band_hi || a.band_wmax < 1 || a.band_wmax > 8 || p.ntap != 1) return false;
+        p.ek = 4;
+    } else if (a.qk) {
+        if (a.N != 576 || a.qk_n != 384 || a.head_dim != 32 || a.heads2 != 12 || !a.vt || p.ntap != 1) return false;
+        p.ek = 1;
+    } else if (a.y_tm) {
+        if (a.N != 192 || a.ldy != 192 || (a.res_tm && a.ldr_tm != 192)) return false;
+        if (a.res_gn && (!a.res_tm || !a.res_part || !a.res_gamma || !a.res_beta)) return false;
+        p.ek = 0;
+        p.res = a.res_tm ? (a.res_gn ? 2 : 1) : 0;
+        p.dup = a.y2_tm ? 1 : 0;
+        p.stats = a.stats ? 1 : 0;
+    } else return false;
+    if ((long long)a.batch * a.seg_rows * 192 * 2 > 0x7ffffff0LL) return false;   // 32-bit byte offsets into the activation tensors
+    const int total = a.batch * ((a.M + 31) / 32);
+    p.per = (total + 255) / 256;
+    p.grid = (total + p.per - 1) / p.per;
+    return true;
+}
+// the instantiations the UNet schedule needs (engine.cpp: run_resblock_tm, run_transformer_tm)
+#define RG_VARIANTS(X)                                                                                     \
+    X(3, 0, 1, 0, false, true)   /* conv1: silu(GN(x)) -> conv3 + emb, statistics                       */ \
+    X(3, 0, 1, 1, false, true)   /* conv2 + identity skip                                              */ \
+    X(3, 0, 1, 1, true, true)    /* ... written to both guidance halves                                 */ \
+    X(1, 0, 0, 2, false, false)  /* attn1.to_out + GroupNorm(x_in)                                      */ \
+    X(1, 0, 0, 2, true, false)   /* ... + the unconditional half's x2 = x1 + c2                         */ \
+    X(1, 0, 0, 1, false, false)  /* attn2.to_out + x1                                                   */ \
+    X(1, 1, 3, 0, false, false)  /* q/k/v of LayerNorm(GroupNorm(x))                                    */ \
+    X(1, 4, 2, 0, false, false)  /* q of LayerNorm(x1) + banded cross-attention                         */
+static int rg_variant(const RgPlan& p) {
+    int i = 0;
+#define X(NT_, EK_, MO_, RE_, DU_, ST_) if (p.ntap == NT_ && p.ek == EK_ && p.mode == MO_ && p.res == RE_ && (p.dup != 0) == DU_ && (p.stats != 0) == ST_) return i; ++i;
+    RG_VARIANTS(X)
+#undef X
+    return -1;
+}
+bool rgemm_supports(const TGemmArgs& a_in, int batch) {
+    TGemmArgs a = a_in; a.batch = batch;
+    RgPlan p;
+    return rg_plan(a, p) && rg_variant(p) >= 0;
+}
+void configure_rgemm_kernels() {
+#define X(nt, ek, mo, re, du, st) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rgemm_kernel<nt, ek, mo, re, du, st>), hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_BYTES);
+    RG_VARIANTS(X)
+#undef X
+}
+bool launch_rgemm(const TGemmArgs& a_in, int batch, hipStream_t s) {
+    TGemmArgs a = a_in;
+    a.batch = batch;
+    RgPlan p;
+    if (!rg_plan(a, p)) return false;
+    const int v = rg_variant(p);
+    if (v < 0) return false;
+    a.pg_per = p.per;
+    int i = 0;
+#define X(nt, ek, mo, re, du, st) if (v == i) hipLaunchKernelGGL((rgemm_kernel<nt, ek, mo, re, du, st>), dim3((unsigned)p.grid), dim3(512), RG_LDS_BYTES, s, a); ++i;
+    RG_VARIANTS(X)
+#undef X
+    return true;
+}
+
+}  // namespace said

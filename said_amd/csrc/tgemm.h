@@ -112,6 +112,10 @@ void configure_xgemm_kernels();
 bool pgemm_supports(const TGemmArgs& a, int batch);
 bool launch_pgemm(const TGemmArgs& a, int batch, hipStream_t s);
 void configure_pgemm_kernels();
+// round 4 (rgemm.hip): register-stationary weights, wave-specialised persistent workgroups: the 192-wide GEMMs with K <= 576 and q/k/v (bf16 mode)
+bool rgemm_supports(const TGemmArgs& a, int batch);
+bool launch_rgemm(const TGemmArgs& a, int batch, hipStream_t s);
+void configure_rgemm_kernels();
 // UNet operand preparation (bf16 mode, large batches): channel-major fp32 x[b][C][pitch] -> transform -> token-major bf16.
 // mode 0: silu(GroupNorm(x)) into dst[b][1 + t][ldd] at column `coff` (rows 0 and T + 1 zero: Conv1d padding), mode 1:
 // LayerNorm(GroupNorm(x)) -> dst[b][t][ldd], mode 2: LayerNorm(x) -> dst and raw x -> dst2 (both [b][t][*]), mode 3: raw x.

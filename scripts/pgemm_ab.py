@@ -1,5 +1,6 @@
-"""Round 4: the persistent weight-stationary GEMMs (pgemm.hip) against round 3's xgemm_kernel, bf16 mode, on one box.
-    python scripts/pgemm_ab.py [check] [time] [B=32] [N=50]
+"""Round 4: the persistent GEMMs (OPT=rgemm: rgemm.hip, register-stationary weights + helper waves; OPT=pgemm: pgemm.hip, weight slices resident
+in LDS) against round 3's xgemm_kernel, bf16 mode, on one box.
+    [OPT=rgemm] python scripts/pgemm_ab.py [check] [time] [B=32] [N=50]
 check: UNet forwards (B = 16 x T = 600, ragged B = 40 x T = 333) with pgemm off / on, against each other and against the CPU oracle,
        plus one guided step at B clips; counts of launches through either kernel family.
 time:  alternating timed runs of the in-situ loop (B clips x N steps), pgemm off (round 3's clip-group policy) vs on with 1, 2, 4 groups."""
@@ -19,6 +20,8 @@ nums = [int(a) for a in args if a.isdigit()]
 B = nums[0] if len(nums) > 0 else 32
 N = nums[1] if len(nums) > 1 else 50
 T = 600
+OPT = os.environ.get("OPT", "rgemm")
+OTHER = "pgemm" if OPT == "rgemm" else "rgemm"
 dev = torch.device("cuda:0")
 torch.set_grad_enabled(False)
 
@@ -28,7 +31,8 @@ def make(pg, groups=None):
     m.load_state_dict(synth.said_state_dict(), strict=True)
     m.to(dev).eval()
     m.set_mfma_dtype("bf16")
-    m._get_engine(2 * B, T).debug_option("pgemm", pg)
+    m._get_engine(2 * B, T).debug_option(OPT, pg)
+    m._get_engine(2 * B, T).debug_option(OTHER, 0)
     if groups is not None:
         m.clip_groups = groups
     return m
@@ -45,11 +49,12 @@ if do_check:
             c = synth.synth_latents(902 + Tf, (Bf, Tf, 768))
             ts = (torch.arange(Bf) * 61 + 5) % 1000
             eng = m._get_engine(Bf, Tf)
-            eng.debug_option("pgemm", pg)
+            eng.debug_option(OPT, pg)
+            eng.debug_option(OTHER, 0)
             eng.debug_option("unet_tgemm_min_tokens", 1)
-            n0p, n0x = eng.debug_get("n_pgemm"), eng.debug_get("n_xgemm")
+            n0p, n0x = eng.debug_get("n_" + OPT), eng.debug_get("n_xgemm")
             out = m(x.to(dev), ts.to(dev), c.to(dev)).cpu()
-            print(f"pgemm={pg} B={Bf} T={Tf}: launches pgemm {eng.debug_get('n_pgemm') - n0p} xgemm {eng.debug_get('n_xgemm') - n0x}", flush=True)
+            print(f"{OPT}={pg} B={Bf} T={Tf}: launches {OPT} {eng.debug_get('n_' + OPT) - n0p} xgemm {eng.debug_get('n_xgemm') - n0x}", flush=True)
             outs[(pg, Bf, Tf)] = out
             if pg == -1:
                 d = float((out - outs[(0, Bf, Tf)]).abs().max())
@@ -77,7 +82,7 @@ if do_time:
     ctx = synth.synth_latents(1, (B, T, 768)).to(dev)
     lat = synth.synth_latents(2, (B, T, 32)).to(dev)
     wav = torch.zeros(B, T * 16000 // 60, device=dev)
-    variants = [("xgemm, round-3 groups", 0, None), ("pgemm, 1 group", -1, 1), ("pgemm, 2 groups", -1, 2), ("pgemm, 4 groups", -1, 4)]
+    variants = [("xgemm, round-3 groups", 0, None), (OPT + ", 1 group", -1, 1), (OPT + ", 2 groups", -1, 2), (OPT + ", 4 groups", -1, 4)]
     for rep in range(2):
         for name, pg, groups in variants:
             m = make(pg, groups)

@@ -30,11 +30,22 @@ clk = eng.debug_clocks(False, read=True)        # [64 launches][8][16]
 eng.debug_option("xgemm_clk", 0)
 names = ["w+issue", "prologue"] + [f"{p}{i}" for i in range(4) for p in ("mma", "epi", "park")]
 for k in range(64):
-    st = clk[k, :4, :15]
+    st = clk[k, :8, :15]
     if st[0, 0] == 0:
         continue
-    base = st[:, 0].min()
+    base = st[:, 0][st[:, 0] > 0].min()
     last = max(int(v) for v in st.flatten() if v > 0)
+    if st[6, 0] > 0:   # rgemm: MFMA wave 0 and helper wave 6 — slot 1 = prologue, then per period k = 1..3: [work, B2, work, B1]
+        for wv, nm in ((0, "mfma0"), (5, "mfma5"), (6, "help0"), (7, "help1")):
+            row = st[wv]
+            cols = [i for i in range(1, 12) if row[i] > 0]
+            parts, prev = [], row[0]
+            for i in cols:
+                parts.append(f"s{i}:{int(row[i] - prev):6d}")
+                prev = row[i]
+            print(f"launch {k:2d} {nm} (+{int(row[0] - base):5d}) | " + " ".join(parts))
+        continue
+    st = st[:4]
     cols = [i for i in range(1, 15) if st[0, i] > 0]
     parts = []
     prev = st[:, 0]
