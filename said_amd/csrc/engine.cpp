@@ -693,6 +693,57 @@ TGemmArgs mkx(const UGeo& g, const void* w, int N, int K) {
 }
 void run_resblock_tm(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, const ActBuf& in0, const ActBuf* in1, const ActBuf& out, hipStream_t s, bool shared) {
     const int nb = shared ? g.Bc : g.Be;
+    // Round 4 (bf16 mode): a concatenated-input ResBlock (K = 1152 / 576 + 384) runs as launches of rgemm_kernel over COLUMN RANGES of the
+    // same packed weights — its register-stationary weight fragments hold 576 columns per wave — with a bf16 partial sum in between (one extra
+    // rounding of a quantity the next kernel rounds anyway): conv1 = [source 0 -> P] + [source 1 + bias + emb + P], and the 1x1 skip over
+    // the raw input becomes the residual of conv2.  The partial / skip tensor lives in tX1 (idle until the block's SpatialTransformer).
+    bool split = false;
+    if (in1 && c->rgemm != 0 && c->bf16_mode && rw.has_skip) {
+        TGemmArgs t = mkx(g, rw.t_conv1, MC, 3 * MC);
+        t.ra[0] = in0.t; t.rmode = 1; t.rtaps = 3; t.gn_part[0] = in0.st; t.gn_cpg = rw.cin / 32; t.gn_eps = 1e-5f; t.gn_gamma = rw.g1; t.gn_beta = rw.b1;
+        t.y_tm = c->tX1; t.w_ld = 3 * rw.cin; t.w_seg = rw.cin;
+        split = rgemm_supports(t, nb);
+    }
+    if (split) {
+        {   // in_layers, source 0: GN -> SiLU -> conv3 over the first 192 input channels -> P
+            TGemmArgs t = mkx(g, rw.t_conv1, MC, 3 * MC);
+            t.ra[0] = in0.t; t.rmode = 1; t.rtaps = 3;
+            t.gn_part[0] = in0.st; t.gn_cpg = rw.cin / 32; t.gn_eps = 1e-5f; t.gn_gamma = rw.g1; t.gn_beta = rw.b1;
+            t.w_ld = 3 * rw.cin; t.w_k0 = 0; t.w_seg = rw.cin;
+            t.y_tm = c->tX1;
+            do_xgemm(c, t, nb, s);
+        }
+        {   // in_layers, source 1 (the skip connection's channels) + bias + emb term + P
+            TGemmArgs t = mkx(g, rw.t_conv1, MC, 3 * MC);
+            t.ra[0] = in1->t; t.rmode = 1; t.rtaps = 3;
+            t.gn_part[0] = in1->st; t.gn_cpg = rw.cin / 32; t.gn_eps = 1e-5f; t.gn_gamma = rw.g1 + MC; t.gn_beta = rw.b1 + MC;
+            t.w_ld = 3 * rw.cin; t.w_k0 = MC; t.w_seg = rw.cin;
+            t.bias = rw.conv1.bias;
+            t.emb = c->EO + (long long)rb_index * MC * c->maxNp; t.emb_pitch = c->maxNp; t.step_ptr = g.step_ptr; t.emb_b_stride = g.emb_b_stride;
+            t.res_tm = c->tX1;
+            t.y_tm = c->M.t; t.stats = c->M.st;
+            do_xgemm(c, t, nb, s);
+        }
+        {   // skip_connection: Conv1d 1x1 over the concatenated raw input (openaimodel.py:194) -> tX1
+            TGemmArgs t = mkx(g, rw.t_conv2, MC, 2 * MC);
+            t.sa[0] = in0.t; t.sld[0] = MC; t.sk[0] = MC;
+            t.sa[1] = in1->t; t.sld[1] = MC; t.sk[1] = MC;
+            t.w_ld = 3 * MC + 2 * MC; t.w_k0 = 3 * MC;
+            t.y_tm = c->tX1;
+            do_xgemm(c, t, nb, s);
+        }
+        {   // out_layers: GN -> SiLU -> conv3 + (both biases) + skip(x)
+            TGemmArgs t = mkx(g, rw.t_conv2, MC, 3 * MC);
+            t.ra[0] = c->M.t; t.rmode = 1; t.rtaps = 3;
+            t.gn_part[0] = c->M.st; t.gn_cpg = 6; t.gn_eps = 1e-5f; t.gn_gamma = rw.g2; t.gn_beta = rw.b2;
+            t.w_ld = 3 * MC + 2 * MC; t.w_k0 = 0;
+            t.bias = rw.bias2;
+            t.res_tm = c->tX1;
+            t.y_tm = out.t; t.stats = out.st;
+            do_xgemm(c, t, nb, s);
+        }
+        return;
+    }
     {   // in_layers: GN -> SiLU -> conv3 + emb term   (openaimodel.py:205-225)
         TGemmArgs t = mkx(g, tw(c, rw.t_conv1, rw.tf_conv1), MC, 3 * rw.cin);
         t.ra[0] = in0.t; t.ra[1] = in1 ? in1->t : nullptr; t.rmode = 1; t.rtaps = 3;

@@ -37,7 +37,7 @@
 
 namespace said {
 
-typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int RG_AP = 200;                        // A tile row pitch in elements (192 + 8: 400 bytes)
@@ -136,17 +136,19 @@ __device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(f
 // EK: 0 token-major activation out, 1 q/k/v split (direct stores), 4 banded cross-attention (transposed product)
 // MODE: operand transform (0 raw, 1 silu(GroupNorm), 2 LayerNorm, 3 LayerNorm(GroupNorm)); RES: 0 none, 1 plain, 2 GroupNorm'ed residual;
 // DUP: second copy of the result (+ per-channel constant); STATS: GroupNorm partials of the stored values
-template <int NTAP, int EK, int MODE, int RES, bool DUP, bool STATS>
+// NCH: 192-channel chunks along K (raw sources sa[0 .. NCH - 1], one tile buffer and one barrier per chunk; NTAP == 1)
+template <int NTAP, int EK, int MODE, int RES, bool DUP, bool STATS, int NCH = 1>
 __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     typedef unsigned short elt_t;
-    constexpr int NCT = EK == 1 ? 3 : 1;          // column tiles per MFMA wave
+    constexpr int NCT = EK == 1 ? 3 : (EK == 2 ? 2 : 1);   // column tiles per MFMA wave (q/k/v: head j of each; GEGLU: a (value, gate) pair)
     constexpr int NACC = NCT == 1 ? 2 : 1;        // accumulators per column tile (one tile: two interleaved chains)
-    constexpr int NTS = NTAP * 12;                // k16 steps
+    static_assert(NCH == 1 || (NTAP == 1 && MODE == 0), "chunked K: raw sources, one tap");
+    constexpr int NTS = NTAP * 12;                // k16 steps per chunk
+    constexpr int NSEG = NTAP * NCH;              // 192-wide K segments of the weight rows: taps or chunks
     constexpr int HALO = NTAP == 3 ? 1 : 0;
     constexpr int NR = 32 + 2 * HALO;             // rows of an A tile
-    constexpr int RPW = NR / 2;                   // rows per helper wave
-    constexpr int NPASS = (RPW + 1) / 2;          // two rows per helper wave and pass
+    constexpr int NPASS = (NR + 7) / 8;           // helper passes: four rows per wave and pass (34 rows: the fifth pass repeats row 33)
     constexpr int AP = RG_AP;
     elt_t* const Abuf = lds;
     float* const wscr = reinterpret_cast<float*>(lds + 2 * RG_A_ELEMS);   // [6 MFMA waves][RG_WS_FLOATS]
@@ -155,7 +157,10 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     const int ntv = (a.M + 31) >> 5;              // valid 32-token tiles per sample
     const int total = a.batch * ntv;
-    const int tb = (int)blockIdx.x * a.pg_per;
+    // workgroup -> (column group, row-tile range); the groups of one range sit on one XCD (they read the same source rows)
+    const unsigned Lb = blockIdx.x, xcd = Lb & 7u, slot_ = Lb >> 3;
+    const int cg = (int)(slot_ % (unsigned)a.pg_s);
+    const int tb = ((int)(slot_ / (unsigned)a.pg_s) * 8 + (int)xcd) * a.pg_per;
     const int n = min(total, tb + a.pg_per) - tb;
     if (n <= 0) return;
     const int t_last = tb + n - 1;
@@ -165,19 +170,20 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
         const int j = w, fr = l & 31, lh = l >> 5;
         float* const ws = wscr + j * RG_WS_FLOATS;
         const elt_t* W = reinterpret_cast<const elt_t*>(a.w);
-        bf16x8 wf[NCT][NTS];
+        bf16x8 wf[NCT][NCH * NTS];
+        const int w_ld = a.w_ld > 0 ? a.w_ld : a.K, w_seg = a.w_seg > 0 ? a.w_seg : 192;   // row pitch, distance between the segments
         {   // ---- weights: rounds of four k16 steps = 128 bytes of each of the wave's 32 rows: four 16-byte loads per lane that cover eight
             // full rows each -> the staging area [32][144 bytes] -> this lane's four fragments
             const int srow = l >> 3, spc = l & 7;           // staging: lane -> (row within 8, 16-byte piece)
             u32x4* const st = reinterpret_cast<u32x4*>(ws);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                const elt_t* wbase = W + (long long)(ct * 192 + 32 * j) * a.K;
+                const elt_t* wbase = W + (long long)(EK == 2 ? cg * 384 + 64 * j + 32 * ct : ct * 192 + 32 * j) * w_ld + a.w_k0;
 #pragma unroll
-                for (int r4 = 0; r4 < NTS / 4; ++r4) {
+                for (int r4 = 0; r4 < NSEG * 3; ++r4) {   // (three rounds per 192-wide segment)
                     u32x4 v[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4*>(wbase + (long long)(8 * q + srow) * a.K + 64 * r4 + 8 * spc);
+                    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4*>(wbase + (long long)(8 * q + srow) * w_ld + (r4 / 3) * w_seg + 64 * (r4 % 3) + 8 * spc);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) st[(8 * q + srow) * 9 + spc] = v[q];
                     __builtin_amdgcn_wave_barrier();
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
         }
         float bias_n[NCT];
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) bias_n[ct] = a.bias ? a.bias[ct * 192 + 32 * j + fr] : 0.f;
+        for (int ct = 0; ct < NCT; ++ct) bias_n[ct] = a.bias ? a.bias[(EK == 2 ? cg * 384 + 64 * j + 32 * ct : ct * 192 + 32 * j) + fr] : 0.f;
         // epilogue mapping (EK 0): lane -> (row 16 q + (l >> 2), columns 8 (l & 3) .. + 7 of the wave's 32)
         const int er = l >> 2, ec = l & 3;
         float rca[8], rcb[8], add2[8];
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
         for (int e = 0; e < 8; ++e) { rca[e] = 1.f; rcb[e] = 0.f; add2[e] = (EK == 0 && DUP && a.y2_add) ? a.y2_add[32 * j + 8 * ec + e] : 0.f; }
         int cur_b = -1;
         const rsrc_t rsrc_res = make_rsrc((EK == 0 && RES != 0) ? a.res_tm : a.w, 0x7ffffff0u);
-        const rsrc_t rsrc_y = make_rsrc(EK == 0 ? a.y_tm : (void*)a.w, 0x7ffffff0u);
+        const rsrc_t rsrc_y = make_rsrc(EK == 0 ? a.y_tm : (EK == 2 ? a.yb : (void*)a.w), 0x7ffffff0u);
         const rsrc_t rsrc_y2 = make_rsrc((EK == 0 && DUP) ? a.y2_tm : (void*)a.w, 0x7ffffff0u);
         clk_stamp_p(a.clk, w, l, 0);
         lds_barrier();                            // (the helpers' coefficient tables of the first samples are published)
@@ -235,28 +241,32 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
                 for (int x = 0; x < NACC; ++x)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[ct][x][r] = 0.f;
-            const elt_t* pa = Abuf + (k & 1) * RG_A_ELEMS + fr * AP + 8 * lh;
             constexpr int GS = NCT == 3 ? 3 : 6;   // fragments per group (q/k/v: three MFMAs per fragment, and 144 + 48 registers already taken)
             constexpr int NG = NTS / GS;
-            bf16x8 fa[2][GS];
 #pragma unroll
-            for (int s = 0; s < GS; ++s) fa[0][s] = *reinterpret_cast<const bf16x8*>(pa + 16 * s);
+            for (int ch = 0; ch < NCH; ++ch) {
+                const elt_t* pa = Abuf + ((k * NCH + ch) & 1) * RG_A_ELEMS + fr * AP + 8 * lh;
+                bf16x8 fa[2][GS];
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g + 1 < NG) {
-                    const int ts0 = (g + 1) * GS, tap = ts0 / 12, s0 = ts0 - 12 * tap;
+                for (int s = 0; s < GS; ++s) fa[0][s] = *reinterpret_cast<const bf16x8*>(pa + 16 * s);
 #pragma unroll
-                    for (int s = 0; s < GS; ++s) fa[(g + 1) & 1][s] = *reinterpret_cast<const bf16x8*>(pa + tap * AP + 16 * (s0 + s));
-                }
+                for (int g = 0; g < NG; ++g) {
+                    if (g + 1 < NG) {
+                        const int ts0 = (g + 1) * GS, tap = ts0 / 12, s0 = ts0 - 12 * tap;
 #pragma unroll
-                for (int s = 0; s < GS; ++s)
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) {
-                        const bool tr = EK == 4 || (EK == 1 && ct == 2);
-                        f32x16& ac = acc[ct][NACC == 2 ? (s & 1) : 0];
-                        if (tr) ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ct][GS * g + s], fa[g & 1][s], ac, 0, 0, 0);
-                        else ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][s], wf[ct][GS * g + s], ac, 0, 0, 0);
+                        for (int s = 0; s < GS; ++s) fa[(g + 1) & 1][s] = *reinterpret_cast<const bf16x8*>(pa + tap * AP + 16 * (s0 + s));
                     }
+#pragma unroll
+                    for (int s = 0; s < GS; ++s)
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) {
+                            const bool tr = EK == 4 || (EK == 1 && ct == 2);
+                            f32x16& ac = acc[ct][NACC == 2 ? (s & 1) : 0];
+                            if (tr) ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ct][ch * NTS + GS * g + s], fa[g & 1][s], ac, 0, 0, 0);
+                            else ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][s], wf[ct][ch * NTS + GS * g + s], ac, 0, 0, 0);
+                        }
+                }
+                if (ch + 1 < NCH) lds_barrier();   // the next chunk is parked
             }
             if constexpr (NACC == 2) {
 #pragma unroll
@@ -296,6 +306,21 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
+            } else if constexpr (EK == 2) {
+                // GEGLU (ldm/attention.py:25-32): value * gelu(gate) of this wave's 32 channels, lane == channel; rows through the scratch
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + fr] = (acc[0][0][r] + bias_n[0]) * gelu_f(acc[1][0][r] + bias_n[1]);
+                __builtin_amdgcn_wave_barrier();
+                const int c0 = a.geglu_c0(cg * 384 + 64 * j);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int row = 16 * q + er;
+                    const f32x4t v0 = *reinterpret_cast<const f32x4t*>(ws + row * 36 + 8 * ec);
+                    const f32x4t v1 = *reinterpret_cast<const f32x4t*>(ws + row * 36 + 8 * ec + 4);
+                    const u32x4 ov = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, row < nrows ? ((R0 + row) * a.ldy + c0 + 8 * ec) * 2 : (int)0x80000000, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();
             } else if constexpr (EK == 4) {
                 const int t = t0 + fr;
                 const bool tv = t < a.M;
@@ -365,16 +390,18 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
     }
 
     // ======================================================================= helper waves
-    const int hw = w - 6, slot = l >> 5, c6 = l & 31;
+    // lane = (row slot l >> 4, channels 12 (l & 15) .. + 11 = 24 bytes): a row is the 16 lanes of one DPP row, so the LayerNorm sums are four
+    // DPP adds; pass p covers rows 8 p + 4 hw + slot of the tile (clamped to its last row: the fifth pass of a 34-row tile rewrites row 33)
+    const int hw = w - 6, slot = l >> 4, c12 = l & 15;
     constexpr bool GN_SRC = MODE == 1 || MODE == 3;
-    const elt_t* src = reinterpret_cast<const elt_t*>(MODE != 0 ? a.ra[0] : a.sa[0]);
-    const rsrc_t rsrc_src = make_rsrc(src, 0x7ffffff0u);
-    float ga[6], gb[6], lg[6], lb[6];
+    const rsrc_t rsrc_src = make_rsrc(MODE != 0 ? a.ra[0] : a.sa[0], 0x7ffffff0u);
+    const rsrc_t rsrc_src1 = make_rsrc((NCH > 1 && a.sa[1]) ? a.sa[1] : a.w, 0x7ffffff0u);   // chunk 1's tensor (chunked K: raw 192-wide sources)
+    float ga[12], gb[12], lg[12], lb[12];
 #pragma unroll
-    for (int e = 0; e < 6; ++e) {
+    for (int e = 0; e < 12; ++e) {
         ga[e] = 1.f; gb[e] = 0.f;
-        lg[e] = MODE >= 2 ? a.ln_gamma[6 * c6 + e] : 1.f;
-        lb[e] = MODE >= 2 ? a.ln_beta[6 * c6 + e] : 0.f;
+        lg[e] = MODE >= 2 ? a.ln_gamma[12 * c12 + e] : 1.f;
+        lb[e] = MODE >= 2 ? a.ln_beta[12 * c12 + e] : 0.f;
     }
     // GroupNorm (a, b) tables of sample b -> coefS[kind][b & 3]: helper wave hw finalises channels [96 hw, 96 hw + 96) — two 48-channel
     // slices, all partial tiles of a slice in flight together — for the source (GN_SRC) and for the GroupNorm'ed residual (RES 2).  Tables are
@@ -408,114 +435,127 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
     constexpr bool TABLES = GN_SRC || (EK == 0 && RES == 2);
     int cur_b_src = -1;
 
-    u32x3 raw[NPASS];
-    auto issue_tile = [&](int ti_) __attribute__((always_inline)) {
-        const int ti = min(ti_, t_last);          // (tiles past the workgroup's range: clamped, their work is done and discarded)
+    u32x4 rawa[NPASS];
+    u32x2 rawb[NPASS];
+    // unit u = tile * NCH + chunk
+    auto issue_tile = [&](int u_) __attribute__((always_inline)) {
+        const int u = min(u_, t_last * NCH + NCH - 1);   // (units past the workgroup's range: clamped, their work is done and discarded)
+        const int ti = u / NCH;
+        const rsrc_t rs = (NCH > 1 && (u % NCH) == 1) ? rsrc_src1 : rsrc_src;
         const int b = ti / ntv, t0 = (ti - b * ntv) * 32;
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            const int rl = 2 * p + slot;
-            const int tt = t0 + hw * RPW + rl - HALO;
-            const int row = b * a.seg_rows + min(max(tt, 0), a.M - 1);
-            raw[p] = __builtin_bit_cast(u32x3, __builtin_amdgcn_raw_buffer_load_b96(rsrc_src, (row * 192 + 6 * c6) * 2, 0, 0));
+            const int r = min(8 * p + 4 * hw + slot, NR - 1);
+            const int tt = t0 + r - HALO;
+            const int off = ((b * a.seg_rows + min(max(tt, 0), a.M - 1)) * 192 + 12 * c12) * 2;
+            rawa[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            rawb[p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, off + 16, 0, 0));
         }
     };
-    auto park_tile = [&](int ti_, int buf) __attribute__((always_inline)) {
-        const int ti = min(ti_, t_last);
+    auto park_tile = [&](int u_, int buf) __attribute__((always_inline)) {
+        const int ti = min(u_, t_last * NCH + NCH - 1) / NCH;
         const int b = ti / ntv, t0 = (ti - b * ntv) * 32;
         if constexpr (GN_SRC) {
             if (b != cur_b_src) {   // (published at least one barrier ago)
                 const float* const tab = coefS + (b & 3) * 384;
 #pragma unroll
-                for (int e = 0; e < 6; ++e) { ga[e] = tab[2 * (6 * c6 + e)]; gb[e] = tab[2 * (6 * c6 + e) + 1]; }
+                for (int e = 0; e < 12; ++e) { ga[e] = tab[2 * (12 * c12 + e)]; gb[e] = tab[2 * (12 * c12 + e) + 1]; }
                 cur_b_src = b;
             }
         }
-        unsigned* const A32 = reinterpret_cast<unsigned*>(Abuf + buf * RG_A_ELEMS);
+        u32x2* const A64 = reinterpret_cast<u32x2*>(Abuf + buf * RG_A_ELEMS);
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            const int rl = min(2 * p + slot, RPW - 1);      // (the odd pass of a 17-row share: slot 1 repeats the share's last row)
-            const int r = hw * RPW + rl;
+            const int r = min(8 * p + 4 * hw + slot, NR - 1);
             const int tt = t0 + r - HALO;
             const bool valid = tt >= 0 && tt < a.M;
-            const u32x3 rw = (2 * p + 1 < RPW) ? raw[p] : u32x3{(unsigned)__shfl((int)raw[p][0], l & 31), (unsigned)__shfl((int)raw[p][1], l & 31), (unsigned)__shfl((int)raw[p][2], l & 31)};
-            unsigned o0, o1, o2;
-            if constexpr (MODE == 0) {
-                o0 = rw[0]; o1 = rw[1]; o2 = rw[2];
-            } else {
-                float x[6] = {bf_lo(rw[0]), bf_hi(rw[0]), bf_lo(rw[1]), bf_hi(rw[1]), bf_lo(rw[2]), bf_hi(rw[2])};
+            unsigned o[6] = {rawa[p][0], rawa[p][1], rawa[p][2], rawa[p][3], rawb[p][0], rawb[p][1]};
+            if constexpr (MODE != 0) {
+                float x[12];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) { x[2 * e] = bf_lo(o[e]); x[2 * e + 1] = bf_hi(o[e]); }
                 if constexpr (GN_SRC) {
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) x[e] = fmaf(x[e], ga[e], gb[e]);
+                    for (int e = 0; e < 12; ++e) x[e] = fmaf(x[e], ga[e], gb[e]);
                 }
                 if constexpr (MODE == 1) {
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) x[e] = silu_f(x[e]);
+                    for (int e = 0; e < 12; ++e) x[e] = silu_f(x[e]);
                 }
-                if constexpr (MODE >= 2) {   // LayerNorm over the row's 192 channels = the 32 lanes of this half-wave
-                    const float ref = __shfl(x[0], l & 32);
-                    float s1 = 0.f, s2 = 0.f;
+                if constexpr (MODE >= 2) {   // LayerNorm over the row's 192 channels = the 16 lanes of this DPP row (two-pass: mean, then squares)
+                    float s1 = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) { const float d = x[e] - ref; s1 += d; s2 = fmaf(d, d, s2); }
-                    s1 = half32_sum(s1); s2 = half32_sum(s2);
-                    const float md = s1 * (1.0f / 192.0f);
-                    const float var = fmaxf(s2 * (1.0f / 192.0f) - md * md, 0.f);
-                    const float mu = ref + md, rs = 1.0f / sqrtf(var + 1e-5f);
+                    for (int e = 0; e < 12; ++e) s1 += x[e];
+                    const float mu = row16_sum(s1) * (1.0f / 192.0f);
+                    float s2 = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) x[e] = fmaf((x[e] - mu) * rs, lg[e], lb[e]);
+                    for (int e = 0; e < 12; ++e) { const float d = x[e] - mu; s2 = fmaf(d, d, s2); }
+                    const float rs = 1.0f / sqrtf(row16_sum(s2) * (1.0f / 192.0f) + 1e-5f);
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) x[e] = fmaf((x[e] - mu) * rs, lg[e], lb[e]);
                 }
-                o0 = pack_bf16(x[0], x[1]); o1 = pack_bf16(x[2], x[3]); o2 = pack_bf16(x[4], x[5]);
+#pragma unroll
+                for (int e = 0; e < 6; ++e) o[e] = pack_bf16(x[2 * e], x[2 * e + 1]);
             }
-            o0 = valid ? o0 : 0u; o1 = valid ? o1 : 0u; o2 = valid ? o2 : 0u;
-            unsigned* d = A32 + r * (AP / 2) + 3 * c6;
-            d[0] = o0; d[1] = o1; d[2] = o2;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) o[e] = valid ? o[e] : 0u;
+            u32x2* d = A64 + r * (AP / 4) + 3 * c12;
+            d[0] = u32x2{o[0], o[1]}; d[1] = u32x2{o[2], o[3]}; d[2] = u32x2{o[4], o[5]};
         }
     };
 
     // ---- prologue
     clk_stamp_p(a.clk, w, l, 0);
-    issue_tile(tb);
+    const int u0 = tb * NCH;
+    issue_tile(u0);
     if constexpr (TABLES) {
         const int b0 = tb / ntv, b1 = min(tb + 1, t_last) / ntv;
         sample_tables(b0);
         if (b1 != b0) sample_tables(b1);
     }
     lds_barrier();
-    park_tile(tb, 0);
-    issue_tile(tb + 1);
+    park_tile(u0, 0);
+    issue_tile(u0 + 1);
     lds_barrier();
     clk_stamp_p(a.clk, w, l, 1);
-    for (int k = 0; k < n; ++k) {
-        park_tile(tb + k + 1, (k + 1) & 1);
-        if (k < 3) clk_stamp_p(a.clk, w, l, 2 + 3 * k);
-        issue_tile(tb + k + 2);
+    for (int q = 0; q < n * NCH; ++q) {
+        park_tile(u0 + q + 1, (q + 1) & 1);
+        if (q < 3) clk_stamp_p(a.clk, w, l, 2 + 3 * q);
+        issue_tile(u0 + q + 2);
         if constexpr (TABLES) {   // a new sample two tiles ahead: its tables now, published by this period's barrier (rare: a self-contained block)
-            const int b1 = min(tb + k + 1, t_last) / ntv, b2 = min(tb + k + 2, t_last) / ntv;
+            const int b1 = min(tb + q + 1, t_last) / ntv, b2 = min(tb + q + 2, t_last) / ntv;
             if (b2 != b1) sample_tables(b2);
         }
-        if (k < 3) clk_stamp_p(a.clk, w, l, 3 + 3 * k);
+        if (q < 3) clk_stamp_p(a.clk, w, l, 3 + 3 * q);
         lds_barrier();
-        if (k < 3) clk_stamp_p(a.clk, w, l, 4 + 3 * k);
+        if (q < 3) clk_stamp_p(a.clk, w, l, 4 + 3 * q);
     }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-struct RgPlan { int ntap, ek, mode, res, dup, stats, per, grid; };
+struct RgPlan { int ntap, ek, mode, res, dup, stats, nch, per, grid, groups; };
 static bool rg_plan(const TGemmArgs& a, RgPlan& p) {
     if (a.f32 || a.seg_rows <= 0 || a.seg_rows % 32 || a.M < 1 || a.M > a.seg_rows) return false;
-    if (a.ra[1] || a.sk[1] || a.sk[2] || a.geglu || a.y_cm) return false;
+    if (a.ra[1] || a.sk[2] || a.y_cm) return false;
+    p.nch = 1;
     if (a.ra[0]) {
-        if (a.sk[0] || (a.rtaps != 1 && a.rtaps != 3) || a.K != a.rtaps * 192) return false;
+        if (a.sk[0] || a.sk[1] || (a.rtaps != 1 && a.rtaps != 3) || a.K != a.rtaps * 192) return false;
         if (a.rmode < 1 || a.rmode > 3) return false;
         if ((a.rmode == 1 || a.rmode == 3) && (!a.gn_part[0] || !a.gn_gamma || !a.gn_beta || a.res_gn)) return false;
         if (a.rmode >= 2 && (!a.ln_gamma || !a.ln_beta || a.rtaps != 1)) return false;
         p.ntap = a.rtaps; p.mode = a.rmode;
     } else {
-        if (!a.sa[0] || a.sk[0] != 192 || a.sld[0] != 192 || a.K != 192) return false;
+        if (!a.sa[0] || a.sk[0] != 192 || a.sld[0] != 192) return false;
+        if (a.sk[1]) { if (a.sk[1] != 192 || a.sld[1] != 192 || !a.sa[1] || a.K != 384) return false; p.nch = 2; }
+        else if (a.K != 192) return false;
         p.ntap = 1; p.mode = 0;
     }
-    p.res = 0; p.dup = 0; p.stats = 0;
-    if (a.band_k) {
+    p.res = 0; p.dup = 0; p.stats = 0; p.groups = 1;
+    if (a.geglu) {
+        if (a.N % 384 || a.N / 384 > 32 || !a.yb || a.ldy % 8 || !a.ra[0] || p.ntap != 1 || a.band_k || a.qk) return false;
+        if ((long long)a.batch * a.seg_rows * a.ldy * 2 > 0x7ffffff0LL) return false;
+        p.ek = 2; p.groups = a.N / 384;
+    } else if (a.band_k) {
         if (a.N != 192 || !a.ra[0] || !a.y_tm || !a.band_lo || !a.band_hi || a.band_wmax < 1 || a.band_wmax > 8 || p.ntap != 1) return false;
         p.ek = 4;
     } else if (a.qk) {
@@ -531,23 +571,28 @@ static bool rg_plan(const TGemmArgs& a, RgPlan& p) {
     } else return false;
     if ((long long)a.batch * a.seg_rows * 192 * 2 > 0x7ffffff0LL) return false;   // 32-bit byte offsets into the activation tensors
     const int total = a.batch * ((a.M + 31) / 32);
-    p.per = (total + 255) / 256;
-    p.grid = (total + p.per - 1) / p.per;
+    const int wpg = std::max(8, 256 / p.groups / 8 * 8);          // workgroups per column group: one workgroup per CU in all
+    p.per = (total + wpg - 1) / wpg;
+    const int ranges = (total + p.per - 1) / p.per;
+    p.grid = 8 * p.groups * ((ranges + 7) / 8);
     return true;
 }
 // the instantiations the UNet schedule needs (engine.cpp: run_resblock_tm, run_transformer_tm)
 #define RG_VARIANTS(X)                                                                                     \
-    X(3, 0, 1, 0, false, true)   /* conv1: silu(GN(x)) -> conv3 + emb, statistics                       */ \
-    X(3, 0, 1, 1, false, true)   /* conv2 + identity skip                                              */ \
-    X(3, 0, 1, 1, true, true)    /* ... written to both guidance halves                                 */ \
-    X(1, 0, 0, 2, false, false)  /* attn1.to_out + GroupNorm(x_in)                                      */ \
-    X(1, 0, 0, 2, true, false)   /* ... + the unconditional half's x2 = x1 + c2                         */ \
-    X(1, 0, 0, 1, false, false)  /* attn2.to_out + x1                                                   */ \
-    X(1, 1, 3, 0, false, false)  /* q/k/v of LayerNorm(GroupNorm(x))                                    */ \
-    X(1, 4, 2, 0, false, false)  /* q of LayerNorm(x1) + banded cross-attention                         */
+    X(3, 0, 1, 0, false, true, 1)   /* conv1: silu(GN(x)) -> conv3 + emb, statistics                       */ \
+    X(3, 0, 1, 1, false, true, 1)   /* conv2 + identity skip                                              */ \
+    X(3, 0, 1, 1, true, true, 1)    /* ... written to both guidance halves                                 */ \
+    X(1, 0, 0, 2, false, false, 1)  /* attn1.to_out + GroupNorm(x_in)                                      */ \
+    X(1, 0, 0, 2, true, false, 1)   /* ... + the unconditional half's x2 = x1 + c2                         */ \
+    X(1, 0, 0, 1, false, false, 1)  /* attn2.to_out + x1                                                   */ \
+    X(1, 1, 3, 0, false, false, 1)  /* q/k/v of LayerNorm(GroupNorm(x))                                    */ \
+    X(1, 4, 2, 0, false, false, 1)  /* q of LayerNorm(x1) + banded cross-attention                         */ \
+    X(1, 2, 2, 0, false, false, 1)  /* GEGLU of LayerNorm(x2): four column groups of six (value, gate) pairs */ \
+    X(3, 0, 1, 0, false, false, 1)  /* one source of a concatenated-input convolution -> partial sum        */ \
+    X(1, 0, 0, 0, false, false, 2)  /* 1x1 skip convolution over the concatenated raw input (two chunks)    */
 static int rg_variant(const RgPlan& p) {
     int i = 0;
-#define X(NT_, EK_, MO_, RE_, DU_, ST_) if (p.ntap == NT_ && p.ek == EK_ && p.mode == MO_ && p.res == RE_ && (p.dup != 0) == DU_ && (p.stats != 0) == ST_) return i; ++i;
+#define X(NT_, EK_, MO_, RE_, DU_, ST_, NC_) if (p.ntap == NT_ && p.ek == EK_ && p.mode == MO_ && p.res == RE_ && (p.dup != 0) == DU_ && (p.stats != 0) == ST_ && p.nch == NC_) return i; ++i;
     RG_VARIANTS(X)
 #undef X
     return -1;
@@ -558,7 +603,7 @@ bool rgemm_supports(const TGemmArgs& a_in, int batch) {
     return rg_plan(a, p) && rg_variant(p) >= 0;
 }
 void configure_rgemm_kernels() {
-#define X(nt, ek, mo, re, du, st) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rgemm_kernel<nt, ek, mo, re, du, st>), hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_BYTES);
+#define X(nt, ek, mo, re, du, st, nc) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rgemm_kernel<nt, ek, mo, re, du, st, nc>), hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_BYTES);
     RG_VARIANTS(X)
 #undef X
 }
@@ -569,9 +614,9 @@ bool launch_rgemm(const TGemmArgs& a_in, int batch, hipStream_t s) {
     if (!rg_plan(a, p)) return false;
     const int v = rg_variant(p);
     if (v < 0) return false;
-    a.pg_per = p.per;
+    a.pg_per = p.per; a.pg_s = p.groups;
     int i = 0;
-#define X(nt, ek, mo, re, du, st) if (v == i) hipLaunchKernelGGL((rgemm_kernel<nt, ek, mo, re, du, st>), dim3((unsigned)p.grid), dim3(512), RG_LDS_BYTES, s, a); ++i;
+#define X(nt, ek, mo, re, du, st, nc) if (v == i) hipLaunchKernelGGL((rgemm_kernel<nt, ek, mo, re, du, st, nc>), dim3((unsigned)p.grid), dim3(512), RG_LDS_BYTES, s, a); ++i;
     RG_VARIANTS(X)
 #undef X
     return true;

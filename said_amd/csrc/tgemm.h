@@ -72,7 +72,9 @@ struct TGemmArgs {
     // channels of ra[0], then of ra[1] (concatenated input) — is loaded ONCE, transformed once per element and parked in LDS;
     // only the weights stream.  k order of W for this segment: [tap][source][channel] (Conv1d weight, tap-major).
     int ntw;               // column tiles per workgroup (0: chosen by launch_xgemm)
-    int pg_s, pg_per;      // pgemm_kernel (filled in by launch_pgemm): column slices of the launch, row tiles per row group
+    int pg_s, pg_per;      // pgemm_kernel / rgemm_kernel (filled in by the launch helper): column slices (groups) of the launch, row tiles per range
+    int w_ld, w_k0, w_seg; // rgemm_kernel: the launch multiplies a COLUMN RANGE of the weight rows — row pitch (0: K), first column, distance between
+                           // the 192-wide segments (taps; 0: 192) — so a long-K GEMM can run as several launches over one packed weight
     long long* clk;        // optional [4 waves][16] shader-clock stamps of workgroup 8 (-DSAID_CLK_STAMPS builds; scripts/xgemm_clocks.py)
     const void* ra[2];     // sources (row pitch 192), or null
     int rmode;             // 0: raw, 1: silu(GroupNorm(x)), 2: LayerNorm(x), 3: LayerNorm(GroupNorm(x))
