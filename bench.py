@@ -51,8 +51,9 @@ def parse():
                    help="editing mode (BASELINE configs[4]: --seconds 30 --num_steps 100 --edit): init_samples + in-betweening mask "
                         "(middle third regenerated, 4 channels pinned), mask blend with the re-noised init every step")
     p.add_argument("--clip_groups", type=int, default=0,
-                   help="0 (default): SAID.inference decides (two concurrent half-batches on two streams for large batches); "
-                        "n >= 1: run every batch as n concurrent clip groups (1: never split)")
+                   help="0 (default): SAID.inference decides (SAID._pick_clip_groups: one group wherever the persistent GEMMs of round 4 fill "
+                        "the chip on their own, two to four concurrent groups on their own streams otherwise); n >= 1: run every batch as n "
+                        "concurrent clip groups (1: never split)")
     p.add_argument("--debug_option", action="append", default=[], metavar="NAME=VALUE",
                    help="development: said_debug_option(NAME, VALUE) on the engine before the first run (scripts/ A/B drivers)")
     p.add_argument("--tm_acts", type=int, nargs="?", const=1, default=-1, choices=[-1, 0, 1],
@@ -185,10 +186,13 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1", grou
     agg = {}
     for st in stages:
         name = (f"attn_kernel<D{32 * st['NB']},KS{st['KS']}>" if st["kind"] == 1 else
+                "battn_kernel" if st["kind"] == 9 else
                 "xattn_kernel" if st["kind"] == 3 else
                 f"{'fgemm' if st['KS'] == 32 else 'tgemm'}_kernel<{st['NB']},{EPI_NAMES[st['epi']]}>" if st["kind"] == 4 else
                 "prep_kernel" if st["kind"] == 5 else
                 f"xgemm_kernel<{st['NB']},{'f32' if st['KS'] == 32 else 'bf16'},{EPI_NAMES[st['epi']]}>" if st["kind"] == 6 else
+                f"rgemm_kernel<{EPI_NAMES[st['epi']]}>" if st["kind"] == 7 else
+                f"pgemm_kernel<{EPI_NAMES[st['epi']]}>" if st["kind"] == 8 else
                 f"{'ugemm' if st['kind'] == 2 else 'cgemm'}_kernel<NB{st['NB']},KS{st['KS']},{EPI_NAMES[st['epi']]}>")
         a = agg.setdefault(name, dict(us=0.0, bytes=0.0, flops=0.0, launches=0))
         a["us"] += st["us"]; a["bytes"] += st["bytes"]; a["flops"] += st["flops"]; a["launches"] += 1
@@ -196,7 +200,13 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1", grou
     d = agg[dom]
     achieved = d["bytes"] / (d["us"] * 1e-6) / 1e9
     from said_amd import _engine
-    unet_bytes = _engine.unet_algorithmic_bytes(Be, T, 4)   # activations are stored in fp32 in both modes
+    # SURVEY 8(d)'s byte model at the element size the schedule actually stores between its kernels: bf16 where the token-major-activation
+    # kernels (xgemm / rgemm / pgemm: stage kinds 6-8) run — the bf16 large-batch default —, fp32 everywhere else (round 3 printed the fp32
+    # model for both and so overstated the bf16 fraction twofold)
+    tm_acts = any(st["kind"] in (6, 7, 8) for st in stages)
+    elem = 2 if (dtype == "bf16" and tm_acts) else 4
+    unet_bytes = _engine.unet_algorithmic_bytes(Be, T, elem)
+    unet_bytes_f32 = _engine.unet_algorithmic_bytes(Be, T, 4)
     unet_flops = _engine.unet_algorithmic_flops(Be, T)
     sum_us = sum(a["us"] for a in agg.values())
     # work the schedule actually EXECUTES (sum over its launches).  Under guidance the prefix shared by the two halves runs
@@ -227,7 +237,9 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1", grou
            "kernel_mfma_frac": round(d["flops"] / (d["us"] * 1e-6) / 1e12 / peak_tf, 5),
            "unet_step": {"ms_loop_per_step": round(step_ms, 4), "sum_kernel_us": round(sum_us, 2), "launches": len(stages) * groups,
                          "alg_bytes": round(unet_bytes), "alg_gflop": round(unet_flops / 1e9, 3),
+                         "alg_bytes_elem_size": elem,
                          "hbm_frac": round(unet_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "hbm_frac_f32_model": round(unet_bytes_f32 / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "mfma_frac": round(unet_flops / (step_ms * 1e-3) / 1e12 / peak_tf, 5),
                          "fracs_are": "effective: reference-equivalent (algorithmic) work of the full UNet batch / loop time",
                          "executed_gflop": round(exec_flops / 1e9, 3), "executed_bytes_per_launch_sum": round(exec_bytes),
@@ -463,6 +475,11 @@ def run(args):
             line["roofline"]["audio_encode"] = audio_encode_block(model, proc, T, B, args.dtype)
             if headline and world == 1 and not args.no_secondary:
                 line["secondary"] = run_secondary(model, dev, args.guidance_scale)
+                # the same figures as flat numeric top-level keys (a parser that keeps only scalars of the line still sees them)
+                for name, sec in line["secondary"].items():
+                    line[name + "_value"] = sec["value"]
+                    line[name + "_ms_per_denoise_step"] = sec["ms_per_denoise_step"]
+                    line[name + "_clip_groups"] = sec["clip_groups"]
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only: other ranks would sit in the final barrier
             line["cpu_baseline"] = cpu_baseline(args, T, Ta)
         print(json.dumps(line), flush=True)

@@ -161,6 +161,12 @@ int said_denoise_loop(said_ctx* ctx, const said_loop_params* p, void* stream);
  * starts their loops from two threads.  Same parameters (same intermediates_dev) as the loop call that follows. */
 int said_loop_prepare(said_ctx* ctx, const said_loop_params* p, void* stream);
 
+/* Progress of the loop running (or last run) on this context: *steps_done <- number of denoise steps completed so far, read from the
+ * device-side step counter through a private stream — never blocks, nor waits for, the stream the loop runs on.  Host wrapper:
+ * `show_process=True` polls it from a thread to drive the progress line the reference prints with tqdm around its Python loop
+ * (/root/reference/said/model/diffusion.py:412-415). */
+int said_loop_progress(said_ctx* ctx, int* steps_done);
+
 /* The standard normals the loop generates with use_step_noise == 2: out_dev (nsteps, B*T*C) <- noise of steps
  * step0 .. step0 + nsteps - 1 for `seed` (element index = ((b*T + t)*C + c)).  Replaces the `randn` drawn inside
  * DDIMScheduler.step for eta > 0 (diffusion.py:441-443); lets a test feed the identical noise to the CPU oracle. */

@@ -18,7 +18,7 @@ _lib = None
 
 PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 NCOEF = 8
-ABI_VERSION = 5   # include/said_hip.h as bound below; a stale libsaid_hip.so is refused at load time
+ABI_VERSION = 6   # include/said_hip.h as bound below; a stale libsaid_hip.so is refused at load time
 
 
 class EngineError(RuntimeError):
@@ -58,6 +58,7 @@ EXPORTS = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "said_axpby": (c_int, [c_void_p, POINTER(c_float), c_void_p, POINTER(c_float), c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "said_graph_num_nodes": (c_int, [c_void_p]),
+    "said_loop_progress": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "said_set_precision": (c_int, [c_void_p, c_int]),
     "said_get_precision": (c_int, [c_void_p]),
     "said_profile_unet": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -372,6 +373,12 @@ class Engine:
         out = np.empty(shape, dtype=np.float32)
         self._chk(self.lib.said_debug_read(self.h, name.encode(), out.ctypes.data_as(c_void_p), out.size), "said_debug_read")
         return out
+
+    def loop_progress(self) -> int:
+        """Denoise steps started so far by the loop running (or last run) on this context; never blocks the loop's stream."""
+        v = c_int(0)
+        self._chk(self.lib.said_loop_progress(self.h, ctypes.byref(v)), "said_loop_progress")
+        return v.value
 
     def graph_num_nodes(self) -> int:
         return int(self.lib.said_graph_num_nodes(self.h))

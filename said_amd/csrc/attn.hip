@@ -348,6 +348,127 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// battn_kernel (round 4) — self-attention of the bf16 large-batch schedule on bf16 OPERANDS, a head's K and V resident in LDS.
+//
+// attn_kernel<1, 1, true, 4> took fp32 q / k / v, staged one 32-key tile at a time through LDS behind a workgroup barrier per tile and
+// converted every fragment to bf16 in each of its four waves: 57 us per launch at 64 x 600 tokens against ~15 us of exp / max / sum
+// work (the MFMAs are a quarter of that).  Here the q/k/v projection (rgemm.hip, TGemmArgs::qkv_bf16) writes bf16 in this kernel's
+// operand layout, and a workgroup (four waves = four 32-query tiles of one (sample, head)) copies the head's WHOLE K [T][32] and
+// V^T [32][T] — 2 x 40 KB for T <= 640 — into LDS once, with plain 16-byte pieces, then runs its key loop WITHOUT any further barrier:
+//   S^T[j][i] = sum_d K[j][d] Q[i][d]   (A = K rows, B = Q rows: two v_mfma_f32_32x32x16_bf16)
+//   O^T[d][i] = sum_j V^T[d][j] P^T[j][i]   (A = V^T rows, B = P^T straight from the S^T accumulators: registers 8 m .. 8 m + 7 of a lane
+//   half are keys 16 m + {0-3, 8-11} + 4 lh — the order V^T's tokens are stored in, so a lane's eight keys are one 16-byte piece)
+// LDS images are unpadded with the 16-byte piece index XOR-swizzled by the row (K: piece ^ ((row >> 2) & 3), V^T: piece ^ (row & 15)):
+// conflict-free ds_read_b128 for both.  2 x 40,960 bytes = exactly half a CU's LDS: two workgroups per CU, one copying while the other
+// multiplies.  Online softmax as in attn_kernel's bf16 path (raw-score running maximum, scale folded into the exp2 argument, rescale
+// skipped while no maximum moved).  Reference semantics: ldm/attention.py:86-128.
+typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256, 2) void battn_kernel(const unsigned short* __restrict__ qk, const unsigned short* __restrict__ vt, unsigned short* __restrict__ outp,
+                                                       int v_bstride, int o_bstride, int pitch, int T, int heads, int rows, float scale) {
+    extern __shared__ __attribute__((aligned(16))) u32x4b bsm[];
+    u32x4b* const Ks = bsm;                 // [640 keys][4 pieces]
+    u32x4b* const Vs = bsm + 640 * 4;       // [32 channels][80 pieces]
+    const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5, w = tid >> 6;
+    const int h = blockIdx.y, b = blockIdx.z, H = heads;
+    const int i0 = (blockIdx.x * 4 + w) * 32;
+    const int nkt = (T + 31) >> 5, nkr = nkt * 32;
+    const unsigned short* kg = qk + (((long long)b * 2 * H + H + h) * rows) * 32;
+    const unsigned short* vg = vt + (long long)b * v_bstride + (long long)(h * 32) * pitch;
+    // ---- the head's K and V^T -> LDS (rows past T: the last row again / the zeros the projection wrote)
+    {
+        const int npc = nkr >> 3;           // 16-byte pieces per V^T row
+        for (int i = tid; i < nkr * 4; i += 256 * 4) {
+            u32x4b kv[4], vv[4];
+            int ki[4], vi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = min(i + 256 * u, nkr * 4 - 1);
+                const int row = idx >> 2, pc = idx & 3;
+                kv[u] = *reinterpret_cast<const u32x4b*>(kg + (long long)min(row, rows - 1) * 32 + 8 * pc);
+                ki[u] = row * 4 + (pc ^ ((row >> 2) & 3));
+                const int d = idx / npc, p = idx - d * npc;        // (32 npc == 4 nkr: the same index range)
+                vv[u] = *reinterpret_cast<const u32x4b*>(vg + (long long)d * pitch + 8 * p);
+                vi[u] = d * 80 + (p ^ (d & 15));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { Ks[ki[u]] = kv[u]; Vs[vi[u]] = vv[u]; }
+        }
+    }
+    const unsigned short* qb = qk + (((long long)b * 2 * H + h) * rows + min(i0 + lt, rows - 1)) * 32 + 8 * lh;
+    const bf16x8a q0 = __builtin_bit_cast(bf16x8a, *reinterpret_cast<const u32x4b*>(qb));
+    const bf16x8a q1 = __builtin_bit_cast(bf16x8a, *reinterpret_cast<const u32x4b*>(qb + 16));
+    __syncthreads();
+    if (i0 >= T) return;                    // (a workgroup's spare wave: it only helped with the copy)
+    float m = -1.0e30f, lsum = 0.f;
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    const float c2 = scale * 1.4426950408889634f;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int j0 = kt * 32, jr = j0 + lt;
+        const bf16x8a k0 = __builtin_bit_cast(bf16x8a, Ks[jr * 4 + (lh ^ ((jr >> 2) & 3))]);
+        const bf16x8a k1 = __builtin_bit_cast(bf16x8a, Ks[jr * 4 + ((2 + lh) ^ ((jr >> 2) & 3))]);
+        const bf16x8a v0 = __builtin_bit_cast(bf16x8a, Vs[lt * 80 + (((j0 >> 3) + lh) ^ (lt & 15))]);
+        const bf16x8a v1 = __builtin_bit_cast(bf16x8a, Vs[lt * 80 + (((j0 >> 3) + 2 + lh) ^ (lt & 15))]);
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q1, s, 0, 0, 0);
+        if (j0 + 32 > T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                s[r] = (j < T) ? s[r] : -1.0e30f;
+            }
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
+        m = mn;
+        const float off = -mn * c2;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, off));
+            ps += s[r];
+        }
+        lsum = lsum * alpha + ps;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        }
+        const f32x4a p0 = {s[0], s[1], s[2], s[3]}, p1 = {s[4], s[5], s[6], s[7]}, p2 = {s[8], s[9], s[10], s[11]}, p3 = {s[12], s[13], s[14], s[15]};
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pk_bf16x8(p0, p1), o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pk_bf16x8(p2, p3), o, 0, 0, 0);
+    }
+    lsum += __shfl_xor(lsum, 32);
+    const float invL = 1.0f / lsum;
+    const int i = i0 + lt;
+    if (i < T) {   // registers 4 q .. 4 q + 3 are channels 8 q + 4 lh + (0 .. 3) of the head: four consecutive bf16 of the query's token-major row
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        __bf16* orow = reinterpret_cast<__bf16*>(outp) + ((long long)b * o_bstride + i) * (H * 32) + h * 32 + 4 * lh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bf16x4 ov = {(__bf16)(o[4 * q] * invL), (__bf16)(o[4 * q + 1] * invL), (__bf16)(o[4 * q + 2] * invL), (__bf16)(o[4 * q + 3] * invL)};
+            *reinterpret_cast<bf16x4*>(orow + 8 * q) = ov;
+        }
+    }
+}
+bool battn_supports(const AttnArgs& a, int head_dim) {
+    return head_dim == 32 && a.T >= 1 && a.T <= 640 && a.pitch >= ((a.T + 31) & ~31) && a.rows >= ((a.T + 31) & ~31) && a.v_bstride <= 0x7fffffffLL && a.o_bstride <= 0x7fffffffLL;
+}
+// q / k: bf16 [b][2 heads][rows][32] at a.qk, v: bf16 [b][heads * 32][pitch] at a.v (tokens permuted per 16: TGemmArgs::qkv_bf16), o: bf16 token-major
+void launch_battn(const AttnArgs& a, int batch, hipStream_t s) {
+    dim3 grid((((a.T + 31) / 32) + 3) / 4, a.heads, batch);
+    hipLaunchKernelGGL(battn_kernel, grid, dim3(256), 81920, s, reinterpret_cast<const unsigned short*>(a.qk), reinterpret_cast<const unsigned short*>(a.v),
+                       reinterpret_cast<unsigned short*>(a.o), (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T, a.heads, a.rows, a.scale);
+}
+
 template <int ND, int KS, bool BF, int QW = 1>
 static void launch_attn_one(const AttnArgs& a, int batch, hipStream_t s) {
     constexpr int D_ = 32 * ND;
@@ -363,6 +484,7 @@ static void configure_attn_one() {
                               160 * 1024);
 }
 void configure_attn_kernels() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     configure_attn_one<1, 8, false>(); configure_attn_one<1, 8, true>(); configure_attn_one<1, 4, false>(); configure_attn_one<1, 4, true>(); configure_attn_one<1, 1, false>(); configure_attn_one<1, 1, true>();
     configure_attn_one<1, 1, false, 4>(); configure_attn_one<1, 1, true, 4>(); configure_attn_one<2, 1, false, 4>(); configure_attn_one<2, 1, true, 4>();
     configure_attn_one<2, 8, false>(); configure_attn_one<2, 8, true>(); configure_attn_one<2, 4, false>(); configure_attn_one<2, 4, true>(); configure_attn_one<2, 1, false>(); configure_attn_one<2, 1, true>();

@@ -154,6 +154,8 @@ struct said_ctx {
     bool hybrid = true;       // bf16 mode at large batch: SpatialTransformers from the attention output on use round 3's token-major kernels
     int xgemm_dbg = 0;
     bool xclk_on = false;
+    int battn = -1;           // round 4: bf16-operand self-attention with a head's K / V resident in LDS (attn.hip: battn_kernel) behind rgemm's q/k/v;
+                              // 0: attn_kernel on fp32 operands (said_debug_option "battn")
     int rgemm = -1;           // round 4: register-stationary, wave-specialised persistent GEMMs (rgemm.hip) wherever launch_rgemm serves the shape
                               // (bf16 mode: 192-wide GEMMs with K <= 576, q/k/v); 0: off (said_debug_option "rgemm")
     long long n_rgemm = 0;
@@ -654,6 +656,15 @@ inline bool use_tm(said_ctx* c, const UGeo& g) {
 // `rows` tokens further into a token-major tensor of row width `ld` (element size by precision mode)
 inline void* tm_at(const said_ctx* c, void* base, long long rows, int ld) { return static_cast<char*>(base) + rows * ld * (c->bf16_mode ? 2 : 4); }
 void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
+    TGemmArgs a2 = a;
+    a2.f32 = c->bf16_mode ? 0 : 1;
+    if (c->xgemm_ntw > 0 && a2.ra[0]) a2.ntw = c->xgemm_ntw;
+    a2.dbg = c->xgemm_dbg;
+    if (c->xclk_on && c->dbg_count < 64) a2.clk = c->clk_dev + (long long)c->dbg_count * 128;
+    if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }
+    // kernel family: 7 = rgemm_kernel (round 4: register-stationary weights, helper waves), 8 = pgemm_kernel (weight slices resident in LDS;
+    // opt-in), 6 = round 3's xgemm_kernel
+    const int fam = (c->rgemm != 0 && !a2.f32 && rgemm_supports(a2, batch)) ? 7 : ((c->pgemm != 0 && !a2.f32 && pgemm_supports(a2, batch)) ? 8 : 6);
     if (c->log_on) {
         const double eb = c->bf16_mode ? 2.0 : 4.0;
         const double out_n = a.geglu ? a.N / 2 : a.N;
@@ -661,20 +672,14 @@ void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
         const double in_k = (a.ra[0] ? (a.ra[1] ? 384.0 : 192.0) : 0.0) + a.sk[0] + a.sk[1] + a.sk[2];   // source channels read per token (a conv reads its tile once)
         const double res_b = a.res_tm ? eb * a.N : 0.0;
         const double band_b = a.band_k ? 2.0 * 4.0 * a.N : 0.0;
-        c->stage_log.push_back({6, a.geglu ? EPI_GEGLU : (a.qk ? EPI_QKV : (a.band_k ? EPI_BAND : EPI_STORE)), a.N % 128 == 0 && (a.geglu || a.N % 96) ? 128 : 96, c->bf16_mode ? 4 : 32,
+        c->stage_log.push_back({fam, a.geglu ? EPI_GEGLU : (a.qk ? EPI_QKV : (a.band_k ? EPI_BAND : EPI_STORE)), a.N % 128 == 0 && (a.geglu || a.N % 96) ? 128 : 96, c->bf16_mode ? 4 : 32,
                                 eb * a.N * a.K + (double)batch * a.M * (eb * in_k + out_b + res_b + band_b), 2.0 * batch * (double)a.M * a.N * a.K});
     }
-    TGemmArgs a2 = a;
-    a2.f32 = c->bf16_mode ? 0 : 1;
-    if (c->xgemm_ntw > 0 && a2.ra[0]) a2.ntw = c->xgemm_ntw;
-    a2.dbg = c->xgemm_dbg;
-    if (c->xclk_on && c->dbg_count < 64) a2.clk = c->clk_dev + (long long)c->dbg_count * 128;
-    if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }
-    if (c->rgemm != 0 && !a2.f32 && rgemm_supports(a2, batch)) {
+    if (fam == 7) {
         if (dbg_go(c)) { launch_rgemm(a2, batch, s); ++c->n_rgemm; }
         return;
     }
-    if (c->pgemm != 0 && !a2.f32 && pgemm_supports(a2, batch)) {
+    if (fam == 8) {
         if (dbg_go(c)) { launch_pgemm(a2, batch, s); ++c->n_pgemm; }
         return;
     }
@@ -778,12 +783,20 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
     const int kv_off = g.Bc > 0 ? g.Bc : 0;
     const long long seg = tm_seg(g);
     const int vt_rows = rup(g.T, 32);
+    bool battn = false;
     {   // x = norm(x); q, k, v = to_{q,k,v}(norm1(x)) into attn.hip's operand layout   (attention.py:227, 168, 93-97)
         TGemmArgs t = mkx(g, tw(c, sw.t_qkv, sw.tf_qkv), 3 * MC, MC);
         t.ra[0] = in.t; t.rmode = 3; t.rtaps = 1;
         t.gn_part[0] = in.st; t.gn_cpg = 6; t.gn_eps = 1e-6f; t.gn_gamma = sw.gn_g; t.gn_beta = sw.gn_b;
         t.ln_gamma = sw.l1g; t.ln_beta = sw.l1b;
         t.qk = c->QK; t.vt = c->VT; t.v_bs = (long long)MC * g.Tp; t.qk_n = 2 * MC; t.head_dim = HD; t.rows = vt_rows; t.heads2 = 2 * HEADS; t.v_pitch = g.Tp;
+        // round 4 (bf16 mode, T <= 640): the projection writes bf16 q / k / v in battn_kernel's operand layout (attn.hip)
+        AttnArgs pa;
+        pa.qk = c->QK; pa.v = c->VT; pa.o = static_cast<float*>(c->tO); pa.v_bstride = (long long)MC * g.Tp; pa.o_bstride = seg;
+        pa.pitch = g.Tp; pa.T = g.T; pa.heads = HEADS; pa.rows = vt_rows; pa.b0 = 0; pa.scale = 0.17677669529663687f;
+        t.qkv_bf16 = (c->battn != 0 && c->bf16_mode && c->rgemm != 0 && battn_supports(pa, HD)) ? 1 : 0;
+        if (t.qkv_bf16 && !rgemm_supports(t, n1)) t.qkv_bf16 = 0;
+        battn = t.qkv_bf16 != 0;
         do_xgemm(c, t, n1, s);
     }
     {   // softmax(q k^T * scale) v -> token-major   (attention.py:99-126)
@@ -792,7 +805,12 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
         a.v_bstride = (long long)MC * g.Tp; a.o_bstride = seg; a.o_mode = c->bf16_mode ? 2 : 1;
         a.pitch = g.Tp; a.T = g.T; a.heads = HEADS; a.rows = vt_rows; a.b0 = 0;
         a.scale = 0.17677669529663687f;
-        do_attn(c, a, n1, HD, -4, s);
+        if (battn) {
+            if (c->log_on) { const double e = (double)n1 * HEADS * HD * g.T; c->stage_log.push_back({9, -1, 1, 1, 4.0 * e * 2.0, 4.0 * e * g.T}); }
+            if (dbg_go(c)) launch_battn(a, n1, s);
+        } else {
+            do_attn(c, a, n1, HD, -4, s);
+        }
     }
     {   // x1 = to_out(attn) + GroupNorm(x_in)   (attention.py:127, 168); under guidance also x2 of the unconditional half = x1 + c2
         TGemmArgs t = mkx(g, tw(c, sw.t_out1, sw.tf_out1), MC, MC);
@@ -830,6 +848,31 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
         t.bias = sw.t_ff1_bias; t.geglu = 1;
         t.yb = c->tF; t.y_bs = seg * FFI; t.ldy = FFI;
         do_xgemm(c, t, g.Be, s);
+    }
+    bool split = false;
+    if (!last && c->rgemm != 0 && c->bf16_mode) {   // round 4: as two rgemm launches over column ranges of the folded weight (see run_resblock_tm)
+        TGemmArgs t = mkx(g, sw.t_ffproj, MC, FFI);
+        t.sa[0] = c->tF; t.sld[0] = FFI; t.sk[0] = FFI; t.w_ld = FFI + MC;
+        t.res_tm = in.t; t.y_tm = c->tX1;
+        split = rgemm_supports(t, g.Be);
+    }
+    if (split) {
+        {   // (P F2) h + x_in -> tX1 (x1 is dead by now)
+            TGemmArgs t = mkx(g, sw.t_ffproj, MC, FFI);
+            t.sa[0] = c->tF; t.sld[0] = FFI; t.sk[0] = FFI; t.w_ld = FFI + MC; t.w_k0 = 0;
+            t.res_tm = in.t;
+            t.y_tm = c->tX1;
+            do_xgemm(c, t, g.Be, s);
+        }
+        {   // + P x2 + (P b2 + bp)
+            TGemmArgs t = mkx(g, sw.t_ffproj, MC, MC);
+            t.sa[0] = c->tX2; t.sld[0] = MC; t.sk[0] = MC; t.w_ld = FFI + MC; t.w_k0 = FFI;
+            t.bias = sw.ffproj.bias;
+            t.res_tm = c->tX1;
+            t.y_tm = out.t; t.stats = out.st;
+            do_xgemm(c, t, g.Be, s);
+        }
+        return;
     }
     {   // proj_out o ff.net.2 over [h ; x2] + x_in   (attention.py:193, 232-234)
         TGemmArgs t = mkx(g, tw(c, sw.t_ffproj, sw.tf_ffproj), MC, FFI + MC);
@@ -1413,7 +1456,7 @@ int check_ready(said_ctx* ctx) {
 // ============================================================================================
 extern "C" {
 
-int said_abi_version(void) { return 5; }   // 5: said_clone, said_loop_params::noise_batch_offset; 4: said_reserve, noise_seed, said_philox_normal, said_debug_option
+int said_abi_version(void) { return 6; }   // 6: said_loop_progress; 5: said_clone, said_loop_params::noise_batch_offset; 4: said_reserve, noise_seed, said_philox_normal, said_debug_option
 
 const char* said_last_error(const said_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -2274,6 +2317,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->pgemm = value < 0 ? -1 : (value != 0);
     } else if (k == "rgemm") {
         ctx->rgemm = value < 0 ? -1 : (value != 0);
+    } else if (k == "battn") {
+        ctx->battn = value < 0 ? -1 : (value != 0);
     } else {
         return fail(ctx, "said_debug_option: unknown option %s", name);
     }
@@ -2389,6 +2434,21 @@ int said_profile_unet(said_ctx* ctx, int Be, int T, int cfg_clips, int reps, int
 }
 
 int said_graph_num_nodes(const said_ctx* ctx) { return ctx ? ctx->gnodes : 0; }
+
+int said_loop_progress(said_ctx* ctx, int* steps_done) {
+    if (!ctx || !steps_done) return -1;
+    DeviceRestore restore_device;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t ps = nullptr;   // (created per call: a live stream holds one of the device's few hardware queues — DESIGN.md 5.1)
+    HIPCHK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+    int v = -1;
+    hipError_t e = hipMemcpyAsync(&v, ctx->step_dev, sizeof(int), hipMemcpyDeviceToHost, ps);
+    if (e == hipSuccess) e = hipStreamSynchronize(ps);
+    (void)hipStreamDestroy(ps);
+    if (e != hipSuccess) return fail(ctx, "said_loop_progress: %s", hipGetErrorString(e));
+    *steps_done = v + 1;        // the counter is -1 before the first step and k - 1 once step k - 1 has STARTED; its kernels complete in order
+    return 0;
+}
 
 int said_set_precision(said_ctx* ctx, int bf16_mfma) {
     if (!ctx) return -1;

@@ -180,6 +180,9 @@ void launch_step_advance(int* step_ptr, hipStream_t s);
 void launch_spin(long long ticks_100mhz, hipStream_t s);   // one wave busy for that long (stream-concurrency probe)
 void configure_gemm_kernels();   // raise the dynamic-LDS limit of every instantiation (call once, outside capture)
 void configure_attn_kernels();
+// round 4: bf16 operands (written by rgemm.hip's q/k/v epilogue), a head's K / V resident in LDS; T <= 640, head_dim 32
+bool battn_supports(const AttnArgs& a, int head_dim);
+void launch_battn(const AttnArgs& a, int batch, hipStream_t s);
 
 struct SchedArgs {
     const float* eps;          // channel-major [Be][C][pitch] model output

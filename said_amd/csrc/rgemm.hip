@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     typedef unsigned short elt_t;
     constexpr int NCT = EK == 1 ? 3 : (EK == 2 ? 2 : 1);   // column tiles per MFMA wave (q/k/v: head j of each; GEGLU: a (value, gate) pair)
-    constexpr int NACC = NCT == 1 ? 2 : 1;        // accumulators per column tile (one tile: two interleaved chains)
+    constexpr int NACC = (NCT == 1 && NCH <= 2) ? 2 : 1;   // accumulators per column tile (one tile: two interleaved chains, registers permitting)
     static_assert(NCH == 1 || (NTAP == 1 && MODE == 0), "chunked K: raw sources, one tap");
     constexpr int NTS = NTAP * 12;                // k16 steps per chunk
     constexpr int NSEG = NTAP * NCH;              // 192-wide K segments of the weight rows: taps or chunks
@@ -173,24 +173,30 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
         bf16x8 wf[NCT][NCH * NTS];
         const int w_ld = a.w_ld > 0 ? a.w_ld : a.K, w_seg = a.w_seg > 0 ? a.w_seg : 192;   // row pitch, distance between the segments
         {   // ---- weights: rounds of four k16 steps = 128 bytes of each of the wave's 32 rows: four 16-byte loads per lane that cover eight
-            // full rows each -> the staging area [32][144 bytes] -> this lane's four fragments
+            // full rows each -> the staging area [32][144 bytes] -> this lane's four fragments.  The loads run TWO rounds ahead of the
+            // staging (three register sets): one round per memory round trip made this prologue 13k clocks of every launch.
             const int srow = l >> 3, spc = l & 7;           // staging: lane -> (row within 8, 16-byte piece)
             u32x4* const st = reinterpret_cast<u32x4*>(ws);
+            constexpr int RPC = NSEG * 3, NRND = NCT * RPC; // rounds per column tile, rounds in all
+            u32x4 v[3][4];
+            auto wload = [&](int rnd, u32x4* dst) __attribute__((always_inline)) {
+                const int ct = rnd / RPC, r4 = rnd - ct * RPC;
+                const elt_t* wbase = W + (long long)(EK == 2 ? cg * 384 + 64 * j + 32 * ct : ct * 192 + 32 * j) * w_ld + a.w_k0 + (r4 / 3) * w_seg + 64 * (r4 % 3) + 8 * spc;
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const elt_t* wbase = W + (long long)(EK == 2 ? cg * 384 + 64 * j + 32 * ct : ct * 192 + 32 * j) * w_ld + a.w_k0;
+                for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const u32x4*>(wbase + (long long)(8 * q + srow) * w_ld);
+            };
+            wload(0, v[0]);
+            if (NRND > 1) wload(1, v[1]);
 #pragma unroll
-                for (int r4 = 0; r4 < NSEG * 3; ++r4) {   // (three rounds per 192-wide segment)
-                    u32x4 v[4];
+            for (int rnd = 0; rnd < NRND; ++rnd) {
+                if (rnd + 2 < NRND) wload(rnd + 2, v[(rnd + 2) % 3]);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4*>(wbase + (long long)(8 * q + srow) * w_ld + (r4 / 3) * w_seg + 64 * (r4 % 3) + 8 * spc);
+                for (int q = 0; q < 4; ++q) st[(8 * q + srow) * 9 + spc] = v[rnd % 3][q];
+                __builtin_amdgcn_wave_barrier();
+                const int ct = rnd / RPC, r4 = rnd - ct * RPC;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) st[(8 * q + srow) * 9 + spc] = v[q];
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) wf[ct][4 * r4 + s4] = __builtin_bit_cast(bf16x8, st[fr * 9 + 2 * s4 + lh]);
-                    __builtin_amdgcn_wave_barrier();
-                }
+                for (int s4 = 0; s4 < 4; ++s4) wf[ct][4 * r4 + s4] = __builtin_bit_cast(bf16x8, st[fr * 9 + 2 * s4 + lh]);
+                __builtin_amdgcn_wave_barrier();
             }
         }
         float bias_n[NCT];
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
                 for (int x = 0; x < NACC; ++x)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[ct][x][r] = 0.f;
-            constexpr int GS = NCT == 3 ? 3 : 6;   // fragments per group (q/k/v: three MFMAs per fragment, and 144 + 48 registers already taken)
+            constexpr int GS = (NCT == 3 || NCH > 2) ? 3 : 6;   // fragments per group (q/k/v: three MFMAs per fragment; q/k/v and four-chunk K: ~190 registers of weights)
             constexpr int NG = NTS / GS;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
@@ -290,6 +296,28 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
                         ws[row * 36 + fr] = acc[ct][0][r] + bv;
                     }
                     __builtin_amdgcn_wave_barrier();
+                    if (a.qkv_bf16) {
+                        // bf16 operands of battn_kernel (attn.hip): same indexing, 64-byte rows: lane -> (row 16 p + (l >> 2), eight elements)
+#pragma unroll
+                        for (int p2 = 0; p2 < 2; ++p2) {
+                            const int row = 16 * p2 + er;
+                            // v (rows = channels, columns = tokens): the stored token order inside a block of 16 is [0-3, 8-11, 4-7, 12-15], so the
+                            // eight stored positions 8 ec .. 8 ec + 7 are tokens x0 .. x0 + 3 and x0 + 8 .. x0 + 11
+                            const int x0 = ct == 2 ? 16 * (ec >> 1) + 4 * (ec & 1) : 8 * ec, x1 = ct == 2 ? x0 + 8 : x0 + 4;
+                            f32x4t v0 = *reinterpret_cast<const f32x4t*>(ws + row * 36 + x0);
+                            f32x4t v1 = *reinterpret_cast<const f32x4t*>(ws + row * 36 + x1);
+                            int off;
+                            if (ct < 2) {
+                                off = row < nrows ? (((b * a.heads2 + ct * 6 + j) * a.rows + t0 + row) * 32 + 8 * ec) * 2 : (int)0x80000000;
+                            } else {   // (padding tokens of the tile: zeros — attention multiplies them by p = 0)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v0[e] = x0 + e < nrows ? v0[e] : 0.f; v1[e] = x1 + e < nrows ? v1[e] : 0.f; }
+                                off = (int)(((long long)b * a.v_bs + (long long)(32 * j + row) * a.v_pitch + t0 + 8 * ec) * 2);
+                            }
+                            const u32x4 ov = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(ov, ct < 2 ? rq : rv, off, 0, 0);
+                        }
+                    } else {
 #pragma unroll
                     for (int p4 = 0; p4 < 4; ++p4) {
                         const int row = 8 * p4 + prow;
@@ -303,6 +331,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
                             off = (int)(((long long)b * a.v_bs + (long long)(32 * j + row) * a.v_pitch + t0 + pc4) * 4);
                         }
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ct < 2 ? rq : rv, off, 0, 0);
+                    }
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -369,7 +398,8 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const float d = row < nrows ? ws[row * 36 + fr] - ref : 0.f;
+                        const float xv = ws[row * 36 + fr];         // (unconditional read, then a select: a guarded read is a branch per register)
+                        const float d = row < nrows ? xv - ref : 0.f;
                         s1 += d; s2 = fmaf(d, d, s2);
                     }
                     s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
@@ -395,7 +425,9 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
     const int hw = w - 6, slot = l >> 4, c12 = l & 15;
     constexpr bool GN_SRC = MODE == 1 || MODE == 3;
     const rsrc_t rsrc_src = make_rsrc(MODE != 0 ? a.ra[0] : a.sa[0], 0x7ffffff0u);
-    const rsrc_t rsrc_src1 = make_rsrc((NCH > 1 && a.sa[1]) ? a.sa[1] : a.w, 0x7ffffff0u);   // chunk 1's tensor (chunked K: raw 192-wide sources)
+    // chunked K: NCH == 2: chunk c is the 192-wide tensor sa[c]; NCH == 4: the chunks are the four 192-column blocks of sa[0] (row pitch sld[0])
+    const rsrc_t rsrc_src1 = make_rsrc((NCH == 2 && a.sa[1]) ? a.sa[1] : a.w, 0x7ffffff0u);
+    const int src_ld = MODE != 0 ? 192 : a.sld[0];
     float ga[12], gb[12], lg[12], lb[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) {
@@ -441,13 +473,14 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
     auto issue_tile = [&](int u_) __attribute__((always_inline)) {
         const int u = min(u_, t_last * NCH + NCH - 1);   // (units past the workgroup's range: clamped, their work is done and discarded)
         const int ti = u / NCH;
-        const rsrc_t rs = (NCH > 1 && (u % NCH) == 1) ? rsrc_src1 : rsrc_src;
+        const rsrc_t rs = (NCH == 2 && (u % NCH) == 1) ? rsrc_src1 : rsrc_src;
+        const int col = NCH == 4 ? 192 * (u % NCH) : 0;
         const int b = ti / ntv, t0 = (ti - b * ntv) * 32;
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             const int r = min(8 * p + 4 * hw + slot, NR - 1);
             const int tt = t0 + r - HALO;
-            const int off = ((b * a.seg_rows + min(max(tt, 0), a.M - 1)) * 192 + 12 * c12) * 2;
+            const int off = ((b * a.seg_rows + min(max(tt, 0), a.M - 1)) * src_ld + col + 12 * c12) * 2;
             rawa[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
             rawb[p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, off + 16, 0, 0));
         }
@@ -545,8 +578,10 @@ static bool rg_plan(const TGemmArgs& a, RgPlan& p) {
         if (a.rmode >= 2 && (!a.ln_gamma || !a.ln_beta || a.rtaps != 1)) return false;
         p.ntap = a.rtaps; p.mode = a.rmode;
     } else {
-        if (!a.sa[0] || a.sk[0] != 192 || a.sld[0] != 192) return false;
-        if (a.sk[1]) { if (a.sk[1] != 192 || a.sld[1] != 192 || !a.sa[1] || a.K != 384) return false; p.nch = 2; }
+        if (!a.sa[0]) return false;
+        if (a.sk[0] == 768) { if (a.sld[0] != 768 || a.sk[1] || a.K != 768) return false; p.nch = 4; }
+        else if (a.sk[0] != 192 || a.sld[0] != 192) return false;
+        else if (a.sk[1]) { if (a.sk[1] != 192 || a.sld[1] != 192 || !a.sa[1] || a.K != 384) return false; p.nch = 2; }
         else if (a.K != 192) return false;
         p.ntap = 1; p.mode = 0;
     }
@@ -569,7 +604,7 @@ static bool rg_plan(const TGemmArgs& a, RgPlan& p) {
         p.dup = a.y2_tm ? 1 : 0;
         p.stats = a.stats ? 1 : 0;
     } else return false;
-    if ((long long)a.batch * a.seg_rows * 192 * 2 > 0x7ffffff0LL) return false;   // 32-bit byte offsets into the activation tensors
+    if ((long long)a.batch * a.seg_rows * (p.nch == 4 ? 768 : 192) * 2 > 0x7ffffff0LL) return false;   // 32-bit byte offsets into the activation tensors
     const int total = a.batch * ((a.M + 31) / 32);
     const int wpg = std::max(8, 256 / p.groups / 8 * 8);          // workgroups per column group: one workgroup per CU in all
     p.per = (total + wpg - 1) / wpg;
@@ -589,7 +624,9 @@ static bool rg_plan(const TGemmArgs& a, RgPlan& p) {
     X(1, 4, 2, 0, false, false, 1)  /* q of LayerNorm(x1) + banded cross-attention                         */ \
     X(1, 2, 2, 0, false, false, 1)  /* GEGLU of LayerNorm(x2): four column groups of six (value, gate) pairs */ \
     X(3, 0, 1, 0, false, false, 1)  /* one source of a concatenated-input convolution -> partial sum        */ \
-    X(1, 0, 0, 0, false, false, 2)  /* 1x1 skip convolution over the concatenated raw input (two chunks)    */
+    X(1, 0, 0, 0, false, false, 2)  /* 1x1 skip convolution over the concatenated raw input (two chunks)    */ \
+    X(1, 0, 0, 1, false, false, 4)  /* folded proj_out o ff.net.2, the GEGLU product's 768 columns + x_in -> partial sum */ \
+    X(1, 0, 0, 1, false, true, 1)   /* ... x2's 192 columns + bias + the partial sum, statistics            */
 static int rg_variant(const RgPlan& p) {
     int i = 0;
 #define X(NT_, EK_, MO_, RE_, DU_, ST_, NC_) if (p.ntap == NT_ && p.ek == EK_ && p.mode == MO_ && p.res == RE_ && (p.dup != 0) == DU_ && (p.stats != 0) == ST_ && p.nch == NC_) return i; ++i;

@@ -24,6 +24,8 @@ struct TGemmArgs {
     float* vt;
     long long v_bs;
     int qk_n, head_dim, rows, heads2, v_pitch;
+    int qkv_bf16;          // rgemm_kernel: q / k / v are written as bf16 in battn_kernel's operand layout (attn.hip: launch_battn) — same indexing, v's
+                           // tokens permuted inside every block of 16 ([0-3, 8-11, 4-7, 12-15]: a lane half's eight keys are one 16-byte piece)
     int M, N, K;
     int batch;             // filled in by launch_tgemm
     int act;               // 0 none, 1 GELU (erf)

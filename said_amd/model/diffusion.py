@@ -49,6 +49,40 @@ class SAIDNoiseAdditionOutput:
     velocity: torch.FloatTensor
 
 
+
+class _Progress:
+    """`show_process=True` (diffusion.py:412-415: tqdm around the reference's Python loop).  Here the loop is a queue of hipGraph launches
+    the host does not step through, so a thread polls the engine's device-side step counter (said_loop_progress: a private stream,
+    the loop's stream is never blocked) and drives the same kind of bar on stderr."""
+
+    def __init__(self, eng, total: int, interval: float = 0.05):
+        from tqdm import tqdm
+        self._eng, self._total, self._interval = eng, total, interval
+        self._bar = tqdm(total=total)
+        self._done = 0
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._poll, name="said-show-process", daemon=True)
+        self._th.start()
+
+    def _advance(self):
+        try:
+            s = min(max(self._eng.loop_progress(), 0), self._total)
+        except Exception:   # the engine was closed under us: nothing to show
+            return
+        if s > self._done:
+            self._bar.update(s - self._done)
+            self._done = s
+
+    def _poll(self):
+        while not self._stop.wait(self._interval):
+            self._advance()
+
+    def close(self):
+        self._stop.set()
+        self._th.join()
+        self._advance()
+        self._bar.close()
+
 class SAID(ABC, nn.Module):
     """Abstract class of SAiD models"""
 
@@ -208,23 +242,25 @@ class SAID(ABC, nn.Module):
 
     def _pick_clip_groups(self, batch_size: int, tokens_per_clip: int) -> int:
         """How many concurrent clip groups SAID.inference runs a batch as (tokens_per_clip: UNet rows per clip, 2 T under
-        guidance).  Measured on one MI355X (scripts/clip_groups_sweep.py, profiles/r03d_clip_groups_sweep.txt): a split pays
-        when every group keeps >= 12000 UNet rows (>= 9000 for two groups in bf16 mode), i.e. stays on the large-batch GEMM
-        kernels with a full wave of workgroups: -4 .. -14 % per step; below that it costs up to +15 %.  Three groups beat two
-        by 1-2 points; four are slower than one (they outnumber the device's hardware queues and serialise)."""
+        guidance).  Clip groups are round 3's answer to launches that could not fill the chip on their own: contiguous sub-batches, each
+        a complete denoising loop on its own stream.
+        * bf16 mode, large batches (round 4): ONE group.  The persistent GEMMs (rgemm.hip: <= 256 workgroups for the whole batch, weights
+          in registers, helper waves) keep every CU busy without a second chain beside them: 1.32 ms per step unsplit against 1.30 / 1.40
+          with two / four groups at 32 clips x 600 frames (round 3's kernels: 1.99 unsplit, 1.73 with four) — and an unsplit batch does
+          not depend on free hardware queues.
+        * fp32 mode (measured on round 3's kernels, scripts/clip_groups_sweep.py): a split pays when every group keeps >= 12000 UNet rows,
+          i.e. stays on the large-batch GEMM kernels with a full wave of workgroups: -4 .. -14 % per step; three groups beat two by 1-2 points.
+        * small batches of 4+ clips that stay on the small-batch kernels as a whole are chains of short latency-bound launches: two such
+          chains side by side overlap almost freely (-5 .. -14 % per step)."""
         if self.clip_groups is not None:
             return max(1, min(int(self.clip_groups), batch_size))
         bf = self.mfma_dtype == "bf16"
-        # (bf16 mode: four groups of >= 9000 rows beat three: 199.5k vs 194.0k frames/s at 32 clips x 50 steps, three alternating pairs;
-        # fp32 mode: 36.5k vs 36.7k — stays at three.  Four groups = the caller's stream + the pool's three = every hardware queue.)
-        for g, need in ((4, 9000 if bf else 1 << 60), (3, 9000 if bf else 12000), (2, 9000 if bf else 12000)):
-            if batch_size >= g and (batch_size // g) * tokens_per_clip >= need:
-                return g
-        # Small batches (below ~the token-major threshold as a whole) are chains of short, latency-bound launches: two such chains side
-        # by side overlap almost freely: -6 .. -14 % per step at 4-8 clips x 600 frames in fp32 mode, -5 .. -14 % at 4-6 clips in bf16
-        # mode (profiles/r03g_clip_groups_small_batches.txt).  At least two clips per group (single short clips side by side: +5 %);
-        # bf16 from 8000 rows on loses (8 clips x 600: +4 %).
-        if batch_size >= 4 and batch_size * tokens_per_clip < (8000 if self.mfma_dtype == "bf16" else 10000):
+        if not bf:
+            for g in (3, 2):
+                if batch_size >= g and (batch_size // g) * tokens_per_clip >= 12000:
+                    return g
+        # At least two clips per group (single short clips side by side: +5 %); bf16 from 8000 rows on runs the persistent kernels: one group.
+        if batch_size >= 4 and batch_size * tokens_per_clip < (8000 if bf else 10000):
             return 2
         return 1
 
@@ -313,6 +349,18 @@ class SAID(ABC, nn.Module):
         # mode; fp32's GEMM tile depends on the launch size, so there sums differ in their last bits: 2e-5 after 6 steps).  The
         # eta noise is the whole batch's (noise_batch_offset).
         G = self._pick_clip_groups(batch_size, (2 if do_cfg else 1) * window_size)
+        progress = _Progress(eng, n_run) if (show_process and n_run > 0) else None
+        try:
+            result, inter = self._run_groups(G, eng, job, batch_size, do_cfg, window_size, n_run, save_intermediate, device)
+            if progress is not None:
+                torch.cuda.current_stream(device).synchronize()   # (the reference's loop is synchronous: the bar ends when the result exists)
+        finally:
+            if progress is not None:
+                progress.close()
+        intermediates = [inter[k] for k in range(n_run)] if save_intermediate else []
+        return SAIDInferenceOutput(result=result, intermediates=intermediates)
+
+    def _run_groups(self, G, eng, job, batch_size, do_cfg, window_size, n_run, save_intermediate, device):
         if G > 1 and n_run > 0:
             bounds = [batch_size * i // G for i in range(G + 1)]
             engines = [eng] + self._group_engines(eng, G - 1, (2 if do_cfg else 1) * max(bounds[i + 1] - bounds[i] for i in range(G)), window_size)
@@ -357,8 +405,7 @@ class SAID(ABC, nn.Module):
             inter = torch.cat([o[2] for o in out], dim=1) if save_intermediate else None
         else:
             result, _, inter = eng.run_loop(job(eng, 0, batch_size))
-        intermediates = [inter[k] for k in range(n_run)] if save_intermediate else []
-        return SAIDInferenceOutput(result=result, intermediates=intermediates)
+        return result, inter
 
 
 class SAID_UNet1D(SAID):

@@ -25,6 +25,52 @@ def clip_range(rank: int, world: int, clips_per_rank: int) -> range:
     return range(rank * clips_per_rank, (rank + 1) * clips_per_rank)
 
 
+def shard_bounds(n_items: int, world: int) -> List[range]:
+    """Contiguous partition of `n_items` independent items (clips, or repeats of one clip) over `world` ranks, UNEVEN shards allowed: the
+    first `n_items % world` ranks own one item more (100 over 8 -> 13, 13, 13, 13, 12, 12, 12, 12; a rank may own none)."""
+    if n_items < 0 or world < 1:
+        raise ValueError(f"bad partition request: {n_items} items over {world} ranks")
+    q, r = divmod(n_items, world)
+    out, lo = [], 0
+    for k in range(world):
+        hi = lo + q + (1 if k < r else 0)
+        out.append(range(lo, hi))
+        lo = hi
+    return out
+
+
+def gather_uneven(dist, local: torch.Tensor, counts: List[int], world: int) -> torch.Tensor:
+    """ONE all-gather of per-rank results with different row counts: every rank pads its (counts[rank], ...) tensor to max(counts) rows,
+    `all_gather_into_tensor` assembles (world, max, ...), and the padding rows are trimmed: (sum(counts), ...) in global item order on
+    every rank.  (`all_gather_into_tensor` needs equal shapes; a second collective for the sizes is not needed: the partition is a pure
+    function of (n_items, world).)"""
+    if world == 1 and dist is None:
+        return local
+    m = max(counts)
+    if local.shape[0] != m:
+        pad = torch.zeros((m - local.shape[0],) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+        local = torch.cat([local, pad])
+    out = torch.empty((world * m,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    if all(c == m for c in counts):
+        return out
+    return torch.cat([out[k * m: k * m + c] for k, c in enumerate(counts)])
+
+
+def sharded_inference(path_fn: Callable[[range], torch.Tensor], n_items: int, *, rank: int, world: int, dist=None) -> torch.Tensor:
+    """The product's multi-GPU entry point (the reference's batched caller, script/test_inference.py:147-202, is
+    single-device): `n_items` independent items are partitioned contiguously over the ranks (shard_bounds), every rank runs
+    `path_fn(global item ids of its shard)` -> (n_local, ...) on its own GPU with no data-path collective, and one all-gather returns
+    the (n_items, ...) result in global order on every rank.  `path_fn` is given GLOBAL ids so that anything random inside it can be
+    seeded per item: the result is then independent of the number of ranks."""
+    shards = shard_bounds(n_items, world)
+    mine = shards[rank]
+    local = path_fn(mine)
+    if local.shape[0] != len(mine):
+        raise RuntimeError(f"path returned {local.shape[0]} items for a shard of {len(mine)}")
+    return gather_uneven(dist, local, [len(r) for r in shards], world)
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

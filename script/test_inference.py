@@ -31,7 +31,13 @@ def test_audio_paths(audio_dir: str, person_ids=None):
 
 
 def build_parser():
-    return _common.parser_with("Repeated SAiD sampling over the BlendVOCA test audio on an MI355X", FLAGS)
+    ap = _common.parser_with("Repeated SAiD sampling over the BlendVOCA test audio on an MI355X", FLAGS)
+    # not a reference flag: the reference's batched caller is single-device (test_inference.py:103-107); see said_amd/shard.py
+    ap.add_argument("--gpus", type=int, default=0,
+                    help="0 (default): one device (--device), start noise from torch's generator as in the reference; N >= 1: the repeats of "
+                         "every clip are partitioned over N MI355X of this node (one process per GPU, one RCCL all-gather per clip), each "
+                         "repeat's start noise seeded by (seed, sentence, repeat) so that the output does not depend on N")
+    return ap
 
 
 def batch_sizes(total: int, limit: int):
@@ -40,28 +46,79 @@ def batch_sizes(total: int, limit: int):
     return [limit] * full + ([rest] if rest else [])
 
 
-def main(argv=None) -> None:
-    args = build_parser().parse_args(argv)
+def repeat_latents(seed: int, sentence: int, repeat: int, frames: int, channels: int = 32) -> torch.Tensor:
+    """Start noise of one repeat of one sentence, a pure function of (seed, sentence, repeat): the same sample whichever rank draws it."""
+    g = torch.Generator().manual_seed((max(seed, 0) * 1000003 + sentence) * 1000003 + repeat)
+    return torch.randn(1, frames, channels, generator=g)
+
+
+def sample_repeats(net, audio, n_frames_model, repeats, args, sentence: int, seeded: bool) -> torch.Tensor:
+    """(len(repeats), T, 32) results for the given repeat ids of one clip, in batches of at most --batch_size.  The clip is encoded ONCE:
+    every row of a batch is the same waveform (the reference encodes the repeated batch, test_inference.py:167-168)."""
+    dev = audio.device
+    emb1 = net.get_audio_embedding(audio, n_frames_model)
+    outs, ids = [], list(repeats)
+    for n in batch_sizes(len(ids), args.batch_size):
+        chunk, ids = ids[:n], ids[n:]
+        kw = {}
+        if seeded:
+            kw["init_latents"] = torch.cat([repeat_latents(args.seed, sentence, r, n_frames_model) for r in chunk]).to(dev)
+        out = net.inference(waveform_processed=audio.expand(n, -1), num_inference_steps=args.num_steps, strength=args.strength,
+                            guidance_scale=args.guidance_scale, guidance_rescale=args.guidance_rescale, eta=args.eta,
+                            show_process=False, audio_embedding=emb1.expand(n, -1, -1).contiguous(), **kw)
+        outs.append(out.result)
+    return torch.cat(outs) if outs else torch.zeros(0, n_frames_model, 32, device=dev)
+
+
+def run_rank(args, rank: int, world: int, dist) -> None:
+    """One rank (world == 1 and dist None: the plain single-device driver)."""
+    from said_amd import shard
+    seeded = args.gpus >= 1
+    if world > 1:
+        args.device = f"cuda:{rank}"
     if args.seed >= 0:
         torch.manual_seed(args.seed)
     net = _common.make_model(args)
     with torch.no_grad():
-        for pid, wav_path in test_audio_paths(args.audio_dir):
+        for si, (pid, wav_path) in enumerate(test_audio_paths(args.audio_dir)):
             stem = os.path.splitext(os.path.basename(wav_path))[0]
             target = os.path.join(args.output_dir, pid)
-            os.makedirs(target, exist_ok=True)
             audio, frames = _common.prepared_audio(net, wav_path, args.fps, args.divisor_unet)
-            stacked = audio.repeat(args.batch_size, 1)
-            done = 0
-            for n in batch_sizes(args.num_repeats, args.batch_size):
-                out = net.inference(waveform_processed=stacked[:n], num_inference_steps=args.num_steps, strength=args.strength,
-                                    guidance_scale=args.guidance_scale, guidance_rescale=args.guidance_rescale, eta=args.eta,
-                                    show_process=False)
-                tables = out.result[:, :frames].cpu().numpy()
-                for k in range(n):
-                    save_blendshape_coeffs(coeffs=tables[k], classes=DEFAULT_BLENDSHAPE_CLASSES,
-                                           output_path=os.path.join(target, f"{stem}-{done + k}.csv"))
-                done += n
+            n_model = int(audio.shape[1] / net.sampling_rate * args.fps)
+            res = shard.sharded_inference(lambda ids: sample_repeats(net, audio, n_model, ids, args, si, seeded), args.num_repeats,
+                                          rank=rank, world=world, dist=dist)
+            if rank == 0:
+                os.makedirs(target, exist_ok=True)
+                tables = res[:, :frames].cpu().numpy()
+                for k in range(args.num_repeats):
+                    save_blendshape_coeffs(coeffs=tables[k], classes=DEFAULT_BLENDSHAPE_CLASSES, output_path=os.path.join(target, f"{stem}-{k}.csv"))
+
+
+def _rank_main(args):
+    from said_amd import shard
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    torch.cuda.set_device(rank)
+    dist = shard.init_process_group("nccl", rank, world, torch.device("cuda", rank))   # "nccl" IS RCCL on ROCm
+    try:
+        run_rank(args, rank, world, dist)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def main(argv=None) -> None:
+    args = build_parser().parse_args(argv)
+    if args.gpus > 1:
+        from said_amd import shard
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"test_inference.py --gpus {args.gpus}: only {have} MI355X device(s) visible to this process")
+        if "WORLD_SIZE" in os.environ:          # started under torch.distributed.run
+            _rank_main(args)
+        else:
+            shard.spawn(_rank_main, (args,), args.gpus)
+        return
+    run_rank(args, 0, 1, None)
 
 
 if __name__ == "__main__":

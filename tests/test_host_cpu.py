@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/said_hip.h but not exported"
     assert declared == set(_engine.EXPORTS), (declared ^ set(_engine.EXPORTS))
-    assert lib.said_abi_version() == _engine.ABI_VERSION == 5
+    assert lib.said_abi_version() == _engine.ABI_VERSION == 6
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -270,7 +270,8 @@ def test_clip_group_policy():
     assert pick(2, 3600) == 1 and pick(8, 3600) == 2 and pick(12, 3600) == 3   # 30 s clips
     m.mfma_dtype = "bf16"
     assert pick(4, 1200) == 2 and pick(6, 1200) == 2 and pick(8, 1200) == 1
-    assert pick(12, 1200) == 1 and pick(16, 1200) == 2 and pick(24, 1200) == 3 and pick(32, 1200) == 4 and pick(64, 1200) == 4
+    # round 4: the persistent GEMMs of the bf16 large-batch schedule fill the chip on their own: never split (round 3: 2 / 3 / 4 groups)
+    assert pick(12, 1200) == 1 and pick(16, 1200) == 1 and pick(24, 1200) == 1 and pick(32, 1200) == 1 and pick(64, 1200) == 1
     m.clip_groups = 1
     assert pick(64, 1200) == 1
     m.clip_groups = 5

@@ -126,3 +126,59 @@ def test_bench_self_launches_ranks_dry_run():
     assert len(lines) == 1                                               # ONE JSON line, from rank 0
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["clip_ranges"] == [[0, 1], [2, 3]] and j["gathered_shape"] == [4, 30, 32] and j["checksum_ok"]
+
+
+# ---------------------------------------------------------------- round 4: the product entry point, uneven shards
+def _item_tensor(i, T):
+    g = torch.Generator().manual_seed(1000 + i)      # seeded by the GLOBAL item id, as script/test_inference.py --gpus N seeds a repeat
+    return torch.randn(T, 32, generator=g)
+
+
+def _uneven_worker(rank, world, port, n_items, T, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist = shard.init_process_group("gloo", rank, world)
+    seen = []
+
+    def path_fn(ids):
+        seen.append(list(ids))
+        return torch.stack([_item_tensor(i, T) for i in ids]) if len(ids) else torch.zeros(0, T, 32)
+
+    res = shard.sharded_inference(path_fn, n_items, rank=rank, world=world, dist=dist)
+    out_q.put((rank, res.clone(), seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_uneven(world, n_items, T):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = shard.free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, n_items, T, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    return res
+
+
+def test_shard_bounds_uneven():
+    assert [len(r) for r in shard.shard_bounds(100, 8)] == [13, 13, 13, 13, 12, 12, 12, 12]
+    assert [len(r) for r in shard.shard_bounds(72, 5)] == [15, 15, 14, 14, 14]
+    assert [len(r) for r in shard.shard_bounds(3, 8)] == [1, 1, 1, 0, 0, 0, 0, 0]
+    for n, w in ((100, 8), (72, 5), (3, 8), (0, 2), (64, 1)):
+        flat = [i for r in shard.shard_bounds(n, w) for i in r]
+        assert flat == list(range(n))                     # contiguous, complete, in order
+
+
+def test_sharded_inference_uneven_equals_one_rank():
+    """100 items over 8 ranks and 72 over 5 (the reference's num_repeats, script/test_inference.py:90) — shards of different sizes, padded to
+    the largest for the ONE all-gather and trimmed after it — give, on every rank, bit for bit the result of a single rank; a world with
+    more ranks than items works too (empty shards)."""
+    T = 4
+    for world, n_items in ((8, 100), (5, 72), (4, 3)):
+        want = shard.sharded_inference(lambda ids: torch.stack([_item_tensor(i, T) for i in ids]), n_items, rank=0, world=1)
+        res = _run_uneven(world, n_items, T)
+        for rank, got, seen in res:
+            assert torch.equal(got, want), (world, n_items, rank)
+            assert seen == [list(shard.shard_bounds(n_items, world)[rank])]      # ONE call, own shard only
