@@ -19,7 +19,7 @@ LIB = os.path.join(LIBDIR, "libsaid_hip.so")
 # gfx950 only.  SAID_OFFLOAD_ARCH may narrow the target ID for experiments (e.g. "gfx950:xnack-"; several, comma-separated,
 # give a fat binary from which the runtime picks the one matching the device).
 ARCHS = os.environ.get("SAID_OFFLOAD_ARCH", "gfx950").split(",")
-SOURCES = ["gemm.hip", "gemm_lds.hip", "attn.hip", "misc.hip", "out_sched.hip", "conv_in.hip", "tgemm.hip", "pgemm.hip", "rgemm.hip", "engine.cpp"]
+SOURCES = ["gemm.hip", "gemm_lds.hip", "attn.hip", "misc.hip", "out_sched.hip", "conv_in.hip", "tgemm.hip", "rgemm.hip", "engine.cpp"]
 FLAGS = [*[f"--offload-arch={a}" for a in ARCHS], "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
 

@@ -363,27 +363,32 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 // conflict-free ds_read_b128 for both.  2 x 40,960 bytes = exactly half a CU's LDS: two workgroups per CU, one copying while the other
 // multiplies.  Online softmax as in attn_kernel's bf16 path (raw-score running maximum, scale folded into the exp2 argument, rescale
 // skipped while no maximum moved).  Reference semantics: ldm/attention.py:86-128.
+// QT = query tiles (= waves) per workgroup.  The key loop is one dependent chain per wave (LDS read -> MFMA -> max -> exp2 -> MFMA): with
+// four waves per workgroup and two workgroups per CU a SIMD holds two such chains and the kernel ran latency-bound (52 us); eight waves
+// put four on every SIMD and halve the K / V copies per query tile.
 typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256, 2) void battn_kernel(const unsigned short* __restrict__ qk, const unsigned short* __restrict__ vt, unsigned short* __restrict__ outp,
+template <int QT>
+__global__ __launch_bounds__(64 * QT, (QT == 8 ? 4 : 2)) void battn_kernel(const unsigned short* __restrict__ qk, const unsigned short* __restrict__ vt, unsigned short* __restrict__ outp,
                                                        int v_bstride, int o_bstride, int pitch, int T, int heads, int rows, float scale) {
     extern __shared__ __attribute__((aligned(16))) u32x4b bsm[];
-    u32x4b* const Ks = bsm;                 // [640 keys][4 pieces]
-    u32x4b* const Vs = bsm + 640 * 4;       // [32 channels][80 pieces]
+    const int nkt = (T + 31) >> 5, nkr = nkt * 32;
+    u32x4b* const Ks = bsm;                 // [nkr keys][4 pieces]
+    u32x4b* const Vs = bsm + nkr * 4;       // [32 channels][80 pieces]
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5, w = tid >> 6;
     const int h = blockIdx.y, b = blockIdx.z, H = heads;
-    const int i0 = (blockIdx.x * 4 + w) * 32;
-    const int nkt = (T + 31) >> 5, nkr = nkt * 32;
+    constexpr int NTH = 64 * QT;
+    const int i0 = (blockIdx.x * QT + w) * 32;
     const unsigned short* kg = qk + (((long long)b * 2 * H + H + h) * rows) * 32;
     const unsigned short* vg = vt + (long long)b * v_bstride + (long long)(h * 32) * pitch;
     // ---- the head's K and V^T -> LDS (rows past T: the last row again / the zeros the projection wrote)
     {
         const int npc = nkr >> 3;           // 16-byte pieces per V^T row
-        for (int i = tid; i < nkr * 4; i += 256 * 4) {
+        for (int i = tid; i < nkr * 4; i += NTH * 4) {
             u32x4b kv[4], vv[4];
             int ki[4], vi[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int idx = min(i + 256 * u, nkr * 4 - 1);
+                const int idx = min(i + NTH * u, nkr * 4 - 1);
                 const int row = idx >> 2, pc = idx & 3;
                 kv[u] = *reinterpret_cast<const u32x4b*>(kg + (long long)min(row, rows - 1) * 32 + 8 * pc);
                 ki[u] = row * 4 + (pc ^ ((row >> 2) & 3));
@@ -463,9 +468,18 @@ bool battn_supports(const AttnArgs& a, int head_dim) {
     return head_dim == 32 && a.T >= 1 && a.T <= 640 && a.pitch >= ((a.T + 31) & ~31) && a.rows >= ((a.T + 31) & ~31) && a.v_bstride <= 0x7fffffffLL && a.o_bstride <= 0x7fffffffLL;
 }
 // q / k: bf16 [b][2 heads][rows][32] at a.qk, v: bf16 [b][heads * 32][pitch] at a.v (tokens permuted per 16: TGemmArgs::qkv_bf16), o: bf16 token-major
-void launch_battn(const AttnArgs& a, int batch, hipStream_t s) {
-    dim3 grid((((a.T + 31) / 32) + 3) / 4, a.heads, batch);
-    hipLaunchKernelGGL(battn_kernel, grid, dim3(256), 81920, s, reinterpret_cast<const unsigned short*>(a.qk), reinterpret_cast<const unsigned short*>(a.v),
+void launch_battn(const AttnArgs& a, int batch, hipStream_t s, int qt) {
+    // K: the key rows actually used; V^T: 80 pieces per row.  T = 600: 79,872 bytes — two workgroups per CU with room to spare (2 x 81,920 is the
+    // whole LDS of a CU to the byte, and measured like ONE workgroup per CU)
+    const int lds_bytes = ((((a.T + 31) / 32) * 32) * 4 + 32 * 80) * 16;
+    if (qt == 4) {
+        dim3 grid((((a.T + 31) / 32) + 3) / 4, a.heads, batch);
+        hipLaunchKernelGGL(battn_kernel<4>, grid, dim3(256), lds_bytes, s, reinterpret_cast<const unsigned short*>(a.qk), reinterpret_cast<const unsigned short*>(a.v),
+                           reinterpret_cast<unsigned short*>(a.o), (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T, a.heads, a.rows, a.scale);
+        return;
+    }
+    dim3 grid((((a.T + 31) / 32) + 7) / 8, a.heads, batch);
+    hipLaunchKernelGGL(battn_kernel<8>, grid, dim3(512), lds_bytes, s, reinterpret_cast<const unsigned short*>(a.qk), reinterpret_cast<const unsigned short*>(a.v),
                        reinterpret_cast<unsigned short*>(a.o), (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T, a.heads, a.rows, a.scale);
 }
 
@@ -484,7 +498,8 @@ static void configure_attn_one() {
                               160 * 1024);
 }
 void configure_attn_kernels() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     configure_attn_one<1, 8, false>(); configure_attn_one<1, 8, true>(); configure_attn_one<1, 4, false>(); configure_attn_one<1, 4, true>(); configure_attn_one<1, 1, false>(); configure_attn_one<1, 1, true>();
     configure_attn_one<1, 1, false, 4>(); configure_attn_one<1, 1, true, 4>(); configure_attn_one<2, 1, false, 4>(); configure_attn_one<2, 1, true, 4>();
     configure_attn_one<2, 8, false>(); configure_attn_one<2, 8, true>(); configure_attn_one<2, 4, false>(); configure_attn_one<2, 4, true>(); configure_attn_one<2, 1, false>(); configure_attn_one<2, 1, true>();

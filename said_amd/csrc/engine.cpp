@@ -159,9 +159,7 @@ struct said_ctx {
     int rgemm = -1;           // round 4: register-stationary, wave-specialised persistent GEMMs (rgemm.hip) wherever launch_rgemm serves the shape
                               // (bf16 mode: 192-wide GEMMs with K <= 576, q/k/v); 0: off (said_debug_option "rgemm")
     long long n_rgemm = 0;
-    int pgemm = 0;            // round 4: the token-major-activation GEMMs as persistent weight-stationary workgroups (pgemm.hip).  -1: wherever
-                              // launch_pgemm serves the shape (bf16 mode), 0: round 3's xgemm_kernel only (said_debug_option "pgemm")
-    long long n_pgemm = 0, n_xgemm = 0;   // launches issued through either kernel family (said_debug_get)
+    long long n_xgemm = 0;    // launches issued through round 3's xgemm_kernel (said_debug_get; n_rgemm: through rgemm_kernel)
     int xgemm_ntw = 0;        // test / measurement: column tiles per workgroup of the resident-source GEMMs (0: launch_xgemm decides)
     void *tX1 = nullptr, *tX2 = nullptr, *tO = nullptr, *tF = nullptr;   // token-major x1, x2, attention output [.][192], GEGLU product [.][768]
     bool unet_tgemm = true;   // SAID_NO_UNET_TGEMM=1 keeps the channel-major kernels in bf16 mode at every batch size
@@ -662,9 +660,8 @@ void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     a2.dbg = c->xgemm_dbg;
     if (c->xclk_on && c->dbg_count < 64) a2.clk = c->clk_dev + (long long)c->dbg_count * 128;
     if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }
-    // kernel family: 7 = rgemm_kernel (round 4: register-stationary weights, helper waves), 8 = pgemm_kernel (weight slices resident in LDS;
-    // opt-in), 6 = round 3's xgemm_kernel
-    const int fam = (c->rgemm != 0 && !a2.f32 && rgemm_supports(a2, batch)) ? 7 : ((c->pgemm != 0 && !a2.f32 && pgemm_supports(a2, batch)) ? 8 : 6);
+    // kernel family: 7 = rgemm_kernel (round 4: register-stationary weights, helper waves), 6 = round 3's xgemm_kernel
+    const int fam = (c->rgemm != 0 && !a2.f32 && rgemm_supports(a2, batch)) ? 7 : 6;
     if (c->log_on) {
         const double eb = c->bf16_mode ? 2.0 : 4.0;
         const double out_n = a.geglu ? a.N / 2 : a.N;
@@ -677,10 +674,6 @@ void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     }
     if (fam == 7) {
         if (dbg_go(c)) { launch_rgemm(a2, batch, s); ++c->n_rgemm; }
-        return;
-    }
-    if (fam == 8) {
-        if (dbg_go(c)) { launch_pgemm(a2, batch, s); ++c->n_pgemm; }
         return;
     }
     ++c->n_xgemm;
@@ -807,7 +800,7 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
         a.scale = 0.17677669529663687f;
         if (battn) {
             if (c->log_on) { const double e = (double)n1 * HEADS * HD * g.T; c->stage_log.push_back({9, -1, 1, 1, 4.0 * e * 2.0, 4.0 * e * g.T}); }
-            if (dbg_go(c)) launch_battn(a, n1, s);
+            if (dbg_go(c)) launch_battn(a, n1, s, c->battn == 4 ? 4 : 8);
         } else {
             do_attn(c, a, n1, HD, -4, s);
         }
@@ -1497,7 +1490,6 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     if (dev_env("SAID_UNET_TGEMM_MIN")) ctx->unet_tgemm_min_tokens = ctx->unet_fgemm_min_tokens = atoll(dev_env("SAID_UNET_TGEMM_MIN"));
     configure_tgemm_kernel();
     configure_xgemm_kernels();
-    configure_pgemm_kernels();
     configure_rgemm_kernels();
 
     int rc = 0;
@@ -2313,12 +2305,10 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->xgemm_dbg = (int)value;
     } else if (k == "tm_acts") {
         ctx->tm_acts = value < 0 ? -1 : (value != 0);
-    } else if (k == "pgemm") {
-        ctx->pgemm = value < 0 ? -1 : (value != 0);
     } else if (k == "rgemm") {
         ctx->rgemm = value < 0 ? -1 : (value != 0);
     } else if (k == "battn") {
-        ctx->battn = value < 0 ? -1 : (value != 0);
+        ctx->battn = value < 0 ? -1 : (int)value;   // 0: off, 4 / 8: query tiles per workgroup (experiments), else on
     } else {
         return fail(ctx, "said_debug_option: unknown option %s", name);
     }
@@ -2334,8 +2324,6 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "audio_chunk") return ctx->audio_chunk;
     if (k == "steps_per_graph") return ctx->spg_limit;
     if (k == "tm_acts") return ctx->tm_acts;
-    if (k == "pgemm") return ctx->pgemm;
-    if (k == "n_pgemm") return ctx->n_pgemm;
     if (k == "rgemm") return ctx->rgemm;
     if (k == "n_rgemm") return ctx->n_rgemm;
     if (k == "n_xgemm") return ctx->n_xgemm;

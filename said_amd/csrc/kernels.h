@@ -182,7 +182,7 @@ void configure_gemm_kernels();   // raise the dynamic-LDS limit of every instant
 void configure_attn_kernels();
 // round 4: bf16 operands (written by rgemm.hip's q/k/v epilogue), a head's K / V resident in LDS; T <= 640, head_dim 32
 bool battn_supports(const AttnArgs& a, int head_dim);
-void launch_battn(const AttnArgs& a, int batch, hipStream_t s);
+void launch_battn(const AttnArgs& a, int batch, hipStream_t s, int qt = 8);   // qt: query tiles (waves) per workgroup, 4 or 8
 
 struct SchedArgs {
     const float* eps;          // channel-major [Be][C][pitch] model output

@@ -74,7 +74,7 @@ struct TGemmArgs {
     // channels of ra[0], then of ra[1] (concatenated input) — is loaded ONCE, transformed once per element and parked in LDS;
     // only the weights stream.  k order of W for this segment: [tap][source][channel] (Conv1d weight, tap-major).
     int ntw;               // column tiles per workgroup (0: chosen by launch_xgemm)
-    int pg_s, pg_per;      // pgemm_kernel / rgemm_kernel (filled in by the launch helper): column slices (groups) of the launch, row tiles per range
+    int pg_s, pg_per;      // rgemm_kernel (filled in by the launch helper): column slices (groups) of the launch, row tiles per range
     int w_ld, w_k0, w_seg; // rgemm_kernel: the launch multiplies a COLUMN RANGE of the weight rows — row pitch (0: K), first column, distance between
                            // the 192-wide segments (taps; 0: 192) — so a long-K GEMM can run as several launches over one packed weight
     long long* clk;        // optional [4 waves][16] shader-clock stamps of workgroup 8 (-DSAID_CLK_STAMPS builds; scripts/xgemm_clocks.py)
@@ -112,10 +112,6 @@ void configure_tgemm_kernel();
 bool xgemm_supports(const TGemmArgs& a);
 bool launch_xgemm(const TGemmArgs& a, int batch, hipStream_t s);
 void configure_xgemm_kernels();
-// round 4 (pgemm.hip): the same launches as persistent weight-stationary workgroups (bf16 mode); false: not served (nothing launched)
-bool pgemm_supports(const TGemmArgs& a, int batch);
-bool launch_pgemm(const TGemmArgs& a, int batch, hipStream_t s);
-void configure_pgemm_kernels();
 // round 4 (rgemm.hip): register-stationary weights, wave-specialised persistent workgroups: the 192-wide GEMMs with K <= 576 and q/k/v (bf16 mode)
 bool rgemm_supports(const TGemmArgs& a, int batch);
 bool launch_rgemm(const TGemmArgs& a, int batch, hipStream_t s);

@@ -1,5 +1,4 @@
-// tgemm_dev.h — device code shared by the token-major GEMM kernels (tgemm.hip: tgemm / fgemm / xgemm; pgemm.hip: the persistent
-// weight-stationary GEMMs of round 4): the epilogues of one 32-row MFMA tile and the banded cross-attention of one head.
+// tgemm_dev.h — device code shared by the token-major GEMM kernels (tgemm.hip: tgemm / fgemm / xgemm; rgemm.hip: the persistent register-stationary GEMMs of round 4): the epilogues of one 32-row MFMA tile and the banded cross-attention of one head.
 #pragma once
 #include "gemm_common.h"
 #include "tgemm.h"

@@ -1,6 +1,6 @@
-"""Per-phase shader-clock stamps of the persistent GEMMs (pgemm_kernel) of one UNet evaluation, workgroup 8 of every launch.
+"""Per-phase shader-clock stamps of the persistent GEMMs (rgemm_kernel) of one UNet evaluation, workgroup 8 of every launch.
 Build with the stamp sites first:  SAID_EXTRA_DEFS=-DSAID_CLK_STAMPS python -m said_amd.build --force
-    python scripts/pgemm_clocks.py [B=32] [T=600]"""
+    python scripts/rgemm_clocks.py [B=32] [T=600]"""
 import os
 import sys
 

@@ -496,6 +496,16 @@ def test_loop_1000_steps_eta1_teacher_forced_vs_oracle(model, sd_full, dev):
     assert worst[1] <= 2e-4 and worst[10] <= 1e-3
 
 
+def test_loop_headline_length_10_step_segments_vs_oracle(model, sd_full, dev):
+    """The headline's own shape: T = 600 (10 s), guidance 2, the 1000-step schedule — 10-step segments (one replay of
+    the ten-step graph) at an early, a middle and the last position of the chain, each from latents at that step's noise level,
+    against the oracle's ten steps from the same latents.  (The 1 s chain above walks all 1000 steps; this pins the multi-step
+    replay, step counter and coefficient rows at the benchmarked length.)"""
+    worst = _teacher_forced(model, sd_full, dev, N=1000, eta=0.0, seg_lens=[10], Ta=160000, starts={10: [0, 500, 990]}, chain=False)
+    print(f"N=1000, T=600 teacher-forced 10-step segments: worst err {worst[10]:.3e}")
+    assert worst[10] <= 1e-3
+
+
 def test_loop_997_steps_remainder_graph_teacher_forced(model, sd_full, dev):
     """Prime step count: the 997-step schedule in 17-step segments = one 10-step graph + the 7-step remainder graph."""
     worst = _teacher_forced(model, sd_full, dev, N=997, eta=0.0, seg_lens=[17], Ta=8000, starts={17: [0, 300, 640, 980]}, chain=False)
