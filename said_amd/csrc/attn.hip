@@ -359,9 +359,8 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 //   S^T[j][i] = sum_d K[j][d] Q[i][d]   (A = K rows, B = Q rows: two v_mfma_f32_32x32x16_bf16)
 //   O^T[d][i] = sum_j V^T[d][j] P^T[j][i]   (A = V^T rows, B = P^T straight from the S^T accumulators: registers 8 m .. 8 m + 7 of a lane
 //   half are keys 16 m + {0-3, 8-11} + 4 lh — the order V^T's tokens are stored in, so a lane's eight keys are one 16-byte piece)
-// LDS images are unpadded with the 16-byte piece index XOR-swizzled by the row (K: piece ^ ((row >> 2) & 3), V^T: piece ^ (row & 15)):
-// conflict-free ds_read_b128 for both.  2 x 40,960 bytes = exactly half a CU's LDS: two workgroups per CU, one copying while the other
-// multiplies.  Online softmax as in attn_kernel's bf16 path (raw-score running maximum, scale folded into the exp2 argument, rescale
+// LDS images: K unpadded with the 16-byte piece index XOR-swizzled by the row (piece ^ ((row >> 2) & 3)), V^T rows padded by one piece:
+// conflict-free ds_read_b128 for both; 80 KB: two workgroups per CU, one copying while the other multiplies.  Online softmax as in attn_kernel's bf16 path (raw-score running maximum, scale folded into the exp2 argument, rescale
 // skipped while no maximum moved).  Reference semantics: ldm/attention.py:86-128.
 // QT = query tiles (= waves) per workgroup.  The key loop is one dependent chain per wave (LDS read -> MFMA -> max -> exp2 -> MFMA): with
 // four waves per workgroup and two workgroups per CU a SIMD holds two such chains and the kernel ran latency-bound (52 us); eight waves
@@ -373,7 +372,7 @@ __global__ __launch_bounds__(64 * QT, (QT == 8 ? 4 : 2)) void battn_kernel(const
     extern __shared__ __attribute__((aligned(16))) u32x4b bsm[];
     const int nkt = (T + 31) >> 5, nkr = nkt * 32;
     u32x4b* const Ks = bsm;                 // [nkr keys][4 pieces]
-    u32x4b* const Vs = bsm + nkr * 4;       // [32 channels][80 pieces]
+    u32x4b* const Vs = bsm + nkr * 4;       // [32 channels][81 pieces]: rows one piece longer than 80 -> conflict-free 16-byte reads of 16 consecutive rows
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5, w = tid >> 6;
     const int h = blockIdx.y, b = blockIdx.z, H = heads;
     constexpr int NTH = 64 * QT;
@@ -394,7 +393,7 @@ __global__ __launch_bounds__(64 * QT, (QT == 8 ? 4 : 2)) void battn_kernel(const
                 ki[u] = row * 4 + (pc ^ ((row >> 2) & 3));
                 const int d = idx / npc, p = idx - d * npc;        // (32 npc == 4 nkr: the same index range)
                 vv[u] = *reinterpret_cast<const u32x4b*>(vg + (long long)d * pitch + 8 * p);
-                vi[u] = d * 80 + (p ^ (d & 15));
+                vi[u] = d * 81 + p;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { Ks[ki[u]] = kv[u]; Vs[vi[u]] = vv[u]; }
@@ -405,20 +404,31 @@ __global__ __launch_bounds__(64 * QT, (QT == 8 ? 4 : 2)) void battn_kernel(const
     const bf16x8a q1 = __builtin_bit_cast(bf16x8a, *reinterpret_cast<const u32x4b*>(qb + 16));
     __syncthreads();
     if (i0 >= T) return;                    // (a workgroup's spare wave: it only helped with the copy)
-    float m = -1.0e30f, lsum = 0.f;
-    f32x16 o;
+    // The loop below is bound by VALU ISSUE — knock-outs on the box (profiles/r04e_battn_knockouts.txt): copy 13 us, loop 30 us = 420 clocks per
+    // key tile and SIMD, of which the 16 v_exp_f32 are 256 (a wave64 VALU instruction holds the SIMD for 4 clocks, a transcendental for 16;
+    // the six MFMAs hide behind them) — so it is written for few instructions per score:
+    //  * q arrives pre-multiplied by scale * log2(e) (the projection's epilogue, before the rounding to bf16): scores are exponents;
+    //  * the score accumulator starts at -ref (a per-query reference, lane == query), so p = exp2(acc) with no subtraction; ref is the
+    //    first tile's maximum and moves only when a later score exceeds it by more than 16 (then o and the sums are rescaled: rare);
+    //  * the row sums come from two extra MFMAs against a fragment of ones (the matrix pipe has room: 6 of ~60 instructions);
+    //  * V^T rows are padded by one 16-byte piece instead of swizzled: the fragment address advances by a constant.
+    float ref = 0.f;
+    f32x16 o, ls;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    const float c2 = scale * 1.4426950408889634f;
+    for (int r = 0; r < 16; ++r) { o[r] = 0.f; ls[r] = 0.f; }
+    const bf16x8a ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    const u32x4b* kp = Ks + lt * 4;
+    const int ksw0 = lh ^ ((lt >> 2) & 3), ksw1 = (2 + lh) ^ ((lt >> 2) & 3);   // (key rows advance by 32: the swizzle term is loop-invariant)
+    const u32x4b* vp = Vs + lt * 81 + lh;
     for (int kt = 0; kt < nkt; ++kt) {
-        const int j0 = kt * 32, jr = j0 + lt;
-        const bf16x8a k0 = __builtin_bit_cast(bf16x8a, Ks[jr * 4 + (lh ^ ((jr >> 2) & 3))]);
-        const bf16x8a k1 = __builtin_bit_cast(bf16x8a, Ks[jr * 4 + ((2 + lh) ^ ((jr >> 2) & 3))]);
-        const bf16x8a v0 = __builtin_bit_cast(bf16x8a, Vs[lt * 80 + (((j0 >> 3) + lh) ^ (lt & 15))]);
-        const bf16x8a v1 = __builtin_bit_cast(bf16x8a, Vs[lt * 80 + (((j0 >> 3) + 2 + lh) ^ (lt & 15))]);
+        const int j0 = kt * 32;
+        const bf16x8a k0 = __builtin_bit_cast(bf16x8a, kp[kt * 128 + ksw0]);
+        const bf16x8a k1 = __builtin_bit_cast(bf16x8a, kp[kt * 128 + ksw1]);
+        const bf16x8a v0 = __builtin_bit_cast(bf16x8a, vp[kt * 4]);
+        const bf16x8a v1 = __builtin_bit_cast(bf16x8a, vp[kt * 4 + 2]);
         f32x16 s;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[r] = -ref;
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0, s, 0, 0, 0);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q1, s, 0, 0, 0);
         if (j0 + 32 > T) {
@@ -428,31 +438,28 @@ __global__ __launch_bounds__(64 * QT, (QT == 8 ? 4 : 2)) void battn_kernel(const
                 s[r] = (j < T) ? s[r] : -1.0e30f;
             }
         }
-        float mx = s[0];
+        float mx = fmaxf(s[0], s[1]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        for (int r = 2; r < 16; r += 2) mx = __builtin_fmaxf(mx, __builtin_fmaxf(s[r], s[r + 1]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mn = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
-        m = mn;
-        const float off = -mn * c2;
-        float ps = 0.f;
+        const bool rebase = kt == 0 || mx > 16.0f;
+        if (__builtin_amdgcn_ballot_w64(rebase)) {
+            const float d = rebase ? mx : 0.f;             // this lane's reference moves up (or, first tile, to) by d
+            const float f = kt == 0 ? 0.f : __builtin_amdgcn_exp2f(-d);
+            ref += d;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, off));
-            ps += s[r];
+            for (int r = 0; r < 16; ++r) { s[r] -= d; o[r] *= f; ls[r] *= f; }
         }
-        lsum = lsum * alpha + ps;
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] *= alpha;
-        }
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
         const f32x4a p0 = {s[0], s[1], s[2], s[3]}, p1 = {s[4], s[5], s[6], s[7]}, p2 = {s[8], s[9], s[10], s[11]}, p3 = {s[12], s[13], s[14], s[15]};
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pk_bf16x8(p0, p1), o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pk_bf16x8(p2, p3), o, 0, 0, 0);
+        const bf16x8a pa = pk_bf16x8(p0, p1), pb = pk_bf16x8(p2, p3);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pa, o, 0, 0, 0);
+        ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pa, ls, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o, 0, 0, 0);
+        ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, ls, 0, 0, 0);
     }
-    lsum += __shfl_xor(lsum, 32);
-    const float invL = 1.0f / lsum;
+    const float invL = 1.0f / ls[0];        // (every row of the ones-product is the query's sum over all keys)
     const int i = i0 + lt;
     if (i < T) {   // registers 4 q .. 4 q + 3 are channels 8 q + 4 lh + (0 .. 3) of the head: four consecutive bf16 of the query's token-major row
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -469,9 +476,9 @@ bool battn_supports(const AttnArgs& a, int head_dim) {
 }
 // q / k: bf16 [b][2 heads][rows][32] at a.qk, v: bf16 [b][heads * 32][pitch] at a.v (tokens permuted per 16: TGemmArgs::qkv_bf16), o: bf16 token-major
 void launch_battn(const AttnArgs& a, int batch, hipStream_t s, int qt) {
-    // K: the key rows actually used; V^T: 80 pieces per row.  T = 600: 79,872 bytes — two workgroups per CU with room to spare (2 x 81,920 is the
+    // K: the key rows actually used; V^T: 81 pieces per row.  T = 600: 80,384 bytes — two workgroups per CU with room to spare (2 x 81,920 is the
     // whole LDS of a CU to the byte, and measured like ONE workgroup per CU)
-    const int lds_bytes = ((((a.T + 31) / 32) * 32) * 4 + 32 * 80) * 16;
+    const int lds_bytes = ((((a.T + 31) / 32) * 32) * 4 + 32 * 81) * 16;
     if (qt == 4) {
         dim3 grid((((a.T + 31) / 32) + 3) / 4, a.heads, batch);
         hipLaunchKernelGGL(battn_kernel<4>, grid, dim3(256), lds_bytes, s, reinterpret_cast<const unsigned short*>(a.qk), reinterpret_cast<const unsigned short*>(a.v),

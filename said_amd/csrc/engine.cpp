@@ -790,6 +790,7 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
         t.qkv_bf16 = (c->battn != 0 && c->bf16_mode && c->rgemm != 0 && battn_supports(pa, HD)) ? 1 : 0;
         if (t.qkv_bf16 && !rgemm_supports(t, n1)) t.qkv_bf16 = 0;
         battn = t.qkv_bf16 != 0;
+        t.q_scale = 0.17677669529663687f * 1.4426950408889634f;   // dim_head ** -0.5 (attention.py:101) x log2(e)
         do_xgemm(c, t, n1, s);
     }
     {   // softmax(q k^T * scale) v -> token-major   (attention.py:99-126)

@@ -314,6 +314,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
                                 for (int e = 0; e < 4; ++e) { v0[e] = x0 + e < nrows ? v0[e] : 0.f; v1[e] = x1 + e < nrows ? v1[e] : 0.f; }
                                 off = (int)(((long long)b * a.v_bs + (long long)(32 * j + row) * a.v_pitch + t0 + 8 * ec) * 2);
                             }
+                            if (ct == 0) { v0 *= a.q_scale; v1 *= a.q_scale; }
                             const u32x4 ov = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
                             __builtin_amdgcn_raw_buffer_store_b128(ov, ct < 2 ? rq : rv, off, 0, 0);
                         }
