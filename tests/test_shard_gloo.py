@@ -145,7 +145,7 @@ def _uneven_worker(rank, world, port, n_items, T, out_q):
         return torch.stack([_item_tensor(i, T) for i in ids]) if len(ids) else torch.zeros(0, T, 32)
 
     res = shard.sharded_inference(path_fn, n_items, rank=rank, world=world, dist=dist)
-    out_q.put((rank, res.clone(), seen))
+    out_q.put((rank, res.numpy().copy(), seen))          # by value: a tensor travels as a file descriptor its (exited) sender must still serve
     dist.barrier()
     dist.destroy_process_group()
 
@@ -180,5 +180,5 @@ def test_sharded_inference_uneven_equals_one_rank():
         want = shard.sharded_inference(lambda ids: torch.stack([_item_tensor(i, T) for i in ids]), n_items, rank=0, world=1)
         res = _run_uneven(world, n_items, T)
         for rank, got, seen in res:
-            assert torch.equal(got, want), (world, n_items, rank)
+            assert torch.equal(torch.from_numpy(got), want), (world, n_items, rank)
             assert seen == [list(shard.shard_bounds(n_items, world)[rank])]      # ONE call, own shard only
