@@ -82,7 +82,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stderr[-8000:])
         if "-c" in cmd:
-            check_scratch(cmd, r.stderr)
+            try:
+                check_scratch(cmd, r.stderr)
+            except RuntimeError:
+                if os.path.exists(cmd[-1]):
+                    os.remove(cmd[-1])   # a re-run must not find (and link) the object of a build that was refused
+                raise
         return r
 
     if jobs:

@@ -40,6 +40,12 @@ namespace said {
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+// Cache policy of the result stores (buffer_store aux bits: 1 = sc0, 2 = nt, 16 = sc1).  sc1 = agent scope: the 16-byte result stores are
+// written THROUGH the XCD's L2 while the launch runs instead of leaving 15 - 59 MB dirty for the write-back at its end, behind which the next
+// launch's first loads queue: 1.243 -> 1.227 / 1.263 -> 1.237 ms per step on two boxes (plain / sc1; nt: 1.266; profiles/r04g_rgemm_ab.txt).
+#ifndef SAID_RG_ST_AUX
+#define SAID_RG_ST_AUX 16
+#endif
 constexpr int RG_AP = 200;                        // A tile row pitch in elements (192 + 8: 400 bytes)
 constexpr int RG_AROWS = 34;                      // 32 tokens + 2 halo
 constexpr int RG_A_ELEMS = RG_AROWS * RG_AP;
@@ -133,6 +139,30 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 __device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
+// value * gelu(gate) for two elements at a time on packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two floats per lane
+// and issue slot).  The GEGLU launch is bound by VALU ISSUE in its MFMA waves' epilogue — 16 products per lane and tile, 19 VALU instructions
+// + 2 transcendentals each in the scalar form against 24 MFMAs — so the erf (gemm_common.h: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7)
+// is evaluated pairwise and without the copysign / 1 + erf round trip:  gelu(g) = g * (x < 0 ? q : 1 - q),  q = (p(t) / 2) t exp(-x^2),
+// x = g / sqrt(2), t = 1 / (1 + 0.3275911 |x|)  (for x < 0 the scalar form computes 1 - (1 - 2q): this one keeps q's own bits).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 geglu2(f32x2 val, f32x2 gate) {
+    const f32x2 x = gate * 0.70710678118654752440f;
+    const f32x2 ax = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+    const f32x2 one = {1.0f, 1.0f};
+    const f32x2 d = __builtin_elementwise_fma(ax, (f32x2){0.3275911f, 0.3275911f}, one);
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 p = __builtin_elementwise_fma(t, (f32x2){0.5f * 1.061405429f, 0.5f * 1.061405429f}, (f32x2){0.5f * -1.453152027f, 0.5f * -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, (f32x2){0.5f * 1.421413741f, 0.5f * 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, (f32x2){0.5f * -0.284496736f, 0.5f * -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, (f32x2){0.5f * 0.254829592f, 0.5f * 0.254829592f});
+    const f32x2 ea = (ax * ax) * -1.4426950408889634f;
+    const f32x2 e = {__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
+    const f32x2 q = (p * t) * e;
+    const f32x2 omq = one - q;
+    const f32x2 sel = {x[0] < 0.f ? q[0] : omq[0], x[1] < 0.f ? q[1] : omq[1]};
+    return (val * gate) * sel;
+}
+
 // EK: 0 token-major activation out, 1 q/k/v split (direct stores), 4 banded cross-attention (transposed product)
 // MODE: operand transform (0 raw, 1 silu(GroupNorm), 2 LayerNorm, 3 LayerNorm(GroupNorm)); RES: 0 none, 1 plain, 2 GroupNorm'ed residual;
 // DUP: second copy of the result (+ per-channel constant); STATS: GroupNorm partials of the stored values
@@ -199,6 +229,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        clk_stamp_p(a.clk, w, l, 11);              // (the weight fragments are in registers)
         float bias_n[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) bias_n[ct] = a.bias ? a.bias[(EK == 2 ? cg * 384 + 64 * j + 32 * ct : ct * 192 + 32 * j) + fr] : 0.f;
@@ -316,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
                             }
                             if (ct == 0) { v0 *= a.q_scale; v1 *= a.q_scale; }
                             const u32x4 ov = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
-                            __builtin_amdgcn_raw_buffer_store_b128(ov, ct < 2 ? rq : rv, off, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(ov, ct < 2 ? rq : rv, off, 0, SAID_RG_ST_AUX);
                         }
                     } else {
 #pragma unroll
@@ -331,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
                             for (int e = 0; e < 4; ++e) v[e] = pc4 + e < nrows ? v[e] : 0.f;
                             off = (int)(((long long)b * a.v_bs + (long long)(32 * j + row) * a.v_pitch + t0 + pc4) * 4);
                         }
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ct < 2 ? rq : rv, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ct < 2 ? rq : rv, off, 0, SAID_RG_ST_AUX);
                     }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -339,7 +370,11 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
             } else if constexpr (EK == 2) {
                 // GEGLU (ldm/attention.py:25-32): value * gelu(gate) of this wave's 32 channels, lane == channel; rows through the scratch
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + fr] = (acc[0][0][r] + bias_n[0]) * gelu_f(acc[1][0][r] + bias_n[1]);
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 pr = geglu2((f32x2){acc[0][0][r], acc[0][0][r + 1]} + bias_n[0], (f32x2){acc[1][0][r], acc[1][0][r + 1]} + bias_n[1]);
+                    ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + fr] = pr[0];
+                    ws[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh) * 36 + fr] = pr[1];
+                }
                 __builtin_amdgcn_wave_barrier();
                 const int c0 = a.geglu_c0(cg * 384 + 64 * j);
 #pragma unroll
@@ -348,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
                     const f32x4t v0 = *reinterpret_cast<const f32x4t*>(ws + row * 36 + 8 * ec);
                     const f32x4t v1 = *reinterpret_cast<const f32x4t*>(ws + row * 36 + 8 * ec + 4);
                     const u32x4 ov = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, row < nrows ? ((R0 + row) * a.ldy + c0 + 8 * ec) * 2 : (int)0x80000000, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, row < nrows ? ((R0 + row) * a.ldy + c0 + 8 * ec) * 2 : (int)0x80000000, 0, SAID_RG_ST_AUX);
                 }
                 __builtin_amdgcn_wave_barrier();
             } else if constexpr (EK == 4) {
@@ -378,13 +413,13 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
                     }
                     const u32x4 ov = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
                     const int off = on ? ((R0 + row) * a.ldy + 32 * j + 8 * ec) * 2 : (int)0x80000000;   // (out of range: the hardware drops the store)
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, off, 0, SAID_RG_ST_AUX);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(ov[e]); v[2 * e + 1] = bf_hi(ov[e]); }   // the stored values
                     if constexpr (DUP) {
                         const u32x4 o2 = {pack_bf16(v[0] + add2[0], v[1] + add2[1]), pack_bf16(v[2] + add2[2], v[3] + add2[3]),
                                           pack_bf16(v[4] + add2[4], v[5] + add2[5]), pack_bf16(v[6] + add2[6], v[7] + add2[7])};
-                        __builtin_amdgcn_raw_buffer_store_b128(o2, rsrc_y2, on ? off + (int)(a.y2_row_off * a.ldy * 2) : (int)0x80000000, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(o2, rsrc_y2, on ? off + (int)(a.y2_row_off * a.ldy * 2) : (int)0x80000000, 0, SAID_RG_ST_AUX);
                     }
                     if constexpr (STATS) {   // back into the scratch for the column sums (lane == column again)
                         const f32x4t w0 = {v[0], v[1], v[2], v[3]}, w1 = {v[4], v[5], v[6], v[7]};
@@ -417,6 +452,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
             lds_barrier();
             if (k < 3) clk_stamp_p(a.clk, w, l, 4 + 3 * k);
         }
+        clk_stamp_p(a.clk, w, l, 14);
         return;
     }
 
@@ -446,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
             const GnP gp = {a.gn_cpg, a.gn_nparts, a.M, a.gn_eps, a.gn_gamma, a.gn_beta, 192};
             const rsrc_t rp = make_rsrc(a.gn_part[0] + (long long)b * a.gn_part_bs, 192u * (unsigned)a.gn_nparts * 8u);
 #pragma unroll 1
-            for (int q = 0; q < 2; ++q) {   // (one slice at a time: 43 registers of loads; both at once spilled in the K = 576 kernels)
+            for (int q = 0; q < 2; ++q) {   // (one slice at a time: 43 registers of loads; both at once spilled in the K = 576 kernels, and all tiles at once through LDS-DMA — no registers, one round trip — measured 4 % SLOWER per step: profiles/r04g_rgemm_ab.txt)
                 GnL20 g0;
                 gn20_issue(gp, rp, 96 * hw + 48 * q, l, g0);
                 gn20_finish(gp, rp, 96 * hw + 48 * q, l, g0, gs, coefS + (b & 3) * 384);
@@ -457,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
             const GnP gp = {a.gn_cpg, a.gn_nparts, a.M, a.res_eps, a.res_gamma, a.res_beta, 192};
             const rsrc_t rp = make_rsrc(a.res_part + (long long)b * a.gn_part_bs, 192u * (unsigned)a.gn_nparts * 8u);
 #pragma unroll 1
-            for (int q = 0; q < 2; ++q) {   // (one slice at a time: 43 registers of loads; both at once spilled in the K = 576 kernels)
+            for (int q = 0; q < 2; ++q) {   // (one slice at a time: 43 registers of loads; both at once spilled in the K = 576 kernels, and all tiles at once through LDS-DMA — no registers, one round trip — measured 4 % SLOWER per step: profiles/r04g_rgemm_ab.txt)
                 GnL20 g0;
                 gn20_issue(gp, rp, 96 * hw + 48 * q, l, g0);
                 gn20_finish(gp, rp, 96 * hw + 48 * q, l, g0, gs, coefS + (4 + (b & 3)) * 384);
@@ -524,7 +560,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
                     float s2 = 0.f;
 #pragma unroll
                     for (int e = 0; e < 12; ++e) { const float d = x[e] - mu; s2 = fmaf(d, d, s2); }
-                    const float rs = 1.0f / sqrtf(row16_sum(s2) * (1.0f / 192.0f) + 1e-5f);
+                    const float rs = __builtin_amdgcn_rsqf(row16_sum(s2) * (1.0f / 192.0f) + 1e-5f);   // v_rsq_f32 (1 ulp); the IEEE 1 / sqrt sequence is ~15 VALU instructions per row
 #pragma unroll
                     for (int e = 0; e < 12; ++e) x[e] = fmaf((x[e] - mu) * rs, lg[e], lb[e]);
                 }
@@ -547,7 +583,9 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
         sample_tables(b0);
         if (b1 != b0) sample_tables(b1);
     }
+    clk_stamp_p(a.clk, w, l, 11);                  // (the first samples' tables are written)
     lds_barrier();
+    clk_stamp_p(a.clk, w, l, 12);
     park_tile(u0, 0);
     issue_tile(u0 + 1);
     lds_barrier();
@@ -564,6 +602,7 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
         lds_barrier();
         if (q < 3) clk_stamp_p(a.clk, w, l, 4 + 3 * q);
     }
+    clk_stamp_p(a.clk, w, l, 14);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------

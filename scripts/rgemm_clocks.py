@@ -38,12 +38,14 @@ for k in range(64):
     if st[6, 0] > 0:   # rgemm: MFMA wave 0 and helper wave 6 — slot 1 = prologue, then per period k = 1..3: [work, B2, work, B1]
         for wv, nm in ((0, "mfma0"), (5, "mfma5"), (6, "help0"), (7, "help1")):
             row = st[wv]
-            cols = [i for i in range(1, 12) if row[i] > 0]
+            cols = [i for i in range(1, 11) if row[i] > 0]
             parts, prev = [], row[0]
             for i in cols:
                 parts.append(f"s{i}:{int(row[i] - prev):6d}")
                 prev = row[i]
-            print(f"launch {k:2d} {nm} (+{int(row[0] - base):5d}) | " + " ".join(parts))
+            # slot 11 / 12: inside the prologue (MFMA wave: weight fragments in registers; helper: tables written / first barrier passed), slot 14: end
+            extra = " ".join(f"[s{i} at {int(row[i] - row[0]):6d}]" for i in (11, 12) if row[i] > 0)
+            print(f"launch {k:2d} {nm} (+{int(row[0] - base):5d}) | " + " ".join(parts) + " " + extra + (f" | end at {int(row[14] - base):6d}" if row[14] > 0 else ""))
         continue
     st = st[:4]
     cols = [i for i in range(1, 15) if st[0, i] > 0]

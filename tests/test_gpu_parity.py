@@ -729,25 +729,38 @@ def test_token_major_path_ragged_length(model, unet_sd, dev, T):
         assert e16 <= 2e-2
 
 
-def test_loop_large_batch_ragged_length_matches_single_clip_runs(model, dev):
-    """Guidance loop at a batch where the full-batch launches take the token-major path and the guidance-shared prefix (half
-    the samples) stays on the channel-major kernels, at a length that is not a multiple of 4 or 32: every clip must come out
-    as if run alone, in both precision modes (bf16: same rounding points, different summation order and tile shapes)."""
+def test_loop_large_batch_ragged_length_matches_single_clip_runs(model, sd_full, dev):
+    """Guidance loop at a batch where the full-batch launches take the large-batch (token-major) kernels, at a length that is not a multiple
+    of 4 or 32: every clip must come out as if run alone.  fp32: the batch against single-clip runs (same arithmetic, other tile shapes).
+    bf16: the two paths round at DIFFERENT points since round 4 (large batch: bf16 activations between the kernels and bf16 attention
+    operands; single clip: fp32 activations, bf16 multiplies), so each is held against the fp32 CPU ORACLE's two steps from the same
+    latents, and their mutual distance is only reported."""
     B, T, N = 24, 333, 2
     ctx = synth.synth_latents(130, (B, T, 768)).to(dev)
     lat = synth.synth_latents(131, (B, T, 32)).to(dev)
     wav = torch.zeros(B, T * 16000 // 60, device=dev)   # only its shape is used when the embedding is injected
-    for mode, tol in (("fp32", 5e-5), ("bf16", 6e-2)):
+    pick = (0, 11, 23)
+    refs = {i: op.inference(sd_full, wav[i:i + 1].cpu(), init_latents=lat[i:i + 1].cpu(), audio_embedding=ctx[i:i + 1].cpu(),
+                            num_inference_steps=N, guidance_scale=2.0).result for i in pick}
+    for mode, tol in (("fp32", 5e-5), ("bf16", BF16_LOOP2_MAX)):
         try:
             model.set_mfma_dtype(mode)
             big = model.inference(wav, audio_embedding=ctx, num_inference_steps=N, guidance_scale=2.0, init_latents=lat).result
-            worst = 0.0
-            for i in (0, 11, 23):
+            worst = worst_big = worst_one = 0.0
+            for i in pick:
                 one = model.inference(wav[i:i + 1], audio_embedding=ctx[i:i + 1], num_inference_steps=N, guidance_scale=2.0,
                                       init_latents=lat[i:i + 1]).result
                 assert bool(torch.isfinite(big[i]).all())
                 worst = max(worst, float((big[i:i + 1] - one).abs().max()))
+                worst_big = max(worst_big, float((big[i:i + 1].cpu() - refs[i]).abs().max()))
+                worst_one = max(worst_one, float((one.cpu() - refs[i]).abs().max()))
         finally:
             model.set_mfma_dtype("fp32")
-        print(f"{mode}: batch of {B} vs single-clip runs at T={T}: max abs diff {worst:.2e}")
-        assert worst <= tol
+        print(f"{mode}: batch of {B} at T={T}: vs single-clip runs {worst:.2e}; vs oracle: batch {worst_big:.2e}, single clip {worst_one:.2e}")
+        if mode == "fp32":
+            assert worst <= tol and worst_big <= 1e-3 and worst_one <= 1e-3
+        else:
+            assert worst_big <= tol and worst_one <= tol
+
+
+BF16_LOOP2_MAX = 0.10   # two free-running guided steps from pure noise (clamped result in [0, 1]); measured: see DESIGN.md section 7.4

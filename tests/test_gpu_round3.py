@@ -400,7 +400,9 @@ def test_token_major_activation_schedule_opt_in_vs_oracle(model, unet_sd, sd_ful
         o.set_timesteps(N)
         _, latf, _ = eng.denoise_loop(latents=lat.to(dev), context=emb.to(dev), timesteps=ts[25:26], coef=coef[25:26], prediction_type="epsilon",
                                       guidance_scale=2.0, guidance_rescale=0.0, latent_scale=1.0)
-        assert eng.graph_num_nodes() == 41
+        # fp32: 41 launches per step; bf16 (round 4): the two concatenated-input ResBlocks run as four rgemm launches each (+4) and the folded
+        # proj_out of the three non-final blocks as two (+3): 48
+        assert eng.graph_num_nodes() == (48 if mode == "bf16" else 41)
         for i in (0, 31):
             ref = _oracle_cfg_step(sd_full, lat[i:i + 1], emb[i:i + 1], int(ts[25]), o)
             e = float((latf.cpu()[i:i + 1] - ref).abs().max())
@@ -431,8 +433,8 @@ def test_clip_groups_two_streams_equal_whole_batch(model, dev, mode):
             out[g] = model.inference(proc, num_inference_steps=N, guidance_scale=2.0, eta=1.0, init_latents=lat, audio_embedding=emb,
                                      save_intermediate=True)
         G = model._pick_clip_groups(B, 2 * T)
-        assert G == (4 if mode == "bf16" else 3)             # the default at this size: 10 + 11 + 11 clips (fp32), 4 x 8 (bf16)
-        assert len(model._clones) == G - 1 and model._eng.debug_get("n_set_weight") > 0
+        assert G == (1 if mode == "bf16" else 3)             # the default at this size: 10 + 11 + 11 clips (fp32); bf16 (round 4's persistent kernels): unsplit
+        assert len(model._clones) >= max(G - 1, 1) and model._eng.debug_get("n_set_weight") > 0
         assert all(c.debug_get("n_set_weight") == model._eng.debug_get("n_set_weight") for c in model._clones)   # weights shared, never re-sent
         assert 3 <= model._eng.debug_get("pool_probed") <= 12        # the groups' streams were picked by the timing probe (engine.cpp pool_init)
         if mode == "bf16":
