@@ -208,20 +208,57 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
             const int srow = l >> 3, spc = l & 7;           // staging: lane -> (row within 8, 16-byte piece)
             u32x4* const st = reinterpret_cast<u32x4*>(ws);
             constexpr int RPC = NSEG * 3, NRND = NCT * RPC; // rounds per column tile, rounds in all
-            u32x4 v[3][4];
+            // RING register sets of raw rows: RING - 1 rounds are requested in the launch's first clocks — whatever is requested then comes back
+            // together, 8k clocks later (stamps), and every later round is another memory round trip behind it
+            constexpr int RING = NRND < 5 ? (NRND < 2 ? 2 : NRND) : 5;   // (7: the K = 576 kernels spill)
+            u32x4 v[RING][4];
             auto wload = [&](int rnd, u32x4* dst) __attribute__((always_inline)) {
                 const int ct = rnd / RPC, r4 = rnd - ct * RPC;
                 const elt_t* wbase = W + (long long)(EK == 2 ? cg * 384 + 64 * j + 32 * ct : ct * 192 + 32 * j) * w_ld + a.w_k0 + (r4 / 3) * w_seg + 64 * (r4 % 3) + 8 * spc;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const u32x4*>(wbase + (long long)(8 * q + srow) * w_ld);
             };
-            wload(0, v[0]);
-            if (NRND > 1) wload(1, v[1]);
+            // The first samples' GroupNorm (a, b) tables are made HERE, by MFMA waves 0-3 (one 48-channel slice each, all partial tiles of the slice
+            // in flight, requested before anything else of the launch), and published by the first barrier, which every wave reaches BEFORE the
+            // bulk of the weights: the helper waves park the first tile while the weights stream.  (Until round 4's stamps the two helper waves
+            // made the tables — four 48-channel slices, one memory round trip each, 11-16k clocks — then parked the first tile, 5k more, with the
+            // six MFMA waves waiting at the barrier from 8-10k on: profiles/r04g_rgemm_clocks_before.txt.)
+            constexpr bool GN_SRC_M = MODE == 1 || MODE == 3, RES_GN_M = EK == 0 && RES == 2;
+            static_assert(!(GN_SRC_M && RES_GN_M), "one table kind per launch");
+            bool w01 = false;
+            if constexpr (GN_SRC_M || RES_GN_M) {
+                if (j < 4) {
+                    const int b0 = tb / ntv, b1 = min(tb + 1, t_last) / ntv;
+#pragma unroll 1
+                    for (int bi = 0; bi < 2; ++bi) {
+                        const int b = bi ? b1 : b0;
+                        if (bi && b1 == b0) break;
+                        const GnP gp = GN_SRC_M ? GnP{a.gn_cpg, a.gn_nparts, a.M, a.gn_eps, a.gn_gamma, a.gn_beta, 192}
+                                                : GnP{a.gn_cpg, a.gn_nparts, a.M, a.res_eps, a.res_gamma, a.res_beta, 192};
+                        const rsrc_t rp = make_rsrc((GN_SRC_M ? a.gn_part[0] : a.res_part) + (long long)b * a.gn_part_bs, 192u * (unsigned)a.gn_nparts * 8u);
+                        GnL20 g0;
+                        gn20_issue(gp, rp, 48 * j, l, g0);
+                        if (!bi) {   // (behind the partials in the queue, in flight during the finish)
+#pragma unroll
+                            for (int r0 = 0; r0 < RING - 1 && r0 < NRND; ++r0) wload(r0, v[r0]);
+                            w01 = true;
+                        }
+                        gn20_finish(gp, rp, 48 * j, l, g0, ws, coefS + ((GN_SRC_M ? 0 : 4) + (b & 3)) * 384);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+            if (!w01) {
+#pragma unroll
+                for (int r0 = 0; r0 < RING - 1 && r0 < NRND; ++r0) wload(r0, v[r0]);
+            }
+            lds_barrier();                            // the tables are published; the helpers park the first tile from here on
+            clk_stamp_p(a.clk, w, l, 12);
 #pragma unroll
             for (int rnd = 0; rnd < NRND; ++rnd) {
-                if (rnd + 2 < NRND) wload(rnd + 2, v[(rnd + 2) % 3]);
+                if (rnd + RING - 1 < NRND) wload(rnd + RING - 1, v[(rnd + RING - 1) % RING]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) st[(8 * q + srow) * 9 + spc] = v[rnd % 3][q];
+                for (int q = 0; q < 4; ++q) st[(8 * q + srow) * 9 + spc] = v[rnd % RING][q];
                 __builtin_amdgcn_wave_barrier();
                 const int ct = rnd / RPC, r4 = rnd - ct * RPC;
 #pragma unroll
@@ -243,7 +280,6 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
         const rsrc_t rsrc_y = make_rsrc(EK == 0 ? a.y_tm : (EK == 2 ? a.yb : (void*)a.w), 0x7ffffff0u);
         const rsrc_t rsrc_y2 = make_rsrc((EK == 0 && DUP) ? a.y2_tm : (void*)a.w, 0x7ffffff0u);
         clk_stamp_p(a.clk, w, l, 0);
-        lds_barrier();                            // (the helpers' coefficient tables of the first samples are published)
         lds_barrier();                            // the first tile is parked
         clk_stamp_p(a.clk, w, l, 1);
         for (int k = 0; k < n; ++k) {
@@ -578,13 +614,8 @@ __global__ __launch_bounds__(512, 2) void rgemm_kernel(const TGemmArgs a) {
     clk_stamp_p(a.clk, w, l, 0);
     const int u0 = tb * NCH;
     issue_tile(u0);
-    if constexpr (TABLES) {
-        const int b0 = tb / ntv, b1 = min(tb + 1, t_last) / ntv;
-        sample_tables(b0);
-        if (b1 != b0) sample_tables(b1);
-    }
-    clk_stamp_p(a.clk, w, l, 11);                  // (the first samples' tables are written)
-    lds_barrier();
+    clk_stamp_p(a.clk, w, l, 11);
+    lds_barrier();                                 // (the tables of the first two tiles' samples: MFMA waves 0-3)
     clk_stamp_p(a.clk, w, l, 12);
     park_tile(u0, 0);
     issue_tile(u0 + 1);
