@@ -583,6 +583,7 @@ void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hi
 bool use_tg(said_ctx* c, const UGeo& g, int nsamples) {
     // (the token-major kernels address their operands with 32-bit element offsets: beyond that the channel-major kernels run)
     const long long widest = ((long long)nsamples * rup(g.T + 2, 32) + 2) * FFI;
+    if (c->band_wmax > 8) return false;   // wide alignment windows: the channel-major schedule (its generic band kernel)
     return (c->bf16_mode ? c->unet_tgemm : c->unet_fgemm) && !c->clk_on && widest < 0x7fffffffLL &&
            (long long)nsamples * g.T >= (c->bf16_mode ? c->unet_tgemm_min_tokens : (c->cur_concurrent ? std::min(c->unet_fgemm_min_tokens, c->unet_fgemm_min_concurrent) : c->unet_fgemm_min_tokens));
 }
@@ -1152,6 +1153,14 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.band.v = c->KV + (long long)(blk * 2 * MC + MC) * g.Sp + (long long)kv_off * kvbs;
         a.band.kv_bstride = kvbs; a.band.kv_pitch = g.Sp;
         a.band.lo = c->band_lo; a.band.hi = c->band_hi; a.band.wmax = c->band_wmax; a.band.scale = 0.17677669529663687f;
+        if (c->band_wmax > 8) {   // windows wider than the fused epilogue's eight keys (S >> T through SAID.forward): plain q projection, then the
+                                  // generic band kernel in place (misc.hip; never on SAID.inference's path)
+            const BandArgs bd = a.band;
+            memset(&a.band, 0, sizeof a.band);
+            do_gemm(c, a, EPI_STORE, n2, 1, 8, s);
+            if (c->log_on) c->stage_log.push_back({5, -2, 0, 0, 0.0, 0.0});
+            if (dbg_go(c)) launch_band_wide(a.y, obs, g.Tp, bd.k, bd.v, bd.kv_bstride, bd.kv_pitch, bd.lo, bd.hi, g.T, HEADS, n2, bd.scale, s);
+        } else
         do_gemm(c, a, EPI_BAND, n2, 1, big ? 4 : 8, s);
     }
     {   // x2 = to_out(attn2) + x1   (conditional half only under guidance: its slots are [Bc, 2 Bc) of X2)
@@ -1359,7 +1368,6 @@ int set_band(said_ctx* ctx, int T, int S, hipStream_t s) {
         wmax = std::max(wmax, b - a);
         if (b <= a) return fail(ctx, "empty alignment window at query %d (T=%d, S=%d)", i, T, S);
     }
-    if (wmax > 8) return fail(ctx, "alignment window of %d keys exceeds the kernel limit of 8 (T=%d, S=%d)", wmax, T, S);
     // work queued earlier on the caller's stream may still read the previous tables: drain it before they change
     // (only happens when the clip length changes)
     HIPCHK(hipStreamSynchronize(s));

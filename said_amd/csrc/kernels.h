@@ -182,6 +182,9 @@ void configure_gemm_kernels();   // raise the dynamic-LDS limit of every instant
 void configure_attn_kernels();
 // round 4: bf16 operands (written by rgemm.hip's q/k/v epilogue), a head's K / V resident in LDS; T <= 640, head_dim 32
 bool battn_supports(const AttnArgs& a, int head_dim);
+// banded cross-attention over alignment windows of any width, q / o in place (misc.hip: band_wide_kernel)
+void launch_band_wide(float* qo, long long qo_bstride, int pitch, const float* k, const float* v, long long kv_bstride, int kv_pitch, const int* lo,
+                      const int* hi, int T, int heads, int batch, float scale, hipStream_t s);
 void launch_battn(const AttnArgs& a, int batch, hipStream_t s, int qt = 8);   // qt: query tiles (waves) per workgroup, 4 or 8
 
 struct SchedArgs {

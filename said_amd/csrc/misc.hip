@@ -607,4 +607,42 @@ void launch_layernorm_cm(const float* x, const float* add, float* y, const float
     hipLaunchKernelGGL(layernorm_cm_kernel, grid, dim3(256), smem, s, x, add, y, gamma, beta, C, T, pitch, bstride, eps);
 }
 
+
+// ---- banded cross-attention for alignment windows wider than the fused epilogue's eight keys (S >> T through SAID.forward; ldm/attention.py:170-191
+// handles any (T, S)).  Never reached by SAID.inference (audio features are interpolated to one token per frame: windows of <= 3 keys), so
+// this path is written for correctness, not speed: one lane = one query of one head, q / o in place in a channel-major [C][pitch] tile,
+// keys lo[t] .. hi[t] - 1 walked with an online softmax (scale after q k^T as attention.py:101, masked keys simply absent: their
+// softmax weight in the reference is exp(-finfo.max - max) = 0).
+__global__ __launch_bounds__(64) void band_wide_kernel(float* qo, long long qo_bstride, int pitch, const float* kk, const float* vv, long long kv_bstride,
+                                                       int kv_pitch, const int* lo, const int* hi, int T, float scale) {
+    const int t = blockIdx.x * 64 + threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    float* q = qo + (long long)b * qo_bstride + (long long)(h * 32) * pitch + t;
+    const float* kb = kk + (long long)b * kv_bstride + (long long)(h * 32) * kv_pitch;
+    const float* vb = vv + (long long)b * kv_bstride + (long long)(h * 32) * kv_pitch;
+    float qv[32], o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) { qv[d] = q[(long long)d * pitch]; o[d] = 0.f; }
+    float m = -3.0e38f, lsum = 0.f;
+    for (int j = lo[t]; j < hi[t]; ++j) {
+        float sdot = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) sdot = fmaf(qv[d], kb[(long long)d * kv_pitch + j], sdot);
+        sdot *= scale;
+        const float mn = fmaxf(m, sdot);
+        const float f = __expf(m - mn), pj = __expf(sdot - mn);
+        lsum = lsum * f + pj;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = fmaf(pj, vb[(long long)d * kv_pitch + j], o[d] * f);
+        m = mn;
+    }
+    const float inv = 1.0f / lsum;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) q[(long long)d * pitch] = o[d] * inv;
+}
+void launch_band_wide(float* qo, long long qo_bstride, int pitch, const float* k, const float* v, long long kv_bstride, int kv_pitch, const int* lo,
+                      const int* hi, int T, int heads, int batch, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(band_wide_kernel, dim3((T + 63) / 64, heads, batch), dim3(64), 0, s, qo, qo_bstride, pitch, k, v, kv_bstride, kv_pitch, lo, hi, T, scale);
+}
+
 }  // namespace said

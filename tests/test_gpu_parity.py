@@ -77,11 +77,12 @@ def test_unet_forward_context_length_differs(golden, model, dev):
 
 
 @pytest.mark.parametrize("B,T,S", [(1, 7, 10), (1, 31, 31), (3, 33, 33), (2, 65, 50), (1, 100, 77), (5, 96, 96), (4, 160, 201),
-                                   (9, 64, 64)])
+                                   (9, 64, 64), (2, 10, 100), (3, 37, 400), (1, 5, 333)])
 def test_unet_forward_ragged_shapes_vs_oracle(model, unet_sd, dev, B, T, S):
     """Frame counts that are not multiples of the 32-token tile, fewer frames than one tile, context lengths shorter and
-    longer than the frame count (general alignment windows), odd batch sizes, and the batch sizes at which the tile
-    shapes change (NB=1 -> 2 at 64 token tiles)."""
+    longer than the frame count (general alignment windows — the last three cases have windows of 12, 13 and 69 keys: wider than the
+    eight the fused band epilogue holds, served by the generic band kernel since round 4), odd batch sizes, and the batch sizes at
+    which the tile shapes change (NB=1 -> 2 at 64 token tiles)."""
     x = synth.synth_latents(300 + T, (B, T, 32))
     c = synth.synth_latents(400 + S, (B, S, 768))
     ts = (torch.arange(B) * 137 + 11) % 1000
@@ -592,7 +593,7 @@ def test_bf16_loop_50_steps_teacher_forced_vs_fp32_oracle(model, sd_full, dev):
     assert worst[1] <= BF16_STEP_MAX
 
 
-BF16_STEP_MAX = 0.13   # 3x the measured 4.3e-2 (worst of the 50 teacher-forced steps; the early steps divide by sqrt(alpha_bar) ~ 1e-2)
+BF16_STEP_MAX = 0.087  # 1.3x the worst measured teacher-forced bf16 step (6.2e-2: the B = 32 guided step at t = 980 of test_gpu_round3.py; the 50-step chain here: 4.3e-2)
 
 
 def test_two_contexts_in_one_process(model, unet_sd, dev):
@@ -630,7 +631,7 @@ def test_pred_original_sample_broadcasts_single_timestep(model, dev):
 
 
 # ---------------------------------------------------------------- bf16 audio encoder (configs[2]; tgemm.hip)
-BF16_AUDIO_TOL = 0.11   # 3x the measured 2.9e-2 (1 s) .. 3.5e-2 (10 s) max abs error on values up to 3.8; rms relative error measured 8e-3
+BF16_AUDIO_TOL = 0.048   # 1.3x the measured 2.8e-2 (1 s) .. 3.7e-2 (10 s, 32 clips) max abs error on values up to 3.8; rms relative error measured 8e-3
 
 
 @pytest.mark.parametrize("Ta,frames", [(16000, 60), (160000, 600)])
@@ -653,7 +654,7 @@ def test_bf16_audio_encoder_vs_fp32_oracle(model, w2v_sd, dev, Ta, frames):
     print(f"bf16 audio encoder {Ta / 16000:g} s: max abs err {float(e.max()):.3e} (|ref| max {float(ref.abs().max()):.2f}), rms rel {rms:.3e}")
     assert b16.shape == ref.shape and torch.isfinite(b16).all()
     assert not torch.equal(b16, f32)
-    assert float(e.max()) <= BF16_AUDIO_TOL and rms <= 5e-2
+    assert float(e.max()) <= BF16_AUDIO_TOL and rms <= 1.2e-2
 
 
 def test_bf16_unet_large_batch_token_major_gemm_path(model, unet_sd, dev):
@@ -763,4 +764,4 @@ def test_loop_large_batch_ragged_length_matches_single_clip_runs(model, sd_full,
             assert worst_big <= tol and worst_one <= tol
 
 
-BF16_LOOP2_MAX = 0.10   # two free-running guided steps from pure noise (clamped result in [0, 1]); measured: see DESIGN.md section 7.4
+BF16_LOOP2_MAX = 0.09   # two free-running guided steps from pure noise (clamped result in [0, 1]); 1.35x the measured 6.6e-2 (batch) / 4.4e-2 (single clip)

@@ -24,8 +24,8 @@ torch.set_grad_enabled(False)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 AUDIO_TOL = 4e-6          # x max(1, |ref|max): the B = 1 bound of test_gpu_parity.py
-BF16_AUDIO_TOL = 0.11     # the B = 1 bf16 bound of test_gpu_parity.py
-BF16_STEP_MAX = 0.13      # teacher-forced bf16 single step, as in test_gpu_parity.py
+BF16_AUDIO_TOL = 0.048    # the bf16 bound of test_gpu_parity.py (1.3x the measured 3.7e-2)
+BF16_STEP_MAX = 0.087     # teacher-forced bf16 single step, as in test_gpu_parity.py (1.3x the measured 6.2e-2)
 
 
 @pytest.fixture(scope="module")
@@ -83,7 +83,7 @@ def test_audio_encoder_batch32_10s_vs_oracle_both_precisions(model, w2v_sd, dev)
         rms16 = float((b16[i] - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
         print(f"audio B=32 clip {i}: fp32 max abs err {e32:.3e}, bf16 {e16:.3e} (rms rel {rms16:.3e}), |ref| max {float(ref.abs().max()):.2f}")
         assert e32 <= AUDIO_TOL * max(1.0, float(ref.abs().max()))
-        assert e16 <= BF16_AUDIO_TOL and rms16 <= 5e-2
+        assert e16 <= BF16_AUDIO_TOL and rms16 <= 1.2e-2
 
 
 @pytest.mark.parametrize("B,Ta", [(1, 16000), (3, 12345), (4, 160000)])

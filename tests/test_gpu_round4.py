@@ -1,0 +1,93 @@
+"""Round-4 GPU tests: a distribution-level statement for bf16 mode (free-running chains of this random-weight network are chaotic, so
+sample-wise end-to-end bounds do not exist: DESIGN.md section 7.4 — an ENSEMBLE bound does), and alignment windows wider than the fused band
+epilogue's eight keys on the large-batch shapes.  All through the C ABI."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import unet as ou  # noqa: E402
+from said_amd.util import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    from said_amd.model.diffusion import SAID_UNet1D
+    m = SAID_UNet1D()
+    m.load_state_dict(synth.said_state_dict(), strict=True)
+    m.to(dev).eval()
+    return m
+
+
+# bounds of the ensemble statement (asserted below, quoted in DESIGN.md 7.4 / 7.6); measured values are printed by the test
+ENS_MEAN_ABS = 2.5e-3     # |per-channel mean(bf16) - mean(fp32)| over 64 clips x 600 frames, result clamped to [0, 1]
+ENS_STD_REL = 0.006      # relative difference of the per-channel standard deviation
+ENS_DIFF_STD_REL = 0.008  # ... of the standard deviation of the temporal difference r[t + 1] - r[t] (the jitter an animator would see)
+
+
+def test_bf16_ensemble_statistics_match_fp32_64_clips_50_steps(model, dev):
+    """BASELINE configs[2]'s chain (50 DDIM steps, guidance 2) on 64 clips x 10 s, free-running, once in fp32 mode and once in bf16 mode from
+    the same start noise and conditioning.  Individual samples differ (chaos amplifies bf16's rounding: printed), the ENSEMBLE does not:
+    per blendshape channel, the mean and the standard deviation of the clamped result over all clips and frames, and the standard deviation
+    of its temporal difference, agree within the bounds above; and the paired per-clip mean difference shows no systematic offset beyond
+    four standard errors."""
+    B, T, N = 64, 600, 50
+    ctx = synth.synth_latents(700, (B, T, 768)).to(dev)
+    lat = synth.synth_latents(701, (B, T, 32)).to(dev)
+    wav = torch.zeros(B, T * 16000 // 60, device=dev)
+    out = {}
+    try:
+        for mode in ("fp32", "bf16"):
+            model.set_mfma_dtype(mode)
+            out[mode] = model.inference(wav, audio_embedding=ctx, num_inference_steps=N, guidance_scale=2.0, init_latents=lat).result.double().cpu()
+    finally:
+        model.set_mfma_dtype("fp32")
+    a, b = out["fp32"], out["bf16"]
+    assert torch.isfinite(b).all() and float(b.min()) >= 0 and float(b.max()) <= 1
+    sample = (a - b).abs()
+    m32, m16 = a.mean((0, 1)), b.mean((0, 1))
+    s32, s16 = a.std((0, 1)), b.std((0, 1))
+    d32, d16 = (a[:, 1:] - a[:, :-1]).std((0, 1)), (b[:, 1:] - b[:, :-1]).std((0, 1))
+    clip_delta = b.mean(1) - a.mean(1)                               # (B, 32) paired per-clip differences
+    se = clip_delta.std(0) / B ** 0.5
+    z = (clip_delta.mean(0).abs() / se.clamp_min(1e-12))
+    dm = float((m16 - m32).abs().max())
+    ds = float(((s16 - s32).abs() / s32.clamp_min(1e-6)).max())
+    dd = float(((d16 - d32).abs() / d32.clamp_min(1e-6)).max())
+    print(f"bf16 vs fp32, 64 clips x 600 frames x 50 steps: sample-wise max |diff| {float(sample.max()):.3f} mean {float(sample.mean()):.4f}; "
+          f"per-channel mean diff max {dm:.2e} (means {float(m32.min()):.3f}..{float(m32.max()):.3f}), std rel diff max {ds:.2e}, "
+          f"temporal-difference std rel diff max {dd:.2e}, paired z max {float(z.max()):.2f}")
+    assert dm <= ENS_MEAN_ABS and ds <= ENS_STD_REL and dd <= ENS_DIFF_STD_REL
+    assert float(z.max()) <= 4.0 or dm <= 1e-3
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_wide_alignment_windows_at_large_batch(model, unet_sd, dev, mode):
+    """S >> T at a batch that would take the token-major GEMM schedules (32 x 333 = 10656 tokens): windows of 9 keys — one more than the
+    fused band epilogue holds — send the whole evaluation through the channel-major schedule and the generic band kernel
+    (ldm/attention.py:170-189 accepts any (T, S); rounds 1-3 returned an error here)."""
+    B, T, S = 32, 333, 2331        # ratio 7: windows of 9 keys
+    x = synth.synth_latents(810, (B, T, 32))
+    c = synth.synth_latents(811, (B, S, 768))
+    ts = (torch.arange(B) * 37 + 5) % 1000
+    try:
+        model.set_mfma_dtype(mode)
+        out = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+    finally:
+        model.set_mfma_dtype("fp32")
+    for i in (0, 31):
+        ref = ou.unet1d_forward(unet_sd, x[i:i + 1], ts[i:i + 1], c[i:i + 1])
+        e = float((out[i:i + 1] - ref).abs().max()) / float(ref.abs().max())
+        print(f"wide windows {mode} sample {i}: {e:.2e} of range vs oracle")
+        assert e <= (1e-4 if mode == "fp32" else 2e-2)
