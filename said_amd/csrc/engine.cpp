@@ -76,6 +76,7 @@ struct said_ctx {
     bool finalized = false, has_audio = false, has_audio_proj = false;
     bool is_clone = false;           // said_clone: the packed weights and tables belong to the parent context
     int w2v_layers = 0;
+    long long n_audio_clips = 0;   // clips encoded by said_audio_encode so far (tests: identical rows of a batch are encoded once)
     int n_set_weight = 0;   // said_set_weight calls so far (tests: capacity growth must not re-upload the weights)
     int w2v_kernel[7] = {0}, w2v_stride[7] = {5, 2, 2, 2, 2, 2, 2};
 
@@ -2329,6 +2330,7 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (!ctx || !name) return -1;
     const std::string k = name;
     if (k == "n_set_weight") return ctx->n_set_weight;
+    if (k == "n_audio_clips") return (int)ctx->n_audio_clips;
     if (k == "unet_tgemm_min_tokens") return ctx->bf16_mode ? ctx->unet_tgemm_min_tokens : ctx->unet_fgemm_min_tokens;
     if (k == "audio_chunk") return ctx->audio_chunk;
     if (k == "steps_per_graph") return ctx->spg_limit;
@@ -2477,6 +2479,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
     if (!ctx->has_audio) return fail(ctx, "audio_encoder.* weights were not loaded");
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
+    ctx->n_audio_clips += B;
     int L[7];
     {
         int len = Ta;

@@ -593,7 +593,7 @@ def test_bf16_loop_50_steps_teacher_forced_vs_fp32_oracle(model, sd_full, dev):
     assert worst[1] <= BF16_STEP_MAX
 
 
-BF16_STEP_MAX = 0.087  # 1.3x the worst measured teacher-forced bf16 step (6.2e-2: the B = 32 guided step at t = 980 of test_gpu_round3.py; the 50-step chain here: 4.3e-2)
+BF16_STEP_MAX = 0.087  # 1.3x the worst measured teacher-forced bf16 step (6.7e-2: the B = 32 guided step at t = 980 of test_gpu_round3.py; the 50-step chain here: 4.3e-2)
 
 
 def test_two_contexts_in_one_process(model, unet_sd, dev):

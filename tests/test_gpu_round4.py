@@ -91,3 +91,22 @@ def test_wide_alignment_windows_at_large_batch(model, unet_sd, dev, mode):
         e = float((out[i:i + 1] - ref).abs().max()) / float(ref.abs().max())
         print(f"wide windows {mode} sample {i}: {e:.2e} of range vs oracle")
         assert e <= (1e-4 if mode == "fp32" else 2e-2)
+
+
+def test_inference_encodes_identical_clips_once(model, dev):
+    """The reference's batched caller passes one clip repeated (script/test_inference.py:167-168): SAID.inference encodes distinct rows once
+    and gathers.  Same result as encoding every row (fp32: bit for bit), at a third of the calls' audio time for 2 distinct clips of 6."""
+    from oracle import pipeline as op
+    Ta, T, N = 16000, 60, 4
+    w = op.process_audio([synth.synth_waveform(900 + i, Ta).numpy() for i in range(2)]).to(dev)
+    wav = w[[0, 1, 0, 0, 1, 0]].contiguous()
+    lat = synth.synth_latents(901, (6, T, 32)).to(dev)
+    res = {}
+    for dd in (True, False):
+        model.dedupe_audio = dd
+        n0 = model._eng.debug_get("n_audio_clips") if model._eng is not None else 0
+        res[dd] = model.inference(wav, num_inference_steps=N, guidance_scale=2.0, init_latents=lat).result
+        res[(dd, "clips")] = model._eng.debug_get("n_audio_clips") - n0
+    model.dedupe_audio = True
+    assert torch.equal(res[True], res[False])
+    assert res[(True, "clips")] == 2 and res[(False, "clips")] == 6
