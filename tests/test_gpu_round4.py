@@ -95,7 +95,8 @@ def test_wide_alignment_windows_at_large_batch(model, unet_sd, dev, mode):
 
 def test_inference_encodes_identical_clips_once(model, dev):
     """The reference's batched caller passes one clip repeated (script/test_inference.py:167-168): SAID.inference encodes distinct rows once
-    and gathers.  Same result as encoding every row (fp32: bit for bit), at a third of the calls' audio time for 2 distinct clips of 6."""
+    and gathers.  Same features up to the summation order of the encoder's GEMM tiles, which are chosen by launch size (2 clips vs 6): the
+    4-step results agree to 1e-4; two of the six clips are encoded."""
     from oracle import pipeline as op
     Ta, T, N = 16000, 60, 4
     w = op.process_audio([synth.synth_waveform(900 + i, Ta).numpy() for i in range(2)]).to(dev)
@@ -108,5 +109,7 @@ def test_inference_encodes_identical_clips_once(model, dev):
         res[dd] = model.inference(wav, num_inference_steps=N, guidance_scale=2.0, init_latents=lat).result
         res[(dd, "clips")] = model._eng.debug_get("n_audio_clips") - n0
     model.dedupe_audio = True
-    assert torch.equal(res[True], res[False])
+    d = float((res[True] - res[False]).abs().max())
+    print(f"identical clips encoded once vs every row: max |diff| of the 4-step result {d:.2e}")
+    assert d <= 1e-4
     assert res[(True, "clips")] == 2 and res[(False, "clips")] == 6
