@@ -509,7 +509,6 @@ void configure_attn_kernels() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     configure_attn_one<1, 8, false>(); configure_attn_one<1, 8, true>(); configure_attn_one<1, 4, false>(); configure_attn_one<1, 4, true>(); configure_attn_one<1, 1, false>(); configure_attn_one<1, 1, true>();
     configure_attn_one<1, 1, false, 4>(); configure_attn_one<1, 1, true, 4>(); configure_attn_one<2, 1, false, 4>(); configure_attn_one<2, 1, true, 4>();
-    configure_attn_one<1, 1, false, 2>(); configure_attn_one<1, 1, true, 2>(); configure_attn_one<1, 1, false, 3>(); configure_attn_one<1, 1, true, 3>();
     configure_attn_one<2, 8, false>(); configure_attn_one<2, 8, true>(); configure_attn_one<2, 4, false>(); configure_attn_one<2, 4, true>(); configure_attn_one<2, 1, false>(); configure_attn_one<2, 1, true>();
 }
 
@@ -518,10 +517,6 @@ void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t
         if (head_dim == 32) return bf16 ? launch_attn_one<1, 1, true, 4>(a, batch, s) : launch_attn_one<1, 1, false, 4>(a, batch, s);
         if (head_dim == 64) return bf16 ? launch_attn_one<2, 1, true, 4>(a, batch, s) : launch_attn_one<2, 1, false, 4>(a, batch, s);
     }
-    // two / three query tiles per workgroup sharing the K / V tiles in LDS: launches of a few hundred (head, tile) pairs, where that is one
-    // workgroup per CU (engine.cpp picks: T = 1800, 2 samples: 684 pairs -> 228 workgroups of three)
-    if (head_dim == 32 && KS == -2) return bf16 ? launch_attn_one<1, 1, true, 2>(a, batch, s) : launch_attn_one<1, 1, false, 2>(a, batch, s);
-    if (head_dim == 32 && KS == -3) return bf16 ? launch_attn_one<1, 1, true, 3>(a, batch, s) : launch_attn_one<1, 1, false, 3>(a, batch, s);
     if (head_dim == 32 && KS == 8) return bf16 ? launch_attn_one<1, 8, true>(a, batch, s) : launch_attn_one<1, 8, false>(a, batch, s);
     if (head_dim == 32 && KS == 4) return bf16 ? launch_attn_one<1, 4, true>(a, batch, s) : launch_attn_one<1, 4, false>(a, batch, s);
     if (head_dim == 32 && KS == 1) return bf16 ? launch_attn_one<1, 1, true>(a, batch, s) : launch_attn_one<1, 1, false>(a, batch, s);

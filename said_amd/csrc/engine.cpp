@@ -145,7 +145,6 @@ struct said_ctx {
     int tm_acts = -1;         // large batches: token-major activations BETWEEN the UNet kernels, operand transforms inside the GEMMs (round 3: 41
                               // launches per step, no preparation kernels).  -1 = by precision mode: ON in bf16 mode (1.774 vs 1.841 ms per step at
                               // 32 clips once its kernels stopped spilling), off in fp32 mode (4.78 vs 4.41); 0 / 1 force it (said_debug_option "tm_acts")
-    int attn_qw = -1;         // query tiles per self-attention workgroup at small batch (said_debug_option "attn_qw"): -1 by the rule in run_transformer, 0 never, 2-4 forced
     bool mt_mid = true;       // multi-tile workgroups for mid-size launches too (said_debug_option "mt_mid")
     int mt_wgs = 0;           // > 0: multi-tile workgroups from this many workgroups per token tile on (said_debug_option "mt_wgs"; default 1024)
     int tgemm_sb = 1;         // audio encoder (bf16): the single-LDS-buffer 128 x 128 GEMM variant, three workgroups per CU (said_debug_option "tgemm_sb"; 0: double buffer, two per CU)
@@ -1115,22 +1114,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         // tile (T <= 256); from there 4 waves with ~5 tiles each merge half as many partial states (B=1: -0.5 % per step)
         // large batches: four query tiles per workgroup sharing each K / V tile through the CU's L1 (-4), see attn.hip
         static const bool no_qw = dev_env("SAID_NO_ATTN_QW") != nullptr;
-        int attn_ks = (!no_qw && tt1 * HEADS >= 2048) ? -4 : ((tt1 * HEADS > 8192) ? 1 : ((g.T <= 256 && tt1 * HEADS <= 2048) ? 8 : 4));
-        if (attn_ks > 0 && c->attn_qw != 0) {
-            // Mid-size launches (round 4; configs[4]: T = 1800, two samples = 684 (head, tile) pairs): the key-split workgroups re-read all
-            // of a head's K / V from L2 once per 32 queries (4.6x the algorithmic traffic, 2.67 workgroups per CU).  QW query tiles per
-            // workgroup share each K / V tile through LDS; QW is the value that leaves the fewest rounds x tiles per workgroup.
-            int best = 0; long long best_cost = 0;
-            const int tiles = (g.T + 31) / 32;
-            for (int qw = 2; qw <= 4; ++qw) {
-                const long long wgs = (long long)((tiles + qw - 1) / qw) * HEADS * n1;
-                const long long cost = ((wgs + 255) / 256) * qw;
-                if (!best || cost < best_cost) { best = qw; best_cost = cost; }
-            }
-            const long long pairs = (long long)tiles * HEADS * n1;
-            if (c->attn_qw > 0) attn_ks = -c->attn_qw;
-            else if (pairs > 300 && g.T > 640) attn_ks = -best;   // (above one workgroup per CU; T <= 640: five key tiles per wave, the key split wins)
-        }
+        const int attn_ks = (!no_qw && tt1 * HEADS >= 2048) ? -4 : ((tt1 * HEADS > 8192) ? 1 : ((g.T <= 256 && tt1 * HEADS <= 2048) ? 8 : 4));
         if (out1_tm && !attn_ks_env && attn_ks == -4) { a.o = static_cast<float*>(c->uPL); a.o_bstride = tg_rows(g); a.o_mode = 1; }
         do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s);
         out1_done = a.o_mode == 1;
@@ -2308,8 +2292,6 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->hybrid = value != 0;
     } else if (k == "hybrid_f32") {
         ctx->hybrid_f32 = value != 0;
-    } else if (k == "attn_qw") {
-        ctx->attn_qw = (int)value;
     } else if (k == "mt_mid") {
         ctx->mt_mid = value != 0;
     } else if (k == "mt_wgs") {

@@ -1573,7 +1573,7 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(const PrepArgs a) {   // f
                 o[k] = tv ? x : 0.f;
                 r[k] = raw;
             }
-            st16(reinterpret_cast<float*>(a.dst) + (long long)b * a.dst_bs + (long long)(t + row_off) * a.ldd + a.coff + c0, o);
+            *reinterpret_cast<f32x4t*>(reinterpret_cast<float*>(a.dst) + (long long)b * a.dst_bs + (long long)(t + row_off) * a.ldd + a.coff + c0) = o;
             if (a.dst2 && tv)   // raw copy (1x1 skip conv over the ResBlock input; x2 for the folded proj_out)
                 *reinterpret_cast<f32x4t*>(reinterpret_cast<float*>(a.dst2) + (long long)b * a.dst2_bs + (long long)t * a.ldd2 + a.coff2 + c0) = r;
         }

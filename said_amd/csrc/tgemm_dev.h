@@ -8,15 +8,6 @@ namespace said {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4t __attribute__((ext_vector_type(4)));
-// 16-byte result store; -DSAID_TG_ST_SC1: agent scope = written through the XCD's L2 (rgemm.hip's SAID_RG_ST_AUX experiment on the round-2/3 kernels)
-template <class V> __device__ __forceinline__ void st16(void* p, V v) {
-    static_assert(sizeof(V) == 16, "16-byte store");
-#ifdef SAID_TG_ST_SC1
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#else
-    *reinterpret_cast<V*>(p) = v;
-#endif
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Epilogues shared by the two tile shapes, one 32-row tile of a wave at a time.
@@ -130,11 +121,11 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
 #pragma unroll
                 for (int e = 1; e < 4; ++e) v4[e] = (m + e < a.M) ? v4[e] : 0.f;
                 const float4 o = make_float4(v4[0], v4[1], v4[2], v4[3]);
-                st16(ybase + (long long)n * pitch + m, __builtin_bit_cast(f32x4t, o));
+                *reinterpret_cast<float4*>(ybase + (long long)n * pitch + m) = o;
                 if (a.y2_cm) {
                     const float ad = a.y2_add_cm ? a.y2_add_cm[n] : 0.f;
-                    st16(a.y2_cm + (long long)b * a.y2_bs + (long long)n * pitch + m,
-                         (f32x4t){v4[0] + ad, (m + 1 < a.M) ? v4[1] + ad : 0.f, (m + 2 < a.M) ? v4[2] + ad : 0.f, (m + 3 < a.M) ? v4[3] + ad : 0.f});
+                    *reinterpret_cast<float4*>(a.y2_cm + (long long)b * a.y2_bs + (long long)n * pitch + m) =
+                        make_float4(v4[0] + ad, (m + 1 < a.M) ? v4[1] + ad : 0.f, (m + 2 < a.M) ? v4[2] + ad : 0.f, (m + 3 < a.M) ? v4[3] + ad : 0.f);
                 }
             }
             if (a.stats) {   // Welford partial of channel n over this 32-token tile: reduce over the row's 8 lanes
@@ -189,9 +180,9 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
             }
             if (a.qk) {   // q / k heads token-major [b][2 heads][rows][head_dim]; head_dim % 4 == 0
                 const int h = n / a.head_dim, d = n - h * a.head_dim;
-                st16(a.qk + (((long long)b * a.heads2 + h) * a.rows + m) * a.head_dim + d, v);
+                *reinterpret_cast<f32x4t*>(a.qk + (((long long)b * a.heads2 + h) * a.rows + m) * a.head_dim + d) = v;
             } else {
-                if (a.yf) st16(a.yf + (long long)b * a.y_bs + (long long)m * a.ldy + n, v);
+                if (a.yf) *reinterpret_cast<f32x4t*>(a.yf + (long long)b * a.y_bs + (long long)m * a.ldy + n) = v;
                 if (a.yb) {
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                     const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
