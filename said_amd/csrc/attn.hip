@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 // put four on every SIMD and halve the K / V copies per query tile.
 typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
 template <int QT>
-__global__ __launch_bounds__(64 * QT, (QT == 8 ? 4 : 2)) void battn_kernel(const unsigned short* __restrict__ qk, const unsigned short* __restrict__ vt, unsigned short* __restrict__ outp,
+__global__ __launch_bounds__(64 * QT, (QT == 10 ? 5 : (QT == 8 ? 4 : 2))) void battn_kernel(const unsigned short* __restrict__ qk, const unsigned short* __restrict__ vt, unsigned short* __restrict__ outp,
                                                        int v_bstride, int o_bstride, int pitch, int T, int heads, int rows, float scale) {
     extern __shared__ __attribute__((aligned(16))) u32x4b bsm[];
     const int nkt = (T + 31) >> 5, nkr = nkt * 32;
@@ -485,6 +485,12 @@ void launch_battn(const AttnArgs& a, int batch, hipStream_t s, int qt) {
                            reinterpret_cast<unsigned short*>(a.o), (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T, a.heads, a.rows, a.scale);
         return;
     }
+    if (qt == 10) {   // 19 query tiles (T = 600) as two workgroups of ten waves: two K / V copies per head instead of three, one idle wave instead of five
+        dim3 grid((((a.T + 31) / 32) + 9) / 10, a.heads, batch);
+        hipLaunchKernelGGL(battn_kernel<10>, grid, dim3(640), lds_bytes, s, reinterpret_cast<const unsigned short*>(a.qk), reinterpret_cast<const unsigned short*>(a.v),
+                           reinterpret_cast<unsigned short*>(a.o), (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T, a.heads, a.rows, a.scale);
+        return;
+    }
     dim3 grid((((a.T + 31) / 32) + 7) / 8, a.heads, batch);
     hipLaunchKernelGGL(battn_kernel<8>, grid, dim3(512), lds_bytes, s, reinterpret_cast<const unsigned short*>(a.qk), reinterpret_cast<const unsigned short*>(a.v),
                        reinterpret_cast<unsigned short*>(a.o), (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T, a.heads, a.rows, a.scale);
@@ -507,6 +513,7 @@ static void configure_attn_one() {
 void configure_attn_kernels() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     configure_attn_one<1, 8, false>(); configure_attn_one<1, 8, true>(); configure_attn_one<1, 4, false>(); configure_attn_one<1, 4, true>(); configure_attn_one<1, 1, false>(); configure_attn_one<1, 1, true>();
     configure_attn_one<1, 1, false, 4>(); configure_attn_one<1, 1, true, 4>(); configure_attn_one<2, 1, false, 4>(); configure_attn_one<2, 1, true, 4>();
     configure_attn_one<2, 8, false>(); configure_attn_one<2, 8, true>(); configure_attn_one<2, 4, false>(); configure_attn_one<2, 4, true>(); configure_attn_one<2, 1, false>(); configure_attn_one<2, 1, true>();

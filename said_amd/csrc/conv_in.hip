@@ -21,6 +21,9 @@ static __device__ __forceinline__ f32x4c ci_bload4(rsrc_t r, int voff, int soff)
 
 constexpr int CI_W = 4, CI_XP = 40;
 
+// TM (round 4, large batches in bf16 mode): the result goes out token-major in bf16, y = [sample][seg rows][192] (dims = seg | copies << 16, Cout = 192) —
+// what the persistent GEMMs read — instead of channel-major fp32 followed by a transposing launch; the partial statistics are the same fp32 ones.
+template <bool TM>
 __global__ __launch_bounds__(64 * CI_W) void conv_in_kernel(const float* x, const float* w4, const float* bias, float* y, float* stats,
                                                             int* step_inc, int T_pitch, int dims) {
     // T_pitch = T | pitch << 16; dims = Cout | copies << 16 (copies: batch halves that receive the result)
@@ -28,7 +31,7 @@ __global__ __launch_bounds__(64 * CI_W) void conv_in_kernel(const float* x, cons
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = T_pitch & 0xffff, pitch = (int)((unsigned)T_pitch >> 16);
-    const int Cout = dims & 0xffff, copies = (int)((unsigned)dims >> 16);
+    const int Cout = TM ? 192 : (dims & 0xffff), copies = (int)((unsigned)dims >> 16), seg = dims & 0xffff;
     const int t0 = blockIdx.x * 32, tile = blockIdx.y, b = blockIdx.z, B = gridDim.z;
     const int np = (T + 31) >> 5;
     if (step_inc && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) *step_inc += 1;
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(64 * CI_W) void conv_in_kernel(const float* x, cons
     __syncthreads();
     const int t = t0 + lt;
     const float cnt = (float)min(32, T - t0);
+    float tmv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = w * 4 + j;
@@ -80,15 +84,23 @@ __global__ __launch_bounds__(64 * CI_W) void conv_in_kernel(const float* x, cons
         const float mean = half32_sum(vv) * __builtin_amdgcn_rcpf(cnt);
         const float d = (t < T) ? (val - mean) : 0.f;
         const float m2 = half32_sum(d * d);
+        tmv[j] = val;
         for (int k = 0; k < copies; ++k) {
             const long long bo = (long long)(b + k * B);
-            if (nok && t < T) y[(bo * Cout + n) * pitch + t] = val;
+            if (!TM && nok && t < T) y[(bo * Cout + n) * pitch + t] = val;
             if (stats && nok && lt == 0) {
                 float* so = stats + ((bo * np + blockIdx.x) * Cout + n) * 2;   // [sample][tile][channel][2]
                 so[0] = mean;
                 so[1] = m2;
             }
         }
+    }
+    if constexpr (TM) {   // this thread's four values are channels tile * 32 + 8 w + 4 lh + (0 .. 3) of token t: one 8-byte store per copy
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        const bf16x4 ov = {(__bf16)tmv[0], (__bf16)tmv[1], (__bf16)tmv[2], (__bf16)tmv[3]};
+        if (t < T)
+            for (int k = 0; k < copies; ++k)
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(y) + ((long long)(b + k * B) * seg + t) * 192 + tile * 32 + 8 * w + 4 * lh) = ov;
     }
 }
 
@@ -98,7 +110,14 @@ bool conv_in_supports(int Cin, int Cout, int taps, int T, int pitch, int copies)
 void launch_conv_in(const float* x, const float* w4, const float* bias, float* y, float* stats, int* step_inc, int B, int copies, int T,
                     int pitch, int Cout, hipStream_t s) {
     dim3 grid((T + 31) / 32, (Cout + 31) / 32, B);
-    hipLaunchKernelGGL(conv_in_kernel, grid, dim3(64 * CI_W), 0, s, x, w4, bias, y, stats, step_inc, T | (pitch << 16), Cout | (copies << 16));
+    hipLaunchKernelGGL(conv_in_kernel<false>, grid, dim3(64 * CI_W), 0, s, x, w4, bias, y, stats, step_inc, T | (pitch << 16), Cout | (copies << 16));
+}
+// token-major bf16 result [sample][seg][192] (Cout = 192, seg <= 0xffff)
+void launch_conv_in_tm(const float* x, const float* w4, const float* bias, void* y_tm, int seg, float* stats, int* step_inc, int B, int copies, int T,
+                       int pitch, hipStream_t s) {
+    dim3 grid((T + 31) / 32, 6, B);
+    hipLaunchKernelGGL(conv_in_kernel<true>, grid, dim3(64 * CI_W), 0, s, x, w4, bias, reinterpret_cast<float*>(y_tm), stats, step_inc, T | (pitch << 16),
+                       seg | (copies << 16));
 }
 
 }  // namespace said

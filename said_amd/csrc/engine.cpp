@@ -803,7 +803,7 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
         a.scale = 0.17677669529663687f;
         if (battn) {
             if (c->log_on) { const double e = (double)n1 * HEADS * HD * g.T; c->stage_log.push_back({9, -1, 1, 1, 4.0 * e * 2.0, 4.0 * e * g.T}); }
-            if (dbg_go(c)) launch_battn(a, n1, s, c->battn == 4 ? 4 : 8);
+            if (dbg_go(c)) launch_battn(a, n1, s, c->battn == 4 ? 4 : (c->battn == 10 ? 10 : 8));
         } else {
             do_attn(c, a, n1, HD, -4, s);
         }
@@ -1252,10 +1252,16 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
     const long long tt = (long long)g.Be * ((g.T + 31) / 32);
     const int in_copies = (g.B_lat > 0 && g.Be % g.B_lat == 0) ? g.Be / g.B_lat : 0;   // samples sharing one clip's latents
     static const bool no_conv_in = dev_env("SAID_NO_CONV_IN") != nullptr;
+    bool conv_in_tm = false;
     if (!no_conv_in && g.b0 == 0 && in_copies >= 1 && c->conv_in.w4[0] && !c->clk_on &&
         conv_in_supports(c->cin, MC, c->conv_in.taps, g.T, g.Tp, in_copies)) {
         // input_blocks.0: Conv1d(32 -> 192, k3), computed once per clip (conv_in.hip)
-        if (dbg_go(c)) launch_conv_in(c->x_cm, c->conv_in.w4[0], c->conv_in.bias, c->H0.p, c->H0.st, g.step_inc, g.B_lat, in_copies, g.T, g.Tp, MC, s);
+        // (large batches in bf16 mode: straight into the token-major bf16 layout the persistent GEMMs read — no channel-major copy, no transposition)
+        conv_in_tm = c->bf16_mode && use_tm(c, g) && tm_seg(g) <= 0xffff;
+        if (dbg_go(c)) {
+            if (conv_in_tm) launch_conv_in_tm(c->x_cm, c->conv_in.w4[0], c->conv_in.bias, c->H0.t, tm_seg(g), c->H0.st, g.step_inc, g.B_lat, in_copies, g.T, g.Tp, s);
+            else launch_conv_in(c->x_cm, c->conv_in.w4[0], c->conv_in.bias, c->H0.p, c->H0.st, g.step_inc, g.B_lat, in_copies, g.T, g.Tp, MC, s);
+        }
         if (c->log_on)
             c->stage_log.push_back({0, EPI_STORE, 1, 4, 4.0 * ((double)MC * c->cin * 3 + (double)g.B_lat * c->cin * g.T + (double)g.Be * MC * g.T),
                                     2.0 * g.B_lat * MC * c->cin * 3 * g.T});
@@ -1272,7 +1278,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
     }
     const bool sh = g.Bc > 0;   // guidance-shared prefix: the two halves first differ at input_blocks.1.1's cross-attention
     if (use_tm(c, g)) {
-        {   // conv_in's result (channel-major fp32 + GroupNorm partials) -> token-major, raw
+        if (!conv_in_tm) {   // conv_in's result (channel-major fp32 + GroupNorm partials) -> token-major, raw
             PrepArgs p = mkprep(g, c->H0.p, 3, c->H0.t, (long long)tm_seg(g) * MC, MC, 0);
             do_prep(c, p, g.Be, s);
         }

@@ -260,6 +260,8 @@ void launch_finish(const float* x_cm, long long x_bstride, int pitch, int B, int
 bool conv_in_supports(int Cin, int Cout, int taps, int T, int pitch, int copies);
 void launch_conv_in(const float* x, const float* w4, const float* bias, float* y, float* stats, int* step_inc, int B, int copies, int T,
                     int pitch, int Cout, hipStream_t s);
+void launch_conv_in_tm(const float* x, const float* w4, const float* bias, void* y_tm, int seg, float* stats, int* step_inc, int B, int copies, int T,
+                       int pitch, hipStream_t s);
 
 // ---- VAE encoder (said/model/vae.py:26-112) ----
 // windows of (L, C) token-major coefficients, window w starting at src + w * win_stride floats (win_stride = L*C for a
