@@ -127,6 +127,8 @@ struct said_ctx {
     // ---- bf16 audio encoder (tgemm.hip): bf16 weights [N][K] (convs: K = tap-major), token-major workspace ----
     void* bw_conv[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *bw_fproj = nullptr, *bw_aproj = nullptr;
+    void* bw_out = nullptr;   // out.2 weights bf16 [in_channels][3 taps][192] for out_sched_tm_kernel (round 4)
+    int out_tm = -1;          // the token-major out + scheduler kernel behind the bf16 large-batch schedule (said_debug_option "out_tm": 0 off)
     void* bw_pos = nullptr;       // positional conv as 16 GEMMs: bf16 [16][64 (48 + 16 zero rows)][taps * 48], tap-major
     float* pos_bias_pad = nullptr; // its bias, 16 zeros appended (the last group's 64-wide tile reads past 768)
     void* bXg = nullptr;          // per-group operand [clips][16][R][48] bf16
@@ -1277,6 +1279,14 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
         do_gemm(c, a, EPI_STORE, g.Be, lc.NB, lc.KS, s);
     }
     const bool sh = g.Bc > 0;   // guidance-shared prefix: the two halves first differ at input_blocks.1.1's cross-attention
+    // round 4: the loop's last kernel reads the token-major bf16 hidden state itself (out_sched.hip: out_sched_tm_kernel)
+    OutSchedArgs osa_tm;
+    bool out_tm = false;
+    if (g.out_sched && c->out_tm != 0 && c->bf16_mode && c->rgemm != 0 && use_tm(c, g) && c->bw_out) {
+        osa_tm = *g.out_sched;
+        osa_tm.x_tm = c->P.t; osa_tm.wb = c->bw_out; osa_tm.seg = tm_seg(g);
+        out_tm = out_sched_tm_supports(osa_tm);
+    }
     if (use_tm(c, g)) {
         if (!conv_in_tm) {   // conv_in's result (channel-major fp32 + GroupNorm partials) -> token-major, raw
             PrepArgs p = mkprep(g, c->H0.p, 3, c->H0.t, (long long)tm_seg(g) * MC, MC, 0);
@@ -1290,7 +1300,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
         run_resblock_tm(c, g, c->res[3], 3, c->P, &c->H1, c->Q, s, false);           // output_blocks.0.0  cat([h, H1])
         run_transformer_tm(c, g, c->st[2], 2, c->Q, c->P, s, false, false);         // output_blocks.0.1
         run_resblock_tm(c, g, c->res[4], 4, c->P, &c->H0, c->Q, s, false);           // output_blocks.1.0  cat([h, H0])
-        run_transformer_tm(c, g, c->st[3], 3, c->Q, c->P, s, false, true);          // output_blocks.1.1 -> channel-major for `out`
+        run_transformer_tm(c, g, c->st[3], 3, c->Q, c->P, s, false, !out_tm);       // output_blocks.1.1 (-> channel-major for out_sched_kernel unless out_tm)
     } else {
     run_resblock(c, g, c->res[0], 0, c->H0, nullptr, c->P, s, sh);   // input_blocks.1.0
     run_transformer(c, g, c->st[0], 0, c->P, c->H1, s, sh);          // input_blocks.1.1   (hs: H0, H1)
@@ -1303,7 +1313,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
     run_transformer(c, g, c->st[3], 3, c->Q, c->P, s);               // output_blocks.1.1
     }
     if (g.out_sched) {   // out conv + guidance + DDIM update in one kernel (out_sched.hip)
-        if (dbg_go(c)) launch_out_sched(*g.out_sched, s);
+        if (dbg_go(c)) { if (out_tm) launch_out_sched_tm(osa_tm, s); else launch_out_sched(*g.out_sched, s); }
     } else {   // out: GN -> SiLU -> Conv1d(192 -> 32, k3)
         GemmArgs a = mkargs(g.T, c->cin);
         a.nseg = 1;
@@ -1703,6 +1713,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
     if (make_pw(ctx, &ctx->te2, D + "time_embed.2.weight", D + "time_embed.2.bias", TE, TE, 0)) return -1;
     if (make_pw(ctx, &ctx->conv_in, D + "input_blocks.0.0.weight", D + "input_blocks.0.0.bias", MC, ctx->cin, 3)) return -1;
     if (make_pw(ctx, &ctx->conv_out, D + "out.2.weight", D + "out.2.bias", ctx->cin, MC, 3, 1, D + "out.0.weight", D + "out.0.bias")) return -1;
+    if (upload_bf16(ctx, &ctx->bw_out, ctx->host_w[D + "out.2.weight"].data.data(), (size_t)ctx->cin, MC, 3)) return -1;
     if (upvec(ctx, &ctx->out_g, D + "out.0.weight", MC) || upvec(ctx, &ctx->out_b, D + "out.0.bias", MC)) return -1;
     used += 8;
     const char* res_names[NRES] = {"input_blocks.1.0", "middle_block.0", "middle_block.2", "output_blocks.0.0", "output_blocks.1.0"};
@@ -2298,6 +2309,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->hybrid = value != 0;
     } else if (k == "hybrid_f32") {
         ctx->hybrid_f32 = value != 0;
+    } else if (k == "out_tm") {
+        ctx->out_tm = (int)value;
     } else if (k == "mt_mid") {
         ctx->mt_mid = value != 0;
     } else if (k == "mt_wgs") {

@@ -262,4 +262,81 @@ __device__ __forceinline__ void gn_finish(const GnP sg, rsrc_t rp, int c_lo, int
 }
 
 
+// GroupNorm coefficients of a 48-channel slice (lane <-> channel, 48 lanes active) with up to TWENTY partial tiles in flight per lane
+// (T <= 640: one memory round trip; gemm_common.h's gn_issue / gn_finish take ten per round).  Same combination order as there.
+struct GnL20 { float2 v[20]; float ref, gamma, beta; };
+__device__ __forceinline__ void gn20_issue(const GnP sg, rsrc_t rp, int c_lo, int lane, GnL20& L) {
+    const bool chok = lane < 48;
+    const int c = c_lo + (chok ? lane : 0);
+    const int gfirst = (int)(((float)c + 0.5f) * __builtin_amdgcn_rcpf((float)sg.gn_cpg)) * sg.gn_cpg;
+    L.ref = bload(rp, gfirst * 8, 0);
+    L.gamma = gload(sg.gn_gamma, c);
+    L.beta = gload(sg.gn_beta, c);
+#pragma unroll
+    for (int r = 0; r < 20; ++r) {
+        const bool ok = chok && (r < sg.gn_nparts);
+        L.v[r] = bload2(rp, ok ? (r * sg.ct + c) * 8 : (int)0x80000000, 0);
+    }
+}
+__device__ __forceinline__ void gn20_finish(const GnP sg, rsrc_t rp, int c_lo, int lane, const GnL20& L, float* scratch, float* cA) {
+    const bool chok = lane < 48;
+    const int c = c_lo + (chok ? lane : 0);
+    const int nparts = sg.gn_nparts;
+    const int tail = sg.Tin - (nparts - 1) * 32;
+    float s1 = 0.f, s2 = 0.f, sm = 0.f;
+#pragma unroll
+    for (int r = 0; r < 20; ++r) {
+        const bool ok = chok && (r < nparts);
+        const float cnt = ok ? ((r == nparts - 1) ? (float)tail : 32.f) : 0.f;
+        const float d = L.v[r].x - L.ref;
+        s1 = fmaf(cnt, d, s1);
+        s2 = fmaf(cnt * d, d, s2);
+        sm += ok ? L.v[r].y : 0.f;
+    }
+    for (int r0 = 20; r0 < nparts; r0 += 10) {   // long sequences: further rounds of 10 tiles
+        float2 v[10];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const bool ok = chok && (r0 + r < nparts);
+            v[r] = bload2(rp, ok ? ((r0 + r) * sg.ct + c) * 8 : (int)0x80000000, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const int pi = r0 + r;
+            const bool ok = chok && (pi < nparts);
+            const float cnt = ok ? ((pi == nparts - 1) ? (float)tail : 32.f) : 0.f;
+            const float d = v[r].x - L.ref;
+            s1 = fmaf(cnt, d, s1);
+            s2 = fmaf(cnt * d, d, s2);
+            sm += ok ? v[r].y : 0.f;
+        }
+    }
+    float* sc = scratch;            // [64][3]
+    float* gs = scratch + 64 * 3;   // [16][2] (mean, rstd) per group of this slice
+    if (chok) { sc[lane * 3] = s1; sc[lane * 3 + 1] = s2; sc[lane * 3 + 2] = sm; }
+    const float rcp_cpg = __builtin_amdgcn_rcpf((float)sg.gn_cpg);
+    const int gpw = (int)((48.0f + 0.5f) * rcp_cpg);
+    if (lane < gpw) {
+        float S1 = 0.f, S2 = 0.f, SM = 0.f;
+        for (int q = 0; q < sg.gn_cpg; ++q) {
+            const int cc = lane * sg.gn_cpg + q;
+            S1 += sc[cc * 3]; S2 += sc[cc * 3 + 1]; SM += sc[cc * 3 + 2];
+        }
+        const float total = (float)sg.gn_cpg * (float)sg.Tin;
+        const float inv_total = __builtin_amdgcn_rcpf(total);
+        const float md = S1 * inv_total;
+        const float var = fmaxf((SM + S2 - total * md * md) * inv_total, 0.f);
+        gs[lane * 2] = md;
+        gs[lane * 2 + 1] = __builtin_amdgcn_rsqf(var + sg.gn_eps);
+    }
+    if (chok) {
+        const int gi = (int)(((float)lane + 0.5f) * rcp_cpg);
+        const float mean = L.ref + gs[gi * 2];
+        const float av = gs[gi * 2 + 1] * L.gamma;
+        cA[2 * c] = av;
+        cA[2 * c + 1] = L.beta - mean * av;
+    }
+}
+
+
 }  // namespace said

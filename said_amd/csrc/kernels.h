@@ -236,8 +236,14 @@ struct OutSchedArgs {
     float guidance_scale, guidance_rescale, latent_scale;
     const unsigned* noise_seed;   // device [2] Philox key: eta noise generated in the kernel (sched_math.h), or null
     unsigned noise_elem0;         // see SchedArgs
+    // out_sched_tm_kernel (bf16 large-batch schedule): the last hidden state token-major bf16 [Be][seg][192], out.2 weights bf16 [32][3 taps][192]
+    const void* x_tm;
+    const void* wb;
+    int seg;
 };
 bool out_sched_supports(const OutSchedArgs& a);
+bool out_sched_tm_supports(const OutSchedArgs& a);
+void launch_out_sched_tm(const OutSchedArgs& a, hipStream_t s);
 void launch_out_sched(const OutSchedArgs& a, hipStream_t s);
 void configure_out_sched_kernel();
 // pre-pass for guidance_rescale > 0: per-block Welford partials of e_c and eps_cfg

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
     }
 }
 
+template <bool CFG> __global__ __launch_bounds__(256) void out_sched_tm_kernel(const OutSchedArgs a);   // (below)
 static int out_sched_smem(bool cfg) {
     const int nh = cfg ? 2 : 1;
     const int stage = OS_KS * nh * OS_CW * OS_XP, red = OS_KS * nh * 16 * 64;
@@ -187,6 +188,8 @@ static int out_sched_smem(bool cfg) {
 void configure_out_sched_kernel() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_tm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_tm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
 bool out_sched_supports(const OutSchedArgs& a) {
     return a.Cin == OS_C && a.Cout <= 32 && a.guidance_rescale <= 0.f && a.gn_nparts < 0x7fff;
@@ -195,6 +198,178 @@ void launch_out_sched(const OutSchedArgs& a, hipStream_t s) {
     dim3 grid((a.T + 31) / 32, a.B);
     if (a.cfg) hipLaunchKernelGGL(out_sched_kernel<true>, grid, dim3(64 * OS_KS), out_sched_smem(true), s, a);
     else hipLaunchKernelGGL(out_sched_kernel<false>, grid, dim3(64 * OS_KS), out_sched_smem(false), s, a);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// out_sched_tm_kernel (round 4) — the same last kernel for the bf16 large-batch schedule, whose activations are token-major bf16
+// [sample][seg rows][192] (rgemm.hip): until now the last block's folded proj_out had to leave that schedule (xgemm_kernel writing
+// channel-major fp32, 60 us at 64 x 600 tokens) to feed out_sched_kernel (19 x 32 workgroups re-reading 2 x 14.7 MB of fp32: 41 us).
+// Workgroup = one 32-token tile of one clip, four waves: GroupNorm tables of the clip's unconditional and conditional sample (wave w: the
+// 48-channel slice w, all partial tiles in flight: gn20_*), GroupNorm + SiLU once per element into a bf16 LDS tile [sample][34 rows][192]
+// (rgemm's 400-byte rows), the convolution as a TRANSPOSED product D[out channel][token] on v_mfma_f32_32x32x16_bf16 — lane == token, as
+// out_sched_kernel's epilogue wants it — with the 36 k-steps split over the four waves (fixed-order LDS reduction), both samples sharing every
+// weight fragment, then exactly out_sched_kernel's epilogue (sched_math.h: same explicitly rounded op sequence).
+typedef __bf16 os_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int os_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int OT_AP = 200, OT_ROWS = 34, OT_NP = 4;   // tile row pitch (elements), rows, 16-byte pieces per thread and sample (34 x 24 = 816 <= 4 x 256)
+
+template <bool CFG>
+__global__ __launch_bounds__(256) void out_sched_tm_kernel(const OutSchedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NH = CFG ? 2 : 1;
+    const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * 32, b = blockIdx.y, T = a.T;
+    float* const coefS = smem;                                   // [NH][192][2]
+    float* const gnS = coefS + NH * 384 + w * GN_SCRATCH;
+    unsigned short* const At = reinterpret_cast<unsigned short*>(coefS + NH * 384 + 4 * GN_SCRATCH);   // [NH][34][OT_AP] bf16
+    float* const red = reinterpret_cast<float*>(At);             // [4 waves][NH][16][64] after the MFMAs
+    const unsigned short* xb = reinterpret_cast<const unsigned short*>(a.x_tm);
+
+    // ---- requests: source rows (raw), epilogue operands, weight fragments; then the statistics partials
+    os_u32x4 raw[NH][OT_NP];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const long long sb = b + h * a.B;
+#pragma unroll
+        for (int i = 0; i < OT_NP; ++i) {
+            const int idx = min(tid + 256 * i, OT_ROWS * 24 - 1);
+            const int row = idx / 24, pc = idx - row * 24;
+            const int tt = min(max(t0 + row - 1, 0), T - 1);
+            raw[h][i] = *reinterpret_cast<const os_u32x4*>(xb + ((sb * a.seg + tt) * 192 + 8 * pc));
+        }
+    }
+    const int step = *a.step_ptr;
+    const float* cf = a.coef + step * 8;
+    float cfv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cfv[i] = cf[i];
+    const int t = t0 + lt;
+    const bool tok = t < T;
+    const rsrc_t rlat = make_rsrc(a.lat + (long long)b * a.lat_bstride, (unsigned)a.Cout * (unsigned)a.pitch * 4u);
+    const rsrc_t rnz = make_rsrc(a.step_noise ? a.step_noise + ((long long)step * a.B + b) * a.lat_bstride : nullptr,
+                                 a.step_noise ? (unsigned)a.Cout * (unsigned)a.pitch * 4u : 0u);
+    const rsrc_t rin = make_rsrc(a.mask ? a.init + (long long)b * a.lat_bstride : nullptr, a.mask ? (unsigned)a.Cout * (unsigned)a.pitch * 4u : 0u);
+    const rsrc_t ren = make_rsrc(a.mask ? a.edit_noise + (long long)b * a.lat_bstride : nullptr, a.mask ? (unsigned)a.Cout * (unsigned)a.pitch * 4u : 0u);
+    const rsrc_t rmk = make_rsrc(a.mask ? a.mask + (long long)b * a.lat_bstride : nullptr, a.mask ? (unsigned)a.Cout * (unsigned)a.pitch * 4u : 0u);
+    float e_x[4], e_nz[4], e_in[4], e_en[4], e_mk[4], e_bias[4];
+    int e_n[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = w + 4 * j;
+        const int n = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        e_n[j] = n;
+        const int vo = (tok && n < a.Cout) ? (n * a.pitch + t) * 4 : (int)0x80000000;
+        e_x[j] = bload(rlat, vo, 0);
+        e_nz[j] = bload(rnz, vo, 0);
+        e_in[j] = bload(rin, vo, 0);
+        e_en[j] = bload(ren, vo, 0);
+        e_mk[j] = bload(rmk, vo, 0);
+        e_bias[j] = a.bias[n < a.Cout ? n : 0];
+    }
+    // this wave's nine k16 steps of the [32][576] weight matrix (row = output channel, k = tap * 192 + channel); rows past Cout: row 0 again (unused)
+    os_bf16x8 wf[9];
+    {
+        const unsigned short* wb = reinterpret_cast<const unsigned short*>(a.wb) + (long long)(lt < a.Cout ? lt : 0) * 576 + 8 * lh;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wf[i] = __builtin_bit_cast(os_bf16x8, *reinterpret_cast<const os_u32x4*>(wb + 16 * (9 * w + i)));
+    }
+    // ---- GroupNorm tables: wave w = channels [48 w, 48 w + 48) of each sample
+    const GnP gp = {OS_C / 32, a.gn_nparts, T, 1e-5f, a.gn_gamma, a.gn_beta, OS_C};
+#pragma unroll 1
+    for (int h = 0; h < NH; ++h) {
+        const rsrc_t rp = make_rsrc(a.gn_part + (long long)(b + h * a.B) * a.gn_part_bstride, (unsigned)OS_C * (unsigned)a.gn_nparts * 8u);
+        GnL20 g0;
+        gn20_issue(gp, rp, 48 * w, l, g0);
+        gn20_finish(gp, rp, 48 * w, l, g0, gnS, coefS + h * 384);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- GroupNorm + SiLU once per element -> bf16 tile (rows outside [0, T): zeros = the convolution's padding)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const float2* cG = reinterpret_cast<const float2*>(coefS + h * 384);
+#pragma unroll
+        for (int i = 0; i < OT_NP; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < OT_ROWS * 24) {
+                const int row = idx / 24, pc = idx - row * 24;
+                const int tt = t0 + row - 1;
+                const bool valid = tt >= 0 && tt < T;
+                os_u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 g0 = cG[8 * pc + 2 * e], g1 = cG[8 * pc + 2 * e + 1];
+                    const float x0 = silu_f(fmaf(__builtin_bit_cast(float, raw[h][i][e] << 16), g0.x, g0.y));
+                    const float x1 = silu_f(fmaf(__builtin_bit_cast(float, raw[h][i][e] & 0xffff0000u), g1.x, g1.y));
+                    typedef __bf16 os_bf16x2 __attribute__((ext_vector_type(2)));
+                    const os_bf16x2 p2 = {(__bf16)x0, (__bf16)x1};
+                    o[e] = valid ? __builtin_bit_cast(unsigned, p2) : 0u;
+                }
+                *reinterpret_cast<os_u32x4*>(At + (h * OT_ROWS + row) * OT_AP + 8 * pc) = o;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- D[out channel][token] += W[out channel][k] A[token + tap][k]: lane == token
+    f32x16 acc[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int sidx = 9 * w + i, tap = sidx / 12, c0 = (sidx - 12 * tap) * 16;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const os_bf16x8 fa = __builtin_bit_cast(os_bf16x8, *reinterpret_cast<const os_u32x4*>(At + (h * OT_ROWS + lt + tap) * OT_AP + c0 + 8 * lh));
+            acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], fa, acc[h], 0, 0, 0);
+        }
+    }
+    __syncthreads();   // (the tile is dead: its memory is the reduction buffer)
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((w * NH + h) * 16 + r) * 64 + l] = acc[h][r];
+    __syncthreads();
+    // ---- epilogue: bias, guidance, DDIM update, noise, mask blend; latents updated in place (out_sched_kernel's)
+    float* latp = a.lat + (long long)b * a.lat_bstride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = w + 4 * j;
+        float eh[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            float s = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) s += red[((w2 * NH + h) * 16 + r) * 64 + l];
+            eh[h] = s + e_bias[j];
+        }
+        const float e = CFG ? cfg_combine(eh[NH - 1], eh[0], a.guidance_scale) : eh[0];
+        const int n = e_n[j];
+        if (!(tok && n < a.Cout)) continue;
+        const float x = e_x[j];
+        if (a.inter) a.inter[(((long long)step * a.B + b) * T + t) * a.Cout + n] = x / a.latent_scale;
+        float prev = ddim_prev(e, x, cfv, a.prediction_type);
+        if (a.step_noise) prev = __fadd_rn(prev, __fmul_rn(cfv[4], e_nz[j]));
+        else if (a.noise_seed) prev = __fadd_rn(prev, __fmul_rn(cfv[4], philox_normal(a.noise_seed[0], a.noise_seed[1], (unsigned)step, a.noise_elem0 + (unsigned)((b * T + t) * a.Cout + n))));
+        if (a.mask) prev = mask_blend(prev, e_in[j], e_en[j], e_mk[j], cfv);
+        latp[(long long)n * a.pitch + t] = prev;
+    }
+}
+static int out_sched_tm_smem(bool cfg) {
+    const int nh = cfg ? 2 : 1;
+    const int tile = nh * OT_ROWS * OT_AP * 2, red = 4 * nh * 16 * 64 * 4;
+    return (nh * 384 + 4 * GN_SCRATCH) * (int)sizeof(float) + (tile > red ? tile : red);
+}
+bool out_sched_tm_supports(const OutSchedArgs& a) {
+    return out_sched_supports(a) && a.x_tm && a.wb && a.seg > 0 && (long long)(a.cfg ? 2 : 1) * a.B * a.seg * 192 < 0x7fffffffLL;
+}
+void launch_out_sched_tm(const OutSchedArgs& a, hipStream_t s) {
+    dim3 grid((a.T + 31) / 32, a.B);
+    if (a.cfg) hipLaunchKernelGGL(out_sched_tm_kernel<true>, grid, dim3(256), out_sched_tm_smem(true), s, a);
+    else hipLaunchKernelGGL(out_sched_tm_kernel<false>, grid, dim3(256), out_sched_tm_smem(false), s, a);
 }
 
 }  // namespace said

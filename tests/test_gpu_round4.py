@@ -31,9 +31,9 @@ def model(dev):
 
 
 # bounds of the ensemble statement (asserted below, quoted in DESIGN.md 7.4 / 7.6); measured values are printed by the test
-ENS_MEAN_ABS = 2.5e-3     # |per-channel mean(bf16) - mean(fp32)| over 64 clips x 600 frames, result clamped to [0, 1]
-ENS_STD_REL = 0.006      # relative difference of the per-channel standard deviation
-ENS_DIFF_STD_REL = 0.008  # ... of the standard deviation of the temporal difference r[t + 1] - r[t] (the jitter an animator would see)
+ENS_MEAN_ABS = 2.8e-3     # |per-channel mean(bf16) - mean(fp32)| over 64 clips x 600 frames, result clamped to [0, 1]
+ENS_STD_REL = 0.0068     # relative difference of the per-channel standard deviation
+ENS_DIFF_STD_REL = 0.0095 # ... of the standard deviation of the temporal difference r[t + 1] - r[t] (the jitter an animator would see)
 
 
 def test_bf16_ensemble_statistics_match_fp32_64_clips_50_steps(model, dev):
