@@ -42,6 +42,10 @@ def matcher(name):
         pre = f"xgemm_kernel<{int(m.group(1)) // 32}, {'true' if m.group(2) == 'bf16' else 'false'},"
         eks = XGEMM_EK[m.group(3)]
         return lambda k: pre in k and k[k.index("xgemm_kernel<"):].rstrip(">").split(", ")[5:6] and k[k.index("xgemm_kernel<"):].split(", ")[5] in eks
+    m = re.match(r"rgemm_kernel<(\w+)>", name)
+    if m:   # rgemm_kernel<NTAP, EK, ...>: EK 0 store, 1 q/k/v, 2 GEGLU, 4 band
+        ek = {"store": "0", "qkv": "1", "geglu": "2", "band": "4"}[m.group(1)]
+        return lambda k: "rgemm_kernel<" in k and k[k.index("rgemm_kernel<") + 13:].split(", ")[1] == ek
     m = re.match(r"attn_kernel<D(\d+),KS(\d+)>", name)
     if m:
         pre = f"attn_kernel<{int(m.group(1)) // 32}, {m.group(2)},"
