@@ -113,3 +113,29 @@ def test_inference_encodes_identical_clips_once(model, dev):
     print(f"identical clips encoded once vs every row: max |diff| of the 4-step result {d:.2e}")
     assert d <= 1e-4
     assert res[(True, "clips")] == 2 and res[(False, "clips")] == 6
+
+
+def test_device_eta_noise_50_steps_four_clips_two_groups_vs_oracle(model, dev):
+    """the device Philox noise path (use_step_noise == 2) over a LONGER free-running chain at B > 1 and through clip groups
+    (the generator's element counter is offset by each group's first clip): 4 clips x 0.5 s, 50 steps, eta = 1, guidance 2, two groups,
+    against the CPU oracle fed said_philox_normal's values for the same seed."""
+    from oracle import pipeline as op
+    B, Ta, N = 4, 8000, 50
+    T = int(Ta / 16000 * 60)
+    proc = op.process_audio([synth.synth_waveform(950 + i, Ta).numpy() for i in range(B)])
+    lat = synth.synth_latents(951, (B, T, 32))
+    emb = model.get_audio_embedding(proc.to(dev), T)
+    model.clip_groups = 2
+    try:
+        torch.manual_seed(17)
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))   # the one draw SAID.inference makes from torch's generator
+        torch.manual_seed(17)
+        r = model.inference(proc.to(dev), num_inference_steps=N, guidance_scale=2.0, eta=1.0, init_latents=lat.to(dev), audio_embedding=emb).result
+    finally:
+        model.clip_groups = None
+    sn = model._eng.philox_normal(seed, 0, N, (B, T, 32)).cpu()
+    ref = op.inference(synth.said_state_dict(), proc, init_latents=lat, num_inference_steps=N, guidance_scale=2.0, eta=1.0, step_noise=sn,
+                       audio_embedding=emb.cpu())
+    err = float((r.cpu() - ref.result).abs().max())
+    print(f"device eta noise, 4 clips in two groups, 50 free-running steps: max abs err vs oracle {err:.3e}")
+    assert err <= 2e-3
