@@ -277,13 +277,19 @@ __global__ __launch_bounds__(256) void out_sched_tm_kernel(const OutSchedArgs a)
     }
     // ---- GroupNorm tables: wave w = channels [48 w, 48 w + 48) of each sample
     const GnP gp = {OS_C / 32, a.gn_nparts, T, 1e-5f, a.gn_gamma, a.gn_beta, OS_C};
-#pragma unroll 1
-    for (int h = 0; h < NH; ++h) {
-        const rsrc_t rp = make_rsrc(a.gn_part + (long long)(b + h * a.B) * a.gn_part_bstride, (unsigned)OS_C * (unsigned)a.gn_nparts * 8u);
-        GnL20 g0;
-        gn20_issue(gp, rp, 48 * w, l, g0);
-        gn20_finish(gp, rp, 48 * w, l, g0, gnS, coefS + h * 384);
-        __builtin_amdgcn_wave_barrier();
+    {   // (both samples' partials in flight together: one memory round trip — at the start of a launch that is 8k clocks, rgemm.hip's stamps)
+        rsrc_t rp[NH];
+        GnL20 gl[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            rp[h] = make_rsrc(a.gn_part + (long long)(b + h * a.B) * a.gn_part_bstride, (unsigned)OS_C * (unsigned)a.gn_nparts * 8u);
+            gn20_issue(gp, rp[h], 48 * w, l, gl[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            gn20_finish(gp, rp[h], 48 * w, l, gl[h], gnS, coefS + h * 384);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     __syncthreads();
     // ---- GroupNorm + SiLU once per element -> bf16 tile (rows outside [0, T): zeros = the convolution's padding)
