@@ -101,7 +101,10 @@ int said_audio_encode(said_ctx* ctx, const float* waveform_dev, int batch, int n
 /* Replaces SAID.forward (diffusion.py:127-155) → UNet1DConditionModel.forward
  * (said/model/unet_1d_condition.py:51-77) → UNetModel.forward
  * (said/model/ldm/openaimodel.py:677-709).  sample_dev (Be, T, C_in),
- * timesteps_host (Be) int64, context_dev (Be, S, ctx_dim) → out_dev (Be, T, C_in). */
+ * timesteps_host (Be) int64, context_dev (Be, S, ctx_dim) → out_dev (Be, T, C_in).
+ * Any (T, S): the cross-attention's alignment windows (ldm/attention.py:170-189) of up to 8 keys —
+ * all that SAID.inference produces — run inside the q projection's epilogue, wider ones (S >> T)
+ * through a generic band kernel on the channel-major schedule (slower; round 4). */
 int said_unet_forward(said_ctx* ctx, const float* sample_dev, const int64_t* timesteps_host, const float* context_dev,
                       int batch_eff, int frames, int ctx_len, float* out_dev, void* stream);
 
