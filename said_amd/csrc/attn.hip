@@ -412,43 +412,44 @@ __global__ __launch_bounds__(64 * QT, (QT == 10 ? 5 : (QT == 8 ? 4 : 2))) void b
     //    first tile's maximum and moves only when a later score exceeds it by more than 16 (then o and the sums are rescaled: rare);
     //  * the row sums come from two extra MFMAs against a fragment of ones (the matrix pipe has room: 6 of ~60 instructions);
     //  * V^T rows are padded by one 16-byte piece instead of swizzled: the fragment address advances by a constant.
-    float ref = 0.f;
-    f32x16 o, ls;
+    f32x16 o, ls, nref;                     // nref: every register = -(the lane's reference): the score MFMAs accumulate onto it (no 16 moves per tile)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o[r] = 0.f; ls[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { o[r] = 0.f; ls[r] = 0.f; nref[r] = 0.f; }
     const bf16x8a ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
     const u32x4b* kp = Ks + lt * 4;
     const int ksw0 = lh ^ ((lt >> 2) & 3), ksw1 = (2 + lh) ^ ((lt >> 2) & 3);   // (key rows advance by 32: the swizzle term is loop-invariant)
     const u32x4b* vp = Vs + lt * 81 + lh;
-    for (int kt = 0; kt < nkt; ++kt) {
+    // One key tile.  MASK: the tile holds keys past T (only the last tile of a T % 32 != 0 sequence) — a separate instantiation, because the
+    // compiler turns a run-time `if (j0 + 32 > T)` around the 16 selects into 32 compare / select instructions executed for EVERY tile (ISA, round 4).
+    auto key_tile = [&](int kt, auto mask_c) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(mask_c)::value;
         const int j0 = kt * 32;
         const bf16x8a k0 = __builtin_bit_cast(bf16x8a, kp[kt * 128 + ksw0]);
         const bf16x8a k1 = __builtin_bit_cast(bf16x8a, kp[kt * 128 + ksw1]);
         const bf16x8a v0 = __builtin_bit_cast(bf16x8a, vp[kt * 4]);
         const bf16x8a v1 = __builtin_bit_cast(bf16x8a, vp[kt * 4 + 2]);
-        f32x16 s;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = -ref;
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0, s, 0, 0, 0);
+        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0, nref, 0, 0, 0);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q1, s, 0, 0, 0);
-        if (j0 + 32 > T) {
+        if constexpr (MASK) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 s[r] = (j < T) ? s[r] : -1.0e30f;
             }
         }
-        float mx = fmaxf(s[0], s[1]);
+        float mx = __builtin_fmaxf(__builtin_fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
-        for (int r = 2; r < 16; r += 2) mx = __builtin_fmaxf(mx, __builtin_fmaxf(s[r], s[r + 1]));
+        for (int r = 3; r < 15; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[r]), s[r + 1]);   // (v_max3_f32)
+        mx = fmaxf(mx, s[15]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const bool rebase = kt == 0 || mx > 16.0f;
         if (__builtin_amdgcn_ballot_w64(rebase)) {
+            asm volatile("; rebase (rare)");               // (a statement the compiler may not speculate: without it the 56 instructions below were
+                                                           //  if-converted into EVERY tile's path with d = 0, f = 1 — ISA, round 4)
             const float d = rebase ? mx : 0.f;             // this lane's reference moves up (or, first tile, to) by d
             const float f = kt == 0 ? 0.f : __builtin_amdgcn_exp2f(-d);
-            ref += d;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] -= d; o[r] *= f; ls[r] *= f; }
+            for (int r = 0; r < 16; ++r) { s[r] -= d; nref[r] -= d; o[r] *= f; ls[r] *= f; }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
@@ -458,7 +459,10 @@ __global__ __launch_bounds__(64 * QT, (QT == 10 ? 5 : (QT == 8 ? 4 : 2))) void b
         ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pa, ls, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o, 0, 0, 0);
         ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb, ls, 0, 0, 0);
-    }
+    };
+    const int nfull = (T & 31) ? nkt - 1 : nkt;
+    for (int kt = 0; kt < nfull; ++kt) key_tile(kt, std::false_type{});
+    if (nfull < nkt) key_tile(nkt - 1, std::true_type{});
     const float invL = 1.0f / ls[0];        // (every row of the ones-product is the query's sum over all keys)
     const int i = i0 + lt;
     if (i < T) {   // registers 4 q .. 4 q + 3 are channels 8 q + 4 lh + (0 .. 3) of the head: four consecutive bf16 of the query's token-major row
