@@ -200,15 +200,19 @@ __device__ __forceinline__ void gn_finish(const GnP sg, rsrc_t rp, int c_lo, int
     const int nparts = sg.gn_nparts;
     const int tail = sg.Tin - (nparts - 1) * 32;
     float s1 = 0.f, s2 = 0.f, sm = 0.f;
+    // Tokens of partial tile pi = clamp(Tin - 32 pi, 0, 32): 32, the tail, or 0 past the end — as arithmetic on a per-lane base (one subtract + one
+    // v_med3 per tile) instead of two compares and two selects; tiles past the end were requested out of range and read as (0, 0), so their
+    // M2 adds an exact zero without a select, and cnt = 0 keeps s1 / s2 bit for bit (round 4: the selects were ~60 of this kernel family's 720
+    // VALU instructions per wave, on the critical path behind the statistics loads).  Lanes with ch >= cw compute on and are never stored.
+    const float cnt_base = (float)(sg.Tin - 32 * ph);
+    (void)tail;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const int pi = ph + nph * r;
-        const bool ok = chok && (pi < nparts);
-        const float cnt = ok ? ((pi == nparts - 1) ? (float)tail : 32.f) : 0.f;
+        const float cnt = __builtin_amdgcn_fmed3f(cnt_base - (float)(32 * nph * r), 0.f, 32.f);
         const float d = L.v[r].x - L.ref;
         s1 = fmaf(cnt, d, s1);
         s2 = fmaf(cnt * d, d, s2);
-        sm += ok ? L.v[r].y : 0.f;
+        sm += L.v[r].y;
     }
     for (int r0 = 10; ph + nph * r0 < nparts; r0 += 10) {  // long sequences: further rounds of 10 tiles
         float2 v[10];
@@ -218,15 +222,14 @@ __device__ __forceinline__ void gn_finish(const GnP sg, rsrc_t rp, int c_lo, int
             const bool ok = chok && (pi < nparts);
             v[r] = bload2(rp, ok ? (pi * sg.ct + c) * 8 : (int)0x80000000, 0);
         }
+        const float cb = cnt_base - (float)(32 * nph * r0);
 #pragma unroll
         for (int r = 0; r < 10; ++r) {
-            const int pi = ph + nph * (r0 + r);
-            const bool ok = chok && (pi < nparts);
-            const float cnt = ok ? ((pi == nparts - 1) ? (float)tail : 32.f) : 0.f;
+            const float cnt = __builtin_amdgcn_fmed3f(cb - (float)(32 * nph * r), 0.f, 32.f);
             const float d = v[r].x - L.ref;
             s1 = fmaf(cnt, d, s1);
             s2 = fmaf(cnt * d, d, s2);
-            sm += ok ? v[r].y : 0.f;
+            sm += v[r].y;
         }
     }
     if (nph == 2) {
@@ -284,14 +287,15 @@ __device__ __forceinline__ void gn20_finish(const GnP sg, rsrc_t rp, int c_lo, i
     const int nparts = sg.gn_nparts;
     const int tail = sg.Tin - (nparts - 1) * 32;
     float s1 = 0.f, s2 = 0.f, sm = 0.f;
+    const float cnt_base = (float)sg.Tin;   // (counts by arithmetic, zeros from the out-of-range loads: see gn_finish)
+    (void)tail;
 #pragma unroll
     for (int r = 0; r < 20; ++r) {
-        const bool ok = chok && (r < nparts);
-        const float cnt = ok ? ((r == nparts - 1) ? (float)tail : 32.f) : 0.f;
+        const float cnt = __builtin_amdgcn_fmed3f(cnt_base - (float)(32 * r), 0.f, 32.f);
         const float d = L.v[r].x - L.ref;
         s1 = fmaf(cnt, d, s1);
         s2 = fmaf(cnt * d, d, s2);
-        sm += ok ? L.v[r].y : 0.f;
+        sm += L.v[r].y;
     }
     for (int r0 = 20; r0 < nparts; r0 += 10) {   // long sequences: further rounds of 10 tiles
         float2 v[10];
@@ -302,13 +306,11 @@ __device__ __forceinline__ void gn20_finish(const GnP sg, rsrc_t rp, int c_lo, i
         }
 #pragma unroll
         for (int r = 0; r < 10; ++r) {
-            const int pi = r0 + r;
-            const bool ok = chok && (pi < nparts);
-            const float cnt = ok ? ((pi == nparts - 1) ? (float)tail : 32.f) : 0.f;
+            const float cnt = __builtin_amdgcn_fmed3f(cnt_base - (float)(32 * (r0 + r)), 0.f, 32.f);
             const float d = v[r].x - L.ref;
             s1 = fmaf(cnt, d, s1);
             s2 = fmaf(cnt * d, d, s2);
-            sm += ok ? v[r].y : 0.f;
+            sm += v[r].y;
         }
     }
     float* sc = scratch;            // [64][3]
