@@ -21,7 +21,12 @@
 //     by DPP) and park the tile in the other LDS buffer, as STRAIGHT-LINE code (compile-time transform, clamped addresses instead of
 //     branches: with loads inside run-time branches hipcc's wait counts fall back to vmcnt(0) and every use of a prefetched register
 //     also waits for the loads issued after it);
-//   * ONE workgroup barrier per tile (LDS data only: s_waitcnt lgkmcnt(0) + s_barrier, global loads stay in flight across it).
+//   * ONE workgroup barrier per tile (LDS data only: s_waitcnt lgkmcnt(0) + s_barrier, global loads stay in flight across it);
+//   * prologue (later in round 4, from the stamps in profiles/r04g_rgemm_clocks_before.txt / r04h_rgemm_clocks.txt): loads requested in a launch's
+//     first clocks come back 8-16k clocks later whatever their number, so MFMA waves 0-3 request the first samples' GroupNorm partials FIRST
+//     (one 48-channel slice each: one round trip), then four rounds of weight rows; the first barrier (tables published) sits BEFORE the bulk of
+//     the weights and the helpers park the first tile while the weights stream; a new sample's tables inside the loop stay with the helpers;
+//   * the 16-byte result stores are agent-scope (sc1: written through L2): the launch does not end with 15-59 MB dirty (-2 % per step).
 //
 // One workgroup of 8 waves per CU (<= 256 VGPRs each), 64 KB of LDS, <= 256 workgroups for the whole batch, each walking over its
 // contiguous share of the 32-token tiles.  All 192 columns of a row tile are produced by ONE workgroup: the operand transform runs once
