@@ -480,6 +480,12 @@ def run(args):
                     line[name + "_value"] = sec["value"]
                     line[name + "_ms_per_denoise_step"] = sec["ms_per_denoise_step"]
                     line[name + "_clip_groups"] = sec["clip_groups"]
+                    rf = sec.get("roofline") or {}
+                    if rf:   # the configuration's own roofline figures (dominant kernel family against the roof that binds it)
+                        line[name + "_roofline_frac"] = rf.get("frac")
+                        line[name + "_roofline_bound"] = rf.get("bound")
+                        line[name + "_hbm_frac_step"] = (rf.get("unet_step") or {}).get("hbm_frac")
+                        line[name + "_mfma_frac_step"] = (rf.get("unet_step") or {}).get("mfma_frac")
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only: other ranks would sit in the final barrier
             line["cpu_baseline"] = cpu_baseline(args, T, Ta)
         print(json.dumps(line), flush=True)
