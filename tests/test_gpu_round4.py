@@ -139,3 +139,34 @@ def test_device_eta_noise_50_steps_four_clips_two_groups_vs_oracle(model, dev):
     err = float((r.cpu() - ref.result).abs().max())
     print(f"device eta noise, 4 clips in two groups, 50 free-running steps: max abs err vs oracle {err:.3e}")
     assert err <= 2e-3
+
+
+@pytest.mark.parametrize("gs", [1.0, 2.0])
+def test_out_sched_tm_matches_channel_major_out_path(model, dev, gs):
+    """The bf16 large-batch loop's last kernel on the token-major hidden state (out_sched_tm_kernel, with and without guidance, with the
+    editing mask and eta noise) against the same loop with said_debug_option("out_tm", 0) — round 3's route: the last block's proj_out written
+    channel-major fp32 by xgemm_kernel, then out_sched_kernel.  Same scheduler arithmetic; the model output differs by the bf16 rounding of the
+    last hidden state and of out.2's weights: 2 steps stay within the bf16 per-step bound."""
+    B, T, N = 24, 600, 2
+    ctx = synth.synth_latents(960, (B, T, 768)).to(dev)
+    init = synth.synth_latents(961, (B, T, 32)).abs().clamp(0, 1).to(dev)
+    en = synth.synth_latents(962, (B, T, 32)).to(dev)
+    mask = torch.zeros(B, T, 32, device=dev)
+    mask[:, 100:300] = 1
+    wav = torch.zeros(B, T * 16000 // 60, device=dev)
+    res = {}
+    try:
+        model.set_mfma_dtype("bf16")
+        for ot in (0, 1):
+            model._get_engine(2 * B, T).debug_option("out_tm", ot)
+            torch.manual_seed(5)
+            res[ot] = model.inference(wav, audio_embedding=ctx, num_inference_steps=N, guidance_scale=gs, eta=1.0, init_samples=init, mask=mask,
+                                      edit_noise=en).result
+        nodes = model._eng.graph_num_nodes()
+    finally:
+        model._eng.debug_option("out_tm", -1)
+        model.set_mfma_dtype("fp32")
+    d = float((res[0] - res[1]).abs().max())
+    print(f"out_sched_tm vs channel-major out path, guidance {gs}: max |diff| after {N} steps {d:.3e} ({nodes} graph nodes per step)")
+    assert torch.isfinite(res[1]).all() and d <= 0.087
+    assert torch.equal(res[1][:, 100:300], res[0][:, 100:300]) or float((res[1][:, 100:300] - res[0][:, 100:300]).abs().max()) <= 0.087
