@@ -247,6 +247,14 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1", grou
            "by_kernel": {k: {"us": round(v["us"], 2), "launches": v["launches"],
                              "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1),
                              "TFLOPs": round(v["flops"] / (v["us"] * 1e-6) / 1e12, 2)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"])}}
+    # `achieved` / `frac` are per-launch ISOLATED replays (HIP events around each launch of said_profile_unet); inside the real step graph the
+    # launches run a little slower (cold instruction cache, the previous launch's write-back).  The loop itself gives the in-situ total:
+    # in_situ_scale = loop time per step / sum of the isolated launch times (one clip group only); the per-kernel in-situ figures of a
+    # rocprofv3 trace of this command are under profiles/ (r04h_kernel_trace_*.txt)
+    if sum_us > 0 and groups == 1:   # (concurrent clip groups share the chip: a launch's in-situ time is then not comparable with its isolated one)
+        scale = (step_ms * 1e3) / sum_us
+        out["in_situ_scale"] = round(scale, 4)
+        out["frac_in_situ_est"] = round(out["frac"] / max(scale, 1.0), 5)
     # HBM traffic from the PMC counters is collected in its own rocprofv3 pass (scripts/gpu_pmc.sh; --pmc must not be
     # combined with tracing) and committed: it is NOT measured in this run, hence the explicit source label
     tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
