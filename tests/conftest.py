@@ -2,6 +2,12 @@ import os
 import sys
 
 import pytest
+import torch
+
+# The CPU oracle runs thousands of small-tensor ops (a 1 s clip is 60 x 192 activations): on a 256-thread host torch's default — one thread per
+# logical CPU — spends its time handing out work (the 1000-step chain of test_gpu_parity.py took 146-222 s by box).  16 threads are as fast as
+# any count here and keep the suite's duration independent of the host.
+torch.set_num_threads(min(16, torch.get_num_threads()))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
