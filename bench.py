@@ -125,7 +125,7 @@ def cpu_baseline(args, T, Ta):
     xw = torch.cat([lat] * 2) if do_cfg else lat
     tw = sch.timesteps[:1].repeat(2 if do_cfg else 1)
     best = None
-    for nt in sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 32)}, reverse=True):
+    for nt in sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 32), min(avail, 16), min(avail, 8)}, reverse=True):
         torch.set_num_threads(nt)
         ou.unet1d_forward(sd_u, xw, tw, ctx)  # warm
         t0 = time.perf_counter()
