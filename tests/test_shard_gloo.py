@@ -182,3 +182,18 @@ def test_sharded_inference_uneven_equals_one_rank():
         for rank, got, seen in res:
             assert torch.equal(torch.from_numpy(got), want), (world, n_items, rank)
             assert seen == [list(shard.shard_bounds(n_items, world)[rank])]      # ONE call, own shard only
+
+
+def test_bench_under_torch_distributed_run_two_ranks_gloo():
+    """The driver's launch form for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus 2 ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) — here with the CPU stand-in path over gloo:
+    ONE JSON line from rank 0, global clip order, n_gpus = 2."""
+    port = shard.free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry_run_gloo", "--seconds", "0.5", "--num_steps", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["checksum_ok"] and j["clip_ranges"] == [[0, 0], [1, 1]]
