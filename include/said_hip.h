@@ -227,7 +227,7 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
 
 /* Test-only switches of one context (the shipped library reads no environment variables):
  *   "unet_tgemm_min_tokens"  tokens per launch from which the UNet takes the token-major GEMM path, both precisions
- *                            (< 0: restore the measured defaults 5800 bf16 / 10000 fp32)
+ *                            (< 0: restore the measured defaults 3000 bf16 / 10000 fp32)
  *   "audio_chunk"            clips per audio-encoder pass (default 32)
  *   "steps_per_graph"        denoise steps captured per hipGraph (default 10)
  *   "tm_acts"                large batches: token-major activations (bf16 / fp32) between the UNet kernels, GroupNorm / LayerNorm applied inside

@@ -169,7 +169,9 @@ struct said_ctx {
     bool unet_fgemm = true;   // SAID_NO_UNET_FGEMM=1: the same for the fp32 mode's token-major path (fgemm_kernel)
     // tokens per launch from which the token-major GEMM path is taken (measured crossovers, scripts/gpu_r2_w.sh: bf16 between 4800
     // and 6000 tokens, fp32 between 9600 and 10800); SAID_UNET_TGEMM_MIN overrides both
-    long long unet_tgemm_min_tokens = 5800, unet_fgemm_min_tokens = 10000;
+    // (bf16: 3000 since round 4 — with the persistent kernels the crossover sits between 2400 rows (2 clips x 600 frames under guidance: 21.9 vs 22.6 ms per
+    //  50 steps) and 3600 (3 clips: 30.3 vs 22.7 ms); rounds 2-3: 5800)
+    long long unet_tgemm_min_tokens = 3000, unet_fgemm_min_tokens = 10000;
     long long unet_fgemm_min_concurrent = 6000;   // fp32 threshold while other contexts' loops run beside this one (said_loop_params::concurrent)
     bool cur_concurrent = false;
     int spg_limit = 10;      // denoise steps captured per graph
@@ -2297,7 +2299,7 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
     if (!ctx || !name) return -1;
     const std::string k = name;
     if (k == "unet_tgemm_min_tokens") {
-        ctx->unet_tgemm_min_tokens = value < 0 ? 5800 : value;
+        ctx->unet_tgemm_min_tokens = value < 0 ? 3000 : value;
         ctx->unet_fgemm_min_tokens = value < 0 ? 10000 : value;
     } else if (k == "audio_chunk") {
         if (value < 1) return fail(ctx, "audio_chunk must be >= 1");

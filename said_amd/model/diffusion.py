@@ -275,8 +275,9 @@ class SAID(ABC, nn.Module):
             for g in (3, 2):
                 if batch_size >= g and (batch_size // g) * tokens_per_clip >= 12000:
                     return g
-        # At least two clips per group (single short clips side by side: +5 %); bf16 from 8000 rows on runs the persistent kernels: one group.
-        if batch_size >= 4 and batch_size * tokens_per_clip < (8000 if bf else 10000):
+        # At least two clips per group (single short clips side by side: +5 %); bf16 from 3000 rows on runs the persistent kernels: one group
+        # (3 clips x 600 frames under guidance: 22.7 ms per 50 steps unsplit on them against 30.3 on the small-batch kernels).
+        if batch_size >= 4 and batch_size * tokens_per_clip < (3000 if bf else 10000):
             return 2
         return 1
 

@@ -658,7 +658,7 @@ def test_bf16_audio_encoder_vs_fp32_oracle(model, w2v_sd, dev, Ta, frames):
 
 
 def test_bf16_unet_large_batch_token_major_gemm_path(model, unet_sd, dev):
-    """bf16 mode at >= 5800 tokens per launch: the ResBlock convolutions, q/k/v, GEGLU and the folded proj_out run on the
+    """bf16 mode at >= 3000 tokens per launch (5800 until round 4): the ResBlock convolutions, q/k/v, GEGLU and the folded proj_out run on the
     token-major bf16 GEMM (tgemm.hip: prep kernel + v_mfma_f32_32x32x16_bf16, channel-major fp32 results with GroupNorm
     partials).  Error against the FP32 ORACLE on the first, a middle and the last sample, and against the small-batch bf16
     path (same rounding points, different summation order)."""
