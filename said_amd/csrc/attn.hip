@@ -37,6 +37,29 @@ static __device__ __forceinline__ bf16x8a pk_bf16x8(const f32x4a a, const f32x4a
     return v;
 }
 
+// Split-fp16 operands (round 4; PM == 2): x ~= h + 2^-11 l with h = RN16(x), l = RN16((x - h) * 2^11) — the remainder is stored at h's own
+// magnitude, so both halves are normal fp16 numbers for 2^-14 <= |x| < 65504 and x is represented to 2^-22 relative (22 significand bits + the
+// remainder's sign; below 2^-14 the pair still resolves 2^-36 absolute where the matrix pipe keeps fp16 denormals) — and
+//   a . b ~= h_a . h_b + 2^-11 (h_a . l_b + l_a . h_b)
+// on v_mfma_f32_32x32x16_f16: three 8-pass MFMAs per 16 contraction steps against eight 16-pass v_mfma_f32_32x32x2_f32 (5.3 x fewer
+// matrix-pipe clocks).  Accumulation is fp32 as before; the cross terms have their own accumulator (merged with one fma per element).  The
+// dropped term 2^-22 l_a . l_b is below the representation error.  Domain: |x| < 65504 (q, k, v are projections of LayerNorm'ed rows; an
+// overflow shows as inf / NaN).
+typedef _Float16 f16x8a __attribute__((ext_vector_type(8)));
+struct SplitH { f16x8a h, l; };
+static __device__ __forceinline__ SplitH split_f16x8(const f32x4a a, const f32x4a b) {
+    SplitH r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 ha = (_Float16)a[i], hb = (_Float16)b[i];
+        r.h[i] = ha;
+        r.h[4 + i] = hb;
+        r.l[i] = (_Float16)((a[i] - (float)ha) * 2048.f);      // (a - ha is exact in fp32)
+        r.l[4 + i] = (_Float16)((b[i] - (float)hb) * 2048.f);
+    }
+    return r;
+}
+
 // The arguments are 14 scalar kernel parameters — exactly what the hardware preloads into SGPRs (build.py compiles this
 // file with -amdgpu-kernarg-preload-count=14) — so the first operand request needs no scalar-memory round trip.
 struct AttnView {
@@ -56,12 +79,14 @@ struct AttnView {
 // all keys, instead of splitting the keys of one query tile.  They walk the same K / V tiles in step, so a tile is fetched
 // from L2 once per workgroup and the other waves hit in the CU's L1: at large batch this kernel is bound by the bytes a CU can
 // keep in flight (every 32-query workgroup re-reads all K and V of its head: 62 B per kFLOP), not by MFMA or VALU work.
-template <int ND, int KS, bool BF, int QW = 1>
+// PM: product mode — 0: v_mfma_f32_32x32x2_f32 on the fp32 operands, 1: bf16 operands (said_set_precision), 2: split-fp16 operands (above).
+template <int ND, int KS, int PM, int QW = 1>
 __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, const float* pv, float* po, int v_bstride, int o_bstride, int ppitch,
                                                        int pT, int pheads, int prows, float pscale, int pb0, int po_mode) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AttnView a = {pqk, pv, po, v_bstride, o_bstride, ppitch, pT, pheads, prows, pscale, pb0, po_mode};
     constexpr int D = 32 * ND, NQ = D / 8;   // NQ dwordx4 per lane and operand row
+    constexpr bool BF = PM == 1, SP = PM == 2;
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     static_assert(QW == 1 || KS == 1, "query-tile waves do not split keys");
     const int w_all = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,12 +106,18 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
     bf16x8a qh[NQ / 2];   // bf16 mode: the query fragments are converted once, not once per key tile
 #pragma unroll
     for (int q = 0; q < NQ / 2; ++q) qh[q] = pk_bf16x8(qf[2 * q], qf[2 * q + 1]);
+    SplitH qs[NQ / 2];    // split mode: likewise
+#pragma unroll
+    for (int q = 0; q < NQ / 2; ++q) qs[q] = split_f16x8(qf[2 * q], qf[2 * q + 1]);
     float m = -1.0e30f, lsum = 0.f;
-    f32x16 o[ND];
+    f32x16 o[ND], ox[SP ? ND : 1];   // ox: the split mode's cross terms (x 2^11)
 #pragma unroll
     for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[nd][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            o[nd][r] = 0.f;
+            if (SP) ox[SP ? nd : 0][r] = 0.f;
+        }
 
     const int nkt = (T + 31) >> 5;
     // K and V fragments of a key tile are fetched together and one tile ahead of the MFMAs that use them
@@ -107,8 +138,24 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        if constexpr (SP) {
+            SplitH ks[NQ / 2];
 #pragma unroll
-        for (int dp = 0; dp < ND * 16; ++dp) {
+            for (int q = 0; q < NQ / 2; ++q) ks[q] = split_f16x8(kf[2 * q], kf[2 * q + 1]);
+            f32x16 sx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sx[r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ / 2; ++q) {
+                sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].l, qs[q].h, sx, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].h, qs[q].h, s, 0, 0, 0);
+                sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].h, qs[q].l, sx, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = fmaf(sx[r], 0x1p-11f, s[r]);
+        }
+#pragma unroll
+        for (int dp = 0; dp < (SP ? 0 : ND * 16); ++dp) {
             if constexpr (BF) {
                 if ((dp & 7) == 0)
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pk_bf16x8(kf[dp >> 2], kf[(dp >> 2) + 1]), qh[dp >> 3], s, 0, 0, 0);
@@ -184,11 +231,43 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
             for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[nd][r] *= alpha;
+                for (int r = 0; r < 16; ++r) {
+                    o[nd][r] *= alpha;
+                    if (SP) ox[SP ? nd : 0][r] *= alpha;
+                }
         }
+        }
+        if constexpr (SP) {
+            // keys past T: p is exactly 0, but the never-written columns of v hold whatever the workspace held — finite, yet not
+            // necessarily inside fp16's range (0 x inf): zeroed in the one tile that has such keys
+            f32x4a vz[ND][4];
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vz[nd][q] = vf[nd][q];
+            if (j0 + 32 > T) {
+#pragma unroll
+                for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vz[nd][q][e] = (j0 + 8 * q + 4 * lh + e < T) ? vz[nd][q][e] : 0.f;
+            }
+#pragma unroll
+            for (int m8 = 0; m8 < 2; ++m8) {
+                const f32x4a p0 = {s[8 * m8], s[8 * m8 + 1], s[8 * m8 + 2], s[8 * m8 + 3]}, p1 = {s[8 * m8 + 4], s[8 * m8 + 5], s[8 * m8 + 6], s[8 * m8 + 7]};
+                const SplitH ps2 = split_f16x8(p0, p1);
+#pragma unroll
+                for (int nd = 0; nd < ND; ++nd) {
+                    const SplitH vs2 = split_f16x8(vz[nd][2 * m8], vz[nd][2 * m8 + 1]);
+                    ox[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vs2.l, ps2.h, ox[nd], 0, 0, 0);
+                    o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vs2.h, ps2.h, o[nd], 0, 0, 0);
+                    ox[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vs2.h, ps2.l, ox[nd], 0, 0, 0);
+                }
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
+        for (int r = 0; r < (SP ? 0 : 16); ++r)
 #pragma unroll
             for (int nd = 0; nd < ND; ++nd) {
                 if constexpr (BF) {
@@ -282,6 +361,12 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
         }
     }
     lsum += __shfl_xor(lsum, 32);
+    if constexpr (SP) {
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[nd][r] = fmaf(ox[nd][r], 0x1p-11f, o[nd][r]);
+    }
 
     // ---- merge the KS partial states ----
     float* ml = sm_w;                 // [KS][2][32]
@@ -500,7 +585,7 @@ void launch_battn(const AttnArgs& a, int batch, hipStream_t s, int qt) {
                        reinterpret_cast<unsigned short*>(a.o), (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T, a.heads, a.rows, a.scale);
 }
 
-template <int ND, int KS, bool BF, int QW = 1>
+template <int ND, int KS, int BF, int QW = 1>
 static void launch_attn_one(const AttnArgs& a, int batch, hipStream_t s) {
     constexpr int D_ = 32 * ND;
     const int smem = (QW * (KS * 64 + KS * ND * 16 * 64) + (QW > 1 ? 2 * (32 * (D_ + 4) + D_ * 36) : 0)) * (int)sizeof(float);
@@ -509,32 +594,41 @@ static void launch_attn_one(const AttnArgs& a, int batch, hipStream_t s) {
     hipLaunchKernelGGL((attn_kernel<ND, KS, BF, QW>), grid, dim3(64 * KS * QW), smem, s, a.qk, a.v, a.o, (int)a.v_bstride, (int)a.o_bstride, a.pitch, a.T,
                        a.heads, a.rows, a.scale, a.b0, a.o_mode);
 }
-template <int ND, int KS, bool BF, int QW = 1>
+template <int ND, int KS, int BF, int QW = 1>
 static void configure_attn_one() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<ND, KS, BF, QW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
+}
+template <int PM>
+static void configure_attn_modes() {
+    configure_attn_one<1, 8, PM>(); configure_attn_one<1, 4, PM>(); configure_attn_one<1, 1, PM>(); configure_attn_one<1, 1, PM, 4>();
+    configure_attn_one<2, 8, PM>(); configure_attn_one<2, 4, PM>(); configure_attn_one<2, 1, PM>(); configure_attn_one<2, 1, PM, 4>();
 }
 void configure_attn_kernels() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
-    configure_attn_one<1, 8, false>(); configure_attn_one<1, 8, true>(); configure_attn_one<1, 4, false>(); configure_attn_one<1, 4, true>(); configure_attn_one<1, 1, false>(); configure_attn_one<1, 1, true>();
-    configure_attn_one<1, 1, false, 4>(); configure_attn_one<1, 1, true, 4>(); configure_attn_one<2, 1, false, 4>(); configure_attn_one<2, 1, true, 4>();
-    configure_attn_one<2, 8, false>(); configure_attn_one<2, 8, true>(); configure_attn_one<2, 4, false>(); configure_attn_one<2, 4, true>(); configure_attn_one<2, 1, false>(); configure_attn_one<2, 1, true>();
+    configure_attn_modes<0>(); configure_attn_modes<1>(); configure_attn_modes<2>();
 }
 
-void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s, bool bf16) {
+template <int PM>
+static bool launch_attn_mode(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s) {
     if (KS == -4) {   // four query tiles per workgroup, no key split (large batches)
-        if (head_dim == 32) return bf16 ? launch_attn_one<1, 1, true, 4>(a, batch, s) : launch_attn_one<1, 1, false, 4>(a, batch, s);
-        if (head_dim == 64) return bf16 ? launch_attn_one<2, 1, true, 4>(a, batch, s) : launch_attn_one<2, 1, false, 4>(a, batch, s);
+        if (head_dim == 32) return launch_attn_one<1, 1, PM, 4>(a, batch, s), true;
+        if (head_dim == 64) return launch_attn_one<2, 1, PM, 4>(a, batch, s), true;
     }
-    if (head_dim == 32 && KS == 8) return bf16 ? launch_attn_one<1, 8, true>(a, batch, s) : launch_attn_one<1, 8, false>(a, batch, s);
-    if (head_dim == 32 && KS == 4) return bf16 ? launch_attn_one<1, 4, true>(a, batch, s) : launch_attn_one<1, 4, false>(a, batch, s);
-    if (head_dim == 32 && KS == 1) return bf16 ? launch_attn_one<1, 1, true>(a, batch, s) : launch_attn_one<1, 1, false>(a, batch, s);
-    if (head_dim == 64 && KS == 8) return bf16 ? launch_attn_one<2, 8, true>(a, batch, s) : launch_attn_one<2, 8, false>(a, batch, s);
-    if (head_dim == 64 && KS == 4) return bf16 ? launch_attn_one<2, 4, true>(a, batch, s) : launch_attn_one<2, 4, false>(a, batch, s);
-    if (head_dim == 64 && KS == 1) return bf16 ? launch_attn_one<2, 1, true>(a, batch, s) : launch_attn_one<2, 1, false>(a, batch, s);
-    launch_fault("unsupported attention config D=%d KS=%d", head_dim, KS);
+    if (head_dim == 32 && KS == 8) return launch_attn_one<1, 8, PM>(a, batch, s), true;
+    if (head_dim == 32 && KS == 4) return launch_attn_one<1, 4, PM>(a, batch, s), true;
+    if (head_dim == 32 && KS == 1) return launch_attn_one<1, 1, PM>(a, batch, s), true;
+    if (head_dim == 64 && KS == 8) return launch_attn_one<2, 8, PM>(a, batch, s), true;
+    if (head_dim == 64 && KS == 4) return launch_attn_one<2, 4, PM>(a, batch, s), true;
+    if (head_dim == 64 && KS == 1) return launch_attn_one<2, 1, PM>(a, batch, s), true;
+    return false;
+}
+// mode: 0 fp32 MFMA, 1 bf16 operands, 2 split-fp16 operands (attn_kernel's PM)
+void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s, int mode) {
+    const bool ok = mode == 1 ? launch_attn_mode<1>(a, batch, head_dim, KS, s) : (mode == 2 ? launch_attn_mode<2>(a, batch, head_dim, KS, s) : launch_attn_mode<0>(a, batch, head_dim, KS, s));
+    if (!ok) launch_fault("unsupported attention config D=%d KS=%d", head_dim, KS);
 }
 
 }  // namespace said

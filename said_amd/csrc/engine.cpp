@@ -159,6 +159,8 @@ struct said_ctx {
     bool xclk_on = false;
     int battn = -1;           // round 4: bf16-operand self-attention with a head's K / V resident in LDS (attn.hip: battn_kernel) behind rgemm's q/k/v;
                               // 0: attn_kernel on fp32 operands (said_debug_option "battn")
+    int attn_split = -1;      // round 4: fp32 mode runs both attention products on split-fp16 operands (attn.hip: PM == 2; 22-bit significands, fp32
+                              // accumulation); 0: v_mfma_f32_32x32x2_f32 on the fp32 operands (said_debug_option "attn_split")
     int rgemm = -1;           // round 4: register-stationary, wave-specialised persistent GEMMs (rgemm.hip) wherever launch_rgemm serves the shape
                               // (bf16 mode: 192-wide GEMMs with K <= 576, q/k/v); 0: off (said_debug_option "rgemm")
     long long n_rgemm = 0;
@@ -576,7 +578,7 @@ void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hi
         if (trace_on()) { fprintf(stderr, "[said] attn #%d D=%d KS=%d T=%d batch=%d\n", c->dbg_count - 1, head_dim, KS, a.T, batch); fflush(stderr); }
         AttnArgs a2 = a;
         a2.b0 = c->cur_b0;
-        launch_attn(a2, batch, head_dim, KS, s, c->bf16_mode);
+        launch_attn(a2, batch, head_dim, KS, s, c->bf16_mode ? 1 : (c->attn_split != 0 ? 2 : 0));
         if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
     }
 }
@@ -2338,6 +2340,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->tm_acts = value < 0 ? -1 : (value != 0);
     } else if (k == "rgemm") {
         ctx->rgemm = value < 0 ? -1 : (value != 0);
+    } else if (k == "attn_split") {
+        ctx->attn_split = value < 0 ? -1 : (value != 0);
     } else if (k == "battn") {
         ctx->battn = value < 0 ? -1 : (int)value;   // 0: off, 4 / 8: query tiles per workgroup (experiments), else on
     } else {
@@ -2650,7 +2654,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     if (aks == -4) {   // the key-split-free variant writes the out_proj operand itself: token-major bf16 [clip][frame][768]
                         a.o = reinterpret_cast<float*>(ctx->bO); a.o_bstride = Fr; a.o_mode = 2;
                     }
-                    launch_attn(a, nb, W2V_HD, aks, s, true);
+                    launch_attn(a, nb, W2V_HD, aks, s, 1);
                     if (aks != -4) launch_cm_to_tm_bf16(ctx->aO, 2 * hs, Fp, ctx->bO, hsT, nb, Fr, W2V_H, s);
                 }
                 {   // out_proj + residual, then layer_norm
@@ -2768,7 +2772,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                 a.qk = ctx->aQK; a.v = ctx->aVT; a.o = ctx->aO;
                 a.v_bstride = hs; a.o_bstride = 2 * hs; a.b0 = 0;
                 a.pitch = Fp; a.T = Fr; a.heads = W2V_HEADS; a.rows = vt_rows; a.scale = 0.125f;
-                launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : (tt * W2V_HEADS <= 8192 ? 4 : 1), s);
+                launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : (tt * W2V_HEADS <= 8192 ? 4 : 1), s, ctx->attn_split != 0 ? 2 : 0);
             }
             {
                 GemmArgs a = mkargs(Fr, W2V_H);

@@ -160,7 +160,7 @@ struct AttnArgs {
 
 // tile shape selection: NB 32-row tiles per workgroup, KS waves splitting K
 void launch_gemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s);
-void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s, bool bf16 = false);   // bf16: both products on bf16 MFMA
+void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s, int mode = 0);   // mode: 0 fp32 MFMA, 1 bf16 operands, 2 split-fp16 operands
 // LDS-staged UNet GEMM (gemm_lds.hip): same arguments; only for shapes ugemm_supports() accepts
 // bf16 = true: multiply in bf16 (v_mfma_f32_32x32x8_bf16_1k; needs Seg::w2), everything else stays fp32
 // tt > 1: multi-tile workgroups (each walks over tt consecutive 32-token tiles keeping its weights in registers)

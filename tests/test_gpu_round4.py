@@ -170,3 +170,65 @@ def test_out_sched_tm_matches_channel_major_out_path(model, dev, gs):
     print(f"out_sched_tm vs channel-major out path, guidance {gs}: max |diff| after {N} steps {d:.3e} ({nodes} graph nodes per step)")
     assert torch.isfinite(res[1]).all() and d <= 0.087
     assert torch.equal(res[1][:, 100:300], res[0][:, 100:300]) or float((res[1][:, 100:300] - res[0][:, 100:300]).abs().max()) <= 0.087
+
+
+# ---------------------------------------------------------------- split-fp16 attention products (fp32 mode)
+def _f64_truth(unet_sd, x, ts, c):
+    """The oracle's op sequence evaluated in float64 on the same fp32 inputs and weights (its `.float()` casts redirected): the yardstick both
+    product modes are measured against — the fp32 oracle itself sits 1e-6 of the output range away from it."""
+    from unittest import mock
+    sd64 = {k: v.double() for k, v in unet_sd.items()}
+    with mock.patch.object(torch.Tensor, "float", torch.Tensor.double):
+        return ou.unet1d_forward(sd64, x.double(), ts, c.double())
+
+
+@pytest.mark.parametrize("B,T", [(1, 600), (2, 37), (12, 600)])
+def test_split_fp16_attention_is_as_close_to_float64_as_fp32_mfma(model, unet_sd, dev, B, T):
+    """fp32 mode runs the two self-attention products on split-fp16 operands (attn.hip, PM == 2: x = h + l, three fp16 MFMAs per fp32 one,
+    fp32 accumulation).  Statement: against the float64 evaluation of the same network its UNet output is no further away than the
+    v_mfma_f32_32x32x2_f32 path's (said_debug_option("attn_split", 0)) beyond a factor 1.5, and both stay inside 2e-5 of the output range
+    (the stated single-evaluation tolerance is 1e-4).  (12, 600) takes the large-batch kernels (four query tiles per workgroup)."""
+    x = synth.synth_latents(700 + B, (B, T, 32))
+    c = synth.synth_latents(800 + B, (B, T, 768))
+    ts = (torch.arange(B) * 83 + 999) % 1000
+    nref = min(B, 2)
+    truth = _f64_truth(unet_sd, x[:nref], ts[:nref], c[:nref])
+    scale = float(truth.abs().max())
+    err = {}
+    try:
+        for sp in (0, 1):
+            model._get_engine(2 * B, T).debug_option("attn_split", sp)
+            out = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+            err[sp] = float((out[:nref].double() - truth).abs().max()) / scale
+    finally:
+        model._eng.debug_option("attn_split", -1)
+    print(f"\n[attn_split] B={B} T={T}: fp32 MFMA {err[0]:.3e}, split fp16 {err[1]:.3e} of the output range")
+    assert err[0] <= 2e-5 and err[1] <= 2e-5
+    assert err[1] <= 1.5 * err[0] + 1e-6
+
+
+def test_split_fp16_attention_small_magnitudes(model, unet_sd, dev):
+    """Operands far below fp16's normal range: the same network with every to_v weight of the self-attention scaled by 2^-14 (v ~ 1e-5:
+    h is an fp16 denormal or 0, l a denormal) and to_out scaled back by 2^14 — exact powers of two, so the fp32 result is unchanged up to
+    underflow.  A matrix pipe that flushed fp16 denormals would lose v here."""
+    sd = {k: v.clone() for k, v in unet_sd.items()}
+    for k in sd:
+        if ".attn1.to_v.weight" in k:
+            sd[k] *= 2.0 ** -14
+        if ".attn1.to_out.0.weight" in k:
+            sd[k] *= 2.0 ** 14
+    from said_amd.model.diffusion import SAID_UNet1D
+    m = SAID_UNet1D()
+    full = synth.said_state_dict()
+    for k, v in sd.items():
+        full["denoiser." + k] = v
+    m.load_state_dict(full, strict=True)
+    m.to(dev).eval()
+    x = synth.synth_latents(901, (1, 96, 32))
+    c = synth.synth_latents(902, (1, 96, 768))
+    ts = torch.tensor([500])
+    truth = _f64_truth(sd, x, ts, c)
+    out = m(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+    err = float((out.double() - truth).abs().max()) / float(truth.abs().max())
+    print(f"\n[attn_split] v scaled by 2^-14: {err:.3e} of the output range")
+    assert err <= 5e-5
