@@ -59,6 +59,26 @@ static __device__ __forceinline__ SplitH split_f16x8(const f32x4a a, const f32x4
     }
     return r;
 }
+// OPERAND FENCE (round 4, found the hard way — profiles/r04i_attn_split_hazard.txt): a v_mfma_f32_32x32x16_f16 whose 128-bit A / B operand was
+// written by VALU instructions (v_cvt_pk_f16_f32, the SDWA converts, v_pk_mul_f32) a few issue slots earlier can read a stale register.  The
+// compiler separates the pair by two wait states; that holds while the SIMD's other waves keep interleaving, and failed — silently, a few
+// 1e-2 errors in some clips, different every run — as soon as the co-resident waves were this engine's memory-bound kernels of ANOTHER clip
+// group, i.e. when this wave issued back to back.  So every split operand of a key tile is computed first, then the scheduler is fenced and
+// the wave idles SAID_SP_FENCE_NOPS issue slots, then the MFMAs go out together (they hide behind the other waves' VALU work anyway).
+#ifndef SAID_SP_FENCE_NOPS
+#define SAID_SP_FENCE_NOPS 16
+#endif
+static __device__ __forceinline__ void operand_fence() {
+    __builtin_amdgcn_sched_barrier(0);
+#if SAID_SP_FENCE_NOPS >= 16
+    asm volatile("s_nop 7\n\ts_nop 7");
+#elif SAID_SP_FENCE_NOPS >= 8
+    asm volatile("s_nop 7");
+#elif SAID_SP_FENCE_NOPS >= 4
+    asm volatile("s_nop 3");
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 // The arguments are 14 scalar kernel parameters — exactly what the hardware preloads into SGPRs (build.py compiles this
 // file with -amdgpu-kernarg-preload-count=14) — so the first operand request needs no scalar-memory round trip.
@@ -142,6 +162,7 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
             SplitH ks[NQ / 2];
 #pragma unroll
             for (int q = 0; q < NQ / 2; ++q) ks[q] = split_f16x8(kf[2 * q], kf[2 * q + 1]);
+            operand_fence();
             f32x16 sx;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sx[r] = 0.f;
@@ -253,18 +274,23 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
                         for (int e = 0; e < 4; ++e) vz[nd][q][e] = (j0 + 8 * q + 4 * lh + e < T) ? vz[nd][q][e] : 0.f;
             }
+            SplitH psa[2], vsa[2][ND];
 #pragma unroll
             for (int m8 = 0; m8 < 2; ++m8) {
                 const f32x4a p0 = {s[8 * m8], s[8 * m8 + 1], s[8 * m8 + 2], s[8 * m8 + 3]}, p1 = {s[8 * m8 + 4], s[8 * m8 + 5], s[8 * m8 + 6], s[8 * m8 + 7]};
-                const SplitH ps2 = split_f16x8(p0, p1);
+                psa[m8] = split_f16x8(p0, p1);
+#pragma unroll
+                for (int nd = 0; nd < ND; ++nd) vsa[m8][nd] = split_f16x8(vz[nd][2 * m8], vz[nd][2 * m8 + 1]);
+            }
+            operand_fence();
+#pragma unroll
+            for (int m8 = 0; m8 < 2; ++m8)
 #pragma unroll
                 for (int nd = 0; nd < ND; ++nd) {
-                    const SplitH vs2 = split_f16x8(vz[nd][2 * m8], vz[nd][2 * m8 + 1]);
-                    ox[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vs2.l, ps2.h, ox[nd], 0, 0, 0);
-                    o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vs2.h, ps2.h, o[nd], 0, 0, 0);
-                    ox[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vs2.h, ps2.l, ox[nd], 0, 0, 0);
+                    ox[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].l, psa[m8].h, ox[nd], 0, 0, 0);
+                    o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].h, psa[m8].h, o[nd], 0, 0, 0);
+                    ox[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].h, psa[m8].l, ox[nd], 0, 0, 0);
                 }
-            }
         }
 #pragma unroll
         for (int r = 0; r < (SP ? 0 : 16); ++r)

@@ -1,0 +1,47 @@
+"""Determinism probe for the split-fp16 attention: fresh model, B clips x 600 frames, 2 steps, twice in one process; prints checksums."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from said_amd import _engine  # noqa: E402
+
+if os.environ.get("SAID_AB_LIB"):
+    _engine._LIB_PATH = os.path.abspath(os.environ["SAID_AB_LIB"])
+from said_amd.model.diffusion import SAID_UNet1D  # noqa: E402
+from said_amd.util import synth  # noqa: E402
+
+torch.set_grad_enabled(False)
+sp, B, groups = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+prefill = len(sys.argv) > 4
+dev = torch.device("cuda:0")
+if prefill:   # dirty the allocator's memory first: stale workspace contents differ from a fresh process's
+    junk = [torch.full((64 << 20,), float(v), device=dev) for v in (3.0e38, -1.0e30, float("nan"))]
+    del junk
+m = SAID_UNet1D()
+m.load_state_dict(synth.said_state_dict(), strict=True)
+m.to(dev).eval()
+if groups:
+    m.clip_groups = groups
+T = 600
+ctx = synth.synth_latents(700 + B, (B, T, 768)).to(dev)
+lat = synth.synth_latents(800 + B, (B, T, 32)).to(dev)
+wav = torch.zeros(B, T * 16000 // 60, device=dev)
+m._get_engine(2 * B, T).debug_option("attn_split", sp)
+bg = None
+if os.environ.get("DET_BG"):   # an MFMA-heavy torch kernel stream beside the loop (another application stream)
+    bg = torch.cuda.Stream(dev)
+    ba = torch.randn(4096, 4096, device=dev)
+    bb = torch.randn(4096, 4096, device=dev)
+r0 = None
+for rep in range(4):
+    if bg is not None:
+        with torch.cuda.stream(bg):
+            for _ in range(int(os.environ["DET_BG"])):
+                bc = ba @ bb
+    r = m.inference(wav, audio_embedding=ctx, num_inference_steps=2, guidance_scale=2.0, init_latents=lat).result
+    if r0 is None:
+        r0 = r.clone()
+    d = (r - r0).abs().amax(dim=(1, 2))
+    bad = [(i, float(d[i])) for i in range(B) if float(d[i]) > 0]
+    print(f"attn_split={sp} B={B} groups={groups} prefill={prefill} rep{rep}: {float(r.double().sum()):.9f} nan={int(torch.isnan(r).sum())} clips differing from rep0: {bad[:6]}", flush=True)

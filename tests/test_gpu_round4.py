@@ -232,3 +232,29 @@ def test_split_fp16_attention_small_magnitudes(model, unet_sd, dev):
     err = float((out.double() - truth).abs().max()) / float(truth.abs().max())
     print(f"\n[attn_split] v scaled by 2^-14: {err:.3e} of the output range")
     assert err <= 5e-5
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_split_fp16_attention_is_deterministic_under_concurrent_clip_groups(dev, dt):
+    """Regression guard for the operand hazard of profiles/r04i_attn_split_hazard.txt: 32 clips as THREE concurrent clip groups (fp32: the default
+    split; bf16: forced), four repetitions, bit for bit.  Before the operand fence the fp32 run differed in a few clips by up to 5e-2 in most repetitions
+    (and only with other groups' kernels co-resident: one group never showed it)."""
+    from said_amd.model.diffusion import SAID_UNet1D
+    m = SAID_UNet1D()
+    m.load_state_dict(synth.said_state_dict(), strict=True)
+    m.to(dev).eval()
+    m.set_mfma_dtype(dt)
+    m.clip_groups = 3
+    B, T = 32, 600
+    ctx = synth.synth_latents(700 + B, (B, T, 768)).to(dev)
+    lat = synth.synth_latents(800 + B, (B, T, 32)).to(dev)
+    wav = torch.zeros(B, T * 16000 // 60, device=dev)
+    first = None
+    for rep in range(4):
+        r = m.inference(wav, audio_embedding=ctx, num_inference_steps=2, guidance_scale=2.0, init_latents=lat).result
+        assert torch.isfinite(r).all()
+        if first is None:
+            first = r.clone()
+        else:
+            assert torch.equal(r, first), f"repetition {rep}: max abs diff {float((r - first).abs().max())}"
+    m._eng.close()
