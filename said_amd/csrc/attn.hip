@@ -175,15 +175,16 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = fmaf(sx[r], 0x1p-11f, s[r]);
         }
+        if constexpr (BF) {   // (converted operands first, then the fence, then the MFMAs: operand_fence)
+            bf16x8a kh[NQ / 2];
 #pragma unroll
-        for (int dp = 0; dp < (SP ? 0 : ND * 16); ++dp) {
-            if constexpr (BF) {
-                if ((dp & 7) == 0)
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pk_bf16x8(kf[dp >> 2], kf[(dp >> 2) + 1]), qh[dp >> 3], s, 0, 0, 0);
-            } else {
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[dp >> 2][dp & 3], qf[dp >> 2][dp & 3], s, 0, 0, 0);
-            }
+            for (int q = 0; q < NQ / 2; ++q) kh[q] = pk_bf16x8(kf[2 * q], kf[2 * q + 1]);
+            operand_fence();
+#pragma unroll
+            for (int q = 0; q < NQ / 2; ++q) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[q], qh[q], s, 0, 0, 0);
         }
+#pragma unroll
+        for (int dp = 0; dp < ((SP || BF) ? 0 : ND * 16); ++dp) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[dp >> 2][dp & 3], qf[dp >> 2][dp & 3], s, 0, 0, 0);
         if constexpr (BF) {
             // bf16 mode: the VALU work per score bounds this kernel once the products are 8x cheaper, so it is trimmed: the
             // running maximum is kept in RAW score units and the scale is folded into the exponent (one fma + one exp2 per
@@ -292,19 +293,25 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
                     ox[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].h, psa[m8].l, ox[nd], 0, 0, 0);
                 }
         }
+        if constexpr (BF) {
+            bf16x8a pb[2], vb8[2][ND];
 #pragma unroll
-        for (int r = 0; r < (SP ? 0 : 16); ++r)
+            for (int m8 = 0; m8 < 2; ++m8) {
+                const f32x4a p0 = {s[8 * m8], s[8 * m8 + 1], s[8 * m8 + 2], s[8 * m8 + 3]}, p1 = {s[8 * m8 + 4], s[8 * m8 + 5], s[8 * m8 + 6], s[8 * m8 + 7]};
+                pb[m8] = pk_bf16x8(p0, p1);
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) {
-                if constexpr (BF) {
-                    if ((r & 7) == 0) {
-                        const f32x4a p0 = {s[r], s[r + 1], s[r + 2], s[r + 3]}, p1 = {s[r + 4], s[r + 5], s[r + 6], s[r + 7]};
-                        o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pk_bf16x8(vf[nd][r >> 2], vf[nd][(r >> 2) + 1]), pk_bf16x8(p0, p1), o[nd], 0, 0, 0);
-                    }
-                } else {
-                    o[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[nd][r >> 2][r & 3], s[r], o[nd], 0, 0, 0);
-                }
+                for (int nd = 0; nd < ND; ++nd) vb8[m8][nd] = pk_bf16x8(vf[nd][2 * m8], vf[nd][2 * m8 + 1]);
             }
+            operand_fence();
+#pragma unroll
+            for (int m8 = 0; m8 < 2; ++m8)
+#pragma unroll
+                for (int nd = 0; nd < ND; ++nd) o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb8[m8][nd], pb[m8], o[nd], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < ((SP || BF) ? 0 : 16); ++r)
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) o[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[nd][r >> 2][r & 3], s[r], o[nd], 0, 0, 0);
     };
     if constexpr (QW > 1) {
         // K / V tiles staged ONCE per workgroup through LDS and shared by its QW query-tile waves.  Fetching fragments straight
@@ -566,6 +573,7 @@ __global__ __launch_bounds__(64 * QT, (QT == 10 ? 5 : (QT == 8 ? 4 : 2))) void b
         for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
         const f32x4a p0 = {s[0], s[1], s[2], s[3]}, p1 = {s[4], s[5], s[6], s[7]}, p2 = {s[8], s[9], s[10], s[11]}, p3 = {s[12], s[13], s[14], s[15]};
         const bf16x8a pa = pk_bf16x8(p0, p1), pb = pk_bf16x8(p2, p3);
+        operand_fence();   // (the converted probabilities are MFMA operands: see operand_fence; never seen failing here, costs nothing measurable)
         o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pa, o, 0, 0, 0);
         ls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pa, ls, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o, 0, 0, 0);
