@@ -251,6 +251,17 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1", grou
     # launches run a little slower (cold instruction cache, the previous launch's write-back).  The loop itself gives the in-situ total:
     # in_situ_scale = loop time per step / sum of the isolated launch times (one clip group only); the per-kernel in-situ figures of a
     # rocprofv3 trace of this command are under profiles/ (r04h_kernel_trace_*.txt)
+    # fp32 mode runs the two self-attention products on split-fp16 operands (attn.hip PM == 2: three fp16 MFMAs per fp32 one, fp32 accumulation,
+    # 22-bit operands): `flops` stay the fp32-equivalent (algorithmic) ones everywhere; for an attention kernel the EXECUTED matrix work is
+    # three times that on the fp16 pipe, priced here against the fp16 dense peak as well
+    try:
+        split = dtype == "f32" and eng.debug_get("attn_split") == 1
+    except Exception:
+        split = False
+    out["fp32_attention_products"] = "split_fp16 (x = h + 2^-11 l; 3 fp16 MFMAs per fp32 MFMA; fp32 accumulate)" if split else "mfma_f32"
+    if split and dom.startswith("attn_kernel"):
+        out["kernel_executed_f16_tflops"] = round(3 * k_tf, 3)
+        out["kernel_executed_f16_frac"] = round(3 * k_tf / MFMA_PEAK_TFLOPS["bf16"], 5)
     if sum_us > 0 and groups == 1:   # (concurrent clip groups share the chip: a launch's in-situ time is then not comparable with its isolated one)
         scale = (step_ms * 1e3) / sum_us
         out["in_situ_scale"] = round(scale, 4)

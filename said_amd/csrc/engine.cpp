@@ -2360,6 +2360,7 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "audio_chunk") return ctx->audio_chunk;
     if (k == "steps_per_graph") return ctx->spg_limit;
     if (k == "tm_acts") return ctx->tm_acts;
+    if (k == "attn_split") return (!ctx->bf16_mode && ctx->attn_split != 0) ? 1 : 0;   // 1: fp32-mode attention products run on split-fp16 operands
     if (k == "rgemm") return ctx->rgemm;
     if (k == "n_rgemm") return ctx->n_rgemm;
     if (k == "n_xgemm") return ctx->n_xgemm;
