@@ -24,7 +24,7 @@ rm -rf gpurun_out/final/sq; mkdir -p gpurun_out/final/sq
 timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace -d gpurun_out/final/sq -o sq -- python bench.py --batch 32 --num_steps 20 --dtype bf16 --steps 1 --warmup 0 --no_cpu_baseline --no_roofline --no_secondary > gpurun_out/final/sq/run.log 2>&1; echo "sq exit=$?"
 python scripts/pmc_generic_summary.py $(find gpurun_out/final/sq -name "sq*_results.db" | head -1) rgemm battn out_sched conv_in tgemm > gpurun_out/final/sq_cfg2.txt 2>&1
 find gpurun_out/final/sq -name "*.db" -delete
-bash scripts/gpu_r3_traffic.sh > gpurun_out/final/traffic_run.log 2>&1; tail -3 gpurun_out/final/traffic_run.log
+if [ -z "$FINAL_SKIP_TRAFFIC" ]; then bash scripts/gpu_r3_traffic.sh > gpurun_out/final/traffic_run.log 2>&1; tail -3 gpurun_out/final/traffic_run.log; fi   # (FINAL_SKIP_TRAFFIC=1: the traffic passes ran first, on the same sources, so that the bench lines above carry a fresh stamp)
 SAID_ALLOW_SCRATCH=1 SAID_EXTRA_DEFS=-DSAID_CLK_STAMPS python -m said_amd.build --force > gpurun_out/final/clk_build.log 2>&1; echo "stamp build exit=$?"
 timeout 300 python scripts/rgemm_clocks.py 32 600 > gpurun_out/final/rgemm_clocks.txt 2>&1; echo "clocks exit=$?"
 du -sh gpurun_out/final
