@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "split_f16.h"
 
 namespace said {
 
@@ -35,49 +36,6 @@ typedef __bf16 bf16x8a __attribute__((ext_vector_type(8)));
 static __device__ __forceinline__ bf16x8a pk_bf16x8(const f32x4a a, const f32x4a b) {
     const bf16x8a v = {(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
     return v;
-}
-
-// Split-fp16 operands (round 4; PM == 2): x ~= h + 2^-11 l with h = RN16(x), l = RN16((x - h) * 2^11) — the remainder is stored at h's own
-// magnitude, so both halves are normal fp16 numbers for 2^-14 <= |x| < 65504 and x is represented to 2^-22 relative (22 significand bits + the
-// remainder's sign; below 2^-14 the pair still resolves 2^-36 absolute where the matrix pipe keeps fp16 denormals) — and
-//   a . b ~= h_a . h_b + 2^-11 (h_a . l_b + l_a . h_b)
-// on v_mfma_f32_32x32x16_f16: three 8-pass MFMAs per 16 contraction steps against eight 16-pass v_mfma_f32_32x32x2_f32 (5.3 x fewer
-// matrix-pipe clocks).  Accumulation is fp32 as before; the cross terms have their own accumulator (merged with one fma per element).  The
-// dropped term 2^-22 l_a . l_b is below the representation error.  Domain: |x| < 65504 (q, k, v are projections of LayerNorm'ed rows; an
-// overflow shows as inf / NaN).
-typedef _Float16 f16x8a __attribute__((ext_vector_type(8)));
-struct SplitH { f16x8a h, l; };
-static __device__ __forceinline__ SplitH split_f16x8(const f32x4a a, const f32x4a b) {
-    SplitH r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const _Float16 ha = (_Float16)a[i], hb = (_Float16)b[i];
-        r.h[i] = ha;
-        r.h[4 + i] = hb;
-        r.l[i] = (_Float16)((a[i] - (float)ha) * 2048.f);      // (a - ha is exact in fp32)
-        r.l[4 + i] = (_Float16)((b[i] - (float)hb) * 2048.f);
-    }
-    return r;
-}
-// OPERAND FENCE (round 4, found the hard way — profiles/r04i_attn_split_hazard.txt): a v_mfma_f32_32x32x16_f16 whose 128-bit A / B operand was
-// written by VALU instructions (v_cvt_pk_f16_f32, the SDWA converts, v_pk_mul_f32) a few issue slots earlier can read a stale register.  The
-// compiler separates the pair by two wait states; that holds while the SIMD's other waves keep interleaving, and failed — silently, a few
-// 1e-2 errors in some clips, different every run — as soon as the co-resident waves were this engine's memory-bound kernels of ANOTHER clip
-// group, i.e. when this wave issued back to back.  So every split operand of a key tile is computed first, then the scheduler is fenced and
-// the wave idles SAID_SP_FENCE_NOPS issue slots, then the MFMAs go out together (they hide behind the other waves' VALU work anyway).
-#ifndef SAID_SP_FENCE_NOPS
-#define SAID_SP_FENCE_NOPS 16
-#endif
-static __device__ __forceinline__ void operand_fence() {
-    __builtin_amdgcn_sched_barrier(0);
-#if SAID_SP_FENCE_NOPS >= 16
-    asm volatile("s_nop 7\n\ts_nop 7");
-#elif SAID_SP_FENCE_NOPS >= 8
-    asm volatile("s_nop 7");
-#elif SAID_SP_FENCE_NOPS >= 4
-    asm volatile("s_nop 3");
-#endif
-    __builtin_amdgcn_sched_barrier(0);
 }
 
 // The arguments are 14 scalar kernel parameters — exactly what the hardware preloads into SGPRs (build.py compiles this
@@ -130,13 +88,13 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
     for (int q = 0; q < NQ / 2; ++q) qs[q] = split_f16x8(qf[2 * q], qf[2 * q + 1]);
     float m = -1.0e30f, lsum = 0.f;
-    f32x16 o[ND], ox[SP ? ND : 1];   // ox: the split mode's cross terms (x 2^11)
+    f32x16 o[ND], ox[SP ? ND : 1], oy[SP ? ND : 1];   // ox, oy: the split mode's cross terms v.l p.h and v.h p.l (x 2^11)
 #pragma unroll
     for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             o[nd][r] = 0.f;
-            if (SP) ox[SP ? nd : 0][r] = 0.f;
+            if (SP) { ox[SP ? nd : 0][r] = 0.f; oy[SP ? nd : 0][r] = 0.f; }
         }
 
     const int nkt = (T + 31) >> 5;
@@ -163,17 +121,20 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
             for (int q = 0; q < NQ / 2; ++q) ks[q] = split_f16x8(kf[2 * q], kf[2 * q + 1]);
             operand_fence();
-            f32x16 sx;
+            // Three accumulators (main, k.l q.h, k.h q.l), MFMAs issued in rotation: two MFMAs on the same accumulator always have two others between
+            // them, so an accumulate never needs the result of an MFMA still in flight.  Same-accumulator MFMAs back to back (or one apart, or with idle
+            // slots between) were NOT bit-stable under concurrent clip groups — profiles/r04i_attn_split_hazard.txt.
+            f32x16 sxa, sxb;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sx[r] = 0.f;
+            for (int r = 0; r < 16; ++r) { sxa[r] = 0.f; sxb[r] = 0.f; }
 #pragma unroll
             for (int q = 0; q < NQ / 2; ++q) {
-                sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].l, qs[q].h, sx, 0, 0, 0);
+                sxa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].l, qs[q].h, sxa, 0, 0, 0);
+                sxb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].h, qs[q].l, sxb, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].h, qs[q].h, s, 0, 0, 0);
-                sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].h, qs[q].l, sx, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = fmaf(sx[r], 0x1p-11f, s[r]);
+            for (int r = 0; r < 16; ++r) s[r] = fmaf(sxa[r] + sxb[r], 0x1p-11f, s[r]);
         }
         if constexpr (BF) {   // (converted operands first, then the fence, then the MFMAs: operand_fence)
             bf16x8a kh[NQ / 2];
@@ -255,7 +216,7 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     o[nd][r] *= alpha;
-                    if (SP) ox[SP ? nd : 0][r] *= alpha;
+                    if (SP) { ox[SP ? nd : 0][r] *= alpha; oy[SP ? nd : 0][r] *= alpha; }
                 }
         }
         }
@@ -287,10 +248,10 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
             for (int m8 = 0; m8 < 2; ++m8)
 #pragma unroll
-                for (int nd = 0; nd < ND; ++nd) {
+                for (int nd = 0; nd < ND; ++nd) {   // (rotation over three accumulators, as for the scores)
                     ox[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].l, psa[m8].h, ox[nd], 0, 0, 0);
+                    oy[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].h, psa[m8].l, oy[nd], 0, 0, 0);
                     o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].h, psa[m8].h, o[nd], 0, 0, 0);
-                    ox[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].h, psa[m8].l, ox[nd], 0, 0, 0);
                 }
         }
         if constexpr (BF) {
@@ -398,7 +359,7 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
         for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[nd][r] = fmaf(ox[nd][r], 0x1p-11f, o[nd][r]);
+            for (int r = 0; r < 16; ++r) o[nd][r] = fmaf(ox[nd][r] + oy[nd][r], 0x1p-11f, o[nd][r]);
     }
 
     // ---- merge the KS partial states ----

@@ -161,6 +161,8 @@ struct said_ctx {
                               // 0: attn_kernel on fp32 operands (said_debug_option "battn")
     int attn_split = -1;      // round 4: fp32 mode runs both attention products on split-fp16 operands (attn.hip: PM == 2; 22-bit significands, fp32
                               // accumulation); 0: v_mfma_f32_32x32x2_f32 on the fp32 operands (said_debug_option "attn_split")
+    int gemm_split = -1;      // round 4: fp32 mode's large-batch token-major GEMMs (fgemm_kernel) on split-fp16 operands too (tgemm.hip: SP); 0: fp32 MFMAs
+                              // (said_debug_option "gemm_split")
     int rgemm = -1;           // round 4: register-stationary, wave-specialised persistent GEMMs (rgemm.hip) wherever launch_rgemm serves the shape
                               // (bf16 mode: 192-wide GEMMs with K <= 576, q/k/v); 0: off (said_debug_option "rgemm")
     long long n_rgemm = 0;
@@ -613,6 +615,7 @@ void do_tgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     TGemmArgs a2 = a;
     a2.f32 = c->bf16_mode ? 0 : 1;
     if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }   // token-major intermediate (GEGLU product) in fp32
+    a2.f32_split = (a2.f32 && c->gemm_split != 0) ? 1 : 0;
     if (dbg_go(c) && !launch_tgemm(a2, batch, s)) {
         char b[160]; snprintf(b, sizeof b, "token-major GEMM: shape M=%d N=%d K=%d (batch %d) is not served by any kernel", a.M, a.N, a.K, batch);
         c->launch_err = b;
@@ -2340,6 +2343,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->tm_acts = value < 0 ? -1 : (value != 0);
     } else if (k == "rgemm") {
         ctx->rgemm = value < 0 ? -1 : (value != 0);
+    } else if (k == "gemm_split") {
+        ctx->gemm_split = value < 0 ? -1 : (value != 0);
     } else if (k == "attn_split") {
         ctx->attn_split = value < 0 ? -1 : (value != 0);
     } else if (k == "battn") {
@@ -2360,6 +2365,7 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "audio_chunk") return ctx->audio_chunk;
     if (k == "steps_per_graph") return ctx->spg_limit;
     if (k == "tm_acts") return ctx->tm_acts;
+    if (k == "gemm_split") return (!ctx->bf16_mode && ctx->gemm_split != 0) ? 1 : 0;
     if (k == "attn_split") return (!ctx->bf16_mode && ctx->attn_split != 0) ? 1 : 0;   // 1: fp32-mode attention products run on split-fp16 operands
     if (k == "rgemm") return ctx->rgemm;
     if (k == "n_rgemm") return ctx->n_rgemm;

@@ -65,6 +65,7 @@ struct TGemmArgs {
     int col_gs;            //   of bias / res / y (the wav2vec2 positional convolution: 16 groups of 48 channels)
     int n_store;           // token-major outputs: columns n >= n_store are not written (0: all N) — a column count padded to the tile
     int f32;               // 1: A and W are fp32 (fgemm_kernel on v_mfma_f32_32x32x2_f32; fp32 mode, large batches); K % 32 == 0
+    int f32_split;         // f32 operands: run the products on split-fp16 operands (fgemm_kernel SP; split_f16.h) — fp32-equivalent results
     int dbg;               // timing experiments (SAID_TG_DBG): bit 0 = skip the epilogue, bit 1 = skip the K loop
     // ==== token-major ACTIVATION interface (round 3; xgemm_kernel only; large batches, both precisions) ====================
     // Between the UNet kernels the activations are token-major [sample][token][192] in the context's element type ET (bf16 in

@@ -21,6 +21,7 @@
 #include "gemm_common.h"
 #include "tgemm.h"
 #include "tgemm_dev.h"
+#include "split_f16.h"
 
 namespace said {
 
@@ -329,8 +330,15 @@ __host__ __device__ constexpr int fgemm_lds_bytes() {
 // two v_mfma_f32_32x32x16_bf16 per column tile.  There the point is not MFMA balance but spread: the 256-row bf16 tiles put a
 // 192-wide convolution on 152 workgroups of a 256-CU chip, and its time is the fp32 epilogue traffic (§7.3).
 constexpr int fgemm_occ(int NJ, int PF, bool BF) { return NJ == 3 ? 4 : 3; }   // workgroups per CU the registers are budgeted for
-template <int NJ, int PF, bool BF, int OCC = fgemm_occ(NJ, PF, BF)>
+// SP (round 4, fp32 operands only): the products run on SPLIT-fp16 operands (split_f16.h: x = h + 2^-11 l, three v_mfma_f32_32x32x16_f16 per eight
+// v_mfma_f32_32x32x2_f32, fp32 accumulation, the cross terms in a second accumulator set).  The LDS tiles stay fp32 — staging, K halves, exchange and
+// epilogue are untouched; a wave's lane half takes the EIGHT consecutive k (16 kh + 8 lh ...) of the 32-k tile as two 16-byte reads per operand row and
+// splits them in registers (A once, W once per column tile — ALL of a k-tile's operands in distinct registers: two workgroups per CU), then operand_fence(), then the
+// 3 NJ MFMAs, then a second fence.  A variant that split one column tile at a time (three workgroups per CU) — its conversions rewriting the operand registers of
+// MFMAs issued 16 idle slots earlier — was not bit-stable from one run to the next (profiles/r04i_attn_split_hazard.txt).
+template <int NJ, int PF, bool BF, int OCC = fgemm_occ(NJ, PF, BF), bool SP = false>
 __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
+    static_assert(!(SP && BF), "the split mode reads fp32 operands");
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [A 64 rows | W BN rows] x 144 bytes
     float* const ldsf = reinterpret_cast<float*>(lds);
     typedef typename std::conditional<BF, unsigned short, float>::type elt_t;
@@ -387,16 +395,38 @@ __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
 #pragma unroll
         for (int i = 0; i < WCH; ++i) *reinterpret_cast<f32x4t*>(ldse + lwoff[i]) = xw[i];
     };
-    f32x16 acc[NJ];
+    f32x16 acc[NJ], accx[SP ? NJ : 1];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            acc[j][r] = 0.f;
+            if (SP) accx[SP ? j : 0][r] = 0.f;
+        }
     // fragment of step ks: bytes 64 kh + 32 ks + 16 (l >> 5) of the row — the same byte offsets for both element types
     const int frow = l & 31, fk = EPC * (l >> 5) + 4 * EPC * kh;
     const elt_t* const pa = ldse + (wr * 32 + frow) * FLP + fk;
     const elt_t* const pw = ldse + BM * FLP + frow * FLP + fk;
+    // (split mode: floats 16 kh + 8 lh .. + 7 of the row)
+    const float* const paS = ldsf + (wr * 32 + frow) * 36 + 16 * kh + 8 * (l >> 5);
+    const float* const pwS = ldsf + BM * 36 + frow * 36 + 16 * kh + 8 * (l >> 5);
     auto compute = [&]() {
+        if constexpr (SP) {
+            const SplitH sa = split_f16x8(*reinterpret_cast<const f32x4s*>(paS), *reinterpret_cast<const f32x4s*>(paS + 4));
+            SplitH sb[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) sb[j] = split_f16x8(*reinterpret_cast<const f32x4s*>(pwS + j * 32 * 36), *reinterpret_cast<const f32x4s*>(pwS + j * 32 * 36 + 4));
+            operand_fence();
+            // two MFMAs on the same accumulator are NJ - 1 or more apart (never back to back: attn.hip)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa.l, sb[j].h, accx[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa.h, sb[j].h, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa.h, sb[j].l, accx[j], 0, 0, 0);
+            operand_fence();   // (the next k-tile's split reuses these operand registers)
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if constexpr (BF) {
@@ -459,6 +489,12 @@ __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
     // area (lane-linear, region r), a barrier, each adds its partner's half to its own; a second barrier frees the area, which
     // then serves as the waves' transposition scratch (245 -> 235 us).  NJ = 3: wave (r, 1) parks everything, wave (r, 0) finishes
     // all three tiles (the 2 : 1 split measured slower: 122.5 -> 126.7 us).
+    if constexpr (SP) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = fmaf(accx[j][r], 0x1p-11f, acc[j][r]);
+    }
     constexpr int NJ0 = NJ == 4 ? 2 : NJ, NJ1 = NJ - NJ0;
     // (unsplit: region r is also wave (r, 0)'s scratch, so the regions are spaced by the scratch size and never overlap)
     float* const xr = ldsf + wr * (NJ1 > 0 ? NJ * 16 * 64 : 32 * (32 * NJ + 4));
@@ -1262,6 +1298,8 @@ void configure_tgemm_kernel() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm256_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 192) * TLP * 2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<4, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<4>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 1, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<4, 1, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<4>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<4, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<4>());
@@ -1280,6 +1318,11 @@ bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
         if ((rows_tot + 2) * (long long)std::max(a.lda, a.lda2) >= 0x7fffffffLL) return false;   // 32-bit operand offsets
         const long long mt8 = ((rows_tot + 63) / 64 + 7) / 8 * 8;   // 64-row tiles, padded to the 8 XCDs
         constexpr int LDS3 = fgemm_lds_bytes<3>(), LDS4 = fgemm_lds_bytes<4>();
+        if (a.f32_split) {   // products on split-fp16 operands (TGemmArgs::f32_split)
+            if (a.N % 128 == 0 && (a.geglu || a.N % 96)) hipLaunchKernelGGL((fgemm_kernel<4, 1, false, 2, true>), dim3((unsigned)(mt8 * (a.N / 128))), dim3(256), LDS4, s, a2);
+            else hipLaunchKernelGGL((fgemm_kernel<3, 1, false, 2, true>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
+            return true;
+        }
         if (a.N % 128 == 0 && (a.geglu || a.N % 96)) hipLaunchKernelGGL((fgemm_kernel<4, 1, false>), dim3((unsigned)(mt8 * (a.N / 128))), dim3(256), LDS4, s, a2);
         else hipLaunchKernelGGL((fgemm_kernel<3, 2, false>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);   // (one register
         // set at five workgroups per CU — the bf16 variant's choice — spills and measured 344 vs 328 ms here)

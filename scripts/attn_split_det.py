@@ -21,6 +21,8 @@ if prefill:   # dirty the allocator's memory first: stale workspace contents dif
 m = SAID_UNet1D()
 m.load_state_dict(synth.said_state_dict(), strict=True)
 m.to(dev).eval()
+if os.environ.get("DET_DTYPE"):
+    m.set_mfma_dtype(os.environ["DET_DTYPE"])
 if groups:
     m.clip_groups = groups
 T = 600
@@ -28,6 +30,8 @@ ctx = synth.synth_latents(700 + B, (B, T, 768)).to(dev)
 lat = synth.synth_latents(800 + B, (B, T, 32)).to(dev)
 wav = torch.zeros(B, T * 16000 // 60, device=dev)
 m._get_engine(2 * B, T).debug_option("attn_split", sp)
+if os.environ.get("DET_GEMM_SPLIT") is not None:
+    (m._eng if hasattr(m, "_eng") else None).debug_option("gemm_split", int(os.environ["DET_GEMM_SPLIT"]))
 bg = None
 if os.environ.get("DET_BG"):   # an MFMA-heavy torch kernel stream beside the loop (another application stream)
     bg = torch.cuda.Stream(dev)

@@ -24,6 +24,8 @@ for g in range(G):
     m.to(dev).eval()
     m.clip_groups = 1
     m._get_engine(2 * B, T).debug_option("attn_split", sp)
+    if os.environ.get("DET_GEMM_SPLIT") is not None:
+        (m._eng if hasattr(m, "_eng") else None).debug_option("gemm_split", int(os.environ["DET_GEMM_SPLIT"]))
     models.append(m)
     inputs.append((synth.synth_latents(700 + g, (B, T, 768)).to(dev), synth.synth_latents(800 + g, (B, T, 32)).to(dev), torch.zeros(B, T * 16000 // 60, device=dev)))
     streams.append(torch.cuda.Stream(dev))

@@ -182,12 +182,14 @@ def _f64_truth(unet_sd, x, ts, c):
         return ou.unet1d_forward(sd64, x.double(), ts, c.double())
 
 
-@pytest.mark.parametrize("B,T", [(1, 600), (2, 37), (12, 600)])
+@pytest.mark.parametrize("B,T", [(1, 600), (2, 37), (12, 600), (20, 600)])
 def test_split_fp16_attention_is_as_close_to_float64_as_fp32_mfma(model, unet_sd, dev, B, T):
     """fp32 mode runs the two self-attention products on split-fp16 operands (attn.hip, PM == 2: x = h + l, three fp16 MFMAs per fp32 one,
     fp32 accumulation).  Statement: against the float64 evaluation of the same network its UNet output is no further away than the
     v_mfma_f32_32x32x2_f32 path's (said_debug_option("attn_split", 0)) beyond a factor 1.5, and both stay inside 2e-5 of the output range
-    (the stated single-evaluation tolerance is 1e-4).  (12, 600) takes the large-batch kernels (four query tiles per workgroup)."""
+    (the stated single-evaluation tolerance is 1e-4).  (12, 600) takes the large-batch attention (four query tiles per workgroup); (20, 600) — 12000 UNet rows —
+    the large-batch fp32 schedule, whose token-major GEMMs (fgemm_kernel) run on split-fp16 operands as well (said_debug_option("gemm_split", 0 / 1)): both
+    options are switched together."""
     x = synth.synth_latents(700 + B, (B, T, 32))
     c = synth.synth_latents(800 + B, (B, T, 768))
     ts = (torch.arange(B) * 83 + 999) % 1000
@@ -198,10 +200,12 @@ def test_split_fp16_attention_is_as_close_to_float64_as_fp32_mfma(model, unet_sd
     try:
         for sp in (0, 1):
             model._get_engine(2 * B, T).debug_option("attn_split", sp)
+            model._eng.debug_option("gemm_split", sp)
             out = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
             err[sp] = float((out[:nref].double() - truth).abs().max()) / scale
     finally:
         model._eng.debug_option("attn_split", -1)
+        model._eng.debug_option("gemm_split", -1)
     print(f"\n[attn_split] B={B} T={T}: fp32 MFMA {err[0]:.3e}, split fp16 {err[1]:.3e} of the output range")
     assert err[0] <= 2e-5 and err[1] <= 2e-5
     assert err[1] <= 1.5 * err[0] + 1e-6
