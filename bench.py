@@ -259,7 +259,12 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1", grou
     except Exception:
         split = False
     out["fp32_attention_products"] = "split_fp16 (x = h + 2^-11 l; 3 fp16 MFMAs per fp32 MFMA; fp32 accumulate)" if split else "mfma_f32"
-    if split and dom.startswith("attn_kernel"):
+    try:
+        gsplit = dtype == "f32" and eng.debug_get("gemm_split") == 1
+    except Exception:
+        gsplit = False
+    out["fp32_large_batch_gemm_products"] = "split_fp16 (fgemm_kernel SP)" if gsplit else "mfma_f32"   # (only the token-major fgemm launches; the channel-major kernels stay on fp32 MFMAs)
+    if (split and dom.startswith("attn_kernel")) or (gsplit and dom.startswith("fgemm_kernel")):
         out["kernel_executed_f16_tflops"] = round(3 * k_tf, 3)
         out["kernel_executed_f16_frac"] = round(3 * k_tf / MFMA_PEAK_TFLOPS["bf16"], 5)
     if sum_us > 0 and groups == 1:   # (concurrent clip groups share the chip: a launch's in-situ time is then not comparable with its isolated one)
