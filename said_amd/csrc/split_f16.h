@@ -27,14 +27,15 @@ static __device__ __forceinline__ SplitH split_f16x8(const f32x4s a, const f32x4
     }
     return r;
 }
-// OPERAND FENCE (round 4, found the hard way — profiles/r04i_attn_split_hazard.txt): a v_mfma_f32_32x32x16_f16 whose 128-bit A / B operand was
-// written by VALU instructions (v_cvt_pk_f16_f32, the SDWA converts, v_pk_mul_f32) a few issue slots earlier can read a stale register.  The
-// compiler separates the pair by two wait states; that holds while the SIMD's other waves keep interleaving, and failed — silently, a few
-// 1e-2 errors in some clips, different every run — as soon as the co-resident waves were this engine's memory-bound kernels of ANOTHER clip
-// group, i.e. when this wave issued back to back.  So every split operand of a key tile is computed first, then the scheduler is fenced and
-// the wave idles SAID_SP_FENCE_NOPS issue slots, then the MFMAs go out together (they hide behind the other waves' VALU work anyway) — and where
-// the NEXT conversions follow the MFMAs directly (fgemm_kernel's k loop), a second fence sits behind them: the registers they read are the ones
-// about to be rewritten.
+// TWO RULES for v_mfma_f32_32x32x16_f16 in this engine, both found the hard way (profiles/r04i_attn_split_hazard.txt: runs that were bit-stable alone and
+// differed by up to 5e-2 in a few clips, silently, as soon as waves of this engine's OTHER kernels shared the SIMD):
+//  1. ROTATION: two MFMAs that accumulate into the same registers have at least two other MFMAs of the wave between them and no idle slots — an accumulate
+//     never needs the result of an MFMA still in flight.  (Hence three accumulators per product: main, l.h, h.l.)  Back to back, one apart, or with idle slots
+//     between them: not bit-stable under concurrent clip groups; the compiler's wait states do not cover it.
+//  2. OPERAND FENCE: all split operands of a tile are computed first, then the scheduler is fenced and the wave idles SAID_SP_FENCE_NOPS issue slots, then the
+//     MFMAs go out together — the machine scheduler otherwise interleaves the next operand's conversions with the MFMAs (a v_cvt_pk_f16_f32 writing a register
+//     of a 128-bit operand two wait states before the MFMA that reads it, or rewriting one two issue slots after it), which breaks rule 1's "no other work
+//     between the MFMAs" and was the first thing seen failing.  Free: the MFMAs hide behind the other waves' VALU work anyway.
 #ifndef SAID_SP_FENCE_NOPS
 #define SAID_SP_FENCE_NOPS 16
 #endif

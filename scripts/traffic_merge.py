@@ -35,7 +35,10 @@ def matcher(name):
         return lambda k: pre + "," in k or pre + ">" in k
     m = re.match(r"(fgemm|tgemm)_kernel<(\d+),(\w+)>", name)
     if m:   # both are instantiations of fgemm_kernel<NJ, KH, BF, ...>: fp32 (K halves) / bf16
-        pre = f"fgemm_kernel<{int(m.group(2)) // 32}, " + ("2, false" if m.group(1) == "fgemm" else "1, true")
+        nj = int(m.group(2)) // 32
+        if m.group(1) == "fgemm":   # fp32 operands: <NJ, 2, false, ...> (fp32 MFMAs) or <NJ, 1, false, 2, true> (split-fp16 products, round 4)
+            return lambda k: f"fgemm_kernel<{nj}, 2, false" in k or f"fgemm_kernel<{nj}, 1, false" in k
+        pre = f"fgemm_kernel<{nj}, 1, true"
         return lambda k: pre in k
     m = re.match(r"xgemm_kernel<(\d+),(bf16|f32),(\w+)>", name)
     if m:
