@@ -159,8 +159,10 @@ struct said_ctx {
     bool xclk_on = false;
     int battn = -1;           // round 4: bf16-operand self-attention with a head's K / V resident in LDS (attn.hip: battn_kernel) behind rgemm's q/k/v;
                               // 0: attn_kernel on fp32 operands (said_debug_option "battn")
-    int attn_split = -1;      // round 4: fp32 mode runs both attention products on split-fp16 operands (attn.hip: PM == 2; 22-bit significands, fp32
-                              // accumulation); 0: v_mfma_f32_32x32x2_f32 on the fp32 operands (said_debug_option "attn_split")
+    int attn_split = -1;      // round 4: > 0: fp32 mode runs both attention products on split-fp16 operands (attn.hip: PM == 2; 22-bit significands, fp32
+                              // accumulation); default (-1) and 0: v_mfma_f32_32x32x2_f32 on the fp32 operands (said_debug_option "attn_split").  OPT-IN: in the
+                              // only issue order that is bit-stable next to other streams (three accumulators in rotation, split_f16.h) it is no faster than
+                              // the fp32 MFMAs (55.9 vs 55.7 us at T = 1800, 9.99 vs 10.19 at T = 600); the faster orders are in git history and not safe.
     int gemm_split = -1;      // round 4: fp32 mode's large-batch token-major GEMMs (fgemm_kernel) on split-fp16 operands too (tgemm.hip: SP); 0: fp32 MFMAs
                               // (said_debug_option "gemm_split")
     int rgemm = -1;           // round 4: register-stationary, wave-specialised persistent GEMMs (rgemm.hip) wherever launch_rgemm serves the shape
@@ -580,7 +582,7 @@ void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hi
         if (trace_on()) { fprintf(stderr, "[said] attn #%d D=%d KS=%d T=%d batch=%d\n", c->dbg_count - 1, head_dim, KS, a.T, batch); fflush(stderr); }
         AttnArgs a2 = a;
         a2.b0 = c->cur_b0;
-        launch_attn(a2, batch, head_dim, KS, s, c->bf16_mode ? 1 : (c->attn_split != 0 ? 2 : 0));
+        launch_attn(a2, batch, head_dim, KS, s, c->bf16_mode ? 1 : (c->attn_split > 0 ? 2 : 0));
         if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
     }
 }
@@ -2366,7 +2368,7 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "steps_per_graph") return ctx->spg_limit;
     if (k == "tm_acts") return ctx->tm_acts;
     if (k == "gemm_split") return (!ctx->bf16_mode && ctx->gemm_split != 0) ? 1 : 0;
-    if (k == "attn_split") return (!ctx->bf16_mode && ctx->attn_split != 0) ? 1 : 0;   // 1: fp32-mode attention products run on split-fp16 operands
+    if (k == "attn_split") return (!ctx->bf16_mode && ctx->attn_split > 0) ? 1 : 0;   // 1: fp32-mode attention products run on split-fp16 operands
     if (k == "rgemm") return ctx->rgemm;
     if (k == "n_rgemm") return ctx->n_rgemm;
     if (k == "n_xgemm") return ctx->n_xgemm;
@@ -2779,7 +2781,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                 a.qk = ctx->aQK; a.v = ctx->aVT; a.o = ctx->aO;
                 a.v_bstride = hs; a.o_bstride = 2 * hs; a.b0 = 0;
                 a.pitch = Fp; a.T = Fr; a.heads = W2V_HEADS; a.rows = vt_rows; a.scale = 0.125f;
-                launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : (tt * W2V_HEADS <= 8192 ? 4 : 1), s, ctx->attn_split != 0 ? 2 : 0);
+                launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : (tt * W2V_HEADS <= 8192 ? 4 : 1), s, ctx->attn_split > 0 ? 2 : 0);
             }
             {
                 GemmArgs a = mkargs(Fr, W2V_H);
