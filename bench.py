@@ -357,6 +357,10 @@ SECONDARY = {
     "cfg3_per_gpu_f32": dict(batch=32, seconds=10.0, num_steps=1000, dtype="f32", eta=0.0, edit=False, passes=1,
                              flags="--batch 32 --steps 1 --warmup 1",
                              workload="BASELINE.json configs[3], ONE GPU's share: 32 clips x 10 s, audio encode + 1000 DDIM steps, guidance 2, fp32 (no all-gather at N = 1)"),
+    "cfg3_split_optin_one_group": dict(batch=32, seconds=10.0, num_steps=1000, dtype="f32", eta=0.0, edit=False, passes=1, clip_groups=1, debug={"gemm_split": 1},
+                                       flags="--batch 32 --steps 1 --warmup 1 --clip_groups 1 --debug_option gemm_split=1",
+                                       workload="configs[3]'s per-GPU share with the OPT-IN split-fp16 GEMMs (DESIGN.md 8.4) as ONE clip group — the combination that was bit-stable "
+                                                "in every run; not the default"),
     "cfg4_edit": dict(batch=1, seconds=30.0, num_steps=100, dtype="f32", eta=0.0, edit=True, passes=2,
                       flags="--seconds 30 --num_steps 100 --edit",
                       workload="BASELINE.json configs[4]: editing mode, 1 clip x 30 s (T=1800), init_samples + in-betweening mask, 100 DDIM steps, guidance 2, fp32"),
@@ -373,6 +377,9 @@ def run_secondary(model, dev, gs):
         B = c["batch"]
         proc, lat0, edit_kw, T, Ta = make_inputs(model, dev, range(B), c["seconds"], c["edit"])
         model.set_mfma_dtype("bf16" if c["dtype"] == "bf16" else "fp32")
+        model.clip_groups = c.get("clip_groups")
+        for k, v in c.get("debug", {}).items():
+            model._get_engine(2 * B if gs > 1.0 else B, T).debug_option(k, v)
 
         def one(n_steps):
             return model.inference(proc, num_inference_steps=n_steps, guidance_scale=gs, eta=c["eta"], init_latents=lat0, **edit_kw).result
@@ -387,7 +394,7 @@ def run_secondary(model, dev, gs):
         assert torch.isfinite(res).all()
         Be = 2 * B if gs > 1.0 else B
         step_ms = loop_step_ms(model, proc, lat0, edit_kw, T, c["num_steps"], gs, c["eta"])
-        rf = roofline(model, Be, T, step_ms, c["dtype"], cfg_clips=B if gs > 1.0 else 0, traffic_key="cfg1" if name == "cfg1_eta1" else name,   # (eta = 1 runs the headline's kernels)
+        rf = roofline(model, Be, T, step_ms, c["dtype"], cfg_clips=B if gs > 1.0 else 0, traffic_key="cfg1" if name == "cfg1_eta1" else ("cfg3_per_gpu_f32" if name.startswith("cfg3") else name),   # (eta = 1 runs the headline's kernels)
                       groups=model._pick_clip_groups(B, Be // B * T))
         rf["audio_encode"] = audio_encode_block(model, proc, T, B, c["dtype"])
         rf.pop("by_kernel", None)      # the headline's roofline carries the per-kernel table; keep the line readable
@@ -396,6 +403,9 @@ def run_secondary(model, dev, gs):
                      "ms_per_denoise_step": round(step_ms, 4), "dtype": c["dtype"], "workload": c["workload"],
                      "command": "python bench.py " + c["flags"], "graph_nodes_per_step": model._eng.graph_num_nodes(), "roofline": rf,
                      "clip_groups": model._pick_clip_groups(B, Be // B * T)}
+        for k in c.get("debug", {}):
+            model._eng.debug_option(k, -1)
+        model.clip_groups = None
     model.set_mfma_dtype("fp32")
     return out
 

@@ -163,8 +163,9 @@ struct said_ctx {
                               // accumulation); default (-1) and 0: v_mfma_f32_32x32x2_f32 on the fp32 operands (said_debug_option "attn_split").  OPT-IN: in the
                               // only issue order that is bit-stable next to other streams (three accumulators in rotation, split_f16.h) it is no faster than
                               // the fp32 MFMAs (55.9 vs 55.7 us at T = 1800, 9.99 vs 10.19 at T = 600); the faster orders are in git history and not safe.
-    int gemm_split = -1;      // round 4: fp32 mode's large-batch token-major GEMMs (fgemm_kernel) on split-fp16 operands too (tgemm.hip: SP); 0: fp32 MFMAs
-                              // (said_debug_option "gemm_split")
+    int gemm_split = -1;      // round 4: > 0: fp32 mode's large-batch token-major GEMMs (fgemm_kernel) on split-fp16 operands (tgemm.hip: SP); default (-1) and 0:
+                              // fp32 MFMAs (said_debug_option "gemm_split").  OPT-IN: +22 % per step with three clip groups, but one soak process in twelve then printed a
+                              // deviating checksum (profiles/r04i_attn_split_hazard.txt); with ONE clip group it was bit-stable in every run observed (+8 %).
     int rgemm = -1;           // round 4: register-stationary, wave-specialised persistent GEMMs (rgemm.hip) wherever launch_rgemm serves the shape
                               // (bf16 mode: 192-wide GEMMs with K <= 576, q/k/v); 0: off (said_debug_option "rgemm")
     long long n_rgemm = 0;
@@ -617,7 +618,7 @@ void do_tgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     TGemmArgs a2 = a;
     a2.f32 = c->bf16_mode ? 0 : 1;
     if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }   // token-major intermediate (GEGLU product) in fp32
-    a2.f32_split = (a2.f32 && c->gemm_split != 0) ? 1 : 0;
+    a2.f32_split = (a2.f32 && c->gemm_split > 0) ? 1 : 0;
     if (dbg_go(c) && !launch_tgemm(a2, batch, s)) {
         char b[160]; snprintf(b, sizeof b, "token-major GEMM: shape M=%d N=%d K=%d (batch %d) is not served by any kernel", a.M, a.N, a.K, batch);
         c->launch_err = b;
@@ -2367,7 +2368,7 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "audio_chunk") return ctx->audio_chunk;
     if (k == "steps_per_graph") return ctx->spg_limit;
     if (k == "tm_acts") return ctx->tm_acts;
-    if (k == "gemm_split") return (!ctx->bf16_mode && ctx->gemm_split != 0) ? 1 : 0;
+    if (k == "gemm_split") return (!ctx->bf16_mode && ctx->gemm_split > 0) ? 1 : 0;
     if (k == "attn_split") return (!ctx->bf16_mode && ctx->attn_split > 0) ? 1 : 0;   // 1: fp32-mode attention products run on split-fp16 operands
     if (k == "rgemm") return ctx->rgemm;
     if (k == "n_rgemm") return ctx->n_rgemm;
