@@ -8,6 +8,8 @@
 //   order 1: two accumulators alternating (one other MFMA between)   a, b, a, b, ...
 //   order 2: three accumulators in rotation (two between)            a, b, c, a, b, c, ...
 //   order 3: one accumulator, 16 idle slots between the MFMAs
+//   order 4: fgemm's FAILING variant: three column tiles per step, each: convert its B operand, fence, (cross_j, main_j, cross_j), fence — six accumulators
+//   order 5: the same without the fences
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_f16_chain scripts/ubench/mfma_f16_chain.hip && /tmp/mfma_f16_chain
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -23,9 +25,9 @@ constexpr int ITER = 4096;
 template <int ORDER>
 __global__ __launch_bounds__(64) void victim(const float* __restrict__ src, float* __restrict__ out) {
     const int l = threadIdx.x;
-    f32x16 a, b, c;
+    f32x16 a, b, c, d, e, f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { a[r] = 0.f; b[r] = 0.f; c[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { a[r] = 0.f; b[r] = 0.f; c[r] = 0.f; d[r] = 0.f; e[r] = 0.f; f[r] = 0.f; }
     float x = src[l & 7];   // 1.0 (read from memory so that nothing folds)
     for (int it = 0; it < ITER; ++it) {
         // fresh operands every step, written by VALU conversions: A rows all (it & 3) + 1, B columns all 1  ->  every element gains 16 * ((it & 3) + 1)
@@ -45,6 +47,22 @@ __global__ __launch_bounds__(64) void victim(const float* __restrict__ src, floa
             a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, a, 0, 0, 0);
             b = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, b, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, c, 0, 0, 0);
+        } else if (ORDER == 4 || ORDER == 5) {
+            // one MFMA per accumulator and step in total (a, b, c main; the cross accumulators add into a / b / c at the end via d, e, f): 3 x 3 MFMAs
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                f16x8 fj;
+                const float vj = x * (float)(j + 1) * (1.0f / (float)(j + 1));   // fresh VALU work per column tile (value 1)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fj[i] = (_Float16)vj;
+                if (ORDER == 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0); }
+                f32x16& xacc = j == 0 ? d : (j == 1 ? e : f);
+                f32x16& macc = j == 0 ? a : (j == 1 ? b : c);
+                xacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fj, xacc, 0, 0, 0);
+                macc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fj, macc, 0, 0, 0);
+                xacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fj, xacc, 0, 0, 0);
+                if (ORDER == 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0); }
+            }
         } else {
             a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, a, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -60,7 +78,7 @@ __global__ __launch_bounds__(64) void victim(const float* __restrict__ src, floa
     }
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s += a[r] + b[r] + c[r];
+    for (int r = 0; r < 16; ++r) s += a[r] + b[r] + c[r] + d[r] + e[r] + f[r];
     out[blockIdx.x * 64 + l] = s;
 }
 
@@ -127,13 +145,15 @@ int main() {
     // expected per-lane sum: each step adds 16 * m per MFMA and element (m = (it & 3) + 1), three MFMAs per step, 16 registers summed
     double per_elem = 0;
     for (int it = 0; it < ITER; ++it) per_elem += 16.0 * ((it & 3) + 1) * 3;
-    const float want = (float)(per_elem * 16);   // (exactly representable? 16 * 3 * 16 * 10240 = 7,864,320 < 2^24: yes)
-    printf("expected lane sum %.1f\n", want);
+    const float want3 = (float)(per_elem * 16);   // (exactly representable? 16 * 3 * 16 * 10240 = 7,864,320 < 2^24: yes)
+    printf("expected lane sum %.1f (orders 4 / 5: three times that, summed per accumulator below 2^24, the lane total rounds identically in every wave)\n", want3);
     std::vector<float> h((size_t)wgs * 64);
     const char* agg_names[] = {"none", "fp32 MFMA loop", "fp16 MFMA loop", "memory stream + fp32 MFMA bursts"};
-    const char* ord_names[] = {"one accumulator back to back", "two accumulators alternating", "three accumulators in rotation", "one accumulator, 16 idle slots between"};
+    const char* ord_names[] = {"one accumulator back to back", "two accumulators alternating", "three accumulators in rotation", "one accumulator, 16 idle slots between",
+                               "per column tile: cvt, fence, x m x, fence", "per column tile: cvt, x m x (no fences)"};
     for (int agg = 0; agg < 4; ++agg)
-        for (int ord = 0; ord < 4; ++ord) {
+        for (int ord = 0; ord < 6; ++ord) {
+            const float want = ord >= 4 ? 3.0f * want3 : want3;
             long bad = 0, waves_bad = 0;
             double worst = 0;
             for (int rep = 0; rep < 6; ++rep) {
@@ -144,6 +164,8 @@ int main() {
                 if (ord == 1) run_victim<1>(sv, src, out, wgs);
                 if (ord == 2) run_victim<2>(sv, src, out, wgs);
                 if (ord == 3) run_victim<3>(sv, src, out, wgs);
+                if (ord == 4) run_victim<4>(sv, src, out, wgs);
+                if (ord == 5) run_victim<5>(sv, src, out, wgs);
                 CHECK(hipStreamSynchronize(sv));
                 CHECK(hipStreamSynchronize(sa));
                 CHECK(hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost));
