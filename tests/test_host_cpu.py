@@ -278,3 +278,21 @@ def test_clip_group_policy():
     assert pick(64, 1200) == 1
     m.clip_groups = 5
     assert pick(3, 1200) == 3 and pick(64, 1200) == 5                   # forced, capped by the batch
+
+
+def test_traffic_matcher_knows_the_kernel_name_variants():
+    """scripts/traffic_merge.py maps bench.py's family names onto rocprofv3's demangled kernel names: the fp32 fgemm family covers both product modes
+    (<NJ, 2, false, ...> fp32 MFMAs, <NJ, 1, false, 2, true> split-fp16), attention names carry the product mode as third template argument.  (The script
+    has a command-line body: only its tables and `matcher` are evaluated here.)"""
+    src = open(os.path.join(ROOT, "scripts", "traffic_merge.py")).read()
+    tables = src[src.index("EPI = {"):src.index("def matcher(")]
+    fn = src[src.index("def matcher("):src.index("\ntag = sys.argv")]
+    ns = {}
+    exec("import re\n" + tables + fn, ns)
+    m = ns["matcher"]("fgemm_kernel<96,store>")
+    assert m("void said::fgemm_kernel<3, 2, false, 4>(said::TGemmArgs)") and m("void said::fgemm_kernel<3, 1, false, 2, true>(said::TGemmArgs)")
+    assert not m("void said::fgemm_kernel<3, 1, true, 4>(said::TGemmArgs)") and not m("void said::fgemm_kernel<4, 1, false, 3>(said::TGemmArgs)")
+    a = ns["matcher"]("attn_kernel<D32,KS4>")
+    assert a("void said::attn_kernel<1, 4, 0, 1>(float const*)") and a("void said::attn_kernel<1, 4, 2, 1>(float const*)") and not a("void said::attn_kernel<2, 4, 0, 1>(float const*)")
+    u = ns["matcher"]("ugemm_kernel<NB1,KS8,store>")
+    assert u("void said::ugemm_kernel<1, 8, 0, 3, false, false>(float const*)") and not u("void said::ugemm_kernel<1, 8, 3, 0, false, false>(float const*)")
