@@ -259,6 +259,15 @@ int said_debug_clocks(said_ctx* ctx, int enable, long long* out_host);
  * ("H0","H1","P","Q","M","X1","X2","X3","O","QK","VT","F","KV","CTX","EO","E0","E1","E2",
  *  "x","eps","stH0","stP","stM", ...) to host memory. */
 int said_debug_read(said_ctx* ctx, const char* name, float* out_host, int64_t n);
+/* Workspace inspection (race hunting, round 5): the context's (max_batch_eff, max_frames)-sized buffers by allocation index.
+ * _info: device pointer, size in bytes and a short name ("H0", "uPA", ..., "?" if unnamed) of buffer `idx`;
+ * _fill: synchronises the device and sets EVERY byte of every workspace buffer to `byte_value` (0xFF: NaN patterns; drops the step graph
+ *        and the cached band tables) — a result that changes with the fill value is a read of memory nobody wrote;
+ * _copy: enqueues a device-to-device copy of the first `bytes` bytes of buffer `idx` to `dst_dev` on `stream`. */
+int said_debug_ws_count(const said_ctx* ctx);
+int said_debug_ws_info(said_ctx* ctx, int idx, void** ptr_out, long long* bytes_out, const char** name_out);
+int said_debug_ws_fill(said_ctx* ctx, int byte_value);
+int said_debug_ws_copy(said_ctx* ctx, int idx, void* dst_dev, long long bytes, void* stream);
 
 /* ---- VAE encoder ----------------------------------------------
  * Replaces the device work of BCVAE.encode -> BCEncoder.forward (said/model/vae.py:26-83,

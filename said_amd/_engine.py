@@ -18,7 +18,7 @@ _lib = None
 
 PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 NCOEF = 8
-ABI_VERSION = 6   # include/said_hip.h as bound below; a stale libsaid_hip.so is refused at load time
+ABI_VERSION = 7   # include/said_hip.h as bound below; a stale libsaid_hip.so is refused at load time
 
 
 class EngineError(RuntimeError):
@@ -69,6 +69,10 @@ EXPORTS = {
     "said_debug_stop_after": (c_int, [c_void_p, c_int]),
     "said_debug_clocks": (c_int, [c_void_p, c_int, c_void_p]),
     "said_debug_read": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
+    "said_debug_ws_count": (c_int, [c_void_p]),
+    "said_debug_ws_info": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(ctypes.c_longlong), POINTER(c_char_p)]),
+    "said_debug_ws_fill": (c_int, [c_void_p, c_int]),
+    "said_debug_ws_copy": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_longlong, c_void_p]),
     "said_unet_algorithmic_bytes": (c_double, [c_int, c_int, c_int]),
     "said_unet_algorithmic_flops": (c_double, [c_int, c_int]),
     "said_vae_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int]),
@@ -372,6 +376,25 @@ class Engine:
     def debug_read(self, name: str, shape) -> np.ndarray:
         out = np.empty(shape, dtype=np.float32)
         self._chk(self.lib.said_debug_read(self.h, name.encode(), out.ctypes.data_as(c_void_p), out.size), "said_debug_read")
+        return out
+
+    def ws_buffers(self):
+        """[(index, name, bytes)] of the context's workspace buffers (said_debug_ws_info)."""
+        out = []
+        for i in range(int(self.lib.said_debug_ws_count(self.h))):
+            p, nb, nm = c_void_p(), ctypes.c_longlong(0), c_char_p()
+            self._chk(self.lib.said_debug_ws_info(self.h, i, ctypes.byref(p), ctypes.byref(nb), ctypes.byref(nm)), "said_debug_ws_info")
+            out.append((i, (nm.value or b"?").decode(), int(nb.value)))
+        return out
+
+    def ws_fill(self, byte_value: int) -> None:
+        self._chk(self.lib.said_debug_ws_fill(self.h, int(byte_value) & 0xFF), "said_debug_ws_fill")
+
+    def ws_snapshot(self, idx: int, nbytes: int) -> torch.Tensor:
+        """Device copy (uint8) of workspace buffer `idx`, enqueued on the current stream."""
+        out = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.index):
+            self._chk(self.lib.said_debug_ws_copy(self.h, idx, _ptr(out), nbytes, _stream()), "said_debug_ws_copy")
         return out
 
     def loop_progress(self) -> int:

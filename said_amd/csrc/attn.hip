@@ -27,6 +27,10 @@
 #include "kernels.h"
 #include "split_f16.h"
 
+#ifndef SAID_ATTN_SP_ORDER
+#define SAID_ATTN_SP_ORDER 0
+#endif
+
 namespace said {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -88,13 +92,15 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
     for (int q = 0; q < NQ / 2; ++q) qs[q] = split_f16x8(qf[2 * q], qf[2 * q + 1]);
     float m = -1.0e30f, lsum = 0.f;
-    f32x16 o[ND], ox[SP ? ND : 1], oy[SP ? ND : 1];   // ox, oy: the split mode's cross terms v.l p.h and v.h p.l (x 2^11)
+    constexpr bool ROT = SP && SAID_ATTN_SP_ORDER == 3;   // (round 4's three-accumulator rotation: race-hunt builds only)
+    f32x16 o[ND], ox[SP ? ND : 1], oy[ROT ? ND : 1];   // ox (, oy): the split mode's cross terms v.l p.h + v.h p.l (x 2^11)
 #pragma unroll
     for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             o[nd][r] = 0.f;
-            if (SP) { ox[SP ? nd : 0][r] = 0.f; oy[SP ? nd : 0][r] = 0.f; }
+            if (SP) ox[SP ? nd : 0][r] = 0.f;
+            if (ROT) oy[ROT ? nd : 0][r] = 0.f;
         }
 
     const int nkt = (T + 31) >> 5;
@@ -121,20 +127,33 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
             for (int q = 0; q < NQ / 2; ++q) ks[q] = split_f16x8(kf[2 * q], kf[2 * q + 1]);
             operand_fence();
-            // Three accumulators (main, k.l q.h, k.h q.l), MFMAs issued in rotation: two MFMAs on the same accumulator always have two others between
-            // them, so an accumulate never needs the result of an MFMA still in flight.  Same-accumulator MFMAs back to back (or one apart, or with idle
-            // slots between) were NOT bit-stable under concurrent clip groups — profiles/r04i_attn_split_hazard.txt.
+            // Two accumulators: main (k.h q.h) and cross (k.l q.h + k.h q.l, scaled by 2^-11 at the end).  Round 4 believed same-accumulator MFMAs had to be
+            // "in rotation over three accumulators" to be bit-stable beside other streams; round 5 found the actual mechanism (a packed-fp32 operand misread in
+            // OTHER kernels' waves while fp16 / bf16 MFMAs run beside them: DESIGN.md 8.4, said_amd/build.py NO_SLP) — the issue order here never mattered.
+            // SAID_ATTN_SP_ORDER (race-hunt builds, scripts/race_localise.py): 2 = idle slots between the MFMAs, the densest aggressor pattern round 4 had
+            // (every concurrent run wrong before the fix), 3 = round 4's three-accumulator rotation.
             f32x16 sxa, sxb;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sxa[r] = 0.f; sxb[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { sxa[r] = 0.f; sxb[r] = 0.f; }   // (sxb: the rotation build's third accumulator)
+#if SAID_ATTN_SP_ORDER == 3
 #pragma unroll
             for (int q = 0; q < NQ / 2; ++q) {
                 sxa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].l, qs[q].h, sxa, 0, 0, 0);
                 sxb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].h, qs[q].l, sxb, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].h, qs[q].h, s, 0, 0, 0);
             }
+#else
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = fmaf(sxa[r] + sxb[r], 0x1p-11f, s[r]);
+            for (int q = 0; q < NQ / 2; ++q) {
+                sxa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].l, qs[q].h, sxa, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].h, qs[q].h, s, 0, 0, 0);
+                if (SAID_ATTN_SP_ORDER == 2) idle_slots16();
+                sxa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ks[q].h, qs[q].l, sxa, 0, 0, 0);
+                if (SAID_ATTN_SP_ORDER == 2) idle_slots16();
+            }
+#endif
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = fmaf(ROT ? sxa[r] + sxb[r] : sxa[r], 0x1p-11f, s[r]);
         }
         if constexpr (BF) {   // (converted operands first, then the fence, then the MFMAs: operand_fence)
             bf16x8a kh[NQ / 2];
@@ -216,26 +235,28 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     o[nd][r] *= alpha;
-                    if (SP) { ox[SP ? nd : 0][r] *= alpha; oy[SP ? nd : 0][r] *= alpha; }
+                    if (SP) ox[SP ? nd : 0][r] *= alpha;
+                    if (ROT) oy[ROT ? nd : 0][r] *= alpha;
                 }
         }
         }
-        if constexpr (SP) {
-            // keys past T: p is exactly 0, but the never-written columns of v hold whatever the workspace held — finite, yet not
-            // necessarily inside fp16's range (0 x inf): zeroed in the one tile that has such keys
-            f32x4a vz[ND][4];
+        // keys past T: p is exactly 0, but the never-written columns of v hold whatever the workspace held (0 x NaN is NaN; in split mode 0 x inf
+        // once a finite value leaves fp16's range): zeroed in the one tile that has such keys, so no result depends on memory nobody wrote
+        // (scripts/poison_ws.py: every workspace byte 0xFF before the run)
+        f32x4a vz[ND][4];
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vz[nd][q] = vf[nd][q];
+        if (j0 + 32 > T) {
 #pragma unroll
             for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) vz[nd][q] = vf[nd][q];
-            if (j0 + 32 > T) {
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int nd = 0; nd < ND; ++nd)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) vz[nd][q][e] = (j0 + 8 * q + 4 * lh + e < T) ? vz[nd][q][e] : 0.f;
-            }
+                    for (int e = 0; e < 4; ++e) vz[nd][q][e] = (j0 + 8 * q + 4 * lh + e < T) ? vz[nd][q][e] : 0.f;
+        }
+        if constexpr (SP) {
             SplitH psa[2], vsa[2][ND];
 #pragma unroll
             for (int m8 = 0; m8 < 2; ++m8) {
@@ -248,10 +269,18 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
             for (int m8 = 0; m8 < 2; ++m8)
 #pragma unroll
-                for (int nd = 0; nd < ND; ++nd) {   // (rotation over three accumulators, as for the scores)
+                for (int nd = 0; nd < ND; ++nd) {   // (two accumulators, as for the scores)
+#if SAID_ATTN_SP_ORDER == 3
                     ox[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].l, psa[m8].h, ox[nd], 0, 0, 0);
-                    oy[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].h, psa[m8].l, oy[nd], 0, 0, 0);
+                    oy[ROT ? nd : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].h, psa[m8].l, oy[ROT ? nd : 0], 0, 0, 0);
                     o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].h, psa[m8].h, o[nd], 0, 0, 0);
+#else
+                    ox[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].l, psa[m8].h, ox[nd], 0, 0, 0);
+                    o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].h, psa[m8].h, o[nd], 0, 0, 0);
+                    if (SAID_ATTN_SP_ORDER == 2) idle_slots16();
+                    ox[nd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vsa[m8][nd].h, psa[m8].l, ox[nd], 0, 0, 0);
+                    if (SAID_ATTN_SP_ORDER == 2) idle_slots16();
+#endif
                 }
         }
         if constexpr (BF) {
@@ -261,7 +290,7 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
                 const f32x4a p0 = {s[8 * m8], s[8 * m8 + 1], s[8 * m8 + 2], s[8 * m8 + 3]}, p1 = {s[8 * m8 + 4], s[8 * m8 + 5], s[8 * m8 + 6], s[8 * m8 + 7]};
                 pb[m8] = pk_bf16x8(p0, p1);
 #pragma unroll
-                for (int nd = 0; nd < ND; ++nd) vb8[m8][nd] = pk_bf16x8(vf[nd][2 * m8], vf[nd][2 * m8 + 1]);
+                for (int nd = 0; nd < ND; ++nd) vb8[m8][nd] = pk_bf16x8(vz[nd][2 * m8], vz[nd][2 * m8 + 1]);
             }
             operand_fence();
 #pragma unroll
@@ -272,7 +301,7 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
         for (int r = 0; r < ((SP || BF) ? 0 : 16); ++r)
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) o[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[nd][r >> 2][r & 3], s[r], o[nd], 0, 0, 0);
+            for (int nd = 0; nd < ND; ++nd) o[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(vz[nd][r >> 2][r & 3], s[r], o[nd], 0, 0, 0);
     };
     if constexpr (QW > 1) {
         // K / V tiles staged ONCE per workgroup through LDS and shared by its QW query-tile waves.  Fetching fragments straight
@@ -359,7 +388,7 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #pragma unroll
         for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[nd][r] = fmaf(ox[nd][r] + oy[nd][r], 0x1p-11f, o[nd][r]);
+            for (int r = 0; r < 16; ++r) o[nd][r] = fmaf(ROT ? ox[nd][r] + oy[ROT ? nd : 0][r] : ox[nd][r], 0x1p-11f, o[nd][r]);
     }
 
     // ---- merge the KS partial states ----

@@ -72,6 +72,7 @@ struct said_ctx {
     std::map<std::string, HostTensor> host_w;
     std::vector<void*> allocs;       // weights, tables and lazily grown buffers: live as long as the context
     std::vector<void*> ws_allocs;    // the (max_batch_eff, max_frames)-sized workspace: replaced as a whole by said_reserve
+    std::map<void*, size_t> alloc_bytes;   // size of every live allocation made through dalloc (said_debug_ws_*)
     std::vector<void*>* alloc_list = &allocs;
     bool finalized = false, has_audio = false, has_audio_proj = false;
     bool is_clone = false;           // said_clone: the packed weights and tables belong to the parent context
@@ -159,13 +160,12 @@ struct said_ctx {
     bool xclk_on = false;
     int battn = -1;           // round 4: bf16-operand self-attention with a head's K / V resident in LDS (attn.hip: battn_kernel) behind rgemm's q/k/v;
                               // 0: attn_kernel on fp32 operands (said_debug_option "battn")
-    int attn_split = -1;      // round 4: > 0: fp32 mode runs both attention products on split-fp16 operands (attn.hip: PM == 2; 22-bit significands, fp32
-                              // accumulation); default (-1) and 0: v_mfma_f32_32x32x2_f32 on the fp32 operands (said_debug_option "attn_split").  OPT-IN: in the
-                              // only issue order that is bit-stable next to other streams (three accumulators in rotation, split_f16.h) it is no faster than
-                              // the fp32 MFMAs (55.9 vs 55.7 us at T = 1800, 9.99 vs 10.19 at T = 600); the faster orders are in git history and not safe.
-    int gemm_split = -1;      // round 4: > 0: fp32 mode's large-batch token-major GEMMs (fgemm_kernel) on split-fp16 operands (tgemm.hip: SP); default (-1) and 0:
-                              // fp32 MFMAs (said_debug_option "gemm_split").  OPT-IN: +22 % per step with three clip groups, but one soak process in twelve then printed a
-                              // deviating checksum (profiles/r04i_attn_split_hazard.txt); with ONE clip group it was bit-stable in every run observed (+8 %).
+    int attn_split = -1;      // fp32 mode: both attention products on split-fp16 operands (attn.hip: PM == 2; x = h + 2^-11 l: 22-bit significands, fp32 accumulation,
+                              // as close to a float64 evaluation as the fp32 MFMAs: tests/test_gpu_round4.py).  Default (-1) and 1: ON since round 5; 0: v_mfma_f32_32x32x2_f32
+                              // on the fp32 operands (said_debug_option "attn_split").  Round 4 shipped it opt-in because runs beside other streams were not bit-stable;
+                              // round 5 found the mechanism in OTHER kernels' packed-fp32 instructions (split_f16.h, build.py NO_SLP) and removed it.
+    int gemm_split = -1;      // fp32 mode: the large-batch token-major GEMMs (fgemm_kernel) on split-fp16 operands (tgemm.hip: SP).  Default (-1) and 1: ON since round 5
+                              // (as above); 0: fp32 MFMAs (said_debug_option "gemm_split").
     int rgemm = -1;           // round 4: register-stationary, wave-specialised persistent GEMMs (rgemm.hip) wherever launch_rgemm serves the shape
                               // (bf16 mode: 192-wide GEMMs with K <= 576, q/k/v); 0: off (said_debug_option "rgemm")
     long long n_rgemm = 0;
@@ -269,6 +269,7 @@ int dalloc(said_ctx* ctx, T** out, size_t n, bool zero = true) {
     HIPCHK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
     if (zero) HIPCHK(hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)));
     ctx->alloc_list->push_back(p);
+    ctx->alloc_bytes[p] = std::max<size_t>(n, 1) * sizeof(T);
     *out = static_cast<T*>(p);
     return 0;
 }
@@ -583,7 +584,7 @@ void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hi
         if (trace_on()) { fprintf(stderr, "[said] attn #%d D=%d KS=%d T=%d batch=%d\n", c->dbg_count - 1, head_dim, KS, a.T, batch); fflush(stderr); }
         AttnArgs a2 = a;
         a2.b0 = c->cur_b0;
-        launch_attn(a2, batch, head_dim, KS, s, c->bf16_mode ? 1 : (c->attn_split > 0 ? 2 : 0));
+        launch_attn(a2, batch, head_dim, KS, s, c->bf16_mode ? 1 : (c->attn_split != 0 ? 2 : 0));
         if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
     }
 }
@@ -618,7 +619,7 @@ void do_tgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     TGemmArgs a2 = a;
     a2.f32 = c->bf16_mode ? 0 : 1;
     if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }   // token-major intermediate (GEGLU product) in fp32
-    a2.f32_split = (a2.f32 && c->gemm_split > 0) ? 1 : 0;
+    a2.f32_split = (a2.f32 && c->gemm_split != 0) ? 1 : 0;
     if (dbg_go(c) && !launch_tgemm(a2, batch, s)) {
         char b[160]; snprintf(b, sizeof b, "token-major GEMM: shape M=%d N=%d K=%d (batch %d) is not served by any kernel", a.M, a.N, a.K, batch);
         c->launch_err = b;
@@ -1485,7 +1486,7 @@ int check_ready(said_ctx* ctx) {
 // ============================================================================================
 extern "C" {
 
-int said_abi_version(void) { return 6; }   // 6: said_loop_progress; 5: said_clone, said_loop_params::noise_batch_offset; 4: said_reserve, noise_seed, said_philox_normal, said_debug_option
+int said_abi_version(void) { return 7; }   // 7: said_debug_ws_*; 6: said_loop_progress; 5: said_clone, said_loop_params::noise_batch_offset; 4: said_reserve, noise_seed, said_philox_normal, said_debug_option
 
 const char* said_last_error(const said_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -2368,8 +2369,8 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "audio_chunk") return ctx->audio_chunk;
     if (k == "steps_per_graph") return ctx->spg_limit;
     if (k == "tm_acts") return ctx->tm_acts;
-    if (k == "gemm_split") return (!ctx->bf16_mode && ctx->gemm_split > 0) ? 1 : 0;
-    if (k == "attn_split") return (!ctx->bf16_mode && ctx->attn_split > 0) ? 1 : 0;   // 1: fp32-mode attention products run on split-fp16 operands
+    if (k == "gemm_split") return (!ctx->bf16_mode && ctx->gemm_split != 0) ? 1 : 0;
+    if (k == "attn_split") return (!ctx->bf16_mode && ctx->attn_split != 0) ? 1 : 0;   // 1: fp32-mode attention products run on split-fp16 operands
     if (k == "rgemm") return ctx->rgemm;
     if (k == "n_rgemm") return ctx->n_rgemm;
     if (k == "n_xgemm") return ctx->n_xgemm;
@@ -2409,6 +2410,48 @@ int said_debug_read(said_ctx* ctx, const char* name, float* out_host, int64_t n)
     if (it == m.end() || !it->second) return fail(ctx, "said_debug_read: unknown or unallocated buffer %s", name);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out_host, it->second, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- workspace inspection (tests / race hunting): every (max_batch_eff, max_frames)-sized buffer by index --------------------------------
+static const char* ws_name(const said_ctx* c, const void* p) {
+    const std::pair<const void*, const char*> t[] = {
+        {c->x_cm, "x"}, {c->eps_cm, "eps"}, {c->H0.p, "H0"}, {c->H1.p, "H1"}, {c->P.p, "P"}, {c->Q.p, "Q"}, {c->M.p, "M"},
+        {c->H0.st, "stH0"}, {c->H1.st, "stH1"}, {c->P.st, "stP"}, {c->Q.st, "stQ"}, {c->M.st, "stM"},
+        {c->X1, "X1"}, {c->X2, "X2"}, {c->X3, "X3"}, {c->O, "O"}, {c->QK, "QK"}, {c->VT, "VT"}, {c->F, "F"}, {c->KV, "KV"}, {c->CTX, "CTX"},
+        {c->E0, "E0"}, {c->E1, "E1"}, {c->E2, "E2"}, {c->EO, "EO"}, {c->ts_dev, "ts"}, {c->coef_dev, "coef"}, {c->axpby_coef, "axpby_coef"},
+        {c->band_lo, "band_lo"}, {c->band_hi, "band_hi"}, {c->init_cm, "init_cm"}, {c->enoise_cm, "enoise_cm"}, {c->mask_cm, "mask_cm"},
+        {c->rescale_part, "rescale_part"}, {c->uPA, "uPA"}, {c->uPB, "uPB"}, {c->uPL, "uPL"}, {c->uPH, "uPH"}, {c->uPX, "uPX"}, {c->gn_coef, "gn_coef"},
+        {c->H0.t, "tH0"}, {c->H1.t, "tH1"}, {c->P.t, "tP"}, {c->Q.t, "tQ"}, {c->M.t, "tM"}, {c->tX1, "tX1"}, {c->tX2, "tX2"}, {c->tO, "tO"}, {c->tF, "tF"}};
+    for (const auto& e : t) if (e.first == p) return e.second;
+    return "?";
+}
+int said_debug_ws_count(const said_ctx* ctx) { return ctx ? (int)ctx->ws_allocs.size() : -1; }
+int said_debug_ws_info(said_ctx* ctx, int idx, void** ptr_out, long long* bytes_out, const char** name_out) {
+    if (!ctx || idx < 0 || idx >= (int)ctx->ws_allocs.size()) return -1;
+    void* p = ctx->ws_allocs[idx];
+    if (ptr_out) *ptr_out = p;
+    if (bytes_out) { auto it = ctx->alloc_bytes.find(p); *bytes_out = it == ctx->alloc_bytes.end() ? 0 : (long long)it->second; }
+    if (name_out) *name_out = ws_name(ctx, p);
+    return 0;
+}
+int said_debug_ws_fill(said_ctx* ctx, int byte_value) {
+    if (!ctx) return -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    for (void* p : ctx->ws_allocs) {
+        auto it = ctx->alloc_bytes.find(p);
+        if (it != ctx->alloc_bytes.end()) HIPCHK(hipMemset(p, byte_value, it->second));
+    }
+    HIPCHK(hipDeviceSynchronize());
+    ctx->band_T = ctx->band_S = -1;   // the band tables were part of it
+    drop_graphs(ctx);
+    return 0;
+}
+int said_debug_ws_copy(said_ctx* ctx, int idx, void* dst_dev, long long bytes, void* stream) {
+    if (!ctx || idx < 0 || idx >= (int)ctx->ws_allocs.size() || !dst_dev) return -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(dst_dev, ctx->ws_allocs[idx], (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
 
@@ -2782,7 +2825,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                 a.qk = ctx->aQK; a.v = ctx->aVT; a.o = ctx->aO;
                 a.v_bstride = hs; a.o_bstride = 2 * hs; a.b0 = 0;
                 a.pitch = Fp; a.T = Fr; a.heads = W2V_HEADS; a.rows = vt_rows; a.scale = 0.125f;
-                launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : (tt * W2V_HEADS <= 8192 ? 4 : 1), s, ctx->attn_split > 0 ? 2 : 0);
+                launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : (tt * W2V_HEADS <= 8192 ? 4 : 1), s, ctx->attn_split != 0 ? 2 : 0);
             }
             {
                 GemmArgs a = mkargs(Fr, W2V_H);

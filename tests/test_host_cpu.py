@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/said_hip.h but not exported"
     assert declared == set(_engine.EXPORTS), (declared ^ set(_engine.EXPORTS))
-    assert lib.said_abi_version() == _engine.ABI_VERSION == 6
+    assert lib.said_abi_version() == _engine.ABI_VERSION == 7
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -296,3 +296,35 @@ def test_traffic_matcher_knows_the_kernel_name_variants():
     assert a("void said::attn_kernel<1, 4, 0, 1>(float const*)") and a("void said::attn_kernel<1, 4, 2, 1>(float const*)") and not a("void said::attn_kernel<2, 4, 0, 1>(float const*)")
     u = ns["matcher"]("ugemm_kernel<NB1,KS8,store>")
     assert u("void said::ugemm_kernel<1, 8, 0, 3, false, false>(float const*)") and not u("void said::ugemm_kernel<1, 8, 3, 0, false, false>(float const*)")
+
+
+def test_no_crossed_packed_f32_in_shipped_isa(tmp_path):
+    """Round 5 (profiles/r05a_pk_fma_hazard.txt): on gfx950 a packed-fp32 instruction whose LOW half reads the HIGH register of an operand pair (an op_sel bit
+    set) can read that operand as 0 in lanes 48-63 while another wave of the SIMD issues fp16 / bf16 MFMAs — the concurrency-only corruption round 4 attributed to
+    the split-fp16 kernels.  The build scans every object's ISA and refuses such instructions; this test (a) checks the scanner on the three forms seen in round 4's
+    objects and on their harmless neighbours, (b) scans the ISA files of the library that is actually shipped (round 4's build: 341 instances)."""
+    from said_amd import build
+    asm = tmp_path / "k.s"
+    asm.write_text("\n".join([
+        "_ZN4said6victimEv:",
+        "\tv_pk_fma_f32 v[34:35], v[4:5], v[8:9], v[8:9] op_sel:[0,0,1] op_sel_hi:[1,0,1]",      # addend = high register for both halves: BAD
+        "\tv_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[1,1]",                   # BAD
+        "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,0] op_sel_hi:[0,1]",                   # BAD (swap)
+        "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7]",                                        # straight
+        "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel_hi:[1,0]",                                # high half reads the low register: never seen failing
+        "\tv_pk_fma_f16 v0, v1, v2, v2 op_sel:[0,0,1] op_sel_hi:[1,0,1]",                       # packed halves of ONE register: not affected
+        ".LBB0_1:", "\ts_endpgm"]))
+    bad = build.crossed_packed_f32(str(asm))
+    assert len(bad) == 3 and all(b.startswith("_ZN4said6victimEv: v_pk_") for b in bad)
+    libdir = os.path.dirname(_engine_lib_path())
+    files = [f for f in os.listdir(libdir) if f.endswith(".s") and "-hip-amdgcn-amd-amdhsa-" in f]
+    if not files:
+        pytest.skip("ISA files not present (library built elsewhere)")
+    assert {f.split("-hip-")[0] + ".hip" for f in files} >= {s for s in build.SOURCES if s.endswith(".hip")}
+    for f in files:
+        assert build.crossed_packed_f32(os.path.join(libdir, f)) == [], f
+
+
+def _engine_lib_path():
+    from said_amd import _engine
+    return _engine.library_path()
