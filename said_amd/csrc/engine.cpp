@@ -42,6 +42,8 @@ struct PW {  // packed GEMM weight (up to 2 K-segments) + bias
     float* w[2] = {nullptr, nullptr};
     float* w4[2] = {nullptr, nullptr};   // dwordx4 packing for the LDS-staged kernel
     float* w2[2] = {nullptr, nullptr};   // bf16 packing for the LDS-staged kernel's bf16 MFMA mode (same tails as w4)
+    float* ws[2] = {nullptr, nullptr};   // split-fp16 packing (kernels.h Seg::ws; same tails as w4) — UNet weights only (said_ctx::pw_split)
+    bool ws_flat = false;                // ws in the flat step layout (GEGLU's one-tile-per-wave shape)
     float* bias = nullptr;
     int N = 0, C[2] = {0, 0}, taps = 1, nseg = 1;
     bool gn_tail = false;                // w4[s] is followed by the GroupNorm gamma[C] and beta[C] of its source segment
@@ -166,6 +168,9 @@ struct said_ctx {
                               // round 5 found the mechanism in OTHER kernels' packed-fp32 instructions (split_f16.h, build.py NO_SLP) and removed it.
     int gemm_split = -1;      // fp32 mode: the large-batch token-major GEMMs (fgemm_kernel) on split-fp16 operands (tgemm.hip: SP).  Default (-1) and 1: ON since round 5
                               // (as above); 0: fp32 MFMAs (said_debug_option "gemm_split").
+    int ugemm_split = -1;     // fp32 mode: the small-batch channel-major GEMMs (ugemm_kernel) on split-fp16 operands too (gemm_lds.hip: SP; weights pre-split on the host:
+                              // Seg::ws).  Default (-1) and 1: ON; 0: fp32 MFMAs (said_debug_option "ugemm_split")
+    int pw_split = 0;         // make_pw: also build the split-fp16 packing (1: per-block layout, 2: flat) — set around the UNet weights only
     int rgemm = -1;           // round 4: register-stationary, wave-specialised persistent GEMMs (rgemm.hip) wherever launch_rgemm serves the shape
                               // (bf16 mode: 192-wide GEMMs with K <= 576, q/k/v); 0: off (said_debug_option "rgemm")
     long long n_rgemm = 0;
@@ -363,6 +368,35 @@ std::vector<float> pack_rows_bf16(const float* W, int Ctot, int taps, const std:
     memcpy(out.data(), h.data(), h.size() * 2);
     return out;
 }
+// split-fp16 packing for v_mfma_f32_32x32x16_f16 (gemm_lds.hip SP; kernels.h Seg::ws): w = h + 2^-11 l with h = RN16(w), l = RN16((w - h) * 2^11) (split_f16.h).
+// Per 24-channel block: NS = 5 (3 taps) / 2 (1 tap) k16 steps x 2 planes (h, l) x 64 lanes x 8 halfs; the 8 halfs of lane l in step s are K-group
+// g = 2 s + (l >> 5) of the block's tap-major K slice (tap = g / 3, channels 8 (g % 3) .. + 7), zeros past the slice's 9 / 3 groups.  flat: C / 16 steps over
+// the whole K (taps == 1), no padding.  Returned as float storage (2 halfs per float).
+std::vector<float> pack_rows_split(const float* W, int Ctot, int taps, const std::vector<int>& row_of, int ntiles_total, int c_begin, int C, bool flat) {
+    const int nblk = flat ? 1 : C / 24, ns = flat ? C / 16 : (taps == 3 ? 5 : 2), ng = flat ? C / 8 : 3 * taps;
+    std::vector<_Float16> h((size_t)ntiles_total * nblk * ns * 2 * 512);
+    size_t o = 0;
+    for (int tile = 0; tile < ntiles_total; ++tile)
+        for (int blk = 0; blk < nblk; ++blk)
+            for (int st = 0; st < ns; ++st)
+                for (int pl = 0; pl < 2; ++pl)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int row = row_of[tile * 32 + (l & 31)];
+                            const int g = 2 * st + (l >> 5);
+                            float v = 0.f;
+                            if (row >= 0 && g < ng) {
+                                const int tap = flat ? 0 : g / 3;
+                                const int c = c_begin + (flat ? 8 * g : 24 * blk + 8 * (g % 3)) + j;
+                                v = W[((size_t)row * Ctot + c) * taps + tap];
+                            }
+                            const _Float16 hv = (_Float16)v;
+                            h[o++] = pl == 0 ? hv : (_Float16)((v - (float)hv) * 2048.f);
+                        }
+    std::vector<float> out(h.size() / 2);
+    memcpy(out.data(), h.data(), h.size() * 2);
+    return out;
+}
 // fp32 host matrix -> bf16 (RNE) device array; `perm` (optional) reorders the K axis of a Conv1d weight [N][C][taps] to
 // tap-major [N][taps][C] (the token-major im2col order of tgemm.hip)
 int upload_bf16(said_ctx* ctx, void** out, const float* W, size_t N, size_t C, size_t taps) {
@@ -436,6 +470,13 @@ int make_pw(said_ctx* ctx, PW* pw, const std::string& wname, const std::string& 
             p2.insert(p2.end(), p4.begin() + w4_floats, p4.end());   // the GroupNorm / LayerNorm tails, unchanged
             if (upload(ctx, &pw->w4[s], p4.data(), p4.size())) return -1;
             if (upload(ctx, &pw->w2[s], p2.data(), p2.size())) return -1;
+            if (ctx->pw_split && C % 192 == 0) {   // (KS = 8 waves x whole 24-channel blocks)
+                const bool flat = ctx->pw_split == 2;
+                auto ps = pack_rows_split(t->data.data(), Ctot, tp, rows, (N + 31) / 32, s * C, C, flat);
+                ps.insert(ps.end(), p4.begin() + w4_floats, p4.end());
+                if (upload(ctx, &pw->ws[s], ps.data(), ps.size())) return -1;
+                pw->ws_flat = flat;
+            }
         }
     }
     if (!bname.empty()) { if (upvec(ctx, &pw->bias, bname, N)) return -1; }
@@ -486,7 +527,7 @@ Seg mkseg(const float* x, long long bstride, int pitch, int C, int taps, int pad
 inline Seg with_w4(Seg s, const float* w4, bool gn_tail = false, bool ln_tail = false) { s.w4 = w4; s.w4_gn_tail = gn_tail ? 1 : 0; s.w4_ln_tail = ln_tail ? 1 : 0; return s; }
 // attach K-segment k of a packed weight: both packings for the LDS-staged kernel and what follows them
 inline Seg with_pw(Seg s, const PW& pw, int k) {
-    s.w4 = pw.w4[k]; s.w2 = pw.w2[k]; s.w4_gn_tail = pw.gn_tail ? 1 : 0; s.w4_ln_tail = pw.ln_tail ? 1 : 0;
+    s.w4 = pw.w4[k]; s.w2 = pw.w2[k]; s.ws = pw.ws[k]; s.ws_flat = pw.ws_flat ? 1 : 0; s.w4_gn_tail = pw.gn_tail ? 1 : 0; s.w4_ln_tail = pw.ln_tail ? 1 : 0;
     return s;
 }
 void seg_gn(Seg& s, const float* part, long long part_bstride, int cpg, int nparts, float eps, const float* g, const float* b) {
@@ -550,6 +591,8 @@ void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS,
     const bool bf = c->bf16_mode;
     if (NB == 3 && epi == EPI_STORE && c->use_ugemm && !ugemm_supports(a2, epi, 3, KS, bf)) NB = 2;   // (the two-segment fp32 shapes spill at NB = 3: not built)
     const int tt = pick_tt(c, a2, epi, batch, NB, KS, bf);
+    // fp32 mode, single-tile workgroups: split-fp16 products wherever the shape is built for them (gemm_lds.hip SP) and the weights carry the packing
+    const bool sp = !bf && tt <= 1 && c->ugemm_split != 0 && c->use_ugemm && !a2.step_inc && ugemm_supports(a2, epi, NB, KS, 2);
     if (c->log_on) {
         double w = 0, in = 0, fl = 0;
         const double nout = (double)a.groups * a.N * (epi == EPI_GEGLU ? 2 : 1);
@@ -569,6 +612,7 @@ void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS,
         if (trace_on()) { fprintf(stderr, "[said] gemm #%d epi=%d NB=%d KS=%d T=%d N=%d batch=%d tt=%d\n", c->dbg_count - 1, epi, NB, KS, a.T, a.N, batch, tt); fflush(stderr); }
         const bool ug = c->use_ugemm && !a2.step_inc;
         if (tt > 1) launch_ugemm(a2, epi, batch, NB, KS, s, bf, tt);
+        else if (sp) launch_ugemm(a2, epi, batch, NB, KS, s, 2);
         else if (ug && bf && ugemm_supports(a2, epi, NB, KS, true)) launch_ugemm(a2, epi, batch, NB, KS, s, true);
         else if (ug && ugemm_supports(a2, epi, NB, KS)) launch_ugemm(a2, epi, batch, NB, KS, s);
         else launch_gemm(a2, epi, batch, NB, KS, s);
@@ -1730,6 +1774,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
     const char* res_names[NRES] = {"input_blocks.1.0", "middle_block.0", "middle_block.2", "output_blocks.0.0", "output_blocks.1.0"};
     const char* st_names[NST] = {"input_blocks.1.1", "middle_block.1", "output_blocks.0.1", "output_blocks.1.1"};
     std::vector<float> emb_w((size_t)NRES * MC * TE), emb_b((size_t)NRES * MC);
+    ctx->pw_split = 1;   // the ResBlock / SpatialTransformer weights also in the split-fp16 packing (small-batch fp32 products: gemm_lds.hip SP)
     for (int r = 0; r < NRES; ++r) {
         const std::string p = D + res_names[r];
         ResW& rw = ctx->res[r];
@@ -1770,6 +1815,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
             used += 2;
         }
     }
+    ctx->pw_split = 0;
     {   // all five emb_layers as one GEMM (960 x 768)
         ctx->host_w["__emb_all.w"] = HostTensor{emb_w, {NRES * MC, TE}};
         ctx->host_w["__emb_all.b"] = HostTensor{emb_b, {NRES * MC}};
@@ -1779,6 +1825,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
     for (int i = 0; i < NST; ++i) {
         const std::string p = D + st_names[i], b = p + ".transformer_blocks.0";
         STW& sw = ctx->st[i];
+        ctx->pw_split = 1;
         if (upvec(ctx, &sw.gn_g, p + ".norm.weight", MC) || upvec(ctx, &sw.gn_b, p + ".norm.bias", MC)) return -1;
         if (upvec(ctx, &sw.l1g, b + ".norm1.weight", MC) || upvec(ctx, &sw.l1b, b + ".norm1.bias", MC)) return -1;
         if (upvec(ctx, &sw.l2g, b + ".norm2.weight", MC) || upvec(ctx, &sw.l2b, b + ".norm2.bias", MC)) return -1;
@@ -1830,7 +1877,9 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
             }
             if (upload(ctx, &ctx->c2[i], c2v.data(), MC)) return -1;
         }
+        ctx->pw_split = 2;   // GEGLU runs as one output tile per wave over the whole K (NB = 4): flat step layout
         if (make_pw(ctx, &sw.ff1, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", 2 * FFI, MC, 0, 1, "", "", b + ".norm3.weight", b + ".norm3.bias")) return -1;
+        ctx->pw_split = 1;
         if (make_pw(ctx, &sw.ff2, b + ".ff.net.2.weight", b + ".ff.net.2.bias", MC, FFI, 0)) return -1;
         if (make_pw(ctx, &sw.proj, p + ".proj_out.weight", p + ".proj_out.bias", MC, MC, 1)) return -1;
         {   // proj_out o ff.net.2 folded into ONE GEMM over [h (768) ; x2 (192)]  (attention.py:193 `ff(norm3(x)) + x`, :232-234):
@@ -1886,10 +1935,11 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
             }
             PW& fp = sw.ffproj;
             fp.N = MC; fp.taps = 1; fp.nseg = 2; fp.bias = t0.bias;
-            fp.w[0] = t0.w[0]; fp.w4[0] = t0.w4[0]; fp.w2[0] = t0.w2[0]; fp.C[0] = FFI;
-            fp.w[1] = t1.w[0]; fp.w4[1] = t1.w4[0]; fp.w2[1] = t1.w2[0]; fp.C[1] = MC;
+            fp.w[0] = t0.w[0]; fp.w4[0] = t0.w4[0]; fp.w2[0] = t0.w2[0]; fp.ws[0] = t0.ws[0]; fp.C[0] = FFI;
+            fp.w[1] = t1.w[0]; fp.w4[1] = t1.w4[0]; fp.w2[1] = t1.w2[0]; fp.ws[1] = t1.ws[0]; fp.C[1] = MC;
         }
         used += 24;
+        ctx->pw_split = 0;
     }
     ctx->host_w["__kv_all"] = HostTensor{kv_w, {NST * 2 * MC, CD}};
     if (make_pw(ctx, &ctx->kv_all, "__kv_all", "", NST * 2 * MC, CD, 0)) return -1;
@@ -2351,6 +2401,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->gemm_split = value < 0 ? -1 : (value != 0);
     } else if (k == "attn_split") {
         ctx->attn_split = value < 0 ? -1 : (value != 0);
+    } else if (k == "ugemm_split") {
+        ctx->ugemm_split = value < 0 ? -1 : (value != 0);
     } else if (k == "battn") {
         ctx->battn = value < 0 ? -1 : (int)value;   // 0: off, 4 / 8: query tiles per workgroup (experiments), else on
     } else {
@@ -2370,6 +2422,7 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "steps_per_graph") return ctx->spg_limit;
     if (k == "tm_acts") return ctx->tm_acts;
     if (k == "gemm_split") return (!ctx->bf16_mode && ctx->gemm_split != 0) ? 1 : 0;
+    if (k == "ugemm_split") return (!ctx->bf16_mode && ctx->ugemm_split != 0) ? 1 : 0;
     if (k == "attn_split") return (!ctx->bf16_mode && ctx->attn_split != 0) ? 1 : 0;   // 1: fp32-mode attention products run on split-fp16 operands
     if (k == "rgemm") return ctx->rgemm;
     if (k == "n_rgemm") return ctx->n_rgemm;

@@ -61,6 +61,11 @@ struct FastHdr {       // unpacked view of the preloaded kernel parameters
 // and the grid width is passed explicitly.
 constexpr int kHdrDwords = 14;
 
+// dwords of one output tile's split-fp16 weights (Seg::ws): per-block layout [C / 24][5 | 2 steps][2 planes][64 lanes][4 dwords]; the flat layout of the
+// one-tile-per-wave GEGLU shape, [C / 16][2][64][4], has the same size as the fp32 packing
+__host__ __device__ constexpr unsigned sp_tile_dwords(int C, int taps, bool flat = false) {
+    return flat ? (unsigned)(C / 16) * 2u * 256u : (unsigned)(C / 24) * (taps == 3 ? 5u : 2u) * 2u * 256u;
+}
 struct UBlock {   // one (segment, channel block) of this wave
     rsrc_t rx, rw;
     int c0;        // first channel of the block (segment-relative)
@@ -81,7 +86,14 @@ enum UVar : int { UV_T3 = 1 /* segment 0 is a 3-tap conv */, UV_GN0 = 2 /* Group
                   UV_DEEP = 32 /* single segment whose per-wave K slice spans several 24-channel blocks (FF out) */,
                   UV_DUP = 64 /* the result is stored twice: y and y2 (+ a per-channel constant), kernels.h GemmCommon::y2 */ };
 
-template <int NB, int KS, int EPI, int VAR, bool TRANS, bool BF, bool MT>
+// SP (round 5, fp32 mode's default at small batch): the products run on SPLIT-fp16 operands (split_f16.h: x = h + 2^-11 l) — three v_mfma_f32_32x32x16_f16 (8 passes
+// each, 16 k) per eight v_mfma_f32_32x32x2_f32 (16 passes each, 2 k): 5.3 x fewer matrix-pipe clocks, fp32 accumulation (cross terms in their own accumulators),
+// as close to a float64 evaluation as the fp32 MFMAs.  The 16-deep MFMA wants 8 CONSECUTIVE k per lane, so the wave-private tile is token-major: two fp16 planes
+// (h, l) [34 token rows][24 channels] (48-byte rows: conflict-free 16-byte fragment reads), written once while staging — the split costs 4 VALU instructions per
+// ELEMENT, not per use: the three taps of a convolution are three row offsets into the same tile, and K-group g = 3 tap + r (8 channels) of a row is simply
+// halfs 8 g .. 8 g + 7 from the start of row `token` (the tile IS the im2col row).  A k16 step takes groups (2 s, 2 s + 1) for the two lane halves; a block's
+// 9 (3 taps) or 3 (1 tap) groups are padded to 5 / 2 steps with zero weights (Seg::ws, engine.cpp: pack_rows_split).  Reduction and epilogues are untouched.
+template <int NB, int KS, int EPI, int VAR, bool TRANS, bool BF, bool MT, bool SP = false>
 __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int bx, int by, int bz) {
     // MT (multi-tile, large batches): the workgroup walks over up to `tt_run` consecutive 32-token tiles of one sample.
     // Weights, arguments and GroupNorm coefficients are fetched / finalised ONCE and stay in registers / LDS; per tile
@@ -90,8 +102,11 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     // path.  Single-block launches only (the host checks).
     // BF: operands are rounded to bf16 (weights on the host, activations after the fused transform) and multiplied with
     // v_mfma_f32_32x32x8_bf16_1k; everything else — statistics, transforms, accumulation, epilogues — stays fp32.
-    using WT = std::conditional_t<BF, float2, f32x4>;   // one lane's weight fragment of an 8-channel round
-    constexpr int WB = BF ? 512 : 1024;                  // bytes per (tile, tap, 8-channel round) in the packed weights
+    static_assert(!(SP && (BF || MT)), "split-fp16 products: fp32 mode, single-tile workgroups");
+    using WT = std::conditional_t<BF, float2, f32x4>;   // one lane's weight fragment of an 8-channel round (SP: of one (k16 step, plane))
+    constexpr int WB = BF ? 512 : 1024;                  // bytes per (tile, tap, 8-channel round) in the packed weights (SP: per (step, plane))
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    constexpr int SPR = 34, SPP = 24;                    // SP tile: token rows (32 + 2 halo), halfs per row
     constexpr int NACC = (EPI == EPI_GEGLU) ? 2 * NB : NB;
     constexpr int NV = NB * 16;
     static_assert(NV % KS == 0, "NB*16 must be divisible by KS");
@@ -106,6 +121,8 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     static_assert(!(MULTI && DEEP), "DEEP describes single-segment launches");
     static_assert(EPI != EPI_QKV || GN0, "q/k/v reads GroupNorm -> LayerNorm input");
     constexpr int TMAX = T3 ? 3 : 1;
+    constexpr int NSX = T3 ? 5 : 2;   // SP: k16 steps of a 24-channel block (9 / 3 K-groups of 8, padded)
+    constexpr bool SPFLAT = SP && EPI == EPI_GEGLU && NB == 4 && !MT && KS == 8 && !(VAR & (UV_MULTI | UV_DEEP));   // == NSPL below: one tile per wave over the whole K
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = bz + (hd.bmod_b0 >> 17);
@@ -136,7 +153,9 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         const int cw = C0 / KS;
         const int sb = b;   // b_mod (all samples reading sample b % b_mod) exists only on the generic kernel: the host checks
         u0.rx = make_rsrc(hd.x + (long long)sb * hd.bstride, (unsigned)C0 * (unsigned)hd.pitch * 4u);
-        u0.rw = make_rsrc(hd.w4, (unsigned)w_tiles * (unsigned)taps0 * (unsigned)(C0 >> 3) * (unsigned)WB);
+        // (SP: [tile][C0 / 24 blocks][NSX steps][2 planes] x 1024 bytes — or, flat (GEGLU): [tile][C0 / 16 steps][2 planes])
+        u0.rw = SP ? make_rsrc(hd.w4, (unsigned)w_tiles * sp_tile_dwords(C0, taps0, SPFLAT) * 4u)
+                   : make_rsrc(hd.w4, (unsigned)w_tiles * (unsigned)taps0 * (unsigned)(C0 >> 3) * (unsigned)WB);
         u0.c0 = w * cw;
         u0.taps = taps0; u0.Tin = hd.T; u0.pitch4 = hd.pitch * 4; u0.C8 = C0 >> 3; u0.xform = xf0;
         u0.cGN = reinterpret_cast<const float2*>(mainS);
@@ -172,10 +191,13 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 #else
     constexpr bool NSPL = (EPI == EPI_GEGLU && NB == 4 && !MT && KS == 8 && !(VAR & (UV_MULTI | UV_DEEP)));
 #endif
+    static_assert(!SP || NSPL == SPFLAT, "the flat split-fp16 weight layout is the one-tile-per-wave shape's");
     constexpr bool ROLL = (NACC >= 8) && !BF && !NSPL;   // bf16 fragments are half the size: all three rounds fit
+    static_assert(!(SP && ROLL), "split-fp16 products: no rolling weight rounds (such shapes stay on the fp32 MFMAs)");
     static_assert(!(MT && ROLL), "multi-tile mode keeps every weight fragment in registers");
     static_assert(!ROLL || TMAX == 1, "rolling weight rounds are for 1-tap GEMMs");
     constexpr int WR = ROLL ? 2 : NRMAX;
+    constexpr int WD0 = SP ? NSX : TMAX, WD1 = SP ? 2 : WR;   // weight fragments of a block: [tap][round] or, SP, [step][plane]
     auto wload = [&](rsrc_t r, int oor, int so) -> WT {
         if constexpr (BF) return bload2(r, (l * 8) | oor, so);
         else return bload4(r, (l * 16) | oor, so);   // the range check covers voffset only: soffset is don't-care when masked
@@ -187,8 +209,19 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             wr[i] = wload(u.rw, oor, (tile_wo[i] * u.C8 + (u.c0 >> 3) + rr) * WB);
         }
     };
-    auto issue_w = [&](const UBlock& u, WT (&wv)[TMAX][WR][NACC], bool valid) {
-        if constexpr (ROLL) {
+    auto issue_w = [&](const UBlock& u, WT (&wv)[WD0][WD1][NACC], bool valid) {
+        if constexpr (SP) {
+            const int ns_u = (u.taps == 3) ? 5 : 2, nblk = (u.C8 * 0x5556) >> 16 /* C / 24 */, bi = (u.c0 * 0xAAB) >> 16 /* c0 / 24 */;
+#pragma unroll
+            for (int st = 0; st < NSX; ++st)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int i = 0; i < NACC; ++i) {
+                        const int oor = (valid && st < ns_u) ? 0 : (int)0x80000000;
+                        wv[st][pl][i] = wload(u.rw, oor, (((tile_wo[i] * nblk + bi) * ns_u + st) * 2 + pl) * 1024);
+                    }
+        } else if constexpr (ROLL) {
             issue_w_round(u, 0, wv[0][0], valid);
             issue_w_round(u, 1, wv[0][1], valid);
         } else {
@@ -206,7 +239,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 
     // ================= phase 0: requests =================
     f32x4 xv[NRMAX];
-    WT wv[TMAX][WR][NACC];
+    WT wv[WD0][WD1][NACC];
     float halo;
     // request order matters (vector loads return in order): the statistics partials of a GroupNorm'ed segment 0 head the
     // longest chain (partials -> coefficients -> staging) and need only the header; then the rest of the argument
@@ -215,7 +248,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     rsrc_t grp_rsrc0 = u0.rx, grp_rsrc1 = u0.rx, grp_rsrcr = u0.rx;
     GnP gp0 = {1, 1, hd.T, 1e-5f, nullptr, nullptr, 0};
     if constexpr (GN0) {
-        const float* gb = hd.w4 + (long long)w_tiles * taps0 * (C0 >> 3) * (WB / 4);   // gamma[C0], beta[C0] behind the weights
+        const float* gb = hd.w4 + (SP ? (long long)w_tiles * sp_tile_dwords(C0, taps0, SPFLAT) : (long long)w_tiles * taps0 * (C0 >> 3) * (WB / 4));   // gamma[C0], beta[C0] behind the weights
         gp0 = {hd.gn_cfg & 0xffff, hd.gn_cfg >> 16, hd.T, ((hd.pack >> 26) & 1) ? 1e-6f : 1e-5f, gb, gb + C0, C0};
         const int sb = b;
         grp_rsrc0 = make_rsrc(hd.gn_part + (long long)sb * hd.gn_bstride, (unsigned)C0 * (unsigned)gp0.gn_nparts * 8u);
@@ -225,11 +258,11 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     issue_x(u0, xv, halo, true);
     f32x4 lnref = {0.f, 0.f, 0.f, 0.f};
     if constexpr (HAS_LN) lnref = bload4(u0.rx, (t0 + 4 * sq) * 4, 0);   // raw channel 0 of this lane's 4 tokens: common shift
-    WT wn[NSPL ? 24 : 1];   // NSPL: this wave's tile, all 24 eight-channel rounds
+    WT wn[NSPL ? 24 : 1];   // NSPL: this wave's tile, all 24 eight-channel rounds (SP: 12 k16 steps x 2 planes, flat layout)
     if constexpr (NSPL) {
         const int tw = (w < NB) ? (tile0 + w) : (tile0 + (w - NB) + gate_tiles);
 #pragma unroll
-        for (int rr = 0; rr < 24; ++rr) wn[rr] = wload(u0.rw, 0, (tw * u0.C8 + rr) * WB);
+        for (int rr = 0; rr < 24; ++rr) wn[rr] = wload(u0.rw, 0, (tw * u0.C8 + rr) * WB);   // (SP: entry rr = 2 * step + plane of the same 24 KB per tile)
     } else {
         issue_w(u0, wv, true);
     }
@@ -260,7 +293,8 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         constexpr int cb = 24;   // every block is three 8-channel rounds (the host guarantees cw % 24 == 0)
         const int sb = b;
         u.rx = make_rsrc(AS(sv, x) + (long long)sb * AS(sv, x_bstride), (unsigned)sC * (unsigned)pitch * 4u);
-        u.rw = make_rsrc(BF ? AS(sv, w2) : AS(sv, w4), (unsigned)w_tiles * (unsigned)taps * (unsigned)(sC >> 3) * (unsigned)WB);
+        u.rw = SP ? make_rsrc(AS(sv, ws), (unsigned)w_tiles * sp_tile_dwords(sC, taps) * 4u)
+                  : make_rsrc(BF ? AS(sv, w2) : AS(sv, w4), (unsigned)w_tiles * (unsigned)taps * (unsigned)(sC >> 3) * (unsigned)WB);
         u.c0 = w * cw + blk * cb;
         u.taps = taps; u.Tin = AS(sv, Tin); u.pitch4 = pitch * 4; u.C8 = sC >> 3; u.xform = AS(sv, xform);
         u.cGN = reinterpret_cast<const float2*>(mainS + coef_off(s));
@@ -305,7 +339,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     if constexpr (HAS_LN) {   // LayerNorm affine of the wave's channel slice (<= 24 channels): lane c
         const int cw = C0 / KS;
         // gamma[C0], beta[C0] sit behind the weights (after the GroupNorm pair, if any)
-        const float* lnp = hd.w4 + (long long)w_tiles * taps0 * (C0 >> 3) * (WB / 4) + (GN0 ? 2 * C0 : 0);
+        const float* lnp = hd.w4 + (SP ? (long long)w_tiles * sp_tile_dwords(C0, taps0, SPFLAT) : (long long)w_tiles * taps0 * (C0 >> 3) * (WB / 4)) + (GN0 ? 2 * C0 : 0);
         const rsrc_t rg = make_rsrc(lnp, (unsigned)C0 * 8u);
         const int vo = (l < cw) ? (w * cw + l) * 4 : (int)0x80000000;
         ln_g = bload(rg, vo, 0);
@@ -495,11 +529,14 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     }
 
     // ================= phase 3: stage -> LDS, MFMA =================
-    f32x16 acc[NACC];
+    f32x16 acc[NACC], accx[SP ? NACC : 1];   // accx: the split mode's cross terms (h.l + l.h, x 2^11)
 #pragma unroll
     for (int i = 0; i < NACC; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            acc[i][r] = 0.f;
+            if (SP) accx[SP ? i : 0][r] = 0.f;
+        }
     clk_stamp_p(clkp, w, l, 4);
 
     // transform the staged registers once and write the wave-private LDS tile
@@ -520,7 +557,15 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                     const float v = xf1<XF>(xs[rr][e], gn, mu4[e], rs4[e], ln);
                     o[e] = (t0 + 4 * sq + e < u.Tin) ? v : 0.f;
                 }
-                if constexpr (BF) {
+                if constexpr (SP) {
+                    _Float16* xh = reinterpret_cast<_Float16*>(xt);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const _Float16 hv = (_Float16)o[e];
+                        xh[(1 + 4 * sq + e) * SPP + rr * 8 + sr] = hv;
+                        xh[(SPR + 1 + 4 * sq + e) * SPP + rr * 8 + sr] = (_Float16)((o[e] - (float)hv) * 2048.f);
+                    }
+                } else if constexpr (BF) {
                     __bf16* xb = reinterpret_cast<__bf16*>(xt);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) xb[(1 + 4 * sq + e) * PB + rr * 8 + sr] = (__bf16)o[e];
@@ -537,7 +582,12 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                     if constexpr (GNX) gn = u.cGN[u.c0 + row];
                     const float v = xf1<XF>(hl, gn, 0.f, 1.f, make_float2(1.f, 0.f));
                     const float hv = ((unsigned)tin < (unsigned)u.Tin) ? v : 0.f;
-                    if constexpr (BF) reinterpret_cast<__bf16*>(xt)[((l & 1) ? 33 : 0) * PB + row] = (__bf16)hv;
+                    if constexpr (SP) {
+                        _Float16* xh = reinterpret_cast<_Float16*>(xt);
+                        const _Float16 hh = (_Float16)hv;
+                        xh[((l & 1) ? 33 : 0) * SPP + row] = hh;
+                        xh[(SPR + ((l & 1) ? 33 : 0)) * SPP + row] = (_Float16)((hv - (float)hh) * 2048.f);
+                    } else if constexpr (BF) reinterpret_cast<__bf16*>(xt)[((l & 1) ? 33 : 0) * PB + row] = (__bf16)hv;
                     else xt[row * XP + ((l & 1) ? 36 : 3)] = hv;
                 }
             }
@@ -559,8 +609,34 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         }
     };
     // pure ds_read + MFMA loop over the block
-    auto mma_block = [&](const UBlock& u, WT (&ws)[TMAX][WR][NACC]) {
-        if constexpr (BF) {
+    auto mma_block = [&](const UBlock& u, WT (&ws)[WD0][WD1][NACC]) {
+        if constexpr (SP) {
+            // row `token` of the tile is the im2col row of that token: K-group g at halfs 8 g; 1-tap blocks start one row down (no left halo)
+            const _Float16* xh = reinterpret_cast<const _Float16*>(xt) + (lt + ((u.taps == 3) ? 0 : 1)) * SPP;
+            const int ns_u = (u.taps == 3) ? 5 : 2, ng = (u.taps == 3) ? 9 : 3;
+#pragma unroll
+            for (int st = 0; st < NSX; ++st) {
+                if (st < ns_u) {
+                    const int g = min(2 * st + lh, ng - 1);   // (the padding group re-reads the last one: finite data against zero weights)
+                    const f16x8 fh = *reinterpret_cast<const f16x8*>(xh + 8 * g);
+                    const f16x8 fl = *reinterpret_cast<const f16x8*>(xh + SPR * SPP + 8 * g);
+#pragma unroll
+                    for (int i = 0; i < NACC; ++i) {
+                        const f16x8 wh = __builtin_bit_cast(f16x8, ws[st][0][i]), wl = __builtin_bit_cast(f16x8, ws[st][1][i]);
+                        if (TRANS) {
+                            accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, wl, accx[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, wh, acc[i], 0, 0, 0);
+                            accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, wh, accx[i], 0, 0, 0);
+                        } else {
+                            accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fh, accx[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fh, acc[i], 0, 0, 0);
+                            accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fl, accx[i], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            return;
+        } else if constexpr (BF) {
             // token row = lt + tap + 1 - pad; this lane's 4 channels of an 8-channel round start at 4 * lh
             const __bf16* xb = reinterpret_cast<const __bf16*>(xt) + (lt + ((u.taps == 3) ? 0 : 1)) * PB + 4 * lh;
             if constexpr (ROLL) {
@@ -651,7 +727,20 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             stage(u0, xv, halo);
             __syncthreads();   // the eight staging tiles together are the [192][XP] X tile every wave multiplies
             clk_stamp_p(clkp, w, l, 5);
-            if constexpr (BF) {   // eight token-major bf16 tiles [token][24 channels], one per staging wave
+            if constexpr (SP) {   // eight split-fp16 tiles, one per staging wave: K-group G = 2 S + lh of the flat K = 192 lives in tile G / 3 at halfs 8 (G % 3)
+                const _Float16* xb = reinterpret_cast<const _Float16*>(lnred + KS * 64) + (lt + 1) * SPP;
+#pragma unroll
+                for (int S = 0; S < 12; ++S) {
+                    constexpr int TH = 2 * 8 * NRMAX * XP;   // halfs between the waves' tiles
+                    const int o0 = ((2 * S) / 3) * TH + 8 * ((2 * S) % 3), o1 = ((2 * S + 1) / 3) * TH + 8 * ((2 * S + 1) % 3);
+                    const _Float16* pg = xb + (lh ? o1 : o0);
+                    const f16x8 fh = *reinterpret_cast<const f16x8*>(pg), fl = *reinterpret_cast<const f16x8*>(pg + SPR * SPP);
+                    const f16x8 wh = __builtin_bit_cast(f16x8, wn[2 * S]), wl = __builtin_bit_cast(f16x8, wn[2 * S + 1]);
+                    accx[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fh, accx[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fh, acc[0], 0, 0, 0);
+                    accx[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fl, accx[0], 0, 0, 0);
+                }
+            } else if constexpr (BF) {   // eight token-major bf16 tiles [token][24 channels], one per staging wave
                 const __bf16* xb = reinterpret_cast<const __bf16*>(lnred + KS * 64) + (lt + 1) * PB + 4 * lh;
 #pragma unroll
                 for (int rr = 0; rr < 24; ++rr) {
@@ -688,7 +777,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 #endif
             constexpr int D = (TMAX == 1 && NACC == 1) ? SAID_PIPE_DEPTH_1TAP : 2;
             f32x4 xq[D - 1][NRMAX];
-            WT wq[D - 1][TMAX][WR][NACC];
+            WT wq[D - 1][WD0][WD1][NACC];
             float hq[D - 1];
             UBlock uq[D - 1];
             const int last = nblk_total - 1;
@@ -713,9 +802,9 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                 for (int rr = 0; rr < NRMAX; ++rr) xv[rr] = xq[0][rr];
                 halo = hq[0];
 #pragma unroll
-                for (int tap = 0; tap < TMAX; ++tap)
+                for (int tap = 0; tap < WD0; ++tap)
 #pragma unroll
-                    for (int rr = 0; rr < WR; ++rr)
+                    for (int rr = 0; rr < WD1; ++rr)
 #pragma unroll
                         for (int ii = 0; ii < NACC; ++ii) wv[tap][rr][ii] = wq[0][tap][rr][ii];
 #pragma unroll
@@ -725,9 +814,9 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 #pragma unroll
                     for (int rr = 0; rr < NRMAX; ++rr) xq[d][rr] = xq[d + 1][rr];
 #pragma unroll
-                    for (int tap = 0; tap < TMAX; ++tap)
+                    for (int tap = 0; tap < WD0; ++tap)
 #pragma unroll
-                        for (int rr = 0; rr < WR; ++rr)
+                        for (int rr = 0; rr < WD1; ++rr)
 #pragma unroll
                             for (int ii = 0; ii < NACC; ++ii) wq[d][tap][rr][ii] = wq[d + 1][tap][rr][ii];
                 }
@@ -736,6 +825,12 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     }
     clk_stamp_p(clkp, w, l, 6);
 
+    if constexpr (SP) {   // main + 2^-11 cross: one fma per element, before anything leaves the registers
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = fmaf(accx[i][r], 0x1p-11f, acc[i][r]);
+    }
     // ================= phase 4: split-K reduction through LDS (fixed order => deterministic) =================
     if (EPI == EPI_GEGLU && tid < 64 * NB) epiS[tid] = geglu_bias;
     __syncthreads();
@@ -968,7 +1063,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     }   // tile loop
 }
 
-template <int NB, int KS, int EPI, int VAR, bool BF, bool MT>
+template <int NB, int KS, int EPI, int VAR, bool BF, bool MT, bool SP = false>
 // multi-tile single-n-tile store kernels are compiled for <= 128 VGPRs (4 waves per SIMD): two workgroups share a CU, so one's
 // staging / reduction / epilogue phases overlap the other's MFMA stream (large batches, SAID_BIG_NB=1)
 __global__ __launch_bounds__(64 * KS, (MT && NB == 1 && EPI == EPI_STORE) ? 4 : 1) void ugemm_kernel(const float* hx, const float* hw4, int hpack, int hTN, int hpitch_gv, int hbstride,
@@ -994,11 +1089,11 @@ __global__ __launch_bounds__(64 * KS, (MT && NB == 1 && EPI == EPI_STORE) ? 4 : 
     const int bx = (int)ubx, by = (int)(L - ubx * ny), bz = (int)blockIdx.y;
     if constexpr (EPI == EPI_QKV) {
         if (by * NB < hgate_vft) {
-            ugemm_body<NB, KS, EPI, VAR, true, BF, MT>(hd, smem, bx, by, bz);
+            ugemm_body<NB, KS, EPI, VAR, true, BF, MT, SP>(hd, smem, bx, by, bz);
             return;
         }
     }
-    ugemm_body<NB, KS, EPI, VAR, false, BF, MT>(hd, smem, bx, by, bz);
+    ugemm_body<NB, KS, EPI, VAR, false, BF, MT, SP>(hd, smem, bx, by, bz);
 }
 
 template <int NB, int EPI>
@@ -1013,7 +1108,7 @@ static int ugemm_smem_floats(const GemmArgs& a, int KS, bool mt = false) {
 }
 
 constexpr int kMaxLds = 160 * 1024;
-template <int NB, int KS, int EPI, int VAR, bool BF, bool MT>
+template <int NB, int KS, int EPI, int VAR, bool BF, bool MT, bool SP = false>
 static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s, int tt) {
     int smem = ugemm_smem_floats<NB, EPI>(a, KS, MT) * (int)sizeof(float);
     static const int min_lds = dev_env("SAID_MIN_LDS") ? atoi(dev_env("SAID_MIN_LDS")) : 0;   // experiment: force one workgroup per CU
@@ -1030,13 +1125,13 @@ static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s, int tt) {
         if (((L * magic) >> 16) != L / ny_host) { launch_fault("block decode magic inexact (grid %u, ny %u)", grid.x, ny_host); return; }
     const int bmod_b0 = (int)(magic & 0x1ffffu) | (a.b0 << 17);
     const int gate_vft = (EPI == EPI_GEGLU) ? a.geglu_gate_tiles : (EPI == EPI_QKV ? a.tm_tiles : 0);   // tm_tiles shares a union
-    hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI, VAR, BF, MT>), grid, dim3(64 * KS), smem, s, s0.x, BF ? s0.w2 : s0.w4, pack,
+    hipLaunchKernelGGL((ugemm_kernel<NB, KS, EPI, VAR, BF, MT, SP>), grid, dim3(64 * KS), smem, s, s0.x, SP ? s0.ws : (BF ? s0.w2 : s0.w4), pack,
                        a.T | (a.N << 16), s0.x_pitch | (gate_vft << 16), (int)s0.x_bstride, bmod_b0, (int)grid.x,
                        gn0 ? s0.gn_part : nullptr, (int)s0.gn_part_bstride, s0.gn_cpg | (s0.gn_nparts << 16), a);
 }
-template <int NB, int KS, int EPI, int VAR, bool BF, bool MT>
+template <int NB, int KS, int EPI, int VAR, bool BF, bool MT, bool SP = false>
 static void uconfigure_one() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ugemm_kernel<NB, KS, EPI, VAR, BF, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ugemm_kernel<NB, KS, EPI, VAR, BF, MT, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
 }
 
 // (epilogue, NB, KS, variant): small-batch tile shapes; large batches use the generic kernel's NB = 3..6 shapes
@@ -1060,6 +1155,26 @@ static void uconfigure_one() {
     X(EPI_BAND, 1, 8, 0)
 #endif
 
+// split-fp16 product shapes (SP; fp32 mode, single-tile workgroups): the small-batch step's launches.  Not built: the shapes that spill with the second
+// accumulator set (NB = 2 with two or three K segments of 3-tap blocks, NB = 3 DEEP / MULTI: 148-180 bytes of scratch per lane) and GEGLU other than the one-tile-per-wave
+// NB = 4 shape (its weights use the flat step layout) — those launches stay on the fp32 MFMAs.
+#ifdef SAID_DEV_ONE_CONFIG
+#define SAID_UGEMM_SP_CONFIGS(X) SAID_UGEMM_EXPAND(X, SAID_DEV_ONE_CONFIG)
+#else
+#define SAID_UGEMM_SP_CONFIGS(X)                                                                                 \
+    X(EPI_STORE, 1, 8, 0) X(EPI_STORE, 1, 8, UV_DEEP) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0)                         \
+    X(EPI_STORE, 1, 8, UV_MULTI) X(EPI_STORE, 2, 8, UV_MULTI)                                                    \
+    X(EPI_STORE, 1, 8, UV_RGN | UV_DUP) X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_DUP) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0 | UV_DUP) \
+    X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_MULTI)                                                                \
+    X(EPI_STORE, 1, 8, UV_T3 | UV_GN0 | UV_GN1 | UV_MULTI) X(EPI_STORE, 1, 8, UV_RGN)                            \
+    X(EPI_STORE, 2, 8, 0) X(EPI_STORE, 2, 8, UV_DEEP) X(EPI_STORE, 2, 8, UV_T3 | UV_GN0)                         \
+    X(EPI_STORE, 3, 8, 0) X(EPI_STORE, 3, 8, UV_T3 | UV_GN0)                                                     \
+    X(EPI_STORE, 3, 8, UV_T3 | UV_GN0 | UV_DUP)                                                                  \
+    X(EPI_QKV, 1, 8, UV_GN0) X(EPI_QKV, 2, 8, UV_GN0) X(EPI_QKV, 3, 8, UV_GN0)                                   \
+    X(EPI_GEGLU, 4, 8, 0)                                                                                        \
+    X(EPI_BAND, 1, 8, 0)
+#endif
+
 // multi-tile shapes (large batches; single-block launches).  (Round 2's single-n-tile store shapes at two workgroups per CU — an
 // experiment that measured slower, two of whose instantiations spilled 6 VGPRs — are gone.)  fp32 GEGLU uses NB = 2: with 8 accumulator tiles the
 // weight fragments only fit by rolling them through the registers, which a multi-tile workgroup cannot do.
@@ -1079,6 +1194,9 @@ static void uconfigure_one() {
 void configure_ugemm_kernels() {
 #define X(E, nb, ks, var) uconfigure_one<nb, ks, E, var, false, false>(); uconfigure_one<nb, ks, E, var, true, false>();
     SAID_UGEMM_CONFIGS(X)
+#undef X
+#define X(E, nb, ks, var) uconfigure_one<nb, ks, E, var, false, false, true>();
+    SAID_UGEMM_SP_CONFIGS(X)
 #undef X
 #define X(E, nb, ks, var, bf) uconfigure_one<nb, ks, E, var, bf != 0, true>();
     SAID_UGEMM_MT_CONFIGS(X)
@@ -1100,7 +1218,8 @@ static int uvar_of(const GemmArgs& a, int epi) {
 
 // The LDS-staged kernel covers stride-1, k in {1,3}, ungrouped GEMMs whose per-wave channel slice is a
 // multiple of 24 (or 8 / 16); everything else stays on the generic kernel.
-bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16, int tt) {
+bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, int pm, int tt) {
+    const bool bf16 = pm == 1, sp = pm == 2;
     bool cfg = false;
     const int var = uvar_of(a, epi);
     if (tt > 1) {   // multi-tile: own shape list, one K block per wave, at most 15 tiles per workgroup
@@ -1115,6 +1234,15 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16, int t
     SAID_UGEMM_CONFIGS(X)
 #undef X
     if (!cfg || a.groups != 1 || a.ntiles_per_group % NB) return false;
+    if (sp) {   // split-fp16 products: single-tile workgroups, every segment packed for them, the flat layout exactly where the kernel expects it
+        bool spc = false;
+#define X(E, nb, ks, v) spc = spc || (epi == E && NB == nb && KS == ks && var == (v));
+        SAID_UGEMM_SP_CONFIGS(X)
+#undef X
+        if (tt > 1 || !spc) return false;
+        const bool flat_shape = epi == EPI_GEGLU && NB == 4 && KS == 8 && !(var & (UV_MULTI | UV_DEEP));
+        for (int s = 0; s < a.nseg; ++s) if (!a.seg[s].ws || (a.seg[s].ws_flat != 0) != flat_shape) return false;
+    }
     {   // what the compile-time variant assumes about the arguments
         const int xf0 = a.seg[0].xform;
         if (epi == EPI_QKV && (xf0 != XF_GN_LN || a.vt_dim <= 0 || (a.vt_dim & (a.vt_dim - 1)))) return false;
@@ -1157,13 +1285,22 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16, int t
     return true;
 }
 
-void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s, bool bf16, int tt) {
+void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s, int pm, int tt) {
     const int var = uvar_of(a, epi);
+    const bool bf16 = pm == 1, sp = pm == 2;
     if (tt > 1) {
 #define X(E, nb, ks, v, bf) \
         if (epi == E && NB == nb && KS == ks && var == (v) && bf16 == (bf != 0)) { ulaunch_one<nb, ks, E, v, bf != 0, true>(a, batch, s, tt); return; }
         SAID_UGEMM_MT_CONFIGS(X)
 #undef X
+    }
+    if (sp) {
+#define X(E, nb, ks, v) \
+        if (epi == E && NB == nb && KS == ks && var == (v)) { ulaunch_one<nb, ks, E, v, false, false, true>(a, batch, s, 1); return; }
+        SAID_UGEMM_SP_CONFIGS(X)
+#undef X
+        launch_fault("unsupported split-fp16 ugemm config epi=%d NB=%d KS=%d", epi, NB, KS);
+        return;
     }
 #define X(E, nb, ks, v) \
     if (epi == E && NB == nb && KS == ks && var == (v)) {                   \

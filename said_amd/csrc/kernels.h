@@ -45,6 +45,10 @@ struct SegFields {
     const float* w4;       // same weights packed for dwordx4 fetch [ntiles][taps][C/8][64 lanes][4 k-pairs] (or null)
     const float* w2;       // bf16 packing for v_mfma_f32_32x32x8_bf16_1k: [ntiles][taps][C/8][64 lanes][4 bf16], value j of
                            // lane l = W[tile*32 + (l&31)][8*cq + 4*(l>>5) + j][tap]; same tails as w4 (or null)
+    const float* ws;       // round 5: split-fp16 packing for v_mfma_f32_32x32x16_f16 (gemm_lds.hip SP; w = h + 2^-11 l, fp16 planes h, l):
+                           // [ntiles][C/24 blocks][NS steps][2 planes][64 lanes][8 halfs], NS = 5 (3 taps) / 2 (1 tap); the 8 halfs of lane l in step s are
+                           // K-group g = 2 s + (l >> 5) of the block's tap-major K slice (tap = g / 3, channels 8 (g % 3) .. + 7; groups past the slice: zeros),
+                           // row tile*32 + (l & 31); ws_flat: [ntiles][C/16 steps][2][64][8] without per-block padding (GEGLU); same tails as w4 (or null)
     const float* gn_part;  // GN partial stats of the source [B][C][nparts][2] (mean, M2), channel 0 of segment
     const float* gn_gamma; // GN affine (segment channel 0)
     const float* gn_beta;
@@ -64,6 +68,7 @@ struct SegFields {
     int c_group_stride;    // source channel offset per conv group (grouped conv), else 0
     int w4_gn_tail;        // 1: w4 is followed by gn_gamma[C], gn_beta[C] of this segment (copies; see FastHdr)
     int w4_ln_tail;        // 1: ... and then by ln_gamma[C], ln_beta[C]
+    int ws_flat;           // 1: ws uses the flat step layout (one output tile per wave over the whole K: the GEGLU shape)
 };
 // padded to 256 bytes: the LDS-staged kernel fetches the argument block with one coalesced 256-B vector
 // load per block and extracts fields with v_readlane (a by-value struct read field-by-field costs one
@@ -162,10 +167,11 @@ struct AttnArgs {
 void launch_gemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s);
 void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s, int mode = 0);   // mode: 0 fp32 MFMA, 1 bf16 operands, 2 split-fp16 operands
 // LDS-staged UNet GEMM (gemm_lds.hip): same arguments; only for shapes ugemm_supports() accepts
-// bf16 = true: multiply in bf16 (v_mfma_f32_32x32x8_bf16_1k; needs Seg::w2), everything else stays fp32
+// pm (product mode): 0 = v_mfma_f32_32x32x2_f32 on fp32 operands; 1 = bf16 (v_mfma_f32_32x32x8_bf16_1k; needs Seg::w2), everything else stays fp32;
+// 2 = split-fp16 operands (round 5: x = h + 2^-11 l, three v_mfma_f32_32x32x16_f16 per eight fp32 MFMAs, fp32 accumulation; needs Seg::ws; tt == 1 only)
 // tt > 1: multi-tile workgroups (each walks over tt consecutive 32-token tiles keeping its weights in registers)
-bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, bool bf16 = false, int tt = 1);
-void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s, bool bf16 = false, int tt = 1);
+bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, int pm = 0, int tt = 1);
+void launch_ugemm(const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s, int pm = 0, int tt = 1);
 void configure_ugemm_kernels();
 
 // token-major (B,T,C) <-> channel-major [B][C][pitch]
