@@ -16,6 +16,7 @@
 
 #include "../../include/said_hip.h"
 #include "kernels.h"
+#include "stchain.h"
 #include "tgemm.h"
 
 using namespace said;
@@ -55,7 +56,8 @@ struct ResW { float *g1, *b1, *g2, *b2; PW conv1, conv2, skip; int cin; bool has
 struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj, ffproj;
              void *t_qkv = nullptr, *t_ff1 = nullptr, *t_ffproj = nullptr; float* t_ff1_bias = nullptr; /* bf16 weights for tgemm.hip */
              void *tf_qkv = nullptr, *tf_ff1 = nullptr, *tf_ffproj = nullptr; /* fp32 copies (fgemm_kernel) */
-             void *t_out1 = nullptr, *t_q2 = nullptr, *t_out2 = nullptr, *tf_out1 = nullptr, *tf_q2 = nullptr, *tf_out2 = nullptr; /* [192][192] (xgemm_kernel) */ };
+             void *t_out1 = nullptr, *t_q2 = nullptr, *t_out2 = nullptr, *tf_out1 = nullptr, *tf_q2 = nullptr, *tf_out2 = nullptr; /* [192][192] (xgemm_kernel) */
+             float *chain_w = nullptr, *chain_vec = nullptr; /* round 5: weight stream + vectors of the fused tail (stchain.hip) */ };
 struct W2VLayer { PW qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln2g, *ln2b; };
 
 struct ActBuf {  // channel-major activation + its GroupNorm partial statistics
@@ -106,6 +108,12 @@ struct said_ctx {
     ActBuf H0, H1, P, Q, M;
     float *X1 = nullptr, *X2 = nullptr, *X3 = nullptr, *O = nullptr, *QK = nullptr, *VT = nullptr, *F = nullptr;
     float *KV = nullptr, *CTX = nullptr;
+    float* KVT = nullptr;        // key-major copy of KV [sample][S][NST * 2 * MC] for the fused SpatialTransformer tail (stchain.hip), made by run_kv
+    bool band_chain_ok = false;  // the alignment band fits stchain's window tile (set_band)
+    long long st_chain_max_tiles = 256;   // ... while the launch is at most this many workgroups (sample x 32-token tiles; said_debug_option "st_chain_max_tiles")
+    bool st_chain_dbg = false;   // debug: the fused kernel also writes x1 / x2 to X1 / X2
+    int st_chain = -1;           // fp32 mode, small batches: everything behind self-attention as ONE launch per block (stchain.hip); 0: the five launches
+                                 // (said_debug_option "st_chain")
     float *E0 = nullptr, *E1 = nullptr, *E2 = nullptr, *EO = nullptr;
     long long* ts_dev = nullptr;
     float* coef_dev = nullptr;
@@ -174,6 +182,7 @@ struct said_ctx {
     int rgemm = -1;           // round 4: register-stationary, wave-specialised persistent GEMMs (rgemm.hip) wherever launch_rgemm serves the shape
                               // (bf16 mode: 192-wide GEMMs with K <= 576, q/k/v); 0: off (said_debug_option "rgemm")
     long long n_rgemm = 0;
+    long long n_stchain = 0;  // launches issued through stchain_kernel (said_debug_get)
     long long n_xgemm = 0;    // launches issued through round 3's xgemm_kernel (said_debug_get; n_rgemm: through rgemm_kernel)
     int xgemm_ntw = 0;        // test / measurement: column tiles per workgroup of the resident-source GEMMs (0: launch_xgemm decides)
     void *tX1 = nullptr, *tX2 = nullptr, *tO = nullptr, *tF = nullptr;   // token-major x1, x2, attention output [.][192], GEGLU product [.][768]
@@ -1160,6 +1169,9 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         do_gemm(c, a, EPI_QKV, n1, lc.NB, lc.KS, s);
     }
     bool out1_done = false;
+    // fp32 mode, small batches: everything behind the self-attention as ONE launch (stchain.hip)
+    const bool chain = !tg && !c->bf16_mode && c->st_chain != 0 && c->use_ugemm && sw.chain_w && sw.chain_vec && c->band_chain_ok && !use_tg(c, g, g.Be) &&
+                       c->cur_b0 == 0 && !c->use_branches && tt <= c->st_chain_max_tiles && g.S == c->band_S && g.T == c->band_T;
     {   // softmax(q k^T * scale) v   (attention.py:99-126)
         AttnArgs a;
         a.qk = c->QK; a.v = c->VT; a.o = c->O;
@@ -1175,6 +1187,30 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         if (out1_tm && !attn_ks_env && attn_ks == -4) { a.o = static_cast<float*>(c->uPL); a.o_bstride = tg_rows(g); a.o_mode = 1; }
         do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s);
         out1_done = a.o_mode == 1;
+    }
+    if (chain && !out1_done) {
+        ChainArgs ca;
+        memset(&ca, 0, sizeof ca);
+        ca.wstream = sw.chain_w; ca.vec = sw.chain_vec;
+        ca.xin_part = in.st; ca.part_bs = g.sts; ca.gn_gamma = sw.gn_g; ca.gn_beta = sw.gn_b;
+        ca.kvt = c->KVT; ca.kvt_bs = (long long)g.S * (NST * 2 * MC); ca.lo = c->band_lo; ca.hi = c->band_hi;
+        ca.y = out.p; ca.y_bs = g.hs; ca.stats_out = out.st; ca.stats_bs = g.sts;
+        ca.S = g.S; ca.np = g.np; ca.koff = blk * 2 * MC; ca.wmax = c->band_wmax; ca.scale = 0.17677669529663687f;
+        if (c->clk_on && c->dbg_count < 64) ca.clk = c->clk_dev + (long long)c->dbg_count * 128;
+        if (c->st_chain_dbg) { ca.dbg_x1 = c->X1; ca.dbg_x2 = c->X2; ca.dbg_o2 = c->X3; }
+        if (c->log_on) {
+            const double w = 4.0 * ((double)3 * MC * MC + 2.0 * FFI * MC + (double)(FFI + MC) * MC);
+            const double io = 4.0 * MC * g.T * ((double)n1 * 2 + g.Be) + 4.0 * 2 * MC * g.T * (double)n2;
+            const double fl = 2.0 * g.T * ((double)n1 * MC * MC + (double)n2 * 2 * MC * MC + (double)g.Be * (2.0 * FFI * MC + (double)(FFI + MC) * MC)) + 4.0 * n2 * MC * g.T * c->band_wmax;
+            c->stage_log.push_back({10, EPI_STORE, 6, 8, w + io, fl});
+        }
+        if (dbg_go(c)) {
+            if (trace_on()) { fprintf(stderr, "[said] stchain #%d T=%d samples=%d shared=%d\n", c->dbg_count - 1, g.T, g.Be, (int)shared); fflush(stderr); }
+            launch_stchain(ca, c->O, in.p, g.T, g.Tp, obs, g.hs, shared ? g.Bc : 0, g.Bc > 0 ? g.Bc : 0, g.Be, s);
+            ++c->n_stchain;
+            if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
+        }
+        return;
     }
     if (out1_done) {   // x1 = to_out(attn) + GroupNorm(x_in) on fgemm_kernel; under guidance also x2 of the unconditional half = x1 + c2
         TGemmArgs t = mktg(g, c->uPL, MC, sw.tf_out1, MC, MC);
@@ -1424,6 +1460,9 @@ void run_kv(said_ctx* c, int b0, int nb, int S, int Sp, hipStream_t s) {
     a.y = c->KV + b0 * ybs; a.y_bstride = ybs; a.y_pitch = Sp;
     const LaunchCfg lc = pick_cfg((long long)nb * ((S + 31) / 32), NST * 2 * MC / 32);
     launch_gemm(a, EPI_STORE, nb, lc.NB, lc.KS, s);
+    // the key-major copy the fused SpatialTransformer tail reads its window tiles from (once per loop; fp32 mode's small-batch schedule only)
+    if (!c->bf16_mode && c->st_chain != 0 && (long long)S * NST * 2 * MC <= (long long)NST * 2 * MC * c->maxTp)
+        launch_cm_to_tm(c->KV + b0 * ybs, c->KVT + (long long)b0 * S * (NST * 2 * MC), nb, S, NST * 2 * MC, Sp, ybs, s);
 }
 
 // alignment band of ldm/attention.py:170-189 with Python's banker's rounding on doubles
@@ -1446,6 +1485,16 @@ int set_band(said_ctx* ctx, int T, int S, hipStream_t s) {
     HIPCHK(hipMemcpy(ctx->band_lo, lo.data(), T * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->band_hi, hi.data(), T * sizeof(int), hipMemcpyHostToDevice));
     ctx->band_T = T; ctx->band_S = S; ctx->band_wmax = wmax;
+    {   // stchain.hip keeps the windows of a 32-token tile as CHAIN_KW key rows starting at lo[first token]: needs a non-decreasing band of that span
+        bool ok = wmax <= 8;
+        for (int i = 1; i < T && ok; ++i) ok = lo[i] >= lo[i - 1];
+        for (int t0 = 0; t0 < T && ok; t0 += 32) {
+            int hmax = 0;
+            for (int i = t0; i < std::min(T, t0 + 32); ++i) hmax = std::max(hmax, hi[i]);
+            ok = hmax - lo[t0] <= CHAIN_KW;
+        }
+        ctx->band_chain_ok = ok;
+    }
     return 0;
 }
 
@@ -1477,6 +1526,7 @@ int alloc_workspace(said_ctx* ctx, int max_batch_eff, int max_frames) {
     rc |= dalloc(ctx, &ctx->VT, Be * HEADS * Tp * HD);
     rc |= dalloc(ctx, &ctx->F, Be * FFI * Tp);
     rc |= dalloc(ctx, &ctx->KV, Be * NST * 2 * MC * Tp);
+    rc |= dalloc(ctx, &ctx->KVT, Be * NST * 2 * MC * Tp);
     rc |= dalloc(ctx, &ctx->CTX, Be * (size_t)ctx_dim * Tp);
     const size_t Np = ctx->maxNp;
     rc |= dalloc(ctx, &ctx->E0, MC * Np); rc |= dalloc(ctx, &ctx->E1, TE * Np); rc |= dalloc(ctx, &ctx->E2, TE * Np);
@@ -1559,6 +1609,7 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     ctx->device = device; ctx->cin = in_channels; ctx->ctx_dim = ctx_dim;
     configure_gemm_kernels();
     configure_ugemm_kernels();
+    configure_stchain_kernel();
     configure_attn_kernels();
     configure_out_sched_kernel();
     ctx->use_ugemm = dev_env("SAID_NO_UGEMM") == nullptr;
@@ -1753,6 +1804,88 @@ int said_set_timestep_freqs(said_ctx* ctx, const float* f, int n) {
     return 0;
 }
 
+// Operands of the fused SpatialTransformer tail (stchain.hip) for block `b` (= "...transformer_blocks.0"):
+//  * one weight stream: for each of the kernel's eight waves, 2 KB units (a k16 step's h and l fragments of v_mfma_f32_32x32x16_f16 A operands: lane l holds
+//    row 32 tile + (l & 31), k = 16 step + 8 (l >> 5) .. + 7) in the order the wave consumes them — waves 0-5 (column owner j = output columns [32 j, 32 j + 32)):
+//    to_out1 12 steps, to_q 12, to_out2 12, GEGLU pairs j, j + 8, j + 16 (12 steps each, value then gate unit per step), folded proj_out over [h ; x2]: 60 steps for
+//    j < 4, steps 0 .. 29 for j = 4, 5; waves 6, 7: GEGLU pairs w, w + 8, w + 16, then steps 30 .. 59 of the folded proj_out's column tiles 4, 5.  LayerNorm2 / LayerNorm3 affines are folded in: W' = W diag(gamma) (formed in double), bias' = bias + W beta.
+//  * the vectors b1, bq = Wq beta2, bo2, c2, bffp, bff' (CHAIN_VEC_FLOATS).
+static int pack_chain(said_ctx* ctx, STW& sw, const std::string& b, const std::vector<float>& c2v) {
+    const HostTensor* W1 = getw(ctx, b + ".attn1.to_out.0.weight", {MC, MC});
+    const HostTensor* B1 = getw(ctx, b + ".attn1.to_out.0.bias", {MC});
+    const HostTensor* Wq = getw(ctx, b + ".attn2.to_q.weight", {MC, MC});
+    const HostTensor* G2 = getw(ctx, b + ".norm2.weight", {MC});
+    const HostTensor* Be2 = getw(ctx, b + ".norm2.bias", {MC});
+    const HostTensor* W3 = getw(ctx, b + ".attn2.to_out.0.weight", {MC, MC});
+    const HostTensor* B3 = getw(ctx, b + ".attn2.to_out.0.bias", {MC});
+    const HostTensor* Wf = getw(ctx, b + ".ff.net.0.proj.weight", {2 * FFI, MC});
+    const HostTensor* Bf = getw(ctx, b + ".ff.net.0.proj.bias", {2 * FFI});
+    const HostTensor* G3 = getw(ctx, b + ".norm3.weight", {MC});
+    const HostTensor* Be3 = getw(ctx, b + ".norm3.bias", {MC});
+    const HostTensor* PF = getw(ctx, "__ffproj.w0", {MC, FFI});
+    const HostTensor* PX = getw(ctx, "__ffproj.w1", {MC, MC});
+    const HostTensor* PB = getw(ctx, "__ffproj.b", {MC});
+    if (!W1 || !B1 || !Wq || !G2 || !Be2 || !W3 || !B3 || !Wf || !Bf || !G3 || !Be3 || !PF || !PX || !PB || (int)c2v.size() != MC) return -1;
+    // element (row n, k) of the matrix a unit multiplies, in double (the folds) -> split into fp16 planes
+    auto elem = [&](int kind, int n, int k) -> double {
+        switch (kind) {
+            case 0: return W1->data[(size_t)n * MC + k];
+            case 1: return (double)Wq->data[(size_t)n * MC + k] * (double)G2->data[k];
+            case 2: return W3->data[(size_t)n * MC + k];
+            case 3: return (double)Wf->data[(size_t)n * MC + k] * (double)G3->data[k];
+            default: return k < FFI ? PF->data[(size_t)n * FFI + k] : PX->data[(size_t)n * MC + (k - FFI)];
+        }
+    };
+    std::vector<_Float16> st(CHAIN_STREAM_BYTES / 2);
+    size_t o = 0;
+    auto put_unit = [&](int kind, int row0, int step) {
+        for (int pl = 0; pl < 2; ++pl)
+            for (int l = 0; l < 64; ++l)
+                for (int i = 0; i < 8; ++i) {
+                    const float v = (float)elem(kind, row0 + (l & 31), 16 * step + 8 * (l >> 5) + i);
+                    const _Float16 hv = (_Float16)v;
+                    st[o++] = pl == 0 ? hv : (_Float16)((v - (float)hv) * 2048.f);
+                }
+    };
+    auto put_geglu = [&](int w) {
+        for (int pi = 0; pi < 3; ++pi)
+            for (int s = 0; s < 12; ++s) {
+                put_unit(3, 32 * (w + 8 * pi), s);
+                put_unit(3, FFI + 32 * (w + 8 * pi), s);
+            }
+    };
+    for (int w = 0; w < 6; ++w) {
+        for (int kind = 0; kind < 3; ++kind)
+            for (int s = 0; s < 12; ++s) put_unit(kind, 32 * w, s);
+        put_geglu(w);
+        for (int s = 0; s < (w < 4 ? 60 : 30); ++s) put_unit(4, 32 * w, s);   // (column tiles 4, 5: steps 30 .. 59 belong to waves 6, 7)
+    }
+    for (int w = 6; w < 8; ++w) {
+        put_geglu(w);
+        for (int s = 30; s < 60; ++s) put_unit(4, 32 * (w - 2), s);
+    }
+    if (o != st.size()) return fail(ctx, "pack_chain: stream size mismatch");
+    std::vector<float> stf(st.size() / 2);
+    memcpy(stf.data(), st.data(), st.size() * 2);
+    if (upload(ctx, &sw.chain_w, stf.data(), stf.size())) return -1;
+    std::vector<float> vec(CHAIN_VEC_FLOATS);
+    for (int n = 0; n < MC; ++n) {
+        double bq = 0.0;
+        for (int k = 0; k < MC; ++k) bq += (double)Wq->data[(size_t)n * MC + k] * (double)Be2->data[k];
+        vec[n] = B1->data[n];
+        vec[MC + n] = (float)bq;
+        vec[2 * MC + n] = B3->data[n];
+        vec[3 * MC + n] = c2v[n];
+        vec[4 * MC + n] = PB->data[n];
+    }
+    for (int n = 0; n < 2 * FFI; ++n) {
+        double bf = Bf->data[n];
+        for (int k = 0; k < MC; ++k) bf += (double)Wf->data[(size_t)n * MC + k] * (double)Be3->data[k];
+        vec[5 * MC + n] = (float)bf;
+    }
+    return upload(ctx, &sw.chain_vec, vec.data(), vec.size());
+}
+
 int said_finalize_weights(said_ctx* ctx, void* stream) {
     (void)stream;
     if (!ctx) return -1;
@@ -1857,6 +1990,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
                 upload_tm_pair(ctx, &sw.t_out2, &sw.tf_out2, w2->data.data(), MC, MC, 1))
                 return -1;
         }
+        std::vector<float> c2_host;
         {   // attn2 output for the unconditional context (null_cond_emb repeated: every key / value identical, softmax
             // uniform => output = to_v(null)), pushed through to_out: c2 = W_out (W_v null) + b_out, in double
             const HostTensor* nc = getw(ctx, "null_cond_emb", {1, 1, CD});
@@ -1876,6 +2010,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
                 c2v[n] = (float)a;
             }
             if (upload(ctx, &ctx->c2[i], c2v.data(), MC)) return -1;
+            c2_host = c2v;
         }
         ctx->pw_split = 2;   // GEGLU runs as one output tile per wave over the whole K (NB = 4): flat step layout
         if (make_pw(ctx, &sw.ff1, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias", 2 * FFI, MC, 0, 1, "", "", b + ".norm3.weight", b + ".norm3.bias")) return -1;
@@ -1938,6 +2073,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
             fp.w[0] = t0.w[0]; fp.w4[0] = t0.w4[0]; fp.w2[0] = t0.w2[0]; fp.ws[0] = t0.ws[0]; fp.C[0] = FFI;
             fp.w[1] = t1.w[0]; fp.w4[1] = t1.w4[0]; fp.w2[1] = t1.w2[0]; fp.ws[1] = t1.ws[0]; fp.C[1] = MC;
         }
+        if (pack_chain(ctx, sw, b, c2_host)) return -1;
         used += 24;
         ctx->pw_split = 0;
     }
@@ -2403,6 +2539,12 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->attn_split = value < 0 ? -1 : (value != 0);
     } else if (k == "ugemm_split") {
         ctx->ugemm_split = value < 0 ? -1 : (value != 0);
+    } else if (k == "st_chain") {
+        ctx->st_chain = value < 0 ? -1 : (value != 0);
+    } else if (k == "st_chain_dbg") {
+        ctx->st_chain_dbg = value != 0;
+    } else if (k == "st_chain_max_tiles") {
+        ctx->st_chain_max_tiles = value;
     } else if (k == "battn") {
         ctx->battn = value < 0 ? -1 : (int)value;   // 0: off, 4 / 8: query tiles per workgroup (experiments), else on
     } else {
@@ -2423,6 +2565,8 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "tm_acts") return ctx->tm_acts;
     if (k == "gemm_split") return (!ctx->bf16_mode && ctx->gemm_split != 0) ? 1 : 0;
     if (k == "ugemm_split") return (!ctx->bf16_mode && ctx->ugemm_split != 0) ? 1 : 0;
+    if (k == "st_chain") return (!ctx->bf16_mode && ctx->st_chain != 0) ? 1 : 0;
+    if (k == "n_stchain") return ctx->n_stchain;
     if (k == "attn_split") return (!ctx->bf16_mode && ctx->attn_split != 0) ? 1 : 0;   // 1: fp32-mode attention products run on split-fp16 operands
     if (k == "rgemm") return ctx->rgemm;
     if (k == "n_rgemm") return ctx->n_rgemm;

@@ -561,7 +561,8 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                     _Float16* xh = reinterpret_cast<_Float16*>(xt);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const _Float16 hv = (_Float16)o[e];
+                        _Float16 hv = (_Float16)o[e];
+                        asm volatile("" : "+v"(hv));   // (the stored half and the one the remainder is taken from must be ONE conversion: split_f16.h)
                         xh[(1 + 4 * sq + e) * SPP + rr * 8 + sr] = hv;
                         xh[(SPR + 1 + 4 * sq + e) * SPP + rr * 8 + sr] = (_Float16)((o[e] - (float)hv) * 2048.f);
                     }
@@ -584,7 +585,8 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                     const float hv = ((unsigned)tin < (unsigned)u.Tin) ? v : 0.f;
                     if constexpr (SP) {
                         _Float16* xh = reinterpret_cast<_Float16*>(xt);
-                        const _Float16 hh = (_Float16)hv;
+                        _Float16 hh = (_Float16)hv;
+                        asm volatile("" : "+v"(hh));
                         xh[((l & 1) ? 33 : 0) * SPP + row] = hh;
                         xh[(SPR + ((l & 1) ? 33 : 0)) * SPP + row] = (_Float16)((hv - (float)hh) * 2048.f);
                     } else if constexpr (BF) reinterpret_cast<__bf16*>(xt)[((l & 1) ? 33 : 0) * PB + row] = (__bf16)hv;

@@ -15,15 +15,31 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 // overflow shows as inf / NaN).
 typedef _Float16 f16x8a __attribute__((ext_vector_type(8)));
 struct SplitH { f16x8a h, l; };
+// The low plane must be computed from the very bits that are stored as the high plane.  Round 5 (stchain.hip bring-up): hipcc converts the stored vector
+// with v_cvt_pk_f16_f32 and, left to itself, the (float)h inside the remainder with a separate v_cvt_f16_f32 — and the two disagree when x lies exactly
+// half-way between two fp16 numbers (one element in 2^13): h from one rounding, l from the other, i.e. an operand off by a whole fp16 ulp (2^-11 relative; seen
+// as 1e-4 errors of single tokens).  The empty asm makes the packed result opaque, so every later use reads those bits.
+typedef _Float16 f16x4a __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ void split_f16x4(const float x0, const float x1, const float x2, const float x3, f16x4a& h, f16x4a& l) {
+    h[0] = (_Float16)x0; h[1] = (_Float16)x1; h[2] = (_Float16)x2; h[3] = (_Float16)x3;
+    asm volatile("" : "+v"(h));
+    l[0] = (_Float16)((x0 - (float)h[0]) * 2048.f);   // (x - h is exact in fp32)
+    l[1] = (_Float16)((x1 - (float)h[1]) * 2048.f);
+    l[2] = (_Float16)((x2 - (float)h[2]) * 2048.f);
+    l[3] = (_Float16)((x3 - (float)h[3]) * 2048.f);
+}
 static __device__ __forceinline__ SplitH split_f16x8(const f32x4s a, const f32x4s b) {
     SplitH r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const _Float16 ha = (_Float16)a[i], hb = (_Float16)b[i];
-        r.h[i] = ha;
-        r.h[4 + i] = hb;
-        r.l[i] = (_Float16)((a[i] - (float)ha) * 2048.f);      // (a - ha is exact in fp32)
-        r.l[4 + i] = (_Float16)((b[i] - (float)hb) * 2048.f);
+        r.h[i] = (_Float16)a[i];
+        r.h[4 + i] = (_Float16)b[i];
+    }
+    asm volatile("" : "+v"(r.h));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r.l[i] = (_Float16)((a[i] - (float)r.h[i]) * 2048.f);      // (a - h is exact in fp32)
+        r.l[4 + i] = (_Float16)((b[i] - (float)r.h[4 + i]) * 2048.f);
     }
     return r;
 }

@@ -1,0 +1,42 @@
+// stchain.h — launch-level interface of the fused SpatialTransformer tail (stchain.hip); shared with engine.cpp, which packs its operands.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace said {
+
+constexpr int CHAIN_KW = 56;                    // key rows of the cross-attention window tile kept in LDS per 32-token tile: the tile's windows must fit
+                                                // (engine.cpp: set_band checks max(hi) - lo[t0] <= CHAIN_KW per tile, else the five-launch schedule runs)
+constexpr size_t CHAIN_STREAM_BYTES = (size_t)(4 * 168 + 2 * 138 + 2 * 102) * 2048;   // 2 KB units (one k16 step: h + l fragments) of the eight waves' streams: 2,359,296 per transformer block
+constexpr int CHAIN_VEC_FLOATS = 5 * 192 + 1536;        // global: b1, bq, bo2, c2, bffp (192 each), bff (1536: value rows, then gate rows)
+constexpr int CHAIN_VEC_FLOATS_LDS = 4 * 192 + 1536;    // LDS: bo2 | c2 share a slot (conditional | unconditional sample)
+
+struct ChainArgs {
+    const float* wstream;    // this block's weight stream (fp16 h / l planes in each wave's consumption order: engine.cpp pack_chain_stream)
+    const float* xin_part;   // GroupNorm partials of the block input [sample][tile][192][2] (mean, M2)
+    const float* gn_gamma;   // SpatialTransformer.norm (eps 1e-6)
+    const float* gn_beta;
+    const float* vec;        // CHAIN_VEC_FLOATS
+    const float* kvt;        // key-major copy of the cross-attention K / V: [sample][S][1536], this block's K at column koff, V at koff + 192
+    const int* lo;           // [T] first visible key of query t; non-decreasing (ldm/attention.py:184-189)
+    const int* hi;           // [T] one past the last visible key
+    float* y;                // block output, channel-major [sample][192][pitch]
+    float* stats_out;        // its GroupNorm partials [sample][tile][192][2], or null
+    float* dbg_x1;           // debug (said_debug_option "st_chain_dbg"): x1 and x2 to channel-major buffers [sample][192][pitch]
+    float* dbg_x2;
+    float* dbg_o2;           // ... and the cross-attention output
+    long long* clk;          // debug: shader-clock stamps [8 waves][16] of workgroup (8, last sample)
+    long long part_bs, kvt_bs, y_bs, stats_bs;   // floats between samples
+    int S;                   // keys
+    int np;                  // partial tiles per channel = ceil(T / 32)
+    int koff;                // = 384 * block index
+    int wmax;                // max(hi - lo) <= 8
+    float scale;             // dim_head ** -0.5
+};
+
+bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long long x_bs);
+// o: attention output [.][192][pitch] (o_bs floats between samples), xin: block input (x_bs); sample s reads o / xin / partials of sample s % in_mod (in_mod > 0:
+// guidance-shared prefix) and skips the cross-attention when s < n_uncond
+void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s);
+void configure_stchain_kernel();
+
+}  // namespace said

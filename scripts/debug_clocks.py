@@ -24,11 +24,11 @@ labels = ["issue", "gn-fin", "ln-stat", "band-ld", "stage", "mma", "bar1", "ldsw
 for k in range(44):
     if clk[k, 0, 0] == 0:
         print(k, "(no stamps)"); continue
-    st = clk[k, :, :10]
+    st = clk[k, :, :16] if k == 5 else clk[k, :, :10]
     base = st[:, 0].min()
     d = np.diff(st, axis=1)
     tot = st[:, 9].max() - base
     print(f"launch {k:2d} total {tot:6d} clk | " + " ".join(f"{n}:{int(d[:, i].mean()):5d}" for i, n in enumerate(labels)))
-    if k in (1, 3):
+    if k in (1, 3, 5):
         for w in range(8):
             print("      wave", w, " ".join(f"{int(v - base):6d}" for v in st[w]))

@@ -294,7 +294,7 @@ def test_loop_is_deterministic_and_graph_replayed(model, dev):
     a = model.inference(proc, num_inference_steps=12, guidance_scale=2.0, init_latents=lat).result
     b = model.inference(proc, num_inference_steps=12, guidance_scale=2.0, init_latents=lat).result
     assert torch.equal(a, b)
-    assert model._eng.graph_num_nodes() >= 30  # one captured graph covers the whole step (40 launches at this batch)
+    assert model._eng.graph_num_nodes() >= 20  # one captured graph covers the whole step (24 launches at this batch since round 5's fused transformer tail; 40 before)
 
 
 def test_idempotent_clamp_and_linearity_properties_full_size(model, dev):
