@@ -193,6 +193,9 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1", grou
                 f"xgemm_kernel<{st['NB']},{'f32' if st['KS'] == 32 else 'bf16'},{EPI_NAMES[st['epi']]}>" if st["kind"] == 6 else
                 f"rgemm_kernel<{EPI_NAMES[st['epi']]}>" if st["kind"] == 7 else
                 f"pgemm_kernel<{EPI_NAMES[st['epi']]}>" if st["kind"] == 8 else
+                "stchain_kernel" if st["kind"] == 10 else
+                "conv_in_kernel" if st["kind"] == 11 else
+                "out_conv (ugemm_kernel<NB1,KS8,store>; in the loop: first half of out_sched_kernel)" if st["kind"] == 12 else
                 f"{'ugemm' if st['kind'] == 2 else 'cgemm'}_kernel<NB{st['NB']},KS{st['KS']},{EPI_NAMES[st['epi']]}>")
         a = agg.setdefault(name, dict(us=0.0, bytes=0.0, flops=0.0, launches=0))
         a["us"] += st["us"]; a["bytes"] += st["bytes"]; a["flops"] += st["flops"]; a["launches"] += 1

@@ -110,7 +110,8 @@ struct said_ctx {
     float *KV = nullptr, *CTX = nullptr;
     float* KVT = nullptr;        // key-major copy of KV [sample][S][NST * 2 * MC] for the fused SpatialTransformer tail (stchain.hip), made by run_kv
     bool band_chain_ok = false;  // the alignment band fits stchain's window tile (set_band)
-    long long st_chain_max_tiles = 256;   // ... while the launch is at most this many workgroups (sample x 32-token tiles; said_debug_option "st_chain_max_tiles")
+    bool st_chain_large = true;  // ... at large batches too, beside the token-major q / k / v GEMM (32 clips: 3.2 -> 2.4 ms per step; said_debug_option "st_chain_large")
+    long long st_chain_max_tiles = 1LL << 40;   // ... while the launch is at most this many workgroups (sample x 32-token tiles; said_debug_option "st_chain_max_tiles")
     bool st_chain_dbg = false;   // debug: the fused kernel also writes x1 / x2 to X1 / X2
     int st_chain = -1;           // fp32 mode, small batches: everything behind self-attention as ONE launch per block (stchain.hip); 0: the five launches
                                  // (said_debug_option "st_chain")
@@ -1132,7 +1133,11 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     if (c->hybrid && (c->bf16_mode || c->hybrid_f32) && tg && use_tg(c, g, g.Be) && g.b0 == 0) { run_transformer_hybrid(c, g, sw, blk, in, out, s, shared); return; }
     // fp32 mode: attn1.to_out on the token-major fp32 GEMM too (the attention kernel writes its operand token-major into the free q/k/v
     // operand buffer; the GroupNorm'ed residual uses the coefficients the q/k/v preparation finalised): 59 -> ~30 us per launch at Be = 64
-    const bool out1_tm = tg && !c->bf16_mode && c->f32_out1_tm && tt1 * HEADS >= 2048 && sw.tf_out1;
+    // fp32 mode: everything behind the self-attention as ONE launch (stchain.hip) — at small batches beside the channel-major GEMMs, at large ones (st_chain_large)
+    // beside the token-major GEMMs' q / k / v (the attention kernel then writes channel-major, as the small-batch schedule has it)
+    const bool chain = !c->bf16_mode && c->st_chain != 0 && c->use_ugemm && sw.chain_w && sw.chain_vec && c->band_chain_ok && c->cur_b0 == 0 && !c->use_branches &&
+                       ((!tg && !use_tg(c, g, g.Be)) || c->st_chain_large) && tt <= c->st_chain_max_tiles && g.S == c->band_S && g.T == c->band_T;
+    const bool out1_tm = tg && !chain && !c->bf16_mode && c->f32_out1_tm && tt1 * HEADS >= 2048 && sw.tf_out1;
     if (tg) {   // q, k, v on the bf16 token-major GEMM: operand = LayerNorm(GroupNorm(x)) prepared once
         PrepArgs p = mkprep(g, in.p, 1, c->uPL, (long long)tg_rows(g) * MC, MC, 0);
         prep_gn(c, p, g, in.st, 6, 1e-6f, sw.gn_g, sw.gn_b, n1, 0, s);
@@ -1169,9 +1174,6 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         do_gemm(c, a, EPI_QKV, n1, lc.NB, lc.KS, s);
     }
     bool out1_done = false;
-    // fp32 mode, small batches: everything behind the self-attention as ONE launch (stchain.hip)
-    const bool chain = !tg && !c->bf16_mode && c->st_chain != 0 && c->use_ugemm && sw.chain_w && sw.chain_vec && c->band_chain_ok && !use_tg(c, g, g.Be) &&
-                       c->cur_b0 == 0 && !c->use_branches && tt <= c->st_chain_max_tiles && g.S == c->band_S && g.T == c->band_T;
     {   // softmax(q k^T * scale) v   (attention.py:99-126)
         AttnArgs a;
         a.qk = c->QK; a.v = c->VT; a.o = c->O;
@@ -1356,7 +1358,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
             else launch_conv_in(c->x_cm, c->conv_in.w4[0], c->conv_in.bias, c->H0.p, c->H0.st, g.step_inc, g.B_lat, in_copies, g.T, g.Tp, MC, s);
         }
         if (c->log_on)
-            c->stage_log.push_back({0, EPI_STORE, 1, 4, 4.0 * ((double)MC * c->cin * 3 + (double)g.B_lat * c->cin * g.T + (double)g.Be * MC * g.T),
+            c->stage_log.push_back({11 /* conv_in_kernel */, EPI_STORE, 1, 4, 4.0 * ((double)MC * c->cin * 3 + (double)g.B_lat * c->cin * g.T + (double)g.Be * MC * g.T),
                                     2.0 * g.B_lat * MC * c->cin * 3 * g.T});
     } else {   // input_blocks.0: Conv1d(32 -> 192, k3)
         GemmArgs a = mkargs(g.T, MC);
@@ -1413,6 +1415,7 @@ void run_unet(said_ctx* c, const UGeo& g, hipStream_t s) {
         a.bias = c->conv_out.bias;
         a.y = c->eps_cm; a.y_bstride = (long long)c->cin * g.Tp; a.y_pitch = g.Tp;
         do_gemm(c, a, EPI_STORE, g.Be, 1, 8, s);
+        if (c->log_on && !c->stage_log.empty()) c->stage_log.back().kind = 12;   // the `out` convolution alone (forward(), profiling): in the loop it is out_sched_kernel's first half
     }
 }
 
@@ -2543,6 +2546,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->st_chain = value < 0 ? -1 : (value != 0);
     } else if (k == "st_chain_dbg") {
         ctx->st_chain_dbg = value != 0;
+    } else if (k == "st_chain_large") {
+        ctx->st_chain_large = value != 0;
     } else if (k == "st_chain_max_tiles") {
         ctx->st_chain_max_tiles = value;
     } else if (k == "battn") {
