@@ -39,14 +39,16 @@ def shard_bounds(n_items: int, world: int) -> List[range]:
     return out
 
 
-def gather_uneven(dist, local: torch.Tensor, counts: List[int], world: int) -> torch.Tensor:
+def gather_uneven(dist, local: torch.Tensor, counts: List[int], world: int, pad_to: Optional[int] = None) -> torch.Tensor:
     """ONE all-gather of per-rank results with different row counts: every rank pads its (counts[rank], ...) tensor to max(counts) rows,
     `all_gather_into_tensor` assembles (world, max, ...), and the padding rows are trimmed: (sum(counts), ...) in global item order on
     every rank.  (`all_gather_into_tensor` needs equal shapes; a second collective for the sizes is not needed: the partition is a pure
     function of (n_items, world).)"""
     if world == 1 and dist is None:
         return local
-    m = max(counts)
+    m = max(counts) if pad_to is None else int(pad_to)   # pad_to: a fixed per-rank capacity >= max(counts) (static shapes across calls; the one-rank RCCL test)
+    if m < max(counts):
+        raise ValueError(f"pad_to {m} is below the largest shard ({max(counts)})")
     if local.shape[0] != m:
         pad = torch.zeros((m - local.shape[0],) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
         local = torch.cat([local, pad])

@@ -35,7 +35,7 @@ def build_parser():
     # not a reference flag: the reference's batched caller is single-device (test_inference.py:103-107); see said_amd/shard.py
     ap.add_argument("--gpus", type=int, default=0,
                     help="0 (default): one device (--device), start noise from torch's generator as in the reference; N >= 1: the repeats of "
-                         "every clip are partitioned over N MI355X of this node (one process per GPU, one RCCL all-gather per clip), each "
+                         "every clip are partitioned over N MI355X of this node (one process per GPU, ONE RCCL all-gather at the end of the run), each "
                          "repeat's start noise seeded by (seed, sentence, repeat) so that the output does not depend on N")
     return ap
 
@@ -79,19 +79,37 @@ def run_rank(args, rank: int, world: int, dist) -> None:
     if args.seed >= 0:
         torch.manual_seed(args.seed)
     net = _common.make_model(args)
+    # The repeats of every clip are sharded over the ranks (contiguous, uneven allowed); a rank runs its repeats of ALL clips with no
+    # collective in between, and ONE all-gather at the end of the run returns everything ("a single RCCL all-gather ... at the
+    # end"; round 4 gathered once per clip: 80 collectives for the BlendVOCA test split).  Clips differ in length: rows are padded to the
+    # longest clip for the gather and trimmed when written.
+    shards = shard.shard_bounds(args.num_repeats, world)
+    mine = shards[rank]
+    clips, local = [], []
     with torch.no_grad():
         for si, (pid, wav_path) in enumerate(test_audio_paths(args.audio_dir)):
             stem = os.path.splitext(os.path.basename(wav_path))[0]
-            target = os.path.join(args.output_dir, pid)
             audio, frames = _common.prepared_audio(net, wav_path, args.fps, args.divisor_unet)
-            n_model = int(audio.shape[1] / net.sampling_rate * args.fps)
-            res = shard.sharded_inference(lambda ids: sample_repeats(net, audio, n_model, ids, args, si, seeded), args.num_repeats,
-                                          rank=rank, world=world, dist=dist)
-            if rank == 0:
+            n_model = int(audio.shape[1] / net.sampling_rate * 60)   # frames the model generates: SAID.inference's own fps (60), as in the reference
+            out = sample_repeats(net, audio, n_model, mine, args, si, seeded)
+            if out.shape[0] != len(mine):
+                raise RuntimeError(f"path returned {out.shape[0]} items for a shard of {len(mine)}")
+            clips.append((pid, stem, frames))
+            local.append(out)
+        if not clips:
+            return
+        t_max = max(o.shape[1] for o in local)
+        stack = torch.zeros(len(mine), len(clips), t_max, 32, device=local[0].device, dtype=local[0].dtype)
+        for ci, o in enumerate(local):
+            stack[:, ci, :o.shape[1]] = o
+        res = shard.gather_uneven(dist, stack, [len(r) for r in shards], world)   # (num_repeats, clips, t_max, 32) on every rank
+        if rank == 0:
+            tables = res.cpu().numpy()
+            for ci, (pid, stem, frames) in enumerate(clips):
+                target = os.path.join(args.output_dir, pid)
                 os.makedirs(target, exist_ok=True)
-                tables = res[:, :frames].cpu().numpy()
                 for k in range(args.num_repeats):
-                    save_blendshape_coeffs(coeffs=tables[k], classes=DEFAULT_BLENDSHAPE_CLASSES, output_path=os.path.join(target, f"{stem}-{k}.csv"))
+                    save_blendshape_coeffs(coeffs=tables[k, ci, :frames], classes=DEFAULT_BLENDSHAPE_CLASSES, output_path=os.path.join(target, f"{stem}-{k}.csv"))
 
 
 def _rank_main(args):

@@ -56,7 +56,7 @@ def test_batch_driver_layout_and_repeats(tmp_path):
     pid = drv.PERSON_IDS_TEST[0]
     os.makedirs(adir / pid)
     _write_wav(str(adir / pid / "sentence01.wav"), 8000, 1)
-    _write_wav(str(adir / pid / "sentence03.wav"), 8000, 2)
+    _write_wav(str(adir / pid / "sentence03.wav"), 12000, 2)   # a longer clip: the run's ONE gather pads every clip to the longest, the writer trims
     os.makedirs(adir / "not_a_test_person")
     _write_wav(str(adir / "not_a_test_person" / "sentence01.wav"), 8000, 3)
     assert [os.path.basename(p) for _, p in drv.test_audio_paths(str(adir))] == ["sentence01.wav", "sentence03.wav"]
@@ -68,6 +68,8 @@ def test_batch_driver_layout_and_repeats(tmp_path):
     a = load_blendshape_coeffs(str(odir / pid / "sentence01-0.csv"))
     b = load_blendshape_coeffs(str(odir / pid / "sentence01-1.csv"))
     assert a.shape == (30, 32) and not torch.equal(a, b)      # repeats differ by start noise only
+    c3 = load_blendshape_coeffs(str(odir / pid / "sentence03-2.csv"))
+    assert c3.shape == (45, 32) and float(c3.min()) >= 0 and float(c3.max()) <= 1
     assert float(a.min()) >= 0 and float(a.max()) <= 1
 
 
@@ -115,3 +117,38 @@ def test_bench_one_rank_rccl_group():
     b = run([])
     assert "one-rank RCCL group" in a["config"]["parallelism"] and b["config"]["parallelism"] == "single GPU"
     assert a["n_gpus"] == 1 and a["config"]["gathered_checksum"] == b["config"]["gathered_checksum"]
+
+
+def test_gather_uneven_pad_and_trim_on_the_one_rank_rccl_group(tmp_path):
+    """said_amd/shard.py::gather_uneven's pad -> all_gather_into_tensor -> trim path on an "nccl" (= RCCL) process group.  A single-GPU box
+    has only a one-rank group, where the shard is never smaller than the largest: `pad_to` (a fixed per-rank capacity, as a caller with static
+    shapes would use) makes the padding and trimming run around a real RCCL collective on device memory."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+from said_amd import shard
+torch.cuda.set_device(0)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(shard.free_port()))
+dist = shard.init_process_group("nccl", 0, 1, torch.device("cuda", 0))
+try:
+    g = torch.Generator().manual_seed(5)
+    local = torch.randn(3, 7, 32, generator=g).cuda()
+    out = shard.gather_uneven(dist, local, [3], 1, pad_to=5)          # padded to 5 rows for the collective, trimmed back to 3
+    assert out.shape == (3, 7, 32) and torch.equal(out, local), out.shape
+    out = shard.gather_uneven(dist, local, [3], 1)                    # no padding needed
+    assert torch.equal(out, local)
+    empty = shard.gather_uneven(dist, local[:0], [0], 1, pad_to=2)    # an empty shard
+    assert empty.shape == (0, 7, 32)
+    try:
+        shard.gather_uneven(dist, local, [3], 1, pad_to=2)
+        raise SystemExit("pad_to below the shard size must be refused")
+    except ValueError:
+        pass
+    print("OK")
+finally:
+    dist.destroy_process_group()
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]

@@ -1,0 +1,160 @@
+"""Round 5 (run on the MI355X with `-m gpu`): the fp32 mode's new arithmetic and schedule.
+
+* small-batch GEMMs on split-fp16 operands (gemm_lds.hip SP; said_debug_option "ugemm_split");
+* the per-token tail of a SpatialTransformer as one launch (stchain.hip; "st_chain"): against the five-launch schedule it replaces
+  and against the CPU oracle, at ragged lengths, under guidance with odd clip counts (shared prefix), with its fall-backs;
+* the split's consistency (split_f16.h): the high and low planes of an operand must come from ONE fp32 -> fp16 conversion — the
+  regression that showed as single tokens off by 1e-4 (an operand off by a whole fp16 ulp wherever a value sat exactly half-way
+  between two fp16 numbers).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline as op
+from oracle import scheduler as osch
+from oracle import unet as ou
+from said_amd.util import synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    from said_amd.model.diffusion import SAID_UNet1D
+    m = SAID_UNet1D()
+    m.load_state_dict(synth.said_state_dict(), strict=True)
+    m.to(dev).eval()
+    return m
+
+
+@pytest.fixture(scope="module")
+def sd_parts():
+    sd = synth.said_state_dict()
+    return (sd,) + tuple(op.split_state_dict(sd))   # full, audio, unet, null embedding
+
+
+def _forward(model, dev, B, T, S=None, opts=None, seed=1):
+    S = T if S is None else S
+    x = synth.synth_latents(seed, (B, T, 32))
+    c = synth.synth_latents(seed + 1, (B, S, 768))
+    ts = (torch.arange(B) * 137 + 500) % 1000
+    eng = model._get_engine(max(B, 2), max(T, 64))
+    for k, v in (opts or {}).items():
+        eng.debug_option(k, v)
+    try:
+        n0 = eng.debug_get("n_stchain")
+        out = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+        n1 = eng.debug_get("n_stchain")
+    finally:
+        for k in (opts or {}):
+            eng.debug_option(k, -1 if k in ("st_chain", "ugemm_split") else 0)
+    return out, (x, ts, c), n1 - n0
+
+
+# measured (MI355X, round 5): chain vs five launches <= 6e-7 of the output range; before the one-conversion fix the same comparison gave
+# 4.8e-6 .. 1.3e-5 (single tokens off by 1e-4 after the first transformer block)
+CHAIN_VS_FIVE = 1e-6
+
+
+@pytest.mark.parametrize("B,T", [(2, 600), (1, 37), (3, 333), (2, 60)])
+def test_stchain_matches_the_five_launch_schedule(model, dev, B, T):
+    a, _, na = _forward(model, dev, B, T, opts={"st_chain": 1})
+    b, _, nb = _forward(model, dev, B, T, opts={"st_chain": 0})
+    assert na == 4 and nb == 0, "one fused launch per transformer block / none with the option off"
+    rng = float(b.max() - b.min())
+    err = float((a - b).abs().max()) / rng
+    print(f"stchain vs five launches B={B} T={T}: {err:.2e} of range")
+    assert err <= CHAIN_VS_FIVE
+
+
+@pytest.mark.parametrize("B,T", [(2, 60), (1, 600)])
+def test_stchain_and_split_gemms_vs_oracle(model, dev, sd_parts, B, T):
+    """Each combination of the two options against the CPU oracle at the fp32 bound of the parity suite (1e-4 of range; measured 4e-7 .. 6e-7)."""
+    _, _, sd_u, _ = sd_parts
+    ref = None
+    for opts in ({"st_chain": 1, "ugemm_split": 1}, {"st_chain": 0, "ugemm_split": 1}, {"st_chain": 0, "ugemm_split": 0}, {"st_chain": 1, "ugemm_split": 0}):
+        out, (x, ts, c), _ = _forward(model, dev, B, T, opts=opts)
+        if ref is None:
+            ref = ou.unet1d_forward(sd_u, x, ts, c)
+        err = float((out - ref).abs().max()) / float(ref.max() - ref.min())
+        print(f"B={B} T={T} {opts}: {err:.2e} of range")
+        assert err <= 1e-4
+
+
+def test_stchain_falls_back_when_the_window_tile_does_not_fit(model, dev, sd_parts):
+    """S >> T: a 32-token tile's alignment windows span more than the kernel's 56 key rows (or are wider than 8 keys): the five launches run."""
+    _, _, sd_u, _ = sd_parts
+    out, (x, ts, c), n = _forward(model, dev, 2, 40, S=400, seed=7)
+    assert n == 0
+    ref = ou.unet1d_forward(sd_u, x, ts, c)
+    assert float((out - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    # S < T (windows advance slower than the tokens) and S slightly above T fit
+    for S in (25, 50):
+        out, (x, ts, c), n = _forward(model, dev, 1, 40, S=S, seed=9)
+        assert n == 4
+        ref = ou.unet1d_forward(sd_u, x, ts, c)
+        assert float((out - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("B,Ta", [(1, 16000), (3, 9867), (2, 160000)])
+def test_guided_step_on_the_fused_schedule_vs_oracle(model, dev, sd_parts, B, Ta):
+    """One guided DDIM step (shared prefix in the first block: one workgroup row per clip feeds both halves; unconditional samples skip the
+    cross-attention) from the same latents as the oracle: odd clip counts, a ragged length (616 frames... 9867 samples = 37 frames), 10 s clips."""
+    sd_full, sd_a, sd_u, null = sd_parts
+    T = int(Ta / 16000 * 60)
+    proc = op.process_audio([synth.synth_waveform(10 + i, Ta).numpy() for i in range(B)])
+    emb = op.get_audio_embedding(sd_a, proc, T)
+    lat = synth.synth_latents(100, (B, T, 32))
+    o = osch.OracleDDIM()
+    o.set_timesteps(50)
+    sch = model.noise_scheduler
+    sch.set_timesteps(50)
+    ts = sch.timesteps.numpy()
+    coef = sch.coef_table(ts, 0.0)
+    k = 24
+    tt = int(ts[k])
+    pred = ou.unet1d_forward(sd_u, torch.cat([lat] * 2), torch.tensor([tt] * (2 * B)), torch.cat([null.repeat(B, T, 1), emb]))
+    e_u, e_c = pred.chunk(2)
+    want = o.step(e_c + 2.0 * (e_c - e_u), tt, lat)
+    eng = model._get_engine(2 * B, T)
+    n0 = eng.debug_get("n_stchain")
+    _, latf, _ = eng.denoise_loop(latents=lat.to(dev), context=emb.to(dev), timesteps=ts[k:k + 1], coef=coef[k:k + 1], prediction_type="epsilon",
+                                  guidance_scale=2.0, guidance_rescale=0.0, latent_scale=1.0, step_noise=None)
+    assert eng.debug_get("n_stchain") > n0
+    err = float((latf.cpu() - want).abs().max())
+    print(f"guided step B={B} T={T}: max abs err {err:.2e}")
+    assert err <= 2e-4   # (measured 4e-6 .. 6e-6; the parity suite's single-step bound)
+
+
+def test_split_planes_come_from_one_conversion(model, dev):
+    """The regression itself, at the API: latents / context chosen so that many LayerNorm / attention outputs cannot be known in advance — instead the
+    property is checked where it bites: the fused schedule (packed conversions in its epilogues) against the five-launch one, PER TOKEN.  With the
+    planes taken from two conversions, single tokens of the first block's output were off by 1e-4 (8e-6 of range) while the rest agreed to 1e-6."""
+    B, T = 2, 600
+    Tp = (T + 31) // 32 * 32
+    eng = model._get_engine(max(B, 2), T)
+    x = synth.synth_latents(1, (B, T, 32)).to(dev)
+    c = synth.synth_latents(2, (B, T, 768)).to(dev)
+    ts = torch.tensor([500] * B).to(dev)
+    res = {}
+    for name, ch, stop in (("chain", 1, 6), ("five", 0, 10)):   # launches up to the end of the first transformer block
+        eng.debug_option("st_chain", ch)
+        eng.debug_stop_after(stop)
+        try:
+            model(x, ts, c)
+            res[name] = eng.debug_read("H1", (B, 192, Tp))[:, :, :T].copy()
+        finally:
+            eng.debug_stop_after(-1)
+            eng.debug_option("st_chain", -1)
+    d = np.abs(res["chain"] - res["five"]).max(axis=(0, 1))   # per token
+    rng = float(res["five"].max() - res["five"].min())
+    print(f"first block, per-token max |chain - five|: median {np.median(d):.2e}, max {d.max():.2e} (range {rng:.1f})")
+    assert d.max() <= 1.5e-5, "a token is off by far more than rounding: split planes from two different conversions?"
