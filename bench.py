@@ -250,6 +250,29 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1", grou
            "by_kernel": {k: {"us": round(v["us"], 2), "launches": v["launches"],
                              "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1),
                              "TFLOPs": round(v["flops"] / (v["us"] * 1e-6) / 1e12, 2)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"])}}
+    # Two byte models: `hbm_frac` above prices the family's PER-LAUNCH operand bytes (weights + operands in + residual + result out of each
+    # launch, as the schedule has decomposed the network); `hbm_frac_8d` prices the family's share of SURVEY 8(d)'s algorithmic bytes of the whole UNet — the
+    # contract's model, in which an activation is counted once however many launches touch it — apportioned by the family's share of the per-launch bytes.
+    tot_launch_bytes = sum(a["bytes"] for a in agg.values())
+    if tot_launch_bytes > 0:
+        out["alg_bytes_8d_share"] = round(unet_bytes * d["bytes"] / tot_launch_bytes)
+        out["hbm_frac_8d"] = round(unet_bytes * d["bytes"] / tot_launch_bytes / (d["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+    # in-situ time of the family from the committed rocprofv3 trace of this configuration (profiles/trace_latest_<cfg>.txt, written by scripts/gpu_r5_final.sh
+    # from `rocprofv3 --kernel-trace --stats` of this command): the isolated replays below run 5-10 % faster than the same launches inside the step graph
+    tfile = os.path.join(ROOT, "profiles", f"trace_latest_{traffic_key}.txt")
+    if os.path.exists(tfile):
+        fam = dom.split("<")[0].split(" ")[0]
+        tot_us, calls = 0.0, 0
+        for ln in open(tfile):
+            parts = ln.split()
+            if len(parts) >= 5 and parts[-1].startswith("said::") and fam in ln:
+                try:
+                    tot_us += float(parts[0]) * 1e3; calls += int(parts[1])
+                except ValueError:
+                    pass
+        if calls:
+            out["in_situ_avg_us"] = round(tot_us / calls, 2)
+            out["in_situ_source"] = f"profiles/trace_latest_{traffic_key}.txt (all `{fam}` instantiations, {calls} launches)"
     # `achieved` / `frac` are per-launch ISOLATED replays (HIP events around each launch of said_profile_unet); inside the real step graph the
     # launches run a little slower (cold instruction cache, the previous launch's write-back).  The loop itself gives the in-situ total:
     # in_situ_scale = loop time per step / sum of the isolated launch times (one clip group only); the per-kernel in-situ figures of a
@@ -266,8 +289,15 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1", grou
         gsplit = dtype == "f32" and eng.debug_get("gemm_split") == 1
     except Exception:
         gsplit = False
+    try:
+        usplit = dtype == "f32" and eng.debug_get("ugemm_split") == 1
+        chain = dtype == "f32" and eng.debug_get("st_chain") == 1
+    except Exception:
+        usplit = chain = False
+    out["fp32_small_batch_gemm_products"] = "split_fp16 (ugemm_kernel SP, stchain_kernel)" if usplit else "mfma_f32"
+    out["fp32_transformer_tail"] = "one launch per block (stchain_kernel)" if chain else "five launches per block"
     out["fp32_large_batch_gemm_products"] = "split_fp16 (fgemm_kernel SP)" if gsplit else "mfma_f32"   # (only the token-major fgemm launches; the channel-major kernels stay on fp32 MFMAs)
-    if (split and dom.startswith("attn_kernel")) or (gsplit and dom.startswith("fgemm_kernel")):
+    if (split and dom.startswith("attn_kernel")) or (gsplit and dom.startswith("fgemm_kernel")) or (usplit and (dom.startswith("stchain") or dom.startswith("ugemm"))):
         out["kernel_executed_f16_tflops"] = round(3 * k_tf, 3)
         out["kernel_executed_f16_frac"] = round(3 * k_tf / MFMA_PEAK_TFLOPS["bf16"], 5)
     if sum_us > 0 and groups == 1:   # (concurrent clip groups share the chip: a launch's in-situ time is then not comparable with its isolated one)
@@ -360,10 +390,9 @@ SECONDARY = {
     "cfg3_per_gpu_f32": dict(batch=32, seconds=10.0, num_steps=1000, dtype="f32", eta=0.0, edit=False, passes=1,
                              flags="--batch 32 --steps 1 --warmup 1",
                              workload="BASELINE.json configs[3], ONE GPU's share: 32 clips x 10 s, audio encode + 1000 DDIM steps, guidance 2, fp32 (no all-gather at N = 1)"),
-    "cfg3_split_optin_one_group": dict(batch=32, seconds=10.0, num_steps=1000, dtype="f32", eta=0.0, edit=False, passes=1, clip_groups=1, debug={"gemm_split": 1},
-                                       flags="--batch 32 --steps 1 --warmup 1 --clip_groups 1 --debug_option gemm_split=1",
-                                       workload="configs[3]'s per-GPU share with the OPT-IN split-fp16 GEMMs (DESIGN.md 8.4) as ONE clip group — the combination that was bit-stable "
-                                                "in every run; not the default"),
+    "cfg3_one_group": dict(batch=32, seconds=10.0, num_steps=1000, dtype="f32", eta=0.0, edit=False, passes=1, clip_groups=1,
+                           flags="--batch 32 --steps 1 --warmup 1 --clip_groups 1",
+                           workload="configs[3]'s per-GPU share as ONE clip group (the default runs three concurrent groups: DESIGN.md 5)"),
     "cfg4_edit": dict(batch=1, seconds=30.0, num_steps=100, dtype="f32", eta=0.0, edit=True, passes=2,
                       flags="--seconds 30 --num_steps 100 --edit",
                       workload="BASELINE.json configs[4]: editing mode, 1 clip x 30 s (T=1800), init_samples + in-betweening mask, 100 DDIM steps, guidance 2, fp32"),

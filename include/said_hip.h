@@ -52,8 +52,9 @@ int said_reserve(said_ctx* ctx, int max_batch_eff, int max_frames);
 int said_capacity(const said_ctx* ctx, int* max_batch_eff, int* max_frames);
 /* A second context on the same device that SHARES the parent's packed weights (read-only) and owns its own workspace, capture
  * streams and step graph: contexts can run said_denoise_loop concurrently on different streams.  The host wrapper uses it to run a
- * large batch as two or three concurrent clip groups (a launch's phases — tile loads, MFMAs, result stores — then overlap across
- * the groups: -7 % bf16 / -8 % fp32 per step at 32 clips x 600 frames).  The clone inherits the parent's precision
+ * large fp32 batch as two or three concurrent clip groups (a launch's phases — tile loads, MFMAs, result stores — then overlap across
+ * the groups: -7 % per pass at 32 clips x 600 frames with round 5's schedule; bf16 large batches run as ONE group since round 4's persistent
+ * kernels).  The clone inherits the parent's precision
  * mode and debug options as they are at this call.  No reference counterpart.  Destroy the clone BEFORE its parent. */
 int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_frames);
 
@@ -196,11 +197,16 @@ int said_axpby(said_ctx* ctx, const float* a_host, const float* x_dev, const flo
 
 /* ---- precision ----------------------------------------------------------- */
 
-/* bf16_mfma != 0: every GEMM / convolution served by the LDS-staged UNet kernel multiplies operands rounded to
- * bfloat16 (weights once at said_finalize_weights, activations after their fused normalisation) with fp32
- * accumulation; statistics, normalisations, softmax, the scheduler and all tensors in HBM stay fp32.  This is the
- * "bf16" of BASELINE.json configs[2]; the reference itself (diffusion.py) only runs fp32, the closest analogue being
- * torch.autocast(bfloat16) around its matmuls/convs.  Default 0.  Takes effect at the next call. */
+/* bf16_mfma != 0: every GEMM / convolution and both attention products multiply operands rounded to bfloat16 (weights once at
+ * said_finalize_weights, activations after their fused normalisation) with fp32 accumulation; statistics, normalisations, softmax,
+ * residual sums and the scheduler stay fp32.  At small batches (< 3000 UNet rows per launch) all tensors in HBM stay fp32; at large
+ * batches the activations BETWEEN the UNet's kernels — and q / k / v — are stored token-major in bf16, i.e. a clip's
+ * result then depends on whether its batch crosses that threshold (bounded in tests/test_gpu_parity.py / test_gpu_round4.py).  This is
+ * the "bf16" of BASELINE.json configs[2]; the reference itself (diffusion.py) only runs fp32, the closest analogue being
+ * torch.autocast(bfloat16) around its matmuls/convs.  Default 0 = fp32 mode: fp32 tensors everywhere, products on split-fp16 operands
+ * (x = h + 2^-11 l: 22-bit significands, three fp16 MFMAs per eight fp32 ones, fp32 accumulation — as close to a float64 evaluation as
+ * the fp32 matrix instructions) unless switched back to v_mfma_f32_32x32x2_f32 by the debug options below.
+ * Takes effect at the next call. */
 int said_set_precision(said_ctx* ctx, int bf16_mfma);
 int said_get_precision(const said_ctx* ctx);
 
@@ -216,7 +222,8 @@ double said_unet_algorithmic_flops(int batch_eff, int frames);
 /* Per-launch timing of one UNet evaluation's kernel schedule at (batch_eff, frames): stage k is
  * replayed `reps` times back to back (one hipGraph) between two HIP events on `stream`.
  * Outputs per stage: average microseconds, algorithmic bytes (weights + operands + result),
- * flops, kind (0 = generic GEMM/conv kernel, 1 = attention, 2 = LDS-staged UNet GEMM), epilogue id, tile shape (NB, KS).
+ * flops, kind (0 = generic GEMM/conv kernel, 1 = attention, 2 = LDS-staged UNet GEMM, 4-9 = the large-batch kernels, 10 = stchain_kernel,
+ * 11 = conv_in_kernel, 12 = the `out` convolution alone — in the loop it is the first half of out_sched_kernel), epilogue id, tile shape (NB, KS).
  * cfg_clips > 0 (= batch_eff / 2): the schedule of the classifier-free-guidance loop (unconditional half first; the
  * prefix shared by the two halves runs once per clip), else the schedule of SAID.forward.
  * Used by bench.py's roofline block; internal buffers must hold finite data (run a forward first). */
@@ -231,15 +238,15 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
  *   "audio_chunk"            clips per audio-encoder pass (default 32)
  *   "steps_per_graph"        denoise steps captured per hipGraph (default 10)
  *   "tm_acts"                large batches: token-major activations (bf16 / fp32) between the UNet kernels, GroupNorm / LayerNorm applied inside
- *                            the consuming GEMM (xgemm_kernel), 41 launches per step, no preparation kernels.  -1 (default): on
+ *                            the consuming GEMM (xgemm_kernel), 41 launches per step, no preparation kernels (NOTEBOOK.md 7.3).  -1 (default): on
  *                            in bf16 mode, off in fp32 mode (measured slower there); 0 / 1 force it
  *   "xgemm_ntw"              column tiles per workgroup of the resident-source GEMMs (0: chosen per launch)
  *   "hybrid"                 0: bf16 mode at large batch keeps round 2's SpatialTransformer schedule throughout (default 1: from the
- *                            attention output on, the block runs on round 3's token-major kernels — DESIGN.md 7.3)
+ *                            attention output on, the block runs on round 3's token-major kernels — NOTEBOOK.md 7.3)
  *   "audio_front_fused"      0: the bf16 audio encoder stores conv0's fp32 activation and runs GroupNorm + GELU and the transpose as separate
  *                            kernels (round 2); default 1: one recomputing pass writes token-major bf16 directly
  *   "mt_mid"                 0: multi-tile workgroups (several token tiles per workgroup, weights kept in registers) only from 1024 workgroups per
- *                            launch on (round 2); default 1: also for launches of 2-4 rounds of one workgroup per CU
+ *                            launch on (round 2); default 1: also for launches of 2-4 rounds of one workgroup per CU (NOTEBOOK.md 7.2)
  *   "mt_wgs"                 > 0: workgroups per token tile from which a launch goes multi-tile (overrides both rules)
  *   "tgemm_sb"               0: the bf16 audio encoder's 128 x 128 GEMM tiles keep two LDS operand buffers (two workgroups per CU; round 2); default 1: one
  *                            buffer, three workgroups per CU (11.12 -> 10.90 ms per 32 clips, bit-identical)
@@ -247,7 +254,17 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
  *   "unet_nb_model"          0: round 2's rule for the column tiles per workgroup of the 192-wide channel-major GEMMs (default 1: busiest-CU model)
  *   "unet_nb"                > 0: forces that number of column tiles per workgroup (1, 2 or 3)
  *   "hybrid_f32"             1: the hybrid SpatialTransformer schedule in fp32 mode too (measured slower: default 0)
- * said_debug_get additionally knows "n_set_weight" (said_set_weight calls so far). */
+ *   "out_tm"                 0: bf16 large batches end the step with round 3's channel-major out conv + scheduler kernel (default -1: out_sched_tm_kernel)
+ *   "rgemm"                  0: bf16 large batches without round 4's persistent register-stationary GEMMs (default -1: on)
+ *   "battn"                  0: bf16 large batches with attn_kernel on fp32 operands instead of battn_kernel (default -1: on; 4 / 8: query tiles per workgroup)
+ *   "gemm_split"             fp32 mode, large batches: 0 puts fgemm_kernel back on v_mfma_f32_32x32x2_f32 (default -1 / 1: split-fp16 products)
+ *   "attn_split"             fp32 mode: 0 puts both self-attention products back on fp32 MFMAs (default -1 / 1: split-fp16 products)
+ *   "ugemm_split"            fp32 mode, channel-major GEMMs (ugemm_kernel): 0 = fp32 MFMAs (default -1 / 1: split-fp16 products, round 5)
+ *   "st_chain"               fp32 mode: 0 runs everything behind a SpatialTransformer's self-attention as five launches (rounds 1-4); default -1 / 1:
+ *                            one launch per block (stchain_kernel, round 5).  "st_chain_large" 0: only below the token-major threshold;
+ *                            "st_chain_max_tiles" n: only while a launch has at most n (sample, 32-token tile) workgroups; "st_chain_dbg" 1: the fused
+ *                            kernel also writes x1 / x2 / the cross-attention input to X1 / X2 / X3 (bring-up)
+ * said_debug_get additionally knows "n_set_weight" (said_set_weight calls so far), "n_stchain" / "n_rgemm" / "n_xgemm" (launches issued through those kernels). */
 int said_debug_option(said_ctx* ctx, const char* name, long long value);
 long long said_debug_get(const said_ctx* ctx, const char* name);
 /* Stop the UNet schedule after `n_launches` kernel launches (< 0: run everything). */
