@@ -170,6 +170,9 @@ int said_loop_prepare(said_ctx* ctx, const said_loop_params* p, void* stream);
  * `show_process=True` polls it from a thread to drive the progress line the reference prints with tqdm around its Python loop
  * (/root/reference/said/model/diffusion.py:412-415). */
 int said_loop_progress(said_ctx* ctx, int* steps_done);
+/* Sets the step counter back to "no step started" synchronously.  The host wrapper calls it before it starts the polling thread, so that a
+ * poll that runs before the new loop's own reset has executed cannot report the PREVIOUS loop's final count (ABI 8). */
+int said_loop_progress_reset(said_ctx* ctx);
 
 /* The standard normals the loop generates with use_step_noise == 2: out_dev (nsteps, B*T*C) <- noise of steps
  * step0 .. step0 + nsteps - 1 for `seed` (element index = ((b*T + t)*C + c)).  Replaces the `randn` drawn inside

@@ -18,7 +18,7 @@ _lib = None
 
 PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 NCOEF = 8
-ABI_VERSION = 7   # include/said_hip.h as bound below; a stale libsaid_hip.so is refused at load time
+ABI_VERSION = 8   # include/said_hip.h as bound below; a stale libsaid_hip.so is refused at load time
 
 
 class EngineError(RuntimeError):
@@ -59,6 +59,7 @@ EXPORTS = {
     "said_axpby": (c_int, [c_void_p, POINTER(c_float), c_void_p, POINTER(c_float), c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "said_graph_num_nodes": (c_int, [c_void_p]),
     "said_loop_progress": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "said_loop_progress_reset": (c_int, [c_void_p]),
     "said_set_precision": (c_int, [c_void_p, c_int]),
     "said_get_precision": (c_int, [c_void_p]),
     "said_profile_unet": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -400,8 +401,13 @@ class Engine:
     def loop_progress(self) -> int:
         """Denoise steps started so far by the loop running (or last run) on this context; never blocks the loop's stream."""
         v = c_int(0)
-        self._chk(self.lib.said_loop_progress(self.h, ctypes.byref(v)), "said_loop_progress")
+        if self.lib.said_loop_progress(self.h, ctypes.byref(v)) != 0:   # (the entry does not record an error text: it runs beside the loop's thread)
+            raise EngineError("said_loop_progress failed")
         return v.value
+
+    def loop_progress_reset(self) -> None:
+        """Forget the previous loop's step count before a polling thread is started."""
+        self._chk(self.lib.said_loop_progress_reset(self.h), "said_loop_progress_reset")
 
     def graph_num_nodes(self) -> int:
         return int(self.lib.said_graph_num_nodes(self.h))

@@ -742,7 +742,16 @@ void do_xgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
                                 eb * a.N * a.K + (double)batch * a.M * (eb * in_k + out_b + res_b + band_b), 2.0 * batch * (double)a.M * a.N * a.K});
     }
     if (fam == 7) {
-        if (dbg_go(c)) { launch_rgemm(a2, batch, s); ++c->n_rgemm; }
+        if (dbg_go(c)) {
+            if (!launch_rgemm(a2, batch, s)) c->launch_err = "rgemm_kernel refused a launch its own rgemm_supports() had accepted";
+            ++c->n_rgemm;
+        }
+        return;
+    }
+    // a launch over a COLUMN RANGE of the packed weights (the split concatenated-input ResBlocks / folded proj_out probe only their first launch) is
+    // something only rgemm_kernel understands: falling through to xgemm_kernel would silently multiply the wrong columns
+    if (a2.w_k0 != 0 || (a2.w_ld != 0 && a2.w_ld != a2.K) || a2.w_seg != 0) {
+        c->launch_err = "token-major GEMM over a weight column range is not served by rgemm_kernel for this shape";
         return;
     }
     ++c->n_xgemm;
@@ -1583,7 +1592,7 @@ int check_ready(said_ctx* ctx) {
 // ============================================================================================
 extern "C" {
 
-int said_abi_version(void) { return 7; }   // 7: said_debug_ws_*; 6: said_loop_progress; 5: said_clone, said_loop_params::noise_batch_offset; 4: said_reserve, noise_seed, said_philox_normal, said_debug_option
+int said_abi_version(void) { return 8; }   // 8: said_loop_progress_reset; 7: said_debug_ws_*; 6: said_loop_progress; 5: said_clone, said_loop_params::noise_batch_offset; 4: said_reserve, noise_seed, said_philox_normal, said_debug_option
 
 const char* said_last_error(const said_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -2724,8 +2733,17 @@ int said_loop_progress(said_ctx* ctx, int* steps_done) {
     hipError_t e = hipMemcpyAsync(&v, ctx->step_dev, sizeof(int), hipMemcpyDeviceToHost, ps);
     if (e == hipSuccess) e = hipStreamSynchronize(ps);
     (void)hipStreamDestroy(ps);
-    if (e != hipSuccess) return fail(ctx, "said_loop_progress: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return -2;   // (no fail(): this is called from a polling thread while the loop's thread may be writing ctx->err — ADVICE r4)
     *steps_done = v + 1;        // the counter is -1 before the first step and k - 1 once step k - 1 has STARTED; its kernels complete in order
+    return 0;
+}
+
+int said_loop_progress_reset(said_ctx* ctx) {
+    if (!ctx) return -1;
+    DeviceRestore restore_device;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int m1 = -1;
+    HIPCHK(hipMemcpy(ctx->step_dev, &m1, sizeof(int), hipMemcpyHostToDevice));   // synchronous: a poller started after this call never sees the previous loop's count
     return 0;
 }
 

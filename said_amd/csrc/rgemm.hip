@@ -605,6 +605,11 @@ static bool rg_plan(const TGemmArgs& a, RgPlan& p) {
         p.stats = a.stats ? 1 : 0;
     } else return false;
     if ((long long)a.batch * a.seg_rows * (p.nch == 4 ? 768 : 192) * 2 > 0x7ffffff0LL) return false;   // 32-bit byte offsets into the activation tensors
+    if (a.qk) {   // ... and into the q / k / v outputs: the fp32 q / k layout is 1536 B per token, four times the bf16 activations' 384
+        const long long el = a.qkv_bf16 ? 2 : 4;
+        if ((long long)a.batch * a.heads2 * a.rows * 32 * el > 0x7ffffff0LL) return false;
+        if ((long long)a.batch * a.v_bs * el > 0x7ffffff0LL) return false;
+    }
     const int total = a.batch * ((a.M + 31) / 32);
     const int wpg = std::max(8, 256 / p.groups / 8 * 8);          // workgroups per column group: one workgroup per CU in all
     p.per = (total + wpg - 1) / wpg;

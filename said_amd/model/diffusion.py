@@ -58,6 +58,7 @@ class _Progress:
     def __init__(self, eng, total: int, interval: float = 0.05):
         from tqdm import tqdm
         self._eng, self._total, self._interval = eng, total, interval
+        eng.loop_progress_reset()   # the previous loop's final count must not be read as this loop's progress
         self._bar = tqdm(total=total)
         self._done = 0
         self._stop = threading.Event()

@@ -158,3 +158,31 @@ def test_split_planes_come_from_one_conversion(model, dev):
     rng = float(res["five"].max() - res["five"].min())
     print(f"first block, per-token max |chain - five|: median {np.median(d):.2e}, max {d.max():.2e} (range {rng:.1f})")
     assert d.max() <= 1.5e-5, "a token is off by far more than rounding: split planes from two different conversions?"
+
+
+def test_show_process_twice_does_not_start_from_the_previous_count(model, dev):
+    """the progress poller used to be able to read the PREVIOUS loop's final step count before the new loop's reset had executed (the bar
+    jumped to `total` at once).  The wrapper now resets the counter synchronously (said_loop_progress_reset) before it starts polling."""
+    from said_amd.model import diffusion as D
+    proc = op.process_audio(synth.synth_waveform(3, 16000)).to(dev)
+    lat = synth.synth_latents(9, (1, 60, 32)).to(dev)
+    seen = []
+    orig = D._Progress._advance
+
+    def spy(self):
+        orig(self)
+        seen[-1].append(self._done)
+
+    D._Progress._advance = spy
+    try:
+        for _ in range(2):
+            seen.append([])
+            model.inference(proc, num_inference_steps=40, guidance_scale=2.0, init_latents=lat, show_process=True)
+            eng = model._eng
+            assert eng.loop_progress() == 40
+        eng.loop_progress_reset()
+        assert eng.loop_progress() == 0
+    finally:
+        D._Progress._advance = orig
+    for s in seen:
+        assert s and s == sorted(s) and s[-1] == 40
