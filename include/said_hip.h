@@ -270,7 +270,9 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
  * said_debug_get additionally knows "n_set_weight" (said_set_weight calls so far), "n_stchain" / "n_rgemm" / "n_xgemm" (launches issued through those kernels). */
 int said_debug_option(said_ctx* ctx, const char* name, long long value);
 long long said_debug_get(const said_ctx* ctx, const char* name);
-/* Stop the UNet schedule after `n_launches` kernel launches (< 0: run everything). */
+/* Stop the UNet schedule after `n_launches` kernel launches, counted from the start of each said_unet_forward / said_denoise_loop call (< 0: run
+ * everything).  In a loop call only the eager warm-up step then runs (its first n launches); the workspace afterwards holds that step's intermediates
+ * (tests/test_gpu_round5.py reads the last hidden state this way). */
 int said_debug_stop_after(said_ctx* ctx, int n_launches);
 /* Enable/disable per-phase shader-clock stamps in the GEMM kernels of the next UNet evaluations and
  * (if out_host != NULL) read back the [64 launches][8 waves][8 slots] stamp table. */

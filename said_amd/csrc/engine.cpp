@@ -2276,6 +2276,7 @@ static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, boo
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->device));
     ctx->cur_concurrent = p->concurrent != 0;
+    ctx->dbg_count = 0;   // (said_debug_stop_after counts launches from the start of the call: the eager warm-up step then runs the first n launches, the captured steps none)
     const int B = p->batch, T = p->frames, N = p->num_steps, C = ctx->cin;
     const bool cfg = p->guidance_scale > 1.0f;
     const int Be = cfg ? 2 * B : B;
@@ -2604,6 +2605,8 @@ int said_philox_normal(said_ctx* ctx, uint64_t seed, int step0, int nsteps, int6
 int said_debug_stop_after(said_ctx* ctx, int n) {
     if (!ctx) return -1;
     ctx->dbg_stop = n;
+    ctx->dbg_count = 0;
+    ctx->gkey.clear();   // a cached step graph holds the other launch count
     return 0;
 }
 

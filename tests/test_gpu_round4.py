@@ -169,7 +169,9 @@ def test_out_sched_tm_matches_channel_major_out_path(model, dev, gs):
     d = float((res[0] - res[1]).abs().max())
     print(f"out_sched_tm vs channel-major out path, guidance {gs}: max |diff| after {N} steps {d:.3e} ({nodes} graph nodes per step)")
     assert torch.isfinite(res[1]).all() and d <= 0.087
-    assert torch.equal(res[1][:, 100:300], res[0][:, 100:300]) or float((res[1][:, 100:300] - res[0][:, 100:300]).abs().max()) <= 0.087
+    # the masked frames are add_noise(init_samples) at the next timestep whatever the model output: bit-identical between the two routes
+    # (the kernel's arithmetic itself is checked against the stand-alone scheduler in tests/test_gpu_round5.py)
+    assert torch.equal(res[1][:, 100:300], res[0][:, 100:300])
 
 
 # ---------------------------------------------------------------- split-fp16 attention products (fp32 mode)
