@@ -75,6 +75,8 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
     const int w = QW > 1 ? 0 : w_all;               // key-split index
     const int wq = QW > 1 ? w_all : 0;              // query tile of this wave within the workgroup
     float* const sm_w = smem + wq * (KS * 64 + KS * ND * 16 * 64);   // private merge scratch per query-tile wave
+    // (round 5, measured neutral and not kept: an XCD-affine block order — every XCD a contiguous run of (sample, head, query tile) so that a head's K / V is
+    //  fetched into one or two L2s instead of eight: cfg4 24.15k vs 24.14k frames/s, headline -0.2 %: profiles/r05g_attn_xcd_affine_ab.txt.  The kernel is not bound by L2 fills.)
     const int i0 = (blockIdx.x * QW + wq) * 32, h = blockIdx.y, b = blockIdx.z + a.b0;
     const int T = a.T, pitch = a.pitch, H = a.heads, rows = a.rows;
     const float* qb = a.qk + (((long long)b * 2 * H + h) * rows) * D + lh * (D / 2);
