@@ -57,7 +57,8 @@ struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out
              void *t_qkv = nullptr, *t_ff1 = nullptr, *t_ffproj = nullptr; float* t_ff1_bias = nullptr; /* bf16 weights for tgemm.hip */
              void *tf_qkv = nullptr, *tf_ff1 = nullptr, *tf_ffproj = nullptr; /* fp32 copies (fgemm_kernel) */
              void *t_out1 = nullptr, *t_q2 = nullptr, *t_out2 = nullptr, *tf_out1 = nullptr, *tf_q2 = nullptr, *tf_out2 = nullptr; /* [192][192] (xgemm_kernel) */
-             float *chain_w = nullptr, *chain_vec = nullptr; /* round 5: weight stream + vectors of the fused tail (stchain.hip) */ };
+             float *chain_w = nullptr, *chain_vec = nullptr; /* round 5: weight stream + vectors of the fused tail (stchain.hip) */
+             void* chain_wb = nullptr; /* ... and the bf16 stream (1 KB units) of its bf16-mode variant */ };
 struct W2VLayer { PW qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln2g, *ln2b; };
 
 struct ActBuf {  // channel-major activation + its GroupNorm partial statistics
@@ -112,6 +113,8 @@ struct said_ctx {
     bool band_chain_ok = false;  // the alignment band fits stchain's window tile (set_band)
     bool st_chain_large = true;  // ... at large batches too, beside the token-major q / k / v GEMM (32 clips: 3.2 -> 2.4 ms per step; said_debug_option "st_chain_large")
     long long st_chain_max_tiles = 1LL << 40;   // ... while the launch is at most this many workgroups (sample x 32-token tiles; said_debug_option "st_chain_max_tiles")
+    int st_chain_bf16 = -1;      // bf16 mode, large batches: the same fused tail on bf16 operands (stchain_kernel<true>) instead of rgemm's five launches; 0: off
+                                 // (said_debug_option "st_chain_bf16")
     bool st_chain_dbg = false;   // debug: the fused kernel also writes x1 / x2 to X1 / X2
     int st_chain = -1;           // fp32 mode, small batches: everything behind self-attention as ONE launch per block (stchain.hip); 0: the five launches
                                  // (said_debug_option "st_chain")
@@ -884,6 +887,28 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
             do_attn(c, a, n1, HD, -4, s);
         }
     }
+    // round 5: everything behind the attention as ONE launch on bf16 operands (stchain_kernel<true>; the token-major bf16 tensors are its operands as they are)
+    if (c->bf16_mode && c->st_chain_bf16 != 0 && !last && sw.chain_wb && sw.chain_vec && c->band_chain_ok && c->cur_b0 == 0 && g.S == c->band_S && g.T == c->band_T &&
+        (long long)g.Be * seg * MC < 0x7fffffffLL) {
+        ChainArgs ca;
+        memset(&ca, 0, sizeof ca);
+        ca.wstream = static_cast<const float*>(sw.chain_wb); ca.vec = sw.chain_vec;
+        ca.xin_part = in.st; ca.part_bs = g.sts; ca.gn_gamma = sw.gn_g; ca.gn_beta = sw.gn_b;
+        ca.kvt = c->KVT; ca.kvt_bs = (long long)g.S * (NST * 2 * MC); ca.lo = c->band_lo; ca.hi = c->band_hi;
+        ca.y = static_cast<float*>(out.t); ca.y_bs = seg * MC; ca.stats_out = out.st; ca.stats_bs = g.sts;
+        ca.S = g.S; ca.np = g.np; ca.koff = blk * 2 * MC; ca.wmax = c->band_wmax; ca.scale = 0.17677669529663687f;
+        if (c->log_on) {
+            const double w = 2.0 * ((double)3 * MC * MC + 2.0 * FFI * MC + (double)(FFI + MC) * MC);
+            const double io = 2.0 * MC * g.T * ((double)n1 * 2 + g.Be) + 4.0 * 2 * MC * g.T * (double)n2;
+            const double fl = 2.0 * g.T * ((double)n1 * MC * MC + (double)n2 * 2 * MC * MC + (double)g.Be * (2.0 * FFI * MC + (double)(FFI + MC) * MC)) + 4.0 * n2 * MC * g.T * c->band_wmax;
+            c->stage_log.push_back({10, EPI_STORE, 6, 8, w + io, fl});
+        }
+        if (dbg_go(c)) {
+            launch_stchain(ca, static_cast<const float*>(c->tO), static_cast<const float*>(in.t), g.T, g.Tp, seg * MC, seg * MC, shared ? g.Bc : 0, g.Bc > 0 ? g.Bc : 0, g.Be, s, true);
+            ++c->n_stchain;
+        }
+        return;
+    }
     {   // x1 = to_out(attn) + GroupNorm(x_in)   (attention.py:127, 168); under guidance also x2 of the unconditional half = x1 + c2
         TGemmArgs t = mkx(g, tw(c, sw.t_out1, sw.tf_out1), MC, MC);
         t.sa[0] = c->tO; t.sld[0] = MC; t.sk[0] = MC;
@@ -1473,7 +1498,7 @@ void run_kv(said_ctx* c, int b0, int nb, int S, int Sp, hipStream_t s) {
     const LaunchCfg lc = pick_cfg((long long)nb * ((S + 31) / 32), NST * 2 * MC / 32);
     launch_gemm(a, EPI_STORE, nb, lc.NB, lc.KS, s);
     // the key-major copy the fused SpatialTransformer tail reads its window tiles from (once per loop; fp32 mode's small-batch schedule only)
-    if (!c->bf16_mode && c->st_chain != 0 && (long long)S * NST * 2 * MC <= (long long)NST * 2 * MC * c->maxTp)
+    if ((c->bf16_mode ? c->st_chain_bf16 != 0 : c->st_chain != 0) && (long long)S * NST * 2 * MC <= (long long)NST * 2 * MC * c->maxTp)
         launch_cm_to_tm(c->KV + b0 * ybs, c->KVT + (long long)b0 * S * (NST * 2 * MC), nb, S, NST * 2 * MC, Sp, ybs, s);
 }
 
@@ -1877,6 +1902,36 @@ static int pack_chain(said_ctx* ctx, STW& sw, const std::string& b, const std::v
         for (int s = 30; s < 60; ++s) put_unit(4, 32 * (w - 2), s);
     }
     if (o != st.size()) return fail(ctx, "pack_chain: stream size mismatch");
+    {   // the bf16 stream: the same units in the same order, ONE plane of bf16 (RNE) — 1 KB per unit
+        std::vector<uint16_t> sb(CHAIN_STREAM_UNITS * 512);
+        size_t ob = 0;
+        auto put_unit_b = [&](int kind, int row0, int step) {
+            for (int l = 0; l < 64; ++l)
+                for (int i = 0; i < 8; ++i) sb[ob++] = bf16_rne((float)elem(kind, row0 + (l & 31), 16 * step + 8 * (l >> 5) + i));
+        };
+        auto put_geglu_b = [&](int w) {
+            for (int pi = 0; pi < 3; ++pi)
+                for (int s = 0; s < 12; ++s) {
+                    put_unit_b(3, 32 * (w + 8 * pi), s);
+                    put_unit_b(3, FFI + 32 * (w + 8 * pi), s);
+                }
+        };
+        for (int w = 0; w < 6; ++w) {
+            for (int kind = 0; kind < 3; ++kind)
+                for (int s = 0; s < 12; ++s) put_unit_b(kind, 32 * w, s);
+            put_geglu_b(w);
+            for (int s = 0; s < (w < 4 ? 60 : 30); ++s) put_unit_b(4, 32 * w, s);
+        }
+        for (int w = 6; w < 8; ++w) {
+            put_geglu_b(w);
+            for (int s = 30; s < 60; ++s) put_unit_b(4, 32 * (w - 2), s);
+        }
+        if (ob != sb.size()) return fail(ctx, "pack_chain: bf16 stream size mismatch");
+        uint16_t* d = nullptr;
+        if (dalloc(ctx, &d, sb.size(), false)) return -1;
+        HIPCHK(hipMemcpy(d, sb.data(), sb.size() * 2, hipMemcpyHostToDevice));
+        sw.chain_wb = d;
+    }
     std::vector<float> stf(st.size() / 2);
     memcpy(stf.data(), st.data(), st.size() * 2);
     if (upload(ctx, &sw.chain_w, stf.data(), stf.size())) return -1;
@@ -2556,6 +2611,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->st_chain = value < 0 ? -1 : (value != 0);
     } else if (k == "st_chain_dbg") {
         ctx->st_chain_dbg = value != 0;
+    } else if (k == "st_chain_bf16") {
+        ctx->st_chain_bf16 = value < 0 ? -1 : (value != 0);
     } else if (k == "st_chain_large") {
         ctx->st_chain_large = value != 0;
     } else if (k == "st_chain_max_tiles") {
@@ -2582,6 +2639,7 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "ugemm_split") return (!ctx->bf16_mode && ctx->ugemm_split != 0) ? 1 : 0;
     if (k == "st_chain") return (!ctx->bf16_mode && ctx->st_chain != 0) ? 1 : 0;
     if (k == "n_stchain") return ctx->n_stchain;
+    if (k == "st_chain_bf16") return (ctx->bf16_mode && ctx->st_chain_bf16 != 0) ? 1 : 0;
     if (k == "attn_split") return (!ctx->bf16_mode && ctx->attn_split != 0) ? 1 : 0;   // 1: fp32-mode attention products run on split-fp16 operands
     if (k == "rgemm") return ctx->rgemm;
     if (k == "n_rgemm") return ctx->n_rgemm;

@@ -6,7 +6,8 @@ namespace said {
 
 constexpr int CHAIN_KW = 56;                    // key rows of the cross-attention window tile kept in LDS per 32-token tile: the tile's windows must fit
                                                 // (engine.cpp: set_band checks max(hi) - lo[t0] <= CHAIN_KW per tile, else the five-launch schedule runs)
-constexpr size_t CHAIN_STREAM_BYTES = (size_t)(4 * 168 + 2 * 138 + 2 * 102) * 2048;   // 2 KB units (one k16 step: h + l fragments) of the eight waves' streams: 2,359,296 per transformer block
+constexpr size_t CHAIN_STREAM_UNITS = 4 * 168 + 2 * 138 + 2 * 102;
+constexpr size_t CHAIN_STREAM_BYTES = CHAIN_STREAM_UNITS * 2048;   // 2 KB units (one k16 step: h + l fragments) of the eight waves' streams: 2,359,296 per transformer block
 constexpr int CHAIN_VEC_FLOATS = 5 * 192 + 1536;        // global: b1, bq, bo2, c2, bffp (192 each), bff (1536: value rows, then gate rows)
 constexpr int CHAIN_VEC_FLOATS_LDS = 4 * 192 + 1536;    // LDS: bo2 | c2 share a slot (conditional | unconditional sample)
 
@@ -35,8 +36,11 @@ struct ChainArgs {
 
 bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long long x_bs);
 // o: attention output [.][192][pitch] (o_bs floats between samples), xin: block input (x_bs); sample s reads o / xin / partials of sample s % in_mod (in_mod > 0:
-// guidance-shared prefix) and skips the cross-attention when s < n_uncond
-void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s);
+// guidance-shared prefix) and skips the cross-attention when s < n_uncond.
+// bf16 = true (bf16 mode, large batches): o, xin and y are TOKEN-major bf16 [sample][row][192] (o_bs / x_bs / y_bs in elements, pitch unused), wstream the bf16 stream
+// (1 KB units), every product one v_mfma_f32_32x32x16_bf16 on operands rounded to bf16; statistics, LayerNorm, softmax, residual sums stay fp32.
+void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s,
+                    bool bf16 = false);
 void configure_stchain_kernel();
 
 }  // namespace said

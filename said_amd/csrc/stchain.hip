@@ -48,7 +48,8 @@ constexpr int CH_LDS = CH_LNP + 32 * 6 * 2 * 4;
 static_assert(CH_LDS <= 160 * 1024, "chain kernel LDS budget");
 static_assert(CHAIN_KW * CH_KP * 4 * 2 <= 2 * CH_HPL, "K / V window tiles fit the GEGLU product region");
 constexpr int CH_NR_OWNER = 8;                     // ring depths (units of one k16 step: h + l fragments = 2 KB per wave): what is in flight is what bounds the stream's
-constexpr int CH_NR_HELPER = 9;                   // rate (latency x bandwidth ~ 160 KB per CU): 6 x 16 + 2 x 24 = 144 KB
+constexpr int CH_NR_HELPER = 9;                    // rate (latency x bandwidth ~ 160 KB per CU): 6 x 16 + 2 x 18 = 132 KB
+constexpr int CH_NR_BF = 20;                       // bf16 variant: 1 KB units, no second accumulator set: 20 KB per wave in flight
 
 // units of a wave's stream: [to_out1 12][to_q 12][to_out2 12][GEGLU 3 pairs x 12 steps x (value, gate)][ffproj 60 | 30]; waves 6, 7: [GEGLU 72][ffproj 30].
 // The folded proj_out (60 k16 steps per column tile) is the one phase where six column owners on four SIMDs are unbalanced (two SIMDs with two owners: 11.5k clocks of
@@ -72,12 +73,16 @@ __device__ __forceinline__ void sfor(F&& f) {
 // (buffer loads: the unit's offset rides in an SGPR / the immediate — with flat pointers the compiler kept a 64-bit VGPR address per in-flight load and spilled the ring)
 template <int NR> struct Ring { f32x4 h[NR], l[NR]; };
 struct WStream { rsrc_t r; int vo; };   // the wave's stream, lane * 16
-template <int MODE, int NR, int Q>
+// BF (bf16 mode, large batches): ONE plane everywhere — weights and activations rounded to bf16 (RNE), v_mfma_f32_32x32x16_bf16, a unit is 1 KB
+typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2c __attribute__((ext_vector_type(2)));
+template <int MODE, bool BF, int NR, int Q>
 __device__ __forceinline__ void ring_issue(Ring<NR>& R, const WStream& wp) {
     if constexpr (Q < n_units<MODE>()) {
         constexpr int u = unit_of<MODE>(Q);
-        R.h[Q % NR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wp.r, wp.vo, u * 2048, 0));
-        R.l[Q % NR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wp.r, wp.vo + 1024, u * 2048, 0));
+        R.h[Q % NR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wp.r, wp.vo, u * (BF ? 1024 : 2048), 0));
+        if constexpr (!BF) R.l[Q % NR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wp.r, wp.vo + 1024, u * 2048, 0));
     }
 }
 
@@ -96,48 +101,59 @@ __device__ __forceinline__ void clk_stamp_c(long long* clk, int w, int lane, int
 // one 192-deep (NS = 12) or longer run of k16 steps: B fragments from the token-major planes at `bh` (this lane's row + k-group offset; low plane `pl` bytes behind)
 // (the B fragments are double-buffered by hand, one step ahead, and a scheduling fence closes every step: left alone the compiler hoists all 2 NS fragment
 //  reads above the MFMAs — 96 registers at NS = 12, which the ring and the accumulators need)
-template <int MODE, int NR, int Q0, int NS>
+template <int MODE, bool BF, int NR, int Q0, int NS>
 __device__ __forceinline__ void gemm_run(Ring<NR>& R, const WStream& wp, const char* bh, int pl, f32x16& acc, f32x16& accx) {
-    f16x8 xh = *reinterpret_cast<const f16x8*>(bh), xl = *reinterpret_cast<const f16x8*>(bh + pl);
+    f16x8 xh = *reinterpret_cast<const f16x8*>(bh), xl = xh;
+    if constexpr (!BF) xl = *reinterpret_cast<const f16x8*>(bh + pl);
     sfor<0, NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         f16x8 nh = xh, nl = xl;
         if constexpr (s + 1 < NS) {
             nh = *reinterpret_cast<const f16x8*>(bh + 32 * (s + 1));
-            nl = *reinterpret_cast<const f16x8*>(bh + pl + 32 * (s + 1));
+            if constexpr (!BF) nl = *reinterpret_cast<const f16x8*>(bh + pl + 32 * (s + 1));
         }
-        const f16x8 wh = __builtin_bit_cast(f16x8, R.h[(Q0 + s) % NR]), wl = __builtin_bit_cast(f16x8, R.l[(Q0 + s) % NR]);
-        accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, accx, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
-        accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accx, 0, 0, 0);
-        ring_issue<MODE, NR, Q0 + s + NR>(R, wp);
+        if constexpr (BF) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8c, R.h[(Q0 + s) % NR]), __builtin_bit_cast(bf16x8c, xh), acc, 0, 0, 0);
+        } else {
+            const f16x8 wh = __builtin_bit_cast(f16x8, R.h[(Q0 + s) % NR]), wl = __builtin_bit_cast(f16x8, R.l[(Q0 + s) % NR]);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, accx, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accx, 0, 0, 0);
+        }
+        ring_issue<MODE, BF, NR, Q0 + s + NR>(R, wp);
         __builtin_amdgcn_sched_barrier(0);
         xh = nh; xl = nl;
     });
 }
 // GEGLU: a (value, gate) tile pair shares every B fragment; units alternate value, gate.  `between(s)` runs behind step s's MFMAs (the previous pair's epilogue in
 // four pieces: its erf / split VALU work rides under this pair's matrix work, and the weight stream never pauses for an epilogue)
-template <int MODE, int NR, int Q0, typename F>
+template <int MODE, bool BF, int NR, int Q0, typename F>
 __device__ __forceinline__ void geglu_run(Ring<NR>& R, const WStream& wp, const char* bh, int pl, f32x16& av, f32x16& avx, f32x16& ag, f32x16& agx, F&& between) {
-    f16x8 xh = *reinterpret_cast<const f16x8*>(bh), xl = *reinterpret_cast<const f16x8*>(bh + pl);
+    f16x8 xh = *reinterpret_cast<const f16x8*>(bh), xl = xh;
+    if constexpr (!BF) xl = *reinterpret_cast<const f16x8*>(bh + pl);
     sfor<0, 12>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         f16x8 nh = xh, nl = xl;
         if constexpr (s + 1 < 12) {
             nh = *reinterpret_cast<const f16x8*>(bh + 32 * (s + 1));
-            nl = *reinterpret_cast<const f16x8*>(bh + pl + 32 * (s + 1));
+            if constexpr (!BF) nl = *reinterpret_cast<const f16x8*>(bh + pl + 32 * (s + 1));
         }
         constexpr int qv = Q0 + 2 * s, qg = Q0 + 2 * s + 1;
-        const f16x8 vh = __builtin_bit_cast(f16x8, R.h[qv % NR]), vl = __builtin_bit_cast(f16x8, R.l[qv % NR]);
-        const f16x8 gh = __builtin_bit_cast(f16x8, R.h[qg % NR]), gl = __builtin_bit_cast(f16x8, R.l[qg % NR]);
-        avx = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, xh, avx, 0, 0, 0);
-        agx = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh, agx, 0, 0, 0);
-        av = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, xh, av, 0, 0, 0);
-        ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh, ag, 0, 0, 0);
-        avx = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, xl, avx, 0, 0, 0);
-        agx = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl, agx, 0, 0, 0);
-        ring_issue<MODE, NR, qv + NR>(R, wp);
-        ring_issue<MODE, NR, qg + NR>(R, wp);
+        if constexpr (BF) {
+            av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8c, R.h[qv % NR]), __builtin_bit_cast(bf16x8c, xh), av, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8c, R.h[qg % NR]), __builtin_bit_cast(bf16x8c, xh), ag, 0, 0, 0);
+        } else {
+            const f16x8 vh = __builtin_bit_cast(f16x8, R.h[qv % NR]), vl = __builtin_bit_cast(f16x8, R.l[qv % NR]);
+            const f16x8 gh = __builtin_bit_cast(f16x8, R.h[qg % NR]), gl = __builtin_bit_cast(f16x8, R.l[qg % NR]);
+            avx = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, xh, avx, 0, 0, 0);
+            agx = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh, agx, 0, 0, 0);
+            av = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, xh, av, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh, ag, 0, 0, 0);
+            avx = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, xl, avx, 0, 0, 0);
+            agx = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl, agx, 0, 0, 0);
+        }
+        ring_issue<MODE, BF, NR, qv + NR>(R, wp);
+        ring_issue<MODE, BF, NR, qg + NR>(R, wp);
         between(sc);
         __builtin_amdgcn_sched_barrier(0);
         xh = nh; xl = nl;
@@ -154,14 +170,22 @@ __device__ __forceinline__ void merge16(float (&v)[16], const f32x16& acc, const
     for (int r = 0; r < 16; ++r) v[r] = fmaf(accx[r], 0x1p-11f, acc[r]);
 }
 // a lane's 16 values (token row `row`, channels col0 + (r & 3) + 8 (r >> 2) [col0 includes 4 lh]) -> split planes: four 8-byte pieces per plane
+template <bool BF>
 __device__ __forceinline__ void put_split(char* plane_h, int pl, int row_bytes, int col0, const float (&v)[16]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        f16x4 h, lo;
-        split_f16x4(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3], h, lo);
         char* p = plane_h + row_bytes + (col0 + 8 * m) * 2;
-        *reinterpret_cast<f16x4*>(p) = h;
-        *reinterpret_cast<f16x4*>(p + pl) = lo;
+        if constexpr (BF) {
+            bf16x4c h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = (__bf16)v[4 * m + i];
+            *reinterpret_cast<bf16x4c*>(p) = h;
+        } else {
+            f16x4 h, lo;
+            split_f16x4(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3], h, lo);
+            *reinterpret_cast<f16x4*>(p) = h;
+            *reinterpret_cast<f16x4*>(p + pl) = lo;
+        }
     }
 }
 // a 192-vector in LDS -> the lane's 16 channels (col0 = 32 j + 4 lh)
@@ -211,9 +235,9 @@ struct ChainHdr {          // the leading kernel parameters (preloaded into SGPR
     int in_mod, n_uncond, wmax;
 };
 
-template <int MODE>
+template <int MODE, bool BF>
 __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& a, char* smem, int w, int l, int s_idx, int in_idx, int t0) {
-    constexpr int NR = (MODE == 2) ? CH_NR_HELPER : CH_NR_OWNER;
+    constexpr int NR = BF ? CH_NR_BF : ((MODE == 2) ? CH_NR_HELPER : CH_NR_OWNER);
     const int tid = threadIdx.x;
     const int lt = l & 31, lh = l >> 5;
     const int j = w;                       // column owner index (MODE 0 / 1)
@@ -233,7 +257,8 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
     // this wave's weight stream: column owners 168 units of 2 KB each, helper waves 72
     const int w_units = w < 4 ? U_END : (w < 6 ? U_W45 : U_W67);
     const int w_first = w < 4 ? w * U_END : (w < 6 ? 4 * U_END + (w - 4) * U_W45 : 4 * U_END + 2 * U_W45 + (w - 6) * U_W67);
-    const WStream wp = {make_rsrc(reinterpret_cast<const char*>(hd.wstream) + (long long)w_first * 2048, (unsigned)w_units * 2048u), l * 16};
+    constexpr int UB = BF ? 1024 : 2048;   // bytes of a unit
+    const WStream wp = {make_rsrc(reinterpret_cast<const char*>(hd.wstream) + (long long)w_first * UB, (unsigned)w_units * (unsigned)UB), l * 16};
     Ring<NR> R;
     clk_stamp_c(clk, w, l, 0);
 
@@ -287,7 +312,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             for (int i0 = KVL; i0 * 128 < kv_n; i0 += KVL) { kv_issue(i0); kv_park(i0); }
         }
         clk_stamp_c(clk, w, l, 2);
-        sfor<0, NR>([&](auto qc) { ring_issue<MODE, NR, decltype(qc)::value>(R, wp); });   // (not needed before GEGLU; behind the window tile, whose registers it reuses)
+        sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, NR, decltype(qc)::value>(R, wp); });   // (not needed before GEGLU; behind the window tile, whose registers it reuses)
         clk_stamp_c(clk, w, l, 3);
         if (!uncond) {   // LayerNorm2 partials, LayerNorm2(x1) planes, cross-attention output planes
             __syncthreads();
@@ -303,9 +328,17 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         // ---- requests: statistics, operands, then the weights (loads return in order; the ring is not needed before the operands are staged) ----
         // (first what the preloaded header alone addresses — the rest of the arguments is a scalar-memory round trip away)
         // attention output tile: thread <-> (channel-in-round tid / 8 (48 per round), token quad tid & 7), four rounds
+        // (BF: the operands are token-major bf16 already — rows t0 .. t0 + 31 of [sample][row][192] are copied as they are: 768 16-byte pieces per tile, two per thread;
+        //  rows past T are out of the buffer's range and read as zeros)
         f32x4 ov[4];
         const int cr = tid >> 3, tq = tid & 7;
-        {
+        const int prow0 = (tid * 2731) >> 16, ppc0 = tid - 24 * prow0;                      // BF: piece tid -> (row tid / 24, 16-byte piece of the row)
+        const int prow1 = ((tid + 384) * 2731) >> 16, ppc1 = (tid + 384) - 24 * prow1;
+        if constexpr (BF) {
+            const rsrc_t ro = make_rsrc(reinterpret_cast<const char*>(hd.o) + (long long)in_idx * hd.o_bs * 2, (unsigned)hd.T * 384u);
+            ov[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, (t0 + prow0) * 384 + ppc0 * 16, 0, 0));
+            ov[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, (t0 + prow1) * 384 + ppc1 * 16, 0, 0));
+        } else {
             const rsrc_t ro = make_rsrc(hd.o + (long long)in_idx * hd.o_bs, 192u * (unsigned)hd.pitch * 4u);
 #pragma unroll
             for (int rnd = 0; rnd < 4; ++rnd) ov[rnd] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, ((48 * rnd + cr) * hd.pitch + t0 + 4 * tq) * 4, 0, 0));
@@ -313,7 +346,11 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         // the block input's tile (the GroupNorm'ed residual of to_out1) the same way: four 16-byte loads per thread and an fp32 tile in LDS instead of sixteen
         // 4-byte loads per lane in accumulator layout (the CU's address path is the prologue's bottleneck: every load instruction costs it >= 13 clocks)
         f32x4 xv4[4];
-        {
+        if constexpr (BF) {
+            const rsrc_t rxin = make_rsrc(reinterpret_cast<const char*>(hd.xin) + (long long)in_idx * hd.x_bs * 2, (unsigned)hd.T * 384u);
+            xv4[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxin, (t0 + prow0) * 384 + ppc0 * 16, 0, 0));
+            xv4[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxin, (t0 + prow1) * 384 + ppc1 * 16, 0, 0));
+        } else {
             const rsrc_t rxin = make_rsrc(hd.xin + (long long)in_idx * hd.x_bs, 192u * (unsigned)hd.pitch * 4u);
 #pragma unroll
             for (int rnd = 0; rnd < 4; ++rnd) xv4[rnd] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxin, ((48 * rnd + cr) * hd.pitch + t0 + 4 * tq) * 4, 0, 0));
@@ -337,24 +374,31 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
                 reinterpret_cast<f32x4*>(vl)[i] = *reinterpret_cast<gf4_p>((unsigned long long)(vg + gi));
             }
         }
-        sfor<0, NR>([&](auto qc) { ring_issue<MODE, NR, decltype(qc)::value>(R, wp); });
+        sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, NR, decltype(qc)::value>(R, wp); });
         clk_stamp_c(clk, w, l, 12);
-        // attention output -> split planes (token-major)
-        {
-            _Float16* ph = reinterpret_cast<_Float16*>(smem + CH_R1);
+        if constexpr (BF) {   // both tiles as they are: bf16 rows of 384 bytes at the planes' 400-byte pitch
+            *reinterpret_cast<f32x4*>(smem + CH_R1 + prow0 * (CH_AP * 2) + ppc0 * 16) = ov[0];
+            *reinterpret_cast<f32x4*>(smem + CH_R1 + prow1 * (CH_AP * 2) + ppc1 * 16) = ov[1];
+            *reinterpret_cast<f32x4*>(smem + CH_R2 + prow0 * (CH_AP * 2) + ppc0 * 16) = xv4[0];
+            *reinterpret_cast<f32x4*>(smem + CH_R2 + prow1 * (CH_AP * 2) + ppc1 * 16) = xv4[1];
+        } else {
+            // attention output -> split planes (token-major)
+            {
+                _Float16* ph = reinterpret_cast<_Float16*>(smem + CH_R1);
 #pragma unroll
-            for (int rnd = 0; rnd < 4; ++rnd)
+                for (int rnd = 0; rnd < 4; ++rnd)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x = (t0 + 4 * tq + e < hd.T) ? ov[rnd][e] : 0.f;
-                    _Float16 hv = (_Float16)x;
-                    asm volatile("" : "+v"(hv));   // (one conversion: split_f16.h)
-                    ph[(4 * tq + e) * CH_AP + 48 * rnd + cr] = hv;
-                    ph[32 * CH_AP + (4 * tq + e) * CH_AP + 48 * rnd + cr] = (_Float16)((x - (float)hv) * 2048.f);
-                }
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = (t0 + 4 * tq + e < hd.T) ? ov[rnd][e] : 0.f;
+                        _Float16 hv = (_Float16)x;
+                        asm volatile("" : "+v"(hv));   // (one conversion: split_f16.h)
+                        ph[(4 * tq + e) * CH_AP + 48 * rnd + cr] = hv;
+                        ph[32 * CH_AP + (4 * tq + e) * CH_AP + 48 * rnd + cr] = (_Float16)((x - (float)hv) * 2048.f);
+                    }
+            }
         }
         clk_stamp_c(clk, w, l, 14);
-        {   // x_in tile [192][32] fp32 (tokens past T: 0)
+        if constexpr (!BF) {   // x_in tile [192][32] fp32 (tokens past T: 0)
             float* xl = reinterpret_cast<float*>(smem + CH_R2);
 #pragma unroll
             for (int rnd = 0; rnd < 4; ++rnd) {
@@ -370,7 +414,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         // ---- to_out1 + GroupNorm'ed residual (attention.py:127, 168, 226-227) ----
         f32x16 acc, accx;
         zero16(acc); zero16(accx);
-        gemm_run<MODE, NR, U_G1, 12>(R, wp, r1h + browA, CH_APL, acc, accx);
+        gemm_run<MODE, BF, NR, U_G1, 12>(R, wp, r1h + browA, CH_APL, acc, accx);
         clk_stamp_c(clk, w, l, 2);
         float x1[16];
         merge16(x1, acc, accx);
@@ -378,9 +422,18 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             float b1[16];
             get_vec(vec, col0, b1);
             float xr[16];
-            const float* xl = reinterpret_cast<const float*>(smem + CH_R2) + col0 * 32 + lt;
+            if constexpr (BF) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xr[r] = xl[((r & 3) + 8 * (r >> 2)) * 32];
+                for (int m = 0; m < 4; ++m) {
+                    const bf16x4c xb = *reinterpret_cast<const bf16x4c*>(r2h + wrowA + (col0 + 8 * m) * 2);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xr[4 * m + i] = (float)xb[i];
+                }
+            } else {
+                const float* xl = reinterpret_cast<const float*>(smem + CH_R2) + col0 * 32 + lt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xr[r] = xl[((r & 3) + 8 * (r >> 2)) * 32];
+            }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const f32x4 c0 = *reinterpret_cast<const f32x4*>(gnc + 2 * (col0 + 8 * m)), c1 = *reinterpret_cast<const f32x4*>(gnc + 2 * (col0 + 8 * m) + 4);
@@ -403,12 +456,12 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
                 float y[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) y[r] = (x1[r] - st.x) * st.y;
-                put_split(r2h, CH_APL, wrowA, col0, y);
+                put_split<BF>(r2h, CH_APL, wrowA, col0, y);
             }
             __syncthreads();
             clk_stamp_c(clk, w, l, 3);
             zero16(acc); zero16(accx);
-            gemm_run<MODE, NR, U_G2, 12>(R, wp, r2h + browA, CH_APL, acc, accx);
+            gemm_run<MODE, BF, NR, U_G2, 12>(R, wp, r2h + browA, CH_APL, acc, accx);
             float q[16];
             merge16(q, acc, accx);
             {
@@ -469,12 +522,12 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
                     }
                 }
             }
-            put_split(r1h, CH_APL, wrowA, col0, o2);
+            put_split<BF>(r1h, CH_APL, wrowA, col0, o2);
             __syncthreads();
             clk_stamp_c(clk, w, l, 5);
             // ---- to_out2 + x1 ----
             zero16(acc); zero16(accx);
-            gemm_run<MODE, NR, U_G3, 12>(R, wp, r1h + browA, CH_APL, acc, accx);
+            gemm_run<MODE, BF, NR, U_G3, 12>(R, wp, r1h + browA, CH_APL, acc, accx);
             merge16(x2, acc, accx);
             float bo[16];
             get_vec(vec + 2 * 192, col0, bo);
@@ -495,8 +548,8 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             float y[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) y[r] = (x2[r] - st3.x) * st3.y;
-            put_split(r1h, CH_APL, wrowA, col0, y);
-            put_split(r2h, CH_APL, wrowA, col0, x2);
+            put_split<BF>(r1h, CH_APL, wrowA, col0, y);
+            put_split<BF>(r2h, CH_APL, wrowA, col0, x2);
         }
         __syncthreads();
     }
@@ -513,17 +566,24 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             float hv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) hv[i] = (pv[4 * m + i] + bv[i]) * gelu_f(pg[4 * m + i] + bg[i]);
-            f16x4 h, lo;
-            split_f16x4(hv[0], hv[1], hv[2], hv[3], h, lo);
             char* pp = hh + wrowH + (32 * p + 4 * lh + 8 * m) * 2;
-            *reinterpret_cast<f16x4*>(pp) = h;
-            *reinterpret_cast<f16x4*>(pp + CH_HPL) = lo;
+            if constexpr (BF) {
+                bf16x4c h;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h[i] = (__bf16)hv[i];
+                *reinterpret_cast<bf16x4c*>(pp) = h;
+            } else {
+                f16x4 h, lo;
+                split_f16x4(hv[0], hv[1], hv[2], hv[3], h, lo);
+                *reinterpret_cast<f16x4*>(pp) = h;
+                *reinterpret_cast<f16x4*>(pp + CH_HPL) = lo;
+            }
         };
         sfor<0, 3>([&](auto pc) {
             constexpr int pi = decltype(pc)::value;
             f32x16 av, avx, ag, agx;
             zero16(av); zero16(avx); zero16(ag); zero16(agx);
-            geglu_run<MODE, NR, QG + 24 * pi>(R, wp, r1h + browA, CH_APL, av, avx, ag, agx, [&](auto sc) {
+            geglu_run<MODE, BF, NR, QG + 24 * pi>(R, wp, r1h + browA, CH_APL, av, avx, ag, agx, [&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 if constexpr (pi > 0 && s % 3 == 1) epi_piece(w + 8 * (pi - 1), s / 3);
             });
@@ -540,8 +600,8 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         constexpr int QH = U_FF - U_GE;
         f32x16 acc, accx;
         zero16(acc); zero16(accx);
-        gemm_run<MODE, NR, QH, 48 - U_HALF>(R, wp, hh + browH + 32 * U_HALF, CH_HPL, acc, accx);
-        gemm_run<MODE, NR, QH + 48 - U_HALF, 12>(R, wp, r2h + browA, CH_APL, acc, accx);
+        gemm_run<MODE, BF, NR, QH, 48 - U_HALF>(R, wp, hh + browH + 32 * U_HALF, CH_HPL, acc, accx);
+        gemm_run<MODE, BF, NR, QH + 48 - U_HALF, 12>(R, wp, r2h + browA, CH_APL, acc, accx);
         float* const fpart = reinterpret_cast<float*>(r1h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) fpart[((w - 6) * 16 + r) * 64 + l] = fmaf(accx[r], 0x1p-11f, acc[r]);
@@ -551,21 +611,31 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         // ---- (proj_out o ff.net.2) over [h ; x2] + x_in, result channel-major + GroupNorm partials of the tile ----
         constexpr int QF = (MODE == 0) ? U_FF : U_FF - (U_GE - U_G2);
         float xr[16];
-        const rsrc_t rxin = make_rsrc(hd.xin + (long long)in_idx * hd.x_bs, 192u * (unsigned)hd.pitch * 4u);
-        const int xvo = tv ? (col0 * hd.pitch + t) * 4 : (int)0x80000000;
+        const rsrc_t rxin = BF ? make_rsrc(reinterpret_cast<const char*>(hd.xin) + (long long)in_idx * hd.x_bs * 2, (unsigned)hd.T * 384u)
+                               : make_rsrc(hd.xin + (long long)in_idx * hd.x_bs, 192u * (unsigned)hd.pitch * 4u);
+        const int xvo = BF ? (t * 384 + col0 * 2) : (tv ? (col0 * hd.pitch + t) * 4 : (int)0x80000000);   // (BF: rows past T are out of the buffer's range)
+        if constexpr (BF) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xr[r] = bload(rxin, xvo, ((r & 3) + 8 * (r >> 2)) * hd.pitch * 4);
+            for (int m = 0; m < 4; ++m) {
+                const bf16x4c xb = __builtin_bit_cast(bf16x4c, __builtin_amdgcn_raw_buffer_load_b64(rxin, xvo + 16 * m, 0, 0));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xr[4 * m + i] = (float)xb[i];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xr[r] = bload(rxin, xvo, ((r & 3) + 8 * (r >> 2)) * hd.pitch * 4);
+        }
         f32x16 acc, accx;
         zero16(acc); zero16(accx);
         float y[16], bp[16];
         float* const fpart = reinterpret_cast<float*>(r1h);   // [2 helper waves][16][64]: their partial sums of column tiles 4, 5 (the LayerNorm3 planes are dead)
         if (w < 4) {
-            gemm_run<MODE, NR, QF, 48>(R, wp, hh + browH, CH_HPL, acc, accx);
-            gemm_run<MODE, NR, QF + 48, 12>(R, wp, r2h + browA, CH_APL, acc, accx);
+            gemm_run<MODE, BF, NR, QF, 48>(R, wp, hh + browH, CH_HPL, acc, accx);
+            gemm_run<MODE, BF, NR, QF + 48, 12>(R, wp, r2h + browA, CH_APL, acc, accx);
             merge16(y, acc, accx);
             __syncthreads();
         } else {
-            gemm_run<MODE, NR, QF, U_HALF>(R, wp, hh + browH, CH_HPL, acc, accx);
+            gemm_run<MODE, BF, NR, QF, U_HALF>(R, wp, hh + browH, CH_HPL, acc, accx);
             merge16(y, acc, accx);
             __syncthreads();
 #pragma unroll
@@ -573,15 +643,29 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         }
         clk_stamp_c(clk, w, l, 9);
         get_vec(vec + 3 * 192, col0, bp);
-        const rsrc_t ryo = make_rsrc(a.y + (long long)s_idx * a.y_bs, 192u * (unsigned)hd.pitch * 4u);
+        const rsrc_t ryo = BF ? make_rsrc(reinterpret_cast<char*>(a.y) + (long long)s_idx * a.y_bs * 2, (unsigned)hd.T * 384u)
+                              : make_rsrc(a.y + (long long)s_idx * a.y_bs, 192u * (unsigned)hd.pitch * 4u);
         float* const so = a.stats_out ? a.stats_out + (long long)s_idx * a.stats_bs + ((long long)(t0 >> 5) * 192) * 2 : nullptr;
         const float cnt = (float)min(32, hd.T - t0);
         const float rcnt = __builtin_amdgcn_rcpf(cnt);
         float mean[16], m2[16];
+        if constexpr (BF) {   // token-major bf16 result [sample][row][192]; the statistics are those of the STORED (rounded) values
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            y[r] += bp[r] + xr[r];
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, y[r]), ryo, xvo, ((r & 3) + 8 * (r >> 2)) * hd.pitch * 4, 0);   // (xvo is out of range past T: dropped)
+            for (int m = 0; m < 4; ++m) {
+                bf16x4c yb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    yb[i] = (__bf16)(y[4 * m + i] + bp[4 * m + i] + xr[4 * m + i]);
+                    y[4 * m + i] = (float)yb[i];
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2c, yb), ryo, xvo + 16 * m, 0, 0);   // (rows past T: out of range, dropped)
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                y[r] += bp[r] + xr[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, y[r]), ryo, xvo, ((r & 3) + 8 * (r >> 2)) * hd.pitch * 4, 0);   // (xvo is out of range past T: dropped)
+            }
         }
         if (so) {   // (all sixteen means, then all sixteen M2s: independent reductions the hardware can overlap)
 #pragma unroll
@@ -600,6 +684,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
     clk_stamp_c(clk, w, l, 10);
 }
 
+template <bool BF>
 __global__ __launch_bounds__(512, 1) void stchain_kernel(const float* h_w, const float* h_o, const float* h_x, const int* h_lo, int h_T, int h_pitch, int h_obs, int h_xbs, int h_inmod,
                                                          int h_nunc_wmax, const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char csmem[];
@@ -610,9 +695,9 @@ __global__ __launch_bounds__(512, 1) void stchain_kernel(const float* h_w, const
     const bool uncond = s_idx < hd.n_uncond;
     const int in_idx = hd.in_mod > 0 ? s_idx % hd.in_mod : s_idx;
     // three self-contained roles (each with its own prologue: nothing but scalars is live across this branch, so each gets its own register allocation)
-    if (w >= 6) chain_body<2>(hd, a, csmem, w, l, s_idx, in_idx, t0);
-    else if (uncond) chain_body<1>(hd, a, csmem, w, l, s_idx, in_idx, t0);
-    else chain_body<0>(hd, a, csmem, w, l, s_idx, in_idx, t0);
+    if (w >= 6) chain_body<2, BF>(hd, a, csmem, w, l, s_idx, in_idx, t0);
+    else if (uncond) chain_body<1, BF>(hd, a, csmem, w, l, s_idx, in_idx, t0);
+    else chain_body<0, BF>(hd, a, csmem, w, l, s_idx, in_idx, t0);
 }
 
 bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long long x_bs) {
@@ -623,13 +708,15 @@ bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long
     return true;
 }
 
-void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s) {
+void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s, bool bf16) {
     if (!stchain_supports(a, T, pitch, o_bs, x_bs)) { launch_fault("stchain: unsupported arguments (T %d, window %d)", T, a.wmax); return; }
     dim3 grid((T + 31) / 32, nsamp);
-    hipLaunchKernelGGL(stchain_kernel, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+    if (bf16) hipLaunchKernelGGL(stchain_kernel<true>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+    else hipLaunchKernelGGL(stchain_kernel<false>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
 }
 void configure_stchain_kernel() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
 }
 
 }  // namespace said

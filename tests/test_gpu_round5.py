@@ -234,7 +234,7 @@ def test_out_sched_tm_against_the_standalone_scheduler_on_its_own_hidden_state(m
                                     guidance_rescale=0.0, latent_scale=1.0, step_noise=sn, **kw)[1]
         got = run().cpu()
         nodes = eng.graph_num_nodes()
-        assert nodes >= 40, "the large-batch bf16 schedule (out_sched_tm is its last node)"
+        assert 24 <= nodes <= 48, "the large-batch bf16 schedule (out_sched_tm is its last node)"
         eng.debug_stop_after(nodes - 1)
         try:
             run()
