@@ -91,7 +91,7 @@ __device__ __forceinline__ void clk_stamp_c(long long* clk, int w, int lane, int
     (void)clk; (void)w; (void)lane; (void)slot;
     return;
 #endif
-    if (clk && blockIdx.x == 8 && blockIdx.y == gridDim.y - 1) {
+    if (clk && blockIdx.x + 8 == gridDim.x) {
         unsigned long long t;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
         if (lane == 0) clk[w * 16 + slot] = (long long)t;
@@ -686,12 +686,23 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
 
 template <bool BF>
 __global__ __launch_bounds__(512, 1) void stchain_kernel(const float* h_w, const float* h_o, const float* h_x, const int* h_lo, int h_T, int h_pitch, int h_obs, int h_xbs, int h_inmod,
-                                                         int h_nunc_wmax, const ChainArgs a) {
+                                                         int h_nunc_wmax, const ChainArgs a, int nsamp) {
     extern __shared__ __attribute__((aligned(16))) char csmem[];
-    const ChainHdr hd = {h_w, h_o, h_x, h_lo, h_T, h_pitch, h_obs, h_xbs, h_inmod, h_nunc_wmax & 0xffffff, (int)((unsigned)h_nunc_wmax >> 24)};
+    const ChainHdr hd = {h_w, h_o, h_x, h_lo, h_T, h_pitch, h_obs, h_xbs, h_inmod & 0xffffff, h_nunc_wmax & 0xffffff, (int)((unsigned)h_nunc_wmax >> 24)};
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int s_idx = blockIdx.y, t0 = blockIdx.x * 32;
+    // Small launches (a few dozen workgroups) are confined to NX of the eight XCDs: workgroups are dealt to the XCDs round-robin by linear id, and every XCD whose L2 serves a
+    // workgroup fetches the block's whole 2.36 MB weight stream from memory (each L2 is cold at launch) — eight copies for 38 workgroups.  The grid is padded to 8 / NX times
+    // the work and the workgroups that land on the other XCDs leave at once.  (1-D grid: x = sample * tiles + tile, padded.)
+    const int nx = (int)((unsigned)h_inmod >> 24), ntt = (h_T + 31) >> 5;
+    int widx = (int)blockIdx.x;
+    if (nx < 8) {
+        const int xcd = widx & 7;
+        if (xcd >= nx) return;
+        widx = (widx >> 3) * nx + xcd;
+    }
+    if (widx >= ntt * nsamp) return;
+    const int s_idx = widx / ntt, t0 = (widx - s_idx * ntt) * 32;
     const bool uncond = s_idx < hd.n_uncond;
     const int in_idx = hd.in_mod > 0 ? s_idx % hd.in_mod : s_idx;
     // three self-contained roles (each with its own prologue: nothing but scalars is live across this branch, so each gets its own register allocation)
@@ -708,11 +719,21 @@ bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long
     return true;
 }
 
-void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s, bool bf16) {
+void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s, bool bf16,
+                    int xcds) {
     if (!stchain_supports(a, T, pitch, o_bs, x_bs)) { launch_fault("stchain: unsupported arguments (T %d, window %d)", T, a.wmax); return; }
-    dim3 grid((T + 31) / 32, nsamp);
-    if (bf16) hipLaunchKernelGGL(stchain_kernel<true>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
-    else hipLaunchKernelGGL(stchain_kernel<false>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+    const int n = ((T + 31) / 32) * nsamp;
+    // XCDs to use: as few as hold the launch at one workgroup per CU (32 CUs per XCD), unless told otherwise
+    int nx = xcds > 0 ? xcds : 8;
+    if (xcds <= 0) for (int k = 1; k <= 8; k *= 2) if (n <= 32 * k) { nx = k; break; }
+    if (nx > 8 || (nx & (nx - 1))) nx = 8;
+    const int gx = nx == 8 ? n : ((n + nx - 1) / nx) * 8;
+    dim3 grid(gx, 1);
+    // (gridDim.y carries the sample count for the index decode; the grid itself is one-dimensional)
+    grid.y = 1;
+    const int inmod_nx = (in_mod & 0xffffff) | (nx << 24);
+    if (bf16) hipLaunchKernelGGL(stchain_kernel<true>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, inmod_nx, n_uncond | (a.wmax << 24), a, nsamp);
+    else hipLaunchKernelGGL(stchain_kernel<false>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, inmod_nx, n_uncond | (a.wmax << 24), a, nsamp);
 }
 void configure_stchain_kernel() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
