@@ -115,7 +115,7 @@ struct said_ctx {
     long long st_chain_max_tiles = 1LL << 40;   // ... while the launch is at most this many workgroups (sample x 32-token tiles; said_debug_option "st_chain_max_tiles")
     int st_chain_bf16 = -1;      // bf16 mode, large batches: the same fused tail on bf16 operands (stchain_kernel<true>) instead of rgemm's five launches; 0: off
                                  // (said_debug_option "st_chain_bf16")
-    int st_chain_xcds = 0;       // XCDs a fused-tail launch is confined to (0: as few as hold it at one workgroup per CU; 8: all — said_debug_option "st_chain_xcds")
+    int st_chain_xcds = 0;       // XCDs a fused-tail launch is confined to (0 / 8: all; 1, 2, 4: measured slower — said_debug_option "st_chain_xcds")
     bool st_chain_dbg = false;   // debug: the fused kernel also writes x1 / x2 to X1 / X2
     int st_chain = -1;           // fp32 mode, small batches: everything behind self-attention as ONE launch per block (stchain.hip); 0: the five launches
                                  // (said_debug_option "st_chain")

@@ -723,9 +723,9 @@ void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T,
                     int xcds) {
     if (!stchain_supports(a, T, pitch, o_bs, x_bs)) { launch_fault("stchain: unsupported arguments (T %d, window %d)", T, a.wmax); return; }
     const int n = ((T + 31) / 32) * nsamp;
-    // XCDs to use: as few as hold the launch at one workgroup per CU (32 CUs per XCD), unless told otherwise
+    // XCDs to use: all eight unless told otherwise.  Measured (profiles/r05i_stchain_xcds_ab.txt): confining a small launch to fewer XCDs shares one L2's copy of the
+    // weight stream among more workgroups but is SLOWER (headline, 38 workgroups per launch: 1955 frames/s on 8 XCDs, 1944 on 4, 1910 on 2; cfg4, 114 workgroups: 23.85k on 8, 23.5k on 4) — the L2->CU fabric of one XCD, not HBM, is the limit.
     int nx = xcds > 0 ? xcds : 8;
-    if (xcds <= 0) for (int k = 1; k <= 8; k *= 2) if (n <= 32 * k) { nx = k; break; }
     if (nx > 8 || (nx & (nx - 1))) nx = 8;
     const int gx = nx == 8 ? n : ((n + nx - 1) / nx) * 8;
     dim3 grid(gx, 1);
