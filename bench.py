@@ -56,6 +56,8 @@ def parse():
                         "concurrent clip groups (1: never split)")
     p.add_argument("--debug_option", action="append", default=[], metavar="NAME=VALUE",
                    help="development: said_debug_option(NAME, VALUE) on the engine before the first run (scripts/ A/B drivers)")
+    p.add_argument("--ab_lib", default=None, metavar="PATH",
+                   help="development: load this build of the library (scripts/build_variant.sh) instead of said_amd/lib/libsaid_hip.so; named in the JSON line")
     p.add_argument("--tm_acts", type=int, nargs="?", const=1, default=-1, choices=[-1, 0, 1],
                    help="large-batch schedule with token-major activations between the UNet kernels and the normalisations inside the consuming "
                         "GEMMs (41 launches per step): -1 (default) = on in bf16 mode, off in fp32 mode; 0 / 1 force it (said_debug_option tm_acts)")
@@ -485,6 +487,9 @@ def run(args):
     # barriers, max-reduce of the time) execute on RCCL on a single-GPU box as well
     dist = shard.init_process_group("nccl", rank, world, dev) if (world > 1 or args.rccl_at_one) else None
 
+    if args.ab_lib:
+        from said_amd import _engine
+        _engine._LIB_PATH = os.path.abspath(args.ab_lib)
     from said_amd.model.diffusion import SAID_UNet1D
     from said_amd.util import synth
     model = SAID_UNet1D()
@@ -529,6 +534,8 @@ def run(args):
                        "clip_ranges": r.clip_ranges, "gathered_checksum": r.checksum,
                        "graph_nodes_per_step": model._eng.graph_num_nodes()},
         }
+        if args.ab_lib or args.debug_option:
+            out["development_build"] = {"ab_lib": args.ab_lib, "debug_option": args.debug_option}   # not the shipped defaults: an A/B run
         if not args.no_roofline:
             step_ms = loop_step_ms(model, proc, lat0, edit_kw, T, args.num_steps, args.guidance_scale, args.eta)
             headline = (B == 1 and args.seconds == 10.0 and args.num_steps == 1000 and args.dtype == "f32" and not args.edit and args.eta == 0.0)

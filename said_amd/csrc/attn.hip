@@ -66,6 +66,9 @@ template <int ND, int KS, int PM, int QW = 1>
 __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, const float* pv, float* po, int v_bstride, int o_bstride, int ppitch,
                                                        int pT, int pheads, int prows, float pscale, int pb0, int po_mode) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef SAID_AB_FLOOR
+    if (pT > 0) return;
+#endif
     const AttnView a = {pqk, pv, po, v_bstride, o_bstride, ppitch, pT, pheads, prows, pscale, pb0, po_mode};
     constexpr int D = 32 * ND, NQ = D / 8;   // NQ dwordx4 per lane and operand row
     constexpr bool BF = PM == 1, SP = PM == 2;

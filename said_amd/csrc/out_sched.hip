@@ -14,6 +14,9 @@
 // keeps the unfused path (conv -> partial statistics -> sched_step_kernel).
 #include "gemm_common.h"
 #include "sched_math.h"
+#ifndef OS_AB
+#define OS_AB 0
+#endif
 
 namespace said {
 
@@ -29,6 +32,9 @@ template <bool CFG>
 __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NH = CFG ? 2 : 1;
+#if OS_AB == 1
+    if (a.T > 0) return;
+#endif
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t0 = blockIdx.x * 32, b = blockIdx.y;
@@ -50,7 +56,9 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
     for (int h = 0; h < NH; ++h) {
         const int sb = b + h * a.B;   // unconditional half first (diffusion.py:397-400)
         rp[h] = make_rsrc(a.gn_part + (long long)sb * a.gn_part_bstride, (unsigned)OS_C * (unsigned)a.gn_nparts * 8u);
+#if OS_AB != 3
         gn_issue(gp, rp[h], w * OS_CW, OS_CW, l, gl[h]);
+#endif
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -69,7 +77,11 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) wv[tap][rr] = bload4(rw, l * 16, (tap * (OS_C / 8) + 3 * w + rr) * 1024);
     // epilogue operands of this wave's two output rows (channels n0, n1 of token t0 + lt)
+#if OS_AB == 2
+    const int step = 0;
+#else
     const int step = *a.step_ptr;
+#endif
     const float* cf = a.coef + step * 8;
     float cfv[8];
 #pragma unroll
@@ -89,7 +101,11 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
         const int r = w + j * OS_KS;
         const int n = (r & 3) + 8 * (r >> 2) + 4 * lh;
         e_n[j] = n;
+#if OS_AB == 2
+        const int vo = (int)0x80000000;
+#else
         const int vo = (tok && n < a.Cout) ? (n * a.pitch + t) * 4 : (int)0x80000000;
+#endif
         e_x[j] = bload(rlat, vo, 0);
         e_nz[j] = bload(rnz, vo, 0);
         e_in[j] = bload(rin, vo, 0);
@@ -100,7 +116,11 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
 
     // ---- GroupNorm coefficients of the wave's own 24 channels, per half ----
 #pragma unroll
+#if OS_AB == 3
+    for (int h = 0; h < NH; ++h) if (l < OS_CW) { coefS[h * 2 * OS_C + 2 * (w * OS_CW + l)] = 1.f; coefS[h * 2 * OS_C + 2 * (w * OS_CW + l) + 1] = 0.f; }
+#else
     for (int h = 0; h < NH; ++h) gn_finish(gp, rp[h], w * OS_CW, OS_CW, l, gl[h], gnS, coefS + h * 2 * OS_C);
+#endif
 
     // ---- stage: GroupNorm + SiLU once per element, wave-private LDS tiles ----
 #pragma unroll
@@ -133,6 +153,9 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
     const float* xrow = xt + lh * OS_XP + lt + 3;
+#if OS_AB == 4
+    acc[0][0] = xrow[0] * wv[0][0][0]; if (NH > 1) acc[NH - 1][1] = xrow[1] * wv[2][2][3];
+#else
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
@@ -144,6 +167,7 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
                     const float xf = xrow[h * (OS_CW * OS_XP) + (rr * 8 + 2 * j) * OS_XP + tap];
                     acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[tap][rr][j], xf, acc[h], 0, 0, 0);
                 }
+#endif
 
     // ---- split-K reduction (fixed order) ----
     __syncthreads();

@@ -688,6 +688,9 @@ template <bool BF>
 __global__ __launch_bounds__(512, 1) void stchain_kernel(const float* h_w, const float* h_o, const float* h_x, const int* h_lo, int h_T, int h_pitch, int h_obs, int h_xbs, int h_inmod,
                                                          int h_nunc_wmax, const ChainArgs a, int nsamp) {
     extern __shared__ __attribute__((aligned(16))) char csmem[];
+#ifdef SAID_AB_FLOOR
+    if (h_T > 0) return;
+#endif
     const ChainHdr hd = {h_w, h_o, h_x, h_lo, h_T, h_pitch, h_obs, h_xbs, h_inmod & 0xffffff, h_nunc_wmax & 0xffffff, (int)((unsigned)h_nunc_wmax >> 24)};
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
