@@ -535,7 +535,7 @@ def run(args):
                        "graph_nodes_per_step": model._eng.graph_num_nodes()},
         }
         if args.ab_lib or args.debug_option:
-            out["development_build"] = {"ab_lib": args.ab_lib, "debug_option": args.debug_option}   # not the shipped defaults: an A/B run
+            line["development_build"] = {"ab_lib": args.ab_lib, "debug_option": args.debug_option}   # not the shipped defaults: an A/B run
         if not args.no_roofline:
             step_ms = loop_step_ms(model, proc, lat0, edit_kw, T, args.num_steps, args.guidance_scale, args.eta)
             headline = (B == 1 and args.seconds == 10.0 and args.num_steps == 1000 and args.dtype == "f32" and not args.edit and args.eta == 0.0)
