@@ -79,7 +79,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
             # leading scalar kernel parameters arrive in SGPRs (14 is what the hardware has room for): see gemm_lds.hip, attn.hip
-            extra = ["-mllvm", "-amdgpu-kernarg-preload-count=14"] if (src in ("gemm_lds.hip", "attn.hip", "conv_in.hip", "stchain.hip") and not os.environ.get("SAID_NO_PRELOAD")) else []
+            extra = ["-mllvm", "-amdgpu-kernarg-preload-count=14"] if (src in ("gemm_lds.hip", "attn.hip", "conv_in.hip", "stchain.hip", "out_sched.hip") and not os.environ.get("SAID_NO_PRELOAD")) else []
             extra += os.environ.get("SAID_EXTRA_DEFS", "").split()   # development: -D switches for A/B builds (scripts/gpu_ab_build.sh)
             if src in NO_SLP and not os.environ.get("SAID_KEEP_SLP"):
                 extra += ["-fno-slp-vectorize"]

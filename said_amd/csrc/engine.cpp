@@ -181,6 +181,7 @@ struct said_ctx {
                               // round 5 found the mechanism in OTHER kernels' packed-fp32 instructions (split_f16.h, build.py NO_SLP) and removed it.
     int gemm_split = -1;      // fp32 mode: the large-batch token-major GEMMs (fgemm_kernel) on split-fp16 operands (tgemm.hip: SP).  Default (-1) and 1: ON since round 5
                               // (as above); 0: fp32 MFMAs (said_debug_option "gemm_split").
+    int out_split = -1;       // out_sched_kernel's convolution on split-fp16 operands (-1 / 1: on; 0: fp32 matrix instructions — said_debug_option "out_split")
     int ugemm_split = -1;     // fp32 mode: the small-batch channel-major GEMMs (ugemm_kernel) on split-fp16 operands too (gemm_lds.hip: SP; weights pre-split on the host:
                               // Seg::ws).  Default (-1) and 1: ON; 0: fp32 MFMAs (said_debug_option "ugemm_split")
     int pw_split = 0;         // make_pw: also build the split-fp16 packing (1: per-block layout, 2: flat) — set around the UNet weights only
@@ -1968,7 +1969,9 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
     if (make_pw(ctx, &ctx->te1, D + "time_embed.0.weight", D + "time_embed.0.bias", TE, MC, 0)) return -1;
     if (make_pw(ctx, &ctx->te2, D + "time_embed.2.weight", D + "time_embed.2.bias", TE, TE, 0)) return -1;
     if (make_pw(ctx, &ctx->conv_in, D + "input_blocks.0.0.weight", D + "input_blocks.0.0.bias", MC, ctx->cin, 3)) return -1;
+    ctx->pw_split = 1;   // (out_sched_kernel's split-fp16 products)
     if (make_pw(ctx, &ctx->conv_out, D + "out.2.weight", D + "out.2.bias", ctx->cin, MC, 3, 1, D + "out.0.weight", D + "out.0.bias")) return -1;
+    ctx->pw_split = 0;
     if (upload_bf16(ctx, &ctx->bw_out, ctx->host_w[D + "out.2.weight"].data.data(), (size_t)ctx->cin, MC, 3)) return -1;
     if (upvec(ctx, &ctx->out_g, D + "out.0.weight", MC) || upvec(ctx, &ctx->out_b, D + "out.0.bias", MC)) return -1;
     used += 8;
@@ -2412,7 +2415,7 @@ static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, boo
     OutSchedArgs osa;
     memset(&osa, 0, sizeof osa);
     osa.x = ctx->P.p; osa.gn_part = ctx->P.st; osa.gn_gamma = ctx->out_g; osa.gn_beta = ctx->out_b;
-    osa.w4 = ctx->conv_out.w4[0]; osa.bias = ctx->conv_out.bias; osa.coef = ctx->coef_dev; osa.step_ptr = ctx->step_dev;
+    osa.w4 = ctx->conv_out.w4[0]; osa.ws = ctx->out_split != 0 ? ctx->conv_out.ws[0] : nullptr; osa.bias = ctx->conv_out.bias; osa.coef = ctx->coef_dev; osa.step_ptr = ctx->step_dev;
     osa.lat = ctx->x_cm; osa.step_noise = sa.step_noise; osa.noise_seed = sa.noise_seed; osa.noise_elem0 = sa.noise_elem0; osa.init = sa.init; osa.edit_noise = sa.edit_noise; osa.mask = sa.mask;
     osa.inter = sa.inter; osa.x_bstride = g.hs; osa.gn_part_bstride = g.sts; osa.lat_bstride = xs;
     osa.pitch = g.Tp; osa.T = T; osa.B = B; osa.Cin = MC; osa.Cout = C; osa.gn_nparts = g.np; osa.cfg = cfg ? 1 : 0;
@@ -2606,6 +2609,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->gemm_split = value < 0 ? -1 : (value != 0);
     } else if (k == "attn_split") {
         ctx->attn_split = value < 0 ? -1 : (value != 0);
+    } else if (k == "out_split") {
+        ctx->out_split = value < 0 ? -1 : (value != 0);
     } else if (k == "ugemm_split") {
         ctx->ugemm_split = value < 0 ? -1 : (value != 0);
     } else if (k == "st_chain") {

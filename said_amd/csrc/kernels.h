@@ -225,7 +225,8 @@ struct OutSchedArgs {
     const float* gn_part;      // its GroupNorm partials [Be][192][gn_nparts][2]
     const float* gn_gamma;     // out.0
     const float* gn_beta;
-    const float* w4;           // out.2 weights, dwordx4 packing [1][3][24][64][4]
+    const float* w4;           // out.2 weights, dwordx4 packing [1][3][24][64][4] (+ out.0's gamma[192], beta[192] behind)
+    const float* ws;           // the same in the split-fp16 packing (Seg::ws layout, one tile; same tail), or null: fp32 matrix instructions
     const float* bias;
     const float* coef;         // device [nsteps][8] scheduler coefficients
     const int* step_ptr;       // device step counter

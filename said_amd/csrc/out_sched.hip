@@ -14,9 +14,6 @@
 // keeps the unfused path (conv -> partial statistics -> sched_step_kernel).
 #include "gemm_common.h"
 #include "sched_math.h"
-#ifndef OS_AB
-#define OS_AB 0
-#endif
 
 namespace said {
 
@@ -28,60 +25,63 @@ static __device__ __forceinline__ f32x4 bload4(rsrc_t r, int voff, int soff) {
 constexpr int OS_KS = 8, OS_C = 192, OS_CW = OS_C / OS_KS, OS_XP = 40;
 static_assert(OS_CW == 24, "one 24-channel block per wave");
 
-template <bool CFG>
-__global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArgs a) {
+// SP (round 5, the default): the convolution on split-fp16 operands (split_f16.h; gemm_lds.hip SP): the wave-private tile is token-major, two fp16 planes [34 rows][24 channels],
+// the weights out.2 in engine.cpp's pack_rows_split layout (a.ws: [8 blocks][5 k16 steps][2 planes][64 lanes][8 halfs], GroupNorm affine behind) — 30 v_mfma_f32_32x32x16_f16
+// of 8 passes per wave instead of 72 v_mfma_f32_32x32x2_f32 of 16 (two waves share a SIMD's matrix pipe: 4.6 of the kernel's 12.8 us were this loop).
+// The leading parameters are what the first requests need (preloaded into SGPRs: build.py): with everything inside the by-value struct the kernel began with a scalar-memory round trip.
+template <bool CFG, bool SP>
+__global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const float* hx, const float* hpart, const float* hw, const int* hstep, int hT_pitch, int hxbs, int hpbs, int hB_np,
+                                                               const OutSchedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NH = CFG ? 2 : 1;
-#if OS_AB == 1
-    if (a.T > 0) return;
-#endif
+    constexpr int SPR = 34, SPP = 24;                       // SP tile: token rows (32 + 2 halo), halfs per row
+    constexpr int TILE_F = SP ? (2 * SPR * SPP) / 2 : OS_CW * OS_XP;   // floats of one half's staging tile
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t0 = blockIdx.x * 32, b = blockIdx.y;
-    const int T = a.T, pitch4 = a.pitch * 4;
+    const int T = hT_pitch & 0xffff, pitch = (int)((unsigned)hT_pitch >> 16), pitch4 = pitch * 4;
+    const int nB = hB_np & 0xffff, nparts = (int)((unsigned)hB_np >> 16);
     const int sr = l >> 3, sq = l & 7;
     float* coefS = smem;                                   // [NH][2 * 192] GroupNorm (a, b) per channel
     float* gnS = coefS + NH * 2 * OS_C + w * GN_SCRATCH;   // per-wave GroupNorm scratch
     float* mainS = coefS + NH * 2 * OS_C + OS_KS * GN_SCRATCH;
-    float* xt = mainS + w * (NH * OS_CW * OS_XP);          // this wave's X tiles [NH][24][XP]
+    float* xt = mainS + w * (NH * TILE_F);                 // this wave's X tiles [NH][24][XP] (SP: [NH][2 planes][34][24] halfs)
     float* red = mainS;                                    // [KS][NH][16][64] after the MFMA loop
 
     // ---- requests: statistics partials first (head of the dependent chain), then operands, weights last ----
-    const GnP gp = {OS_C / 32, a.gn_nparts, T, 1e-5f, a.gn_gamma, a.gn_beta, OS_C};
+    constexpr unsigned W_DW = SP ? 8u * 5u * 2u * 256u : 3u * (OS_C / 8) * 256u;   // dwords of the packed weights; gamma[192], beta[192] follow
+    const GnP gp = {OS_C / 32, nparts, T, 1e-5f, hw + W_DW, hw + W_DW + OS_C, OS_C};
     GnLoads gl[NH];
     rsrc_t rp[NH], rx[NH];
     f32x4 xv[NH][3];
     float halo[NH];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-        const int sb = b + h * a.B;   // unconditional half first (diffusion.py:397-400)
-        rp[h] = make_rsrc(a.gn_part + (long long)sb * a.gn_part_bstride, (unsigned)OS_C * (unsigned)a.gn_nparts * 8u);
-#if OS_AB != 3
+        const int sb = b + h * nB;   // unconditional half first (diffusion.py:397-400)
+        rp[h] = make_rsrc(hpart + (long long)sb * hpbs, (unsigned)OS_C * (unsigned)nparts * 8u);
         gn_issue(gp, rp[h], w * OS_CW, OS_CW, l, gl[h]);
-#endif
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-        const int sb = b + h * a.B;
-        rx[h] = make_rsrc(a.x + (long long)sb * a.x_bstride, (unsigned)OS_C * (unsigned)a.pitch * 4u);
+        const int sb = b + h * nB;
+        rx[h] = make_rsrc(hx + (long long)sb * hxbs, (unsigned)OS_C * (unsigned)pitch * 4u);
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) xv[h][rr] = bload4(rx[h], sr * pitch4 + (t0 + 4 * sq) * 4, (w * OS_CW + rr * 8) * pitch4);
         const int row = l >> 1, tin = (l & 1) ? (t0 + 32) : (t0 - 1);
         const bool ok = (row < OS_CW) && ((unsigned)tin < (unsigned)T);
         halo[h] = bload(rx[h], ok ? (row * pitch4 + tin * 4) : (int)0x80000000, (w * OS_CW) * pitch4);
     }
-    const rsrc_t rw = make_rsrc(a.w4, 3u * (OS_C / 8) * 1024u);
-    f32x4 wv[3][3];
+    const rsrc_t rw = make_rsrc(hw, W_DW * 4u);
+    constexpr int WD0 = SP ? 5 : 3, WD1 = SP ? 2 : 3;      // SP: [k16 step][plane], else [tap][8-channel round]
+    f32x4 wv[WD0][WD1];
 #pragma unroll
-    for (int tap = 0; tap < 3; ++tap)
+    for (int i0 = 0; i0 < WD0; ++i0)
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr) wv[tap][rr] = bload4(rw, l * 16, (tap * (OS_C / 8) + 3 * w + rr) * 1024);
+        for (int i1 = 0; i1 < WD1; ++i1)
+            wv[i0][i1] = SP ? bload4(rw, l * 16, ((w * 5 + i0) * 2 + i1) * 1024) : bload4(rw, l * 16, (i0 * (OS_C / 8) + 3 * w + i1) * 1024);
     // epilogue operands of this wave's two output rows (channels n0, n1 of token t0 + lt)
-#if OS_AB == 2
-    const int step = 0;
-#else
-    const int step = *a.step_ptr;
-#endif
+    const int step = *hstep;
     const float* cf = a.coef + step * 8;
     float cfv[8];
 #pragma unroll
@@ -101,11 +101,7 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
         const int r = w + j * OS_KS;
         const int n = (r & 3) + 8 * (r >> 2) + 4 * lh;
         e_n[j] = n;
-#if OS_AB == 2
-        const int vo = (int)0x80000000;
-#else
         const int vo = (tok && n < a.Cout) ? (n * a.pitch + t) * 4 : (int)0x80000000;
-#endif
         e_x[j] = bload(rlat, vo, 0);
         e_nz[j] = bload(rnz, vo, 0);
         e_in[j] = bload(rin, vo, 0);
@@ -116,16 +112,13 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
 
     // ---- GroupNorm coefficients of the wave's own 24 channels, per half ----
 #pragma unroll
-#if OS_AB == 3
-    for (int h = 0; h < NH; ++h) if (l < OS_CW) { coefS[h * 2 * OS_C + 2 * (w * OS_CW + l)] = 1.f; coefS[h * 2 * OS_C + 2 * (w * OS_CW + l) + 1] = 0.f; }
-#else
     for (int h = 0; h < NH; ++h) gn_finish(gp, rp[h], w * OS_CW, OS_CW, l, gl[h], gnS, coefS + h * 2 * OS_C);
-#endif
 
     // ---- stage: GroupNorm + SiLU once per element, wave-private LDS tiles ----
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-        float* xth = xt + h * (OS_CW * OS_XP);
+        float* xth = xt + h * TILE_F;
+        _Float16* xhh = reinterpret_cast<_Float16*>(xth);
         const float2* cG = reinterpret_cast<const float2*>(coefS + h * 2 * OS_C);
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) {
@@ -136,13 +129,31 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
                 const float v = silu_f(fmaf(xv[h][rr][e], g.x, g.y));
                 o[e] = (t0 + 4 * sq + e < T) ? v : 0.f;
             }
-            *reinterpret_cast<f32x4*>(xth + (rr * 8 + sr) * OS_XP + 4 + 4 * sq) = o;
+            if constexpr (SP) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 hv = (_Float16)o[e];
+                    asm volatile("" : "+v"(hv));   // (one conversion for the stored half and the remainder: split_f16.h)
+                    xhh[(1 + 4 * sq + e) * SPP + rr * 8 + sr] = hv;
+                    xhh[(SPR + 1 + 4 * sq + e) * SPP + rr * 8 + sr] = (_Float16)((o[e] - (float)hv) * 2048.f);
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(xth + (rr * 8 + sr) * OS_XP + 4 + 4 * sq) = o;
+            }
         }
         const int row = l >> 1, tin = (l & 1) ? (t0 + 32) : (t0 - 1);
         if (row < OS_CW) {
             const float2 g = cG[w * OS_CW + row];
             const float v = silu_f(fmaf(halo[h], g.x, g.y));
-            xth[row * OS_XP + ((l & 1) ? 36 : 3)] = ((unsigned)tin < (unsigned)T) ? v : 0.f;
+            const float hv = ((unsigned)tin < (unsigned)T) ? v : 0.f;
+            if constexpr (SP) {
+                _Float16 hh = (_Float16)hv;
+                asm volatile("" : "+v"(hh));
+                xhh[((l & 1) ? 33 : 0) * SPP + row] = hh;
+                xhh[(SPR + ((l & 1) ? 33 : 0)) * SPP + row] = (_Float16)((hv - (float)hh) * 2048.f);
+            } else {
+                xth[row * OS_XP + ((l & 1) ? 36 : 3)] = hv;
+            }
         }
     }
 
@@ -152,22 +163,45 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
     for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
-    const float* xrow = xt + lh * OS_XP + lt + 3;
-#if OS_AB == 4
-    acc[0][0] = xrow[0] * wv[0][0][0]; if (NH > 1) acc[NH - 1][1] = xrow[1] * wv[2][2][3];
-#else
+    if constexpr (SP) {
+        f32x16 accx[NH];
 #pragma unroll
-    for (int tap = 0; tap < 3; ++tap)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int rr = 0; rr < 3; ++rr)
+            for (int r = 0; r < 16; ++r) accx[h][r] = 0.f;
+        // row `token` of the tile is the im2col row of that token (three rows of 24 channels = nine K-groups of 8; the tenth re-reads the ninth against zero weights)
+        const _Float16* xh = reinterpret_cast<const _Float16*>(xt) + lt * SPP;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int st = 0; st < 5; ++st) {
+            const int g = (2 * st + lh < 9) ? 2 * st + lh : 8;
+            const f16x8 wh = __builtin_bit_cast(f16x8, wv[st][0]), wl = __builtin_bit_cast(f16x8, wv[st][WD1 - 1]);
 #pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    const float xf = xrow[h * (OS_CW * OS_XP) + (rr * 8 + 2 * j) * OS_XP + tap];
-                    acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[tap][rr][j], xf, acc[h], 0, 0, 0);
-                }
-#endif
+            for (int h = 0; h < NH; ++h) {
+                const f16x8 fh = *reinterpret_cast<const f16x8*>(xh + h * (2 * SPR * SPP) + 8 * g);
+                const f16x8 fl = *reinterpret_cast<const f16x8*>(xh + h * (2 * SPR * SPP) + SPR * SPP + 8 * g);
+                accx[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fh, accx[h], 0, 0, 0);
+                acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fh, acc[h], 0, 0, 0);
+                accx[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fl, accx[h], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[h][r] = fmaf(accx[h][r], 0x1p-11f, acc[h][r]);   // main + 2^-11 cross
+    } else {
+        const float* xrow = xt + lh * OS_XP + lt + 3;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        const float xf = xrow[h * TILE_F + (rr * 8 + 2 * j) * OS_XP + tap];
+                        acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[tap < WD0 ? tap : 0][rr < WD1 ? rr : 0][j], xf, acc[h], 0, 0, 0);
+                    }
+    }
 
     // ---- split-K reduction (fixed order) ----
     __syncthreads();
@@ -204,24 +238,32 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const OutSchedArg
 }
 
 template <bool CFG> __global__ __launch_bounds__(256) void out_sched_tm_kernel(const OutSchedArgs a);   // (below)
-static int out_sched_smem(bool cfg) {
+static int out_sched_smem(bool cfg) {   // (the split-fp16 tile is the smaller one: 2 x 34 x 24 halfs against 24 x 40 floats)
     const int nh = cfg ? 2 : 1;
     const int stage = OS_KS * nh * OS_CW * OS_XP, red = OS_KS * nh * 16 * 64;
     return (nh * 2 * OS_C + OS_KS * GN_SCRATCH + (stage > red ? stage : red)) * (int)sizeof(float);
 }
 void configure_out_sched_kernel() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_tm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&out_sched_tm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
 bool out_sched_supports(const OutSchedArgs& a) {
-    return a.Cin == OS_C && a.Cout <= 32 && a.guidance_rescale <= 0.f && a.gn_nparts < 0x7fff;
+    return a.Cin == OS_C && a.Cout <= 32 && a.guidance_rescale <= 0.f && a.gn_nparts < 0x7fff && a.T <= 0xffff && a.pitch <= 0xffff && a.B <= 0xffff &&
+           a.x_bstride <= 0x7fffffffLL && a.gn_part_bstride <= 0x7fffffffLL;
 }
 void launch_out_sched(const OutSchedArgs& a, hipStream_t s) {
     dim3 grid((a.T + 31) / 32, a.B);
-    if (a.cfg) hipLaunchKernelGGL(out_sched_kernel<true>, grid, dim3(64 * OS_KS), out_sched_smem(true), s, a);
-    else hipLaunchKernelGGL(out_sched_kernel<false>, grid, dim3(64 * OS_KS), out_sched_smem(false), s, a);
+    const int tp = a.T | (a.pitch << 16), bn = a.B | (a.gn_nparts << 16);
+    const bool sp = a.ws != nullptr;   // split-fp16 products (engine.cpp: fp32 mode's default; said_debug_option "out_split")
+#define OS_LAUNCH(CFG, SP) hipLaunchKernelGGL((out_sched_kernel<CFG, SP>), grid, dim3(64 * OS_KS), out_sched_smem(CFG), s, a.x, a.gn_part, (SP) ? a.ws : a.w4, a.step_ptr, tp, (int)a.x_bstride, \
+                                              (int)a.gn_part_bstride, bn, a)
+    if (a.cfg) { if (sp) OS_LAUNCH(true, true); else OS_LAUNCH(true, false); }
+    else { if (sp) OS_LAUNCH(false, true); else OS_LAUNCH(false, false); }
+#undef OS_LAUNCH
 }
 
 
