@@ -91,7 +91,7 @@ __device__ __forceinline__ void clk_stamp_c(long long* clk, int w, int lane, int
     (void)clk; (void)w; (void)lane; (void)slot;
     return;
 #endif
-    if (clk && blockIdx.x + 8 == gridDim.x) {
+    if (clk && blockIdx.x == 8 && blockIdx.y + 1 == gridDim.y) {
         unsigned long long t;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
         if (lane == 0) clk[w * 16 + slot] = (long long)t;
@@ -365,13 +365,17 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             blo = __builtin_bit_cast(int, bload(rlo, tv ? t * 4 : (int)0x80000000, 0));   // (tokens past T: an empty window)
             bhi = __builtin_bit_cast(int, bload(rhi, tv ? t * 4 : (int)0x80000000, 0));
         }
-        {   // the vectors: b1, bq, bo2 | c2, bffp, bff
-            float* vl = reinterpret_cast<float*>(smem + CH_VEC);
-            const f32x4* vg = reinterpret_cast<const f32x4*>(a.vec);
-            for (int i = tid; i < CHAIN_VEC_FLOATS_LDS / 4; i += 384) {
+        // the vectors b1, bq, bo2 | c2, bffp, bff: requested with everything else, parked in LDS behind the operand tiles (a load-then-store loop here made the whole
+        // request phase wait for its own first loads: one memory round trip before the weight ring was even requested)
+        f32x4 vecv[2];
+        {
+            const rsrc_t rvec = make_rsrc(a.vec, (unsigned)CHAIN_VEC_FLOATS * 4u);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = tid + 384 * k;
                 // slot 2 of the table is bo2 for conditional samples, c2 for unconditional ones (global layout: b1, bq, bo2, c2, bffp, bff)
                 const int gi = (i < 96) ? i : ((i < 144) ? (MODE == 1 ? i + 48 : i) : i + 48);
-                reinterpret_cast<f32x4*>(vl)[i] = *reinterpret_cast<gf4_p>((unsigned long long)(vg + gi));
+                vecv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rvec, (i < CHAIN_VEC_FLOATS_LDS / 4) ? gi * 16 : (int)0x80000000, 0, 0));
             }
         }
         sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, NR, decltype(qc)::value>(R, wp); });
@@ -407,6 +411,11 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
                 for (int e = 0; e < 4; ++e) v[e] = (t0 + 4 * tq + e < hd.T) ? v[e] : 0.f;
                 *reinterpret_cast<f32x4*>(xl + (48 * rnd + cr) * 32 + 4 * tq) = v;
             }
+        }
+        {
+            f32x4* vl = reinterpret_cast<f32x4*>(smem + CH_VEC);
+            vl[tid] = vecv[0];
+            if (tid + 384 < CHAIN_VEC_FLOATS_LDS / 4) vl[tid + 384] = vecv[1];
         }
         if (w < 4) gn20_finish(gp, rpart, 48 * w, l, gl, reinterpret_cast<float*>(smem + CH_R0) + w * GN_SCRATCH, reinterpret_cast<float*>(smem + CH_GNC));
         __syncthreads();
@@ -686,26 +695,18 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
 
 template <bool BF>
 __global__ __launch_bounds__(512, 1) void stchain_kernel(const float* h_w, const float* h_o, const float* h_x, const int* h_lo, int h_T, int h_pitch, int h_obs, int h_xbs, int h_inmod,
-                                                         int h_nunc_wmax, const ChainArgs a, int nsamp) {
+                                                         int h_nunc_wmax, const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char csmem[];
 #ifdef SAID_AB_FLOOR
     if (h_T > 0) return;
 #endif
-    const ChainHdr hd = {h_w, h_o, h_x, h_lo, h_T, h_pitch, h_obs, h_xbs, h_inmod & 0xffffff, h_nunc_wmax & 0xffffff, (int)((unsigned)h_nunc_wmax >> 24)};
+    const ChainHdr hd = {h_w, h_o, h_x, h_lo, h_T, h_pitch, h_obs, h_xbs, h_inmod, h_nunc_wmax & 0xffffff, (int)((unsigned)h_nunc_wmax >> 24)};
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Small launches (a few dozen workgroups) are confined to NX of the eight XCDs: workgroups are dealt to the XCDs round-robin by linear id, and every XCD whose L2 serves a
-    // workgroup fetches the block's whole 2.36 MB weight stream from memory (each L2 is cold at launch) — eight copies for 38 workgroups.  The grid is padded to 8 / NX times
-    // the work and the workgroups that land on the other XCDs leave at once.  (1-D grid: x = sample * tiles + tile, padded.)
-    const int nx = (int)((unsigned)h_inmod >> 24), ntt = (h_T + 31) >> 5;
-    int widx = (int)blockIdx.x;
-    if (nx < 8) {
-        const int xcd = widx & 7;
-        if (xcd >= nx) return;
-        widx = (widx >> 3) * nx + xcd;
-    }
-    if (widx >= ntt * nsamp) return;
-    const int s_idx = widx / ntt, t0 = (widx - s_idx * ntt) * 32;
+    // (Confining small launches to fewer XCDs — a padded 1-D grid whose workgroups leave at once on the unwanted XCDs, so that one L2's copy of the weight stream serves more
+    //  workgroups — was measured slower at every setting: profiles/r05i_stchain_xcds_ab.txt; and the sample count it read from the kernel arguments in
+    //  memory cost every launch a scalar-memory round trip before its first request: 29.9 -> 31.4 us.  The grid is (token tiles, samples).)
+    const int s_idx = blockIdx.y, t0 = blockIdx.x * 32;
     const bool uncond = s_idx < hd.n_uncond;
     const int in_idx = hd.in_mod > 0 ? s_idx % hd.in_mod : s_idx;
     // three self-contained roles (each with its own prologue: nothing but scalars is live across this branch, so each gets its own register allocation)
@@ -725,18 +726,10 @@ bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long
 void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s, bool bf16,
                     int xcds) {
     if (!stchain_supports(a, T, pitch, o_bs, x_bs)) { launch_fault("stchain: unsupported arguments (T %d, window %d)", T, a.wmax); return; }
-    const int n = ((T + 31) / 32) * nsamp;
-    // XCDs to use: all eight unless told otherwise.  Measured (profiles/r05i_stchain_xcds_ab.txt): confining a small launch to fewer XCDs shares one L2's copy of the
-    // weight stream among more workgroups but is SLOWER (headline, 38 workgroups per launch: 1955 frames/s on 8 XCDs, 1944 on 4, 1910 on 2; cfg4, 114 workgroups: 23.85k on 8, 23.5k on 4) — the L2->CU fabric of one XCD, not HBM, is the limit.
-    int nx = xcds > 0 ? xcds : 8;
-    if (nx > 8 || (nx & (nx - 1))) nx = 8;
-    const int gx = nx == 8 ? n : ((n + nx - 1) / nx) * 8;
-    dim3 grid(gx, 1);
-    // (gridDim.y carries the sample count for the index decode; the grid itself is one-dimensional)
-    grid.y = 1;
-    const int inmod_nx = (in_mod & 0xffffff) | (nx << 24);
-    if (bf16) hipLaunchKernelGGL(stchain_kernel<true>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, inmod_nx, n_uncond | (a.wmax << 24), a, nsamp);
-    else hipLaunchKernelGGL(stchain_kernel<false>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, inmod_nx, n_uncond | (a.wmax << 24), a, nsamp);
+    dim3 grid((T + 31) / 32, nsamp);
+    (void)xcds;   // (the XCD confinement experiment: see the kernel)
+    if (bf16) hipLaunchKernelGGL(stchain_kernel<true>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+    else hipLaunchKernelGGL(stchain_kernel<false>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
 }
 void configure_stchain_kernel() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
