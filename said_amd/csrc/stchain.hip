@@ -47,9 +47,23 @@ constexpr int CH_LNP = CH_GNC + 384 * 4;           // LayerNorm partials [32 tok
 constexpr int CH_LDS = CH_LNP + 32 * 6 * 2 * 4;
 static_assert(CH_LDS <= 160 * 1024, "chain kernel LDS budget");
 static_assert(CHAIN_KW * CH_KP * 4 * 2 <= 2 * CH_HPL, "K / V window tiles fit the GEGLU product region");
+// The bf16 variant's carve: <= 80 KB and <= 128 VGPRs, so that TWO workgroups share a CU (large batches: 1216 workgroups at 32 clips) and one's un-overlapped phases
+// (prologue, LayerNorm exchanges, the band) run under the other's weight stream.  One plane per region; the K / V window tiles in bf16 (43,904 B) leave 5,760 B of the
+// GEGLU product region (49,664 B) free until GEGLU starts: the GroupNorm coefficients, the LayerNorm partials and b1 / bq / bo2 | c2 — all dead by then — live there;
+// bffp comes from memory (requested before the last barrier), bff keeps its own 6 KB.
+template <bool BF> struct Carve {   // fp32 (split-fp16 planes): the constants above
+    static constexpr int R0 = CH_R0, R1 = CH_R1, R2 = CH_R2, VEC = CH_VEC, BFF = CH_VEC + 4 * 192 * 4, GNC = CH_GNC, LNP = CH_LNP, LDS = CH_LDS;
+};
+template <> struct Carve<true> {
+    static constexpr int KV = CHAIN_KW * CH_KP * 2 * 2;
+    static constexpr int R0 = 0, GNC = KV, LNP = GNC + 384 * 4, VEC = LNP + 32 * 6 * 2 * 4;
+    static constexpr int R1 = CH_HPL, R2 = R1 + CH_APL, BFF = R2 + CH_APL, LDS = BFF + 1536 * 4;
+    static_assert(VEC + 3 * 192 * 4 <= CH_HPL, "the early tables fit behind the K / V tiles");
+    static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+};
 constexpr int CH_NR_OWNER = 8;                     // ring depths (units of one k16 step: h + l fragments = 2 KB per wave): what is in flight is what bounds the stream's
 constexpr int CH_NR_HELPER = 9;                    // rate (latency x bandwidth ~ 160 KB per CU): 6 x 16 + 2 x 18 = 132 KB
-constexpr int CH_NR_BF = 20;                       // bf16 variant: 1 KB units, no second accumulator set: 20 KB per wave in flight
+constexpr int CH_NR_BF = 5;                        // bf16 variant: 1 KB units; 5 KB per wave in flight x 16 waves of the CU's two workgroups (128 VGPRs)
 
 // units of a wave's stream: [to_out1 12][to_q 12][to_out2 12][GEGLU 3 pairs x 12 steps x (value, gate)][ffproj 60 | 30]; waves 6, 7: [GEGLU 72][ffproj 30].
 // The folded proj_out (60 k16 steps per column tile) is the one phase where six column owners on four SIMDs are unbalanced (two SIMDs with two owners: 11.5k clocks of
@@ -244,12 +258,13 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
     const int col0 = 32 * j + 4 * lh;      // this lane's first channel of the owner's 32
     const int t = t0 + lt;
     const bool tv = t < hd.T;
-    char* const r1h = smem + CH_R1;
-    char* const r2h = smem + CH_R2;
-    char* const hh = smem + CH_R0;
-    const float* vec = reinterpret_cast<const float*>(smem + CH_VEC);
-    const float* gnc = reinterpret_cast<const float*>(smem + CH_GNC);
-    float* lnp = reinterpret_cast<float*>(smem + CH_LNP);
+    using CV = Carve<BF>;
+    char* const r1h = smem + CV::R1;
+    char* const r2h = smem + CV::R2;
+    char* const hh = smem + CV::R0;
+    const float* vec = reinterpret_cast<const float*>(smem + CV::VEC);   // b1, bq, bo2 | c2 (fp32 variant: bffp and bff behind)
+    const float* gnc = reinterpret_cast<const float*>(smem + CV::GNC);
+    float* lnp = reinterpret_cast<float*>(smem + CV::LNP);
     long long* const clk = a.clk;
     const int browA = lt * (CH_AP * 2) + 16 * lh;   // this lane's B-fragment row in a 192-wide plane (bytes)
     const int browH = lt * (CH_HP * 2) + 16 * lh;
@@ -297,7 +312,15 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         auto kv_park = [&](int i0) {
             float* kt = reinterpret_cast<float*>(smem + CH_R0);
             kv_walk(i0, [&](int i, int k, int p4) {
-                *reinterpret_cast<f32x4*>(kt + (p4 < 48 ? 0 : CHAIN_KW * CH_KP) + k * CH_KP + 4 * (p4 < 48 ? p4 : p4 - 48)) = kvv[i];
+                const int e = (p4 < 48 ? 0 : CHAIN_KW * CH_KP) + k * CH_KP + 4 * (p4 < 48 ? p4 : p4 - 48);
+                if constexpr (BF) {   // bf16 tiles (RNE)
+                    bf16x4c b;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[q] = (__bf16)kvv[i][q];
+                    *reinterpret_cast<bf16x4c*>(reinterpret_cast<__bf16*>(kt) + e) = b;
+                } else {
+                    *reinterpret_cast<f32x4*>(kt + e) = kvv[i];
+                }
             });
         };
         if (!uncond) {
@@ -381,10 +404,10 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, NR, decltype(qc)::value>(R, wp); });
         clk_stamp_c(clk, w, l, 12);
         if constexpr (BF) {   // both tiles as they are: bf16 rows of 384 bytes at the planes' 400-byte pitch
-            *reinterpret_cast<f32x4*>(smem + CH_R1 + prow0 * (CH_AP * 2) + ppc0 * 16) = ov[0];
-            *reinterpret_cast<f32x4*>(smem + CH_R1 + prow1 * (CH_AP * 2) + ppc1 * 16) = ov[1];
-            *reinterpret_cast<f32x4*>(smem + CH_R2 + prow0 * (CH_AP * 2) + ppc0 * 16) = xv4[0];
-            *reinterpret_cast<f32x4*>(smem + CH_R2 + prow1 * (CH_AP * 2) + ppc1 * 16) = xv4[1];
+            *reinterpret_cast<f32x4*>(smem + CV::R1 + prow0 * (CH_AP * 2) + ppc0 * 16) = ov[0];
+            *reinterpret_cast<f32x4*>(smem + CV::R1 + prow1 * (CH_AP * 2) + ppc1 * 16) = ov[1];
+            *reinterpret_cast<f32x4*>(smem + CV::R2 + prow0 * (CH_AP * 2) + ppc0 * 16) = xv4[0];
+            *reinterpret_cast<f32x4*>(smem + CV::R2 + prow1 * (CH_AP * 2) + ppc1 * 16) = xv4[1];
         } else {
             // attention output -> split planes (token-major)
             {
@@ -412,12 +435,19 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
                 *reinterpret_cast<f32x4*>(xl + (48 * rnd + cr) * 32 + 4 * tq) = v;
             }
         }
-        {
-            f32x4* vl = reinterpret_cast<f32x4*>(smem + CH_VEC);
-            vl[tid] = vecv[0];
-            if (tid + 384 < CHAIN_VEC_FLOATS_LDS / 4) vl[tid + 384] = vecv[1];
+        {   // float4 index i of the LDS order: [0, 144) b1, bq, bo2 | c2; [144, 192) bffp; [192, 576) bff
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = tid + 384 * k;
+                if constexpr (BF) {
+                    if (i < 144) reinterpret_cast<f32x4*>(smem + CV::VEC)[i] = vecv[k];
+                    else if (i >= 192 && i < CHAIN_VEC_FLOATS_LDS / 4) reinterpret_cast<f32x4*>(smem + CV::BFF)[i - 192] = vecv[k];
+                } else {
+                    if (i < CHAIN_VEC_FLOATS_LDS / 4) reinterpret_cast<f32x4*>(smem + CV::VEC)[i] = vecv[k];
+                }
+            }
         }
-        if (w < 4) gn20_finish(gp, rpart, 48 * w, l, gl, reinterpret_cast<float*>(smem + CH_R0) + w * GN_SCRATCH, reinterpret_cast<float*>(smem + CH_GNC));
+        if (w < 4) gn20_finish(gp, rpart, 48 * w, l, gl, reinterpret_cast<float*>(smem + CH_R0) + w * GN_SCRATCH, reinterpret_cast<float*>(smem + CV::GNC));
         __syncthreads();
         clk_stamp_c(clk, w, l, 1);
         // ---- to_out1 + GroupNorm'ed residual (attention.py:127, 168, 226-227) ----
@@ -485,7 +515,17 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             {
                 const int lo = blo, hi = bhi;
                 const float* kt = reinterpret_cast<const float*>(smem + CH_R0);
-                const float* vt = kt + CHAIN_KW * CH_KP;
+                auto kv4 = [&](int e) -> f32x4 {   // four consecutive elements of the window tiles (element index from the K tile's start; BF: bf16 tiles)
+                    if constexpr (BF) {
+                        const bf16x4c b = *reinterpret_cast<const bf16x4c*>(reinterpret_cast<const __bf16*>(kt) + e);
+                        f32x4 o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = (float)b[q];
+                        return o;
+                    } else {
+                        return *reinterpret_cast<const f32x4*>(kt + e);
+                    }
+                };
                 float sc[8];
                 float mx = -3.0e38f;
 #pragma unroll
@@ -493,10 +533,9 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
                     float p = 0.f;
                     if (wi < hd.wmax) {
                         const int row = min(max(lo - kmin + wi, 0), CHAIN_KW - 1);
-                        const float* kr = kt + row * CH_KP + col0;
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
-                            const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + 8 * m);
+                            const f32x4 kv = kv4(row * CH_KP + col0 + 8 * m);
 #pragma unroll
                             for (int i = 0; i < 4; ++i) p = fmaf(q[4 * m + i], kv[i], p);
                         }
@@ -520,11 +559,10 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
                 for (int wi = 0; wi < 8; ++wi) {
                     if (wi < hd.wmax) {
                         const int row = min(max(lo - kmin + wi, 0), CHAIN_KW - 1);
-                        const float* vr = vt + row * CH_KP + col0;
                         const float pw = sc[wi] * inv;
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
-                            const f32x4 vv = *reinterpret_cast<const f32x4*>(vr + 8 * m);
+                            const f32x4 vv = kv4(CHAIN_KW * CH_KP + row * CH_KP + col0 + 8 * m);
 #pragma unroll
                             for (int i = 0; i < 4; ++i) o2[4 * m + i] = fmaf(pw, vv[i], o2[4 * m + i]);
                         }
@@ -568,7 +606,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
     // the phase) the weight stream pauses during every epilogue.  The epilogue of pair pi is therefore executed in four pieces inside pair pi + 1's MFMA loop.
     {
         constexpr int QG = (MODE == 0) ? U_GE : (MODE == 1 ? U_G2 : 0);   // logical position of the wave's first GEGLU unit
-        const float* bff = vec + 4 * 192;
+        const float* bff = reinterpret_cast<const float*>(smem + CV::BFF);
         float pv[16], pg[16];   // the previous pair's value and gate sums
         auto epi_piece = [&](int p, int m) {   // channels 32 p + 4 lh + 8 m .. + 3 of the token: bias, gelu, product, split, 8 bytes per plane
             const f32x4 bv = *reinterpret_cast<const f32x4*>(bff + 32 * p + 4 * lh + 8 * m), bg = *reinterpret_cast<const f32x4*>(bff + 768 + 32 * p + 4 * lh + 8 * m);
@@ -602,6 +640,12 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         });
 #pragma unroll
         for (int m = 0; m < 4; ++m) epi_piece(w + 16, m);
+    }
+    f32x4 bpv[4];   // BF: bffp of this lane's 16 channels, from memory (global layout of ChainArgs::vec: b1, bq, bo2, c2, bffp, bff)
+    if constexpr (BF && MODE != 2) {
+        const rsrc_t rvec = make_rsrc(a.vec, (unsigned)CHAIN_VEC_FLOATS * 4u);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bpv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rvec, (4 * 192 + col0 + 8 * m) * 4, 0, 0));
     }
     __syncthreads();
     clk_stamp_c(clk, w, l, 8);
@@ -651,7 +695,14 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             for (int r = 0; r < 16; ++r) y[r] += fpart[((w - 4) * 16 + r) * 64 + l];
         }
         clk_stamp_c(clk, w, l, 9);
-        get_vec(vec + 3 * 192, col0, bp);
+        if constexpr (BF) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bp[4 * m + i] = bpv[m][i];
+        } else {
+            get_vec(vec + 3 * 192, col0, bp);
+        }
         const rsrc_t ryo = BF ? make_rsrc(reinterpret_cast<char*>(a.y) + (long long)s_idx * a.y_bs * 2, (unsigned)hd.T * 384u)
                               : make_rsrc(a.y + (long long)s_idx * a.y_bs, 192u * (unsigned)hd.pitch * 4u);
         float* const so = a.stats_out ? a.stats_out + (long long)s_idx * a.stats_bs + ((long long)(t0 >> 5) * 192) * 2 : nullptr;
@@ -694,7 +745,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
 }
 
 template <bool BF>
-__global__ __launch_bounds__(512, 1) void stchain_kernel(const float* h_w, const float* h_o, const float* h_x, const int* h_lo, int h_T, int h_pitch, int h_obs, int h_xbs, int h_inmod,
+__global__ __launch_bounds__(512, BF ? 4 : 1) void stchain_kernel(const float* h_w, const float* h_o, const float* h_x, const int* h_lo, int h_T, int h_pitch, int h_obs, int h_xbs, int h_inmod,
                                                          int h_nunc_wmax, const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char csmem[];
 #ifdef SAID_AB_FLOOR
@@ -728,12 +779,12 @@ void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T,
     if (!stchain_supports(a, T, pitch, o_bs, x_bs)) { launch_fault("stchain: unsupported arguments (T %d, window %d)", T, a.wmax); return; }
     dim3 grid((T + 31) / 32, nsamp);
     (void)xcds;   // (the XCD confinement experiment: see the kernel)
-    if (bf16) hipLaunchKernelGGL(stchain_kernel<true>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+    if (bf16) hipLaunchKernelGGL(stchain_kernel<true>, grid, dim3(512), Carve<true>::LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
     else hipLaunchKernelGGL(stchain_kernel<false>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
 }
 void configure_stchain_kernel() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, Carve<true>::LDS);
 }
 
 }  // namespace said
