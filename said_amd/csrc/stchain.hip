@@ -63,7 +63,7 @@ template <> struct Carve<true> {
 };
 constexpr int CH_NR_OWNER = 8;                     // ring depths (units of one k16 step: h + l fragments = 2 KB per wave): what is in flight is what bounds the stream's
 constexpr int CH_NR_HELPER = 9;                    // rate (latency x bandwidth ~ 160 KB per CU): 6 x 16 + 2 x 18 = 132 KB
-constexpr int CH_NR_BF = 5;                        // bf16 variant: 1 KB units; 5 KB per wave in flight x 16 waves of the CU's two workgroups (128 VGPRs)
+constexpr int CH_NR_BF = 6;                        // bf16 variant: 1 KB units; 6 KB per wave in flight x 16 waves of the CU's two workgroups (128 VGPRs)
 
 // units of a wave's stream: [to_out1 12][to_q 12][to_out2 12][GEGLU 3 pairs x 12 steps x (value, gate)][ffproj 60 | 30]; waves 6, 7: [GEGLU 72][ffproj 30].
 // The folded proj_out (60 k16 steps per column tile) is the one phase where six column owners on four SIMDs are unbalanced (two SIMDs with two owners: 11.5k clocks of
@@ -632,14 +632,20 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             zero16(av); zero16(avx); zero16(ag); zero16(agx);
             geglu_run<MODE, BF, NR, QG + 24 * pi>(R, wp, r1h + browA, CH_APL, av, avx, ag, agx, [&](auto sc) {
                 constexpr int s = decltype(sc)::value;
-                if constexpr (pi > 0 && s % 3 == 1) epi_piece(w + 8 * (pi - 1), s / 3);
+                if constexpr (!BF && pi > 0 && s % 3 == 1) epi_piece(w + 8 * (pi - 1), s / 3);
             });
             clk_stamp_c(clk, w, l, 11 + 2 * pi);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { pv[r] = fmaf(avx[r], 0x1p-11f, av[r]); pg[r] = fmaf(agx[r], 0x1p-11f, ag[r]); }
-        });
+            if constexpr (BF) {   // two workgroups share the CU: the other one's stream runs under this epilogue, and the 32 registers of a carried pair buy ring depth instead
 #pragma unroll
-        for (int m = 0; m < 4; ++m) epi_piece(w + 16, m);
+                for (int m = 0; m < 4; ++m) epi_piece(w + 8 * pi, m);
+            }
+        });
+        if constexpr (!BF) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) epi_piece(w + 16, m);
+        }
     }
     f32x4 bpv[4];   // BF: bffp of this lane's 16 channels, from memory (global layout of ChainArgs::vec: b1, bq, bo2, c2, bffp, bff)
     if constexpr (BF && MODE != 2) {
