@@ -134,6 +134,32 @@ def test_guided_step_on_the_fused_schedule_vs_oracle(model, dev, sd_parts, B, Ta
     assert err <= 2e-4   # (measured 4e-6 .. 6e-6; the parity suite's single-step bound)
 
 
+def test_out_sched_split_products_against_fp32_products(model, dev, sd_parts):
+    """out_sched_kernel's convolution on split-fp16 operands (the default) against the fp32 matrix instructions (said_debug_option "out_split" = 0) over five guided
+    steps from the same latents: same scheduler arithmetic, the model output differs by the products' rounding only."""
+    sd_full, sd_a, sd_u, null = sd_parts
+    B, T = 2, 190
+    lat = synth.synth_latents(77, (B, T, 32))
+    emb = synth.synth_latents(78, (B, T, 768))
+    sch = model.noise_scheduler
+    sch.set_timesteps(50)
+    ts = sch.timesteps.numpy()
+    coef = sch.coef_table(ts, 0.0)
+    eng = model._get_engine(2 * B, T)
+    res = {}
+    for v in (1, 0):
+        eng.debug_option("out_split", v)
+        try:
+            _, latf, _ = eng.denoise_loop(latents=lat.to(dev), context=emb.to(dev), timesteps=ts[20:25], coef=coef[20:25], prediction_type="epsilon",
+                                          guidance_scale=2.0, guidance_rescale=0.0, latent_scale=1.0, step_noise=None)
+            res[v] = latf.cpu()
+        finally:
+            eng.debug_option("out_split", -1)
+    d = float((res[1] - res[0]).abs().max())
+    print(f"out_sched split vs fp32 products, 5 guided steps: max |diff| {d:.2e} (latent range {float(res[0].abs().max()):.2f})")
+    assert torch.isfinite(res[1]).all() and d <= 2e-5
+
+
 def test_split_planes_come_from_one_conversion(model, dev):
     """The regression itself, at the API: latents / context chosen so that many LayerNorm / attention outputs cannot be known in advance — instead the
     property is checked where it bites: the fused schedule (packed conversions in its epilogues) against the five-launch one, PER TOKEN.  With the
