@@ -115,7 +115,6 @@ struct said_ctx {
     long long st_chain_max_tiles = 1LL << 40;   // ... while the launch is at most this many workgroups (sample x 32-token tiles; said_debug_option "st_chain_max_tiles")
     int st_chain_bf16 = -1;      // bf16 mode, large batches: the same fused tail on bf16 operands (stchain_kernel<true>) instead of rgemm's five launches; 0: off
                                  // (said_debug_option "st_chain_bf16")
-    int st_chain_xcds = 0;       // XCDs a fused-tail launch is confined to (0 / 8: all; 1, 2, 4: measured slower — said_debug_option "st_chain_xcds")
     bool st_chain_dbg = false;   // debug: the fused kernel also writes x1 / x2 to X1 / X2
     int st_chain = -1;           // fp32 mode, small batches: everything behind self-attention as ONE launch per block (stchain.hip); 0: the five launches
                                  // (said_debug_option "st_chain")
@@ -906,7 +905,7 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
             c->stage_log.push_back({10, EPI_STORE, 6, 8, w + io, fl});
         }
         if (dbg_go(c)) {
-            launch_stchain(ca, static_cast<const float*>(c->tO), static_cast<const float*>(in.t), g.T, g.Tp, seg * MC, seg * MC, shared ? g.Bc : 0, g.Bc > 0 ? g.Bc : 0, g.Be, s, true, c->st_chain_xcds);
+            launch_stchain(ca, static_cast<const float*>(c->tO), static_cast<const float*>(in.t), g.T, g.Tp, seg * MC, seg * MC, shared ? g.Bc : 0, g.Bc > 0 ? g.Bc : 0, g.Be, s, true);
             ++c->n_stchain;
         }
         return;
@@ -1244,7 +1243,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         }
         if (dbg_go(c)) {
             if (trace_on()) { fprintf(stderr, "[said] stchain #%d T=%d samples=%d shared=%d\n", c->dbg_count - 1, g.T, g.Be, (int)shared); fflush(stderr); }
-            launch_stchain(ca, c->O, in.p, g.T, g.Tp, obs, g.hs, shared ? g.Bc : 0, g.Bc > 0 ? g.Bc : 0, g.Be, s, false, c->st_chain_xcds);
+            launch_stchain(ca, c->O, in.p, g.T, g.Tp, obs, g.hs, shared ? g.Bc : 0, g.Bc > 0 ? g.Bc : 0, g.Be, s, false);
             ++c->n_stchain;
             if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
         }
@@ -2619,8 +2618,6 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->st_chain_dbg = value != 0;
     } else if (k == "st_chain_bf16") {
         ctx->st_chain_bf16 = value < 0 ? -1 : (value != 0);
-    } else if (k == "st_chain_xcds") {
-        ctx->st_chain_xcds = (int)value;
     } else if (k == "st_chain_large") {
         ctx->st_chain_large = value != 0;
     } else if (k == "st_chain_max_tiles") {

@@ -40,7 +40,7 @@ bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long
 // bf16 = true (bf16 mode, large batches): o, xin and y are TOKEN-major bf16 [sample][row][192] (o_bs / x_bs / y_bs in elements, pitch unused), wstream the bf16 stream
 // (1 KB units), every product one v_mfma_f32_32x32x16_bf16 on operands rounded to bf16; statistics, LayerNorm, softmax, residual sums stay fp32.
 void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s,
-                    bool bf16 = false, int xcds = 0);   // xcds: XCDs the launch is confined to (0 / 8: all)
+                    bool bf16 = false);
 void configure_stchain_kernel();
 
 }  // namespace said

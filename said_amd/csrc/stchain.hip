@@ -780,11 +780,9 @@ bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long
     return true;
 }
 
-void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s, bool bf16,
-                    int xcds) {
+void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s, bool bf16) {
     if (!stchain_supports(a, T, pitch, o_bs, x_bs)) { launch_fault("stchain: unsupported arguments (T %d, window %d)", T, a.wmax); return; }
     dim3 grid((T + 31) / 32, nsamp);
-    (void)xcds;   // (the XCD confinement experiment: see the kernel)
     if (bf16) hipLaunchKernelGGL(stchain_kernel<true>, grid, dim3(512), Carve<true>::LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
     else hipLaunchKernelGGL(stchain_kernel<false>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
 }
