@@ -160,6 +160,140 @@ def test_out_sched_split_products_against_fp32_products(model, dev, sd_parts):
     assert torch.isfinite(res[1]).all() and d <= 2e-5
 
 
+@pytest.mark.parametrize("B,stores", [(2, False), (16, True)])
+def test_bf16_mode_against_the_bf16_emulating_oracle(model, dev, sd_parts, B, stores):
+    """VERDICT r4 #3b, end to end — and why the kernel-by-kernel test below is the instrument.  bf16 mode's whole UNet evaluation beside the oracle with the SAME
+    roundings switched on (oracle/unet.py ROUND_OPERANDS; ROUND_STORES for the large-batch schedule, whose hidden state is stored in bf16 between kernels).  Measured:
+    the deviation from the emulation (rms 1.1e-3 of range at B = 2) is hardly smaller than the deviation from the fp32 oracle (1.35e-3), although every kernel agrees
+    with the emulation of its OWN inputs to 1e-7 .. 1e-5.  A rounding is a discontinuity: a 1e-6 difference in an operand that sits next to a bf16 boundary becomes a
+    2^-9 relative one, those differences create more flips downstream, and within one SpatialTransformer two bf16 evaluations with different summation orders have
+    decorrelated to the size of the rounding noise itself (scripts/probe_bf16_emu.py prints the growth launch by launch: 5e-6, 1.3e-5, 6e-5, 1.6e-4, 3e-4 of range).
+    So end to end only the bound against the fp32 oracle is asserted; the figures against the emulation are printed for the record."""
+    sd_full, sd_a, sd_u, null = sd_parts
+    T = 600
+    x = synth.synth_latents(171, (B, T, 32))
+    c = synth.synth_latents(172, (B, T, 768))
+    ts = (torch.arange(B) * 61 + 5) % 1000
+    eng = model._get_engine(max(B, 2), T)
+    try:
+        model.set_mfma_dtype("bf16")
+        n0 = eng.debug_get("n_stchain")
+        out = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+        chained = eng.debug_get("n_stchain") > n0
+    finally:
+        model.set_mfma_dtype("fp32")
+    assert chained == stores, "the large batch runs the token-major bf16 schedule with the fused tail, the small one does not"
+    worst = (0.0, 0.0, 0.0, 0.0)
+    for i in sorted({0, B // 2, B - 1}):
+        ref = ou.unet1d_forward(sd_u, x[i:i + 1], ts[i:i + 1], c[i:i + 1])
+        try:
+            ou.ROUND_OPERANDS, ou.ROUND_STORES, ou.ATTN_KS = "bf16", stores, (None if stores else 4)   # (battn_kernel's tiling is not restated: plain softmax there)
+            emu = ou.unet1d_forward(sd_u, x[i:i + 1], ts[i:i + 1], c[i:i + 1])
+        finally:
+            ou.ROUND_OPERANDS, ou.ROUND_STORES, ou.ATTN_KS = None, False, 4
+        rng = float(ref.abs().max())
+        d_emu, d_ref = out[i:i + 1] - emu, out[i:i + 1] - ref
+        m_emu, m_ref = float(d_emu.abs().max()) / rng, float(d_ref.abs().max()) / rng
+        r_emu, r_ref = float(d_emu.pow(2).mean().sqrt()) / rng, float(d_ref.pow(2).mean().sqrt()) / rng
+        print(f"bf16 mode B={B} sample {i}: vs emulating oracle max {m_emu:.2e} rms {r_emu:.2e} of range | vs fp32 oracle max {m_ref:.2e} rms {r_ref:.2e}")
+        worst = max(worst, (m_emu, r_emu, m_ref, r_ref))
+        assert m_ref <= 2e-2
+    print(f"worst: {worst}")
+
+
+def test_bf16_kernels_against_the_operand_rounded_evaluation_of_their_own_inputs(model, dev, sd_parts):
+    """VERDICT r4 #3b, kernel by kernel.  bf16 mode, small-batch schedule (B = 2, T = 600): the schedule is stopped behind each of the first ten launches (first
+    ResBlock, first SpatialTransformer), the launch's INPUT buffers are read back, and the stage is re-evaluated on the CPU with both operands of every product rounded
+    to bf16 (float64 accumulation; oracle/unet.py ROUND_OPERANDS) — statistics, normalisations, activations, biases and residual sums in fp32 as in the kernels.  On its own
+    inputs every GEMM-type kernel must agree with that evaluation at the level of single rounding flips, 2-3 orders of magnitude below its distance from the fp32
+    evaluation of the same inputs (which is the bf16 rounding itself); self-attention is restated with the kernel's online softmax (it rounds probabilities relative
+    to a running maximum per key slice)."""
+    import torch.nn.functional as F
+    sd_full, sd_a, sd = sd_parts[0], sd_parts[1], sd_parts[2]
+    B, T = 2, 600
+    Tp = (T + 31) // 32 * 32
+    x = synth.synth_latents(181, (B, T, 32))
+    c = synth.synth_latents(182, (B, T, 768))
+    ts = torch.tensor([999, 17])
+    eng = model._get_engine(2, T)
+    bufs = {}
+
+    def grab(k, name, rows, C):
+        eng.debug_stop_after(k)
+        model(x.to(dev), ts.to(dev), c.to(dev))
+        bufs[(k, name)] = torch.from_numpy(eng.debug_read(name, (B, rows, Tp))[:, :C, :T].copy())
+
+    try:
+        model.set_mfma_dtype("bf16")
+        for k, name, rows, C in ((1, "H0", 192, 192), (2, "M", 192, 192), (3, "P", 192, 192), (5, "O", 384, 192), (6, "X1", 192, 192), (7, "O", 384, 192), (8, "X2", 192, 192),
+                                 (9, "F", 768, 768), (10, "H1", 192, 192)):
+            grab(k, name, rows, C)
+    finally:
+        eng.debug_stop_after(-1)
+        model.set_mfma_dtype("fp32")
+    H0, M, P, O1, X1, O2, X2, Fg, H1 = (bufs[k] for k in ((1, "H0"), (2, "M"), (3, "P"), (5, "O"), (6, "X1"), (7, "O"), (8, "X2"), (9, "F"), (10, "H1")))
+    rb, st = "model.input_blocks.1.0", "model.input_blocks.1.1"
+    tb = st + ".transformer_blocks.0"
+    emb = ou.time_embed(sd, ts)
+    e = F.linear(F.silu(emb), sd[rb + ".emb_layers.1.weight"], sd[rb + ".emb_layers.1.bias"])
+    ln = lambda t, n: F.layer_norm(t, (192,), sd[tb + f".norm{n}.weight"], sd[tb + f".norm{n}.bias"])
+
+    def stages(rounded):
+        out = {}
+        ou.ROUND_OPERANDS = "bf16" if rounded else None
+        try:
+            h = F.silu(F.group_norm(H0, 32, sd[rb + ".in_layers.0.weight"], sd[rb + ".in_layers.0.bias"], eps=1e-5))
+            out["2 ResBlock conv 1"] = (ou._conv1d(h, sd[rb + ".in_layers.2.weight"], None, padding=1) + (sd[rb + ".in_layers.2.bias"][None] + e)[..., None], M)
+            h = F.silu(F.group_norm(M, 32, sd[rb + ".out_layers.0.weight"], sd[rb + ".out_layers.0.bias"], eps=1e-5))
+            out["3 ResBlock conv 2 + x"] = (ou._conv1d(h, sd[rb + ".out_layers.3.weight"], sd[rb + ".out_layers.3.bias"], padding=1) + H0, P)
+            g = F.group_norm(P, 32, sd[st + ".norm.weight"], sd[st + ".norm.bias"], eps=1e-6).transpose(1, 2)
+            y = ln(g, 1)
+            q, k, v = (ou._linear(y, sd[tb + f".attn1.to_{n}.weight"]) for n in "qkv")
+            sp = lambda t: t.reshape(B, T, 6, 32).permute(0, 2, 1, 3).reshape(B * 6, T, 32)
+            if rounded:
+                a = ou.attn_bf16_online(sp(q), sp(k), sp(v), 4)
+            else:
+                a = torch.einsum("bij,bjd->bid", (torch.einsum("bid,bjd->bij", sp(q), sp(k)) * 32 ** -0.5).softmax(dim=-1), sp(v))
+            out["4+5 q/k/v + self-attention"] = (a.reshape(B, 6, T, 32).permute(0, 2, 1, 3).reshape(B, T, 192).transpose(1, 2), O1)
+            out["6 to_out + norm(x)"] = ((ou._linear(O1.transpose(1, 2), sd[tb + ".attn1.to_out.0.weight"], sd[tb + ".attn1.to_out.0.bias"]) + g).transpose(1, 2), X1)
+            x1 = X1.transpose(1, 2)
+            q2 = ou._linear(ln(x1, 2), sd[tb + ".attn2.to_q.weight"])
+            k2, v2 = F.linear(c, sd[tb + ".attn2.to_k.weight"]), F.linear(c, sd[tb + ".attn2.to_v.weight"])
+            mask = ou.alignment_mask(B, T, T)
+            sim = (torch.einsum("bid,bjd->bij", sp(q2), sp(k2)) * 32 ** -0.5).masked_fill(mask[:, None].expand(B, 6, T, T).reshape(B * 6, T, T), -torch.finfo(torch.float32).max)
+            a2 = torch.einsum("bij,bjd->bid", sim.softmax(dim=-1), sp(v2))
+            out["7 to_q + banded cross-attention"] = (a2.reshape(B, 6, T, 32).permute(0, 2, 1, 3).reshape(B, T, 192).transpose(1, 2), O2)
+            out["8 to_out + x1"] = ((ou._linear(O2.transpose(1, 2), sd[tb + ".attn2.to_out.0.weight"], sd[tb + ".attn2.to_out.0.bias"]) + x1).transpose(1, 2), X2)
+            x2 = X2.transpose(1, 2)
+            yv = ou._linear(ln(x2, 3), sd[tb + ".ff.net.0.proj.weight"], sd[tb + ".ff.net.0.proj.bias"])
+            av, gate = yv.chunk(2, dim=-1)
+            out["9 GEGLU"] = ((av * F.gelu(gate)).transpose(1, 2), Fg)
+            Pw = sd[st + ".proj_out.weight"].reshape(192, 192).double()
+            PF = (Pw @ sd[tb + ".ff.net.2.weight"].double()).float()
+            PB = (Pw @ sd[tb + ".ff.net.2.bias"].double() + sd[st + ".proj_out.bias"].double()).float()
+            out["10 folded proj_out + x_in"] = ((ou._linear(Fg.transpose(1, 2), PF) + ou._linear(x2, Pw.float()) + PB).transpose(1, 2) + P, H1)
+        finally:
+            ou.ROUND_OPERANDS = None
+        return out
+
+    emu, plain = stages(True), stages(False)
+    for name in emu:
+        want, got = emu[name]
+        rng = float(got.abs().max())
+        d = (got - want).abs()
+        d32 = (got - plain[name][0]).abs()
+        mx, rms, rms32 = float(d.max()) / rng, float(d.pow(2).mean().sqrt()) / rng, float(d32.pow(2).mean().sqrt()) / rng
+        print(f"bf16 kernel vs its inputs' operand-rounded evaluation | {name:34s}: max {mx:.2e} rms {rms:.2e} of range"
+              f"   (vs the unrounded evaluation: max {float(d32.max()) / rng:.2e} rms {rms32:.2e})")
+        # measured (B = 2, T = 600): products + residual (6, 8, 10) max 6e-8 .. 1.5e-7; convolutions behind GroupNorm + SiLU rms 8e-7 .. 2.8e-6, max 1.7e-4 (an operand next to
+        # a bf16 boundary rounds the other way: one flip is 2^-9 of that operand); self-attention rms 1.2e-5, max 6e-4; cross-attention 4.6e-6; GEGLU 4e-7 — against
+        # 1.1e-4 .. 6.2e-4 rms for the unrounded evaluation of the same inputs
+        if name.startswith(("6 ", "8 ", "10 ")):
+            assert mx <= 1e-6
+        else:
+            assert rms <= 4e-5 and rms <= 0.1 * rms32 and mx <= 2e-3
+
+
 def test_split_planes_come_from_one_conversion(model, dev):
     """The regression itself, at the API: latents / context chosen so that many LayerNorm / attention outputs cannot be known in advance — instead the
     property is checked where it bites: the fused schedule (packed conversions in its epilogues) against the five-launch one, PER TOKEN.  With the
