@@ -164,3 +164,28 @@ def test_g10_vae_encoder_reference_weights(golden):
     mean, logvar = ov.encode(sd, coeffs)
     np.testing.assert_allclose(mean.numpy(), g["real_mean"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(logvar.numpy(), g["real_log_var"], rtol=1e-5, atol=1e-6)
+
+
+def test_bf16_emulating_mode_of_the_oracle(unet_sd):
+    """oracle/unet.py ROUND_OPERANDS (test infrastructure for bf16 mode, tests/test_gpu_round5.py): off by default and reversible (the golden-pinned path is untouched);
+    on operands that ARE bf16 numbers the rounded product is the exact one; the restated online softmax equals the plain one up to the rounding of the probabilities
+    and does not depend on how the keys are sliced beyond that."""
+    import torch.nn.functional as F
+    x = synth.synth_latents(5, (1, 40, 32)); c = synth.synth_latents(6, (1, 40, 768)); ts = torch.tensor([321])
+    ref = ou.unet1d_forward(unet_sd, x, ts, c)
+    try:
+        ou.ROUND_OPERANDS = "bf16"
+        emu = ou.unet1d_forward(unet_sd, x, ts, c)
+        a = synth.synth_latents(7, (3, 17, 192)).to(torch.bfloat16).float()
+        w = synth.synth_latents(8, (1, 48, 192))[0].to(torch.bfloat16).float()
+        assert torch.equal(ou._linear(a, w), F.linear(a.double(), w.double()).float())
+    finally:
+        ou.ROUND_OPERANDS = None
+    assert torch.equal(ou.unet1d_forward(unet_sd, x, ts, c), ref)
+    d = float((emu - ref).abs().max()) / float(ref.abs().max())
+    assert 1e-4 < d < 2e-2, d     # bf16 roundings: percent-level on this random-weight network, never zero
+    q, k, v = (synth.synth_latents(10 + i, (4, 100, 32)) for i in range(3))
+    r = lambda t: t.to(torch.bfloat16).float()
+    plain = torch.einsum("bij,bjd->bid", (torch.einsum("bid,bjd->bij", r(q), r(k)) * 32 ** -0.5).softmax(dim=-1), r(v))
+    o1, o4 = ou.attn_bf16_online(q, k, v, 1), ou.attn_bf16_online(q, k, v, 4)
+    assert float((o1 - plain).abs().max()) < 2e-2 and float((o4 - o1).abs().max()) < 2e-2 and float((o4 - plain).abs().max()) > 0
