@@ -294,6 +294,38 @@ def test_bf16_kernels_against_the_operand_rounded_evaluation_of_their_own_inputs
             assert rms <= 4e-5 and rms <= 0.1 * rms32 and mx <= 2e-3
 
 
+def test_stchain_bf16_beside_the_six_launch_tail(model, dev, sd_parts):
+    """The token-major bf16 schedule with the fused tail (stchain_kernel<bf16>, two workgroups per CU) and with rgemm's six launches (said_debug_option
+    "st_chain_bf16" = 0): two bf16 evaluations with different rounding points (the fused kernel keeps x1 / x2 in fp32 registers and rounds them only as operands; its
+    K / V window tiles are bf16) — each within the bf16 bound of the fp32 oracle, equally far from it, and no further from each other than from the oracle."""
+    sd_u = sd_parts[2]
+    B, T = 16, 600
+    x = synth.synth_latents(191, (B, T, 32))
+    c = synth.synth_latents(192, (B, T, 768))
+    ts = (torch.arange(B) * 53 + 11) % 1000
+    eng = model._get_engine(B, T)
+    res, used = {}, {}
+    try:
+        model.set_mfma_dtype("bf16")
+        for v in (1, 0):
+            eng.debug_option("st_chain_bf16", v)
+            n0 = eng.debug_get("n_stchain")
+            res[v] = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+            used[v] = eng.debug_get("n_stchain") - n0
+    finally:
+        eng.debug_option("st_chain_bf16", -1)
+        model.set_mfma_dtype("fp32")
+    assert used[1] == 3 and used[0] == 0   # (the last block's tail feeds out_sched_tm's input through the rgemm pair)
+    rms = lambda d, rng: float(d.pow(2).mean().sqrt()) / rng
+    for i in (0, B - 1):
+        ref = ou.unet1d_forward(sd_u, x[i:i + 1], ts[i:i + 1], c[i:i + 1])
+        rng = float(ref.abs().max())
+        e1, e0, e10 = rms(res[1][i:i + 1] - ref, rng), rms(res[0][i:i + 1] - ref, rng), rms(res[1][i:i + 1] - res[0][i:i + 1], rng)
+        m1 = float((res[1][i:i + 1] - ref).abs().max()) / rng
+        print(f"bf16 B={B} sample {i}: fused tail vs fp32 oracle rms {e1:.2e} (max {m1:.2e}), six launches {e0:.2e}, fused vs six launches {e10:.2e} of range")
+        assert m1 <= 2e-2 and e1 <= 1.3 * e0 + 1e-4 and e10 <= 1.5 * max(e1, e0)
+
+
 def test_split_planes_come_from_one_conversion(model, dev):
     """The regression itself, at the API: latents / context chosen so that many LayerNorm / attention outputs cannot be known in advance — instead the
     property is checked where it bites: the fused schedule (packed conversions in its epilogues) against the five-launch one, PER TOKEN.  With the
