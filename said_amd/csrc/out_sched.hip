@@ -112,7 +112,8 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const float* hx, 
 
     // ---- GroupNorm coefficients of the wave's own 24 channels, per half ----
 #pragma unroll
-    for (int h = 0; h < NH; ++h) gn_finish(gp, rp[h], w * OS_CW, OS_CW, l, gl[h], gnS, coefS + h * 2 * OS_C);
+    for (int h = 0; h < NH; ++h)   // (the second sample's scratch is the wave's own, not yet written, staging tile: two independent chains the scheduler can interleave)
+        gn_finish(gp, rp[h], w * OS_CW, OS_CW, l, gl[h], h == 0 ? gnS : xt, coefS + h * 2 * OS_C);
 
     // ---- stage: GroupNorm + SiLU once per element, wave-private LDS tiles ----
 #pragma unroll
