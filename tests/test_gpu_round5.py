@@ -381,6 +381,21 @@ def test_show_process_twice_does_not_start_from_the_previous_count(model, dev):
 
 
 # ---------------------------------------------------------------- bf16 large batch: the step's last kernel against the tested scheduler (VERDICT r4 #3a)
+def _gn_coef_from_partials(st, T, gamma, beta, eps):
+    """GroupNorm(32 groups of 6 channels) coefficients (a, b) per (sample, channel) from a producer's partial statistics [sample][32-token tile][192][(mean, M2)]:
+    what the consuming kernels finalise (gemm_common.h gn_finish) — the statistics of the producer's fp32 values, not of their bf16 store."""
+    Be, npart = st.shape[0], st.shape[1]
+    cnt = torch.tensor([min(32, T - 32 * p) for p in range(npart)], dtype=torch.float64).view(1, npart, 1)
+    mean_pc, m2_pc = st[..., 0].double(), st[..., 1].double()
+    gm = (cnt * mean_pc).view(Be, npart, 32, 6).sum(dim=(1, 3)) / (6 * T)
+    gm_c = gm.repeat_interleave(6, dim=1).view(Be, 1, 192)
+    m2 = (m2_pc + cnt * (mean_pc - gm_c) ** 2).view(Be, npart, 32, 6).sum(dim=(1, 3))
+    rstd = 1.0 / torch.sqrt(m2 / (6 * T) + eps)
+    a = (gamma.double().view(1, 192) * rstd.repeat_interleave(6, dim=1)).float()
+    b = (beta.double().view(1, 192) - gm.repeat_interleave(6, dim=1) * a.double()).float()
+    return a, b   # (Be, 192) each
+
+
 def _ws(eng, name, nbytes_max=None):
     for i, nm, nb in eng.ws_buffers():
         if nm == name:
@@ -422,6 +437,8 @@ def test_stchain_bf16_against_the_operand_rounded_evaluation_of_its_own_inputs(m
         eng.debug_stop_after(k_chain - 1)
         model(x.to(dev), ts.to(dev), c.to(dev))
         xin = rd("tP")
+        npart = (T + 31) // 32
+        st_in = _ws(eng, "stP", B * npart * 192 * 2 * 4).view(torch.float32).view(B, npart, 192, 2).cpu()   # the block input's GroupNorm partials (of the producer's fp32 values)
     finally:
         eng.debug_stop_after(-1)
         model.set_mfma_dtype("fp32")
@@ -440,7 +457,8 @@ def test_stchain_bf16_against_the_operand_rounded_evaluation_of_its_own_inputs(m
     sp = lambda t: t.reshape(T, 6, 32).permute(1, 0, 2)
     worst_frac, worst_rms = 1.0, 0.0
     for i in (0, B - 1):
-        g = F.group_norm(xin[i].t()[None], 32, sd[st + ".norm.weight"], sd[st + ".norm.bias"], eps=1e-6)[0].t()
+        ga, gb = _gn_coef_from_partials(st_in[i:i + 1], T, sd[st + ".norm.weight"], sd[st + ".norm.bias"], 1e-6)
+        g = xin[i] * ga + gb
         x1 = lin(O[i], W(".attn1.to_out.0.weight")) + W(".attn1.to_out.0.bias") + g
         q = lin(lnn(x1), Wq) + bq
         kk = F.linear(c[i], W(".attn2.to_k.weight")).to(torch.bfloat16).float()
@@ -461,6 +479,51 @@ def test_stchain_bf16_against_the_operand_rounded_evaluation_of_its_own_inputs(m
               f"(half a bf16 ulp at the range is {2 ** -9 * 0.5:.1e}); x1 without roundings differs from the emulated x1 by {float((x1p - x1).abs().max()) / rng:.1e}")
         worst_frac, worst_rms = min(worst_frac, same), max(worst_rms, rms)
     assert worst_frac >= 0.97 and worst_rms <= 1.5e-3
+
+
+def test_rgemm_convolutions_bf16_against_the_operand_rounded_evaluation_of_their_own_inputs(model, dev, sd_parts):
+    """The same check for the token-major schedule's ResBlock convolutions (rgemm_kernel: GroupNorm + SiLU on the stored bf16 hidden state, bf16 operands, fp32
+    accumulation, bias + time-embedding row + residual in fp32, bf16 store): first ResBlock, 16 x 600 frames, both convolutions on their own read-back inputs."""
+    import torch.nn.functional as F
+    sd = sd_parts[2]
+    B, T = 16, 600
+    seg = (T + 63) // 64 * 64
+    x = synth.synth_latents(211, (B, T, 32))
+    c = synth.synth_latents(212, (B, T, 768))
+    ts = (torch.arange(B) * 47 + 3) % 1000
+    eng = model._get_engine(B, T)
+    rb = "model.input_blocks.1.0"
+    bufs = {}
+    try:
+        model.set_mfma_dtype("bf16")
+        for k, name in ((2, "tH0"), (3, "tM"), (4, "tP")):   # launch 1 prepares the time-embedding rows; conv_in, conv 1, conv 2 follow (scripts/probe_tm_stages.py)
+            eng.debug_stop_after(k)
+            model(x.to(dev), ts.to(dev), c.to(dev))
+            bufs[name] = _ws(eng, name, B * seg * 192 * 2).view(torch.bfloat16).view(B, seg, 192)[:, :T].float().cpu()
+            assert float(bufs[name].abs().max()) > 0, f"launch {k} did not write {name}: the schedule's launch order changed"
+            npart = (T + 31) // 32
+            bufs["s" + name] = _ws(eng, "s" + name, B * npart * 192 * 2 * 4).view(torch.float32).view(B, npart, 192, 2).cpu()
+    finally:
+        eng.debug_stop_after(-1)
+        model.set_mfma_dtype("fp32")
+    e = F.linear(F.silu(ou.time_embed(sd, ts)), sd[rb + ".emb_layers.1.weight"], sd[rb + ".emb_layers.1.bias"])
+    for i in (0, B - 1):
+        H0, M, P = (bufs[n][i].t()[None] for n in ("tH0", "tM", "tP"))   # (1, 192, T)
+        a0, b0 = _gn_coef_from_partials(bufs["stH0"][i:i + 1], T, sd[rb + ".in_layers.0.weight"], sd[rb + ".in_layers.0.bias"], 1e-5)
+        a1, b1 = _gn_coef_from_partials(bufs["stM"][i:i + 1], T, sd[rb + ".out_layers.0.weight"], sd[rb + ".out_layers.0.bias"], 1e-5)
+        try:
+            ou.ROUND_OPERANDS = "bf16"
+            h = F.silu(H0 * a0[..., None] + b0[..., None])
+            m = ou._conv1d(h, sd[rb + ".in_layers.2.weight"], None, padding=1) + (sd[rb + ".in_layers.2.bias"] + e[i])[None, :, None]
+            h = F.silu(M * a1[..., None] + b1[..., None])
+            p = ou._conv1d(h, sd[rb + ".out_layers.3.weight"], sd[rb + ".out_layers.3.bias"], padding=1) + H0
+        finally:
+            ou.ROUND_OPERANDS = None
+        for name, want, got in (("conv 1 + embedding row", m, M), ("conv 2 + x", p, P)):
+            same = float((want.to(torch.bfloat16).float() == got).float().mean())
+            d = float((got - want).abs().max()) / float(got.abs().max())
+            print(f"rgemm {name:24s} sample {i}: {100 * same:.2f} % of the stored bf16 values are the rounded emulation, max |diff| {d:.2e} of range")
+            assert same >= 0.97 and d <= 8e-3
 
 
 @pytest.mark.parametrize("case", ["cfg", "cfg_eta_mask", "nocfg_eta"])
