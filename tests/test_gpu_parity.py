@@ -761,7 +761,8 @@ def test_loop_large_batch_ragged_length_matches_single_clip_runs(model, sd_full,
         if mode == "fp32":
             assert worst <= tol and worst_big <= 1e-3 and worst_one <= 1e-3
         else:
-            assert worst_big <= tol and worst_one <= tol
+            # (the batch against the single-clip runs is bounded too — two bf16 schedules with different rounding points, two free-running steps: measured 6.7e-2)
+            assert worst_big <= tol and worst_one <= tol and worst <= tol
 
 
 BF16_LOOP2_MAX = 0.09   # two free-running guided steps from pure noise (clamped result in [0, 1]); 1.35x the measured 6.6e-2 (batch) / 4.4e-2 (single clip)
