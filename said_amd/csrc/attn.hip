@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
 #endif
     const AttnView a = {pqk, pv, po, v_bstride, o_bstride, ppitch, pT, pheads, prows, pscale, pb0, po_mode};
     constexpr int D = 32 * ND, NQ = D / 8;   // NQ dwordx4 per lane and operand row
-    constexpr bool BF = PM == 1, SP = PM == 2;
+    constexpr bool BF = PM == 1, SP = PM == 2 || PM == 3, PS = PM == 3;   // PS: K and V arrive split (packed h | l dwords: split_f16.h pack_split_f16)
     const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
     static_assert(QW == 1 || KS == 1, "query-tile waves do not split keys");
     const int w_all = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
         if constexpr (SP) {
             SplitH ks[NQ / 2];
 #pragma unroll
-            for (int q = 0; q < NQ / 2; ++q) ks[q] = split_f16x8(kf[2 * q], kf[2 * q + 1]);
+            for (int q = 0; q < NQ / 2; ++q) ks[q] = PS ? unpack_f16x8(kf[2 * q], kf[2 * q + 1]) : split_f16x8(kf[2 * q], kf[2 * q + 1]);
             operand_fence();
             // Two accumulators: main (k.h q.h) and cross (k.l q.h + k.h q.l, scaled by 2^-11 at the end).  Round 4 believed same-accumulator MFMAs had to be
             // "in rotation over three accumulators" to be bit-stable beside other streams; round 5 found the actual mechanism (a packed-fp32 operand misread in
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * KS * QW) void attn_kernel(const float* pqk, co
                 const f32x4a p0 = {s[8 * m8], s[8 * m8 + 1], s[8 * m8 + 2], s[8 * m8 + 3]}, p1 = {s[8 * m8 + 4], s[8 * m8 + 5], s[8 * m8 + 6], s[8 * m8 + 7]};
                 psa[m8] = split_f16x8(p0, p1);
 #pragma unroll
-                for (int nd = 0; nd < ND; ++nd) vsa[m8][nd] = split_f16x8(vz[nd][2 * m8], vz[nd][2 * m8 + 1]);
+                for (int nd = 0; nd < ND; ++nd) vsa[m8][nd] = PS ? unpack_f16x8(vz[nd][2 * m8], vz[nd][2 * m8 + 1]) : split_f16x8(vz[nd][2 * m8], vz[nd][2 * m8 + 1]);
             }
             operand_fence();
 #pragma unroll
@@ -638,6 +638,7 @@ void configure_attn_kernels() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     configure_attn_modes<0>(); configure_attn_modes<1>(); configure_attn_modes<2>();
+    configure_attn_one<1, 8, 3>(); configure_attn_one<1, 4, 3>();
 }
 
 template <int PM>
@@ -654,8 +655,14 @@ static bool launch_attn_mode(const AttnArgs& a, int batch, int head_dim, int KS,
     if (head_dim == 64 && KS == 1) return launch_attn_one<2, 1, PM>(a, batch, s), true;
     return false;
 }
-// mode: 0 fp32 MFMA, 1 bf16 operands, 2 split-fp16 operands (attn_kernel's PM)
+// mode: 0 fp32 MFMA, 1 bf16 operands, 2 split-fp16 operands, 3 split-fp16 operands with K and V stored pre-split by the q/k/v GEMM (head_dim 32, key-split shapes only)
 void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s, int mode) {
+    if (mode == 3) {
+        if (head_dim == 32 && KS == 8) { launch_attn_one<1, 8, 3>(a, batch, s); return; }
+        if (head_dim == 32 && KS == 4) { launch_attn_one<1, 4, 3>(a, batch, s); return; }
+        launch_fault("pre-split attention operands: unsupported config D=%d KS=%d", head_dim, KS);
+        return;
+    }
     const bool ok = mode == 1 ? launch_attn_mode<1>(a, batch, head_dim, KS, s) : (mode == 2 ? launch_attn_mode<2>(a, batch, head_dim, KS, s) : launch_attn_mode<0>(a, batch, head_dim, KS, s));
     if (!ok) launch_fault("unsupported attention config D=%d KS=%d", head_dim, KS);
 }

@@ -180,6 +180,8 @@ struct said_ctx {
                               // round 5 found the mechanism in OTHER kernels' packed-fp32 instructions (split_f16.h, build.py NO_SLP) and removed it.
     int gemm_split = -1;      // fp32 mode: the large-batch token-major GEMMs (fgemm_kernel) on split-fp16 operands (tgemm.hip: SP).  Default (-1) and 1: ON since round 5
                               // (as above); 0: fp32 MFMAs (said_debug_option "gemm_split").
+    int attn_presplit = -1;   // fp32 small batch: the q/k/v GEMM stores k and v as packed split-fp16 pairs and attn_kernel<PM = 3> unpacks them instead of splitting all of K and V
+                              // again in each of a sample's query-tile workgroups (-1 / 1: on; 0: off — said_debug_option "attn_presplit")
     int out_split = -1;       // out_sched_kernel's convolution on split-fp16 operands (-1 / 1: on; 0: fp32 matrix instructions — said_debug_option "out_split")
     int ugemm_split = -1;     // fp32 mode: the small-batch channel-major GEMMs (ugemm_kernel) on split-fp16 operands too (gemm_lds.hip: SP; weights pre-split on the host:
                               // Seg::ws).  Default (-1) and 1: ON; 0: fp32 MFMAs (said_debug_option "ugemm_split")
@@ -629,11 +631,12 @@ void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS,
         else if (sp) launch_ugemm(a2, epi, batch, NB, KS, s, 2);
         else if (ug && bf && ugemm_supports(a2, epi, NB, KS, true)) launch_ugemm(a2, epi, batch, NB, KS, s, true);
         else if (ug && ugemm_supports(a2, epi, NB, KS)) launch_ugemm(a2, epi, batch, NB, KS, s);
+        else if (epi == EPI_QKV && a2.kv_split) c->launch_err = "q/k/v GEMM asked for pre-split k / v but does not run on ugemm_kernel";
         else launch_gemm(a2, epi, batch, NB, KS, s);
         if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
     }
 }
-void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s) {
+void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s, bool presplit = false) {
     if (c->log_on) {
         const double e = (double)batch * a.heads * head_dim * a.T;
         c->stage_log.push_back({1, -1, head_dim / 32, KS, 4.0 * e * 4.0, 4.0 * e * a.T});
@@ -642,7 +645,7 @@ void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hi
         if (trace_on()) { fprintf(stderr, "[said] attn #%d D=%d KS=%d T=%d batch=%d\n", c->dbg_count - 1, head_dim, KS, a.T, batch); fflush(stderr); }
         AttnArgs a2 = a;
         a2.b0 = c->cur_b0;
-        launch_attn(a2, batch, head_dim, KS, s, c->bf16_mode ? 1 : (c->attn_split != 0 ? 2 : 0));
+        launch_attn(a2, batch, head_dim, KS, s, c->bf16_mode ? 1 : (c->attn_split != 0 ? (presplit ? 3 : 2) : 0));
         if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
     }
 }
@@ -1173,6 +1176,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     const bool chain = !c->bf16_mode && c->st_chain != 0 && c->use_ugemm && sw.chain_w && sw.chain_vec && c->band_chain_ok && c->cur_b0 == 0 && !c->use_branches &&
                        ((!tg && !use_tg(c, g, g.Be)) || c->st_chain_large) && tt <= c->st_chain_max_tiles && g.S == c->band_S && g.T == c->band_T;
     const bool out1_tm = tg && !chain && !c->bf16_mode && c->f32_out1_tm && tt1 * HEADS >= 2048 && sw.tf_out1;
+    bool presplit = false;   // k and v stored as packed split-fp16 pairs for attn_kernel<PM = 3> (see below)
     if (tg) {   // q, k, v on the bf16 token-major GEMM: operand = LayerNorm(GroupNorm(x)) prepared once
         PrepArgs p = mkprep(g, in.p, 1, c->uPL, (long long)tg_rows(g) * MC, MC, 0);
         prep_gn(c, p, g, in.st, 6, 1e-6f, sw.gn_g, sw.gn_b, n1, 0, s);
@@ -1206,6 +1210,15 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
             }
         }
         const LaunchCfg lc = big_qkv ? LaunchCfg{6, 4} : LaunchCfg{qkv_nb, 8};
+        // k and v pre-split for the key-split attention shapes (same rule as below), when this GEMM runs on ugemm_kernel (the only epilogue that packs)
+        {
+            const bool key_split = !(tt1 * HEADS >= 2048) && !(tt1 * HEADS > 8192) && !dev_env("SAID_ATTN_KS") && !dev_env("SAID_NO_ATTN_QW");
+            GemmArgs probe = a;
+            probe.b0 = c->cur_b0;
+            presplit = !c->bf16_mode && c->attn_split != 0 && c->attn_presplit != 0 && key_split && c->use_ugemm && !big_qkv && !c->clk_on &&
+                       (ugemm_supports(probe, EPI_QKV, lc.NB, lc.KS, 2) || ugemm_supports(probe, EPI_QKV, lc.NB, lc.KS));
+            a.kv_split = presplit ? 1 : 0;
+        }
         do_gemm(c, a, EPI_QKV, n1, lc.NB, lc.KS, s);
     }
     bool out1_done = false;
@@ -1222,7 +1235,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         static const bool no_qw = dev_env("SAID_NO_ATTN_QW") != nullptr;
         const int attn_ks = (!no_qw && tt1 * HEADS >= 2048) ? -4 : ((tt1 * HEADS > 8192) ? 1 : ((g.T <= 256 && tt1 * HEADS <= 2048) ? 8 : 4));
         if (out1_tm && !attn_ks_env && attn_ks == -4) { a.o = static_cast<float*>(c->uPL); a.o_bstride = tg_rows(g); a.o_mode = 1; }
-        do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s);
+        do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s, presplit && (attn_ks == 4 || attn_ks == 8));
         out1_done = a.o_mode == 1;
     }
     if (chain && !out1_done) {
@@ -2608,6 +2621,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->gemm_split = value < 0 ? -1 : (value != 0);
     } else if (k == "attn_split") {
         ctx->attn_split = value < 0 ? -1 : (value != 0);
+    } else if (k == "attn_presplit") {
+        ctx->attn_presplit = value < 0 ? -1 : (value != 0);
     } else if (k == "out_split") {
         ctx->out_split = value < 0 ? -1 : (value != 0);
     } else if (k == "ugemm_split") {

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "gemm_common.h"
+#include "split_f16.h"
 
 namespace said {
 
@@ -923,6 +924,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             const int vdim = AH(vt_dim);
             const int vn = tile * 32 + lt;
             const int h = vn >> __builtin_ctz(vdim), d = vn & (vdim - 1);   // head_dim is a power of two (host checks)
+            if (AH(kv_split) && 2 * h >= AH(vt_heads)) val = pack_split_f16(val);   // (k heads: the second half of vt's head axis)
             if (t < aT && nl < aN)
                 gstore(AH(vt), (((long long)b * AH(vt_heads) + h) * AH(vt_rows) + t) * vdim + d, val);
             continue;
@@ -971,6 +973,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                 val += rv;
             }
         }
+        if (EPI == EPI_QKV && AH(kv_split)) val = pack_split_f16(val);   // (v tiles)
         if (ok) gstore(yp, (long long)b * y_bs + (long long)ng * y_pitch + t, val);
         if constexpr (DUP) {
             float add2 = 0.f;

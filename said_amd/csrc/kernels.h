@@ -106,6 +106,7 @@ struct GemmCommon {        // 8-byte members first, then 4-byte ones: no interna
             float* vt;     // = 2 * heads (q heads, then k heads); the remaining tiles (v) go to y channel-major with
             int vt_heads, vt_dim, vt_rows;   // channel index n - 32 * tm_tiles (rows = padded T of the vt buffer).  This is
             int tm_tiles;  // the operand layout attn.hip fetches with dwordx4.
+            int kv_split;  // 1: k and v elements are stored as packed split-fp16 pairs (split_f16.h pack_split_f16) for attn_kernel<PM = 3>
         };
         struct {           // EPI_STORE: optional second copy of the result, y2[b][n][t] = y[b][n][t] + y2_add[n]
             float* y2;     // (same pitch as y).  Under classifier-free guidance the unconditional half's cross-attention

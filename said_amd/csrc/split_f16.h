@@ -43,6 +43,28 @@ static __device__ __forceinline__ SplitH split_f16x8(const f32x4s a, const f32x4
     }
     return r;
 }
+// A split operand element as ONE dword (h in the low half, l in the high half): what a producer stores when every consumer would split the value again
+// (the q/k/v GEMM's k and v tiles: each of a sample's 19 query-tile workgroups used to split all of K and V for itself — attn.hip PM = 3).
+static __device__ __forceinline__ float pack_split_f16(float x) {
+    _Float16 h = (_Float16)x;
+    asm volatile("" : "+v"(h));
+    const _Float16 lo = (_Float16)((x - (float)h) * 2048.f);
+    const unsigned u = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+    return __builtin_bit_cast(float, u);
+}
+// eight packed elements -> the two MFMA operand planes: one v_perm_b32 per two elements and plane
+static __device__ __forceinline__ SplitH unpack_f16x8(const f32x4s a, const f32x4s b) {
+    typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+    const u32x4s ua = __builtin_bit_cast(u32x4s, a), ub = __builtin_bit_cast(u32x4s, b);
+    const u32x4s hh = {__builtin_amdgcn_perm(ua[1], ua[0], 0x05040100u), __builtin_amdgcn_perm(ua[3], ua[2], 0x05040100u),
+                       __builtin_amdgcn_perm(ub[1], ub[0], 0x05040100u), __builtin_amdgcn_perm(ub[3], ub[2], 0x05040100u)};
+    const u32x4s ll = {__builtin_amdgcn_perm(ua[1], ua[0], 0x07060302u), __builtin_amdgcn_perm(ua[3], ua[2], 0x07060302u),
+                       __builtin_amdgcn_perm(ub[1], ub[0], 0x07060302u), __builtin_amdgcn_perm(ub[3], ub[2], 0x07060302u)};
+    SplitH r;
+    r.h = __builtin_bit_cast(f16x8a, hh);
+    r.l = __builtin_bit_cast(f16x8a, ll);
+    return r;
+}
 // HISTORY (round 4 -> round 5).  With these kernels on, runs next to other streams of this engine were not bit-stable (a few clips off by 1e-4 .. 5e-2, never
 // alone); round 4 derived issue-order rules for v_mfma_f32_32x32x16_f16 from soaks ("rotation over three accumulators", "operand fence with idle slots") and could
 // not prove them.  Round 5 localised the damage (scripts/race_localise.py) and it was never in these kernels: it was in OTHER kernels' waves sharing the SIMD — a

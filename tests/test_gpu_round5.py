@@ -326,6 +326,32 @@ def test_stchain_bf16_beside_the_six_launch_tail(model, dev, sd_parts):
         assert m1 <= 2e-2 and e1 <= 1.3 * e0 + 1e-4 and e10 <= 1.5 * max(e1, e0)
 
 
+@pytest.mark.parametrize("B,T", [(2, 600), (1, 37), (3, 333), (2, 1800)])
+def test_presplit_kv_attention_matches_splitting_in_the_attention_kernel(model, dev, sd_parts, B, T):
+    """fp32 small batch: the q/k/v GEMM stores k and v as packed split-fp16 pairs (one split per element) and attn_kernel<PM = 3> unpacks them, instead of every
+    query-tile workgroup splitting all of K and V again (said_debug_option "attn_presplit" = 0).  The same h / l planes reach the same MFMAs — up to the one
+    element in 8192 where the scalar conversion of the GEMM's epilogue and the packed conversion of the attention kernel round a tie differently — so the two
+    agree far below the oracle bound; both against the oracle."""
+    sd_u = sd_parts[2]
+    x = synth.synth_latents(221, (B, T, 32))
+    c = synth.synth_latents(222, (B, T, 768))
+    ts = (torch.arange(B) * 331 + 7) % 1000
+    eng = model._get_engine(max(B, 2), T)
+    res = {}
+    for v in (1, 0):
+        eng.debug_option("attn_presplit", v)
+        try:
+            res[v] = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
+        finally:
+            eng.debug_option("attn_presplit", -1)
+    ref = ou.unet1d_forward(sd_u, x, ts, c)
+    rng = float(ref.abs().max())
+    d10 = float((res[1] - res[0]).abs().max()) / rng
+    e1, e0 = float((res[1] - ref).abs().max()) / rng, float((res[0] - ref).abs().max()) / rng
+    print(f"pre-split k / v B={B} T={T}: vs splitting in the kernel {d10:.2e} of range; vs oracle {e1:.2e} (off: {e0:.2e})")
+    assert d10 <= 2e-6 and e1 <= 1e-4 and e0 <= 1e-4
+
+
 def test_split_planes_come_from_one_conversion(model, dev):
     """The regression itself, at the API: latents / context chosen so that many LayerNorm / attention outputs cannot be known in advance — instead the
     property is checked where it bites: the fused schedule (packed conversions in its epilogues) against the five-launch one, PER TOKEN.  With the
