@@ -27,6 +27,8 @@ def main():
     sd["null_cond_emb"] = synth.fill_tensor("null_cond_emb", (1, 1, 768))
     eng = _engine.Engine(dev, max(B, 2), max(T, S, 64))
     eng.load_weights(sd)
+    eng.debug_option("st_chain", 0)        # the stage list below is the five-launch tail's (rounds 1-4); round 5's fused tail has no intermediate buffers to read
+    eng.debug_option("attn_presplit", 0)   # QK / VT as plain fp32 (round 5 stores k and v as packed split-fp16 pairs otherwise)
     x = synth.synth_latents(21, (B, T, 32))
     c = synth.synth_latents(121, (B, S, 768))
     ts = torch.tensor([999, 17, 500, 3][:B])
