@@ -111,9 +111,11 @@ struct said_ctx {
     float *KV = nullptr, *CTX = nullptr;
     float* KVT = nullptr;        // key-major copy of KV [sample][S][NST * 2 * MC] for the fused SpatialTransformer tail (stchain.hip), made by run_kv
     bool band_chain_ok = false;  // the alignment band fits stchain's window tile (set_band)
+    bool band_chain2_ok = false; // ... and the two-tile bf16 variant's (pairs of tiles: CHAIN2_KW rows)
     bool st_chain_large = true;  // ... at large batches too, beside the token-major q / k / v GEMM (32 clips: 3.2 -> 2.4 ms per step; said_debug_option "st_chain_large")
     long long st_chain_max_tiles = 1LL << 40;   // ... while the launch is at most this many workgroups (sample x 32-token tiles; said_debug_option "st_chain_max_tiles")
-    int st_chain_bf16 = -1;      // bf16 mode, large batches: the same fused tail on bf16 operands (stchain_kernel<true>) instead of rgemm's five launches; 0: off
+    int st_chain_bf16 = -1;      // bf16 mode, large batches: the same fused tail on bf16 operands instead of rgemm's five launches; 0: off; -1 / 1: stchain_kernel<true> (one token tile per
+                                 // workgroup, two workgroups per CU); 2: stchain2_kernel (two tiles per workgroup sharing every weight fragment: measured slower, 96 vs 83 us)
                                  // (said_debug_option "st_chain_bf16")
     bool st_chain_dbg = false;   // debug: the fused kernel also writes x1 / x2 to X1 / X2
     int st_chain = -1;           // fp32 mode, small batches: everything behind self-attention as ONE launch per block (stchain.hip); 0: the five launches
@@ -908,7 +910,7 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
             c->stage_log.push_back({10, EPI_STORE, 6, 8, w + io, fl});
         }
         if (dbg_go(c)) {
-            launch_stchain(ca, static_cast<const float*>(c->tO), static_cast<const float*>(in.t), g.T, g.Tp, seg * MC, seg * MC, shared ? g.Bc : 0, g.Bc > 0 ? g.Bc : 0, g.Be, s, true);
+            launch_stchain(ca, static_cast<const float*>(c->tO), static_cast<const float*>(in.t), g.T, g.Tp, seg * MC, seg * MC, shared ? g.Bc : 0, g.Bc > 0 ? g.Bc : 0, g.Be, s, true, c->st_chain_bf16 == 2 && c->band_chain2_ok);
             ++c->n_stchain;
         }
         return;
@@ -1545,6 +1547,12 @@ int set_band(said_ctx* ctx, int T, int S, hipStream_t s) {
             ok = hmax - lo[t0] <= CHAIN_KW;
         }
         ctx->band_chain_ok = ok;
+        for (int t0 = 0; t0 < T && ok; t0 += 64) {   // stchain2_kernel: one window tile per PAIR of token tiles
+            int hmax = 0;
+            for (int i = t0; i < std::min(T, t0 + 64); ++i) hmax = std::max(hmax, hi[i]);
+            ok = hmax - lo[t0] <= CHAIN2_KW;
+        }
+        ctx->band_chain2_ok = ok;
     }
     return 0;
 }
@@ -2632,7 +2640,7 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
     } else if (k == "st_chain_dbg") {
         ctx->st_chain_dbg = value != 0;
     } else if (k == "st_chain_bf16") {
-        ctx->st_chain_bf16 = value < 0 ? -1 : (value != 0);
+        ctx->st_chain_bf16 = value < 0 ? -1 : (value > 2 ? 2 : (int)value);   // 0 off, 1 (= default) one tile per workgroup, 2 two tiles per workgroup
     } else if (k == "st_chain_large") {
         ctx->st_chain_large = value != 0;
     } else if (k == "st_chain_max_tiles") {

@@ -6,6 +6,7 @@ namespace said {
 
 constexpr int CHAIN_KW = 56;                    // key rows of the cross-attention window tile kept in LDS per 32-token tile: the tile's windows must fit
                                                 // (engine.cpp: set_band checks max(hi) - lo[t0] <= CHAIN_KW per tile, else the five-launch schedule runs)
+constexpr int CHAIN2_KW = 88;                   // ... of a PAIR of tiles in the two-tile bf16 variant (stchain2_kernel)
 constexpr size_t CHAIN_STREAM_UNITS = 4 * 168 + 2 * 138 + 2 * 102;
 constexpr size_t CHAIN_STREAM_BYTES = CHAIN_STREAM_UNITS * 2048;   // 2 KB units (one k16 step: h + l fragments) of the eight waves' streams: 2,359,296 per transformer block
 constexpr int CHAIN_VEC_FLOATS = 5 * 192 + 1536;        // global: b1, bq, bo2, c2, bffp (192 each), bff (1536: value rows, then gate rows)
@@ -40,7 +41,7 @@ bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long
 // bf16 = true (bf16 mode, large batches): o, xin and y are TOKEN-major bf16 [sample][row][192] (o_bs / x_bs / y_bs in elements, pitch unused), wstream the bf16 stream
 // (1 KB units), every product one v_mfma_f32_32x32x16_bf16 on operands rounded to bf16; statistics, LayerNorm, softmax, residual sums stay fp32.
 void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s,
-                    bool bf16 = false);
+                    bool bf16 = false, bool two_tiles = false);   // two_tiles (bf16 only): stchain2_kernel, two token tiles per workgroup (window rows per tile pair <= CHAIN2_KW)
 void configure_stchain_kernel();
 
 }  // namespace said

@@ -750,6 +750,486 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
     clk_stamp_c(clk, w, l, 10);
 }
 
+// ==================================================================================================================================================
+// stchain2 — the bf16 variant with TWO token tiles per workgroup (tiles 2 x, 2 x + 1 of a sample), one workgroup per CU.  MEASURED SLOWER than stchain_kernel<true> at two
+// workgroups per CU (96 against 83 us per launch at 32 clips: profiles/r05p_stchain2_two_tiles_ab.txt) and therefore NOT the default (said_debug_option "st_chain_bf16" = 2
+// selects it; bit-identical results, tests/test_gpu_round5.py): with bf16 operands the weight stream (9.5 us per workgroup) and the matrix pipe (9 us for two tiles) are not
+// what bounds the tail — the prologue, the LayerNorm exchanges and the LDS-bound band products are, and those this variant runs twice per workgroup with nothing beside them,
+// where two independent workgroups per CU cover each other's.  Kept as the measured counter-example to "share the weight fragments".  Every weight fragment a wave pulls through the
+// CU's L2 port multiplies both tiles (two MFMAs per unit): the 1.18 MB stream per workgroup serves 64 tokens instead of 32, which is what bounds the one-tile variant at
+// large batches (1.4 GB of L2 reads per launch at 32 clips).  256 VGPRs again, so the ring is 16 units deep.  Same weight stream, same roles, same barrier structure; the
+// per-tile stages simply run twice.  LDS: GEGLU product planes 2 x 49,664 (before GEGLU: the K / V window tiles of the 64 tokens in bf16, CH2_KW rows, and behind them the
+// tables that are dead by then), 2 x 2 activation planes, bff: 156,672 B.
+// ==================================================================================================================================================
+static_assert(CHAIN2_KW == 88, "stchain.h");
+constexpr int CH2_KW = CHAIN2_KW;      // key rows of the 64-token window tile (engine.cpp set_band: max(hi) - lo[first token] over each pair of tiles)
+constexpr int CH_NR_BF2 = 16;
+struct Carve2 {
+    static constexpr int KV = CH2_KW * CH_KP * 2 * 2;
+    static constexpr int R0 = 0, GNC = KV, LNP = GNC + 384 * 4, VEC = LNP + 2 * (32 * 6 * 2 * 4);
+    static constexpr int R1 = 2 * CH_HPL, R2 = R1 + 2 * CH_APL, BFF = R2 + 2 * CH_APL, LDS = BFF + 1536 * 4;
+    static_assert(VEC + 3 * 192 * 4 <= 2 * CH_HPL, "the early tables fit behind the K / V tiles");
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+template <int MODE, int NR, int Q0, int NS>
+__device__ __forceinline__ void gemm_run2(Ring<NR>& R, const WStream& wp, const char* b0, const char* b1, f32x16& a0, f32x16& a1) {
+    f16x8 x0 = *reinterpret_cast<const f16x8*>(b0), x1 = *reinterpret_cast<const f16x8*>(b1);
+    sfor<0, NS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        f16x8 n0 = x0, n1 = x1;
+        if constexpr (s + 1 < NS) {
+            n0 = *reinterpret_cast<const f16x8*>(b0 + 32 * (s + 1));
+            n1 = *reinterpret_cast<const f16x8*>(b1 + 32 * (s + 1));
+        }
+        const bf16x8c wf = __builtin_bit_cast(bf16x8c, R.h[(Q0 + s) % NR]);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8c, x0), a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8c, x1), a1, 0, 0, 0);
+        ring_issue<MODE, true, NR, Q0 + s + NR>(R, wp);
+        __builtin_amdgcn_sched_barrier(0);
+        x0 = n0; x1 = n1;
+    });
+}
+template <int MODE, int NR, int Q0>
+__device__ __forceinline__ void geglu_run2(Ring<NR>& R, const WStream& wp, const char* b0, const char* b1, f32x16 (&av)[2], f32x16 (&ag)[2]) {
+    f16x8 x0 = *reinterpret_cast<const f16x8*>(b0), x1 = *reinterpret_cast<const f16x8*>(b1);
+    sfor<0, 12>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        f16x8 n0 = x0, n1 = x1;
+        if constexpr (s + 1 < 12) {
+            n0 = *reinterpret_cast<const f16x8*>(b0 + 32 * (s + 1));
+            n1 = *reinterpret_cast<const f16x8*>(b1 + 32 * (s + 1));
+        }
+        constexpr int qv = Q0 + 2 * s, qg = Q0 + 2 * s + 1;
+        const bf16x8c wv = __builtin_bit_cast(bf16x8c, R.h[qv % NR]), wg = __builtin_bit_cast(bf16x8c, R.h[qg % NR]);
+        av[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8c, x0), av[0], 0, 0, 0);
+        ag[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg, __builtin_bit_cast(bf16x8c, x0), ag[0], 0, 0, 0);
+        av[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8c, x1), av[1], 0, 0, 0);
+        ag[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg, __builtin_bit_cast(bf16x8c, x1), ag[1], 0, 0, 0);
+        ring_issue<MODE, true, NR, qv + NR>(R, wp);
+        ring_issue<MODE, true, NR, qg + NR>(R, wp);
+        __builtin_amdgcn_sched_barrier(0);
+        x0 = n0; x1 = n1;
+    });
+}
+// LayerNorm statistics of both tiles' tokens with ONE barrier (ln_stats per tile otherwise)
+__device__ __forceinline__ void ln_stats2(const float (&v)[2][16], float* lnp, int j, int lt, int lh, float2 (&out)[2]) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += v[ti][r];
+        const float m16 = s * 0.0625f;
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = v[ti][r] - m16; q = fmaf(d, d, q); }
+        const float mo = __shfl_xor(m16, 32), qo = __shfl_xor(q, 32);
+        const float dl = mo - m16;
+        const float m32 = 0.5f * (m16 + mo), q32 = q + qo + dl * dl * 8.f;
+        if (lh == 0) { lnp[ti * 384 + (lt * 6 + j) * 2] = m32; lnp[ti * 384 + (lt * 6 + j) * 2 + 1] = q32; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const float* lp = lnp + ti * 384 + (lt * 6) * 2;
+        float mean = lp[0], M2 = lp[1];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) {
+            const float mk = lp[2 * k], qk = lp[2 * k + 1];
+            const float d = mk - mean;
+            const float n = 32.f * (float)k, nn = n + 32.f;
+            mean = fmaf(d, 32.f / nn, mean);
+            M2 += qk + d * d * (n * 32.f / nn);
+        }
+        out[ti] = make_float2(mean, __builtin_amdgcn_rsqf(M2 * (1.0f / 192.f) + 1e-5f));
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void chain_body2(const ChainHdr& hd, const ChainArgs& a, char* smem, int w, int l, int s_idx, int in_idx, int t0) {
+    constexpr int NR = CH_NR_BF2;
+    using CV = Carve2;
+    const int tid = threadIdx.x;
+    const int lt = l & 31, lh = l >> 5;
+    const int j = w;
+    const int col0 = 32 * j + 4 * lh;
+    const int tt[2] = {t0 + lt, t0 + 32 + lt};
+    const bool tv[2] = {tt[0] < hd.T, tt[1] < hd.T};
+    char* const r1h = smem + CV::R1;
+    char* const r2h = smem + CV::R2;
+    char* const hh = smem + CV::R0;
+    const float* vec = reinterpret_cast<const float*>(smem + CV::VEC);
+    const float* gnc = reinterpret_cast<const float*>(smem + CV::GNC);
+    float* lnp = reinterpret_cast<float*>(smem + CV::LNP);
+    const int browA = lt * (CH_AP * 2) + 16 * lh;
+    const int browH = lt * (CH_HP * 2) + 16 * lh;
+    const int wrowA = lt * (CH_AP * 2), wrowH = lt * (CH_HP * 2);
+    const int w_units = w < 4 ? U_END : (w < 6 ? U_W45 : U_W67);
+    const int w_first = w < 4 ? w * U_END : (w < 6 ? 4 * U_END + (w - 4) * U_W45 : 4 * U_END + 2 * U_W45 + (w - 6) * U_W67);
+    const WStream wp = {make_rsrc(reinterpret_cast<const char*>(hd.wstream) + (long long)w_first * 1024, (unsigned)w_units * 1024u), l * 16};
+    Ring<NR> R;
+    int kmin = 0;
+    if constexpr (MODE == 0) kmin = cload(hd.lo, min(t0, hd.T - 1));
+    if constexpr (MODE == 2) {
+        const bool uncond = s_idx < hd.n_uncond;
+        constexpr int KVL = 26;
+        f32x4 kvv[KVL];
+        int kv_n = 0;
+        const int l2 = (w - 6) * 64 + l;
+        const rsrc_t rkv = make_rsrc(a.kvt + (long long)s_idx * a.kvt_bs, (unsigned)a.S * 1536u * 4u);
+        auto kv_walk = [&](int i0, auto&& f) {
+            int idx0 = l2 + 128 * i0;
+            int key = (int)(((unsigned)idx0 * 43691u) >> 22), f4 = idx0 - key * 96;
+            const int lastk = (kv_n - 1) / 96, lastf = (kv_n - 1) - lastk * 96;
+#pragma unroll
+            for (int i = 0; i < KVL; ++i) {
+                const bool in = (key * 96 + f4) < kv_n;
+                const int k = in ? key : lastk, p4 = in ? f4 : lastf;
+                f(i, k, p4);
+                f4 += 32; key += 1;
+                if (f4 >= 96) { f4 -= 96; key += 1; }
+            }
+        };
+        auto kv_issue = [&](int i0) {
+            kv_walk(i0, [&](int i, int k, int p4) {
+                kvv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rkv, ((kmin + k) * 1536 + a.koff + 4 * p4) * 4, 0, 0));
+            });
+        };
+        auto kv_park = [&](int i0) {
+            __bf16* kt = reinterpret_cast<__bf16*>(smem + CV::R0);
+            kv_walk(i0, [&](int i, int k, int p4) {
+                const int e = (p4 < 48 ? 0 : CH2_KW * CH_KP) + k * CH_KP + 4 * (p4 < 48 ? p4 : p4 - 48);
+                bf16x4c b;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[q] = (__bf16)kvv[i][q];
+                *reinterpret_cast<bf16x4c*>(kt + e) = b;
+            });
+        };
+        if (!uncond) {
+            kmin = cload(hd.lo, min(t0, hd.T - 1));
+            kv_n = (min(cload(hd.lo, min(t0 + 63, hd.T - 1)) + hd.wmax - kmin, CH2_KW)) * 96;
+            kv_issue(0);
+        }
+        __syncthreads();   // operands staged
+        if (!uncond) {
+            kv_park(0);
+            for (int i0 = KVL; i0 * 128 < kv_n; i0 += KVL) { kv_issue(i0); kv_park(i0); }
+        }
+        sfor<0, NR>([&](auto qc) { ring_issue<MODE, true, NR, decltype(qc)::value>(R, wp); });
+        if (!uncond) {
+            __syncthreads();
+            __syncthreads();
+            __syncthreads();
+        }
+        __syncthreads();
+        __syncthreads();
+    } else {
+        // ---- requests ----
+        f32x4 ov[2][2], xv4[2][2];
+        const int prow0 = (tid * 2731) >> 16, ppc0 = tid - 24 * prow0;
+        const int prow1 = ((tid + 384) * 2731) >> 16, ppc1 = (tid + 384) - 24 * prow1;
+        {
+            const rsrc_t ro = make_rsrc(reinterpret_cast<const char*>(hd.o) + (long long)in_idx * hd.o_bs * 2, (unsigned)hd.T * 384u);
+            const rsrc_t rxin = make_rsrc(reinterpret_cast<const char*>(hd.xin) + (long long)in_idx * hd.x_bs * 2, (unsigned)hd.T * 384u);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                ov[ti][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, (t0 + 32 * ti + prow0) * 384 + ppc0 * 16, 0, 0));
+                ov[ti][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, (t0 + 32 * ti + prow1) * 384 + ppc1 * 16, 0, 0));
+                xv4[ti][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxin, (t0 + 32 * ti + prow0) * 384 + ppc0 * 16, 0, 0));
+                xv4[ti][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxin, (t0 + 32 * ti + prow1) * 384 + ppc1 * 16, 0, 0));
+            }
+        }
+        GnL20 gl;
+        const GnP gp = {6, a.np, hd.T, 1e-6f, a.gn_gamma, a.gn_beta, 192};
+        const rsrc_t rpart = make_rsrc(a.xin_part + (long long)in_idx * a.part_bs, 192u * (unsigned)a.np * 8u);
+        if (w < 4) gn20_issue(gp, rpart, 48 * w, l, gl);
+        int blo[2] = {0, 0}, bhi[2] = {0, 0};
+        if constexpr (MODE == 0) {
+            const rsrc_t rlo = make_rsrc(hd.lo, (unsigned)hd.T * 4u), rhi = make_rsrc(a.hi, (unsigned)hd.T * 4u);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                blo[ti] = __builtin_bit_cast(int, bload(rlo, tv[ti] ? tt[ti] * 4 : (int)0x80000000, 0));
+                bhi[ti] = __builtin_bit_cast(int, bload(rhi, tv[ti] ? tt[ti] * 4 : (int)0x80000000, 0));
+            }
+        }
+        f32x4 vecv[2];
+        {
+            const rsrc_t rvec = make_rsrc(a.vec, (unsigned)CHAIN_VEC_FLOATS * 4u);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = tid + 384 * k;
+                const int gi = (i < 96) ? i : ((i < 144) ? (MODE == 1 ? i + 48 : i) : i + 48);
+                vecv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rvec, (i < CHAIN_VEC_FLOATS_LDS / 4) ? gi * 16 : (int)0x80000000, 0, 0));
+            }
+        }
+        sfor<0, NR>([&](auto qc) { ring_issue<MODE, true, NR, decltype(qc)::value>(R, wp); });
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            *reinterpret_cast<f32x4*>(r1h + ti * CH_APL + prow0 * (CH_AP * 2) + ppc0 * 16) = ov[ti][0];
+            *reinterpret_cast<f32x4*>(r1h + ti * CH_APL + prow1 * (CH_AP * 2) + ppc1 * 16) = ov[ti][1];
+            *reinterpret_cast<f32x4*>(r2h + ti * CH_APL + prow0 * (CH_AP * 2) + ppc0 * 16) = xv4[ti][0];
+            *reinterpret_cast<f32x4*>(r2h + ti * CH_APL + prow1 * (CH_AP * 2) + ppc1 * 16) = xv4[ti][1];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + 384 * k;
+            if (i < 144) reinterpret_cast<f32x4*>(smem + CV::VEC)[i] = vecv[k];
+            else if (i >= 192 && i < CHAIN_VEC_FLOATS_LDS / 4) reinterpret_cast<f32x4*>(smem + CV::BFF)[i - 192] = vecv[k];
+        }
+        if (w < 4) gn20_finish(gp, rpart, 48 * w, l, gl, reinterpret_cast<float*>(smem + CV::R0) + w * GN_SCRATCH, reinterpret_cast<float*>(smem + CV::GNC));
+        __syncthreads();
+        // ---- to_out1 + GroupNorm'ed residual ----
+        f32x16 acc[2];
+        zero16(acc[0]); zero16(acc[1]);
+        gemm_run2<MODE, NR, U_G1, 12>(R, wp, r1h + browA, r1h + CH_APL + browA, acc[0], acc[1]);
+        float x1[2][16];
+        {
+            float b1[16];
+            get_vec(vec, col0, b1);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                float xr[16];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const bf16x4c xb = *reinterpret_cast<const bf16x4c*>(r2h + ti * CH_APL + wrowA + (col0 + 8 * m) * 2);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xr[4 * m + i] = (float)xb[i];
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(gnc + 2 * (col0 + 8 * m)), c1 = *reinterpret_cast<const f32x4*>(gnc + 2 * (col0 + 8 * m) + 4);
+                    x1[ti][4 * m + 0] = acc[ti][4 * m + 0] + (b1[4 * m + 0] + fmaf(xr[4 * m + 0], c0[0], c0[1]));
+                    x1[ti][4 * m + 1] = acc[ti][4 * m + 1] + (b1[4 * m + 1] + fmaf(xr[4 * m + 1], c0[2], c0[3]));
+                    x1[ti][4 * m + 2] = acc[ti][4 * m + 2] + (b1[4 * m + 2] + fmaf(xr[4 * m + 2], c1[0], c1[1]));
+                    x1[ti][4 * m + 3] = acc[ti][4 * m + 3] + (b1[4 * m + 3] + fmaf(xr[4 * m + 3], c1[2], c1[3]));
+                }
+            }
+        }
+        float x2[2][16];
+        if constexpr (MODE == 1) {
+            float c2[16];
+            get_vec(vec + 2 * 192, col0, c2);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x2[ti][r] = x1[ti][r] + c2[r];
+        } else {
+            float2 st[2];
+            ln_stats2(x1, lnp, j, lt, lh, st);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                float y[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[r] = (x1[ti][r] - st[ti].x) * st[ti].y;
+                put_split<true>(r2h + ti * CH_APL, CH_APL, wrowA, col0, y);
+            }
+            __syncthreads();
+            zero16(acc[0]); zero16(acc[1]);
+            gemm_run2<MODE, NR, U_G2, 12>(R, wp, r2h + browA, r2h + CH_APL + browA, acc[0], acc[1]);
+            float bq[16];
+            get_vec(vec + 192, col0, bq);
+            const __bf16* kt = reinterpret_cast<const __bf16*>(smem + CV::R0);
+            auto kv4 = [&](int e) -> f32x4 {
+                const bf16x4c b = *reinterpret_cast<const bf16x4c*>(kt + e);
+                f32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (float)b[q];
+                return o;
+            };
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                float q[16], o2[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) q[r] = acc[ti][r] + bq[r];
+                const int lo = blo[ti], hi = bhi[ti];
+                float sc[8];
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int wi = 0; wi < 8; ++wi) {
+                    float p = 0.f;
+                    if (wi < hd.wmax) {
+                        const int row = min(max(lo - kmin + wi, 0), CH2_KW - 1);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const f32x4 kv = kv4(row * CH_KP + col0 + 8 * m);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) p = fmaf(q[4 * m + i], kv[i], p);
+                        }
+                    }
+                    p += __shfl_xor(p, 32);
+                    const bool vis = (wi < hd.wmax) && (lo + wi < hi);
+                    sc[wi] = vis ? p * a.scale : -3.0e38f;
+                    mx = fmaxf(mx, sc[wi]);
+                }
+                float den = 0.f;
+#pragma unroll
+                for (int wi = 0; wi < 8; ++wi) {
+                    const bool vis = (wi < hd.wmax) && (lo + wi < hi);
+                    sc[wi] = vis ? __expf(sc[wi] - mx) : 0.f;
+                    den += sc[wi];
+                }
+                const float inv = den > 0.f ? 1.0f / den : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o2[r] = 0.f;
+#pragma unroll
+                for (int wi = 0; wi < 8; ++wi) {
+                    if (wi < hd.wmax) {
+                        const int row = min(max(lo - kmin + wi, 0), CH2_KW - 1);
+                        const float pw = sc[wi] * inv;
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const f32x4 vv = kv4(CH2_KW * CH_KP + row * CH_KP + col0 + 8 * m);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) o2[4 * m + i] = fmaf(pw, vv[i], o2[4 * m + i]);
+                        }
+                    }
+                }
+                put_split<true>(r1h + ti * CH_APL, CH_APL, wrowA, col0, o2);
+            }
+            __syncthreads();
+            zero16(acc[0]); zero16(acc[1]);
+            gemm_run2<MODE, NR, U_G3, 12>(R, wp, r1h + browA, r1h + CH_APL + browA, acc[0], acc[1]);
+            float bo[16];
+            get_vec(vec + 2 * 192, col0, bo);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x2[ti][r] = acc[ti][r] + (bo[r] + x1[ti][r]);
+        }
+        // ---- LayerNorm3 (folded into GEGLU's weights) and the raw x2 as B operands ----
+        float2 st3[2];
+        ln_stats2(x2, lnp, j, lt, lh, st3);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            float y[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] = (x2[ti][r] - st3[ti].x) * st3[ti].y;
+            put_split<true>(r1h + ti * CH_APL, CH_APL, wrowA, col0, y);
+            put_split<true>(r2h + ti * CH_APL, CH_APL, wrowA, col0, x2[ti]);
+        }
+        __syncthreads();
+    }
+    // ---- GEGLU: pairs w, w + 8, w + 16, both tiles ----
+    {
+        constexpr int QG = (MODE == 0) ? U_GE : (MODE == 1 ? U_G2 : 0);
+        const float* bff = reinterpret_cast<const float*>(smem + CV::BFF);
+        sfor<0, 3>([&](auto pc) {
+            constexpr int pi = decltype(pc)::value;
+            f32x16 av[2], ag[2];
+            zero16(av[0]); zero16(av[1]); zero16(ag[0]); zero16(ag[1]);
+            geglu_run2<MODE, NR, QG + 24 * pi>(R, wp, r1h + browA, r1h + CH_APL + browA, av, ag);
+            const int p = w + 8 * pi;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bff + 32 * p + 4 * lh + 8 * m), bg = *reinterpret_cast<const f32x4*>(bff + 768 + 32 * p + 4 * lh + 8 * m);
+                    bf16x4c h;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[i] = (__bf16)((av[ti][4 * m + i] + bv[i]) * gelu_f(ag[ti][4 * m + i] + bg[i]));
+                    *reinterpret_cast<bf16x4c*>(hh + ti * CH_HPL + wrowH + (32 * p + 4 * lh + 8 * m) * 2) = h;
+                }
+        });
+    }
+    f32x4 bpv[4];
+    if constexpr (MODE != 2) {
+        const rsrc_t rvec = make_rsrc(a.vec, (unsigned)CHAIN_VEC_FLOATS * 4u);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bpv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rvec, (4 * 192 + col0 + 8 * m) * 4, 0, 0));
+    }
+    __syncthreads();
+    float* const fpart = reinterpret_cast<float*>(r1h);   // [2 helper waves][2 tiles][16][64]: partial sums of column tiles 4, 5 (the LayerNorm3 planes are dead)
+    if constexpr (MODE == 2) {
+        constexpr int QH = U_FF - U_GE;
+        f32x16 acc[2];
+        zero16(acc[0]); zero16(acc[1]);
+        gemm_run2<MODE, NR, QH, 48 - U_HALF>(R, wp, hh + browH + 32 * U_HALF, hh + CH_HPL + browH + 32 * U_HALF, acc[0], acc[1]);
+        gemm_run2<MODE, NR, QH + 48 - U_HALF, 12>(R, wp, r2h + browA, r2h + CH_APL + browA, acc[0], acc[1]);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fpart[(((w - 6) * 2 + ti) * 16 + r) * 64 + l] = acc[ti][r];
+        __syncthreads();
+    }
+    if constexpr (MODE != 2) {
+        constexpr int QF = (MODE == 0) ? U_FF : U_FF - (U_GE - U_G2);
+        const rsrc_t rxin = make_rsrc(reinterpret_cast<const char*>(hd.xin) + (long long)in_idx * hd.x_bs * 2, (unsigned)hd.T * 384u);
+        float xr[2][16];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const bf16x4c xb = __builtin_bit_cast(bf16x4c, __builtin_amdgcn_raw_buffer_load_b64(rxin, tt[ti] * 384 + col0 * 2 + 16 * m, 0, 0));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xr[ti][4 * m + i] = (float)xb[i];
+            }
+        f32x16 acc[2];
+        zero16(acc[0]); zero16(acc[1]);
+        if (w < 4) {
+            gemm_run2<MODE, NR, QF, 48>(R, wp, hh + browH, hh + CH_HPL + browH, acc[0], acc[1]);
+            gemm_run2<MODE, NR, QF + 48, 12>(R, wp, r2h + browA, r2h + CH_APL + browA, acc[0], acc[1]);
+            __syncthreads();
+        } else {
+            gemm_run2<MODE, NR, QF, U_HALF>(R, wp, hh + browH, hh + CH_HPL + browH, acc[0], acc[1]);
+            __syncthreads();
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ti][r] += fpart[(((w - 4) * 2 + ti) * 16 + r) * 64 + l];
+        }
+        const rsrc_t ryo = make_rsrc(reinterpret_cast<char*>(a.y) + (long long)s_idx * a.y_bs * 2, (unsigned)hd.T * 384u);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            float y[16];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                bf16x4c yb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    yb[i] = (__bf16)(acc[ti][4 * m + i] + bpv[m][i] + xr[ti][4 * m + i]);
+                    y[4 * m + i] = (float)yb[i];
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2c, yb), ryo, tt[ti] * 384 + col0 * 2 + 16 * m, 0, 0);   // (rows past T: out of range, dropped)
+            }
+            const int t0i = t0 + 32 * ti;
+            float* const so = (a.stats_out && t0i < hd.T) ? a.stats_out + (long long)s_idx * a.stats_bs + ((long long)(t0i >> 5) * 192) * 2 : nullptr;
+            if (so) {
+                const float cnt = (float)min(32, hd.T - t0i);
+                const float rcnt = __builtin_amdgcn_rcpf(cnt);
+                float mean[16], m2[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mean[r] = half32_sum(tv[ti] ? y[r] : 0.f) * rcnt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float d = tv[ti] ? (y[r] - mean[r]) : 0.f; m2[r] = half32_sum(d * d); }
+                if (lt == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = col0 + (r & 3) + 8 * (r >> 2);
+                        gstore(so, 2 * c, mean[r]); gstore(so, 2 * c + 1, m2[r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void stchain2_kernel(const float* h_w, const float* h_o, const float* h_x, const int* h_lo, int h_T, int h_pitch, int h_obs, int h_xbs, int h_inmod,
+                                                          int h_nunc_wmax, const ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char csmem[];
+#ifdef SAID_AB_FLOOR
+    if (h_T > 0) return;
+#endif
+    const ChainHdr hd = {h_w, h_o, h_x, h_lo, h_T, h_pitch, h_obs, h_xbs, h_inmod, h_nunc_wmax & 0xffffff, (int)((unsigned)h_nunc_wmax >> 24)};
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s_idx = blockIdx.y, t0 = blockIdx.x * 64;
+    const bool uncond = s_idx < hd.n_uncond;
+    const int in_idx = hd.in_mod > 0 ? s_idx % hd.in_mod : s_idx;
+    if (w >= 6) chain_body2<2>(hd, a, csmem, w, l, s_idx, in_idx, t0);
+    else if (uncond) chain_body2<1>(hd, a, csmem, w, l, s_idx, in_idx, t0);
+    else chain_body2<0>(hd, a, csmem, w, l, s_idx, in_idx, t0);
+}
+
 template <bool BF>
 __global__ __launch_bounds__(512, BF ? 4 : 1) void stchain_kernel(const float* h_w, const float* h_o, const float* h_x, const int* h_lo, int h_T, int h_pitch, int h_obs, int h_xbs, int h_inmod,
                                                          int h_nunc_wmax, const ChainArgs a) {
@@ -780,15 +1260,17 @@ bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long
     return true;
 }
 
-void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s, bool bf16) {
+void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s, bool bf16, bool two_tiles) {
     if (!stchain_supports(a, T, pitch, o_bs, x_bs)) { launch_fault("stchain: unsupported arguments (T %d, window %d)", T, a.wmax); return; }
     dim3 grid((T + 31) / 32, nsamp);
-    if (bf16) hipLaunchKernelGGL(stchain_kernel<true>, grid, dim3(512), Carve<true>::LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+    if (bf16 && two_tiles) hipLaunchKernelGGL(stchain2_kernel, dim3((grid.x + 1) / 2, nsamp), dim3(512), Carve2::LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+    else if (bf16) hipLaunchKernelGGL(stchain_kernel<true>, grid, dim3(512), Carve<true>::LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
     else hipLaunchKernelGGL(stchain_kernel<false>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
 }
 void configure_stchain_kernel() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, Carve<true>::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Carve2::LDS);
 }
 
 }  // namespace said
