@@ -909,6 +909,7 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
             const double fl = 2.0 * g.T * ((double)n1 * MC * MC + (double)n2 * 2 * MC * MC + (double)g.Be * (2.0 * FFI * MC + (double)(FFI + MC) * MC)) + 4.0 * n2 * MC * g.T * c->band_wmax;
             c->stage_log.push_back({10, EPI_STORE, 6, 8, w + io, fl});
         }
+        if (c->xclk_on && c->dbg_count < 64) ca.clk = c->clk_dev + (long long)c->dbg_count * 128;   // (said_debug_option "xgemm_clk": -DSAID_CLK_STAMPS builds)
         if (dbg_go(c)) {
             launch_stchain(ca, static_cast<const float*>(c->tO), static_cast<const float*>(in.t), g.T, g.Tp, seg * MC, seg * MC, shared ? g.Bc : 0, g.Bc > 0 ? g.Bc : 0, g.Be, s, true, c->st_chain_bf16 == 2 && c->band_chain2_ok);
             ++c->n_stchain;
@@ -1515,7 +1516,11 @@ void run_kv(said_ctx* c, int b0, int nb, int S, int Sp, hipStream_t s) {
     launch_gemm(a, EPI_STORE, nb, lc.NB, lc.KS, s);
     // the key-major copy the fused SpatialTransformer tail reads its window tiles from (once per loop; fp32 mode's small-batch schedule only)
     if ((c->bf16_mode ? c->st_chain_bf16 != 0 : c->st_chain != 0) && (long long)S * NST * 2 * MC <= (long long)NST * 2 * MC * c->maxTp)
-        launch_cm_to_tm(c->KV + b0 * ybs, c->KVT + (long long)b0 * S * (NST * 2 * MC), nb, S, NST * 2 * MC, Sp, ybs, s);
+    {
+        // (bf16 mode: the copy itself is bf16 — the kernels round the window tiles to bf16 anyway, and at 32 clips the windows are 64 of a launch's 117 MB of HBM traffic in fp32)
+        if (c->bf16_mode) launch_cm_to_tm_bf16(c->KV + b0 * ybs, ybs, Sp, reinterpret_cast<unsigned short*>(c->KVT) + (long long)b0 * S * (NST * 2 * MC), (long long)S * (NST * 2 * MC), nb, S, NST * 2 * MC, s);
+        else launch_cm_to_tm(c->KV + b0 * ybs, c->KVT + (long long)b0 * S * (NST * 2 * MC), nb, S, NST * 2 * MC, Sp, ybs, s);
+    }
 }
 
 // alignment band of ldm/attention.py:170-189 with Python's banker's rounding on doubles

@@ -284,55 +284,104 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         // The key rows lo[t0] .. hi[last token] - 1 (<= CHAIN_KW: engine.cpp set_band) of K and V from the key-major copy: 26 loads per lane requested first thing (one round for
         // the 34 rows of S == T), parked in LDS behind the first barrier — the column owners' operand staging does not wait for them; first read behind the third barrier.
         const bool uncond = s_idx < hd.n_uncond;
-        constexpr int KVL = 26;
-        f32x4 kvv[KVL];
-        int kv_n = 0;
-        const int l2 = (w - 6) * 64 + l;
-        const rsrc_t rkv = make_rsrc(a.kvt + (long long)s_idx * a.kvt_bs, (unsigned)a.S * 1536u * 4u);
-        // flat piece index idx = l2 + 128 i -> (key row, piece of the row's 96): advanced incrementally (a division per piece costs ~100 clocks of VALU beside the
-        // owners' MFMAs); pieces past the end repeat the last one (same source, same destination: harmless) instead of being predicated
-        auto kv_walk = [&](int i0, auto&& f) {
-            int idx0 = l2 + 128 * i0;
-            int key = (int)(((unsigned)idx0 * 43691u) >> 22), f4 = idx0 - key * 96;   // idx0 / 96 (exact for idx0 < 2^15)
-            const int lastk = (kv_n - 1) / 96, lastf = (kv_n - 1) - lastk * 96;
-#pragma unroll
-            for (int i = 0; i < KVL; ++i) {
-                const bool in = (key * 96 + f4) < kv_n;
-                const int k = in ? key : lastk, p4 = in ? f4 : lastf;
-                f(i, k, p4);
-                f4 += 32; key += 1;
-                if (f4 >= 96) { f4 -= 96; key += 1; }
-            }
-        };
-        auto kv_issue = [&](int i0) {
-            kv_walk(i0, [&](int i, int k, int p4) {
-                kvv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rkv, ((kmin + k) * 1536 + a.koff + 4 * p4) * 4, 0, 0));
-            });
-        };
-        auto kv_park = [&](int i0) {
-            float* kt = reinterpret_cast<float*>(smem + CH_R0);
-            kv_walk(i0, [&](int i, int k, int p4) {
-                const int e = (p4 < 48 ? 0 : CHAIN_KW * CH_KP) + k * CH_KP + 4 * (p4 < 48 ? p4 : p4 - 48);
-                if constexpr (BF) {   // bf16 tiles (RNE)
-                    bf16x4c b;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) b[q] = (__bf16)kvv[i][q];
-                    *reinterpret_cast<bf16x4c*>(reinterpret_cast<__bf16*>(kt) + e) = b;
-                } else {
-                    *reinterpret_cast<f32x4*>(kt + e) = kvv[i];
+        if constexpr (BF) {
+            constexpr int KVL = 13;
+            f32x4 kvv[KVL];
+            int kv_n = 0;
+            const int l2 = (w - 6) * 64 + l;
+            // bf16 key-major copy (engine.cpp run_kv, bf16 mode): a key row of this block is 384 consecutive bf16 (K then V) = 48 pieces of 16 bytes
+            const rsrc_t rkv = make_rsrc(reinterpret_cast<const char*>(a.kvt) + (long long)s_idx * a.kvt_bs * 2, (unsigned)a.S * 1536u * 2u);
+            auto kv_walk = [&](int i0, auto&& f) {
+                int idx0 = l2 + 128 * i0;
+                int key = (int)(((unsigned)idx0 * 43691u) >> 21), f8 = idx0 - key * 48;   // idx0 / 48 (exact for idx0 < 2^17)
+                const int lastk = (kv_n - 1) / 48, lastf = (kv_n - 1) - lastk * 48;
+    #pragma unroll
+                for (int i = 0; i < KVL; ++i) {
+                    const bool in = (key * 48 + f8) < kv_n;
+                    const int k = in ? key : lastk, p8 = in ? f8 : lastf;
+                    f(i, k, p8);
+                    f8 += 32; key += 2;
+                    if (f8 >= 48) { f8 -= 48; key += 1; }
                 }
-            });
-        };
-        if (!uncond) {
-            kmin = cload(hd.lo, t0);
-            kv_n = (min(cload(hd.lo, min(t0 + 31, hd.T - 1)) + hd.wmax - kmin, CHAIN_KW)) * 96;   // float4 pieces: 48 of K and 48 of V per key row
-            kv_issue(0);
-        }
-        __syncthreads();   // operands staged
-        clk_stamp_c(clk, w, l, 1);
-        if (!uncond) {
-            kv_park(0);
-            for (int i0 = KVL; i0 * 128 < kv_n; i0 += KVL) { kv_issue(i0); kv_park(i0); }
+            };
+            auto kv_issue = [&](int i0) {
+                kv_walk(i0, [&](int i, int k, int p8) {
+                    kvv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rkv, ((kmin + k) * 1536 + a.koff + 8 * p8) * 2, 0, 0));
+                });
+            };
+            auto kv_park = [&](int i0) {
+                __bf16* kt = reinterpret_cast<__bf16*>(smem + CH_R0);
+                kv_walk(i0, [&](int i, int k, int p8) {
+                    const int e = (p8 < 24 ? 0 : CHAIN_KW * CH_KP) + k * CH_KP + 8 * (p8 < 24 ? p8 : p8 - 24);   // (392-byte rows: two 8-byte stores)
+                    typedef unsigned int u32x2k __attribute__((ext_vector_type(2)));
+                    typedef unsigned int u32x4k __attribute__((ext_vector_type(4)));
+                    const u32x4k v = __builtin_bit_cast(u32x4k, kvv[i]);
+                    const u32x2k v0 = {v[0], v[1]}, v1 = {v[2], v[3]};
+                    *reinterpret_cast<u32x2k*>(kt + e) = v0;
+                    *reinterpret_cast<u32x2k*>(kt + e + 4) = v1;
+                });
+            };
+            if (!uncond) {
+                kmin = cload(hd.lo, min(t0, hd.T - 1));
+                kv_n = (min(cload(hd.lo, min(t0 + 31, hd.T - 1)) + hd.wmax - kmin, CHAIN_KW)) * 48;
+                kv_issue(0);
+            }
+            __syncthreads();   // operands staged
+            if (!uncond) {
+                kv_park(0);
+                for (int i0 = KVL; i0 * 128 < kv_n; i0 += KVL) { kv_issue(i0); kv_park(i0); }
+            }
+        } else {
+            constexpr int KVL = 26;
+            f32x4 kvv[KVL];
+            int kv_n = 0;
+            const int l2 = (w - 6) * 64 + l;
+            const rsrc_t rkv = make_rsrc(a.kvt + (long long)s_idx * a.kvt_bs, (unsigned)a.S * 1536u * 4u);
+            // flat piece index idx = l2 + 128 i -> (key row, piece of the row's 96): advanced incrementally (a division per piece costs ~100 clocks of VALU beside the
+            // owners' MFMAs); pieces past the end repeat the last one (same source, same destination: harmless) instead of being predicated
+            auto kv_walk = [&](int i0, auto&& f) {
+                int idx0 = l2 + 128 * i0;
+                int key = (int)(((unsigned)idx0 * 43691u) >> 22), f4 = idx0 - key * 96;   // idx0 / 96 (exact for idx0 < 2^15)
+                const int lastk = (kv_n - 1) / 96, lastf = (kv_n - 1) - lastk * 96;
+    #pragma unroll
+                for (int i = 0; i < KVL; ++i) {
+                    const bool in = (key * 96 + f4) < kv_n;
+                    const int k = in ? key : lastk, p4 = in ? f4 : lastf;
+                    f(i, k, p4);
+                    f4 += 32; key += 1;
+                    if (f4 >= 96) { f4 -= 96; key += 1; }
+                }
+            };
+            auto kv_issue = [&](int i0) {
+                kv_walk(i0, [&](int i, int k, int p4) {
+                    kvv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rkv, ((kmin + k) * 1536 + a.koff + 4 * p4) * 4, 0, 0));
+                });
+            };
+            auto kv_park = [&](int i0) {
+                float* kt = reinterpret_cast<float*>(smem + CH_R0);
+                kv_walk(i0, [&](int i, int k, int p4) {
+                    const int e = (p4 < 48 ? 0 : CHAIN_KW * CH_KP) + k * CH_KP + 4 * (p4 < 48 ? p4 : p4 - 48);
+                    if constexpr (BF) {   // bf16 tiles (RNE)
+                        bf16x4c b;
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) b[q] = (__bf16)kvv[i][q];
+                        *reinterpret_cast<bf16x4c*>(reinterpret_cast<__bf16*>(kt) + e) = b;
+                    } else {
+                        *reinterpret_cast<f32x4*>(kt + e) = kvv[i];
+                    }
+                });
+            };
+            if (!uncond) {
+                kmin = cload(hd.lo, t0);
+                kv_n = (min(cload(hd.lo, min(t0 + 31, hd.T - 1)) + hd.wmax - kmin, CHAIN_KW)) * 96;   // float4 pieces: 48 of K and 48 of V per key row
+                kv_issue(0);
+            }
+            __syncthreads();   // operands staged
+            clk_stamp_c(clk, w, l, 1);
+            if (!uncond) {
+                kv_park(0);
+                for (int i0 = KVL; i0 * 128 < kv_n; i0 += KVL) { kv_issue(i0); kv_park(i0); }
+            }
         }
         clk_stamp_c(clk, w, l, 2);
         sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, NR, decltype(qc)::value>(R, wp); });   // (not needed before GEGLU; behind the window tile, whose registers it reuses)
@@ -872,42 +921,45 @@ __device__ __forceinline__ void chain_body2(const ChainHdr& hd, const ChainArgs&
     if constexpr (MODE == 0) kmin = cload(hd.lo, min(t0, hd.T - 1));
     if constexpr (MODE == 2) {
         const bool uncond = s_idx < hd.n_uncond;
-        constexpr int KVL = 26;
+        constexpr int KVL = 13;
         f32x4 kvv[KVL];
         int kv_n = 0;
         const int l2 = (w - 6) * 64 + l;
-        const rsrc_t rkv = make_rsrc(a.kvt + (long long)s_idx * a.kvt_bs, (unsigned)a.S * 1536u * 4u);
+        // bf16 key-major copy (engine.cpp run_kv, bf16 mode): a key row of this block is 384 consecutive bf16 (K then V) = 48 pieces of 16 bytes
+        const rsrc_t rkv = make_rsrc(reinterpret_cast<const char*>(a.kvt) + (long long)s_idx * a.kvt_bs * 2, (unsigned)a.S * 1536u * 2u);
         auto kv_walk = [&](int i0, auto&& f) {
             int idx0 = l2 + 128 * i0;
-            int key = (int)(((unsigned)idx0 * 43691u) >> 22), f4 = idx0 - key * 96;
-            const int lastk = (kv_n - 1) / 96, lastf = (kv_n - 1) - lastk * 96;
+            int key = (int)(((unsigned)idx0 * 43691u) >> 21), f8 = idx0 - key * 48;   // idx0 / 48 (exact for idx0 < 2^17)
+            const int lastk = (kv_n - 1) / 48, lastf = (kv_n - 1) - lastk * 48;
 #pragma unroll
             for (int i = 0; i < KVL; ++i) {
-                const bool in = (key * 96 + f4) < kv_n;
-                const int k = in ? key : lastk, p4 = in ? f4 : lastf;
-                f(i, k, p4);
-                f4 += 32; key += 1;
-                if (f4 >= 96) { f4 -= 96; key += 1; }
+                const bool in = (key * 48 + f8) < kv_n;
+                const int k = in ? key : lastk, p8 = in ? f8 : lastf;
+                f(i, k, p8);
+                f8 += 32; key += 2;
+                if (f8 >= 48) { f8 -= 48; key += 1; }
             }
         };
         auto kv_issue = [&](int i0) {
-            kv_walk(i0, [&](int i, int k, int p4) {
-                kvv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rkv, ((kmin + k) * 1536 + a.koff + 4 * p4) * 4, 0, 0));
+            kv_walk(i0, [&](int i, int k, int p8) {
+                kvv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rkv, ((kmin + k) * 1536 + a.koff + 8 * p8) * 2, 0, 0));
             });
         };
         auto kv_park = [&](int i0) {
             __bf16* kt = reinterpret_cast<__bf16*>(smem + CV::R0);
-            kv_walk(i0, [&](int i, int k, int p4) {
-                const int e = (p4 < 48 ? 0 : CH2_KW * CH_KP) + k * CH_KP + 4 * (p4 < 48 ? p4 : p4 - 48);
-                bf16x4c b;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) b[q] = (__bf16)kvv[i][q];
-                *reinterpret_cast<bf16x4c*>(kt + e) = b;
+            kv_walk(i0, [&](int i, int k, int p8) {
+                const int e = (p8 < 24 ? 0 : CH2_KW * CH_KP) + k * CH_KP + 8 * (p8 < 24 ? p8 : p8 - 24);   // (392-byte rows: two 8-byte stores)
+                typedef unsigned int u32x2k __attribute__((ext_vector_type(2)));
+                typedef unsigned int u32x4k __attribute__((ext_vector_type(4)));
+                const u32x4k v = __builtin_bit_cast(u32x4k, kvv[i]);
+                const u32x2k v0 = {v[0], v[1]}, v1 = {v[2], v[3]};
+                *reinterpret_cast<u32x2k*>(kt + e) = v0;
+                *reinterpret_cast<u32x2k*>(kt + e + 4) = v1;
             });
         };
         if (!uncond) {
             kmin = cload(hd.lo, min(t0, hd.T - 1));
-            kv_n = (min(cload(hd.lo, min(t0 + 63, hd.T - 1)) + hd.wmax - kmin, CH2_KW)) * 96;
+            kv_n = (min(cload(hd.lo, min(t0 + 63, hd.T - 1)) + hd.wmax - kmin, CH2_KW)) * 48;
             kv_issue(0);
         }
         __syncthreads();   // operands staged
