@@ -269,6 +269,9 @@ int said_profile_unet(said_ctx* ctx, int batch_eff, int frames, int cfg_clips, i
  *                            one launch per block (stchain_kernel, round 5).  "st_chain_large" 0: only below the token-major threshold;
  *                            "st_chain_max_tiles" n: only while a launch has at most n (sample, 32-token tile) workgroups; "st_chain_dbg" 1: the fused
  *                            kernel also writes x1 / x2 / the cross-attention input to X1 / X2 / X3 (bring-up)
+ *   "st_chain_bf16"          bf16 mode, large batches: 0 = rgemm's six launches behind self-attention; -1 / 1 (default) = stchain_kernel<bf16>, one token tile per workgroup,
+ *                            two workgroups per CU; 2 = stchain2_kernel, two tiles per workgroup sharing every weight fragment (bit-identical, measured slower)
+ *   "xgemm_clk"              1: shader-clock stamps of the token-major schedule's kernels (-DSAID_CLK_STAMPS builds; read with said_debug_clocks)
  * said_debug_get additionally knows "n_set_weight" (said_set_weight calls so far), "n_stchain" / "n_rgemm" / "n_xgemm" (launches issued through those kernels). */
 int said_debug_option(said_ctx* ctx, const char* name, long long value);
 long long said_debug_get(const said_ctx* ctx, const char* name);
