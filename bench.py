@@ -30,8 +30,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MODES = {"f32": "fp32", "bf16": "bf16", "f32_strict": "fp32_strict"}   # --dtype -> SAID.set_mfma_dtype
+DTYPE_LABEL = {"f32": "f32 (split-fp16 products)", "bf16": "bf16", "f32_strict": "f32"}   # the arithmetic the products run in (include/said_hip.h, said_set_precision)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured copy
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense peaks (MI355X_MICROARCH.md); never the 2:1-sparsity figures
+# dense peaks of the matrix pipes (MI355X_MICROARCH.md); never the 2:1-sparsity figures.  A kernel is priced against the pipe its instructions run on.
+PIPE_PEAK_TFLOPS = {"mfma_f32": 157.3, "mfma_f16": 2500.0, "mfma_bf16": 2500.0}
 EPI_NAMES = {0: "store", 1: "qkv", 2: "geglu", 3: "band", -1: "attn"}
 
 
@@ -45,8 +48,9 @@ def parse():
     p.add_argument("--num_steps", type=int, default=1000, help="denoising steps per clip")
     p.add_argument("--guidance_scale", type=float, default=2.0)
     p.add_argument("--eta", type=float, default=0.0)
-    p.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                   help="f32 (BASELINE configs[1]) or bf16 multiplies with fp32 accumulation (configs[2]: --batch 32 --num_steps 50 --dtype bf16)")
+    p.add_argument("--dtype", choices=["f32", "bf16", "f32_strict"], default="f32",
+                   help="f32 (BASELINE configs[1]: fp32 tensors, products on split-fp16 operands), f32_strict (products on fp32 matrix instructions) or bf16 "
+                        "multiplies with fp32 accumulation (configs[2]: --batch 32 --num_steps 50 --dtype bf16)")
     p.add_argument("--edit", action="store_true",
                    help="editing mode (BASELINE configs[4]: --seconds 30 --num_steps 100 --edit): init_samples + in-betweening mask "
                         "(middle third regenerated, 4 channels pinned), mask blend with the re-noised init every step")
@@ -173,141 +177,172 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+# What a kernel's matrix products execute on, from its family name and the engine's arithmetic (include/said_hip.h, said_set_precision):
+# fp32 mode multiplies on SPLIT-fp16 operands — three v_mfma_f32_32x32x16_f16 per k16 step where the fp32 matrix pipe would need eight
+# v_mfma_f32_32x32x2_f32 — so its kernels' roof is the fp16 pipe (2.5 PFLOP/s dense) against the instructions they EXECUTE (3 x the
+# fp32-equivalent flops), or equivalently 2500 / 3 = 833 TFLOP/s against fp32-equivalent flops.  VERDICT r5 #3: pricing fp32-equivalent
+# flops against the fp32 pipe's 157.3 TFLOP/s gave "fractions" above 1.
+def kernel_pipe(name, dtype, sp):
+    """(pipe, executed MFMA flops per algorithmic flop) of a kernel family; pipe None: no matrix instructions."""
+    fam = name.split("<")[0].split(" ")[0]
+    if fam in ("prep_kernel",):
+        return None, 0.0
+    if dtype == "bf16":
+        return "mfma_bf16", 1.0
+    split = {"stchain_kernel": sp["chain"], "ugemm_kernel": sp["ugemm"], "out_conv": sp["ugemm"], "fgemm_kernel": sp["gemm"], "attn_kernel": sp["attn"]}.get(fam, False)
+    return ("mfma_f16", 3.0) if split else ("mfma_f32", 1.0)
+
+
+def trace_name_prefix(name, dtype):
+    """The rocprofv3 kernel-name prefix of a family label of roofline() (exact instantiation where the label carries it)."""
+    epi_no = {v: k for k, v in EPI_NAMES.items()}
+    fam = name.split("<")[0].split(" ")[0]
+    args = name[name.index("<") + 1:name.rindex(">")].split(",") if "<" in name else []
+    if fam == "stchain_kernel":
+        return "said::stchain_kernel<" + ("true" if dtype == "bf16" else "false") + ">"
+    if fam == "attn_kernel" and len(args) == 2:
+        return f"said::attn_kernel<{int(args[0][1:]) // 32}, {args[1][2:]},"
+    if fam in ("ugemm_kernel", "cgemm_kernel") and len(args) == 3:
+        return f"said::{fam}<{args[0][2:]}, {args[1][2:]}, {epi_no.get(args[2], 0)}" + ("," if fam == "ugemm_kernel" else ">")
+    return "said::" + fam + ("<" if fam not in ("prep_kernel", "battn_kernel") else "")
+
+
+def in_situ_from_trace(traffic_key, name, dtype):
+    """(avg us, launches, file) of the family in the committed rocprofv3 kernel trace of this configuration — only when the trace was taken on the
+    sources this run was built from (its `# source_hash=` header; scripts/gpu_r6_final.sh writes it), else None: a stale trace says nothing."""
+    import re
+    tfile = os.path.join(ROOT, "profiles", f"trace_latest_{traffic_key}.txt")
+    if not os.path.exists(tfile):
+        return None
+    lines = open(tfile).read().splitlines()
+    m = re.match(r"#\s*source_hash=(\w+)", lines[0]) if lines else None
+    if not m or m.group(1) != source_hash():
+        return None
+    pre = trace_name_prefix(name, dtype)
+    row = re.compile(r"^\s*([\d.]+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+(.*)$")
+    tot_us, calls = 0.0, 0
+    for ln in lines:
+        r = row.match(ln)
+        if r and r.group(5).startswith(pre):
+            tot_us += float(r.group(1)) * 1e3
+            calls += int(r.group(2))
+    return (tot_us / calls, calls, f"profiles/trace_latest_{traffic_key}.txt") if calls else None
+
+
 def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1", groups=1):
-    """Per-kernel HIP-event timing of one UNet evaluation (said_profile_unet: every launch of the schedule replayed
-    back to back in a graph on the caller's stream and timed with hipEvents) + the whole-step figures.  With clip groups
-    (SAID.inference runs the batch as `groups` concurrent sub-batches) the launches are one GROUP's: the per-kernel figures are
-    those of the largest group's UNet evaluation timed alone; the whole-step figures are the whole batch's work / loop time."""
+    """Per-kernel HIP-event timing of one UNet evaluation (said_profile_unet: every launch of the schedule replayed back to back in a graph on the
+    caller's stream between two hipEvents) + the whole-step figures.  With clip groups (SAID.inference runs the batch as `groups` concurrent
+    sub-batches) the launches are one GROUP's.
+
+    Fractions (all <= 1 by construction):
+      frac_hbm              algorithmic bytes of the launch (weights + operands in + residual + result out) / time / 8 TB/s
+      frac_mfma_executed    matrix flops the kernel's instructions EXECUTE / time / the dense peak of the pipe they run on
+      frac_fp32_equivalent  fp32-equivalent (algorithmic) flops / time / the rate at which that pipe delivers fp32-equivalent products (peak / 3 for
+                            split-fp16 kernels); numerically equal to frac_mfma_executed, kept under the name earlier rounds reported
+      frac                  the one of the roof that binds by arithmetic intensity (`bound`)
+    Time: the in-situ average of a rocprofv3 trace taken on these very sources when profiles/ holds one, else the isolated replays (`time_source`)."""
     eng = model._eng
     B = cfg_clips if cfg_clips else Be
     per = Be // B                                    # UNet samples per clip (2 under guidance)
     sizes = [B * (i + 1) // groups - B * i // groups for i in range(groups)]
     nmax = max(sizes)
     stages = eng.profile_unet(per * nmax, T, reps=40, cfg_clips=nmax if cfg_clips else 0)
-    peak_tf = MFMA_PEAK_TFLOPS[dtype]
+    sp = dict(attn=False, gemm=False, ugemm=False, chain=False)
+    if dtype in ("f32", "f32_strict"):
+        for k, opt in (("attn", "attn_split"), ("gemm", "gemm_split"), ("ugemm", "ugemm_split"), ("chain", "st_chain")):
+            try:
+                sp[k] = eng.debug_get(opt) == 1
+            except Exception:
+                pass
     agg = {}
     for st in stages:
         name = (f"attn_kernel<D{32 * st['NB']},KS{st['KS']}>" if st["kind"] == 1 else
                 "battn_kernel" if st["kind"] == 9 else
-                "xattn_kernel" if st["kind"] == 3 else
                 f"{'fgemm' if st['KS'] == 32 else 'tgemm'}_kernel<{st['NB']},{EPI_NAMES[st['epi']]}>" if st["kind"] == 4 else
                 "prep_kernel" if st["kind"] == 5 else
                 f"xgemm_kernel<{st['NB']},{'f32' if st['KS'] == 32 else 'bf16'},{EPI_NAMES[st['epi']]}>" if st["kind"] == 6 else
                 f"rgemm_kernel<{EPI_NAMES[st['epi']]}>" if st["kind"] == 7 else
-                f"pgemm_kernel<{EPI_NAMES[st['epi']]}>" if st["kind"] == 8 else
                 "stchain_kernel" if st["kind"] == 10 else
                 "conv_in_kernel" if st["kind"] == 11 else
                 "out_conv (ugemm_kernel<NB1,KS8,store>; in the loop: first half of out_sched_kernel)" if st["kind"] == 12 else
                 f"{'ugemm' if st['kind'] == 2 else 'cgemm'}_kernel<NB{st['NB']},KS{st['KS']},{EPI_NAMES[st['epi']]}>")
         a = agg.setdefault(name, dict(us=0.0, bytes=0.0, flops=0.0, launches=0))
         a["us"] += st["us"]; a["bytes"] += st["bytes"]; a["flops"] += st["flops"]; a["launches"] += 1
+    for name, a in agg.items():
+        a["pipe"], a["mult"] = kernel_pipe(name, "bf16" if dtype == "bf16" else "f32", sp)
     dom = max(agg, key=lambda k: agg[k]["us"])
     d = agg[dom]
-    achieved = d["bytes"] / (d["us"] * 1e-6) / 1e9
+    t_iso = d["us"] / d["launches"]
+    situ = in_situ_from_trace(traffic_key, dom, dtype) if groups == 1 else None
+    t_us = situ[0] if situ else t_iso
+    bytes_l, flops_l = d["bytes"] / d["launches"], d["flops"] / d["launches"]
+    pipe_peak = PIPE_PEAK_TFLOPS[d["pipe"]] if d["pipe"] else None
+    gbs = bytes_l / (t_us * 1e-6) / 1e9
+    tf_alg = flops_l / (t_us * 1e-6) / 1e12
+    tf_exec = tf_alg * d["mult"]
+    frac_hbm = gbs / HBM_PEAK_GBS
+    frac_exec = tf_exec / pipe_peak if pipe_peak else 0.0
+    mfma_bound = bool(pipe_peak) and (flops_l * d["mult"] / max(bytes_l, 1.0)) > pipe_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
     from said_amd import _engine
-    # SURVEY 8(d)'s byte model at the element size the schedule actually stores between its kernels: bf16 where the token-major-activation
-    # kernels (xgemm / rgemm / pgemm: stage kinds 6-8) run — the bf16 large-batch default —, fp32 everywhere else (round 3 printed the fp32
-    # model for both and so overstated the bf16 fraction twofold)
+    # SURVEY 8(d)'s byte model at the element size the schedule stores between its kernels: bf16 where the token-major-activation kernels run, fp32 elsewhere
     tm_acts = any(st["kind"] in (6, 7, 8) for st in stages)
     elem = 2 if (dtype == "bf16" and tm_acts) else 4
     unet_bytes = _engine.unet_algorithmic_bytes(Be, T, elem)
-    unet_bytes_f32 = _engine.unet_algorithmic_bytes(Be, T, 4)
     unet_flops = _engine.unet_algorithmic_flops(Be, T)
     sum_us = sum(a["us"] for a in agg.values())
-    # work the schedule actually EXECUTES (sum over its launches).  Under guidance the prefix shared by the two halves runs
-    # once per clip and the unconditional half's cross-attention is a constant, so this is less than the reference-equivalent
-    # (algorithmic) work of a 2B-sample UNet evaluation: `mfma_frac` / `hbm_frac` below are EFFECTIVE rates (reference work /
-    # time), `*_executed` the hardware's.
+    # the whole step against the matrix pipes: the time the pipes would need at their dense peaks for the instructions the schedule executes (per family:
+    # executed flops / its pipe's peak) over the loop's step time.  Under guidance the shared prefix runs once per clip, so executed < reference-equivalent work.
+    t_pipes_us = 0.0
     exec_flops = exec_bytes = 0.0
     for n in sorted(set(sizes)):
         st_n = stages if n == nmax else eng.profile_unet(per * n, T, reps=1, cfg_clips=n if cfg_clips else 0)
         exec_flops += sizes.count(n) * sum(st["flops"] for st in st_n)
         exec_bytes += sizes.count(n) * sum(st["bytes"] for st in st_n)
-    # which roof binds the dominant kernel: its arithmetic intensity against the ridge point peak FLOP/s : 8 TB/s (fp32 MFMA: 19.7
-    # FLOP/B, bf16: 312).  Both fractions are always reported (hbm_frac / kernel_mfma_frac); `bound` / `achieved` / `peak` /
-    # `frac` are the binding roof's.
-    k_tf = d["flops"] / (d["us"] * 1e-6) / 1e12
-    mfma_bound = d["flops"] / max(d["bytes"], 1.0) > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+    for a in agg.values():
+        if a["pipe"]:
+            t_pipes_us += (sum(sizes) / nmax) * a["flops"] * a["mult"] / (PIPE_PEAK_TFLOPS[a["pipe"]] * 1e12) * 1e6   # (agg is ONE group of nmax clips)
+    arith = ("bf16 operands (v_mfma_f32_32x32x16_bf16), fp32 accumulation" if dtype == "bf16" else
+             "split-fp16 operands (x = h + 2^-11 l; three v_mfma_f32_32x32x16_f16 per k16 step), fp32 accumulation" if d["pipe"] == "mfma_f16" else
+             "fp32 operands (v_mfma_f32_32x32x2_f32)" if d["pipe"] else "no matrix instructions")
     out = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom,
-           "achieved": round(k_tf, 3) if mfma_bound else round(achieved, 2), "peak": peak_tf if mfma_bound else HBM_PEAK_GBS,
+           "achieved": round(tf_exec, 3) if mfma_bound else round(gbs, 2), "peak": pipe_peak if mfma_bound else HBM_PEAK_GBS,
            "unit": "TFLOP/s" if mfma_bound else "GB/s",
-           "frac": round(k_tf / peak_tf, 5) if mfma_bound else round(achieved / HBM_PEAK_GBS, 5),
-           "arithmetic_intensity": round(d["flops"] / max(d["bytes"], 1.0), 1),
-           "hbm_GBps": round(achieved, 2), "hbm_frac": round(achieved / HBM_PEAK_GBS, 5),
-           "traffic": None, "traffic_source": None,
-           "launches_per_unet": d["launches"], "avg_launch_us": round(d["us"] / d["launches"], 3),
-           "alg_bytes_per_launch": round(d["bytes"] / d["launches"]),
-           "kernel_tflops": round(d["flops"] / (d["us"] * 1e-6) / 1e12, 3),
-           "mfma_peak_tflops": peak_tf, "mfma_dtype": dtype, "clip_groups": groups, "launch_unet_batch": per * nmax,
-           "kernel_mfma_frac": round(d["flops"] / (d["us"] * 1e-6) / 1e12 / peak_tf, 5),
-           "unet_step": {"ms_loop_per_step": round(step_ms, 4), "sum_kernel_us": round(sum_us, 2), "launches": len(stages) * groups,
-                         "alg_bytes": round(unet_bytes), "alg_gflop": round(unet_flops / 1e9, 3),
-                         "alg_bytes_elem_size": elem,
+           "frac": round(frac_exec if mfma_bound else frac_hbm, 5),
+           "frac_hbm": round(frac_hbm, 5), "frac_mfma_executed": round(frac_exec, 5), "frac_fp32_equivalent": round(frac_exec, 5),
+           "fp32_equivalent_peak_tflops": round(pipe_peak / d["mult"], 1) if pipe_peak and d["mult"] else None,
+           "kernel_arithmetic": arith, "pipe": d["pipe"], "executed_flops_per_algorithmic_flop": d["mult"],
+           "arithmetic_intensity_executed": round(flops_l * d["mult"] / max(bytes_l, 1.0), 1),
+           "hbm_GBps": round(gbs, 2), "traffic": None, "traffic_source": None,
+           "launches_per_unet": d["launches"], "avg_launch_us": round(t_us, 3), "time_source": (f"in situ: {situ[2]} ({situ[1]} launches, same source hash)" if situ else
+                                                                                              "isolated replays (HIP events around 40 back-to-back launches per stage, this run)"),
+           "avg_launch_us_isolated": round(t_iso, 3),
+           "alg_bytes_per_launch": round(bytes_l), "alg_gflop_per_launch": round(flops_l / 1e9, 4),
+           "kernel_tflops_fp32_equivalent": round(tf_alg, 3), "kernel_tflops_executed": round(tf_exec, 3),
+           "clip_groups": groups, "launch_unet_batch": per * nmax,
+           "unet_step": {"ms_loop_per_step": round(step_ms, 4), "sum_kernel_us_isolated": round(sum_us, 2), "launches": len(stages) * groups,
+                         "alg_bytes": round(unet_bytes), "alg_gflop": round(unet_flops / 1e9, 3), "alg_bytes_elem_size": elem,
                          "hbm_frac": round(unet_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "hbm_frac_f32_model": round(unet_bytes_f32 / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "mfma_frac": round(unet_flops / (step_ms * 1e-3) / 1e12 / peak_tf, 5),
-                         "fracs_are": "effective: reference-equivalent (algorithmic) work of the full UNet batch / loop time",
-                         "executed_gflop": round(exec_flops / 1e9, 3), "executed_bytes_per_launch_sum": round(exec_bytes),
-                         "mfma_frac_executed": round(exec_flops / (step_ms * 1e-3) / 1e12 / peak_tf, 5)},
-           "by_kernel": {k: {"us": round(v["us"], 2), "launches": v["launches"],
-                             "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1),
-                             "TFLOPs": round(v["flops"] / (v["us"] * 1e-6) / 1e12, 2)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"])}}
-    # Two byte models (VERDICT r4 #7): `hbm_frac` above prices the family's PER-LAUNCH operand bytes (weights + operands in + residual + result out of each
-    # launch, as the schedule has decomposed the network); `hbm_frac_8d` prices the family's share of SURVEY 8(d)'s algorithmic bytes of the whole UNet — the
-    # contract's model, in which an activation is counted once however many launches touch it — apportioned by the family's share of the per-launch bytes.
+                         "hbm_frac_is": "SURVEY 8(d) algorithmic bytes of the full UNet batch / loop time per step / 8 TB/s (north_star bar: 0.40)",
+                         "mfma_frac_executed": round(t_pipes_us / (step_ms * 1e3), 5),
+                         "mfma_frac_executed_is": "time the matrix pipes need at dense peak for the instructions the schedule executes / loop time per step",
+                         "executed_gflop_fp32_equivalent": round(exec_flops / 1e9, 3), "executed_bytes_per_launch_sum": round(exec_bytes)},
+           "by_kernel": {k: {"us": round(v["us"], 2), "launches": v["launches"], "pipe": v["pipe"],
+                             "frac_hbm": round(v["bytes"] / (v["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                             "frac_mfma_executed": round(v["flops"] * v["mult"] / (v["us"] * 1e-6) / 1e12 / PIPE_PEAK_TFLOPS[v["pipe"]], 4) if v["pipe"] else 0.0}
+                         for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["us"])}}
+    # Two byte models: `frac_hbm` prices the family's PER-LAUNCH operand bytes; `hbm_frac_8d` its share of SURVEY 8(d)'s whole-UNet bytes
+    # (an activation counted once however many launches touch it), apportioned by the family's share of the per-launch bytes.
     tot_launch_bytes = sum(a["bytes"] for a in agg.values())
     if tot_launch_bytes > 0:
         out["alg_bytes_8d_share"] = round(unet_bytes * d["bytes"] / tot_launch_bytes)
-        out["hbm_frac_8d"] = round(unet_bytes * d["bytes"] / tot_launch_bytes / (d["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
-    # in-situ time of the family from the committed rocprofv3 trace of this configuration (profiles/trace_latest_<cfg>.txt, written by scripts/gpu_r5_final.sh
-    # from `rocprofv3 --kernel-trace --stats` of this command): the isolated replays below run 5-10 % faster than the same launches inside the step graph
-    tfile = os.path.join(ROOT, "profiles", f"trace_latest_{traffic_key}.txt")
-    if os.path.exists(tfile):
-        fam = dom.split("<")[0].split(" ")[0]
-        tot_us, calls = 0.0, 0
-        for ln in open(tfile):
-            parts = ln.split()
-            if len(parts) >= 5 and parts[-1].startswith("said::") and fam in ln:
-                try:
-                    tot_us += float(parts[0]) * 1e3; calls += int(parts[1])
-                except ValueError:
-                    pass
-        if calls:
-            out["in_situ_avg_us"] = round(tot_us / calls, 2)
-            out["in_situ_source"] = f"profiles/trace_latest_{traffic_key}.txt (all `{fam}` instantiations, {calls} launches)"
-    # `achieved` / `frac` are per-launch ISOLATED replays (HIP events around each launch of said_profile_unet); inside the real step graph the
-    # launches run a little slower (cold instruction cache, the previous launch's write-back).  The loop itself gives the in-situ total:
-    # in_situ_scale = loop time per step / sum of the isolated launch times (one clip group only); the per-kernel in-situ figures of a
-    # rocprofv3 trace of this command are under profiles/ (r04h_kernel_trace_*.txt)
-    # fp32 mode runs the two self-attention products on split-fp16 operands (attn.hip PM == 2: three fp16 MFMAs per fp32 one, fp32 accumulation,
-    # 22-bit operands): `flops` stay the fp32-equivalent (algorithmic) ones everywhere; for an attention kernel the EXECUTED matrix work is
-    # three times that on the fp16 pipe, priced here against the fp16 dense peak as well
-    try:
-        split = dtype == "f32" and eng.debug_get("attn_split") == 1
-    except Exception:
-        split = False
-    out["fp32_attention_products"] = "split_fp16 (x = h + 2^-11 l; 3 fp16 MFMAs per fp32 MFMA; fp32 accumulate)" if split else "mfma_f32"
-    try:
-        gsplit = dtype == "f32" and eng.debug_get("gemm_split") == 1
-    except Exception:
-        gsplit = False
-    try:
-        usplit = dtype == "f32" and eng.debug_get("ugemm_split") == 1
-        chain = dtype == "f32" and eng.debug_get("st_chain") == 1
-    except Exception:
-        usplit = chain = False
-    out["fp32_small_batch_gemm_products"] = "split_fp16 (ugemm_kernel SP, stchain_kernel)" if usplit else "mfma_f32"
-    out["fp32_transformer_tail"] = "one launch per block (stchain_kernel)" if chain else "five launches per block"
-    out["fp32_large_batch_gemm_products"] = "split_fp16 (fgemm_kernel SP)" if gsplit else "mfma_f32"   # (only the token-major fgemm launches; the channel-major kernels stay on fp32 MFMAs)
-    if (split and dom.startswith("attn_kernel")) or (gsplit and dom.startswith("fgemm_kernel")) or (usplit and (dom.startswith("stchain") or dom.startswith("ugemm"))):
-        out["kernel_executed_f16_tflops"] = round(3 * k_tf, 3)
-        out["kernel_executed_f16_frac"] = round(3 * k_tf / MFMA_PEAK_TFLOPS["bf16"], 5)
+        out["hbm_frac_8d"] = round(unet_bytes * d["bytes"] / tot_launch_bytes / (t_us * d["launches"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+    out["precision_mode"] = eng.effective_precision()
+    out["fp32_products"] = {"attention": "split_fp16" if sp["attn"] else "mfma_f32", "small_batch_gemms": "split_fp16 (ugemm_kernel SP)" if sp["ugemm"] else "mfma_f32",
+                            "transformer_tail": "stchain_kernel (split_fp16)" if sp["chain"] else "five launches", "large_batch_gemms": "split_fp16 (fgemm_kernel SP)" if sp["gemm"] else "mfma_f32"} if dtype != "bf16" else None
     if sum_us > 0 and groups == 1:   # (concurrent clip groups share the chip: a launch's in-situ time is then not comparable with its isolated one)
-        scale = (step_ms * 1e3) / sum_us
-        out["in_situ_scale"] = round(scale, 4)
-        out["frac_in_situ_est"] = round(out["frac"] / max(scale, 1.0), 5)
-    # HBM traffic from the PMC counters is collected in its own rocprofv3 pass (scripts/gpu_pmc.sh; --pmc must not be
-    # combined with tracing) and committed: it is NOT measured in this run, hence the explicit source label
+        out["in_situ_scale"] = round((step_ms * 1e3) / sum_us, 4)   # loop time per step / sum of the isolated launch times (includes the ~1.8 us per graph node between kernels)
+    # HBM traffic from the PMC counters is collected in its own rocprofv3 passes (scripts/gpu_r3_traffic.sh; --pmc must not be combined with tracing) and
+    # committed: it is NOT measured in this run, hence the explicit source label and the staleness flag
     tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tf):
         try:
@@ -315,7 +350,6 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1", grou
             if tr and tr.get("kernel") == dom:
                 out["traffic"] = tr.get("hbm_bytes_per_launch")
                 out["traffic_source"] = "profiles/traffic_latest.json[" + traffic_key + "] (" + str(tr.get("source", "separate rocprofv3 --pmc passes")) + ")"
-                # the figure is only as current as the sources it was measured on
                 out["traffic_stale"] = tr.get("source_hash") != source_hash()
                 out["traffic_git_sha"] = tr.get("git_sha")
         except Exception:
@@ -343,7 +377,8 @@ def audio_encode_block(model, proc, T, B, dtype):
     act_b = 512 * ((Ta - 10) // 5 + 1) * 4.0 * 2     # conv0 activation written + read once per clip
     return {"ms_per_clip": round(ms / B, 4), "ms_per_batch": round(ms, 3), "clips": B,
             "tflops": round(2 * mac * B / (ms * 1e-3) / 1e12, 2),
-            "mfma_dtype": dtype, "mfma_frac": round(2 * mac * B / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[dtype], 4),
+            "mfma_dtype": dtype, "mfma_frac": round(2 * mac * B / (ms * 1e-3) / 1e12 / PIPE_PEAK_TFLOPS["mfma_bf16" if dtype == "bf16" else "mfma_f32"], 4),
+            "mfma_frac_is": "fp32-equivalent flops against the bf16 pipe (bf16 mode) / the fp32 pipe (fp32 modes: the encoder's GEMMs run on v_mfma_f32_32x32x2_f32; only its attention products are split-fp16)",
             "alg_bytes": round(weights_b + B * act_b), "alg_GBps": round((weights_b + B * act_b) / (ms * 1e-3) / 1e9, 1)}
 
 
@@ -398,6 +433,9 @@ SECONDARY = {
     "cfg4_edit": dict(batch=1, seconds=30.0, num_steps=100, dtype="f32", eta=0.0, edit=True, passes=2,
                       flags="--seconds 30 --num_steps 100 --edit",
                       workload="BASELINE.json configs[4]: editing mode, 1 clip x 30 s (T=1800), init_samples + in-betweening mask, 100 DDIM steps, guidance 2, fp32"),
+    "cfg1_strict_fp32": dict(batch=1, seconds=10.0, num_steps=1000, dtype="f32_strict", eta=0.0, edit=False, passes=2,
+                             flags="--dtype f32_strict",
+                             workload="BASELINE.json configs[1] in SAID_PREC_FP32_STRICT: every product on v_mfma_f32_32x32x2_f32 with fp32 operands (the price of true fp32 matrix instructions; the transformer tail as five launches)"),
     "cfg1_eta1": dict(batch=1, seconds=10.0, num_steps=1000, dtype="f32", eta=1.0, edit=False, passes=2,
                       flags="--eta 1",
                       workload="BASELINE.json configs[1] with eta = 1 (ancestral / DDPM-variance sampling, noise generated in the step's last kernel): 1 clip x 10 s, 1000 steps, guidance 2, fp32"),
@@ -410,7 +448,7 @@ def run_secondary(model, dev, gs):
     for name, c in SECONDARY.items():
         B = c["batch"]
         proc, lat0, edit_kw, T, Ta = make_inputs(model, dev, range(B), c["seconds"], c["edit"])
-        model.set_mfma_dtype("bf16" if c["dtype"] == "bf16" else "fp32")
+        model.set_mfma_dtype(MODES[c["dtype"]])
         model.clip_groups = c.get("clip_groups")
         for k, v in c.get("debug", {}).items():
             model._get_engine(2 * B if gs > 1.0 else B, T).debug_option(k, v)
@@ -428,13 +466,13 @@ def run_secondary(model, dev, gs):
         assert torch.isfinite(res).all()
         Be = 2 * B if gs > 1.0 else B
         step_ms = loop_step_ms(model, proc, lat0, edit_kw, T, c["num_steps"], gs, c["eta"])
-        rf = roofline(model, Be, T, step_ms, c["dtype"], cfg_clips=B if gs > 1.0 else 0, traffic_key="cfg1" if name == "cfg1_eta1" else ("cfg3_per_gpu_f32" if name.startswith("cfg3") else name),   # (eta = 1 runs the headline's kernels)
+        rf = roofline(model, Be, T, step_ms, c["dtype"], cfg_clips=B if gs > 1.0 else 0, traffic_key="cfg1" if name == "cfg1_eta1" else "cfg1_strict" if name == "cfg1_strict_fp32" else ("cfg3_per_gpu_f32" if name.startswith("cfg3") else name),   # (eta = 1 runs the headline's kernels)
                       groups=model._pick_clip_groups(B, Be // B * T))
         rf["audio_encode"] = audio_encode_block(model, proc, T, B, c["dtype"])
         rf.pop("by_kernel", None)      # the headline's roofline carries the per-kernel table; keep the line readable
         out[name] = {"value": round(B * T / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "passes": c["passes"],
                      "clips_per_s": round(B / dt, 4), "realtime_factor": round(B * T / dt / 60.0, 2),
-                     "ms_per_denoise_step": round(step_ms, 4), "dtype": c["dtype"], "workload": c["workload"],
+                     "ms_per_denoise_step": round(step_ms, 4), "dtype": DTYPE_LABEL[c["dtype"]], "workload": c["workload"],
                      "command": "python bench.py " + c["flags"], "graph_nodes_per_step": model._eng.graph_num_nodes(), "roofline": rf,
                      "clip_groups": model._pick_clip_groups(B, Be // B * T)}
         for k in c.get("debug", {}):
@@ -487,6 +525,16 @@ def run(args):
     # barriers, max-reduce of the time) execute on RCCL on a single-GPU box as well
     dist = shard.init_process_group("nccl", rank, world, dev) if (world > 1 or args.rccl_at_one) else None
 
+    if dist is not None:
+        # one process per GPU, really: a mis-launch (two ranks on one device) must not be able to report an N-GPU number from fewer GPUs
+        pr = torch.cuda.get_device_properties(dev)
+        ident = "|".join(str(getattr(pr, k, "?")) for k in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id")) + f"|visible#{local}|{os.environ.get('HIP_VISIBLE_DEVICES', '')}"
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if len(set(idents)) != dist.get_world_size() or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: {dist.get_world_size()} ranks on {len(set(idents))} distinct devices: {idents}")
+
+    t_start = time.perf_counter()
     if args.ab_lib:
         from said_amd import _engine
         _engine._LIB_PATH = os.path.abspath(args.ab_lib)
@@ -495,7 +543,9 @@ def run(args):
     model = SAID_UNet1D()
     model.load_state_dict(synth.said_state_dict(), strict=True)
     model.to(dev).eval()
-    model.set_mfma_dtype("bf16" if args.dtype == "bf16" else "fp32")
+    torch.cuda.synchronize(dev)
+    t_model = time.perf_counter()
+    model.set_mfma_dtype(MODES[args.dtype])
     model.clip_groups = args.clip_groups or None
     for kv in args.debug_option:
         k, v = kv.split("=")
@@ -510,6 +560,17 @@ def run(args):
         return model.inference(proc, num_inference_steps=args.num_steps, guidance_scale=args.guidance_scale, eta=args.eta,
                                init_latents=lat0, **edit_kw).result
 
+    # Per-rank start-up, outside the timed passes and reported beside them: the first call creates the engine context, packs and uploads the
+    # weights (101 M packed parameters), encodes the audio once and captures the step graph (which does not depend on the step count: ten steps suffice).
+    model.inference(proc, num_inference_steps=min(args.num_steps, 10), guidance_scale=args.guidance_scale, eta=args.eta, init_latents=lat0, **edit_kw)
+    torch.cuda.synchronize(dev)
+    t_ready = time.perf_counter()
+    startup = [t_model - t_start, t_ready - t_model]
+    if dist is not None:
+        st = torch.tensor(startup, device=dev, dtype=torch.float64)
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        startup = st.tolist()
+
     r = shard.timed_sharded_passes(path_fn, rank=rank, world=world, clips_per_rank=B, steps=args.steps, warmup=args.warmup,
                                    dist=dist, device=dev)
     elapsed = r.elapsed_s
@@ -522,12 +583,15 @@ def run(args):
             "metric": "blendshape frames/sec (and clips/sec) at 1000 DDPM steps, 10 s audio",
             "value": round(frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": DTYPE_LABEL[args.dtype], "data": "synthetic",
             "clips_per_s": round(world * B * args.steps / elapsed, 4),
             "realtime_factor": round(frames / elapsed / 60.0, 2),
+            "startup_s": {"model_build_and_to_device": round(startup[0], 3), "engine_create_weight_pack_upload_first_encode_graph_capture": round(startup[1], 3),
+                          "note": "max over ranks; outside the timed passes (once per process, not per pass)"},
             "config": {"workload": f"{B} clip(s)/GPU x {args.seconds:g} s synthetic audio (T={T} frames), audio encode + "
                                    f"{args.num_steps} DDIM steps (eta={args.eta:g}), guidance_scale={args.guidance_scale:g} "
-                                   f"(UNet batch {Be}), " + ("editing mode: init_samples + in-betweening mask; " if args.edit else "") + ("fp32; BASELINE.json configs[1]" if args.dtype == "f32" else
+                                   f"(UNet batch {Be}), " + ("editing mode: init_samples + in-betweening mask; " if args.edit else "") + ("fp32 tensors, products on split-fp16 operands (22-bit significands, fp32 accumulation); BASELINE.json configs[1]" if args.dtype == "f32" else
+                                                              "strict fp32 (fp32 matrix instructions); BASELINE.json configs[1]" if args.dtype == "f32_strict" else
                                                               "bf16 mode (UNet: bf16 multiplies, fp32 accumulation and storage; audio encoder: bf16 GEMM operands and activations, fp32 residual stream); BASELINE.json configs[2] shape"),
                        "batch_per_gpu": B, "frames": T, "num_steps": args.num_steps, "guidance_scale": args.guidance_scale,
                        "eta": args.eta, "parallelism": f"clips sharded over {world} GPU(s), one RCCL all-gather" if world > 1 else ("single GPU, one-rank RCCL group (all-gather + barriers executed)" if dist is not None else "single GPU"),
@@ -558,7 +622,7 @@ def run(args):
                         line[name + "_roofline_frac"] = rf.get("frac")
                         line[name + "_roofline_bound"] = rf.get("bound")
                         line[name + "_hbm_frac_step"] = (rf.get("unet_step") or {}).get("hbm_frac")
-                        line[name + "_mfma_frac_step"] = (rf.get("unet_step") or {}).get("mfma_frac")
+                        line[name + "_mfma_frac_executed_step"] = (rf.get("unet_step") or {}).get("mfma_frac_executed")
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only: other ranks would sit in the final barrier
             line["cpu_baseline"] = cpu_baseline(args, T, Ta)
         print(json.dumps(line), flush=True)

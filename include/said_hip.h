@@ -200,18 +200,42 @@ int said_axpby(said_ctx* ctx, const float* a_host, const float* x_dev, const flo
 
 /* ---- precision ----------------------------------------------------------- */
 
-/* bf16_mfma != 0: every GEMM / convolution and both attention products multiply operands rounded to bfloat16 (weights once at
- * said_finalize_weights, activations after their fused normalisation) with fp32 accumulation; statistics, normalisations, softmax,
- * residual sums and the scheduler stay fp32.  At small batches (< 3000 UNet rows per launch) all tensors in HBM stay fp32; at large
- * batches the activations BETWEEN the UNet's kernels — and q / k / v — are stored token-major in bf16, i.e. a clip's
- * result then depends on whether its batch crosses that threshold (bounded in tests/test_gpu_parity.py / test_gpu_round4.py).  This is
- * the "bf16" of BASELINE.json configs[2]; the reference itself (diffusion.py) only runs fp32, the closest analogue being
- * torch.autocast(bfloat16) around its matmuls/convs.  Default 0 = fp32 mode: fp32 tensors everywhere, products on split-fp16 operands
- * (x = h + 2^-11 l: 22-bit significands, three fp16 MFMAs per eight fp32 ones, fp32 accumulation — as close to a float64 evaluation as
- * the fp32 matrix instructions) unless switched back to v_mfma_f32_32x32x2_f32 by the debug options below.
+/* How the GEMMs / convolutions and both attention products of the UNet (and of the audio encoder) multiply.  Statistics, normalisations,
+ * softmax, residual sums and the scheduler are fp32 in every mode; accumulation is fp32 in every mode.  The reference itself
+ * (diffusion.py) only runs fp32.
+ *
+ * SAID_PREC_FP32 (default): fp32 tensors everywhere; products on SPLIT-fp16 operands — x = h + 2^-11 l with h = RN16(x),
+ *   l = RN16((x - h) 2^11): 22-bit significands, three v_mfma_f32_32x32x16_f16 per eight v_mfma_f32_32x32x2_f32, the l.l term
+ *   (2^-22 relative) dropped.  DOMAIN of every product operand: |x| < 65504 (fp16's range), and an operand
+ *   resolves 2^-36 absolute (fp16 denormals), i.e. a tensor whose largest element is below 2^-14 loses relative precision.
+ *   Weights are checked against [2^-14, 2^15) at said_finalize_weights: outside it this mode runs as SAID_PREC_FP32_STRICT
+ *   (said_effective_precision / said_precision_note say so).  Activations are not range-checked per element; most operands are
+ *   GroupNorm / LayerNorm outputs (bounded by sqrt(channels) x gain), but the residual stream, the GEGLU product, the attention
+ *   output and the concatenated skip input are not normalised: one beyond 65504 becomes inf / NaN in its product, reaches the
+ *   step's model output through every later layer, and is recorded by the step's last kernel — said_numeric_status reports it;
+ *   the host wrapper (SAID.inference) then re-runs the call in SAID_PREC_FP32_STRICT.  Nothing is silently clamped: final
+ *   clamps keep NaN like torch.clamp.
+ * SAID_PREC_FP32_STRICT: fp32 tensors, every product on v_mfma_f32_32x32x2_f32 with fp32 operands (the arithmetic of rounds
+ *   1-4; the fused SpatialTransformer tail runs as five launches).  About 1.25x slower per step at batch 1 (bench.py
+ *   secondary.cfg1_strict_fp32).
+ * SAID_PREC_BF16: operands rounded to bfloat16 (weights once at said_finalize_weights, activations after their fused
+ *   normalisation).  At small batches (< 3000 UNet rows per launch) all tensors in HBM stay fp32; at large batches the activations
+ *   BETWEEN the UNet's kernels — and q / k / v — are stored token-major in bf16, i.e. a clip's result then
+ *   depends on whether its batch crosses that threshold (bounded in tests/test_gpu_parity.py / test_gpu_round4.py).  This is
+ *   the "bf16" of BASELINE.json configs[2]; the closest analogue in the reference is torch.autocast(bfloat16).
  * Takes effect at the next call. */
-int said_set_precision(said_ctx* ctx, int bf16_mfma);
-int said_get_precision(const said_ctx* ctx);
+enum { SAID_PREC_FP32 = 0, SAID_PREC_BF16 = 1, SAID_PREC_FP32_STRICT = 2 };
+int said_set_precision(said_ctx* ctx, int mode);
+int said_get_precision(const said_ctx* ctx);         /* the mode asked for */
+int said_effective_precision(const said_ctx* ctx);   /* the mode that runs: SAID_PREC_FP32 becomes _STRICT when a weight tensor is out of the split range */
+const char* said_precision_note(const said_ctx* ctx);/* "" or which tensor forced strict fp32 */
+
+/* Sticky numeric status of the last said_denoise_loop / said_unet_forward on this context.  Synchronises `stream` (the stream the
+ * call was enqueued on).  *first_bad_step <- index of the first denoise step whose model output held an inf / NaN (-1: none);
+ * *result_nonfinite <- 1 when the final latents (loop) / the model output (forward) hold one.  The reference would return the same
+ * inf / NaN from an fp32 overflow of its own; in SAID_PREC_FP32 the cause can also be an operand beyond the split-fp16 domain,
+ * which SAID_PREC_FP32_STRICT does not have: the host wrapper retries there. */
+int said_numeric_status(said_ctx* ctx, void* stream, int* first_bad_step, int* result_nonfinite);
 
 /* ---- introspection ------------------------------------------------------- */
 

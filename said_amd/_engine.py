@@ -17,8 +17,9 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "lib
 _lib = None
 
 PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
+PRECISIONS = {"fp32": 0, "bf16": 1, "fp32_strict": 2}   # SAID_PREC_* of include/said_hip.h
 NCOEF = 8
-ABI_VERSION = 8   # include/said_hip.h as bound below; a stale libsaid_hip.so is refused at load time
+ABI_VERSION = 9   # include/said_hip.h as bound below; a stale libsaid_hip.so is refused at load time
 
 
 class EngineError(RuntimeError):
@@ -62,6 +63,9 @@ EXPORTS = {
     "said_loop_progress_reset": (c_int, [c_void_p]),
     "said_set_precision": (c_int, [c_void_p, c_int]),
     "said_get_precision": (c_int, [c_void_p]),
+    "said_effective_precision": (c_int, [c_void_p]),
+    "said_precision_note": (c_char_p, [c_void_p]),
+    "said_numeric_status": (c_int, [c_void_p, c_void_p, POINTER(c_int), POINTER(c_int)]),
     "said_profile_unet": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, POINTER(c_int), c_void_p]),
     "said_philox_normal": (c_int, [c_void_p, ctypes.c_uint64, c_int, c_int, c_int64, c_void_p, c_void_p]),
@@ -412,12 +416,34 @@ class Engine:
     def graph_num_nodes(self) -> int:
         return int(self.lib.said_graph_num_nodes(self.h))
 
-    def set_precision(self, bf16_mfma: bool) -> None:
-        """bf16 multiplies (fp32 accumulation, fp32 everything else) in the UNet GEMMs; see said_set_precision."""
-        self._chk(self.lib.said_set_precision(self.h, 1 if bf16_mfma else 0), "said_set_precision")
+    def set_precision(self, mode) -> None:
+        """"fp32" (split-fp16 products), "fp32_strict" (fp32 matrix instructions) or "bf16"; see said_set_precision.  (True / False: "bf16" / "fp32".)"""
+        if isinstance(mode, str):
+            if mode not in PRECISIONS:
+                raise EngineError(f"unknown precision mode {mode!r}: one of {sorted(PRECISIONS)}")
+            mode = PRECISIONS[mode]
+        else:
+            mode = 1 if mode else 0
+        self._chk(self.lib.said_set_precision(self.h, int(mode)), "said_set_precision")
 
     def get_precision(self) -> str:
-        return "bf16" if self.lib.said_get_precision(self.h) else "fp32"
+        """The mode asked for."""
+        return {v: k for k, v in PRECISIONS.items()}[int(self.lib.said_get_precision(self.h))]
+
+    def effective_precision(self) -> str:
+        """The mode that runs: "fp32" becomes "fp32_strict" when a weight tensor lies outside the split-fp16 range (precision_note() says which)."""
+        return {v: k for k, v in PRECISIONS.items()}[int(self.lib.said_effective_precision(self.h))]
+
+    def precision_note(self) -> str:
+        return (self.lib.said_precision_note(self.h) or b"").decode()
+
+    def numeric_status(self):
+        """(first_bad_step, result_nonfinite) of the last loop / forward call on this context: the index of the first denoise step whose model output
+        held an inf / NaN (-1: none) and whether the final latents / the model output hold one.  Synchronises the current stream."""
+        a, b = c_int(-1), c_int(0)
+        with torch.cuda.device(self.index):
+            self._chk(self.lib.said_numeric_status(self.h, _stream(), ctypes.byref(a), ctypes.byref(b)), "said_numeric_status")
+        return a.value, bool(b.value)
 
 
 class VaeEngine:

@@ -138,7 +138,11 @@ struct said_ctx {
     hipStream_t cap_stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool use_branches = false;  // SAID_BRANCHES=1: capture the two halves of the UNet batch as parallel graph branches
-    bool bf16_mode = false;  // said_set_precision: multiply in bf16 wherever the LDS-staged kernel is used
+    bool bf16_mode = false;  // said_set_precision(SAID_PREC_BF16): multiply in bf16 wherever the LDS-staged kernel is used
+    int prec_mode = 0;       // the SAID_PREC_* mode asked for (said_set_precision)
+    bool split_unsafe = false;   // a weight tensor lies outside the split-fp16 representation's range (scan_split_range): SAID_PREC_FP32 then runs as SAID_PREC_FP32_STRICT
+    std::string split_note;      // ... which tensor and why (said_precision_note)
+    int* status_dev = nullptr;   // [2] sticky numeric status of the last loop / forward call (said_numeric_status)
     bool use_ugemm = true;   // SAID_NO_UGEMM=1 forces the generic kernel everywhere (A/B testing)
 
     // ---- bf16 audio encoder (tgemm.hip): bf16 weights [N][K] (convs: K = tap-major), token-major workspace ----
@@ -238,6 +242,28 @@ int fail(said_ctx* c, const char* fmt, ...) {
     va_end(ap);
     if (c) c->err = buf; else g_create_err = buf;
     return -1;
+}
+
+// fp32 mode multiplies on split-fp16 operands (split_f16.h) unless the caller asked for strict fp32 (said_set_precision) or the weights do not fit the
+// representation (scan_split_range): `opt` is one of the per-kernel-family development switches (said_debug_option), all on by default.
+inline bool strict_f32(const said_ctx* c) { return !c->bf16_mode && (c->prec_mode == SAID_PREC_FP32_STRICT || c->split_unsafe); }
+inline bool sp_on(const said_ctx* c, int opt) { return opt != 0 && !strict_f32(c); }
+
+// Range check of a tensor whose elements are split into fp16 planes (w = h + 2^-11 l, both fp16): h is finite for |w| < 65504 — a 2x margin is kept — and the
+// pair resolves 2^-36 absolute, i.e. 2^-22 of the tensor's largest element (fp32's own resolution in a dot product) only while that element is >= 2^-14.
+// Outside this range fp32 mode keeps the fp32 matrix instructions for EVERYTHING (one arithmetic per run), and said_precision_note says why.
+void scan_split_range(said_ctx* ctx, const std::string& name, const float* w, size_t n) {
+    if (ctx->split_unsafe) return;
+    float mx = 0.f;
+    bool finite = true;
+    for (size_t i = 0; i < n; ++i) { const float a = std::fabs(w[i]); if (!(a <= 3.4028234663852886e38f)) finite = false; else if (a > mx) mx = a; }
+    if (!finite || mx >= 32768.f || (mx > 0.f && mx < 6.103515625e-05f)) {
+        char b[320];
+        snprintf(b, sizeof b, "%s: max |w| = %.3g is outside [2^-14, 2^15): fp32 mode runs on v_mfma_f32_32x32x2_f32 (SAID_PREC_FP32_STRICT) instead of split-fp16 products",
+                 name.c_str(), finite ? (double)mx : INFINITY);
+        ctx->split_unsafe = true;
+        ctx->split_note = b;
+    }
 }
 
 static bool trace_on() { static int v = -1; if (v < 0) v = dev_env("SAID_TRACE") ? 1 : 0; return v == 1; }
@@ -490,6 +516,7 @@ int make_pw(said_ctx* ctx, PW* pw, const std::string& wname, const std::string& 
             if (upload(ctx, &pw->w2[s], p2.data(), p2.size())) return -1;
             if (ctx->pw_split && C % 192 == 0) {   // (KS = 8 waves x whole 24-channel blocks)
                 const bool flat = ctx->pw_split == 2;
+                if (s == 0) scan_split_range(ctx, wname, t->data.data(), t->data.size());
                 auto ps = pack_rows_split(t->data.data(), Ctot, tp, rows, (N + 31) / 32, s * C, C, flat);
                 ps.insert(ps.end(), p4.begin() + w4_floats, p4.end());
                 if (upload(ctx, &pw->ws[s], ps.data(), ps.size())) return -1;
@@ -610,7 +637,7 @@ void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS,
     if (NB == 3 && epi == EPI_STORE && c->use_ugemm && !ugemm_supports(a2, epi, 3, KS, bf)) NB = 2;   // (the two-segment fp32 shapes spill at NB = 3: not built)
     const int tt = pick_tt(c, a2, epi, batch, NB, KS, bf);
     // fp32 mode, single-tile workgroups: split-fp16 products wherever the shape is built for them (gemm_lds.hip SP) and the weights carry the packing
-    const bool sp = !bf && tt <= 1 && c->ugemm_split != 0 && c->use_ugemm && !a2.step_inc && ugemm_supports(a2, epi, NB, KS, 2);
+    const bool sp = !bf && tt <= 1 && sp_on(c, c->ugemm_split) && c->use_ugemm && !a2.step_inc && ugemm_supports(a2, epi, NB, KS, 2);
     if (c->log_on) {
         double w = 0, in = 0, fl = 0;
         const double nout = (double)a.groups * a.N * (epi == EPI_GEGLU ? 2 : 1);
@@ -647,7 +674,7 @@ void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hi
         if (trace_on()) { fprintf(stderr, "[said] attn #%d D=%d KS=%d T=%d batch=%d\n", c->dbg_count - 1, head_dim, KS, a.T, batch); fflush(stderr); }
         AttnArgs a2 = a;
         a2.b0 = c->cur_b0;
-        launch_attn(a2, batch, head_dim, KS, s, c->bf16_mode ? 1 : (c->attn_split != 0 ? (presplit ? 3 : 2) : 0));
+        launch_attn(a2, batch, head_dim, KS, s, c->bf16_mode ? 1 : (sp_on(c, c->attn_split) ? (presplit ? 3 : 2) : 0));
         if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
     }
 }
@@ -682,7 +709,7 @@ void do_tgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     TGemmArgs a2 = a;
     a2.f32 = c->bf16_mode ? 0 : 1;
     if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }   // token-major intermediate (GEGLU product) in fp32
-    a2.f32_split = (a2.f32 && c->gemm_split != 0) ? 1 : 0;
+    a2.f32_split = (a2.f32 && sp_on(c, c->gemm_split)) ? 1 : 0;
     if (dbg_go(c) && !launch_tgemm(a2, batch, s)) {
         char b[160]; snprintf(b, sizeof b, "token-major GEMM: shape M=%d N=%d K=%d (batch %d) is not served by any kernel", a.M, a.N, a.K, batch);
         c->launch_err = b;
@@ -1176,7 +1203,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     // operand buffer; the GroupNorm'ed residual uses the coefficients the q/k/v preparation finalised): 59 -> ~30 us per launch at Be = 64
     // fp32 mode: everything behind the self-attention as ONE launch (stchain.hip) — at small batches beside the channel-major GEMMs, at large ones (st_chain_large)
     // beside the token-major GEMMs' q / k / v (the attention kernel then writes channel-major, as the small-batch schedule has it)
-    const bool chain = !c->bf16_mode && c->st_chain != 0 && c->use_ugemm && sw.chain_w && sw.chain_vec && c->band_chain_ok && c->cur_b0 == 0 && !c->use_branches &&
+    const bool chain = !c->bf16_mode && sp_on(c, c->st_chain) && c->use_ugemm && sw.chain_w && sw.chain_vec && c->band_chain_ok && c->cur_b0 == 0 && !c->use_branches &&
                        ((!tg && !use_tg(c, g, g.Be)) || c->st_chain_large) && tt <= c->st_chain_max_tiles && g.S == c->band_S && g.T == c->band_T;
     const bool out1_tm = tg && !chain && !c->bf16_mode && c->f32_out1_tm && tt1 * HEADS >= 2048 && sw.tf_out1;
     bool presplit = false;   // k and v stored as packed split-fp16 pairs for attn_kernel<PM = 3> (see below)
@@ -1218,7 +1245,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
             const bool key_split = !(tt1 * HEADS >= 2048) && !(tt1 * HEADS > 8192) && !dev_env("SAID_ATTN_KS") && !dev_env("SAID_NO_ATTN_QW");
             GemmArgs probe = a;
             probe.b0 = c->cur_b0;
-            presplit = !c->bf16_mode && c->attn_split != 0 && c->attn_presplit != 0 && key_split && c->use_ugemm && !big_qkv && !c->clk_on &&
+            presplit = !c->bf16_mode && sp_on(c, c->attn_split) && c->attn_presplit != 0 && key_split && c->use_ugemm && !big_qkv && !c->clk_on &&
                        (ugemm_supports(probe, EPI_QKV, lc.NB, lc.KS, 2) || ugemm_supports(probe, EPI_QKV, lc.NB, lc.KS));
             a.kv_split = presplit ? 1 : 0;
         }
@@ -1515,7 +1542,7 @@ void run_kv(said_ctx* c, int b0, int nb, int S, int Sp, hipStream_t s) {
     const LaunchCfg lc = pick_cfg((long long)nb * ((S + 31) / 32), NST * 2 * MC / 32);
     launch_gemm(a, EPI_STORE, nb, lc.NB, lc.KS, s);
     // the key-major copy the fused SpatialTransformer tail reads its window tiles from (once per loop; fp32 mode's small-batch schedule only)
-    if ((c->bf16_mode ? c->st_chain_bf16 != 0 : c->st_chain != 0) && (long long)S * NST * 2 * MC <= (long long)NST * 2 * MC * c->maxTp)
+    if ((c->bf16_mode ? c->st_chain_bf16 != 0 : sp_on(c, c->st_chain)) && (long long)S * NST * 2 * MC <= (long long)NST * 2 * MC * c->maxTp)
     {
         // (bf16 mode: the copy itself is bf16 — the kernels round the window tiles to bf16 anyway, and at 32 clips the windows are 64 of a launch's 117 MB of HBM traffic in fp32)
         if (c->bf16_mode) launch_cm_to_tm_bf16(c->KV + b0 * ybs, ybs, Sp, reinterpret_cast<unsigned short*>(c->KVT) + (long long)b0 * S * (NST * 2 * MC), (long long)S * (NST * 2 * MC), nb, S, NST * 2 * MC, s);
@@ -1644,7 +1671,7 @@ int check_ready(said_ctx* ctx) {
 // ============================================================================================
 extern "C" {
 
-int said_abi_version(void) { return 8; }   // 8: said_loop_progress_reset; 7: said_debug_ws_*; 6: said_loop_progress; 5: said_clone, said_loop_params::noise_batch_offset; 4: said_reserve, noise_seed, said_philox_normal, said_debug_option
+int said_abi_version(void) { return 9; }   // 9: said_set_precision modes (SAID_PREC_FP32_STRICT), said_effective_precision, said_precision_note, said_numeric_status; 8: said_loop_progress_reset; 7: said_debug_ws_*; 6: said_loop_progress; 5: said_clone, said_loop_params::noise_batch_offset; 4: said_reserve, noise_seed, said_philox_normal, said_debug_option
 
 const char* said_last_error(const said_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -1691,6 +1718,7 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     int rc = 0;
     rc |= dalloc(ctx, &ctx->coef1_dev, 8);
     rc |= dalloc(ctx, &ctx->step_dev, 4);
+    rc |= dalloc(ctx, &ctx->status_dev, 4);
     rc |= dalloc(ctx, &ctx->seed_dev, 4);
     rc |= dalloc(ctx, &ctx->clk_dev, 64 * 128);
     rc |= dalloc(ctx, &ctx->freqs, MC / 2);
@@ -1830,6 +1858,7 @@ int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_fram
     int rc = 0;
     rc |= dalloc(ctx, &c->coef1_dev, 8);
     rc |= dalloc(ctx, &c->step_dev, 4);
+    rc |= dalloc(ctx, &c->status_dev, 4);
     rc |= dalloc(ctx, &c->seed_dev, 4);
     rc |= dalloc(ctx, &c->clk_dev, 64 * 128);
     rc |= alloc_workspace(c, max_batch_eff, max_frames);
@@ -1900,6 +1929,13 @@ static int pack_chain(said_ctx* ctx, STW& sw, const std::string& b, const std::v
             default: return k < FFI ? PF->data[(size_t)n * FFI + k] : PX->data[(size_t)n * MC + (k - FFI)];
         }
     };
+    {   // the matrices the stream holds that make_pw has not seen: the LayerNorm-folded to_q and GEGLU projections
+        std::vector<float> f((size_t)2 * FFI * MC);
+        for (int n = 0; n < MC; ++n) for (int k = 0; k < MC; ++k) f[(size_t)n * MC + k] = (float)elem(1, n, k);
+        scan_split_range(ctx, b + ".attn2.to_q.weight * norm2.weight", f.data(), (size_t)MC * MC);
+        for (int n = 0; n < 2 * FFI; ++n) for (int k = 0; k < MC; ++k) f[(size_t)n * MC + k] = (float)elem(3, n, k);
+        scan_split_range(ctx, b + ".ff.net.0.proj.weight * norm3.weight", f.data(), f.size());
+    }
     std::vector<_Float16> st(CHAIN_STREAM_BYTES / 2);
     size_t o = 0;
     auto put_unit = [&](int kind, int row0, int step) {
@@ -2328,11 +2364,13 @@ int said_unet_forward(said_ctx* ctx, const float* sample_dev, const int64_t* tim
     HIPCHK(hipMemcpyAsync(ctx->ts_dev, ts.data(), Be * sizeof(long long), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));  // ts is a stack-local staging buffer
     ctx->dbg_count = 0;
+    HIPCHK(hipMemsetAsync(ctx->status_dev, 0, 2 * sizeof(int), s));
     run_time_embed(ctx, Be, s);
     launch_tm_to_cm(context_dev, ctx->CTX, Be, S, ctx->ctx_dim, g.Sp, (long long)ctx->ctx_dim * g.Sp, s);
     run_kv(ctx, 0, Be, S, g.Sp, s);
     launch_tm_to_cm(sample_dev, ctx->x_cm, Be, T, ctx->cin, g.Tp, (long long)ctx->cin * g.Tp, s);
     run_unet(ctx, g, s);
+    if (ctx->dbg_stop < 0) launch_nonfinite_check(ctx->eps_cm, (long long)ctx->cin * g.Tp, g.Tp, Be, T, ctx->cin, ctx->status_dev, s);
     launch_cm_to_tm(ctx->eps_cm, out_dev, Be, T, ctx->cin, g.Tp, (long long)ctx->cin * g.Tp, s);
     LAUNCHCHK();
     HIPCHK(hipGetLastError());
@@ -2351,7 +2389,7 @@ static std::vector<long long> loop_graph_key(const said_ctx* ctx, const said_loo
     int spg = std::min(ctx->spg_limit, p->num_steps);
     if (ctx->use_branches) spg = 1;
     const int rem = spg > 0 ? p->num_steps % spg : 0;
-    return {spg, rem, p->batch, p->frames, cfg, gsi, gri, lsi, p->prediction_type, p->use_mask, p->use_step_noise, ctx->bf16_mode, p->noise_batch_offset, p->concurrent != 0,
+    return {spg, rem, p->batch, p->frames, cfg, gsi, gri, lsi, p->prediction_type, p->use_mask, p->use_step_noise, ctx->bf16_mode ? 1 : (strict_f32(ctx) ? 2 : 0), p->noise_batch_offset, p->concurrent != 0,
             (long long)(uintptr_t)(p->save_intermediate ? p->intermediates_dev : nullptr), (long long)(uintptr_t)(p->use_step_noise == 1 ? noise_cm : nullptr)};
 }
 
@@ -2422,6 +2460,7 @@ static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, boo
         launch_tm_to_cm(p->step_noise_dev, ctx->noise_cm, N * B, T, C, g.Tp, xs, s);
     }
     HIPCHK(hipMemsetAsync(ctx->step_dev, 0xFF, sizeof(int), s));  // step = -1
+    HIPCHK(hipMemsetAsync(ctx->status_dev, 0, 2 * sizeof(int), s));   // numeric status of THIS loop (the eager warm-up step below sees step 0's own data)
 
     // per-step graph
     SchedArgs sa;
@@ -2436,16 +2475,18 @@ static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, boo
     sa.init = p->use_mask ? ctx->init_cm : nullptr; sa.edit_noise = p->use_mask ? ctx->enoise_cm : nullptr;
     sa.mask = p->use_mask ? ctx->mask_cm : nullptr;
     sa.inter = p->save_intermediate ? p->intermediates_dev : nullptr; sa.latent_scale = p->latent_scale;
+    sa.status = ctx->status_dev;
 
     OutSchedArgs osa;
     memset(&osa, 0, sizeof osa);
     osa.x = ctx->P.p; osa.gn_part = ctx->P.st; osa.gn_gamma = ctx->out_g; osa.gn_beta = ctx->out_b;
-    osa.w4 = ctx->conv_out.w4[0]; osa.ws = ctx->out_split != 0 ? ctx->conv_out.ws[0] : nullptr; osa.bias = ctx->conv_out.bias; osa.coef = ctx->coef_dev; osa.step_ptr = ctx->step_dev;
+    osa.w4 = ctx->conv_out.w4[0]; osa.ws = sp_on(ctx, ctx->out_split) ? ctx->conv_out.ws[0] : nullptr; osa.bias = ctx->conv_out.bias; osa.coef = ctx->coef_dev; osa.step_ptr = ctx->step_dev;
     osa.lat = ctx->x_cm; osa.step_noise = sa.step_noise; osa.noise_seed = sa.noise_seed; osa.noise_elem0 = sa.noise_elem0; osa.init = sa.init; osa.edit_noise = sa.edit_noise; osa.mask = sa.mask;
     osa.inter = sa.inter; osa.x_bstride = g.hs; osa.gn_part_bstride = g.sts; osa.lat_bstride = xs;
     osa.pitch = g.Tp; osa.T = T; osa.B = B; osa.Cin = MC; osa.Cout = C; osa.gn_nparts = g.np; osa.cfg = cfg ? 1 : 0;
     osa.prediction_type = p->prediction_type; osa.guidance_scale = p->guidance_scale; osa.guidance_rescale = sa.guidance_rescale;
     osa.latent_scale = p->latent_scale;
+    osa.status = ctx->status_dev;
     static const bool no_fuse = dev_env("SAID_NO_FUSE_SCHED") != nullptr;
     const bool fused = !no_fuse && !ctx->use_branches && ctx->conv_out.w4[0] && out_sched_supports(osa);
     if (fused) g.out_sched = &osa;
@@ -2533,7 +2574,7 @@ static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, boo
         if (rem > 0) HIPCHK(hipGraphLaunch(ctx->gexec_rem, s));
     }
     TRACE("loop: graphs launched");
-    launch_finish(ctx->x_cm, xs, g.Tp, B, T, C, p->latent_scale, p->latents_dev, p->result_dev, s);
+    launch_finish(ctx->x_cm, xs, g.Tp, B, T, C, p->latent_scale, p->latents_dev, p->result_dev, s, ctx->dbg_stop < 0 ? ctx->status_dev : nullptr);
     LAUNCHCHK();
     HIPCHK(hipGetLastError());
     return 0;
@@ -2668,12 +2709,12 @@ long long said_debug_get(const said_ctx* ctx, const char* name) {
     if (k == "audio_chunk") return ctx->audio_chunk;
     if (k == "steps_per_graph") return ctx->spg_limit;
     if (k == "tm_acts") return ctx->tm_acts;
-    if (k == "gemm_split") return (!ctx->bf16_mode && ctx->gemm_split != 0) ? 1 : 0;
-    if (k == "ugemm_split") return (!ctx->bf16_mode && ctx->ugemm_split != 0) ? 1 : 0;
-    if (k == "st_chain") return (!ctx->bf16_mode && ctx->st_chain != 0) ? 1 : 0;
+    if (k == "gemm_split") return (!ctx->bf16_mode && sp_on(ctx, ctx->gemm_split)) ? 1 : 0;
+    if (k == "ugemm_split") return (!ctx->bf16_mode && sp_on(ctx, ctx->ugemm_split)) ? 1 : 0;
+    if (k == "st_chain") return (!ctx->bf16_mode && sp_on(ctx, ctx->st_chain)) ? 1 : 0;
     if (k == "n_stchain") return ctx->n_stchain;
     if (k == "st_chain_bf16") return (ctx->bf16_mode && ctx->st_chain_bf16 != 0) ? 1 : 0;
-    if (k == "attn_split") return (!ctx->bf16_mode && ctx->attn_split != 0) ? 1 : 0;   // 1: fp32-mode attention products run on split-fp16 operands
+    if (k == "attn_split") return (!ctx->bf16_mode && sp_on(ctx, ctx->attn_split)) ? 1 : 0;   // 1: fp32-mode attention products run on split-fp16 operands
     if (k == "rgemm") return ctx->rgemm;
     if (k == "n_rgemm") return ctx->n_rgemm;
     if (k == "n_xgemm") return ctx->n_xgemm;
@@ -2723,7 +2764,7 @@ static const char* ws_name(const said_ctx* c, const void* p) {
     const std::pair<const void*, const char*> t[] = {
         {c->x_cm, "x"}, {c->eps_cm, "eps"}, {c->H0.p, "H0"}, {c->H1.p, "H1"}, {c->P.p, "P"}, {c->Q.p, "Q"}, {c->M.p, "M"},
         {c->H0.st, "stH0"}, {c->H1.st, "stH1"}, {c->P.st, "stP"}, {c->Q.st, "stQ"}, {c->M.st, "stM"},
-        {c->X1, "X1"}, {c->X2, "X2"}, {c->X3, "X3"}, {c->O, "O"}, {c->QK, "QK"}, {c->VT, "VT"}, {c->F, "F"}, {c->KV, "KV"}, {c->CTX, "CTX"},
+        {c->X1, "X1"}, {c->X2, "X2"}, {c->X3, "X3"}, {c->O, "O"}, {c->QK, "QK"}, {c->VT, "VT"}, {c->F, "F"}, {c->KV, "KV"}, {c->KVT, "KVT"}, {c->CTX, "CTX"},
         {c->E0, "E0"}, {c->E1, "E1"}, {c->E2, "E2"}, {c->EO, "EO"}, {c->ts_dev, "ts"}, {c->coef_dev, "coef"}, {c->axpby_coef, "axpby_coef"},
         {c->band_lo, "band_lo"}, {c->band_hi, "band_hi"}, {c->init_cm, "init_cm"}, {c->enoise_cm, "enoise_cm"}, {c->mask_cm, "mask_cm"},
         {c->rescale_part, "rescale_part"}, {c->uPA, "uPA"}, {c->uPB, "uPB"}, {c->uPL, "uPL"}, {c->uPH, "uPH"}, {c->uPX, "uPX"}, {c->gn_coef, "gn_coef"},
@@ -2841,16 +2882,31 @@ int said_loop_progress_reset(said_ctx* ctx) {
     return 0;
 }
 
-int said_set_precision(said_ctx* ctx, int bf16_mfma) {
+int said_set_precision(said_ctx* ctx, int mode) {
     if (!ctx) return -1;
-    const bool want = bf16_mfma != 0;
-    if (want != ctx->bf16_mode) {
-        ctx->bf16_mode = want;
+    if (mode != SAID_PREC_FP32 && mode != SAID_PREC_BF16 && mode != SAID_PREC_FP32_STRICT) return fail(ctx, "said_set_precision: unknown mode %d", mode);
+    if (mode != ctx->prec_mode) {
+        ctx->prec_mode = mode;
+        ctx->bf16_mode = mode == SAID_PREC_BF16;
         ctx->gkey.clear();   // the captured step graph holds the other kernels
     }
     return 0;
 }
-int said_get_precision(const said_ctx* ctx) { return (ctx && ctx->bf16_mode) ? 1 : 0; }
+int said_get_precision(const said_ctx* ctx) { return ctx ? ctx->prec_mode : 0; }
+int said_effective_precision(const said_ctx* ctx) { return !ctx ? 0 : (ctx->bf16_mode ? SAID_PREC_BF16 : (strict_f32(ctx) ? SAID_PREC_FP32_STRICT : SAID_PREC_FP32)); }
+const char* said_precision_note(const said_ctx* ctx) { return ctx ? ctx->split_note.c_str() : ""; }
+
+int said_numeric_status(said_ctx* ctx, void* stream, int* first_bad_step, int* result_nonfinite) {
+    if (!ctx) return -1;
+    DeviceRestore restore_device;
+    HIPCHK(hipSetDevice(ctx->device));
+    int v[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(v, ctx->status_dev, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (first_bad_step) *first_bad_step = v[0] - 1;
+    if (result_nonfinite) *result_nonfinite = v[1];
+    return 0;
+}
 
 double said_unet_algorithmic_bytes(int Be, int T, int bytes_per_elem) {
     // W + Be*T*A, A = 63,232 B/token at fp32
@@ -3139,7 +3195,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                 a.qk = ctx->aQK; a.v = ctx->aVT; a.o = ctx->aO;
                 a.v_bstride = hs; a.o_bstride = 2 * hs; a.b0 = 0;
                 a.pitch = Fp; a.T = Fr; a.heads = W2V_HEADS; a.rows = vt_rows; a.scale = 0.125f;
-                launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : (tt * W2V_HEADS <= 8192 ? 4 : 1), s, ctx->attn_split != 0 ? 2 : 0);
+                launch_attn(a, nb, W2V_HD, tt * W2V_HEADS <= 2048 ? 8 : (tt * W2V_HEADS <= 8192 ? 4 : 1), s, sp_on(ctx, ctx->attn_split) ? 2 : 0);
             }
             {
                 GemmArgs a = mkargs(Fr, W2V_H);

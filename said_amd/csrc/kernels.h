@@ -217,6 +217,7 @@ struct SchedArgs {
     float latent_scale;
     const unsigned* noise_seed;   // device [2] Philox key: the eta noise is generated in the kernel (sched_math.h), or null
     unsigned noise_elem0;         // element index of this call's first clip in the whole batch (clip groups on concurrent streams draw the noise of ONE batch)
+    int* status;                  // device [2] sticky numeric status (said_numeric_status): [0] <- 1 + the first step whose model output was not finite, or null
 };
 void launch_sched_step(const SchedArgs& a, hipStream_t s);
 
@@ -248,6 +249,7 @@ struct OutSchedArgs {
     const void* x_tm;
     const void* wb;
     int seg;
+    int* status;               // see SchedArgs
 };
 bool out_sched_supports(const OutSchedArgs& a);
 bool out_sched_tm_supports(const OutSchedArgs& a);
@@ -266,8 +268,11 @@ void launch_axpby(const float* a_dev, const float* x, const float* c_dev, const 
 // out (nsteps, B, T, C) token-major <- the standard normals the loop's kernels generate for (seed, step0 + k, element)
 void launch_philox_normal(const unsigned* seed_dev, int step0, int nsteps, long long n_per_step, float* out, hipStream_t s);
 // result = clamp(x / latent_scale, 0, 1), channel-major -> token-major; also copies latents out
+// status (optional): [1] <- 1 when a final latent is not finite (said_numeric_status)
 void launch_finish(const float* x_cm, long long x_bstride, int pitch, int B, int T, int C, float latent_scale,
-                   float* latents_tm, float* result_tm, hipStream_t s);
+                   float* latents_tm, float* result_tm, hipStream_t s, int* status = nullptr);
+// status[1] <- 1 when any of x[b][c][t < T] (channel-major) is not finite: said_unet_forward's model output
+void launch_nonfinite_check(const float* x_cm, long long x_bstride, int pitch, int B, int T, int C, int* status, hipStream_t s);
 
 // UNet input conv (32 -> Cout, k3) + GroupNorm partials + step-counter increment (conv_in.hip): one result per clip,
 // written to `copies` batch halves (clip b -> samples b, b + B, ...)

@@ -254,6 +254,7 @@ __global__ void sched_step_kernel(const SchedArgs a) {
     }
     float* xp = a.x + (long long)b * a.x_bstride + off;
     const float x = *xp;
+    note_nonfinite(e, a.status, step);
     if (a.inter) a.inter[(((long long)step * a.B + b) * a.T + t) * a.C + c] = x / a.latent_scale;
     float prev = ddim_prev(e, x, cf, a.prediction_type);
     if (a.step_noise) {
@@ -321,7 +322,7 @@ void launch_axpby(const float* a_dev, const float* x, const float* c_dev, const 
 }
 
 __global__ void finish_kernel(const float* __restrict__ x, long long x_bstride, int pitch, int T, int C, float latent_scale,
-                              float* __restrict__ latents_tm, float* __restrict__ result_tm) {
+                              float* __restrict__ latents_tm, float* __restrict__ result_tm, int* __restrict__ status) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -335,15 +336,24 @@ __global__ void finish_kernel(const float* __restrict__ x, long long x_bstride, 
         if (c < C && t < T) {
             const float v = tile[tx][r];
             const long long o = ((long long)b * T + t) * C + c;
+            if (status && !(fabsf(v) <= 3.4028234663852886e38f)) status[1] = 1;
             if (latents_tm) latents_tm[o] = v;
-            if (result_tm) result_tm[o] = fminf(fmaxf(v / latent_scale, 0.f), 1.f);  // diffusion.py:470
+            const float q = v / latent_scale;
+            if (result_tm) result_tm[o] = (q != q) ? q : fminf(fmaxf(q, 0.f), 1.f);  // diffusion.py:470 (torch.clamp keeps a NaN)
         }
     }
 }
 void launch_finish(const float* x_cm, long long x_bstride, int pitch, int B, int T, int C, float latent_scale,
-                   float* latents_tm, float* result_tm, hipStream_t s) {
+                   float* latents_tm, float* result_tm, hipStream_t s, int* status) {
     dim3 grid((T + 31) / 32, (C + 31) / 32, B);
-    hipLaunchKernelGGL(finish_kernel, grid, dim3(256), 0, s, x_cm, x_bstride, pitch, T, C, latent_scale, latents_tm, result_tm);
+    hipLaunchKernelGGL(finish_kernel, grid, dim3(256), 0, s, x_cm, x_bstride, pitch, T, C, latent_scale, latents_tm, result_tm, status);
+}
+__global__ void nonfinite_check_kernel(const float* __restrict__ x, long long x_bstride, int pitch, int T, int* __restrict__ status) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T && !(fabsf(x[(long long)blockIdx.z * x_bstride + (long long)blockIdx.y * pitch + t]) <= 3.4028234663852886e38f)) status[1] = 1;
+}
+void launch_nonfinite_check(const float* x_cm, long long x_bstride, int pitch, int B, int T, int C, int* status, hipStream_t s) {
+    hipLaunchKernelGGL(nonfinite_check_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, s, x_cm, x_bstride, pitch, T, status);
 }
 
 // ------------------------------------------------------------------------------------------

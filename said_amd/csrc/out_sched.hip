@@ -229,6 +229,7 @@ __global__ __launch_bounds__(64 * OS_KS) void out_sched_kernel(const float* hx, 
         const int n = e_n[j];
         if (!(tok && n < a.Cout)) continue;
         const float x = e_x[j];
+        note_nonfinite(e, a.status, step);
         if (a.inter) a.inter[(((long long)step * a.B + b) * T + t) * a.Cout + n] = x / a.latent_scale;
         float prev = ddim_prev(e, x, cfv, a.prediction_type);
         if (a.step_noise) prev = __fadd_rn(prev, __fmul_rn(cfv[4], e_nz[j]));
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(256) void out_sched_tm_kernel(const OutSchedArgs a)
         const int n = e_n[j];
         if (!(tok && n < a.Cout)) continue;
         const float x = e_x[j];
+        note_nonfinite(e, a.status, step);
         if (a.inter) a.inter[(((long long)step * a.B + b) * T + t) * a.Cout + n] = x / a.latent_scale;
         float prev = ddim_prev(e, x, cfv, a.prediction_type);
         if (a.step_noise) prev = __fadd_rn(prev, __fmul_rn(cfv[4], e_nz[j]));

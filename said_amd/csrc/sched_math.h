@@ -27,8 +27,13 @@ __device__ __forceinline__ float ddim_prev(float model_out, float x, const float
         x0 = __fsub_rn(__fmul_rn(sa, x), __fmul_rn(sb, model_out));
         e = __fadd_rn(__fmul_rn(sa, model_out), __fmul_rn(sb, x));
     }
-    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);  // clip_sample=True, range 1.0
+    x0 = (x0 != x0) ? x0 : fminf(fmaxf(x0, -1.0f), 1.0f);  // clip_sample=True, range 1.0 (torch.clamp keeps a NaN; fminf / fmaxf alone would turn it into -1)
     return __fadd_rn(__fmul_rn(sap, x0), __fmul_rn(dir, e));
+}
+// The model output of a step is not finite: remember the first such step (said_numeric_status).  fp32 mode multiplies on split-fp16 operands
+// (split_f16.h: |x| < 65504); an operand beyond that becomes inf / NaN in its product and reaches this point through every later layer.
+__device__ __forceinline__ void note_nonfinite(float model_out, int* status, int step) {
+    if (status && !(fabsf(model_out) <= 3.4028234663852886e38f)) atomicCAS(status, 0, step + 1);
 }
 __device__ __forceinline__ float mask_blend(float prev, float init, float enoise, float mask, const float* cf) {
     // diffusion.py:446-456: add_noise(init, noise, t_next) * mask + latents * (1 - mask)

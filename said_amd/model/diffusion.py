@@ -16,6 +16,7 @@ so a CPU oracle and the GPU path can be fed identical noise.
 from __future__ import annotations
 
 import threading
+import warnings
 import weakref
 from abc import ABC
 from dataclasses import dataclass
@@ -116,7 +117,12 @@ class SAID(ABC, nn.Module):
         self._eng_key = None
         self._eng_stale = True
         self._param_list = None
-        self.mfma_dtype = "fp32"   # "bf16": bf16 multiplies in the UNet GEMMs (BASELINE.json configs[2]); set_mfma_dtype()
+        self.mfma_dtype = "fp32"   # "fp32" (split-fp16 products) | "fp32_strict" (fp32 matrix instructions) | "bf16" (BASELINE.json configs[2]); set_mfma_dtype()
+        # What inference() / forward() do when the model output of a step is not finite (said_numeric_status).  In "fp32" mode that can be an operand beyond the
+        # split-fp16 products' domain (|x| < 65504: include/said_hip.h) where the reference's fp32 would have been fine:
+        #   "strict_retry" (default): warn and run the call again on fp32 matrix instructions, with the same random draws;
+        #   "raise": EngineError;   "ignore": no check (and no stream synchronisation at the end of inference()).
+        self.on_nonfinite = "strict_retry"
         self.dedupe_audio = True    # SAID.inference encodes byte-identical rows of a batch once (not part of the reference surface)
         self.clip_groups = None     # None: decided per call (_pick_clip_groups); n >= 1: that many concurrent clip groups
         self._clones: List[_engine.Engine] = []
@@ -186,16 +192,27 @@ class SAID(ABC, nn.Module):
                 e.close()
                 self._eng = None
                 raise
-        e.set_precision(self.mfma_dtype == "bf16")
+        e.set_precision(self.mfma_dtype)
         return e
 
     def set_mfma_dtype(self, dtype: str) -> "SAID":
-        """"fp32" (default; the reference's precision) or "bf16": operands of the UNet GEMMs / convolutions are rounded
-        to bfloat16, accumulation and everything else stays fp32.  Not part of the reference surface."""
-        if dtype not in ("fp32", "bf16"):
-            raise ValueError(f"mfma dtype must be 'fp32' or 'bf16', got {dtype!r}")
+        """How the matrix products multiply (include/said_hip.h, said_set_precision): "fp32" (default: fp32 tensors, products on split-fp16
+        operands, 22-bit significands, operand domain |x| < 65504), "fp32_strict" (fp32 matrix instructions on fp32 operands: the reference's
+        arithmetic, slower) or "bf16" (operands rounded to bfloat16).  Accumulation and everything else is fp32 in every mode.  Not part of the
+        reference surface."""
+        if dtype not in _engine.PRECISIONS:
+            raise ValueError(f"mfma dtype must be one of {sorted(_engine.PRECISIONS)}, got {dtype!r}")
         self.mfma_dtype = dtype
         return self
+
+    def _nonfinite(self, engines) -> Optional[str]:
+        """None, or a description of the first engine whose last call produced an inf / NaN (synchronises the current stream)."""
+        for i, e in enumerate(engines):
+            step, res = e.numeric_status()
+            if step >= 0 or res:
+                where = f"model output of denoise step {step}" if step >= 0 else "result"
+                return f"{where} is not finite" + (f" (clip group {i})" if len(engines) > 1 else "")
+        return None
 
     # ---- reference surface -----------------------------------------------------
     def forward(self, noisy_samples: torch.FloatTensor, timesteps: torch.LongTensor, audio_embedding: torch.FloatTensor) -> torch.FloatTensor:
@@ -203,7 +220,20 @@ class SAID(ABC, nn.Module):
         timestep_size = timesteps.size()
         if len(timestep_size) == 0 or timestep_size[0] == 1:
             timesteps = timesteps.reshape(-1)[:1].repeat(noisy_samples.shape[0])
-        return self.denoiser(noisy_samples, timesteps, audio_embedding)
+        out = self.denoiser(noisy_samples, timesteps, audio_embedding)
+        if self.on_nonfinite != "ignore" and self._eng is not None:
+            bad = self._nonfinite([self._eng])
+            if bad is not None and self._eng.effective_precision() == "fp32":
+                if self.on_nonfinite == "raise":
+                    raise _engine.EngineError(f"SAID.forward: {bad} in fp32 mode (split-fp16 products, operand domain |x| < 65504); use set_mfma_dtype('fp32_strict')")
+                warnings.warn(f"SAID.forward: {bad} on split-fp16 products; evaluating again on fp32 matrix instructions (set_mfma_dtype('fp32_strict') avoids the first attempt)",
+                              RuntimeWarning, stacklevel=2)
+                old, self.mfma_dtype = self.mfma_dtype, "fp32_strict"
+                try:
+                    out = self.denoiser(noisy_samples, timesteps, audio_embedding)
+                finally:
+                    self.mfma_dtype = old
+        return out
 
     def pred_original_sample(self, noisy_samples, noise, timesteps):
         """x_0 = (x_t - sqrt(1-ā) eps) / sqrt(ā)  (diffusion.py:157-186)."""
@@ -291,7 +321,7 @@ class SAID(ABC, nn.Module):
         while len(self._clones) < n:
             self._clones.append(eng.clone(max_batch_eff, frames_r))
         for c in self._clones[:n]:
-            c.set_precision(self.mfma_dtype == "bf16")
+            c.set_precision(self.mfma_dtype)
         return self._clones[:n]
 
     def inference(self, waveform_processed: torch.FloatTensor, init_samples: Optional[torch.FloatTensor] = None,
@@ -373,6 +403,25 @@ class SAID(ABC, nn.Module):
         progress = _Progress(eng, n_run) if (show_process and n_run > 0) else None
         try:
             result, inter = self._run_groups(G, eng, job, batch_size, do_cfg, window_size, n_run, save_intermediate, device)
+            if self.on_nonfinite != "ignore" and n_run > 0:
+                # One synchronisation per call: did a step's model output overflow?  (The final clamp to [0, 1] would otherwise be all a caller sees.)
+                used = [eng] + (self._clones[:G - 1] if G > 1 else [])
+                bad = self._nonfinite(used)
+                if bad is not None and eng.effective_precision() == "fp32":
+                    if self.on_nonfinite == "raise":
+                        raise _engine.EngineError(f"SAID.inference: {bad} in fp32 mode (split-fp16 products, operand domain |x| < 65504); use set_mfma_dtype('fp32_strict')")
+                    warnings.warn(f"SAID.inference: {bad} on split-fp16 products (operand domain |x| < 65504); running the call again on fp32 matrix instructions "
+                                  "with the same random draws (set_mfma_dtype('fp32_strict') avoids the first attempt)", RuntimeWarning, stacklevel=2)
+                    old, self.mfma_dtype = self.mfma_dtype, "fp32_strict"
+                    try:
+                        eng.set_precision("fp32_strict")
+                        result, inter = self._run_groups(G, eng, job, batch_size, do_cfg, window_size, n_run, save_intermediate, device)
+                        bad = self._nonfinite(used)
+                    finally:
+                        self.mfma_dtype = old
+                        eng.set_precision(old)
+                if bad is not None:   # bf16 / strict fp32: the reference's own fp32 evaluation would overflow likewise (or bf16's range did)
+                    warnings.warn(f"SAID.inference: {bad} ({eng.effective_precision()} mode)", RuntimeWarning, stacklevel=2)
             if progress is not None:
                 torch.cuda.current_stream(device).synchronize()   # (the reference's loop is synchronous: the bar ends when the result exists)
         finally:

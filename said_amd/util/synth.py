@@ -252,3 +252,35 @@ def synth_latents(index: int, shape: Tuple[int, ...]) -> torch.Tensor:
     g = torch.Generator()
     g.manual_seed(index)
     return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+def trained_like_state_dict(num_w2v_layers: int = W2V_LAYERS, ctx_dim: int = 768, salt: int = 0) -> Dict[str, torch.Tensor]:
+    """said_state_dict() reshaped towards what trained checkpoints look like (none is reachable offline): the denoiser's linear / conv
+    weights get a log-normal heavy tail (x exp(0.5 N(0, 1))), two outlier output rows and two outlier input columns per matrix (x 8), and
+    a tenth of every GroupNorm / LayerNorm's gains are drawn log-uniformly from [0.1, 10] with biases up to +-1 — the statistics that
+    stress reduced-precision products (outlier channels, gains >> 1, un-normalised residual streams of O(100)).  Deterministic, name-keyed."""
+    sd = said_state_dict(num_w2v_layers, ctx_dim, salt)
+    for k in list(sd):
+        if not k.startswith("denoiser."):
+            continue
+        v = sd[k]
+        g = torch.Generator()
+        g.manual_seed((zlib.crc32(("trained:" + k).encode()) + 7919 * salt) & 0x7FFFFFFF)
+        name = k[len("denoiser."):]
+        if _is_norm_name(name):
+            n = v.shape[0]
+            pick = torch.rand(n, generator=g) < 0.1
+            if k.endswith(".weight"):
+                wide = torch.exp((torch.rand(n, generator=g) * 2 - 1) * 2.302585092994046)   # log-uniform in [0.1, 10]
+                v = torch.where(pick, wide, v)
+            else:
+                v = torch.where(pick, torch.rand(n, generator=g) * 2 - 1, v)
+        elif v.dim() >= 2:
+            v = v * torch.exp(0.5 * torch.randn(v.shape, generator=g))
+            rows = torch.randint(0, v.shape[0], (2,), generator=g)
+            cols = torch.randint(0, v.shape[1], (2,), generator=g)
+            v = v.clone()
+            v[rows] *= 8.0
+            v[:, cols] *= 8.0
+        sd[k] = v.contiguous()
+    return sd

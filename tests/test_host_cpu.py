@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/said_hip.h but not exported"
     assert declared == set(_engine.EXPORTS), (declared ^ set(_engine.EXPORTS))
-    assert lib.said_abi_version() == _engine.ABI_VERSION == 8
+    assert lib.said_abi_version() == _engine.ABI_VERSION == 9
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
