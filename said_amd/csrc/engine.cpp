@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/said_hip.h"
+#include "said_hip_debug.h"
 #include "kernels.h"
 #include "stchain.h"
 #include "tgemm.h"
@@ -58,6 +59,7 @@ struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out
              void *tf_qkv = nullptr, *tf_ff1 = nullptr, *tf_ffproj = nullptr; /* fp32 copies (fgemm_kernel) */
              void *t_out1 = nullptr, *t_q2 = nullptr, *t_out2 = nullptr, *tf_out1 = nullptr, *tf_q2 = nullptr, *tf_out2 = nullptr; /* [192][192] (xgemm_kernel) */
              float *chain_w = nullptr, *chain_vec = nullptr; /* round 5: weight stream + vectors of the fused tail (stchain.hip) */
+             float* chain_w3 = nullptr; /* round 6: the three-slice stream (small launches: three workgroups per token tile) */
              void* chain_wb = nullptr; /* ... and the bf16 stream (1 KB units) of its bf16-mode variant */ };
 struct W2VLayer { PW qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln2g, *ln2b; };
 
@@ -111,13 +113,16 @@ struct said_ctx {
     float *KV = nullptr, *CTX = nullptr;
     float* KVT = nullptr;        // key-major copy of KV [sample][S][NST * 2 * MC] for the fused SpatialTransformer tail (stchain.hip), made by run_kv
     bool band_chain_ok = false;  // the alignment band fits stchain's window tile (set_band)
-    bool band_chain2_ok = false; // ... and the two-tile bf16 variant's (pairs of tiles: CHAIN2_KW rows)
     bool st_chain_large = true;  // ... at large batches too, beside the token-major q / k / v GEMM (32 clips: 3.2 -> 2.4 ms per step; said_debug_option "st_chain_large")
     long long st_chain_max_tiles = 1LL << 40;   // ... while the launch is at most this many workgroups (sample x 32-token tiles; said_debug_option "st_chain_max_tiles")
     int st_chain_bf16 = -1;      // bf16 mode, large batches: the same fused tail on bf16 operands instead of rgemm's five launches; 0: off; -1 / 1: stchain_kernel<true> (one token tile per
-                                 // workgroup, two workgroups per CU); 2: stchain2_kernel (two tiles per workgroup sharing every weight fragment: measured slower, 96 vs 83 us)
-                                 // (said_debug_option "st_chain_bf16")
+                                 // workgroup, two workgroups per CU; said_debug_option "st_chain_bf16").  (Round 5's two-tiles-per-workgroup variant measured slower — 96 vs 83 us,
+                                 // profiles/r05p_stchain2_two_tiles_ab.txt — and was removed in round 6.)
     bool st_chain_dbg = false;   // debug: the fused kernel also writes x1 / x2 to X1 / X2
+    int st_chain_slices = -1;    // fp32 mode: -1 / 3: launches of at most CHAIN3_MAX_TILES (sample, token tile) pairs run THREE workgroups per tile (stchain.hip S3); 1: never
+                                 // (said_debug_option "st_chain_slices")
+    float* chain_part = nullptr; // ... their partial sums [CHAIN3_MAX_TILES][3][6][16][64] (workspace)
+    int* chain_ticket = nullptr; // ... and arrival counters [CHAIN3_MAX_TILES][6]: zero between launches (not part of the workspace: said_debug_ws_fill must not touch them)
     int st_chain = -1;           // fp32 mode, small batches: everything behind self-attention as ONE launch per block (stchain.hip); 0: the five launches
                                  // (said_debug_option "st_chain")
     float *E0 = nullptr, *E1 = nullptr, *E2 = nullptr, *EO = nullptr;
@@ -165,16 +170,15 @@ struct said_ctx {
     float* gn_coef = nullptr;   // [2 slots][maxBe][192][2] GroupNorm coefficients for prep_kernel
     void *uPA = nullptr, *uPB = nullptr, *uPL = nullptr, *uPH = nullptr, *uPX = nullptr;   // conv operand [Be][T+2][384], raw cat input
                                                                                             // [Be][T][384], LN'd [Be][T][192], GEGLU out [Be][T][768], raw x2 [Be][T][192]
-    int tm_acts = -1;         // large batches: token-major activations BETWEEN the UNet kernels, operand transforms inside the GEMMs (round 3: 41
-                              // launches per step, no preparation kernels).  -1 = by precision mode: ON in bf16 mode (1.774 vs 1.841 ms per step at
-                              // 32 clips once its kernels stopped spilling), off in fp32 mode (4.78 vs 4.41); 0 / 1 force it (said_debug_option "tm_acts")
+    int tm_acts = -1;         // bf16 mode, large batches: token-major bf16 activations BETWEEN the UNet kernels, operand transforms inside the GEMMs (-1 / 1: on; 0: the
+                              // channel-major schedule with preparation kernels — said_debug_option "tm_acts").  The fp32 twin of this schedule (round 3: 4.78 vs 4.41 ms per
+                              // step at 32 clips) was removed in round 6 together with xgemm_kernel's fp32 instantiations.
     bool mt_mid = true;       // multi-tile workgroups for mid-size launches too (said_debug_option "mt_mid")
     int mt_wgs = 0;           // > 0: multi-tile workgroups from this many workgroups per token tile on (said_debug_option "mt_wgs"; default 1024)
     int tgemm_sb = 1;         // audio encoder (bf16): the single-LDS-buffer 128 x 128 GEMM variant, three workgroups per CU (said_debug_option "tgemm_sb"; 0: double buffer, two per CU)
     int unet_nb = 0;          // > 0: forces pick_unet's column tiles per workgroup (said_debug_option "unet_nb")
     bool unet_nb_model = true; // pick_unet by the busiest-CU model (0: round 2's rule; said_debug_option "unet_nb_model")
     bool f32_out1_tm = true;  // fp32 large batch: attn1.to_out on the token-major fp32 GEMM (said_debug_option "f32_out1_tm")
-    bool hybrid_f32 = false;  // (experiment: the hybrid schedule in fp32 mode too — said_debug_option "hybrid_f32")
     bool hybrid = true;       // bf16 mode at large batch: SpatialTransformers from the attention output on use round 3's token-major kernels
     int xgemm_dbg = 0;
     bool xclk_on = false;
@@ -217,7 +221,6 @@ struct said_ctx {
     size_t a_tok_elems = 0; int a_chunk = 0;
 
     // ---- per-step graph ----
-    bool audio_front_fused = true;     // bf16 encoder: conv0 + GroupNorm + GELU in one recomputing pass (said_debug_option "audio_front_fused")
     hipStream_t cap_stream = nullptr;  // private stream used only to capture the per-step graph
     hipStream_t own_stream = nullptr;  // a clone's stream (said_stream): from the process-wide pool below, never destroyed
     int n_clones = 0;                  // clones made of this context so far (picks the pool slot)
@@ -754,7 +757,7 @@ inline int tm_seg(const UGeo& g) { return rup(g.T, 64); }   // sample pitch in t
 // (32-bit element offsets inside the kernels: the widest token-major tensor here is the GEGLU product, sample pitch tm_seg — up to 4/3 of
 // the rup(T + 2, 32) pitch use_tg's guard is written for)
 inline bool use_tm(said_ctx* c, const UGeo& g) {
-    return (c->tm_acts < 0 ? c->bf16_mode : c->tm_acts != 0) && use_tg(c, g, g.Be) && g.b0 == 0 && ((long long)g.Be * tm_seg(g) + 2) * FFI < 0x7fffffffLL;
+    return c->bf16_mode && c->tm_acts != 0 && use_tg(c, g, g.Be) && g.b0 == 0 && ((long long)g.Be * tm_seg(g) + 2) * FFI < 0x7fffffffLL;
 }
 // `rows` tokens further into a token-major tensor of row width `ld` (element size by precision mode)
 inline void* tm_at(const said_ctx* c, void* base, long long rows, int ld) { return static_cast<char*>(base) + rows * ld * (c->bf16_mode ? 2 : 4); }
@@ -938,7 +941,7 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
         }
         if (c->xclk_on && c->dbg_count < 64) ca.clk = c->clk_dev + (long long)c->dbg_count * 128;   // (said_debug_option "xgemm_clk": -DSAID_CLK_STAMPS builds)
         if (dbg_go(c)) {
-            launch_stchain(ca, static_cast<const float*>(c->tO), static_cast<const float*>(in.t), g.T, g.Tp, seg * MC, seg * MC, shared ? g.Bc : 0, g.Bc > 0 ? g.Bc : 0, g.Be, s, true, c->st_chain_bf16 == 2 && c->band_chain2_ok);
+            launch_stchain(ca, static_cast<const float*>(c->tO), static_cast<const float*>(in.t), g.T, g.Tp, seg * MC, seg * MC, shared ? g.Bc : 0, g.Bc > 0 ? g.Bc : 0, g.Be, s, true);
             ++c->n_stchain;
         }
         return;
@@ -1198,7 +1201,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     const int vt_rows = rup(g.T, 32);
     const long long obs = 2LL * MC * g.Tp;   // batch stride of O (shared with QK so attention uses one stride)
     const bool tg = use_tg(c, g, n1);
-    if (c->hybrid && (c->bf16_mode || c->hybrid_f32) && tg && use_tg(c, g, g.Be) && g.b0 == 0) { run_transformer_hybrid(c, g, sw, blk, in, out, s, shared); return; }
+    if (c->hybrid && c->bf16_mode && tg && use_tg(c, g, g.Be) && g.b0 == 0) { run_transformer_hybrid(c, g, sw, blk, in, out, s, shared); return; }
     // fp32 mode: attn1.to_out on the token-major fp32 GEMM too (the attention kernel writes its operand token-major into the free q/k/v
     // operand buffer; the GroupNorm'ed residual uses the coefficients the q/k/v preparation finalised): 59 -> ~30 us per launch at Be = 64
     // fp32 mode: everything behind the self-attention as ONE launch (stchain.hip) — at small batches beside the channel-major GEMMs, at large ones (st_chain_large)
@@ -1276,6 +1279,10 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         ca.kvt = c->KVT; ca.kvt_bs = (long long)g.S * (NST * 2 * MC); ca.lo = c->band_lo; ca.hi = c->band_hi;
         ca.y = out.p; ca.y_bs = g.hs; ca.stats_out = out.st; ca.stats_bs = g.sts;
         ca.S = g.S; ca.np = g.np; ca.koff = blk * 2 * MC; ca.wmax = c->band_wmax; ca.scale = 0.17677669529663687f;
+        // small launches: three workgroups per token tile, each streaming a third of the GEGLU / folded proj_out weights (38 workgroups on 256 CUs were bound by
+        // one CU's L2 port each: 2.36 MB per workgroup) — while the launch still is one round of the chip
+        ca.slices = (c->st_chain_slices != 1 && sw.chain_w3 && tt <= CHAIN3_MAX_TILES && !c->st_chain_dbg) ? 3 : 1;
+        if (ca.slices == 3) { ca.wstream = sw.chain_w3; ca.part = c->chain_part; ca.ticket = c->chain_ticket; }
         if (c->clk_on && c->dbg_count < 64) ca.clk = c->clk_dev + (long long)c->dbg_count * 128;
         if (c->st_chain_dbg) { ca.dbg_x1 = c->X1; ca.dbg_x2 = c->X2; ca.dbg_o2 = c->X3; }
         if (c->log_on) {
@@ -1579,12 +1586,6 @@ int set_band(said_ctx* ctx, int T, int S, hipStream_t s) {
             ok = hmax - lo[t0] <= CHAIN_KW;
         }
         ctx->band_chain_ok = ok;
-        for (int t0 = 0; t0 < T && ok; t0 += 64) {   // stchain2_kernel: one window tile per PAIR of token tiles
-            int hmax = 0;
-            for (int i = t0; i < std::min(T, t0 + 64); ++i) hmax = std::max(hmax, hi[i]);
-            ok = hmax - lo[t0] <= CHAIN2_KW;
-        }
-        ctx->band_chain2_ok = ok;
     }
     return 0;
 }
@@ -1618,6 +1619,7 @@ int alloc_workspace(said_ctx* ctx, int max_batch_eff, int max_frames) {
     rc |= dalloc(ctx, &ctx->F, Be * FFI * Tp);
     rc |= dalloc(ctx, &ctx->KV, Be * NST * 2 * MC * Tp);
     rc |= dalloc(ctx, &ctx->KVT, Be * NST * 2 * MC * Tp);
+    rc |= dalloc(ctx, &ctx->chain_part, (size_t)CHAIN3_MAX_TILES * 3 * 6 * 16 * 64);
     rc |= dalloc(ctx, &ctx->CTX, Be * (size_t)ctx_dim * Tp);
     const size_t Np = ctx->maxNp;
     rc |= dalloc(ctx, &ctx->E0, MC * Np); rc |= dalloc(ctx, &ctx->E1, TE * Np); rc |= dalloc(ctx, &ctx->E2, TE * Np);
@@ -1719,6 +1721,7 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     rc |= dalloc(ctx, &ctx->coef1_dev, 8);
     rc |= dalloc(ctx, &ctx->step_dev, 4);
     rc |= dalloc(ctx, &ctx->status_dev, 4);
+    rc |= dalloc(ctx, &ctx->chain_ticket, CHAIN3_MAX_TILES * 6);
     rc |= dalloc(ctx, &ctx->seed_dev, 4);
     rc |= dalloc(ctx, &ctx->clk_dev, 64 * 128);
     rc |= dalloc(ctx, &ctx->freqs, MC / 2);
@@ -1859,6 +1862,7 @@ int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_fram
     rc |= dalloc(ctx, &c->coef1_dev, 8);
     rc |= dalloc(ctx, &c->step_dev, 4);
     rc |= dalloc(ctx, &c->status_dev, 4);
+    rc |= dalloc(ctx, &c->chain_ticket, CHAIN3_MAX_TILES * 6);
     rc |= dalloc(ctx, &c->seed_dev, 4);
     rc |= dalloc(ctx, &c->clk_dev, 64 * 128);
     rc |= alloc_workspace(c, max_batch_eff, max_frames);
@@ -1998,6 +2002,33 @@ static int pack_chain(said_ctx* ctx, STW& sw, const std::string& b, const std::v
     std::vector<float> stf(st.size() / 2);
     memcpy(stf.data(), st.data(), st.size() * 2);
     if (upload(ctx, &sw.chain_w, stf.data(), stf.size())) return -1;
+    {   // the three-slice stream (stchain.h CHAIN3_*): slice c = GEGLU pairs 8 c .. 8 c + 7 (one per wave) + k16 steps 16 c .. 16 c + 15 of the folded proj_out's GEGLU
+        // segment + steps 4 c .. 4 c + 3 of its x2 segment (steps 48 .. 59 of the 60); the three 192 x 192 projections in front are in every slice
+        st.assign(CHAIN3_STREAM_BYTES / 2, (_Float16)0.f);
+        o = 0;
+        for (int c = 0; c < 3; ++c) {
+            int ff[20];
+            for (int i = 0; i < 16; ++i) ff[i] = 16 * c + i;
+            for (int i = 0; i < 4; ++i) ff[16 + i] = 48 + 4 * c + i;
+            auto put_pair = [&](int p) {
+                for (int s2 = 0; s2 < 12; ++s2) { put_unit(3, 32 * p, s2); put_unit(3, FFI + 32 * p, s2); }
+            };
+            for (int w = 0; w < 6; ++w) {
+                for (int kind = 0; kind < 3; ++kind)
+                    for (int s2 = 0; s2 < 12; ++s2) put_unit(kind, 32 * w, s2);
+                put_pair(8 * c + w);
+                for (int i = 0; i < (w < 4 ? 20 : 10); ++i) put_unit(4, 32 * w, ff[i]);
+            }
+            for (int w = 6; w < 8; ++w) {
+                put_pair(8 * c + w);
+                for (int i = 10; i < 20; ++i) put_unit(4, 32 * (w - 2), ff[i]);
+            }
+        }
+        if (o != st.size()) return fail(ctx, "pack_chain: three-slice stream size mismatch");
+        stf.resize(st.size() / 2);
+        memcpy(stf.data(), st.data(), st.size() * 2);
+        if (upload(ctx, &sw.chain_w3, stf.data(), stf.size())) return -1;
+    }
     std::vector<float> vec(CHAIN_VEC_FLOATS);
     for (int n = 0; n < MC; ++n) {
         double bq = 0.0;
@@ -2642,8 +2673,6 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->spg_limit = (int)value;
     } else if (k == "hybrid") {
         ctx->hybrid = value != 0;
-    } else if (k == "hybrid_f32") {
-        ctx->hybrid_f32 = value != 0;
     } else if (k == "out_tm") {
         ctx->out_tm = (int)value;
     } else if (k == "mt_mid") {
@@ -2658,8 +2687,6 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->unet_nb_model = value != 0;
     } else if (k == "f32_out1_tm") {
         ctx->f32_out1_tm = value != 0;
-    } else if (k == "audio_front_fused") {   // bf16 encoder: 0 = conv0 -> fp32 activation -> rownorm+GELU -> transpose (round 2's three kernels)
-        ctx->audio_front_fused = value != 0;
     } else if (k == "xgemm_clk") {   // shader-clock stamps of the token-major-activation GEMMs (-DSAID_CLK_STAMPS builds); read with said_debug_clocks
         ctx->xclk_on = value != 0;
     } else if (k == "xgemm_ntw") {
@@ -2683,10 +2710,12 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->ugemm_split = value < 0 ? -1 : (value != 0);
     } else if (k == "st_chain") {
         ctx->st_chain = value < 0 ? -1 : (value != 0);
+    } else if (k == "st_chain_slices") {
+        ctx->st_chain_slices = value < 0 ? -1 : (value == 3 ? 3 : 1);
     } else if (k == "st_chain_dbg") {
         ctx->st_chain_dbg = value != 0;
     } else if (k == "st_chain_bf16") {
-        ctx->st_chain_bf16 = value < 0 ? -1 : (value > 2 ? 2 : (int)value);   // 0 off, 1 (= default) one tile per workgroup, 2 two tiles per workgroup
+        ctx->st_chain_bf16 = value < 0 ? -1 : (value != 0);
     } else if (k == "st_chain_large") {
         ctx->st_chain_large = value != 0;
     } else if (k == "st_chain_max_tiles") {
@@ -2764,7 +2793,7 @@ static const char* ws_name(const said_ctx* c, const void* p) {
     const std::pair<const void*, const char*> t[] = {
         {c->x_cm, "x"}, {c->eps_cm, "eps"}, {c->H0.p, "H0"}, {c->H1.p, "H1"}, {c->P.p, "P"}, {c->Q.p, "Q"}, {c->M.p, "M"},
         {c->H0.st, "stH0"}, {c->H1.st, "stH1"}, {c->P.st, "stP"}, {c->Q.st, "stQ"}, {c->M.st, "stM"},
-        {c->X1, "X1"}, {c->X2, "X2"}, {c->X3, "X3"}, {c->O, "O"}, {c->QK, "QK"}, {c->VT, "VT"}, {c->F, "F"}, {c->KV, "KV"}, {c->KVT, "KVT"}, {c->CTX, "CTX"},
+        {c->X1, "X1"}, {c->X2, "X2"}, {c->X3, "X3"}, {c->O, "O"}, {c->QK, "QK"}, {c->VT, "VT"}, {c->F, "F"}, {c->KV, "KV"}, {c->KVT, "KVT"}, {c->chain_part, "chain_part"}, {c->CTX, "CTX"},
         {c->E0, "E0"}, {c->E1, "E1"}, {c->E2, "E2"}, {c->EO, "EO"}, {c->ts_dev, "ts"}, {c->coef_dev, "coef"}, {c->axpby_coef, "axpby_coef"},
         {c->band_lo, "band_lo"}, {c->band_hi, "band_hi"}, {c->init_cm, "init_cm"}, {c->enoise_cm, "enoise_cm"}, {c->mask_cm, "mask_cm"},
         {c->rescale_part, "rescale_part"}, {c->uPA, "uPA"}, {c->uPB, "uPB"}, {c->uPL, "uPL"}, {c->uPH, "uPH"}, {c->uPX, "uPX"}, {c->gn_coef, "gn_coef"},
@@ -2990,8 +3019,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
             const int pitch0 = rup(L[0], 32);
             const long long bs0 = (long long)W2V_CONV * pitch0;
             // conv0 + GroupNorm + GELU straight to token-major bf16 (abufA, sized for the fp32 activation, serves as its scratch)
-            if (!ctx->audio_front_fused ||
-                !launch_conv0_gn_gelu_tm_bf16(wav_dev + (long long)b0 * Ta, ctx->c0_w, ctx->c0_g, ctx->c0_b, ctx->abufA, ctx->bA0, nb, Ta, W2V_CONV,
+            if (!launch_conv0_gn_gelu_tm_bf16(wav_dev + (long long)b0 * Ta, ctx->c0_w, ctx->c0_g, ctx->c0_b, ctx->abufA, ctx->bA0, nb, Ta, W2V_CONV,
                                               ctx->w2v_kernel[0], ctx->w2v_stride[0], L[0], 1e-5f, s)) {
                 launch_conv0(wav_dev + (long long)b0 * Ta, ctx->c0_w, ctx->abufA, nb, Ta, W2V_CONV, ctx->w2v_kernel[0], ctx->w2v_stride[0], L[0], pitch0, bs0, s);
                 launch_rownorm_gelu(ctx->abufA, ctx->c0_g, ctx->c0_b, W2V_CONV, nb, L[0], pitch0, bs0, 1e-5f, s);

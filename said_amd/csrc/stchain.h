@@ -6,9 +6,13 @@ namespace said {
 
 constexpr int CHAIN_KW = 56;                    // key rows of the cross-attention window tile kept in LDS per 32-token tile: the tile's windows must fit
                                                 // (engine.cpp: set_band checks max(hi) - lo[t0] <= CHAIN_KW per tile, else the five-launch schedule runs)
-constexpr int CHAIN2_KW = 88;                   // ... of a PAIR of tiles in the two-tile bf16 variant (stchain2_kernel)
 constexpr size_t CHAIN_STREAM_UNITS = 4 * 168 + 2 * 138 + 2 * 102;
 constexpr size_t CHAIN_STREAM_BYTES = CHAIN_STREAM_UNITS * 2048;   // 2 KB units (one k16 step: h + l fragments) of the eight waves' streams: 2,359,296 per transformer block
+// round 6, small launches: three workgroups ("slices") per token tile, each with its own stream: [to_out1 | to_q | to_out2] as above, ONE GEGLU pair per wave
+// (hidden tiles 8 c + w) and a third of the folded proj_out's K (k16 steps 16 c .. 16 c + 15 of the GEGLU product, steps 4 c .. 4 c + 3 of x2)
+constexpr size_t CHAIN3_SLICE_UNITS = 4 * 80 + 2 * 70 + 2 * 34;             // 528 units = 1,081,344 bytes per slice
+constexpr size_t CHAIN3_STREAM_BYTES = 3 * CHAIN3_SLICE_UNITS * 2048;
+constexpr int CHAIN3_MAX_TILES = 85;                    // (sample, token tile) pairs a three-slice launch may have: 3 x 85 <= 256 workgroups, one round of the chip
 constexpr int CHAIN_VEC_FLOATS = 5 * 192 + 1536;        // global: b1, bq, bo2, c2, bffp (192 each), bff (1536: value rows, then gate rows)
 constexpr int CHAIN_VEC_FLOATS_LDS = 4 * 192 + 1536;    // LDS: bo2 | c2 share a slot (conditional | unconditional sample)
 
@@ -33,6 +37,9 @@ struct ChainArgs {
     int koff;                // = 384 * block index
     int wmax;                // max(hi - lo) <= 8
     float scale;             // dim_head ** -0.5
+    int slices;              // 1, or 3: wstream is the three-slice stream (CHAIN3_STREAM_BYTES) and the launch has three workgroups per token tile
+    float* part;             // slices == 3: partial sums [sample][tile][3 slices][6 column tiles][16][64 lanes] fp32
+    int* ticket;             // slices == 3: [sample][tile][6] arrival counters, zero before and after every launch
 };
 
 bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long long x_bs);
@@ -41,7 +48,7 @@ bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long
 // bf16 = true (bf16 mode, large batches): o, xin and y are TOKEN-major bf16 [sample][row][192] (o_bs / x_bs / y_bs in elements, pitch unused), wstream the bf16 stream
 // (1 KB units), every product one v_mfma_f32_32x32x16_bf16 on operands rounded to bf16; statistics, LayerNorm, softmax, residual sums stay fp32.
 void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s,
-                    bool bf16 = false, bool two_tiles = false);   // two_tiles (bf16 only): stchain2_kernel, two token tiles per workgroup (window rows per tile pair <= CHAIN2_KW)
+                    bool bf16 = false);
 void configure_stchain_kernel();
 
 }  // namespace said

@@ -68,13 +68,26 @@ constexpr int CH_NR_BF = 6;                        // bf16 variant: 1 KB units; 
 // units of a wave's stream: [to_out1 12][to_q 12][to_out2 12][GEGLU 3 pairs x 12 steps x (value, gate)][ffproj 60 | 30]; waves 6, 7: [GEGLU 72][ffproj 30].
 // The folded proj_out (60 k16 steps per column tile) is the one phase where six column owners on four SIMDs are unbalanced (two SIMDs with two owners: 11.5k clocks of
 // MFMA against 5.8k): column tiles 4 and 5 are split over K — waves 4, 5 take steps 0 .. 29, the helper waves 6, 7 steps 30 .. 59 and hand their partial sums over through LDS.
-constexpr int U_G1 = 0, U_G2 = 12, U_G3 = 24, U_GE = 36, U_FF = 108, U_END = 168;
-constexpr int U_HALF = 30;                                          // ffproj steps of waves 4-7
-constexpr int U_W45 = U_FF + U_HALF, U_W67 = (U_FF - U_GE) + U_HALF;   // units of waves 4, 5 (138) and 6, 7 (102)
+// S3 (round 6, small launches): THREE workgroups per token tile, each with a third of the GEGLU / folded-proj_out work (a "slice": GEGLU pairs 8 c .. 8 c + 7 — one per
+// wave — and the matching third of the folded proj_out's K: 16 k16 steps over its 256 GEGLU columns + 4 over a third of x2), everything in front of GEGLU computed by all
+// three.  The stream a workgroup pulls through its CU's L2 port shrinks from 1152 to 528 units (2.36 -> 1.08 MB); the partial sums meet in memory (see the epilogue).
+template <bool S3> struct CU {
+    static constexpr int G1 = 0, G2 = 12, G3 = 24, GE = 36;
+    static constexpr int NPAIR = S3 ? 1 : 3;                 // GEGLU (value, gate) pairs per wave
+    static constexpr int FF = GE + 24 * NPAIR;               // first unit of the folded proj_out (108 | 60)
+    static constexpr int FFS = S3 ? 20 : 60;                 // its k16 steps per column tile in this slice ...
+    static constexpr int FFH = S3 ? 16 : 48;                 // ... of which over the GEGLU product (the rest over x2)
+    static constexpr int HALF = FFS / 2;                     // steps of waves 4-7 (column tiles 4, 5 are split over K between an owner and a helper wave)
+    static constexpr int END = FF + FFS;                     // units of waves 0-3 (168 | 80)
+    static constexpr int W45 = FF + HALF, W67 = 24 * NPAIR + HALF;   // units of waves 4, 5 (138 | 70) and 6, 7 (102 | 34)
+    static constexpr int SLICE = 4 * END + 2 * W45 + 2 * W67;        // units of one workgroup's stream (1152 | 528)
+};
+static_assert(CU<false>::SLICE == (int)CHAIN_STREAM_UNITS && CU<true>::SLICE == (int)CHAIN3_SLICE_UNITS, "stchain.h");
+constexpr int U_G1 = 0, U_G2 = 12, U_G3 = 24, U_GE = 36;
 // MODE 0: column owner, conditional sample; 1: column owner, unconditional (skips to_q / to_out2); 2: helper wave.  A request past the end of the wave's stream (the
 // shorter streams of waves 4-7, the ring running ahead at the end) is out of the buffer's range: no memory access, zeros.
 template <int MODE> __device__ __forceinline__ constexpr int unit_of(int q) { return MODE == 0 ? q : (MODE == 1 ? (q < U_G2 ? q : q + (U_GE - U_G2)) : q); }
-template <int MODE> __device__ __forceinline__ constexpr int n_units() { return MODE == 0 ? U_END : (MODE == 1 ? U_END - (U_GE - U_G2) : U_W67); }
+template <int MODE, bool S3> __device__ __forceinline__ constexpr int n_units() { return MODE == 0 ? CU<S3>::END : (MODE == 1 ? CU<S3>::END - (U_GE - U_G2) : CU<S3>::W67); }
 
 template <int B, int E, typename F>
 __device__ __forceinline__ void sfor(F&& f) {
@@ -91,9 +104,9 @@ struct WStream { rsrc_t r; int vo; };   // the wave's stream, lane * 16
 typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2c __attribute__((ext_vector_type(2)));
-template <int MODE, bool BF, int NR, int Q>
+template <int MODE, bool BF, bool S3, int NR, int Q>
 __device__ __forceinline__ void ring_issue(Ring<NR>& R, const WStream& wp) {
-    if constexpr (Q < n_units<MODE>()) {
+    if constexpr (Q < n_units<MODE, S3>()) {
         constexpr int u = unit_of<MODE>(Q);
         R.h[Q % NR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wp.r, wp.vo, u * (BF ? 1024 : 2048), 0));
         if constexpr (!BF) R.l[Q % NR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wp.r, wp.vo + 1024, u * 2048, 0));
@@ -115,7 +128,7 @@ __device__ __forceinline__ void clk_stamp_c(long long* clk, int w, int lane, int
 // one 192-deep (NS = 12) or longer run of k16 steps: B fragments from the token-major planes at `bh` (this lane's row + k-group offset; low plane `pl` bytes behind)
 // (the B fragments are double-buffered by hand, one step ahead, and a scheduling fence closes every step: left alone the compiler hoists all 2 NS fragment
 //  reads above the MFMAs — 96 registers at NS = 12, which the ring and the accumulators need)
-template <int MODE, bool BF, int NR, int Q0, int NS>
+template <int MODE, bool BF, bool S3, int NR, int Q0, int NS>
 __device__ __forceinline__ void gemm_run(Ring<NR>& R, const WStream& wp, const char* bh, int pl, f32x16& acc, f32x16& accx) {
     f16x8 xh = *reinterpret_cast<const f16x8*>(bh), xl = xh;
     if constexpr (!BF) xl = *reinterpret_cast<const f16x8*>(bh + pl);
@@ -134,14 +147,14 @@ __device__ __forceinline__ void gemm_run(Ring<NR>& R, const WStream& wp, const c
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
             accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accx, 0, 0, 0);
         }
-        ring_issue<MODE, BF, NR, Q0 + s + NR>(R, wp);
+        ring_issue<MODE, BF, S3, NR, Q0 + s + NR>(R, wp);
         __builtin_amdgcn_sched_barrier(0);
         xh = nh; xl = nl;
     });
 }
 // GEGLU: a (value, gate) tile pair shares every B fragment; units alternate value, gate.  `between(s)` runs behind step s's MFMAs (the previous pair's epilogue in
 // four pieces: its erf / split VALU work rides under this pair's matrix work, and the weight stream never pauses for an epilogue)
-template <int MODE, bool BF, int NR, int Q0, typename F>
+template <int MODE, bool BF, bool S3, int NR, int Q0, typename F>
 __device__ __forceinline__ void geglu_run(Ring<NR>& R, const WStream& wp, const char* bh, int pl, f32x16& av, f32x16& avx, f32x16& ag, f32x16& agx, F&& between) {
     f16x8 xh = *reinterpret_cast<const f16x8*>(bh), xl = xh;
     if constexpr (!BF) xl = *reinterpret_cast<const f16x8*>(bh + pl);
@@ -166,8 +179,8 @@ __device__ __forceinline__ void geglu_run(Ring<NR>& R, const WStream& wp, const 
             avx = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, xl, avx, 0, 0, 0);
             agx = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl, agx, 0, 0, 0);
         }
-        ring_issue<MODE, BF, NR, qv + NR>(R, wp);
-        ring_issue<MODE, BF, NR, qg + NR>(R, wp);
+        ring_issue<MODE, BF, S3, NR, qv + NR>(R, wp);
+        ring_issue<MODE, BF, S3, NR, qg + NR>(R, wp);
         between(sc);
         __builtin_amdgcn_sched_barrier(0);
         xh = nh; xl = nl;
@@ -249,8 +262,11 @@ struct ChainHdr {          // the leading kernel parameters (preloaded into SGPR
     int in_mod, n_uncond, wmax;
 };
 
-template <int MODE, bool BF>
-__device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& a, char* smem, int w, int l, int s_idx, int in_idx, int t0) {
+template <int MODE, bool BF, bool S3>
+__device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& a, char* smem, int w, int l, int s_idx, int in_idx, int t0, int slice) {
+    static_assert(!(BF && S3), "the three-slice variant exists for the fp32 mode's small launches only");
+    using U = CU<S3>;
+    constexpr int U_FF = U::FF, U_HALF = U::HALF, U_END = U::END, U_W45 = U::W45, U_W67 = U::W67;
     constexpr int NR = BF ? CH_NR_BF : ((MODE == 2) ? CH_NR_HELPER : CH_NR_OWNER);
     const int tid = threadIdx.x;
     const int lt = l & 31, lh = l >> 5;
@@ -273,7 +289,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
     const int w_units = w < 4 ? U_END : (w < 6 ? U_W45 : U_W67);
     const int w_first = w < 4 ? w * U_END : (w < 6 ? 4 * U_END + (w - 4) * U_W45 : 4 * U_END + 2 * U_W45 + (w - 6) * U_W67);
     constexpr int UB = BF ? 1024 : 2048;   // bytes of a unit
-    const WStream wp = {make_rsrc(reinterpret_cast<const char*>(hd.wstream) + (long long)w_first * UB, (unsigned)w_units * (unsigned)UB), l * 16};
+    const WStream wp = {make_rsrc(reinterpret_cast<const char*>(hd.wstream) + ((long long)slice * U::SLICE + w_first) * UB, (unsigned)w_units * (unsigned)UB), l * 16};
     Ring<NR> R;
     clk_stamp_c(clk, w, l, 0);
 
@@ -384,7 +400,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             }
         }
         clk_stamp_c(clk, w, l, 2);
-        sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, NR, decltype(qc)::value>(R, wp); });   // (not needed before GEGLU; behind the window tile, whose registers it reuses)
+        sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, S3, NR, decltype(qc)::value>(R, wp); });   // (not needed before GEGLU; behind the window tile, whose registers it reuses)
         clk_stamp_c(clk, w, l, 3);
         if (!uncond) {   // LayerNorm2 partials, LayerNorm2(x1) planes, cross-attention output planes
             __syncthreads();
@@ -450,7 +466,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
                 vecv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rvec, (i < CHAIN_VEC_FLOATS_LDS / 4) ? gi * 16 : (int)0x80000000, 0, 0));
             }
         }
-        sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, NR, decltype(qc)::value>(R, wp); });
+        sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, S3, NR, decltype(qc)::value>(R, wp); });
         clk_stamp_c(clk, w, l, 12);
         if constexpr (BF) {   // both tiles as they are: bf16 rows of 384 bytes at the planes' 400-byte pitch
             *reinterpret_cast<f32x4*>(smem + CV::R1 + prow0 * (CH_AP * 2) + ppc0 * 16) = ov[0];
@@ -502,7 +518,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         // ---- to_out1 + GroupNorm'ed residual (attention.py:127, 168, 226-227) ----
         f32x16 acc, accx;
         zero16(acc); zero16(accx);
-        gemm_run<MODE, BF, NR, U_G1, 12>(R, wp, r1h + browA, CH_APL, acc, accx);
+        gemm_run<MODE, BF, S3, NR, U_G1, 12>(R, wp, r1h + browA, CH_APL, acc, accx);
         clk_stamp_c(clk, w, l, 2);
         float x1[16];
         merge16(x1, acc, accx);
@@ -549,7 +565,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             __syncthreads();
             clk_stamp_c(clk, w, l, 3);
             zero16(acc); zero16(accx);
-            gemm_run<MODE, BF, NR, U_G2, 12>(R, wp, r2h + browA, CH_APL, acc, accx);
+            gemm_run<MODE, BF, S3, NR, U_G2, 12>(R, wp, r2h + browA, CH_APL, acc, accx);
             float q[16];
             merge16(q, acc, accx);
             {
@@ -623,7 +639,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             clk_stamp_c(clk, w, l, 5);
             // ---- to_out2 + x1 ----
             zero16(acc); zero16(accx);
-            gemm_run<MODE, BF, NR, U_G3, 12>(R, wp, r1h + browA, CH_APL, acc, accx);
+            gemm_run<MODE, BF, S3, NR, U_G3, 12>(R, wp, r1h + browA, CH_APL, acc, accx);
             merge16(x2, acc, accx);
             float bo[16];
             get_vec(vec + 2 * 192, col0, bo);
@@ -657,8 +673,9 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         constexpr int QG = (MODE == 0) ? U_GE : (MODE == 1 ? U_G2 : 0);   // logical position of the wave's first GEGLU unit
         const float* bff = reinterpret_cast<const float*>(smem + CV::BFF);
         float pv[16], pg[16];   // the previous pair's value and gate sums
+        const int gp0 = S3 ? 8 * slice : 0;   // S3: this workgroup's pairs are the hidden tiles 8 slice .. 8 slice + 7; its product plane holds them at columns 0 .. 255
         auto epi_piece = [&](int p, int m) {   // channels 32 p + 4 lh + 8 m .. + 3 of the token: bias, gelu, product, split, 8 bytes per plane
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bff + 32 * p + 4 * lh + 8 * m), bg = *reinterpret_cast<const f32x4*>(bff + 768 + 32 * p + 4 * lh + 8 * m);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bff + 32 * (gp0 + p) + 4 * lh + 8 * m), bg = *reinterpret_cast<const f32x4*>(bff + 768 + 32 * (gp0 + p) + 4 * lh + 8 * m);
             float hv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) hv[i] = (pv[4 * m + i] + bv[i]) * gelu_f(pg[4 * m + i] + bg[i]);
@@ -675,11 +692,11 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
                 *reinterpret_cast<f16x4*>(pp + CH_HPL) = lo;
             }
         };
-        sfor<0, 3>([&](auto pc) {
+        sfor<0, U::NPAIR>([&](auto pc) {
             constexpr int pi = decltype(pc)::value;
             f32x16 av, avx, ag, agx;
             zero16(av); zero16(avx); zero16(ag); zero16(agx);
-            geglu_run<MODE, BF, NR, QG + 24 * pi>(R, wp, r1h + browA, CH_APL, av, avx, ag, agx, [&](auto sc) {
+            geglu_run<MODE, BF, S3, NR, QG + 24 * pi>(R, wp, r1h + browA, CH_APL, av, avx, ag, agx, [&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 if constexpr (!BF && pi > 0 && s % 3 == 1) epi_piece(w + 8 * (pi - 1), s / 3);
             });
@@ -693,7 +710,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         });
         if constexpr (!BF) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) epi_piece(w + 16, m);
+            for (int m = 0; m < 4; ++m) epi_piece(w + 8 * (U::NPAIR - 1), m);
         }
     }
     f32x4 bpv[4];   // BF: bffp of this lane's 16 channels, from memory (global layout of ChainArgs::vec: b1, bq, bo2, c2, bffp, bff)
@@ -708,8 +725,8 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         constexpr int QH = U_FF - U_GE;
         f32x16 acc, accx;
         zero16(acc); zero16(accx);
-        gemm_run<MODE, BF, NR, QH, 48 - U_HALF>(R, wp, hh + browH + 32 * U_HALF, CH_HPL, acc, accx);
-        gemm_run<MODE, BF, NR, QH + 48 - U_HALF, 12>(R, wp, r2h + browA, CH_APL, acc, accx);
+        gemm_run<MODE, BF, S3, NR, QH, U::FFH - U_HALF>(R, wp, hh + browH + 32 * U_HALF, CH_HPL, acc, accx);
+        gemm_run<MODE, BF, S3, NR, QH + U::FFH - U_HALF, U::FFS - U::FFH>(R, wp, r2h + browA + (S3 ? 128 * slice : 0), CH_APL, acc, accx);   // (S3: x2's k16 steps 4 slice .. + 3)
         float* const fpart = reinterpret_cast<float*>(r1h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) fpart[((w - 6) * 16 + r) * 64 + l] = fmaf(accx[r], 0x1p-11f, acc[r]);
@@ -738,18 +755,44 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         float y[16], bp[16];
         float* const fpart = reinterpret_cast<float*>(r1h);   // [2 helper waves][16][64]: their partial sums of column tiles 4, 5 (the LayerNorm3 planes are dead)
         if (w < 4) {
-            gemm_run<MODE, BF, NR, QF, 48>(R, wp, hh + browH, CH_HPL, acc, accx);
-            gemm_run<MODE, BF, NR, QF + 48, 12>(R, wp, r2h + browA, CH_APL, acc, accx);
+            gemm_run<MODE, BF, S3, NR, QF, U::FFH>(R, wp, hh + browH, CH_HPL, acc, accx);
+            gemm_run<MODE, BF, S3, NR, QF + U::FFH, U::FFS - U::FFH>(R, wp, r2h + browA + (S3 ? 128 * slice : 0), CH_APL, acc, accx);
             merge16(y, acc, accx);
             __syncthreads();
         } else {
-            gemm_run<MODE, BF, NR, QF, U_HALF>(R, wp, hh + browH, CH_HPL, acc, accx);
+            gemm_run<MODE, BF, S3, NR, QF, U_HALF>(R, wp, hh + browH, CH_HPL, acc, accx);
             merge16(y, acc, accx);
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < 16; ++r) y[r] += fpart[((w - 4) * 16 + r) * 64 + l];
         }
         clk_stamp_c(clk, w, l, 9);
+        if constexpr (S3) {
+            // The three slices' partial sums of this (token tile, column tile) meet in memory, per WAVE: each stores its 32 x 32 partial (agent-scope stores: written
+            // through the XCD's L2 — the three workgroups run on different XCDs), waits for the stores, and takes a ticket; the wave that draws the last one reads all three
+            // back and sums them in slice order (bit-reproducible whoever arrives last), then finishes the tile as the one-workgroup kernel does.  No barrier, no fence: the
+            // partial buffer and the ticket are only ever touched by agent-scope accesses.
+            float* const P = a.part + (((long long)s_idx * a.np + (t0 >> 5)) * 3) * (6 * 16 * 64);
+            int* const tk = a.ticket + ((long long)s_idx * a.np + (t0 >> 5)) * 6 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __hip_atomic_store(P + ((slice * 6 + j) * 16 + r) * 64 + l, y[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int old = 0;
+            if (l == 0) old = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old != 2) return;
+            if (l == 0) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (kernel boundaries order it)
+            asm volatile("" ::: "memory");
+            float p0[16], p1[16], p2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p0[r] = __hip_atomic_load(P + ((0 * 6 + j) * 16 + r) * 64 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p1[r] = __hip_atomic_load(P + ((1 * 6 + j) * 16 + r) * 64 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p2[r] = __hip_atomic_load(P + ((2 * 6 + j) * 16 + r) * 64 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] = (p0[r] + p1[r]) + p2[r];
+        }
         if constexpr (BF) {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -799,490 +842,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
     clk_stamp_c(clk, w, l, 10);
 }
 
-// ==================================================================================================================================================
-// stchain2 — the bf16 variant with TWO token tiles per workgroup (tiles 2 x, 2 x + 1 of a sample), one workgroup per CU.  MEASURED SLOWER than stchain_kernel<true> at two
-// workgroups per CU (96 against 83 us per launch at 32 clips: profiles/r05p_stchain2_two_tiles_ab.txt) and therefore NOT the default (said_debug_option "st_chain_bf16" = 2
-// selects it; bit-identical results, tests/test_gpu_round5.py): with bf16 operands the weight stream (9.5 us per workgroup) and the matrix pipe (9 us for two tiles) are not
-// what bounds the tail — the prologue, the LayerNorm exchanges and the LDS-bound band products are, and those this variant runs twice per workgroup with nothing beside them,
-// where two independent workgroups per CU cover each other's.  Kept as the measured counter-example to "share the weight fragments".  Every weight fragment a wave pulls through the
-// CU's L2 port multiplies both tiles (two MFMAs per unit): the 1.18 MB stream per workgroup serves 64 tokens instead of 32, which is what bounds the one-tile variant at
-// large batches (1.4 GB of L2 reads per launch at 32 clips).  256 VGPRs again, so the ring is 16 units deep.  Same weight stream, same roles, same barrier structure; the
-// per-tile stages simply run twice.  LDS: GEGLU product planes 2 x 49,664 (before GEGLU: the K / V window tiles of the 64 tokens in bf16, CH2_KW rows, and behind them the
-// tables that are dead by then), 2 x 2 activation planes, bff: 156,672 B.
-// ==================================================================================================================================================
-static_assert(CHAIN2_KW == 88, "stchain.h");
-constexpr int CH2_KW = CHAIN2_KW;      // key rows of the 64-token window tile (engine.cpp set_band: max(hi) - lo[first token] over each pair of tiles)
-constexpr int CH_NR_BF2 = 16;
-struct Carve2 {
-    static constexpr int KV = CH2_KW * CH_KP * 2 * 2;
-    static constexpr int R0 = 0, GNC = KV, LNP = GNC + 384 * 4, VEC = LNP + 2 * (32 * 6 * 2 * 4);
-    static constexpr int R1 = 2 * CH_HPL, R2 = R1 + 2 * CH_APL, BFF = R2 + 2 * CH_APL, LDS = BFF + 1536 * 4;
-    static_assert(VEC + 3 * 192 * 4 <= 2 * CH_HPL, "the early tables fit behind the K / V tiles");
-    static_assert(LDS <= 160 * 1024, "LDS budget");
-};
-
-template <int MODE, int NR, int Q0, int NS>
-__device__ __forceinline__ void gemm_run2(Ring<NR>& R, const WStream& wp, const char* b0, const char* b1, f32x16& a0, f32x16& a1) {
-    f16x8 x0 = *reinterpret_cast<const f16x8*>(b0), x1 = *reinterpret_cast<const f16x8*>(b1);
-    sfor<0, NS>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        f16x8 n0 = x0, n1 = x1;
-        if constexpr (s + 1 < NS) {
-            n0 = *reinterpret_cast<const f16x8*>(b0 + 32 * (s + 1));
-            n1 = *reinterpret_cast<const f16x8*>(b1 + 32 * (s + 1));
-        }
-        const bf16x8c wf = __builtin_bit_cast(bf16x8c, R.h[(Q0 + s) % NR]);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8c, x0), a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8c, x1), a1, 0, 0, 0);
-        ring_issue<MODE, true, NR, Q0 + s + NR>(R, wp);
-        __builtin_amdgcn_sched_barrier(0);
-        x0 = n0; x1 = n1;
-    });
-}
-template <int MODE, int NR, int Q0>
-__device__ __forceinline__ void geglu_run2(Ring<NR>& R, const WStream& wp, const char* b0, const char* b1, f32x16 (&av)[2], f32x16 (&ag)[2]) {
-    f16x8 x0 = *reinterpret_cast<const f16x8*>(b0), x1 = *reinterpret_cast<const f16x8*>(b1);
-    sfor<0, 12>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        f16x8 n0 = x0, n1 = x1;
-        if constexpr (s + 1 < 12) {
-            n0 = *reinterpret_cast<const f16x8*>(b0 + 32 * (s + 1));
-            n1 = *reinterpret_cast<const f16x8*>(b1 + 32 * (s + 1));
-        }
-        constexpr int qv = Q0 + 2 * s, qg = Q0 + 2 * s + 1;
-        const bf16x8c wv = __builtin_bit_cast(bf16x8c, R.h[qv % NR]), wg = __builtin_bit_cast(bf16x8c, R.h[qg % NR]);
-        av[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8c, x0), av[0], 0, 0, 0);
-        ag[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg, __builtin_bit_cast(bf16x8c, x0), ag[0], 0, 0, 0);
-        av[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8c, x1), av[1], 0, 0, 0);
-        ag[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg, __builtin_bit_cast(bf16x8c, x1), ag[1], 0, 0, 0);
-        ring_issue<MODE, true, NR, qv + NR>(R, wp);
-        ring_issue<MODE, true, NR, qg + NR>(R, wp);
-        __builtin_amdgcn_sched_barrier(0);
-        x0 = n0; x1 = n1;
-    });
-}
-// LayerNorm statistics of both tiles' tokens with ONE barrier (ln_stats per tile otherwise)
-__device__ __forceinline__ void ln_stats2(const float (&v)[2][16], float* lnp, int j, int lt, int lh, float2 (&out)[2]) {
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += v[ti][r];
-        const float m16 = s * 0.0625f;
-        float q = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { const float d = v[ti][r] - m16; q = fmaf(d, d, q); }
-        const float mo = __shfl_xor(m16, 32), qo = __shfl_xor(q, 32);
-        const float dl = mo - m16;
-        const float m32 = 0.5f * (m16 + mo), q32 = q + qo + dl * dl * 8.f;
-        if (lh == 0) { lnp[ti * 384 + (lt * 6 + j) * 2] = m32; lnp[ti * 384 + (lt * 6 + j) * 2 + 1] = q32; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const float* lp = lnp + ti * 384 + (lt * 6) * 2;
-        float mean = lp[0], M2 = lp[1];
-#pragma unroll
-        for (int k = 1; k < 6; ++k) {
-            const float mk = lp[2 * k], qk = lp[2 * k + 1];
-            const float d = mk - mean;
-            const float n = 32.f * (float)k, nn = n + 32.f;
-            mean = fmaf(d, 32.f / nn, mean);
-            M2 += qk + d * d * (n * 32.f / nn);
-        }
-        out[ti] = make_float2(mean, __builtin_amdgcn_rsqf(M2 * (1.0f / 192.f) + 1e-5f));
-    }
-}
-
-template <int MODE>
-__device__ __forceinline__ void chain_body2(const ChainHdr& hd, const ChainArgs& a, char* smem, int w, int l, int s_idx, int in_idx, int t0) {
-    constexpr int NR = CH_NR_BF2;
-    using CV = Carve2;
-    const int tid = threadIdx.x;
-    const int lt = l & 31, lh = l >> 5;
-    const int j = w;
-    const int col0 = 32 * j + 4 * lh;
-    const int tt[2] = {t0 + lt, t0 + 32 + lt};
-    const bool tv[2] = {tt[0] < hd.T, tt[1] < hd.T};
-    char* const r1h = smem + CV::R1;
-    char* const r2h = smem + CV::R2;
-    char* const hh = smem + CV::R0;
-    const float* vec = reinterpret_cast<const float*>(smem + CV::VEC);
-    const float* gnc = reinterpret_cast<const float*>(smem + CV::GNC);
-    float* lnp = reinterpret_cast<float*>(smem + CV::LNP);
-    const int browA = lt * (CH_AP * 2) + 16 * lh;
-    const int browH = lt * (CH_HP * 2) + 16 * lh;
-    const int wrowA = lt * (CH_AP * 2), wrowH = lt * (CH_HP * 2);
-    const int w_units = w < 4 ? U_END : (w < 6 ? U_W45 : U_W67);
-    const int w_first = w < 4 ? w * U_END : (w < 6 ? 4 * U_END + (w - 4) * U_W45 : 4 * U_END + 2 * U_W45 + (w - 6) * U_W67);
-    const WStream wp = {make_rsrc(reinterpret_cast<const char*>(hd.wstream) + (long long)w_first * 1024, (unsigned)w_units * 1024u), l * 16};
-    Ring<NR> R;
-    int kmin = 0;
-    if constexpr (MODE == 0) kmin = cload(hd.lo, min(t0, hd.T - 1));
-    if constexpr (MODE == 2) {
-        const bool uncond = s_idx < hd.n_uncond;
-        constexpr int KVL = 13;
-        f32x4 kvv[KVL];
-        int kv_n = 0;
-        const int l2 = (w - 6) * 64 + l;
-        // bf16 key-major copy (engine.cpp run_kv, bf16 mode): a key row of this block is 384 consecutive bf16 (K then V) = 48 pieces of 16 bytes
-        const rsrc_t rkv = make_rsrc(reinterpret_cast<const char*>(a.kvt) + (long long)s_idx * a.kvt_bs * 2, (unsigned)a.S * 1536u * 2u);
-        auto kv_walk = [&](int i0, auto&& f) {
-            int idx0 = l2 + 128 * i0;
-            int key = (int)(((unsigned)idx0 * 43691u) >> 21), f8 = idx0 - key * 48;   // idx0 / 48 (exact for idx0 < 2^17)
-            const int lastk = (kv_n - 1) / 48, lastf = (kv_n - 1) - lastk * 48;
-#pragma unroll
-            for (int i = 0; i < KVL; ++i) {
-                const bool in = (key * 48 + f8) < kv_n;
-                const int k = in ? key : lastk, p8 = in ? f8 : lastf;
-                f(i, k, p8);
-                f8 += 32; key += 2;
-                if (f8 >= 48) { f8 -= 48; key += 1; }
-            }
-        };
-        auto kv_issue = [&](int i0) {
-            kv_walk(i0, [&](int i, int k, int p8) {
-                kvv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rkv, ((kmin + k) * 1536 + a.koff + 8 * p8) * 2, 0, 0));
-            });
-        };
-        auto kv_park = [&](int i0) {
-            __bf16* kt = reinterpret_cast<__bf16*>(smem + CV::R0);
-            kv_walk(i0, [&](int i, int k, int p8) {
-                const int e = (p8 < 24 ? 0 : CH2_KW * CH_KP) + k * CH_KP + 8 * (p8 < 24 ? p8 : p8 - 24);   // (392-byte rows: two 8-byte stores)
-                typedef unsigned int u32x2k __attribute__((ext_vector_type(2)));
-                typedef unsigned int u32x4k __attribute__((ext_vector_type(4)));
-                const u32x4k v = __builtin_bit_cast(u32x4k, kvv[i]);
-                const u32x2k v0 = {v[0], v[1]}, v1 = {v[2], v[3]};
-                *reinterpret_cast<u32x2k*>(kt + e) = v0;
-                *reinterpret_cast<u32x2k*>(kt + e + 4) = v1;
-            });
-        };
-        if (!uncond) {
-            kmin = cload(hd.lo, min(t0, hd.T - 1));
-            kv_n = (min(cload(hd.lo, min(t0 + 63, hd.T - 1)) + hd.wmax - kmin, CH2_KW)) * 48;
-            kv_issue(0);
-        }
-        __syncthreads();   // operands staged
-        if (!uncond) {
-            kv_park(0);
-            for (int i0 = KVL; i0 * 128 < kv_n; i0 += KVL) { kv_issue(i0); kv_park(i0); }
-        }
-        sfor<0, NR>([&](auto qc) { ring_issue<MODE, true, NR, decltype(qc)::value>(R, wp); });
-        if (!uncond) {
-            __syncthreads();
-            __syncthreads();
-            __syncthreads();
-        }
-        __syncthreads();
-        __syncthreads();
-    } else {
-        // ---- requests ----
-        f32x4 ov[2][2], xv4[2][2];
-        const int prow0 = (tid * 2731) >> 16, ppc0 = tid - 24 * prow0;
-        const int prow1 = ((tid + 384) * 2731) >> 16, ppc1 = (tid + 384) - 24 * prow1;
-        {
-            const rsrc_t ro = make_rsrc(reinterpret_cast<const char*>(hd.o) + (long long)in_idx * hd.o_bs * 2, (unsigned)hd.T * 384u);
-            const rsrc_t rxin = make_rsrc(reinterpret_cast<const char*>(hd.xin) + (long long)in_idx * hd.x_bs * 2, (unsigned)hd.T * 384u);
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                ov[ti][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, (t0 + 32 * ti + prow0) * 384 + ppc0 * 16, 0, 0));
-                ov[ti][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, (t0 + 32 * ti + prow1) * 384 + ppc1 * 16, 0, 0));
-                xv4[ti][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxin, (t0 + 32 * ti + prow0) * 384 + ppc0 * 16, 0, 0));
-                xv4[ti][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxin, (t0 + 32 * ti + prow1) * 384 + ppc1 * 16, 0, 0));
-            }
-        }
-        GnL20 gl;
-        const GnP gp = {6, a.np, hd.T, 1e-6f, a.gn_gamma, a.gn_beta, 192};
-        const rsrc_t rpart = make_rsrc(a.xin_part + (long long)in_idx * a.part_bs, 192u * (unsigned)a.np * 8u);
-        if (w < 4) gn20_issue(gp, rpart, 48 * w, l, gl);
-        int blo[2] = {0, 0}, bhi[2] = {0, 0};
-        if constexpr (MODE == 0) {
-            const rsrc_t rlo = make_rsrc(hd.lo, (unsigned)hd.T * 4u), rhi = make_rsrc(a.hi, (unsigned)hd.T * 4u);
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                blo[ti] = __builtin_bit_cast(int, bload(rlo, tv[ti] ? tt[ti] * 4 : (int)0x80000000, 0));
-                bhi[ti] = __builtin_bit_cast(int, bload(rhi, tv[ti] ? tt[ti] * 4 : (int)0x80000000, 0));
-            }
-        }
-        f32x4 vecv[2];
-        {
-            const rsrc_t rvec = make_rsrc(a.vec, (unsigned)CHAIN_VEC_FLOATS * 4u);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int i = tid + 384 * k;
-                const int gi = (i < 96) ? i : ((i < 144) ? (MODE == 1 ? i + 48 : i) : i + 48);
-                vecv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rvec, (i < CHAIN_VEC_FLOATS_LDS / 4) ? gi * 16 : (int)0x80000000, 0, 0));
-            }
-        }
-        sfor<0, NR>([&](auto qc) { ring_issue<MODE, true, NR, decltype(qc)::value>(R, wp); });
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-            *reinterpret_cast<f32x4*>(r1h + ti * CH_APL + prow0 * (CH_AP * 2) + ppc0 * 16) = ov[ti][0];
-            *reinterpret_cast<f32x4*>(r1h + ti * CH_APL + prow1 * (CH_AP * 2) + ppc1 * 16) = ov[ti][1];
-            *reinterpret_cast<f32x4*>(r2h + ti * CH_APL + prow0 * (CH_AP * 2) + ppc0 * 16) = xv4[ti][0];
-            *reinterpret_cast<f32x4*>(r2h + ti * CH_APL + prow1 * (CH_AP * 2) + ppc1 * 16) = xv4[ti][1];
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int i = tid + 384 * k;
-            if (i < 144) reinterpret_cast<f32x4*>(smem + CV::VEC)[i] = vecv[k];
-            else if (i >= 192 && i < CHAIN_VEC_FLOATS_LDS / 4) reinterpret_cast<f32x4*>(smem + CV::BFF)[i - 192] = vecv[k];
-        }
-        if (w < 4) gn20_finish(gp, rpart, 48 * w, l, gl, reinterpret_cast<float*>(smem + CV::R0) + w * GN_SCRATCH, reinterpret_cast<float*>(smem + CV::GNC));
-        __syncthreads();
-        // ---- to_out1 + GroupNorm'ed residual ----
-        f32x16 acc[2];
-        zero16(acc[0]); zero16(acc[1]);
-        gemm_run2<MODE, NR, U_G1, 12>(R, wp, r1h + browA, r1h + CH_APL + browA, acc[0], acc[1]);
-        float x1[2][16];
-        {
-            float b1[16];
-            get_vec(vec, col0, b1);
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                float xr[16];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const bf16x4c xb = *reinterpret_cast<const bf16x4c*>(r2h + ti * CH_APL + wrowA + (col0 + 8 * m) * 2);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) xr[4 * m + i] = (float)xb[i];
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(gnc + 2 * (col0 + 8 * m)), c1 = *reinterpret_cast<const f32x4*>(gnc + 2 * (col0 + 8 * m) + 4);
-                    x1[ti][4 * m + 0] = acc[ti][4 * m + 0] + (b1[4 * m + 0] + fmaf(xr[4 * m + 0], c0[0], c0[1]));
-                    x1[ti][4 * m + 1] = acc[ti][4 * m + 1] + (b1[4 * m + 1] + fmaf(xr[4 * m + 1], c0[2], c0[3]));
-                    x1[ti][4 * m + 2] = acc[ti][4 * m + 2] + (b1[4 * m + 2] + fmaf(xr[4 * m + 2], c1[0], c1[1]));
-                    x1[ti][4 * m + 3] = acc[ti][4 * m + 3] + (b1[4 * m + 3] + fmaf(xr[4 * m + 3], c1[2], c1[3]));
-                }
-            }
-        }
-        float x2[2][16];
-        if constexpr (MODE == 1) {
-            float c2[16];
-            get_vec(vec + 2 * 192, col0, c2);
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x2[ti][r] = x1[ti][r] + c2[r];
-        } else {
-            float2 st[2];
-            ln_stats2(x1, lnp, j, lt, lh, st);
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                float y[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) y[r] = (x1[ti][r] - st[ti].x) * st[ti].y;
-                put_split<true>(r2h + ti * CH_APL, CH_APL, wrowA, col0, y);
-            }
-            __syncthreads();
-            zero16(acc[0]); zero16(acc[1]);
-            gemm_run2<MODE, NR, U_G2, 12>(R, wp, r2h + browA, r2h + CH_APL + browA, acc[0], acc[1]);
-            float bq[16];
-            get_vec(vec + 192, col0, bq);
-            const __bf16* kt = reinterpret_cast<const __bf16*>(smem + CV::R0);
-            auto kv4 = [&](int e) -> f32x4 {
-                const bf16x4c b = *reinterpret_cast<const bf16x4c*>(kt + e);
-                f32x4 o;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = (float)b[q];
-                return o;
-            };
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                float q[16], o2[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) q[r] = acc[ti][r] + bq[r];
-                const int lo = blo[ti], hi = bhi[ti];
-                float sc[8];
-                float mx = -3.0e38f;
-#pragma unroll
-                for (int wi = 0; wi < 8; ++wi) {
-                    float p = 0.f;
-                    if (wi < hd.wmax) {
-                        const int row = min(max(lo - kmin + wi, 0), CH2_KW - 1);
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            const f32x4 kv = kv4(row * CH_KP + col0 + 8 * m);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) p = fmaf(q[4 * m + i], kv[i], p);
-                        }
-                    }
-                    p += __shfl_xor(p, 32);
-                    const bool vis = (wi < hd.wmax) && (lo + wi < hi);
-                    sc[wi] = vis ? p * a.scale : -3.0e38f;
-                    mx = fmaxf(mx, sc[wi]);
-                }
-                float den = 0.f;
-#pragma unroll
-                for (int wi = 0; wi < 8; ++wi) {
-                    const bool vis = (wi < hd.wmax) && (lo + wi < hi);
-                    sc[wi] = vis ? __expf(sc[wi] - mx) : 0.f;
-                    den += sc[wi];
-                }
-                const float inv = den > 0.f ? 1.0f / den : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o2[r] = 0.f;
-#pragma unroll
-                for (int wi = 0; wi < 8; ++wi) {
-                    if (wi < hd.wmax) {
-                        const int row = min(max(lo - kmin + wi, 0), CH2_KW - 1);
-                        const float pw = sc[wi] * inv;
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            const f32x4 vv = kv4(CH2_KW * CH_KP + row * CH_KP + col0 + 8 * m);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) o2[4 * m + i] = fmaf(pw, vv[i], o2[4 * m + i]);
-                        }
-                    }
-                }
-                put_split<true>(r1h + ti * CH_APL, CH_APL, wrowA, col0, o2);
-            }
-            __syncthreads();
-            zero16(acc[0]); zero16(acc[1]);
-            gemm_run2<MODE, NR, U_G3, 12>(R, wp, r1h + browA, r1h + CH_APL + browA, acc[0], acc[1]);
-            float bo[16];
-            get_vec(vec + 2 * 192, col0, bo);
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x2[ti][r] = acc[ti][r] + (bo[r] + x1[ti][r]);
-        }
-        // ---- LayerNorm3 (folded into GEGLU's weights) and the raw x2 as B operands ----
-        float2 st3[2];
-        ln_stats2(x2, lnp, j, lt, lh, st3);
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-            float y[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) y[r] = (x2[ti][r] - st3[ti].x) * st3[ti].y;
-            put_split<true>(r1h + ti * CH_APL, CH_APL, wrowA, col0, y);
-            put_split<true>(r2h + ti * CH_APL, CH_APL, wrowA, col0, x2[ti]);
-        }
-        __syncthreads();
-    }
-    // ---- GEGLU: pairs w, w + 8, w + 16, both tiles ----
-    {
-        constexpr int QG = (MODE == 0) ? U_GE : (MODE == 1 ? U_G2 : 0);
-        const float* bff = reinterpret_cast<const float*>(smem + CV::BFF);
-        sfor<0, 3>([&](auto pc) {
-            constexpr int pi = decltype(pc)::value;
-            f32x16 av[2], ag[2];
-            zero16(av[0]); zero16(av[1]); zero16(ag[0]); zero16(ag[1]);
-            geglu_run2<MODE, NR, QG + 24 * pi>(R, wp, r1h + browA, r1h + CH_APL + browA, av, ag);
-            const int p = w + 8 * pi;
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bff + 32 * p + 4 * lh + 8 * m), bg = *reinterpret_cast<const f32x4*>(bff + 768 + 32 * p + 4 * lh + 8 * m);
-                    bf16x4c h;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) h[i] = (__bf16)((av[ti][4 * m + i] + bv[i]) * gelu_f(ag[ti][4 * m + i] + bg[i]));
-                    *reinterpret_cast<bf16x4c*>(hh + ti * CH_HPL + wrowH + (32 * p + 4 * lh + 8 * m) * 2) = h;
-                }
-        });
-    }
-    f32x4 bpv[4];
-    if constexpr (MODE != 2) {
-        const rsrc_t rvec = make_rsrc(a.vec, (unsigned)CHAIN_VEC_FLOATS * 4u);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) bpv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rvec, (4 * 192 + col0 + 8 * m) * 4, 0, 0));
-    }
-    __syncthreads();
-    float* const fpart = reinterpret_cast<float*>(r1h);   // [2 helper waves][2 tiles][16][64]: partial sums of column tiles 4, 5 (the LayerNorm3 planes are dead)
-    if constexpr (MODE == 2) {
-        constexpr int QH = U_FF - U_GE;
-        f32x16 acc[2];
-        zero16(acc[0]); zero16(acc[1]);
-        gemm_run2<MODE, NR, QH, 48 - U_HALF>(R, wp, hh + browH + 32 * U_HALF, hh + CH_HPL + browH + 32 * U_HALF, acc[0], acc[1]);
-        gemm_run2<MODE, NR, QH + 48 - U_HALF, 12>(R, wp, r2h + browA, r2h + CH_APL + browA, acc[0], acc[1]);
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) fpart[(((w - 6) * 2 + ti) * 16 + r) * 64 + l] = acc[ti][r];
-        __syncthreads();
-    }
-    if constexpr (MODE != 2) {
-        constexpr int QF = (MODE == 0) ? U_FF : U_FF - (U_GE - U_G2);
-        const rsrc_t rxin = make_rsrc(reinterpret_cast<const char*>(hd.xin) + (long long)in_idx * hd.x_bs * 2, (unsigned)hd.T * 384u);
-        float xr[2][16];
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const bf16x4c xb = __builtin_bit_cast(bf16x4c, __builtin_amdgcn_raw_buffer_load_b64(rxin, tt[ti] * 384 + col0 * 2 + 16 * m, 0, 0));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) xr[ti][4 * m + i] = (float)xb[i];
-            }
-        f32x16 acc[2];
-        zero16(acc[0]); zero16(acc[1]);
-        if (w < 4) {
-            gemm_run2<MODE, NR, QF, 48>(R, wp, hh + browH, hh + CH_HPL + browH, acc[0], acc[1]);
-            gemm_run2<MODE, NR, QF + 48, 12>(R, wp, r2h + browA, r2h + CH_APL + browA, acc[0], acc[1]);
-            __syncthreads();
-        } else {
-            gemm_run2<MODE, NR, QF, U_HALF>(R, wp, hh + browH, hh + CH_HPL + browH, acc[0], acc[1]);
-            __syncthreads();
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ti][r] += fpart[(((w - 4) * 2 + ti) * 16 + r) * 64 + l];
-        }
-        const rsrc_t ryo = make_rsrc(reinterpret_cast<char*>(a.y) + (long long)s_idx * a.y_bs * 2, (unsigned)hd.T * 384u);
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-            float y[16];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                bf16x4c yb;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    yb[i] = (__bf16)(acc[ti][4 * m + i] + bpv[m][i] + xr[ti][4 * m + i]);
-                    y[4 * m + i] = (float)yb[i];
-                }
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2c, yb), ryo, tt[ti] * 384 + col0 * 2 + 16 * m, 0, 0);   // (rows past T: out of range, dropped)
-            }
-            const int t0i = t0 + 32 * ti;
-            float* const so = (a.stats_out && t0i < hd.T) ? a.stats_out + (long long)s_idx * a.stats_bs + ((long long)(t0i >> 5) * 192) * 2 : nullptr;
-            if (so) {
-                const float cnt = (float)min(32, hd.T - t0i);
-                const float rcnt = __builtin_amdgcn_rcpf(cnt);
-                float mean[16], m2[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mean[r] = half32_sum(tv[ti] ? y[r] : 0.f) * rcnt;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { const float d = tv[ti] ? (y[r] - mean[r]) : 0.f; m2[r] = half32_sum(d * d); }
-                if (lt == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int c = col0 + (r & 3) + 8 * (r >> 2);
-                        gstore(so, 2 * c, mean[r]); gstore(so, 2 * c + 1, m2[r]);
-                    }
-                }
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(512, 1) void stchain2_kernel(const float* h_w, const float* h_o, const float* h_x, const int* h_lo, int h_T, int h_pitch, int h_obs, int h_xbs, int h_inmod,
-                                                          int h_nunc_wmax, const ChainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char csmem[];
-#ifdef SAID_AB_FLOOR
-    if (h_T > 0) return;
-#endif
-    const ChainHdr hd = {h_w, h_o, h_x, h_lo, h_T, h_pitch, h_obs, h_xbs, h_inmod, h_nunc_wmax & 0xffffff, (int)((unsigned)h_nunc_wmax >> 24)};
-    const int tid = threadIdx.x, l = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int s_idx = blockIdx.y, t0 = blockIdx.x * 64;
-    const bool uncond = s_idx < hd.n_uncond;
-    const int in_idx = hd.in_mod > 0 ? s_idx % hd.in_mod : s_idx;
-    if (w >= 6) chain_body2<2>(hd, a, csmem, w, l, s_idx, in_idx, t0);
-    else if (uncond) chain_body2<1>(hd, a, csmem, w, l, s_idx, in_idx, t0);
-    else chain_body2<0>(hd, a, csmem, w, l, s_idx, in_idx, t0);
-}
-
-template <bool BF>
+template <bool BF, bool S3>
 __global__ __launch_bounds__(512, BF ? 4 : 1) void stchain_kernel(const float* h_w, const float* h_o, const float* h_x, const int* h_lo, int h_T, int h_pitch, int h_obs, int h_xbs, int h_inmod,
                                                          int h_nunc_wmax, const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char csmem[];
@@ -1294,14 +854,15 @@ __global__ __launch_bounds__(512, BF ? 4 : 1) void stchain_kernel(const float* h
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (Confining small launches to fewer XCDs — a padded 1-D grid whose workgroups leave at once on the unwanted XCDs, so that one L2's copy of the weight stream serves more
     //  workgroups — was measured slower at every setting: profiles/r05i_stchain_xcds_ab.txt; and the sample count it read from the kernel arguments in
-    //  memory cost every launch a scalar-memory round trip before its first request: 29.9 -> 31.4 us.  The grid is (token tiles, samples).)
+    //  memory cost every launch a scalar-memory round trip before its first request: 29.9 -> 31.4 us.  The grid is (token tiles, samples[, slices]).)
     const int s_idx = blockIdx.y, t0 = blockIdx.x * 32;
+    const int slice = S3 ? (int)blockIdx.z : 0;
     const bool uncond = s_idx < hd.n_uncond;
     const int in_idx = hd.in_mod > 0 ? s_idx % hd.in_mod : s_idx;
     // three self-contained roles (each with its own prologue: nothing but scalars is live across this branch, so each gets its own register allocation)
-    if (w >= 6) chain_body<2, BF>(hd, a, csmem, w, l, s_idx, in_idx, t0);
-    else if (uncond) chain_body<1, BF>(hd, a, csmem, w, l, s_idx, in_idx, t0);
-    else chain_body<0, BF>(hd, a, csmem, w, l, s_idx, in_idx, t0);
+    if (w >= 6) chain_body<2, BF, S3>(hd, a, csmem, w, l, s_idx, in_idx, t0, slice);
+    else if (uncond) chain_body<1, BF, S3>(hd, a, csmem, w, l, s_idx, in_idx, t0, slice);
+    else chain_body<0, BF, S3>(hd, a, csmem, w, l, s_idx, in_idx, t0, slice);
 }
 
 bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long long x_bs) {
@@ -1312,17 +873,19 @@ bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long
     return true;
 }
 
-void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s, bool bf16, bool two_tiles) {
+void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s, bool bf16) {
     if (!stchain_supports(a, T, pitch, o_bs, x_bs)) { launch_fault("stchain: unsupported arguments (T %d, window %d)", T, a.wmax); return; }
     dim3 grid((T + 31) / 32, nsamp);
-    if (bf16 && two_tiles) hipLaunchKernelGGL(stchain2_kernel, dim3((grid.x + 1) / 2, nsamp), dim3(512), Carve2::LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
-    else if (bf16) hipLaunchKernelGGL(stchain_kernel<true>, grid, dim3(512), Carve<true>::LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
-    else hipLaunchKernelGGL(stchain_kernel<false>, grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+    if (bf16) hipLaunchKernelGGL((stchain_kernel<true, false>), grid, dim3(512), Carve<true>::LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+    else if (a.slices == 3) {
+        if (!a.part || !a.ticket) { launch_fault("stchain: three slices need the partial-sum buffer and the tickets"); return; }
+        hipLaunchKernelGGL((stchain_kernel<false, true>), dim3(grid.x, grid.y, 3), dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+    } else hipLaunchKernelGGL((stchain_kernel<false, false>), grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
 }
 void configure_stchain_kernel() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, Carve<true>::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Carve2::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Carve<true>::LDS);
 }
 
 }  // namespace said

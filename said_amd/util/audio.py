@@ -75,9 +75,26 @@ def _decode_wav(path: str):
     return torch.from_numpy(np.ascontiguousarray(pcm.T)), int(rate)
 
 
+def _decode(path: str):
+    """(channels, time) float32 and the file's sample rate.  RIFF/WAV through scipy (always present); other containers (flac, ogg, ...: the reference's
+    `torchaudio.load` takes any, audio.py:34) through `soundfile` when that package is importable — neither it nor torchaudio ships in this stack, so
+    there the error says what is missing instead of guessing."""
+    with open(path, "rb") as f:
+        magic = f.read(4)
+    if magic in (b"RIFF", b"RIFX", b"RF64"):
+        return _decode_wav(path)
+    try:
+        import soundfile as sf
+    except ImportError as e:
+        raise RuntimeError(f"{path}: not a RIFF/WAV file, and decoding other containers needs the `soundfile` package (not installed); "
+                           "convert the audio to WAV") from e
+    data, rate = sf.read(path, dtype="float32", always_2d=True)     # (time, channels), integer PCM scaled to [-1, 1) like torchaudio
+    return torch.from_numpy(np.ascontiguousarray(data.T)), int(rate)
+
+
 def load_audio(audio_path: str, sampling_rate: int) -> torch.FloatTensor:
     """Mono waveform (T_a,) at `sampling_rate`: decode, resample each channel if needed, average the channels."""
-    channels, rate = _decode_wav(audio_path)
+    channels, rate = _decode(audio_path)
     if rate != sampling_rate:
         channels = resample(channels, rate, sampling_rate)
     return channels.mean(dim=0)

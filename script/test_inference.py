@@ -70,6 +70,14 @@ def sample_repeats(net, audio, n_frames_model, repeats, args, sentence: int, see
     return torch.cat(outs) if outs else torch.zeros(0, n_frames_model, 32, device=dev)
 
 
+def write_clip(args, pid: str, stem: str, frames: int, table) -> None:
+    """One CSV per repeat of a clip: <output_dir>/<person>/<sentence>-<k>.csv, the first `frames` frames (test_inference.py:188-200)."""
+    target = os.path.join(args.output_dir, pid)
+    os.makedirs(target, exist_ok=True)
+    for k in range(table.shape[0]):
+        save_blendshape_coeffs(coeffs=table[k, :frames], classes=DEFAULT_BLENDSHAPE_CLASSES, output_path=os.path.join(target, f"{stem}-{k}.csv"))
+
+
 def run_rank(args, rank: int, world: int, dist) -> None:
     """One rank (world == 1 and dist None: the plain single-device driver)."""
     from said_amd import shard
@@ -94,6 +102,11 @@ def run_rank(args, rank: int, world: int, dist) -> None:
             out = sample_repeats(net, audio, n_model, mine, args, si, seeded)
             if out.shape[0] != len(mine):
                 raise RuntimeError(f"path returned {out.shape[0]} items for a shard of {len(mine)}")
+            if world == 1 and dist is None:
+                # single device: written as it is produced, like the reference's loop (test_inference.py:188-200) — a failure on a later clip keeps what
+                # exists, and nothing but the current clip is held
+                write_clip(args, pid, stem, frames, out.cpu().numpy())
+                continue
             clips.append((pid, stem, frames))
             local.append(out)
         if not clips:
@@ -106,10 +119,7 @@ def run_rank(args, rank: int, world: int, dist) -> None:
         if rank == 0:
             tables = res.cpu().numpy()
             for ci, (pid, stem, frames) in enumerate(clips):
-                target = os.path.join(args.output_dir, pid)
-                os.makedirs(target, exist_ok=True)
-                for k in range(args.num_repeats):
-                    save_blendshape_coeffs(coeffs=tables[k, ci, :frames], classes=DEFAULT_BLENDSHAPE_CLASSES, output_path=os.path.join(target, f"{stem}-{k}.csv"))
+                write_clip(args, pid, stem, frames, tables[:, ci])
 
 
 def _rank_main(args):

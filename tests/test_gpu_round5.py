@@ -307,7 +307,7 @@ def test_stchain_bf16_beside_the_six_launch_tail(model, dev, sd_parts):
     res, used = {}, {}
     try:
         model.set_mfma_dtype("bf16")
-        for v in (2, 1, 0):   # two tiles per workgroup (stchain2_kernel: measured slower, opt-in), one tile per workgroup (stchain_kernel<bf16>, the default), six launches
+        for v in (1, 0):   # one tile per workgroup (stchain_kernel<bf16>, the default), six launches (round 5's two-tile variant was removed in round 6: measured slower)
             eng.debug_option("st_chain_bf16", v)
             n0 = eng.debug_get("n_stchain")
             res[v] = model(x.to(dev), ts.to(dev), c.to(dev)).cpu()
@@ -315,9 +315,7 @@ def test_stchain_bf16_beside_the_six_launch_tail(model, dev, sd_parts):
     finally:
         eng.debug_option("st_chain_bf16", -1)
         model.set_mfma_dtype("fp32")
-    assert used[2] == 3 and used[1] == 3 and used[0] == 0   # (the last block's tail feeds out_sched_tm's input through the rgemm pair)
-    # the two fused variants run the same arithmetic on the same operands (two MFMAs per weight fragment instead of one): bit-identical
-    assert torch.equal(res[2], res[1]), float((res[2] - res[1]).abs().max())
+    assert used[1] == 3 and used[0] == 0   # (the last block's tail feeds out_sched_tm's input through the rgemm pair)
     rms = lambda d, rng: float(d.pow(2).mean().sqrt()) / rng
     for i in (0, B - 1):
         ref = ou.unet1d_forward(sd_u, x[i:i + 1], ts[i:i + 1], c[i:i + 1])

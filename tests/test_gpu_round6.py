@@ -288,3 +288,54 @@ def test_trained_like_guided_loop_split_vs_strict(dev):
     d = float((a - b).abs().max())
     print(f"split vs strict after 10 guided steps: {d:.2e} abs on [0, 1]")
     assert d <= 5e-2   # (both are fp32-accurate evaluations of a network whose fp32 conditioning is ~1e-3 per evaluation: see the test above)
+
+
+# ---------------------------------------------------------------- the fused tail as three workgroups per token tile (stchain.hip S3)
+@pytest.mark.parametrize("B,T", [(2, 600), (1, 37), (3, 333), (4, 600), (1, 1800)])
+def test_three_slice_tail_matches_one_workgroup_per_tile_and_is_bit_reproducible(dev, B, T):
+    """Small launches run the fused SpatialTransformer tail as three workgroups per token tile, each with a third of the GEGLU / folded proj_out weights; the
+    partial sums meet in memory and are added in slice order by whichever wave arrives last.  Against the one-workgroup kernel (said_debug_option
+    "st_chain_slices" = 1): only the folded proj_out's K is summed in three pieces instead of one (<= 1e-6 of range); repeated runs are bit-identical
+    (the arrival order must not show); launches above 85 (sample, tile) pairs keep one workgroup per tile ((4, 600): 76 tiles use it, (1, 1800): 57)."""
+    sd = _base_sd()
+    m = _make(sd, dev)
+    x, ts, c = _inputs(B, T, seed=21)
+    eng = m._get_engine(max(B, 2), max(T, 64))
+    n0 = eng.debug_get("n_stchain")
+    y3 = [_fwd(m, dev, x, ts, c) for _ in range(4)]
+    assert eng.debug_get("n_stchain") - n0 == 16
+    for k in range(1, 4):
+        assert torch.equal(y3[0], y3[k]), f"run {k} differs: {float((y3[0] - y3[k]).abs().max()):.3e}"
+    eng.debug_option("st_chain_slices", 1)
+    try:
+        y1 = _fwd(m, dev, x, ts, c)
+    finally:
+        eng.debug_option("st_chain_slices", -1)
+    ref = _oracle(sd, x, ts, c)
+    e31, e3, e1 = _rel(y3[0], y1), _rel(y3[0], ref), _rel(y1, ref)
+    print(f"B={B} T={T}: three slices vs one workgroup {e31:.2e}; vs oracle {e3:.2e} / {e1:.2e} (of range)")
+    assert e31 <= 1e-6 and e3 <= 1e-4 and e1 <= 1e-4
+    assert (e31 > 0) == (B * ((T + 31) // 32) <= 85), "three slices exactly where the launch is at most 85 tiles"
+
+
+def test_three_slice_tail_in_the_guided_loop_is_bit_reproducible(dev):
+    """The loop's schedule (shared prefix: one workgroup row feeds both guidance halves; unconditional samples skip the cross-attention) on the three-slice
+    kernel: 12 steps twice from the same draws, bit-identical, and within the loop bound of the one-workgroup schedule."""
+    sd = _base_sd()
+    m = _make(sd, dev)
+    lat = synth.synth_latents(7, (1, 600, 32)).to(dev)
+    emb = synth.synth_latents(8, (1, 600, 768)).to(dev)
+    wav = torch.zeros(1, 160000, device=dev)
+    kwi = dict(num_inference_steps=12, guidance_scale=2.0, eta=0.0, init_latents=lat, audio_embedding=emb)
+    a = m.inference(wav, **kwi).result.cpu()
+    b = m.inference(wav, **kwi).result.cpu()
+    assert torch.equal(a, b)
+    eng = m._get_engine(2, 640)
+    eng.debug_option("st_chain_slices", 1)
+    try:
+        c1 = m.inference(wav, **kwi).result.cpu()
+    finally:
+        eng.debug_option("st_chain_slices", -1)
+    d = float((a - c1).abs().max())
+    print(f"three slices vs one workgroup after 12 guided steps: {d:.2e} abs on [0, 1]")
+    assert d <= 1e-4
