@@ -119,6 +119,7 @@ struct said_ctx {
                                  // workgroup, two workgroups per CU; said_debug_option "st_chain_bf16").  (Round 5's two-tiles-per-workgroup variant measured slower — 96 vs 83 us,
                                  // profiles/r05p_stchain2_two_tiles_ab.txt — and was removed in round 6.)
     bool st_chain_dbg = false;   // debug: the fused kernel also writes x1 / x2 to X1 / X2
+    int attn_ks_force = 0;       // development: != 0 forces the self-attention workgroup shape (8 / 4 / 1: key-split waves; -4: four query tiles per workgroup) — said_debug_option "attn_ks"
     int st_chain_slices = -1;    // fp32 mode: -1 / 3: launches of at most CHAIN3_MAX_TILES (sample, token tile) pairs run THREE workgroups per tile (stchain.hip S3); 1: never
                                  // (said_debug_option "st_chain_slices")
     float* chain_part = nullptr; // ... their partial sums [CHAIN3_MAX_TILES][3][6][16][64] (workspace)
@@ -1245,7 +1246,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         const LaunchCfg lc = big_qkv ? LaunchCfg{6, 4} : LaunchCfg{qkv_nb, 8};
         // k and v pre-split for the key-split attention shapes (same rule as below), when this GEMM runs on ugemm_kernel (the only epilogue that packs)
         {
-            const bool key_split = !(tt1 * HEADS >= 2048) && !(tt1 * HEADS > 8192) && !dev_env("SAID_ATTN_KS") && !dev_env("SAID_NO_ATTN_QW");
+            const bool key_split = !(tt1 * HEADS >= 2048) && !(tt1 * HEADS > 8192) && !dev_env("SAID_ATTN_KS") && !dev_env("SAID_NO_ATTN_QW") && !c->attn_ks_force;
             GemmArgs probe = a;
             probe.b0 = c->cur_b0;
             presplit = !c->bf16_mode && sp_on(c, c->attn_split) && c->attn_presplit != 0 && key_split && c->use_ugemm && !big_qkv && !c->clk_on &&
@@ -1261,7 +1262,8 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         a.v_bstride = (long long)MC * g.Tp; a.o_bstride = obs;
         a.pitch = g.Tp; a.T = g.T; a.heads = HEADS; a.rows = vt_rows; a.b0 = 0;
         a.scale = 0.17677669529663687f;  // 32 ** -0.5
-        static const int attn_ks_env = dev_env("SAID_ATTN_KS") ? atoi(dev_env("SAID_ATTN_KS")) : 0;   // experiment knob
+        static const int attn_ks_env0 = dev_env("SAID_ATTN_KS") ? atoi(dev_env("SAID_ATTN_KS")) : 0;   // experiment knob
+        const int attn_ks_env = c->attn_ks_force ? c->attn_ks_force : attn_ks_env0;
         // waves per workgroup = ways the key tiles are split: 8 only pays while a wave would otherwise hold a single
         // tile (T <= 256); from there 4 waves with ~5 tiles each merge half as many partial states (B=1: -0.5 % per step)
         // large batches: four query tiles per workgroup sharing each K / V tile through the CU's L1 (-4), see attn.hip
@@ -2710,6 +2712,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->ugemm_split = value < 0 ? -1 : (value != 0);
     } else if (k == "st_chain") {
         ctx->st_chain = value < 0 ? -1 : (value != 0);
+    } else if (k == "attn_ks") {
+        ctx->attn_ks_force = (int)value;
     } else if (k == "st_chain_slices") {
         ctx->st_chain_slices = value < 0 ? -1 : (value == 3 ? 3 : 1);
     } else if (k == "st_chain_dbg") {

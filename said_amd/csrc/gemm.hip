@@ -346,6 +346,9 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
         const float2* cGN = reinterpret_cast<const float2*>(mainS + coef_off[0]);
         float* lnred = mainS + coef_off[a.nseg - 1] + seg_coef_floats(a.seg[a.nseg - 1]);
         const bool gnx = sg.xform == XF_GN_LN;
+        // the common shift is channel 0 of the token AS THE STATISTICS SEE IT (behind the GroupNorm affine when there is one: rounds 1-5 shifted by the raw value, which
+        // cancels digits of E[d^2] - E[d]^2 once the raw residual stream is large against the normalised values — round 6, tests/test_gpu_round6.py trained-like fill)
+        if (gnx) ln_ref = fmaf(ln_ref, cGN[0].x, cGN[0].y);
         float s1 = 0.f, s2 = 0.f;
         if (fast0 && sg.taps == 1 && Nq0 <= DMAX) {
             // the wave's operand registers ARE its share of the token rows: no extra loads

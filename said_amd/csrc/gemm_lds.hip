@@ -257,8 +257,6 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     }
     const ArgView V = arg_view_hs<MULTI>(l, kHdrDwords);   // common block (+ segments 1, 2): coalesced loads, fields via v_readlane
     issue_x(u0, xv, halo, true);
-    f32x4 lnref = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (HAS_LN) lnref = bload4(u0.rx, (t0 + 4 * sq) * 4, 0);   // raw channel 0 of this lane's 4 tokens: common shift
     WT wn[NSPL ? 24 : 1];   // NSPL: this wave's tile, all 24 eight-channel rounds (SP: 12 k16 steps x 2 planes, flat layout)
     if constexpr (NSPL) {
         const int tw = (w < NB) ? (tile0 + w) : (tile0 + (w - NB) + gate_tiles);
@@ -448,62 +446,78 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     // next tile's X (MT): requested before the current tile is staged
     f32x4 xvn[MT ? NRMAX : 1];
     float halon = 0.f;
-    f32x4 lnrefn = {0.f, 0.f, 0.f, 0.f};
     for (int ti = 0; ti < ntr; ++ti) {
     if constexpr (MT) {
         const bool more = ti + 1 < ntr;
         issue_x_at(u0, xvn, halon, more, t0 + 32);
-        if constexpr (HAS_LN) lnrefn = bload4(u0.rx, ((t0 + 32 + 4 * sq) * 4) | (more ? 0 : (int)0x80000000), 0);
     }
     // ================= phase 2: LayerNorm statistics from the staged registers =================
     f32x4 mu4 = {0.f, 0.f, 0.f, 0.f}, rs4 = {1.f, 1.f, 1.f, 1.f};
     if constexpr (HAS_LN) {   // single block (host guarantees C/KS == CB), taps == 1
         constexpr bool gnx = GN0;
         const float ln_eps = 1e-5f;   // host guarantees (ugemm_supports)
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        // Round 6: (mean, M2) pairs merged with Chan's update all the way — per lane over its NRMAX values of a token (two passes over registers), over the eight
+        // lanes that hold the token's other channels of this wave's block, over the KS waves through LDS.  (Rounds 1-5 summed d = v - ref and d^2 with ref = the RAW
+        // channel 0 of the token and took E[d^2] - E[d]^2: behind a GroupNorm the values are O(1) while the raw residual stream is O(100) on trained-like weights, and
+        // the subtraction cancelled five digits — tests/test_gpu_round6.py, the trained-like fill: 2e-3 of the output range instead of 1e-5.)
+        f32x4 m4, q4;
+        {
+            float vg[NRMAX][4];
 #pragma unroll
-        for (int rr = 0; rr < NRMAX; ++rr) {
-            {
+            for (int rr = 0; rr < NRMAX; ++rr) {
                 const int c = u0.c0 + rr * 8 + sr;
                 float2 cg = make_float2(1.f, 0.f);
                 if (gnx) cg = u0.cGN[c];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float vv = gnx ? fmaf(xv[rr][e], cg.x, cg.y) : xv[rr][e];
-                    const float d = vv - lnref[e];
-                    s1[e] += d;
-                    s2[e] = fmaf(d, d, s2[e]);
-                }
+                for (int e = 0; e < 4; ++e) vg[rr][e] = gnx ? fmaf(xv[rr][e], cg.x, cg.y) : xv[rr][e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sm = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < NRMAX; ++rr) sm += vg[rr][e];
+                m4[e] = sm * (1.0f / (float)NRMAX);
+                float qq = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < NRMAX; ++rr) { const float d = vg[rr][e] - m4[e]; qq = fmaf(d, d, qq); }
+                q4[e] = qq;
             }
         }
-        // sum over the 8 staging rows (lanes with equal token quad): xor 8 (DPP row_ror 8), 16, 32
+        // the 8 staging rows (lanes with equal token quad): xor 8, 16, 32 — equal counts n on both sides: mean' = (ma + mb) / 2, M2' = M2a + M2b + (mb - ma)^2 n / 2
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            s1[e] = dpp_add<0x128>(s1[e]); s2[e] = dpp_add<0x128>(s2[e]);
-            s1[e] += __shfl_xor(s1[e], 16); s2[e] += __shfl_xor(s2[e], 16);
-            s1[e] += __shfl_xor(s1[e], 32); s2[e] += __shfl_xor(s2[e], 32);
+        for (int st = 0; st < 3; ++st) {
+            const float half_n = 0.5f * (float)(NRMAX << st);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float mo = __shfl_xor(m4[e], 8 << st), qo = __shfl_xor(q4[e], 8 << st);
+                const float d = mo - m4[e];
+                q4[e] = q4[e] + qo + d * d * half_n;
+                m4[e] = 0.5f * (m4[e] + mo);
+            }
         }
         if (sr == 0) {   // lanes 0..7: tokens 4*sq..+3
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                lnred[(w * 32 + 4 * sq + e) * 2] = s1[e];
-                lnred[(w * 32 + 4 * sq + e) * 2 + 1] = s2[e];
+                lnred[(w * 32 + 4 * sq + e) * 2] = m4[e];
+                lnred[(w * 32 + 4 * sq + e) * 2 + 1] = q4[e];
             }
         }
         __syncthreads();
         const float invC = 1.0f / (float)C0;
+        const float nw = (float)(8 * NRMAX);   // values per wave and token
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float S1 = 0.f, S2 = 0.f;
+            float mean = lnred[(4 * sq + e) * 2], M2 = lnred[(4 * sq + e) * 2 + 1];
 #pragma unroll
-            for (int w2 = 0; w2 < KS; ++w2) {
-                S1 += lnred[(w2 * 32 + 4 * sq + e) * 2];
-                S2 += lnred[(w2 * 32 + 4 * sq + e) * 2 + 1];
+            for (int w2 = 1; w2 < KS; ++w2) {   // fixed order
+                const float mk = lnred[(w2 * 32 + 4 * sq + e) * 2], qk = lnred[(w2 * 32 + 4 * sq + e) * 2 + 1];
+                const float d = mk - mean;
+                const float n = nw * (float)w2, nn = n + nw;
+                mean = fmaf(d, nw / nn, mean);
+                M2 += qk + d * d * (n * nw / nn);
             }
-            const float md = S1 * invC;
-            const float var = fmaxf(S2 * invC - md * md, 0.f);
-            mu4[e] = lnref[e] + md;
-            rs4[e] = __builtin_amdgcn_rsqf(var + ln_eps);   // v_rsq_f32 (1 ulp): the IEEE 1/sqrt sequence is ~40 VALU ops
+            mu4[e] = mean;
+            rs4[e] = __builtin_amdgcn_rsqf(M2 * invC + ln_eps);   // v_rsq_f32 (1 ulp): the IEEE 1/sqrt sequence is ~40 VALU ops
         }
     }
     clk_stamp_p(clkp, w, l, 3);
@@ -1060,7 +1074,6 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 #pragma unroll
             for (int rr = 0; rr < NRMAX; ++rr) xv[rr] = xvn[rr];
             halo = halon;
-            lnref = lnrefn;
             t0 += 32;
             issue_tile_operands(t0);
         }

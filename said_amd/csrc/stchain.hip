@@ -118,7 +118,7 @@ __device__ __forceinline__ void clk_stamp_c(long long* clk, int w, int lane, int
     (void)clk; (void)w; (void)lane; (void)slot;
     return;
 #endif
-    if (clk && blockIdx.x == 8 && blockIdx.y + 1 == gridDim.y) {
+    if (clk && blockIdx.x == 8 && blockIdx.y + 1 == gridDim.y && blockIdx.z == 0) {   // (three-slice launches: slice 0)
         unsigned long long t;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
         if (lane == 0) clk[w * 16 + slot] = (long long)t;

@@ -1566,29 +1566,36 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(const PrepArgs a) {   // f
     float mu = 0.f, rs = 1.f;
     if (ln) {
         const int tt = tid & 31, part = tid >> 5;   // 8 parts x 24 channels
-        const float ref = gn ? fmaf(tile[0][tt], coefS[0][0], coefS[0][1]) : tile[0][tt];
-        float s1 = 0.f, s2 = 0.f;
+        // (mean, M2) of this part's 24 channels in two passes, merged over the eight parts with Chan's update (round 6: the shifted one-pass sums of rounds 2-5 —
+        // d = x - x[channel 0] — lose digits when channel 0 is an outlier channel: gains of 10 on trained-like weights)
+        float xs[24];
+        float sm = 0.f;
 #pragma unroll
         for (int i = 0; i < 24; ++i) {
             const int c = part * 24 + i;
             float x = tile[c][tt];
             if (gn) x = fmaf(x, coefS[c][0], coefS[c][1]);
-            const float d = x - ref;
-            s1 += d;
-            s2 = fmaf(d, d, s2);
+            xs[i] = x;
+            sm += x;
         }
-        lnp[part][tt][0] = s1;
-        lnp[part][tt][1] = s2;
+        const float mp = sm * (1.0f / 24.0f);
+        float qp = 0.f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) { const float d = xs[i] - mp; qp = fmaf(d, d, qp); }
+        lnp[part][tt][0] = mp;
+        lnp[part][tt][1] = qp;
         __syncthreads();
         if (tid < 32) {
-            float S1 = 0.f, S2 = 0.f;
+            float mean = lnp[0][tid][0], M2 = lnp[0][tid][1];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) { S1 += lnp[p][tid][0]; S2 += lnp[p][tid][1]; }
-            const float md = S1 * (1.0f / 192.0f);
-            const float var = fmaxf(S2 * (1.0f / 192.0f) - md * md, 0.f);
-            const float r0 = gn ? fmaf(tile[0][tid], coefS[0][0], coefS[0][1]) : tile[0][tid];
-            lnst[tid][0] = r0 + md;
-            lnst[tid][1] = 1.0f / sqrtf(var + 1e-5f);
+            for (int p = 1; p < 8; ++p) {
+                const float d = lnp[p][tid][0] - mean;
+                const float n = 24.f * (float)p, nn = n + 24.f;
+                mean = fmaf(d, 24.f / nn, mean);
+                M2 += lnp[p][tid][1] + d * d * (n * 24.f / nn);
+            }
+            lnst[tid][0] = mean;
+            lnst[tid][1] = 1.0f / sqrtf(M2 * (1.0f / 192.0f) + 1e-5f);
         }
         __syncthreads();
     }

@@ -18,3 +18,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/r6t2/tr -o cfg1 -- py
 python scripts/prof_summary.py $(find gpurun_out/r6t2/tr -name "cfg1_results.db" | head -1) > gpurun_out/r6t2/trace_cfg1.txt 2>&1
 find gpurun_out/r6t2/tr -name "*.db" -delete
 head -16 gpurun_out/r6t2/trace_cfg1.txt
+for v in 0 -4 8; do
+  echo "== cfg4 attn_ks=$v" | tee -a gpurun_out/r6t2/ab.txt
+  timeout 600 python bench.py --seconds 30 --num_steps 100 --edit --steps 3 --warmup 1 --no_cpu_baseline --no_secondary --no_roofline --debug_option attn_ks=$v 2>&1 | tail -1 | cut -c1-200 | tee -a gpurun_out/r6t2/ab.txt
+done

@@ -270,24 +270,26 @@ def test_trained_like_weight_statistics_through_the_unet(dev, B, T):
     assert res["bf16"][0] <= 8e-2 and res["bf16"][1] <= 1e-2
 
 
-def test_trained_like_guided_loop_split_vs_strict(dev):
-    """Ten guided DDIM steps on the trained-like fill, 1 s of audio: split-fp16 mode against strict fp32 from the same draws (both are fp32-accurate evaluations:
-    they part only through the chain's sensitivity)."""
+def test_trained_like_guided_steps_split_vs_strict(dev):
+    """Guided DDIM steps on the trained-like fill through the loop (shared prefix, fused scheduler), split-fp16 mode against strict fp32 from the same latents:
+    1 and 2 steps (teacher-forced in effect).  A longer free-running chain of THIS network is chaotic — ten steps part by O(1) between any two fp32
+    evaluations (measured: 1.0 on [0, 1]) — so nothing is claimed about it (DESIGN.md 7.2 says the same of the plain fill after 200 steps)."""
     sd = synth.trained_like_state_dict(num_w2v_layers=2)
     m = _make(sd, dev)
     lat = synth.synth_latents(5, (2, 60, 32)).to(dev)
     emb = synth.synth_latents(6, (2, 60, 768)).to(dev)
     wav = torch.zeros(2, 16000, device=dev)
-    kwi = dict(num_inference_steps=10, guidance_scale=2.0, eta=0.0, init_latents=lat, audio_embedding=emb)
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")
-        a = m.inference(wav, **kwi).result.cpu()
-        m.set_mfma_dtype("fp32_strict")
-        b = m.inference(wav, **kwi).result.cpu()
-    _, sd_u, null = op.split_state_dict(sd)
-    d = float((a - b).abs().max())
-    print(f"split vs strict after 10 guided steps: {d:.2e} abs on [0, 1]")
-    assert d <= 5e-2   # (both are fp32-accurate evaluations of a network whose fp32 conditioning is ~1e-3 per evaluation: see the test above)
+    for n, bound in ((1, 1e-4), (2, 2e-3)):
+        kwi = dict(num_inference_steps=n, guidance_scale=2.0, eta=0.0, init_latents=lat, audio_embedding=emb)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            m.set_mfma_dtype("fp32")
+            a = m.inference(wav, **kwi).result.cpu()
+            m.set_mfma_dtype("fp32_strict")
+            b = m.inference(wav, **kwi).result.cpu()
+        d = float((a - b).abs().max())
+        print(f"trained-like fill, {n} guided step(s): split vs strict {d:.2e} abs on [0, 1]")
+        assert d <= bound
 
 
 # ---------------------------------------------------------------- the fused tail as three workgroups per token tile (stchain.hip S3)
