@@ -95,6 +95,23 @@ for cfg, name in FAMILY.items():
                            "note": "(2*FETCH_SIZE + WRITE_SIZE) * 1024, launch-weighted over the family's variants; gfx950 half-count correction on reads",
                            "source": f"profiles/{tag}_pmc_hbm_traffic.txt", "source_hash": SRC_HASH, "git_sha": sha}
     lines.append(f"{cfg:18s} {name:32s} launches {n:6d}  FETCH {fk / n:10.1f} KB  WRITE {wk / n:10.1f} KB  HBM {(per) / 1e6:8.2f} MB per launch")
+    # the top SINGLE kernel (one instantiation) of the in-situ trace taken in the same batch, with its own traffic (bench.py's dominant FAMILY can be
+    # a sum over several instantiations while the trace's top row is another kernel)
+    tr = os.path.join(ROOT, "gpurun_out", "final", f"trace_{cfg}.txt")
+    if os.path.exists(tr):
+        for ln in open(tr):
+            mm = re.match(r"\s*([\d.]+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+(said::\S.*)$", ln)
+            if mm:
+                kname = mm.group(5).strip()
+                key = re.sub(r"^said::", "", kname)
+                nf = sum(r["launches"] for r in f if r["counter"] == "FETCH_SIZE" and r["kernel"].endswith(key))
+                fk1 = sum(r["sum"] for r in f if r["counter"] == "FETCH_SIZE" and r["kernel"].endswith(key))
+                wk1 = sum(r["sum"] for r in w if r["counter"] == "WRITE_SIZE" and r["kernel"].endswith(key))
+                out["configs"][cfg]["top_single_kernel_in_trace"] = {"kernel": kname, "share_of_kernel_time_pct": float(mm.group(4)), "avg_us_in_situ": float(mm.group(3)),
+                                                                    "hbm_bytes_per_launch": round((2 * fk1 + wk1) * 1024 / nf) if nf else None}
+                lines.append(f"    top single kernel of the in-situ trace: {kname} ({mm.group(4)} % of kernel time, {mm.group(3)} us): "
+                             + (f"{(2 * fk1 + wk1) * 1024 / nf / 1e6:.2f} MB per launch" if nf else "not in the PMC passes"))
+                break
     # the rest of the step, for the record
     fam = {}
     for r in f:
