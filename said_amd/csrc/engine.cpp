@@ -60,6 +60,7 @@ struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out
              void *t_out1 = nullptr, *t_q2 = nullptr, *t_out2 = nullptr, *tf_out1 = nullptr, *tf_q2 = nullptr, *tf_out2 = nullptr; /* [192][192] (xgemm_kernel) */
              float *chain_w = nullptr, *chain_vec = nullptr; /* round 5: weight stream + vectors of the fused tail (stchain.hip) */
              float* chain_w3 = nullptr; /* round 6: the three-slice stream (small launches: three workgroups per token tile) */
+             float* chain_w2 = nullptr; /* ... and the two-slice stream (launches of 86 .. 128 tiles) */
              void* chain_wb = nullptr; /* ... and the bf16 stream (1 KB units) of its bf16-mode variant */ };
 struct W2VLayer { PW qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln2g, *ln2b; };
 
@@ -120,7 +121,8 @@ struct said_ctx {
                                  // profiles/r05p_stchain2_two_tiles_ab.txt — and was removed in round 6.)
     bool st_chain_dbg = false;   // debug: the fused kernel also writes x1 / x2 to X1 / X2
     int attn_ks_force = 0;       // development: != 0 forces the self-attention workgroup shape (8 / 4 / 1: key-split waves; -4: four query tiles per workgroup) — said_debug_option "attn_ks"
-    int st_chain_slices = -1;    // fp32 mode: -1 / 3: launches of at most CHAIN3_MAX_TILES (sample, token tile) pairs run THREE workgroups per tile (stchain.hip S3); 1: never
+    int st_chain_slices = -1;    // fp32 mode: -1 / 3: launches of at most CHAIN3_MAX_TILES (sample, token tile) pairs run THREE workgroups per tile, of at most CHAIN2_MAX_TILES two
+                                 // (stchain.hip CU<>); 2: two wherever slicing is possible; 1: never
                                  // (said_debug_option "st_chain_slices")
     float* chain_part = nullptr; // ... their partial sums [CHAIN3_MAX_TILES][3][6][16][64] (workspace)
     int* chain_ticket = nullptr; // ... and arrival counters [CHAIN3_MAX_TILES][6]: zero between launches (not part of the workspace: said_debug_ws_fill must not touch them)
@@ -1246,7 +1248,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         const LaunchCfg lc = big_qkv ? LaunchCfg{6, 4} : LaunchCfg{qkv_nb, 8};
         // k and v pre-split for the key-split attention shapes (same rule as below), when this GEMM runs on ugemm_kernel (the only epilogue that packs)
         {
-            const bool key_split = !(tt1 * HEADS >= 2048) && !(tt1 * HEADS > 8192) && !dev_env("SAID_ATTN_KS") && !dev_env("SAID_NO_ATTN_QW") && !c->attn_ks_force;
+            const bool key_split = (c->attn_ks_force == 4 || c->attn_ks_force == 8) || (!(tt1 * HEADS >= 2048) && !(tt1 * HEADS > 8192) && !dev_env("SAID_ATTN_KS") && !dev_env("SAID_NO_ATTN_QW") && !c->attn_ks_force);
             GemmArgs probe = a;
             probe.b0 = c->cur_b0;
             presplit = !c->bf16_mode && sp_on(c, c->attn_split) && c->attn_presplit != 0 && key_split && c->use_ugemm && !big_qkv && !c->clk_on &&
@@ -1270,7 +1272,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         static const bool no_qw = dev_env("SAID_NO_ATTN_QW") != nullptr;
         const int attn_ks = (!no_qw && tt1 * HEADS >= 2048) ? -4 : ((tt1 * HEADS > 8192) ? 1 : ((g.T <= 256 && tt1 * HEADS <= 2048) ? 8 : 4));
         if (out1_tm && !attn_ks_env && attn_ks == -4) { a.o = static_cast<float*>(c->uPL); a.o_bstride = tg_rows(g); a.o_mode = 1; }
-        do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s, presplit && (attn_ks == 4 || attn_ks == 8));
+        do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s, presplit && ((attn_ks_env ? attn_ks_env : attn_ks) == 4 || (attn_ks_env ? attn_ks_env : attn_ks) == 8));
         out1_done = a.o_mode == 1;
     }
     if (chain && !out1_done) {
@@ -1283,8 +1285,12 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         ca.S = g.S; ca.np = g.np; ca.koff = blk * 2 * MC; ca.wmax = c->band_wmax; ca.scale = 0.17677669529663687f;
         // small launches: three workgroups per token tile, each streaming a third of the GEGLU / folded proj_out weights (38 workgroups on 256 CUs were bound by
         // one CU's L2 port each: 2.36 MB per workgroup) — while the launch still is one round of the chip
-        ca.slices = (c->st_chain_slices != 1 && sw.chain_w3 && tt <= CHAIN3_MAX_TILES && !c->st_chain_dbg) ? 3 : 1;
-        if (ca.slices == 3) { ca.wstream = sw.chain_w3; ca.part = c->chain_part; ca.ticket = c->chain_ticket; }
+        ca.slices = 1;
+        if (c->st_chain_slices != 1 && sw.chain_w3 && sw.chain_w2 && !c->st_chain_dbg) {
+            if (tt <= CHAIN3_MAX_TILES && c->st_chain_slices != 2) ca.slices = 3;
+            else if (tt <= CHAIN2_MAX_TILES) ca.slices = 2;
+        }
+        if (ca.slices > 1) { ca.wstream = ca.slices == 3 ? sw.chain_w3 : sw.chain_w2; ca.part = c->chain_part; ca.ticket = c->chain_ticket; }
         if (c->clk_on && c->dbg_count < 64) ca.clk = c->clk_dev + (long long)c->dbg_count * 128;
         if (c->st_chain_dbg) { ca.dbg_x1 = c->X1; ca.dbg_x2 = c->X2; ca.dbg_o2 = c->X3; }
         if (c->log_on) {
@@ -1621,7 +1627,7 @@ int alloc_workspace(said_ctx* ctx, int max_batch_eff, int max_frames) {
     rc |= dalloc(ctx, &ctx->F, Be * FFI * Tp);
     rc |= dalloc(ctx, &ctx->KV, Be * NST * 2 * MC * Tp);
     rc |= dalloc(ctx, &ctx->KVT, Be * NST * 2 * MC * Tp);
-    rc |= dalloc(ctx, &ctx->chain_part, (size_t)CHAIN3_MAX_TILES * 3 * 6 * 16 * 64);
+    rc |= dalloc(ctx, &ctx->chain_part, (size_t)256 * 6 * 16 * 64);   // (85 x 3 or 128 x 2 workgroups)
     rc |= dalloc(ctx, &ctx->CTX, Be * (size_t)ctx_dim * Tp);
     const size_t Np = ctx->maxNp;
     rc |= dalloc(ctx, &ctx->E0, MC * Np); rc |= dalloc(ctx, &ctx->E1, TE * Np); rc |= dalloc(ctx, &ctx->E2, TE * Np);
@@ -1723,7 +1729,7 @@ int said_create(said_ctx** out, int device, int max_batch_eff, int max_frames, i
     rc |= dalloc(ctx, &ctx->coef1_dev, 8);
     rc |= dalloc(ctx, &ctx->step_dev, 4);
     rc |= dalloc(ctx, &ctx->status_dev, 4);
-    rc |= dalloc(ctx, &ctx->chain_ticket, CHAIN3_MAX_TILES * 6);
+    rc |= dalloc(ctx, &ctx->chain_ticket, CHAIN2_MAX_TILES * 6);
     rc |= dalloc(ctx, &ctx->seed_dev, 4);
     rc |= dalloc(ctx, &ctx->clk_dev, 64 * 128);
     rc |= dalloc(ctx, &ctx->freqs, MC / 2);
@@ -1864,7 +1870,7 @@ int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_fram
     rc |= dalloc(ctx, &c->coef1_dev, 8);
     rc |= dalloc(ctx, &c->step_dev, 4);
     rc |= dalloc(ctx, &c->status_dev, 4);
-    rc |= dalloc(ctx, &c->chain_ticket, CHAIN3_MAX_TILES * 6);
+    rc |= dalloc(ctx, &c->chain_ticket, CHAIN2_MAX_TILES * 6);
     rc |= dalloc(ctx, &c->seed_dev, 4);
     rc |= dalloc(ctx, &c->clk_dev, 64 * 128);
     rc |= alloc_workspace(c, max_batch_eff, max_frames);
@@ -2030,6 +2036,33 @@ static int pack_chain(said_ctx* ctx, STW& sw, const std::string& b, const std::v
         stf.resize(st.size() / 2);
         memcpy(stf.data(), st.data(), st.size() * 2);
         if (upload(ctx, &sw.chain_w3, stf.data(), stf.size())) return -1;
+    }
+    {   // the two-slice stream (stchain.h CHAIN2_*): slice c = GEGLU pairs 12 c .. 12 c + 11 — waves 0-3 two each (local pairs w, w + 4), waves 4-7 one (w + 4) —
+        // + k16 steps 24 c .. 24 c + 23 of the folded proj_out's GEGLU segment + steps 6 c .. 6 c + 5 of its x2 segment
+        st.assign(CHAIN2_STREAM_BYTES / 2, (_Float16)0.f);
+        o = 0;
+        for (int c = 0; c < 2; ++c) {
+            int ff[30];
+            for (int i = 0; i < 24; ++i) ff[i] = 24 * c + i;
+            for (int i = 0; i < 6; ++i) ff[24 + i] = 48 + 6 * c + i;
+            auto put_pair = [&](int p) {
+                for (int s2 = 0; s2 < 12; ++s2) { put_unit(3, 32 * p, s2); put_unit(3, FFI + 32 * p, s2); }
+            };
+            for (int w = 0; w < 6; ++w) {
+                for (int kind = 0; kind < 3; ++kind)
+                    for (int s2 = 0; s2 < 12; ++s2) put_unit(kind, 32 * w, s2);
+                if (w < 4) { put_pair(12 * c + w); put_pair(12 * c + w + 4); } else put_pair(12 * c + w + 4);
+                for (int i = 0; i < (w < 4 ? 30 : 15); ++i) put_unit(4, 32 * w, ff[i]);
+            }
+            for (int w = 6; w < 8; ++w) {
+                put_pair(12 * c + w + 4);
+                for (int i = 15; i < 30; ++i) put_unit(4, 32 * (w - 2), ff[i]);
+            }
+        }
+        if (o != st.size()) return fail(ctx, "pack_chain: two-slice stream size mismatch");
+        stf.resize(st.size() / 2);
+        memcpy(stf.data(), st.data(), st.size() * 2);
+        if (upload(ctx, &sw.chain_w2, stf.data(), stf.size())) return -1;
     }
     std::vector<float> vec(CHAIN_VEC_FLOATS);
     for (int n = 0; n < MC; ++n) {
@@ -2715,7 +2748,7 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
     } else if (k == "attn_ks") {
         ctx->attn_ks_force = (int)value;
     } else if (k == "st_chain_slices") {
-        ctx->st_chain_slices = value < 0 ? -1 : (value == 3 ? 3 : 1);
+        ctx->st_chain_slices = value < 0 ? -1 : ((value == 3 || value == 2) ? (int)value : 1);   // 2: two slices wherever a sliced launch is possible (<= 128 tiles)
     } else if (k == "st_chain_dbg") {
         ctx->st_chain_dbg = value != 0;
     } else if (k == "st_chain_bf16") {

@@ -13,6 +13,10 @@ constexpr size_t CHAIN_STREAM_BYTES = CHAIN_STREAM_UNITS * 2048;   // 2 KB units
 constexpr size_t CHAIN3_SLICE_UNITS = 4 * 80 + 2 * 70 + 2 * 34;             // 528 units = 1,081,344 bytes per slice
 constexpr size_t CHAIN3_STREAM_BYTES = 3 * CHAIN3_SLICE_UNITS * 2048;
 constexpr int CHAIN3_MAX_TILES = 85;                    // (sample, token tile) pairs a three-slice launch may have: 3 x 85 <= 256 workgroups, one round of the chip
+// ... and two slices for launches of 86 .. 128 pairs: twelve GEGLU pairs per slice (waves 0-3 two each, waves 4-7 one), 24 + 6 k16 steps of the folded proj_out
+constexpr size_t CHAIN2_SLICE_UNITS = 4 * 114 + 2 * 75 + 2 * 39;            // 684 units per slice
+constexpr size_t CHAIN2_STREAM_BYTES = 2 * CHAIN2_SLICE_UNITS * 2048;
+constexpr int CHAIN2_MAX_TILES = 128;
 constexpr int CHAIN_VEC_FLOATS = 5 * 192 + 1536;        // global: b1, bq, bo2, c2, bffp (192 each), bff (1536: value rows, then gate rows)
 constexpr int CHAIN_VEC_FLOATS_LDS = 4 * 192 + 1536;    // LDS: bo2 | c2 share a slot (conditional | unconditional sample)
 
@@ -37,9 +41,9 @@ struct ChainArgs {
     int koff;                // = 384 * block index
     int wmax;                // max(hi - lo) <= 8
     float scale;             // dim_head ** -0.5
-    int slices;              // 1, or 3: wstream is the three-slice stream (CHAIN3_STREAM_BYTES) and the launch has three workgroups per token tile
-    float* part;             // slices == 3: partial sums [sample][tile][3 slices][6 column tiles][16][64 lanes] fp32
-    int* ticket;             // slices == 3: [sample][tile][6] arrival counters, zero before and after every launch
+    int slices;              // 1, or 2 / 3: wstream is that slice count's stream (CHAIN2_ / CHAIN3_STREAM_BYTES) and the launch has 2 / 3 workgroups per token tile
+    float* part;             // slices > 1: partial sums [sample][tile][slices][6 column tiles][16][64 lanes] fp32
+    int* ticket;             // slices > 1: [sample][tile][6] arrival counters, zero before and after every launch
 };
 
 bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long long x_bs);

@@ -68,26 +68,33 @@ constexpr int CH_NR_BF = 6;                        // bf16 variant: 1 KB units; 
 // units of a wave's stream: [to_out1 12][to_q 12][to_out2 12][GEGLU 3 pairs x 12 steps x (value, gate)][ffproj 60 | 30]; waves 6, 7: [GEGLU 72][ffproj 30].
 // The folded proj_out (60 k16 steps per column tile) is the one phase where six column owners on four SIMDs are unbalanced (two SIMDs with two owners: 11.5k clocks of
 // MFMA against 5.8k): column tiles 4 and 5 are split over K — waves 4, 5 take steps 0 .. 29, the helper waves 6, 7 steps 30 .. 59 and hand their partial sums over through LDS.
-// S3 (round 6, small launches): THREE workgroups per token tile, each with a third of the GEGLU / folded-proj_out work (a "slice": GEGLU pairs 8 c .. 8 c + 7 — one per
-// wave — and the matching third of the folded proj_out's K: 16 k16 steps over its 256 GEGLU columns + 4 over a third of x2), everything in front of GEGLU computed by all
-// three.  The stream a workgroup pulls through its CU's L2 port shrinks from 1152 to 528 units (2.36 -> 1.08 MB); the partial sums meet in memory (see the epilogue).
-template <bool S3> struct CU {
+// Slices (round 6, small launches): NS = 3 or 2 workgroups per token tile, each with 1 / NS of the GEGLU / folded-proj_out work — slice c owns GEGLU pairs
+// (24 / NS) c .. + 24 / NS - 1 and the matching part of the folded proj_out's K (48 / NS k16 steps over its GEGLU columns + 12 / NS over x2); everything in front of GEGLU is
+// computed by every slice.  The stream a workgroup pulls through its CU's L2 port shrinks from 1152 units (2.36 MB) to 684 (NS = 2) / 528 (NS = 3); the partial sums
+// meet in memory (see the epilogue).  NS = 3: one pair per wave.  NS = 2: twelve pairs on eight waves — waves 0-3 take two (local pairs w, w + 4), waves 4-7 one
+// (w + 4): three pairs per SIMD; the two wave classes have different stream layouts behind GEGLU, hence WC.
+// SC = 2 NS + WC (wave class: 0 = waves 0-3 — and every wave when NS != 2 —, 1 = waves 4-7 of a two-slice workgroup).
+template <int SC> struct CU {
+    static constexpr int NS = SC >> 1, WC = SC & 1;
+    static_assert(NS >= 1 && NS <= 3 && (WC == 0 || NS == 2), "slice configuration");
     static constexpr int G1 = 0, G2 = 12, G3 = 24, GE = 36;
-    static constexpr int NPAIR = S3 ? 1 : 3;                 // GEGLU (value, gate) pairs per wave
-    static constexpr int FF = GE + 24 * NPAIR;               // first unit of the folded proj_out (108 | 60)
-    static constexpr int FFS = S3 ? 20 : 60;                 // its k16 steps per column tile in this slice ...
-    static constexpr int FFH = S3 ? 16 : 48;                 // ... of which over the GEGLU product (the rest over x2)
-    static constexpr int HALF = FFS / 2;                     // steps of waves 4-7 (column tiles 4, 5 are split over K between an owner and a helper wave)
-    static constexpr int END = FF + FFS;                     // units of waves 0-3 (168 | 80)
-    static constexpr int W45 = FF + HALF, W67 = 24 * NPAIR + HALF;   // units of waves 4, 5 (138 | 70) and 6, 7 (102 | 34)
-    static constexpr int SLICE = 4 * END + 2 * W45 + 2 * W67;        // units of one workgroup's stream (1152 | 528)
+    static constexpr int NP0 = NS == 1 ? 3 : (NS == 2 ? 2 : 1), NP1 = NS == 1 ? 3 : 1;   // GEGLU (value, gate) pairs of waves 0-3 / 4-7
+    static constexpr int NPAIR = WC ? NP1 : NP0;               // ... of this wave class
+    static constexpr int LSTEP = NS == 1 ? 8 : 4, L0 = (NS == 2 && WC) ? 4 : 0;          // local pair of (wave w, pair pi) = w + LSTEP pi + L0
+    static constexpr int FF = GE + 24 * NPAIR;                 // first unit of the folded proj_out in this wave class's streams
+    static constexpr int FFS = 60 / NS;                        // its k16 steps per column tile in this slice ...
+    static constexpr int FFH = 48 / NS;                        // ... of which over the GEGLU product (the rest, 12 / NS, over x2)
+    static constexpr int HALF = FFS / 2;                       // steps of waves 4-7 (column tiles 4, 5 are split over K between an owner and a helper wave)
+    static constexpr int END = GE + 24 * NP0 + FFS;            // units of waves 0-3 (168 | 114 | 80)
+    static constexpr int W45 = GE + 24 * NP1 + HALF, W67 = 24 * NP1 + HALF;   // units of waves 4, 5 (138 | 75 | 70) and 6, 7 (102 | 39 | 34)
+    static constexpr int SLICE = 4 * END + 2 * W45 + 2 * W67;  // units of one workgroup's stream (1152 | 684 | 528)
 };
-static_assert(CU<false>::SLICE == (int)CHAIN_STREAM_UNITS && CU<true>::SLICE == (int)CHAIN3_SLICE_UNITS, "stchain.h");
+static_assert(CU<2>::SLICE == (int)CHAIN_STREAM_UNITS && CU<4>::SLICE == (int)CHAIN2_SLICE_UNITS && CU<6>::SLICE == (int)CHAIN3_SLICE_UNITS, "stchain.h");
 constexpr int U_G1 = 0, U_G2 = 12, U_G3 = 24, U_GE = 36;
 // MODE 0: column owner, conditional sample; 1: column owner, unconditional (skips to_q / to_out2); 2: helper wave.  A request past the end of the wave's stream (the
 // shorter streams of waves 4-7, the ring running ahead at the end) is out of the buffer's range: no memory access, zeros.
 template <int MODE> __device__ __forceinline__ constexpr int unit_of(int q) { return MODE == 0 ? q : (MODE == 1 ? (q < U_G2 ? q : q + (U_GE - U_G2)) : q); }
-template <int MODE, bool S3> __device__ __forceinline__ constexpr int n_units() { return MODE == 0 ? CU<S3>::END : (MODE == 1 ? CU<S3>::END - (U_GE - U_G2) : CU<S3>::W67); }
+template <int MODE, int SC> __device__ __forceinline__ constexpr int n_units() { return MODE == 0 ? CU<SC>::FF + CU<SC>::FFS : (MODE == 1 ? CU<SC>::FF + CU<SC>::FFS - (U_GE - U_G2) : CU<SC>::W67); }
 
 template <int B, int E, typename F>
 __device__ __forceinline__ void sfor(F&& f) {
@@ -104,9 +111,9 @@ struct WStream { rsrc_t r; int vo; };   // the wave's stream, lane * 16
 typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2c __attribute__((ext_vector_type(2)));
-template <int MODE, bool BF, bool S3, int NR, int Q>
+template <int MODE, bool BF, int SC, int NR, int Q>
 __device__ __forceinline__ void ring_issue(Ring<NR>& R, const WStream& wp) {
-    if constexpr (Q < n_units<MODE, S3>()) {
+    if constexpr (Q < n_units<MODE, SC>()) {
         constexpr int u = unit_of<MODE>(Q);
         R.h[Q % NR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wp.r, wp.vo, u * (BF ? 1024 : 2048), 0));
         if constexpr (!BF) R.l[Q % NR] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wp.r, wp.vo + 1024, u * 2048, 0));
@@ -128,7 +135,7 @@ __device__ __forceinline__ void clk_stamp_c(long long* clk, int w, int lane, int
 // one 192-deep (NS = 12) or longer run of k16 steps: B fragments from the token-major planes at `bh` (this lane's row + k-group offset; low plane `pl` bytes behind)
 // (the B fragments are double-buffered by hand, one step ahead, and a scheduling fence closes every step: left alone the compiler hoists all 2 NS fragment
 //  reads above the MFMAs — 96 registers at NS = 12, which the ring and the accumulators need)
-template <int MODE, bool BF, bool S3, int NR, int Q0, int NS>
+template <int MODE, bool BF, int SC, int NR, int Q0, int NS>
 __device__ __forceinline__ void gemm_run(Ring<NR>& R, const WStream& wp, const char* bh, int pl, f32x16& acc, f32x16& accx) {
     f16x8 xh = *reinterpret_cast<const f16x8*>(bh), xl = xh;
     if constexpr (!BF) xl = *reinterpret_cast<const f16x8*>(bh + pl);
@@ -147,14 +154,14 @@ __device__ __forceinline__ void gemm_run(Ring<NR>& R, const WStream& wp, const c
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
             accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, accx, 0, 0, 0);
         }
-        ring_issue<MODE, BF, S3, NR, Q0 + s + NR>(R, wp);
+        ring_issue<MODE, BF, SC, NR, Q0 + s + NR>(R, wp);
         __builtin_amdgcn_sched_barrier(0);
         xh = nh; xl = nl;
     });
 }
 // GEGLU: a (value, gate) tile pair shares every B fragment; units alternate value, gate.  `between(s)` runs behind step s's MFMAs (the previous pair's epilogue in
 // four pieces: its erf / split VALU work rides under this pair's matrix work, and the weight stream never pauses for an epilogue)
-template <int MODE, bool BF, bool S3, int NR, int Q0, typename F>
+template <int MODE, bool BF, int SC, int NR, int Q0, typename F>
 __device__ __forceinline__ void geglu_run(Ring<NR>& R, const WStream& wp, const char* bh, int pl, f32x16& av, f32x16& avx, f32x16& ag, f32x16& agx, F&& between) {
     f16x8 xh = *reinterpret_cast<const f16x8*>(bh), xl = xh;
     if constexpr (!BF) xl = *reinterpret_cast<const f16x8*>(bh + pl);
@@ -179,8 +186,8 @@ __device__ __forceinline__ void geglu_run(Ring<NR>& R, const WStream& wp, const 
             avx = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, xl, avx, 0, 0, 0);
             agx = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl, agx, 0, 0, 0);
         }
-        ring_issue<MODE, BF, S3, NR, qv + NR>(R, wp);
-        ring_issue<MODE, BF, S3, NR, qg + NR>(R, wp);
+        ring_issue<MODE, BF, SC, NR, qv + NR>(R, wp);
+        ring_issue<MODE, BF, SC, NR, qg + NR>(R, wp);
         between(sc);
         __builtin_amdgcn_sched_barrier(0);
         xh = nh; xl = nl;
@@ -262,10 +269,12 @@ struct ChainHdr {          // the leading kernel parameters (preloaded into SGPR
     int in_mod, n_uncond, wmax;
 };
 
-template <int MODE, bool BF, bool S3>
+template <int MODE, bool BF, int SC>
 __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& a, char* smem, int w, int l, int s_idx, int in_idx, int t0, int slice) {
-    static_assert(!(BF && S3), "the three-slice variant exists for the fp32 mode's small launches only");
-    using U = CU<S3>;
+    using U = CU<SC>;
+    constexpr int NSL = U::NS;
+    constexpr bool S3 = NSL > 1;   // sliced launch
+    static_assert(!(BF && S3), "the sliced variants exist for the fp32 mode's small launches only");
     constexpr int U_FF = U::FF, U_HALF = U::HALF, U_END = U::END, U_W45 = U::W45, U_W67 = U::W67;
     constexpr int NR = BF ? CH_NR_BF : ((MODE == 2) ? CH_NR_HELPER : CH_NR_OWNER);
     const int tid = threadIdx.x;
@@ -400,7 +409,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             }
         }
         clk_stamp_c(clk, w, l, 2);
-        sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, S3, NR, decltype(qc)::value>(R, wp); });   // (not needed before GEGLU; behind the window tile, whose registers it reuses)
+        sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, SC, NR, decltype(qc)::value>(R, wp); });   // (not needed before GEGLU; behind the window tile, whose registers it reuses)
         clk_stamp_c(clk, w, l, 3);
         if (!uncond) {   // LayerNorm2 partials, LayerNorm2(x1) planes, cross-attention output planes
             __syncthreads();
@@ -466,7 +475,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
                 vecv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rvec, (i < CHAIN_VEC_FLOATS_LDS / 4) ? gi * 16 : (int)0x80000000, 0, 0));
             }
         }
-        sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, S3, NR, decltype(qc)::value>(R, wp); });
+        sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, SC, NR, decltype(qc)::value>(R, wp); });
         clk_stamp_c(clk, w, l, 12);
         if constexpr (BF) {   // both tiles as they are: bf16 rows of 384 bytes at the planes' 400-byte pitch
             *reinterpret_cast<f32x4*>(smem + CV::R1 + prow0 * (CH_AP * 2) + ppc0 * 16) = ov[0];
@@ -518,7 +527,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         // ---- to_out1 + GroupNorm'ed residual (attention.py:127, 168, 226-227) ----
         f32x16 acc, accx;
         zero16(acc); zero16(accx);
-        gemm_run<MODE, BF, S3, NR, U_G1, 12>(R, wp, r1h + browA, CH_APL, acc, accx);
+        gemm_run<MODE, BF, SC, NR, U_G1, 12>(R, wp, r1h + browA, CH_APL, acc, accx);
         clk_stamp_c(clk, w, l, 2);
         float x1[16];
         merge16(x1, acc, accx);
@@ -565,7 +574,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             __syncthreads();
             clk_stamp_c(clk, w, l, 3);
             zero16(acc); zero16(accx);
-            gemm_run<MODE, BF, S3, NR, U_G2, 12>(R, wp, r2h + browA, CH_APL, acc, accx);
+            gemm_run<MODE, BF, SC, NR, U_G2, 12>(R, wp, r2h + browA, CH_APL, acc, accx);
             float q[16];
             merge16(q, acc, accx);
             {
@@ -639,7 +648,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             clk_stamp_c(clk, w, l, 5);
             // ---- to_out2 + x1 ----
             zero16(acc); zero16(accx);
-            gemm_run<MODE, BF, S3, NR, U_G3, 12>(R, wp, r1h + browA, CH_APL, acc, accx);
+            gemm_run<MODE, BF, SC, NR, U_G3, 12>(R, wp, r1h + browA, CH_APL, acc, accx);
             merge16(x2, acc, accx);
             float bo[16];
             get_vec(vec + 2 * 192, col0, bo);
@@ -673,7 +682,8 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         constexpr int QG = (MODE == 0) ? U_GE : (MODE == 1 ? U_G2 : 0);   // logical position of the wave's first GEGLU unit
         const float* bff = reinterpret_cast<const float*>(smem + CV::BFF);
         float pv[16], pg[16];   // the previous pair's value and gate sums
-        const int gp0 = S3 ? 8 * slice : 0;   // S3: this workgroup's pairs are the hidden tiles 8 slice .. 8 slice + 7; its product plane holds them at columns 0 .. 255
+        const int gp0 = (24 / NSL) * slice;   // sliced: this workgroup's pairs are the hidden tiles gp0 .. gp0 + 24 / NS - 1; its product plane holds them from column 0
+        auto lpair = [&](int pi) { return w + U::LSTEP * pi + U::L0; };   // local pair (= column tile of the product plane) of this wave's pair pi
         auto epi_piece = [&](int p, int m) {   // channels 32 p + 4 lh + 8 m .. + 3 of the token: bias, gelu, product, split, 8 bytes per plane
             const f32x4 bv = *reinterpret_cast<const f32x4*>(bff + 32 * (gp0 + p) + 4 * lh + 8 * m), bg = *reinterpret_cast<const f32x4*>(bff + 768 + 32 * (gp0 + p) + 4 * lh + 8 * m);
             float hv[4];
@@ -696,21 +706,21 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             constexpr int pi = decltype(pc)::value;
             f32x16 av, avx, ag, agx;
             zero16(av); zero16(avx); zero16(ag); zero16(agx);
-            geglu_run<MODE, BF, S3, NR, QG + 24 * pi>(R, wp, r1h + browA, CH_APL, av, avx, ag, agx, [&](auto sc) {
+            geglu_run<MODE, BF, SC, NR, QG + 24 * pi>(R, wp, r1h + browA, CH_APL, av, avx, ag, agx, [&](auto sc) {
                 constexpr int s = decltype(sc)::value;
-                if constexpr (!BF && pi > 0 && s % 3 == 1) epi_piece(w + 8 * (pi - 1), s / 3);
+                if constexpr (!BF && pi > 0 && s % 3 == 1) epi_piece(lpair(pi - 1), s / 3);
             });
             clk_stamp_c(clk, w, l, 11 + 2 * pi);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { pv[r] = fmaf(avx[r], 0x1p-11f, av[r]); pg[r] = fmaf(agx[r], 0x1p-11f, ag[r]); }
             if constexpr (BF) {   // two workgroups share the CU: the other one's stream runs under this epilogue, and the 32 registers of a carried pair buy ring depth instead
 #pragma unroll
-                for (int m = 0; m < 4; ++m) epi_piece(w + 8 * pi, m);
+                for (int m = 0; m < 4; ++m) epi_piece(lpair(pi), m);
             }
         });
         if constexpr (!BF) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) epi_piece(w + 8 * (U::NPAIR - 1), m);
+            for (int m = 0; m < 4; ++m) epi_piece(lpair(U::NPAIR - 1), m);
         }
     }
     f32x4 bpv[4];   // BF: bffp of this lane's 16 channels, from memory (global layout of ChainArgs::vec: b1, bq, bo2, c2, bffp, bff)
@@ -725,8 +735,8 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         constexpr int QH = U_FF - U_GE;
         f32x16 acc, accx;
         zero16(acc); zero16(accx);
-        gemm_run<MODE, BF, S3, NR, QH, U::FFH - U_HALF>(R, wp, hh + browH + 32 * U_HALF, CH_HPL, acc, accx);
-        gemm_run<MODE, BF, S3, NR, QH + U::FFH - U_HALF, U::FFS - U::FFH>(R, wp, r2h + browA + (S3 ? 128 * slice : 0), CH_APL, acc, accx);   // (S3: x2's k16 steps 4 slice .. + 3)
+        gemm_run<MODE, BF, SC, NR, QH, U::FFH - U_HALF>(R, wp, hh + browH + 32 * U_HALF, CH_HPL, acc, accx);
+        gemm_run<MODE, BF, SC, NR, QH + U::FFH - U_HALF, U::FFS - U::FFH>(R, wp, r2h + browA + 32 * (12 / NSL) * slice, CH_APL, acc, accx);   // (sliced: x2's k16 steps (12 / NS) slice ..)
         float* const fpart = reinterpret_cast<float*>(r1h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) fpart[((w - 6) * 16 + r) * 64 + l] = fmaf(accx[r], 0x1p-11f, acc[r]);
@@ -755,12 +765,12 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         float y[16], bp[16];
         float* const fpart = reinterpret_cast<float*>(r1h);   // [2 helper waves][16][64]: their partial sums of column tiles 4, 5 (the LayerNorm3 planes are dead)
         if (w < 4) {
-            gemm_run<MODE, BF, S3, NR, QF, U::FFH>(R, wp, hh + browH, CH_HPL, acc, accx);
-            gemm_run<MODE, BF, S3, NR, QF + U::FFH, U::FFS - U::FFH>(R, wp, r2h + browA + (S3 ? 128 * slice : 0), CH_APL, acc, accx);
+            gemm_run<MODE, BF, SC, NR, QF, U::FFH>(R, wp, hh + browH, CH_HPL, acc, accx);
+            gemm_run<MODE, BF, SC, NR, QF + U::FFH, U::FFS - U::FFH>(R, wp, r2h + browA + 32 * (12 / NSL) * slice, CH_APL, acc, accx);
             merge16(y, acc, accx);
             __syncthreads();
         } else {
-            gemm_run<MODE, BF, S3, NR, QF, U_HALF>(R, wp, hh + browH, CH_HPL, acc, accx);
+            gemm_run<MODE, BF, SC, NR, QF, U_HALF>(R, wp, hh + browH, CH_HPL, acc, accx);
             merge16(y, acc, accx);
             __syncthreads();
 #pragma unroll
@@ -768,11 +778,11 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         }
         clk_stamp_c(clk, w, l, 9);
         if constexpr (S3) {
-            // The three slices' partial sums of this (token tile, column tile) meet in memory, per WAVE: each stores its 32 x 32 partial (agent-scope stores: written
-            // through the XCD's L2 — the three workgroups run on different XCDs), waits for the stores, and takes a ticket; the wave that draws the last one reads all three
-            // back and sums them in slice order (bit-reproducible whoever arrives last), then finishes the tile as the one-workgroup kernel does.  No barrier, no fence: the
-            // partial buffer and the ticket are only ever touched by agent-scope accesses.
-            float* const P = a.part + (((long long)s_idx * a.np + (t0 >> 5)) * 3) * (6 * 16 * 64);
+            // The slices' partial sums of this (token tile, column tile) meet in memory, per WAVE: each stores its 32 x 32 partial (agent-scope stores: written
+            // through the XCD's L2 — the workgroups of a tile run on different XCDs), waits for the stores, and takes a ticket; the wave that draws the last one reads all
+            // of them back and sums them in slice order (bit-reproducible whoever arrives last), then finishes the tile as the one-workgroup kernel does.  No barrier, no
+            // fence: the partial buffer and the ticket are only ever touched by agent-scope accesses.
+            float* const P = a.part + (((long long)s_idx * a.np + (t0 >> 5)) * NSL) * (6 * 16 * 64);
             int* const tk = a.ticket + ((long long)s_idx * a.np + (t0 >> 5)) * 6 + j;
 #pragma unroll
             for (int r = 0; r < 16; ++r) __hip_atomic_store(P + ((slice * 6 + j) * 16 + r) * 64 + l, y[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -780,18 +790,21 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             int old = 0;
             if (l == 0) old = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             old = __builtin_amdgcn_readfirstlane(old);
-            if (old != 2) return;
+            if (old != NSL - 1) return;
             if (l == 0) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (kernel boundaries order it)
             asm volatile("" ::: "memory");
-            float p0[16], p1[16], p2[16];
+            float ps[NSL][16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int c = 0; c < NSL; ++c) ps[c][r] = __hip_atomic_load(P + ((c * 6 + j) * 16 + r) * 64 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                p0[r] = __hip_atomic_load(P + ((0 * 6 + j) * 16 + r) * 64 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                p1[r] = __hip_atomic_load(P + ((1 * 6 + j) * 16 + r) * 64 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                p2[r] = __hip_atomic_load(P + ((2 * 6 + j) * 16 + r) * 64 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+                float acc3 = ps[0][r];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) y[r] = (p0[r] + p1[r]) + p2[r];
+                for (int c = 1; c < NSL; ++c) acc3 += ps[c][r];
+                y[r] = acc3;
+            }
         }
         if constexpr (BF) {
 #pragma unroll
@@ -842,7 +855,8 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
     clk_stamp_c(clk, w, l, 10);
 }
 
-template <bool BF, bool S3>
+// NS: slices (workgroups per token tile): 1, or 2 / 3 for small launches of fp32 mode (CU<> above)
+template <bool BF, int NS>
 __global__ __launch_bounds__(512, BF ? 4 : 1) void stchain_kernel(const float* h_w, const float* h_o, const float* h_x, const int* h_lo, int h_T, int h_pitch, int h_obs, int h_xbs, int h_inmod,
                                                          int h_nunc_wmax, const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char csmem[];
@@ -856,13 +870,18 @@ __global__ __launch_bounds__(512, BF ? 4 : 1) void stchain_kernel(const float* h
     //  workgroups — was measured slower at every setting: profiles/r05i_stchain_xcds_ab.txt; and the sample count it read from the kernel arguments in
     //  memory cost every launch a scalar-memory round trip before its first request: 29.9 -> 31.4 us.  The grid is (token tiles, samples[, slices]).)
     const int s_idx = blockIdx.y, t0 = blockIdx.x * 32;
-    const int slice = S3 ? (int)blockIdx.z : 0;
+    const int slice = NS > 1 ? (int)blockIdx.z : 0;
     const bool uncond = s_idx < hd.n_uncond;
     const int in_idx = hd.in_mod > 0 ? s_idx % hd.in_mod : s_idx;
-    // three self-contained roles (each with its own prologue: nothing but scalars is live across this branch, so each gets its own register allocation)
-    if (w >= 6) chain_body<2, BF, S3>(hd, a, csmem, w, l, s_idx, in_idx, t0, slice);
-    else if (uncond) chain_body<1, BF, S3>(hd, a, csmem, w, l, s_idx, in_idx, t0, slice);
-    else chain_body<0, BF, S3>(hd, a, csmem, w, l, s_idx, in_idx, t0, slice);
+    // self-contained roles (each with its own prologue: nothing but scalars is live across this branch, so each gets its own register allocation); two slices:
+    // waves 0-3 and 4-7 also differ in their streams' layout (CU<>: WC)
+    constexpr int SC0 = 2 * NS, SC1 = NS == 2 ? 2 * NS + 1 : 2 * NS;
+    if (w >= 6) chain_body<2, BF, SC1>(hd, a, csmem, w, l, s_idx, in_idx, t0, slice);
+    else if (NS == 2 && w >= 4) {
+        if (uncond) chain_body<1, BF, SC1>(hd, a, csmem, w, l, s_idx, in_idx, t0, slice);
+        else chain_body<0, BF, SC1>(hd, a, csmem, w, l, s_idx, in_idx, t0, slice);
+    } else if (uncond) chain_body<1, BF, SC0>(hd, a, csmem, w, l, s_idx, in_idx, t0, slice);
+    else chain_body<0, BF, SC0>(hd, a, csmem, w, l, s_idx, in_idx, t0, slice);
 }
 
 bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long long x_bs) {
@@ -876,16 +895,18 @@ bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long
 void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s, bool bf16) {
     if (!stchain_supports(a, T, pitch, o_bs, x_bs)) { launch_fault("stchain: unsupported arguments (T %d, window %d)", T, a.wmax); return; }
     dim3 grid((T + 31) / 32, nsamp);
-    if (bf16) hipLaunchKernelGGL((stchain_kernel<true, false>), grid, dim3(512), Carve<true>::LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
-    else if (a.slices == 3) {
-        if (!a.part || !a.ticket) { launch_fault("stchain: three slices need the partial-sum buffer and the tickets"); return; }
-        hipLaunchKernelGGL((stchain_kernel<false, true>), dim3(grid.x, grid.y, 3), dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
-    } else hipLaunchKernelGGL((stchain_kernel<false, false>), grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+    if (bf16) hipLaunchKernelGGL((stchain_kernel<true, 1>), grid, dim3(512), Carve<true>::LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+    else if (a.slices == 3 || a.slices == 2) {
+        if (!a.part || !a.ticket) { launch_fault("stchain: a sliced launch needs the partial-sum buffer and the tickets"); return; }
+        if (a.slices == 3) hipLaunchKernelGGL((stchain_kernel<false, 3>), dim3(grid.x, grid.y, 3), dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+        else hipLaunchKernelGGL((stchain_kernel<false, 2>), dim3(grid.x, grid.y, 2), dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
+    } else hipLaunchKernelGGL((stchain_kernel<false, 1>), grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
 }
 void configure_stchain_kernel() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Carve<true>::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stchain_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Carve<true>::LDS);
 }
 
 }  // namespace said

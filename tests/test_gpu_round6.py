@@ -292,32 +292,38 @@ def test_trained_like_guided_steps_split_vs_strict(dev):
         assert d <= bound
 
 
-# ---------------------------------------------------------------- the fused tail as three workgroups per token tile (stchain.hip S3)
-@pytest.mark.parametrize("B,T", [(2, 600), (1, 37), (3, 333), (4, 600), (1, 1800)])
-def test_three_slice_tail_matches_one_workgroup_per_tile_and_is_bit_reproducible(dev, B, T):
-    """Small launches run the fused SpatialTransformer tail as three workgroups per token tile, each with a third of the GEGLU / folded proj_out weights; the
-    partial sums meet in memory and are added in slice order by whichever wave arrives last.  Against the one-workgroup kernel (said_debug_option
-    "st_chain_slices" = 1): only the folded proj_out's K is summed in three pieces instead of one (<= 1e-6 of range); repeated runs are bit-identical
-    (the arrival order must not show); launches above 85 (sample, tile) pairs keep one workgroup per tile ((4, 600): 76 tiles use it, (1, 1800): 57)."""
+# ---------------------------------------------------------------- the fused tail as two / three workgroups per token tile (stchain.hip CU<>)
+@pytest.mark.parametrize("B,T,slices", [(2, 600, 3), (1, 37, 3), (3, 333, 3), (4, 600, 3), (2, 1800, 2), (5, 600, 2), (8, 600, 1)])
+def test_sliced_tail_matches_one_workgroup_per_tile_and_is_bit_reproducible(dev, B, T, slices):
+    """Small launches run the fused SpatialTransformer tail as three (<= 85 (sample, tile) pairs) or two (<= 128) workgroups per token tile, each with a third / half
+    of the GEGLU / folded proj_out weights; the partial sums meet in memory and are added in slice order by whichever wave arrives last.  Against the one-workgroup
+    kernel (said_debug_option "st_chain_slices" = 1): only the folded proj_out's K is summed in pieces (<= 1e-6 of range); repeated runs are bit-identical (the
+    arrival order must not show); larger launches keep one workgroup per tile.  Where three slices run, two are checked as well (option value 2)."""
     sd = _base_sd()
     m = _make(sd, dev)
     x, ts, c = _inputs(B, T, seed=21)
     eng = m._get_engine(max(B, 2), max(T, 64))
     n0 = eng.debug_get("n_stchain")
-    y3 = [_fwd(m, dev, x, ts, c) for _ in range(4)]
+    ys = [_fwd(m, dev, x, ts, c) for _ in range(4)]
     assert eng.debug_get("n_stchain") - n0 == 16
     for k in range(1, 4):
-        assert torch.equal(y3[0], y3[k]), f"run {k} differs: {float((y3[0] - y3[k]).abs().max()):.3e}"
-    eng.debug_option("st_chain_slices", 1)
-    try:
-        y1 = _fwd(m, dev, x, ts, c)
-    finally:
-        eng.debug_option("st_chain_slices", -1)
+        assert torch.equal(ys[0], ys[k]), f"run {k} differs: {float((ys[0] - ys[k]).abs().max()):.3e}"
+    variants = {}
+    for opt in ((1, 2) if slices == 3 else (1,)):
+        eng.debug_option("st_chain_slices", opt)
+        try:
+            variants[opt] = _fwd(m, dev, x, ts, c)
+        finally:
+            eng.debug_option("st_chain_slices", -1)
+    y1 = variants[1]
     ref = _oracle(sd, x, ts, c)
-    e31, e3, e1 = _rel(y3[0], y1), _rel(y3[0], ref), _rel(y1, ref)
-    print(f"B={B} T={T}: three slices vs one workgroup {e31:.2e}; vs oracle {e3:.2e} / {e1:.2e} (of range)")
-    assert e31 <= 1e-6 and e3 <= 1e-4 and e1 <= 1e-4
-    assert (e31 > 0) == (B * ((T + 31) // 32) <= 85), "three slices exactly where the launch is at most 85 tiles"
+    e_s1, e_s, e_1 = _rel(ys[0], y1), _rel(ys[0], ref), _rel(y1, ref)
+    print(f"B={B} T={T}: {slices} slice(s) vs one workgroup {e_s1:.2e}; vs oracle {e_s:.2e} / {e_1:.2e} (of range)" +
+          (f"; forced two slices vs one {_rel(variants[2], y1):.2e}" if 2 in variants else ""))
+    assert e_s1 <= 1e-6 and e_s <= 1e-4 and e_1 <= 1e-4
+    assert (e_s1 > 0) == (slices > 1), "sliced exactly where the launch is at most 128 tiles"
+    if 2 in variants:
+        assert 0 < _rel(variants[2], y1) <= 1e-6 and not torch.equal(variants[2], ys[0])
 
 
 def test_three_slice_tail_in_the_guided_loop_is_bit_reproducible(dev):
