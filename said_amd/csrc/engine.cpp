@@ -53,10 +53,12 @@ struct PW {  // packed GEMM weight (up to 2 K-segments) + bias
 };
 struct ResW { float *g1, *b1, *g2, *b2; PW conv1, conv2, skip; int cin; bool has_skip; float* bias2;
               void *t_conv1 = nullptr, *t_conv2 = nullptr; /* bf16 [192][taps * cin] (conv2: [576 | 384 skip]) for tgemm.hip */
-              void *tf_conv1 = nullptr, *tf_conv2 = nullptr; /* the same matrices in fp32 (fgemm_kernel) */ };
+              void *tf_conv1 = nullptr, *tf_conv2 = nullptr; /* the same matrices in fp32 (fgemm_kernel) */
+              void *tp_conv1 = nullptr, *tp_conv2 = nullptr; /* ... and as packed split-fp16 pairs (h | l << 16 per element: fgemm_kernel's packed mode, round 6) */ };
 struct STW { float *gn_g, *gn_b, *l1g, *l1b, *l2g, *l2b, *l3g, *l3b; PW qkv, out1, q2, out2, ff1, ff2, proj, ffproj;
              void *t_qkv = nullptr, *t_ff1 = nullptr, *t_ffproj = nullptr; float* t_ff1_bias = nullptr; /* bf16 weights for tgemm.hip */
              void *tf_qkv = nullptr, *tf_ff1 = nullptr, *tf_ffproj = nullptr; /* fp32 copies (fgemm_kernel) */
+             void* tp_qkv = nullptr; /* q/k/v rows as packed split-fp16 pairs (fgemm_kernel's packed mode) */
              void *t_out1 = nullptr, *t_q2 = nullptr, *t_out2 = nullptr, *tf_out1 = nullptr, *tf_q2 = nullptr, *tf_out2 = nullptr; /* [192][192] (xgemm_kernel) */
              float *chain_w = nullptr, *chain_vec = nullptr; /* round 5: weight stream + vectors of the fused tail (stchain.hip) */
              float* chain_w3 = nullptr; /* round 6: the three-slice stream (small launches: three workgroups per token tile) */
@@ -191,6 +193,8 @@ struct said_ctx {
                               // as close to a float64 evaluation as the fp32 MFMAs: tests/test_gpu_round4.py).  Default (-1) and 1: ON since round 5; 0: v_mfma_f32_32x32x2_f32
                               // on the fp32 operands (said_debug_option "attn_split").  Round 4 shipped it opt-in because runs beside other streams were not bit-stable;
                               // round 5 found the mechanism in OTHER kernels' packed-fp32 instructions (split_f16.h, build.py NO_SLP) and removed it.
+    int gemm_presplit = -1;   // fp32 mode, large batches: the ResBlock convolutions' and q / k / v's operands reach fgemm_kernel already split (prep_kernel packs the activations,
+                              // the weights have a packed copy): -1 / 1 on; 0: fp32 operands split in the k loop (said_debug_option "gemm_presplit"; bit-identical)
     int gemm_split = -1;      // fp32 mode: the large-batch token-major GEMMs (fgemm_kernel) on split-fp16 operands (tgemm.hip: SP).  Default (-1) and 1: ON since round 5
                               // (as above); 0: fp32 MFMAs (said_debug_option "gemm_split").
     int attn_presplit = -1;   // fp32 small batch: the q/k/v GEMM stores k and v as packed split-fp16 pairs and attn_kernel<PM = 3> unpacks them instead of splitting all of K and V
@@ -461,7 +465,9 @@ int upload_bf16(said_ctx* ctx, void** out, const float* W, size_t N, size_t C, s
     return 0;
 }
 // the same matrix in bf16 AND fp32 (UNet operands of the token-major GEMMs: the precision mode is chosen per call)
-int upload_tm_pair(said_ctx* ctx, void** out_bf, void** out_f32, const float* W, size_t N, size_t C, size_t taps) {
+// out_packed (optional): a third copy whose elements are split-fp16 pairs, one dword h | l << 16 each (split_f16.h pack_split_f16: the same two conversions) —
+// fgemm_kernel's packed mode unpacks them with v_perm instead of splitting fp32 weights in its k loop
+int upload_tm_pair(said_ctx* ctx, void** out_bf, void** out_f32, const float* W, size_t N, size_t C, size_t taps, void** out_packed = nullptr) {
     if (upload_bf16(ctx, out_bf, W, N, C, taps)) return -1;
     std::vector<float> h(N * C * taps);
     for (size_t n = 0; n < N; ++n)
@@ -470,6 +476,21 @@ int upload_tm_pair(said_ctx* ctx, void** out_bf, void** out_f32, const float* W,
     float* d = nullptr;
     if (upload(ctx, &d, h.data(), h.size())) return -1;
     *out_f32 = d;
+    if (out_packed) {
+        std::vector<float> pk(h.size());
+        for (size_t i = 0; i < h.size(); ++i) {
+            const float v = h[i];
+            const _Float16 hv = (_Float16)v;
+            const _Float16 lv = (_Float16)((v - (float)hv) * 2048.f);
+            uint16_t hb, lb;
+            memcpy(&hb, &hv, 2); memcpy(&lb, &lv, 2);
+            const uint32_t u = (uint32_t)hb | ((uint32_t)lb << 16);
+            memcpy(&pk[i], &u, 4);
+        }
+        float* dp = nullptr;
+        if (upload(ctx, &dp, pk.data(), pk.size())) return -1;
+        *out_packed = dp;
+    }
     return 0;
 }
 std::vector<int> rows_dense(int N, int row0 = 0) {
@@ -702,6 +723,7 @@ void do_prep(said_ctx* c, const PrepArgs& a, int batch, hipStream_t s) {
     if (c->log_on) c->stage_log.push_back({5, -2, 0, 0, (double)batch * a.C * a.T * (4.0 + (c->bf16_mode ? 2.0 : 4.0)) * (a.dst2 ? 1.5 : 1.0), 0.0});
     PrepArgs a2 = a;
     a2.f32 = c->bf16_mode ? 0 : 1;
+    if (!a2.f32) a2.pack = 0;
     if (dbg_go(c) && !launch_prep(a2, batch, s)) c->launch_err = "operand preparation kernel: unsupported shape";
 }
 void do_tgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
@@ -716,6 +738,7 @@ void do_tgemm(said_ctx* c, const TGemmArgs& a, int batch, hipStream_t s) {
     a2.f32 = c->bf16_mode ? 0 : 1;
     if (a2.f32 && a2.yb) { a2.yf = reinterpret_cast<float*>(a2.yb); a2.yb = nullptr; }   // token-major intermediate (GEGLU product) in fp32
     a2.f32_split = (a2.f32 && sp_on(c, c->gemm_split)) ? 1 : 0;
+    if (!a2.f32_split) a2.f32_packed = 0;
     if (dbg_go(c) && !launch_tgemm(a2, batch, s)) {
         char b[160]; snprintf(b, sizeof b, "token-major GEMM: shape M=%d N=%d K=%d (batch %d) is not served by any kernel", a.M, a.N, a.K, batch);
         c->launch_err = b;
@@ -1111,18 +1134,23 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
     const long long tt = (long long)nb * ((g.T + 31) / 32);
     if (use_tg(c, g, nb)) {
         const long long T2 = tg_rows(g);
+        // fp32 mode: the operands reach fgemm_kernel already split (packed h | l pairs: prep_kernel's pack mode + the packed weight copies)
+        const int pk = (!c->bf16_mode && sp_on(c, c->gemm_split) && c->gemm_presplit != 0 && rw.tp_conv1 && rw.tp_conv2) ? 1 : 0;
         {   // in_layers: GN -> SiLU -> conv3 + emb term   (openaimodel.py:205-225)
             PrepArgs p = mkprep(g, in0.p, 0, c->uPA, T2 * rw.cin, rw.cin, 0);
+            p.pack = pk;
             prep_gn(c, p, g, in0.st, cpg, 1e-5f, rw.g1, rw.b1, nb, 0, s);
             if (rw.has_skip) { p.dst2 = c->uPB; p.dst2_bs = T2 * 2 * MC; p.ldd2 = 2 * MC; p.coff2 = 0; }   // raw copy for the 1x1 skip conv
             do_prep(c, p, nb, s);
             if (in1) {
                 PrepArgs q = mkprep(g, in1->p, 0, c->uPA, T2 * rw.cin, rw.cin, MC);
+                q.pack = pk;
                 prep_gn(c, q, g, in1->st, cpg, 1e-5f, rw.g1 + MC, rw.b1 + MC, nb, 1, s);
                 if (rw.has_skip) { q.dst2 = c->uPB; q.dst2_bs = T2 * 2 * MC; q.ldd2 = 2 * MC; q.coff2 = MC; }
                 do_prep(c, q, nb, s);
             }
-            TGemmArgs t = mktg(g, c->uPA, rw.cin, tw(c, rw.t_conv1, rw.tf_conv1), MC, 3 * rw.cin);
+            TGemmArgs t = mktg(g, c->uPA, rw.cin, pk ? rw.tp_conv1 : tw(c, rw.t_conv1, rw.tf_conv1), MC, 3 * rw.cin);
+            t.f32_packed = pk;
             t.bias = rw.conv1.bias;
             t.emb = c->EO + (long long)rb_index * MC * c->maxNp; t.emb_pitch = c->maxNp; t.step_ptr = g.step_ptr; t.emb_b_stride = g.emb_b_stride;
             tg_cm_out(t, g, c->M);
@@ -1130,9 +1158,11 @@ void run_resblock(said_ctx* c, const UGeo& g, const ResW& rw, int rb_index, cons
         }
         {   // out_layers: GN -> SiLU -> conv3 ; + skip(x)   (openaimodel.py:226-227)
             PrepArgs p = mkprep(g, c->M.p, 0, c->uPA, T2 * MC, MC, 0);
+            p.pack = pk;
             prep_gn(c, p, g, c->M.st, 6, 1e-5f, rw.g2, rw.b2, nb, 0, s);
             do_prep(c, p, nb, s);
-            TGemmArgs t = mktg(g, c->uPA, MC, tw(c, rw.t_conv2, rw.tf_conv2), MC, 3 * MC);
+            TGemmArgs t = mktg(g, c->uPA, MC, pk ? rw.tp_conv2 : tw(c, rw.t_conv2, rw.tf_conv2), MC, 3 * MC);
+            t.f32_packed = pk;
             if (rw.has_skip) {   // 1x1 conv over the concatenated raw input as a second K segment
                 // (the raw copies of the two inputs were written into uPB by the in_layers operand preparation above)
                 t.a2 = c->uPB; t.a2_bs = 0; t.lda2 = 2 * MC; t.K1 = 3 * MC; t.K = 5 * MC;
@@ -1214,12 +1244,15 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     const bool out1_tm = tg && !chain && !c->bf16_mode && c->f32_out1_tm && tt1 * HEADS >= 2048 && sw.tf_out1;
     bool presplit = false;   // k and v stored as packed split-fp16 pairs for attn_kernel<PM = 3> (see below)
     if (tg) {   // q, k, v on the bf16 token-major GEMM: operand = LayerNorm(GroupNorm(x)) prepared once
+        const int pk = (!c->bf16_mode && sp_on(c, c->gemm_split) && c->gemm_presplit != 0 && sw.tp_qkv) ? 1 : 0;   // operands arrive split (see run_resblock)
         PrepArgs p = mkprep(g, in.p, 1, c->uPL, (long long)tg_rows(g) * MC, MC, 0);
+        p.pack = pk;
         prep_gn(c, p, g, in.st, 6, 1e-6f, sw.gn_g, sw.gn_b, n1, 0, s);
         p.ln_gamma = sw.l1g; p.ln_beta = sw.l1b;
         if (out1_tm && p.part) { p.coef_out = c->gn_coef; p.coef_out_bs = 2 * MC; }
         do_prep(c, p, n1, s);
-        TGemmArgs t = mktg(g, c->uPL, MC, tw(c, sw.t_qkv, sw.tf_qkv), 3 * MC, MC);
+        TGemmArgs t = mktg(g, c->uPL, MC, pk ? sw.tp_qkv : tw(c, sw.t_qkv, sw.tf_qkv), 3 * MC, MC);
+        t.f32_packed = pk;
         t.qk = c->QK; t.vt = c->VT; t.v_bs = (long long)MC * g.Tp; t.qk_n = 2 * MC; t.head_dim = HD; t.rows = vt_rows; t.heads2 = 2 * HEADS; t.v_pitch = g.Tp;
         do_tgemm(c, t, n1, s);
     } else
@@ -2116,7 +2149,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
         if (upvec(ctx, &rw.g2, p + ".out_layers.0.weight", MC) || upvec(ctx, &rw.b2, p + ".out_layers.0.bias", MC)) return -1;
         if (make_pw(ctx, &rw.conv2, p + ".out_layers.3.weight", p + ".out_layers.3.bias", MC, MC, 3, 1, p + ".out_layers.0.weight", p + ".out_layers.0.bias")) return -1;
         {   // tgemm.hip operands: conv1 [192][3 * cin] tap-major; conv2 [192][576 (+ 384 skip columns)]
-            if (upload_tm_pair(ctx, &rw.t_conv1, &rw.tf_conv1, ctx->host_w[p + ".in_layers.2.weight"].data.data(), MC, (size_t)rw.cin, 3)) return -1;
+            if (upload_tm_pair(ctx, &rw.t_conv1, &rw.tf_conv1, ctx->host_w[p + ".in_layers.2.weight"].data.data(), MC, (size_t)rw.cin, 3, &rw.tp_conv1)) return -1;
             const HostTensor& c2w = ctx->host_w[p + ".out_layers.3.weight"];
             std::vector<float> cat((size_t)MC * (3 * MC + (rw.has_skip ? 2 * MC : 0)));
             const size_t Kc = 3 * MC + (rw.has_skip ? 2 * MC : 0);
@@ -2127,7 +2160,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
                     for (int cc = 0; cc < MC; ++cc) cat[n * Kc + t * MC + cc] = c2w.data[((size_t)n * MC + cc) * 3 + t];
                 if (sk) for (int cc = 0; cc < 2 * MC; ++cc) cat[n * Kc + 3 * MC + cc] = sk->data[(size_t)n * 2 * MC + cc];
             }
-            if (upload_tm_pair(ctx, &rw.t_conv2, &rw.tf_conv2, cat.data(), MC, Kc, 1)) return -1;
+            if (upload_tm_pair(ctx, &rw.t_conv2, &rw.tf_conv2, cat.data(), MC, Kc, 1, &rw.tp_conv2)) return -1;
         }
         const HostTensor* ew = getw(ctx, p + ".emb_layers.1.weight", {MC, TE});
         const HostTensor* eb = getw(ctx, p + ".emb_layers.1.bias", {MC});
@@ -2246,7 +2279,7 @@ int said_finalize_weights(said_ctx* ctx, void* stream) {
             PW t0, t1;
             if (make_pw(ctx, &t0, "__ffproj.w0", "__ffproj.b", MC, FFI, 0) || make_pw(ctx, &t1, "__ffproj.w1", "", MC, MC, 0)) return -1;
             {   // tgemm.hip operands of this block: q/k/v rows, GEGLU rows tile-interleaved (value, gate), [P F2 | P]
-                if (upload_tm_pair(ctx, &sw.t_qkv, &sw.tf_qkv, qkv.data(), 3 * MC, MC, 1)) return -1;
+                if (upload_tm_pair(ctx, &sw.t_qkv, &sw.tf_qkv, qkv.data(), 3 * MC, MC, 1, &sw.tp_qkv)) return -1;
                 const HostTensor* f1 = getw(ctx, b + ".ff.net.0.proj.weight", {2 * FFI, MC});
                 const HostTensor* f1b = getw(ctx, b + ".ff.net.0.proj.bias", {2 * FFI});
                 if (!f1 || !f1b) return -1;
@@ -2733,6 +2766,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->tm_acts = value < 0 ? -1 : (value != 0);
     } else if (k == "rgemm") {
         ctx->rgemm = value < 0 ? -1 : (value != 0);
+    } else if (k == "gemm_presplit") {
+        ctx->gemm_presplit = value < 0 ? -1 : (value != 0);
     } else if (k == "gemm_split") {
         ctx->gemm_split = value < 0 ? -1 : (value != 0);
     } else if (k == "attn_split") {

@@ -34,6 +34,8 @@ extern "C" {
  *   "out_tm"                 0: bf16 large batches end the step with round 3's channel-major out conv + scheduler kernel (default -1: out_sched_tm_kernel)
  *   "rgemm"                  0: bf16 large batches without round 4's persistent register-stationary GEMMs (default -1: on)
  *   "battn"                  0: bf16 large batches with attn_kernel on fp32 operands instead of battn_kernel (default -1: on; 4 / 8: query tiles per workgroup)
+ *   "gemm_presplit"          fp32 mode, large batches: 0 = fgemm_kernel splits fp32 operands in its k loop (round 5); -1 / 1 (default): the ResBlock convolutions' and q / k / v's
+ *                            operands arrive split (prep_kernel packs h | l pairs, packed weight copies; bit-identical, round 6)
  *   "gemm_split"             fp32 mode, large batches: 0 puts fgemm_kernel back on v_mfma_f32_32x32x2_f32 (default -1 / 1: split-fp16 products)
  *   "attn_split"             fp32 mode: 0 puts both self-attention products back on fp32 MFMAs (default -1 / 1: split-fp16 products)
  *   "ugemm_split"            fp32 mode, channel-major GEMMs (ugemm_kernel): 0 = fp32 MFMAs (default -1 / 1: split-fp16 products, round 5)

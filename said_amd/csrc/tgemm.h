@@ -66,6 +66,8 @@ struct TGemmArgs {
     int n_store;           // token-major outputs: columns n >= n_store are not written (0: all N) — a column count padded to the tile
     int f32;               // 1: A and W are fp32 (fgemm_kernel on v_mfma_f32_32x32x2_f32; fp32 mode, large batches); K % 32 == 0
     int f32_split;         // f32 operands: run the products on split-fp16 operands (fgemm_kernel SP; split_f16.h) — fp32-equivalent results
+    int f32_packed;        // ... and A, A2 and W ARRIVE split: every element one dword h | l << 16 (split_f16.h pack_split_f16: prep_kernel PrepArgs::pack, engine.cpp
+                           // upload_tm_pair): the k loop unpacks with v_perm instead of splitting (round 6: the loop was VALU-bound on the splits); bit-identical results
     int dbg;               // timing experiments (SAID_TG_DBG): bit 0 = skip the epilogue, bit 1 = skip the K loop
     // ==== token-major ACTIVATION interface (round 3; xgemm_kernel only; large batches, both precisions) ====================
     // Between the UNet kernels the activations are token-major [sample][token][192] in the context's element type ET (bf16 in
@@ -133,6 +135,7 @@ struct PrepArgs {
     float* coef_out; long long coef_out_bs;      // != null: the first tile's workgroup of every sample also stores the finalised (a, b) [b][192][2]
     int mode;
     int f32;               // 1: dst / dst2 are fp32 (operands of the fp32 token-major GEMM), else bf16
+    int pack;              // f32 only: dst / dst2 elements are written as split-fp16 pairs (h | l << 16: split_f16.h pack_split_f16) for fgemm_kernel's packed mode
 };
 bool launch_prep(const PrepArgs& a, int batch, hipStream_t s);
 // GroupNorm coefficients of a 192-channel tensor from its Welford partials [b][192][nparts][2] -> coef_out[b][192][2]

@@ -329,6 +329,7 @@ __host__ __device__ constexpr int fgemm_lds_bytes() {
 // BF: the same workgroup on bf16 operands (bf16 mode's UNet GEMMs): a k-tile is again 128 bytes per row (64 halfs), each K half
 // two v_mfma_f32_32x32x16_bf16 per column tile.  There the point is not MFMA balance but spread: the 256-row bf16 tiles put a
 // 192-wide convolution on 152 workgroups of a 256-CU chip, and its time is the fp32 epilogue traffic (§7.3).
+constexpr int FGEMM_PK_LDS3 = 2 * (64 + 96) * 144 > fgemm_lds_bytes<3>() ? 2 * (64 + 96) * 144 : fgemm_lds_bytes<3>();   // packed mode: two operand buffers
 constexpr int fgemm_occ(int NJ, int PF, bool BF) { return NJ == 3 ? 4 : 3; }   // workgroups per CU the registers are budgeted for
 // SP (round 4, fp32 operands only): the products run on SPLIT-fp16 operands (split_f16.h: x = h + 2^-11 l, three v_mfma_f32_32x32x16_f16 per eight
 // v_mfma_f32_32x32x2_f32, fp32 accumulation, the cross terms in a second accumulator set).  The LDS tiles stay fp32 — staging, K halves, exchange and
@@ -336,9 +337,13 @@ constexpr int fgemm_occ(int NJ, int PF, bool BF) { return NJ == 3 ? 4 : 3; }   /
 // splits them in registers (A once, W once per column tile — ALL of a k-tile's operands in distinct registers: two workgroups per CU), then operand_fence(), then the
 // 3 NJ MFMAs, then a second fence.  A variant that split one column tile at a time (three workgroups per CU) — its conversions rewriting the operand registers of
 // MFMAs issued 16 idle slots earlier — was not bit-stable from one run to the next (profiles/r04i_attn_split_hazard.txt).
-template <int NJ, int PF, bool BF, int OCC = fgemm_occ(NJ, PF, BF), bool SP = false>
+// PK (round 6, SP only): the operands ARRIVE split — every element of A / A2 / W is one dword h | l << 16 (prep_kernel's pack mode, engine.cpp's packed weight copies) — and a
+// fragment is unpacked with eight v_perm_b32 instead of ~40 VALU instructions of conversion: with one k16 step (9 MFMAs of 8 passes) per k-tile and wave, the splits of A and of
+// three W fragments were 2.4 x the matrix time.  Same planes, same products: bit-identical to the in-kernel split.
+template <int NJ, int PF, bool BF, int OCC = fgemm_occ(NJ, PF, BF), bool SP = false, bool PK = false>
 __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
     static_assert(!(SP && BF), "the split mode reads fp32 operands");
+    static_assert(!PK || SP, "packed operands are split operands");
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // [A 64 rows | W BN rows] x 144 bytes
     float* const ldsf = reinterpret_cast<float*>(lds);
     typedef typename std::conditional<BF, unsigned short, float>::type elt_t;
@@ -389,11 +394,14 @@ __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
 #pragma unroll
         for (int i = 0; i < WCH; ++i) xw[i] = *reinterpret_cast<const f32x4t*>(W + (woff[i] + kt * FBK));
     };
-    auto lds_store = [&](const f32x4t* xa, const f32x4t* xw) {
+    // PK: TWO operand buffers in LDS — the next tile is parked in the other buffer before the one barrier of a k-step (the single-buffer loop pays two barriers per
+    // nine MFMAs of a wave); the other variants keep one buffer (their k loop is bound elsewhere, and their occupancy is budgeted on 23-28 KB)
+    constexpr int BUFE = PK ? (BM + BN) * FLP : 0;   // elements between the two buffers
+    auto lds_store = [&](const f32x4t* xa, const f32x4t* xw, int buf = 0) {
 #pragma unroll
-        for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4t*>(ldse + loff[i]) = xa[i];
+        for (int i = 0; i < ACH; ++i) *reinterpret_cast<f32x4t*>(ldse + buf * BUFE + loff[i]) = xa[i];
 #pragma unroll
-        for (int i = 0; i < WCH; ++i) *reinterpret_cast<f32x4t*>(ldse + lwoff[i]) = xw[i];
+        for (int i = 0; i < WCH; ++i) *reinterpret_cast<f32x4t*>(ldse + buf * BUFE + lwoff[i]) = xw[i];
     };
     f32x16 acc[NJ], accx[SP ? NJ : 1];
 #pragma unroll
@@ -410,12 +418,17 @@ __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
     // (split mode: floats 16 kh + 8 lh .. + 7 of the row)
     const float* const paS = ldsf + (wr * 32 + frow) * 36 + 16 * kh + 8 * (l >> 5);
     const float* const pwS = ldsf + BM * 36 + frow * 36 + 16 * kh + 8 * (l >> 5);
-    auto compute = [&]() {
+    auto compute = [&](int buf = 0) {
         if constexpr (SP) {
-            const SplitH sa = split_f16x8(*reinterpret_cast<const f32x4s*>(paS), *reinterpret_cast<const f32x4s*>(paS + 4));
+            const float* const pa2 = paS + buf * BUFE;
+            const float* const pw2 = pwS + buf * BUFE;
+            const SplitH sa = PK ? unpack_f16x8(*reinterpret_cast<const f32x4s*>(pa2), *reinterpret_cast<const f32x4s*>(pa2 + 4))
+                                 : split_f16x8(*reinterpret_cast<const f32x4s*>(pa2), *reinterpret_cast<const f32x4s*>(pa2 + 4));
             SplitH sb[NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) sb[j] = split_f16x8(*reinterpret_cast<const f32x4s*>(pwS + j * 32 * 36), *reinterpret_cast<const f32x4s*>(pwS + j * 32 * 36 + 4));
+            for (int j = 0; j < NJ; ++j)
+                sb[j] = PK ? unpack_f16x8(*reinterpret_cast<const f32x4s*>(pw2 + j * 32 * 36), *reinterpret_cast<const f32x4s*>(pw2 + j * 32 * 36 + 4))
+                           : split_f16x8(*reinterpret_cast<const f32x4s*>(pw2 + j * 32 * 36), *reinterpret_cast<const f32x4s*>(pw2 + j * 32 * 36 + 4));
             operand_fence();
             // two MFMAs on the same accumulator are NJ - 1 or more apart (never back to back: attn.hip)
 #pragma unroll
@@ -471,6 +484,18 @@ __global__ __launch_bounds__(256, OCC) void fgemm_kernel(const TGemmArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             lds_store(ra, rw);
+            __syncthreads();
+        }
+    } else if constexpr (PK) {
+        // tile kt multiplies from buffer kt & 1 while tile kt + 1 (in registers since the previous step) is parked in the other one — free since every wave passed the
+        // previous barrier behind its products on it — and tile kt + 2 is requested: ONE barrier per k-step
+        gload_tile(ra, rw, min(1, nk - 1));
+        for (int kt = 0; kt < nloop; ++kt) {
+            __builtin_amdgcn_sched_barrier(0);
+            compute(kt & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_store(ra, rw, (kt + 1) & 1);
+            gload_tile(ra, rw, min(kt + 2, nk - 1));
             __syncthreads();
         }
     } else {
@@ -1299,6 +1324,7 @@ void configure_tgemm_kernel() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<4, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<4>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 1, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 1, false, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FGEMM_PK_LDS3);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<4, 1, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<4>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fgemm_kernel<3, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fgemm_lds_bytes<3>());
@@ -1319,6 +1345,11 @@ bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
         const long long mt8 = ((rows_tot + 63) / 64 + 7) / 8 * 8;   // 64-row tiles, padded to the 8 XCDs
         constexpr int LDS3 = fgemm_lds_bytes<3>(), LDS4 = fgemm_lds_bytes<4>();
         if (a.f32_split) {   // products on split-fp16 operands (TGemmArgs::f32_split)
+            if (a.f32_packed) {   // ... which arrive split (NJ = 3 shapes: the ResBlock convolutions and q / k / v)
+                if (a.N % 96 || a.geglu) return false;
+                hipLaunchKernelGGL((fgemm_kernel<3, 1, false, 2, true, true>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), FGEMM_PK_LDS3, s, a2);
+                return true;
+            }
             if (a.N % 128 == 0 && (a.geglu || a.N % 96)) hipLaunchKernelGGL((fgemm_kernel<4, 1, false, 2, true>), dim3((unsigned)(mt8 * (a.N / 128))), dim3(256), LDS4, s, a2);
             else hipLaunchKernelGGL((fgemm_kernel<3, 1, false, 2, true>), dim3((unsigned)(mt8 * (a.N / 96))), dim3(256), LDS3, s, a2);
             return true;
@@ -1623,6 +1654,7 @@ __global__ __launch_bounds__(256, 5) void prep_kernel(const PrepArgs a) {   // f
                 if (ln) x = fmaf((x - mu) * rs, a.ln_gamma[c], a.ln_beta[c]);
                 o[k] = tv ? x : 0.f;
                 r[k] = raw;
+                if (a.pack) { o[k] = pack_split_f16(o[k]); r[k] = pack_split_f16(r[k]); }   // (0 packs to 0: the padding rows stay all-zero bits)
             }
             *reinterpret_cast<f32x4t*>(reinterpret_cast<float*>(a.dst) + (long long)b * a.dst_bs + (long long)(t + row_off) * a.ldd + a.coff + c0) = o;
             if (a.dst2 && tv)   // raw copy (1x1 skip conv over the ResBlock input; x2 for the folded proj_out)

@@ -1,0 +1,18 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r6t10
+timeout 900 python -m pytest tests/test_gpu_round6.py -m gpu -q -s -x -k "presplit" > gpurun_out/r6t10/tests.log 2>&1; echo "tests exit=$?"
+grep -E "passed|failed|pre-split|Error" gpurun_out/r6t10/tests.log | tail -8
+for rep in 1; do
+for v in 0 1; do
+  echo "== cfg3 (32 clips x 100 steps) gemm_presplit=$v" | tee -a gpurun_out/r6t10/ab.txt
+  timeout 900 python bench.py --batch 32 --num_steps 100 --steps 2 --warmup 1 --no_cpu_baseline --no_secondary --no_roofline --debug_option gemm_presplit=$v 2>&1 | tail -1 | cut -c1-200 | tee -a gpurun_out/r6t10/ab.txt
+done; done
+for v in 0 1; do
+  echo "== cfg3 one group gemm_presplit=$v" | tee -a gpurun_out/r6t10/ab.txt
+  timeout 900 python bench.py --batch 32 --num_steps 100 --steps 2 --warmup 1 --no_cpu_baseline --no_secondary --no_roofline --clip_groups 1 --debug_option gemm_presplit=$v 2>&1 | tail -1 | cut -c1-200 | tee -a gpurun_out/r6t10/ab.txt
+done
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/r6t10/tr -o cfg3 -- python bench.py --batch 32 --num_steps 50 --steps 1 --warmup 1 --no_cpu_baseline --no_roofline --no_secondary > gpurun_out/r6t10/run_trace.log 2>&1
+python scripts/prof_summary.py $(find gpurun_out/r6t10/tr -name "cfg3_results.db" | head -1) > gpurun_out/r6t10/trace_cfg3.txt 2>&1
+find gpurun_out/r6t10/tr -name "*.db" -delete
+head -12 gpurun_out/r6t10/trace_cfg3.txt

@@ -347,3 +347,28 @@ def test_three_slice_tail_in_the_guided_loop_is_bit_reproducible(dev):
     d = float((a - c1).abs().max())
     print(f"three slices vs one workgroup after 12 guided steps: {d:.2e} abs on [0, 1]")
     assert d <= 1e-4
+
+
+# ---------------------------------------------------------------- fp32 large batches: fgemm_kernel's operands arrive split
+def test_presplit_operands_of_the_large_batch_gemms_are_bit_identical(dev):
+    """fp32 mode from 10000 UNet rows per launch on: prep_kernel writes the ResBlock convolutions' and q / k / v's activations as packed split-fp16 pairs (h | l << 16) and the
+    weights have a packed copy, so fgemm_kernel<SP> unpacks with v_perm instead of converting in its k loop.  Same planes, same products: bit-identical to the in-kernel split
+    (said_debug_option "gemm_presplit" = 0), and the usual bound against the oracle.  B = 20: 12000 rows, two ragged lengths."""
+    sd = _base_sd()
+    m = _make(sd, dev)
+    for B, T in ((20, 600), (34, 333)):
+        x, ts, c = _inputs(B, T, seed=31)
+        eng = m._get_engine(B, max(T, 64))
+        assert eng.debug_get("gemm_split") == 1
+        y1 = _fwd(m, dev, x, ts, c)
+        eng.debug_option("gemm_presplit", 0)
+        try:
+            y0 = _fwd(m, dev, x, ts, c)
+        finally:
+            eng.debug_option("gemm_presplit", -1)
+        assert torch.equal(y0, y1), f"B={B} T={T}: {float((y0 - y1).abs().max()):.3e}"
+        for i in (0, B - 1):
+            ref = _oracle(sd, x[i:i + 1], ts[i:i + 1], c[i:i + 1])
+            e = _rel(y1[i:i + 1], ref)
+            print(f"pre-split operands B={B} T={T} sample {i}: {e:.2e} of range vs the oracle")
+            assert e <= 1e-4
