@@ -198,8 +198,8 @@ def trace_name_prefix(name, dtype):
     epi_no = {v: k for k, v in EPI_NAMES.items()}
     fam = name.split("<")[0].split(" ")[0]
     args = name[name.index("<") + 1:name.rindex(">")].split(",") if "<" in name else []
-    if fam == "stchain_kernel":
-        return "said::stchain_kernel<" + ("true" if dtype == "bf16" else "false") + ">"
+    if fam == "stchain_kernel":   # stchain_kernel<bf16, slices>: every slice count of the precision mode
+        return "said::stchain_kernel<" + ("true" if dtype == "bf16" else "false") + ","
     if fam == "attn_kernel" and len(args) == 2:
         return f"said::attn_kernel<{int(args[0][1:]) // 32}, {args[1][2:]},"
     if fam in ("ugemm_kernel", "cgemm_kernel") and len(args) == 3:
