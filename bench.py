@@ -466,7 +466,7 @@ def run_secondary(model, dev, gs):
         assert torch.isfinite(res).all()
         Be = 2 * B if gs > 1.0 else B
         step_ms = loop_step_ms(model, proc, lat0, edit_kw, T, c["num_steps"], gs, c["eta"])
-        rf = roofline(model, Be, T, step_ms, c["dtype"], cfg_clips=B if gs > 1.0 else 0, traffic_key="cfg1" if name == "cfg1_eta1" else "cfg1_strict" if name == "cfg1_strict_fp32" else ("cfg3_per_gpu_f32" if name.startswith("cfg3") else name),   # (eta = 1 runs the headline's kernels)
+        rf = roofline(model, Be, T, step_ms, c["dtype"], cfg_clips=B if gs > 1.0 else 0, traffic_key="cfg1" if name == "cfg1_eta1" else "cfg1_strict" if name == "cfg1_strict_fp32" else ("cfg3_per_gpu_f32" if name == "cfg3_per_gpu_f32" else name),   # (eta = 1 runs the headline's kernels)
                       groups=model._pick_clip_groups(B, Be // B * T))
         rf["audio_encode"] = audio_encode_block(model, proc, T, B, c["dtype"])
         rf.pop("by_kernel", None)      # the headline's roofline carries the per-kernel table; keep the line readable
