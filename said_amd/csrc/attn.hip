@@ -638,7 +638,7 @@ void configure_attn_kernels() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&battn_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     configure_attn_modes<0>(); configure_attn_modes<1>(); configure_attn_modes<2>();
-    configure_attn_one<1, 8, 3>(); configure_attn_one<1, 4, 3>();
+    configure_attn_one<1, 8, 3>(); configure_attn_one<1, 4, 3>(); configure_attn_one<1, 1, 3, 4>();
 }
 
 template <int PM>
@@ -655,11 +655,12 @@ static bool launch_attn_mode(const AttnArgs& a, int batch, int head_dim, int KS,
     if (head_dim == 64 && KS == 1) return launch_attn_one<2, 1, PM>(a, batch, s), true;
     return false;
 }
-// mode: 0 fp32 MFMA, 1 bf16 operands, 2 split-fp16 operands, 3 split-fp16 operands with K and V stored pre-split by the q/k/v GEMM (head_dim 32, key-split shapes only)
+// mode: 0 fp32 MFMA, 1 bf16 operands, 2 split-fp16 operands, 3 split-fp16 operands with K and V stored pre-split by the q/k/v GEMM (head_dim 32: key-split shapes and the four-query-tile shape)
 void launch_attn(const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s, int mode) {
     if (mode == 3) {
         if (head_dim == 32 && KS == 8) { launch_attn_one<1, 8, 3>(a, batch, s); return; }
         if (head_dim == 32 && KS == 4) { launch_attn_one<1, 4, 3>(a, batch, s); return; }
+        if (head_dim == 32 && KS == -4) { launch_attn_one<1, 1, 3, 4>(a, batch, s); return; }   // (round 6: large batches — the token-major q/k/v GEMM packs k and v too)
         launch_fault("pre-split attention operands: unsupported config D=%d KS=%d", head_dim, KS);
         return;
     }

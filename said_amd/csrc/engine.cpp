@@ -116,6 +116,8 @@ struct said_ctx {
     float *KV = nullptr, *CTX = nullptr;
     float* KVT = nullptr;        // key-major copy of KV [sample][S][NST * 2 * MC] for the fused SpatialTransformer tail (stchain.hip), made by run_kv
     bool band_chain_ok = false;  // the alignment band fits stchain's window tile (set_band)
+    int kvt_S = -1;              // key count of the key-major copy KVT as run_kv last made it (-1: not made — the fused tail then does not run: ADVICE r5)
+    int kvt_bf16 = 0;            // ... and its element type
     bool st_chain_large = true;  // ... at large batches too, beside the token-major q / k / v GEMM (32 clips: 3.2 -> 2.4 ms per step; said_debug_option "st_chain_large")
     long long st_chain_max_tiles = 1LL << 40;   // ... while the launch is at most this many workgroups (sample x 32-token tiles; said_debug_option "st_chain_max_tiles")
     int st_chain_bf16 = -1;      // bf16 mode, large batches: the same fused tail on bf16 operands instead of rgemm's five launches; 0: off; -1 / 1: stchain_kernel<true> (one token tile per
@@ -950,7 +952,7 @@ void run_transformer_tm(said_ctx* c, const UGeo& g, const STW& sw, int blk, cons
         }
     }
     // round 5: everything behind the attention as ONE launch on bf16 operands (stchain_kernel<true>; the token-major bf16 tensors are its operands as they are)
-    if (c->bf16_mode && c->st_chain_bf16 != 0 && !last && sw.chain_wb && sw.chain_vec && c->band_chain_ok && c->cur_b0 == 0 && g.S == c->band_S && g.T == c->band_T &&
+    if (c->bf16_mode && c->st_chain_bf16 != 0 && !last && sw.chain_wb && sw.chain_vec && c->band_chain_ok && c->kvt_S == g.S && c->kvt_bf16 && c->cur_b0 == 0 && g.S == c->band_S && g.T == c->band_T &&
         (long long)g.Be * seg * MC < 0x7fffffffLL) {
         ChainArgs ca;
         memset(&ca, 0, sizeof ca);
@@ -1239,7 +1241,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
     // operand buffer; the GroupNorm'ed residual uses the coefficients the q/k/v preparation finalised): 59 -> ~30 us per launch at Be = 64
     // fp32 mode: everything behind the self-attention as ONE launch (stchain.hip) — at small batches beside the channel-major GEMMs, at large ones (st_chain_large)
     // beside the token-major GEMMs' q / k / v (the attention kernel then writes channel-major, as the small-batch schedule has it)
-    const bool chain = !c->bf16_mode && sp_on(c, c->st_chain) && c->use_ugemm && sw.chain_w && sw.chain_vec && c->band_chain_ok && c->cur_b0 == 0 && !c->use_branches &&
+    const bool chain = !c->bf16_mode && sp_on(c, c->st_chain) && c->use_ugemm && sw.chain_w && sw.chain_vec && c->band_chain_ok && c->kvt_S == g.S && !c->kvt_bf16 && c->cur_b0 == 0 && !c->use_branches &&
                        ((!tg && !use_tg(c, g, g.Be)) || c->st_chain_large) && tt <= c->st_chain_max_tiles && g.S == c->band_S && g.T == c->band_T;
     const bool out1_tm = tg && !chain && !c->bf16_mode && c->f32_out1_tm && tt1 * HEADS >= 2048 && sw.tf_out1;
     bool presplit = false;   // k and v stored as packed split-fp16 pairs for attn_kernel<PM = 3> (see below)
@@ -1254,6 +1256,11 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         TGemmArgs t = mktg(g, c->uPL, MC, pk ? sw.tp_qkv : tw(c, sw.t_qkv, sw.tf_qkv), 3 * MC, MC);
         t.f32_packed = pk;
         t.qk = c->QK; t.vt = c->VT; t.v_bs = (long long)MC * g.Tp; t.qk_n = 2 * MC; t.head_dim = HD; t.rows = vt_rows; t.heads2 = 2 * HEADS; t.v_pitch = g.Tp;
+        // round 6: this GEMM's epilogue stores k and v pre-split too (as ugemm_kernel's does at small batch), for every attention shape that unpacks them: the
+        // key-split ones and the four-query-tile one of large batches (each wave of which used to split all of K and V for itself)
+        presplit = !c->bf16_mode && sp_on(c, c->attn_split) && c->attn_presplit != 0 && sp_on(c, c->gemm_split) && !c->attn_ks_force && !dev_env("SAID_ATTN_KS") &&
+                   !dev_env("SAID_NO_ATTN_QW") && !c->clk_on;   // (then the attention shape below is -4, 8 or 4: all unpack)
+        t.kv_pack = presplit ? 1 : 0;
         do_tgemm(c, t, n1, s);
     } else
     {   // x = norm(x) (GroupNorm eps 1e-6); q,k,v = to_{q,k,v}(norm1(x))   (attention.py:227, 168, 93-97)
@@ -1305,7 +1312,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         static const bool no_qw = dev_env("SAID_NO_ATTN_QW") != nullptr;
         const int attn_ks = (!no_qw && tt1 * HEADS >= 2048) ? -4 : ((tt1 * HEADS > 8192) ? 1 : ((g.T <= 256 && tt1 * HEADS <= 2048) ? 8 : 4));
         if (out1_tm && !attn_ks_env && attn_ks == -4) { a.o = static_cast<float*>(c->uPL); a.o_bstride = tg_rows(g); a.o_mode = 1; }
-        do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s, presplit && ((attn_ks_env ? attn_ks_env : attn_ks) == 4 || (attn_ks_env ? attn_ks_env : attn_ks) == 8));
+        do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s, presplit && ((attn_ks_env ? attn_ks_env : attn_ks) == 4 || (attn_ks_env ? attn_ks_env : attn_ks) == 8 || (attn_ks_env ? attn_ks_env : attn_ks) == -4));
         out1_done = a.o_mode == 1;
     }
     if (chain && !out1_done) {
@@ -1590,8 +1597,10 @@ void run_kv(said_ctx* c, int b0, int nb, int S, int Sp, hipStream_t s) {
     const LaunchCfg lc = pick_cfg((long long)nb * ((S + 31) / 32), NST * 2 * MC / 32);
     launch_gemm(a, EPI_STORE, nb, lc.NB, lc.KS, s);
     // the key-major copy the fused SpatialTransformer tail reads its window tiles from (once per loop; fp32 mode's small-batch schedule only)
+    c->kvt_S = -1;
     if ((c->bf16_mode ? c->st_chain_bf16 != 0 : sp_on(c, c->st_chain)) && (long long)S * NST * 2 * MC <= (long long)NST * 2 * MC * c->maxTp)
     {
+        c->kvt_S = S; c->kvt_bf16 = c->bf16_mode ? 1 : 0;
         // (bf16 mode: the copy itself is bf16 — the kernels round the window tiles to bf16 anyway, and at 32 clips the windows are 64 of a launch's 117 MB of HBM traffic in fp32)
         if (c->bf16_mode) launch_cm_to_tm_bf16(c->KV + b0 * ybs, ybs, Sp, reinterpret_cast<unsigned short*>(c->KVT) + (long long)b0 * S * (NST * 2 * MC), (long long)S * (NST * 2 * MC), nb, S, NST * 2 * MC, s);
         else launch_cm_to_tm(c->KV + b0 * ybs, c->KVT + (long long)b0 * S * (NST * 2 * MC), nb, S, NST * 2 * MC, Sp, ybs, s);
@@ -1689,6 +1698,7 @@ int alloc_workspace(said_ctx* ctx, int max_batch_eff, int max_frames) {
     }
     ctx->alloc_list = &ctx->allocs;
     ctx->band_T = ctx->band_S = -1;   // the band tables are part of the workspace
+    ctx->kvt_S = -1;                  // ... and so is the key-major K / V copy
     return rc;
 }
 
@@ -1894,6 +1904,7 @@ int said_clone(said_ctx* parent, said_ctx** out, int max_batch_eff, int max_fram
     c->bA0 = c->bA1 = c->bX = c->bHb = c->bF = c->bO = nullptr; c->bH = c->bT = c->bPosT = nullptr; c->b_conv_elems[0] = c->b_conv_elems[1] = 0; c->b_tok = 0;
     c->bXg = nullptr; c->bXg_elems = 0;
     c->noise_cm = nullptr; c->noise_cm_elems = 0;
+    c->kvt_S = -1;   // (the clone's own workspace holds no key-major copy yet)
     said_ctx* ctx = c;
     auto bail = [&](const char* what) { parent->err = std::string("said_clone: ") + what + (c->err.empty() ? "" : ": " + c->err); said_destroy(c); return -1; };
     c->own_stream = pool_stream(parent->device, parent->n_clones++ % POOL_STREAMS);

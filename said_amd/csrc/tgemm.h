@@ -24,6 +24,7 @@ struct TGemmArgs {
     float* vt;
     long long v_bs;
     int qk_n, head_dim, rows, heads2, v_pitch;
+    int kv_pack;           // fp32 q/k/v outputs: k and v elements are stored as packed split-fp16 pairs (split_f16.h pack_split_f16) for attn_kernel<PM = 3> (fgemm_kernel's epilogue)
     float q_scale;         // qkv_bf16: q is stored multiplied by this (battn_kernel wants scale * log2(e) folded in before the rounding)
     int qkv_bf16;          // rgemm_kernel: q / k / v are written as bf16 in battn_kernel's operand layout (attn.hip: launch_battn) — same indexing, v's
                            // tokens permuted inside every block of 16 ([0-3, 8-11, 4-7, 12-15]: a lane half's eight keys are one 16-byte piece)

@@ -2,6 +2,7 @@
 #pragma once
 #include "gemm_common.h"
 #include "tgemm.h"
+#include "split_f16.h"
 
 namespace said {
 
@@ -120,6 +121,10 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
                              // nobody prepared; attention multiplies V's padding columns by p = 0, and 0 x NaN is NaN)
 #pragma unroll
                 for (int e = 1; e < 4; ++e) v4[e] = (m + e < a.M) ? v4[e] : 0.f;
+                if (v_rows && a.kv_pack) {   // v for attn_kernel<PM = 3>: packed split pairs (0 stays all-zero bits)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = pack_split_f16(v4[e]);
+                }
                 const float4 o = make_float4(v4[0], v4[1], v4[2], v4[3]);
                 *reinterpret_cast<float4*>(ybase + (long long)n * pitch + m) = o;
                 if (a.y2_cm) {
@@ -180,6 +185,10 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
             }
             if (a.qk) {   // q / k heads token-major [b][2 heads][rows][head_dim]; head_dim % 4 == 0
                 const int h = n / a.head_dim, d = n - h * a.head_dim;
+                if (a.kv_pack && 2 * h >= a.heads2) {   // k heads (the second half of the head axis) as packed split pairs
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = pack_split_f16(v[e]);
+                }
                 *reinterpret_cast<f32x4t*>(a.qk + (((long long)b * a.heads2 + h) * a.rows + m) * a.head_dim + d) = v;
             } else {
                 if (a.yf) *reinterpret_cast<f32x4t*>(a.yf + (long long)b * a.y_bs + (long long)m * a.ldy + n) = v;

@@ -372,3 +372,38 @@ def test_presplit_operands_of_the_large_batch_gemms_are_bit_identical(dev):
             e = _rel(y1[i:i + 1], ref)
             print(f"pre-split operands B={B} T={T} sample {i}: {e:.2e} of range vs the oracle")
             assert e <= 1e-4
+
+
+def test_presplit_kv_for_the_large_batch_attention_is_bit_identical(dev):
+    """Large batches: the token-major q/k/v GEMM stores k and v as packed split pairs and the four-query-tile attention (attn_kernel<1, 1, 3, 4>) unpacks them instead of
+    every wave splitting all of K and V for itself; so does the key-split attention of the guidance-shared first block.  Same planes: bit-identical to "attn_presplit" = 0."""
+    sd = _base_sd()
+    m = _make(sd, dev)
+    for B, T in ((20, 600), (34, 333)):
+        x, ts, c = _inputs(B, T, seed=41)
+        eng = m._get_engine(B, max(T, 64))
+        y1 = _fwd(m, dev, x, ts, c)
+        eng.debug_option("attn_presplit", 0)
+        try:
+            y0 = _fwd(m, dev, x, ts, c)
+        finally:
+            eng.debug_option("attn_presplit", -1)
+        assert torch.equal(y0, y1), f"B={B} T={T}: {float((y0 - y1).abs().max()):.3e}"
+        ref = _oracle(sd, x[:1], ts[:1], c[:1])
+        e = _rel(y1[:1], ref)
+        print(f"pre-split K / V, large batch B={B} T={T}: {e:.2e} of range vs the oracle")
+        assert e <= 1e-4
+    # a guided loop step at 12 clips (24 samples: the shared first block runs the key-split attention on 12): same statement through the loop
+    lat = synth.synth_latents(9, (12, 600, 32)).to(dev)
+    emb = synth.synth_latents(10, (12, 600, 768)).to(dev)
+    wav = torch.zeros(12, 160000, device=dev)
+    kwi = dict(num_inference_steps=2, guidance_scale=2.0, eta=0.0, init_latents=lat, audio_embedding=emb)
+    m.clip_groups = 1
+    a = m.inference(wav, **kwi).result.cpu()
+    eng = m._get_engine(24, 640)
+    eng.debug_option("attn_presplit", 0)
+    try:
+        b = m.inference(wav, **kwi).result.cpu()
+    finally:
+        eng.debug_option("attn_presplit", -1)
+    assert torch.equal(a, b)
