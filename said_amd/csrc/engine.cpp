@@ -202,6 +202,8 @@ struct said_ctx {
     int attn_presplit = -1;   // fp32 small batch: the q/k/v GEMM stores k and v as packed split-fp16 pairs and attn_kernel<PM = 3> unpacks them instead of splitting all of K and V
                               // again in each of a sample's query-tile workgroups (-1 / 1: on; 0: off — said_debug_option "attn_presplit")
     int out_split = -1;       // out_sched_kernel's convolution on split-fp16 operands (-1 / 1: on; 0: fp32 matrix instructions — said_debug_option "out_split")
+    int kconv = -1;           // fp32 mode, small batch: the K-long ResBlock convolutions of the up path as straight-line two- / three-block waves (gemm_lds.hip kconv_body; -1 / 1: on,
+                              // 0: ugemm_body's block loop — said_debug_option "kconv"; bit-identical)
     int ugemm_split = -1;     // fp32 mode: the small-batch channel-major GEMMs (ugemm_kernel) on split-fp16 operands too (gemm_lds.hip: SP; weights pre-split on the host:
                               // Seg::ws).  Default (-1) and 1: ON; 0: fp32 MFMAs (said_debug_option "ugemm_split")
     int pw_split = 0;         // make_pw: also build the split-fp16 packing (1: per-block layout, 2: flat) — set around the UNet weights only
@@ -662,6 +664,7 @@ static int pick_tt(said_ctx* c, const GemmArgs& a, int epi, int batch, int& NB, 
 void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s) {
     GemmArgs a2 = a;
     a2.b0 = c->cur_b0;
+    a2.kconv_off = (c->kconv == 0) ? 1 : 0;
     const bool bf = c->bf16_mode;
     if (NB == 3 && epi == EPI_STORE && c->use_ugemm && !ugemm_supports(a2, epi, 3, KS, bf)) NB = 2;   // (the two-segment fp32 shapes spill at NB = 3: not built)
     const int tt = pick_tt(c, a2, epi, batch, NB, KS, bf);
@@ -2789,6 +2792,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->out_split = value < 0 ? -1 : (value != 0);
     } else if (k == "ugemm_split") {
         ctx->ugemm_split = value < 0 ? -1 : (value != 0);
+    } else if (k == "kconv") {
+        ctx->kconv = value < 0 ? -1 : (value != 0);
     } else if (k == "st_chain") {
         ctx->st_chain = value < 0 ? -1 : (value != 0);
     } else if (k == "attn_ks") {

@@ -1081,6 +1081,270 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
     }   // tile loop
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// kconv_body (round 6): the K-long ResBlock convolutions of the UNet's up path on split-fp16 products, NB = 1, KS = 8 —
+//   GN1  (in_layers over the concatenated [h ; skip]):   two 3-tap GroupNorm + SiLU segments of 8 x 24 channels;
+//   !GN1 (out_layers + the 1x1 skip convolution):        one 3-tap GroupNorm + SiLU segment and one or two plain 1-tap segments.
+// ugemm_body walks a wave's (segment, block) list in a run-time loop: the arguments of segments 1 / 2 are decoded per block, block i + 1 is requested only
+// when block i is about to be staged (behind both GroupNorm finalisations), the transform is a run-time switch, and in the GN1 instantiation the compiler
+// serialised the eight scalar epilogue loads (one s_waitcnt each) for lack of SGPRs: 25.4k / 21.9k clocks per launch against 12.5k for the single-segment
+// convolution (profiles/r06f_kconv_clocks.txt).  Here the wave's two or three blocks are straight-line code: every operand of every block is requested in
+// the request phase (segment 0 from the preloaded header at entry, segments 1 / 2 as soon as the argument block has arrived), epilogue constants come
+// through the vector path, the tiles of the blocks are separate (a block is staged while the previous one's MFMAs drain) and the reduction buffer no longer
+// aliases them (one barrier).  Same weights (Seg::ws), same (block, step, product) order per accumulator, same reduction order: bit-identical results
+// (tests/test_gpu_round6.py).  The host checks the shapes (ugemm_supports) and sizes the LDS (kconv_smem_floats).
+// LDS (floats): [8 waves][GN_SCRATCH] | coefficient tables 2 C0 (+ 2 C1) | tiles [8 waves][NBLK][8 * NRMAX * XP] | reduction [8][16][64]
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int kconv_smem_floats(int C0, int C1gn, int nblk) {
+    return 8 * GN_SCRATCH + 2 * C0 + 2 * C1gn + 8 * nblk * (8 * NRMAX * XP) + 8 * 16 * 64;
+}
+template <bool GN1>
+__device__ __forceinline__ void kconv_body(const FastHdr& hd, float* smem, int bx, int by, int bz) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    constexpr int KS = 8, SPR = 34, SPP = 24, NBLK = GN1 ? 2 : 3, TILE = 8 * NRMAX * XP;
+    constexpr int NS1 = GN1 ? 5 : 2;          // k16 steps of a block of segments 1 / 2 (3 taps: 9 K-groups of 8 -> 5; 1 tap: 3 -> 2)
+    const int tid = threadIdx.x, l = tid & 63, lt = l & 31, lh = l >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = bz + (hd.bmod_b0 >> 17);
+    const int t0 = bx * 32, tile0 = by;
+    const int aT = hd.T, aN = hd.N;
+    const int ntiles = (aN + 31) >> 5;
+    const int sr = l >> 3, sq = l & 7;
+    const int C0 = hd.pack & 0xffff;
+    const int c0 = w * 24;                    // the wave's channel slice of every segment (the host guarantees C / 8 == 24)
+
+    float* gnS = smem + w * GN_SCRATCH;
+    float* coef0 = smem + KS * GN_SCRATCH;
+    float* coef1 = coef0 + 2 * C0;
+
+    // ================= requests: segment 0 from the preloaded header =================
+    const rsrc_t rx0 = make_rsrc(hd.x + (long long)b * hd.bstride, (unsigned)C0 * (unsigned)hd.pitch * 4u);
+    const unsigned wbytes0 = (unsigned)ntiles * sp_tile_dwords(C0, 3) * 4u;
+    const rsrc_t rw0 = make_rsrc(hd.w4, wbytes0);
+    const float* gb0 = hd.w4 + (long long)ntiles * sp_tile_dwords(C0, 3);   // gamma[C0], beta[C0] behind the weights
+    const GnP gp0 = {hd.gn_cfg & 0xffff, hd.gn_cfg >> 16, hd.T, ((hd.pack >> 26) & 1) ? 1e-6f : 1e-5f, gb0, gb0 + C0, C0};
+    const rsrc_t rp0 = make_rsrc(hd.gn_part + (long long)b * hd.gn_bstride, (unsigned)C0 * (unsigned)gp0.gn_nparts * 8u);
+    GnLoads gl0;
+    gn_issue(gp0, rp0, c0, 24, l, gl0);
+    const ArgView V = arg_view_hs<true>(l, kHdrDwords);
+    auto issue_x = [&](rsrc_t rx, int pitch4, int Tin, bool three, f32x4 (&xv)[NRMAX], float& halo, bool valid) {
+        const int oor = valid ? 0 : (int)0x80000000;
+#pragma unroll
+        for (int rr = 0; rr < NRMAX; ++rr) xv[rr] = bload4(rx, (sr * pitch4 + (t0 + 4 * sq) * 4) | oor, (c0 + rr * 8) * pitch4);
+        halo = 0.f;
+        if (three) {   // lane -> (row = l >> 1, side = l & 1): token t0 - 1 or t0 + 32
+            const int row = l >> 1, tin = (l & 1) ? (t0 + 32) : (t0 - 1);
+            const bool ok = valid && (row < NRMAX * 8) && ((unsigned)tin < (unsigned)Tin);
+            halo = bload(rx, ok ? (row * pitch4 + tin * 4) : (int)0x80000000, c0 * pitch4);
+        }
+    };
+    // weights of (tile0, block w) of a segment: [tile][8 blocks][ns steps][2 planes] x 1024 bytes
+    auto issue_w5 = [&](rsrc_t rw, f32x4 (&wv)[5][2], bool valid) {
+        const int oor = valid ? 0 : (int)0x80000000;
+#pragma unroll
+        for (int st = 0; st < 5; ++st)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wv[st][pl] = bload4(rw, (l * 16) | oor, (((tile0 * 8 + w) * 5 + st) * 2 + pl) * 1024);
+    };
+    auto issue_w2 = [&](rsrc_t rw, f32x4 (&wv)[2][2], bool valid) {
+        const int oor = valid ? 0 : (int)0x80000000;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wv[st][pl] = bload4(rw, (l * 16) | oor, (((tile0 * 8 + w) * 2 + st) * 2 + pl) * 1024);
+    };
+    f32x4 x0[NRMAX], w0[5][2];
+    float halo0;
+    issue_x(rx0, hd.pitch * 4, hd.T, true, x0, halo0, true);
+    issue_w5(rw0, w0, true);
+    // (the machine scheduler otherwise hoists the argument-block loads and their readlanes above these requests and sinks the requests behind that round trip)
+    __builtin_amdgcn_sched_barrier(0);
+    long long* const clkp = AH(clk);
+    clk_stamp_p(clkp, w, l, 0);
+
+    // ================= requests: segments 1 (and 2) once the argument block is here =================
+    const int nseg = (hd.pack >> 24) & 3;
+    const unsigned sv1 = V.s1, sv2 = V.s2;
+    const int* const stepp = AH(step_ptr);
+    const float* const embp = AH(emb);
+    // (the step counter heads a dependent chain — counter -> embedding row -> load: its scalar round trip runs under the requests below)
+    const int step_raw = cload(stepp ? stepp : reinterpret_cast<const int*>(hd.w4), 0);
+    const int C1 = AS(sv1, C), pitch1 = AS(sv1, x_pitch), Tin1 = AS(sv1, Tin);
+    const rsrc_t rx1 = make_rsrc(AS(sv1, x) + (long long)b * AS(sv1, x_bstride), (unsigned)C1 * (unsigned)pitch1 * 4u);
+    const rsrc_t rw1 = make_rsrc(AS(sv1, ws), (unsigned)ntiles * sp_tile_dwords(C1, GN1 ? 3 : 1) * 4u);
+    GnLoads gl1;
+    GnP gp1 = gp0;
+    rsrc_t rp1 = rp0;
+    if constexpr (GN1) {
+        gp1 = {AS(sv1, gn_cpg), AS(sv1, gn_nparts), Tin1, AS(sv1, gn_eps), AS(sv1, gn_gamma), AS(sv1, gn_beta), C1};
+        rp1 = make_rsrc(AS(sv1, gn_part) + (long long)b * AS(sv1, gn_part_bstride), (unsigned)C1 * (unsigned)gp1.gn_nparts * 8u);
+        gn_issue(gp1, rp1, c0, 24, l, gl1);
+    }
+    f32x4 x1[NRMAX], w1[NS1][2];
+    float halo1;
+    issue_x(rx1, pitch1 * 4, Tin1, GN1, x1, halo1, true);
+    if constexpr (GN1) issue_w5(rw1, w1, true); else issue_w2(rw1, w1, true);
+    f32x4 x2[GN1 ? 1 : NRMAX], w2[GN1 ? 1 : 2][2];
+    int Tin2 = 0;
+    const bool has2 = !GN1 && nseg > 2;
+    if constexpr (!GN1) {   // (absent third segment: every request out of range — zeros against zero weights, never multiplied)
+        const int C2 = AS(sv2, C), pitch2 = AS(sv2, x_pitch);
+        Tin2 = AS(sv2, Tin);
+        const rsrc_t rx2 = make_rsrc(AS(sv2, x) + (long long)b * AS(sv2, x_bstride), has2 ? (unsigned)C2 * (unsigned)pitch2 * 4u : 0u);
+        const rsrc_t rw2 = make_rsrc(AS(sv2, ws), has2 ? (unsigned)ntiles * sp_tile_dwords(C2, 1) * 4u : 0u);
+        float h2;
+        issue_x(rx2, pitch2 * 4, Tin2, false, x2, h2, has2);
+        issue_w2(rw2, w2, has2);
+    }
+    // epilogue constants of the wave's two accumulator rows (VPW = 2: r = w, w + 8) through the vector path: row by lane half
+    const float* const biasp = AH(bias);
+    const int e_act = AH(act);
+    const rsrc_t r_bias = make_rsrc(biasp, biasp ? (unsigned)aN * 4u : 0u);
+    const int emb_pitch = AH(emb_pitch);
+    const rsrc_t r_emb = make_rsrc(embp, embp ? (unsigned)aN * (unsigned)emb_pitch * 4u : 0u);
+    const int erow = (stepp ? step_raw : 0) + b * AH(emb_b_stride);
+    float e_bias[2], e_emb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = w + j * KS;
+        const int n = min(tile0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, aN - 1);   // rows past N read row N - 1 (never stored)
+        e_bias[j] = bload(r_bias, n * 4, 0);
+        e_emb[j] = bload(r_emb, (n * emb_pitch + erow) * 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    clk_stamp_p(clkp, w, l, 1);
+
+    // ================= GroupNorm coefficients of the wave's slice of segment 0 =================
+    gn_finish(gp0, rp0, c0, 24, l, gl0, gnS, coef0);
+    clk_stamp_p(clkp, w, l, 2);
+    clk_stamp_p(clkp, w, l, 3);
+
+    f32x16 acc, accx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accx[r] = 0.f; }
+    float* const tiles = coef1 + (GN1 ? 2 * C1 : 0) + w * (NBLK * TILE);
+    clk_stamp_p(clkp, w, l, 4);
+
+    // one conversion per stored half (split_f16.h): the remainder is taken from the very bits that are stored
+    auto put = [&](_Float16* xh, int idx, float o) {
+        _Float16 hv = (_Float16)o;
+        asm volatile("" : "+v"(hv));
+        xh[idx] = hv;
+        xh[SPR * SPP + idx] = (_Float16)((o - (float)hv) * 2048.f);
+    };
+    auto stage_gn3 = [&](float* xt, const float2* cGN, const f32x4 (&xs)[NRMAX], float hl, int Tin) {   // GroupNorm + SiLU, three taps (halo rows 0 and 33)
+        _Float16* xh = reinterpret_cast<_Float16*>(xt);
+#pragma unroll
+        for (int rr = 0; rr < NRMAX; ++rr) {
+            const float2 gn = cGN[c0 + rr * 8 + sr];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = xf1<XF_GN_SILU>(xs[rr][e], gn, 0.f, 1.f, make_float2(1.f, 0.f));
+                put(xh, (1 + 4 * sq + e) * SPP + rr * 8 + sr, (t0 + 4 * sq + e < Tin) ? v : 0.f);
+            }
+        }
+        const int row = l >> 1, tin = (l & 1) ? (t0 + 32) : (t0 - 1);
+        if (row < NRMAX * 8) {
+            const float v = xf1<XF_GN_SILU>(hl, cGN[c0 + row], 0.f, 1.f, make_float2(1.f, 0.f));
+            put(xh, ((l & 1) ? 33 : 0) * SPP + row, ((unsigned)tin < (unsigned)Tin) ? v : 0.f);
+        }
+    };
+    auto stage_raw1 = [&](float* xt, const f32x4 (&xs)[NRMAX], int Tin) {   // plain operand, one tap
+        _Float16* xh = reinterpret_cast<_Float16*>(xt);
+#pragma unroll
+        for (int rr = 0; rr < NRMAX; ++rr)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) put(xh, (1 + 4 * sq + e) * SPP + rr * 8 + sr, (t0 + 4 * sq + e < Tin) ? xs[rr][e] : 0.f);
+    };
+    // row `token` of the tile is the im2col row of that token: K-group g at halfs 8 g; a 1-tap block starts one row down (no left halo)
+    auto mma5 = [&](const float* xt, const f32x4 (&ws)[5][2]) {
+        const _Float16* xh = reinterpret_cast<const _Float16*>(xt) + lt * SPP;
+#pragma unroll
+        for (int st = 0; st < 5; ++st) {
+            const int g = min(2 * st + lh, 8);   // (the padding group re-reads the last one: finite data against zero weights)
+            const f16x8 fh = *reinterpret_cast<const f16x8*>(xh + 8 * g), fl = *reinterpret_cast<const f16x8*>(xh + SPR * SPP + 8 * g);
+            const f16x8 wh = __builtin_bit_cast(f16x8, ws[st][0]), wl = __builtin_bit_cast(f16x8, ws[st][1]);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fh, accx, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fh, acc, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fl, accx, 0, 0, 0);
+        }
+    };
+    auto mma2 = [&](const float* xt, const f32x4 (&ws)[2][2]) {
+        const _Float16* xh = reinterpret_cast<const _Float16*>(xt) + (lt + 1) * SPP;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int g = min(2 * st + lh, 2);
+            const f16x8 fh = *reinterpret_cast<const f16x8*>(xh + 8 * g), fl = *reinterpret_cast<const f16x8*>(xh + SPR * SPP + 8 * g);
+            const f16x8 wh = __builtin_bit_cast(f16x8, ws[st][0]), wl = __builtin_bit_cast(f16x8, ws[st][1]);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fh, accx, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fh, acc, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fl, accx, 0, 0, 0);
+        }
+    };
+
+    // ================= stage + multiply, block by block =================
+    stage_gn3(tiles, reinterpret_cast<const float2*>(coef0), x0, halo0, hd.T);
+    clk_stamp_p(clkp, w, l, 5);
+    mma5(tiles, w0);
+    if constexpr (GN1) {
+        gn_finish(gp1, rp1, c0, 24, l, gl1, gnS, coef1);
+        stage_gn3(tiles + TILE, reinterpret_cast<const float2*>(coef1), x1, halo1, Tin1);
+        mma5(tiles + TILE, w1);
+    } else {
+        stage_raw1(tiles + TILE, x1, Tin1);
+        mma2(tiles + TILE, w1);
+        if (has2) {
+            stage_raw1(tiles + 2 * TILE, x2, Tin2);
+            mma2(tiles + 2 * TILE, w2);
+        }
+    }
+    clk_stamp_p(clkp, w, l, 6);
+
+    // ================= split-K reduction through LDS (fixed order => deterministic), epilogue =================
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = fmaf(accx[r], 0x1p-11f, acc[r]);   // main + 2^-11 cross
+    float* red = coef1 + (GN1 ? 2 * C1 : 0) + KS * (NBLK * TILE);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + l] = acc[r];
+    clk_stamp_p(clkp, w, l, 7);
+    __syncthreads();
+    clk_stamp_p(clkp, w, l, 8);
+    float* const yp = AH(y);
+    const long long y_bs = AH(y_bstride);
+    const int y_pitch = AH(y_pitch);
+    float* const statsp = AH(stats_out);
+    const long long st_bs = AH(stats_bstride);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = w + j * KS;
+        float val = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < KS; ++w2) val += red[(w2 * 16 + r) * 64 + l];
+        const int nl = tile0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int t = t0 + lt;
+        const bool ok = (nl < aN) && (t < aT);
+        val += e_bias[j];
+        if (e_act == ACT_SILU) val = silu_f(val);
+        else if (e_act == ACT_GELU) val = gelu_f(val);
+        val += e_emb[j];
+        if (ok) gstore(yp, (long long)b * y_bs + (long long)nl * y_pitch + t, val);
+        if (statsp) {   // GroupNorm partials of the stored values: [tile][channel][2] (mean, M2)
+            const float cnt = (float)min(32, aT - t0);
+            const float vv = (t < aT) ? val : 0.f;
+            const float mean = half32_sum(vv) * __builtin_amdgcn_rcpf(cnt);
+            const float d = (t < aT) ? (val - mean) : 0.f;
+            const float m2 = half32_sum(d * d);
+            if (lt == 0 && nl < aN) {
+                float* so = statsp + (long long)b * st_bs + ((long long)(t0 >> 5) * aN + nl) * 2;
+                gstore(so, 0, mean);
+                gstore(so, 1, m2);
+            }
+        }
+    }
+    clk_stamp_p(clkp, w, l, 9);
+}
+
 template <int NB, int KS, int EPI, int VAR, bool BF, bool MT, bool SP = false>
 // multi-tile single-n-tile store kernels are compiled for <= 128 VGPRs (4 waves per SIMD): two workgroups share a CU, so one's
 // staging / reduction / epilogue phases overlap the other's MFMA stream (large batches, SAID_BIG_NB=1)
@@ -1108,6 +1372,12 @@ __global__ __launch_bounds__(64 * KS, (MT && NB == 1 && EPI == EPI_STORE) ? 4 : 
     // L / ny as a multiply-shift with the host's magic number (exact for every L < grid width: the host checks)
     const unsigned ubx = (L * ((unsigned)hbmod_b0 & 0x1ffffu)) >> 16;
     const int bx = (int)ubx, by = (int)(L - ubx * ny), bz = (int)blockIdx.y;
+    if constexpr (SP && !MT && NB == 1 && KS == 8 && EPI == EPI_STORE && (VAR == (UV_T3 | UV_GN0 | UV_MULTI) || VAR == (UV_T3 | UV_GN0 | UV_GN1 | UV_MULTI))) {
+        if (!(hpack & (1 << 27))) {   // (bit 27: said_debug_option "kconv" = 0 — the block loop of ugemm_body, the A/B reference)
+            kconv_body<(VAR & UV_GN1) != 0>(hd, smem, bx, by, bz);
+            return;
+        }
+    }
     if constexpr (EPI == EPI_QKV) {
         if (by * NB < hgate_vft) {
             ugemm_body<NB, KS, EPI, VAR, true, BF, MT, SP>(hd, smem, bx, by, bz);
@@ -1132,6 +1402,11 @@ constexpr int kMaxLds = 160 * 1024;
 template <int NB, int KS, int EPI, int VAR, bool BF, bool MT, bool SP = false>
 static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s, int tt) {
     int smem = ugemm_smem_floats<NB, EPI>(a, KS, MT) * (int)sizeof(float);
+    constexpr bool KCONV = SP && !MT && NB == 1 && KS == 8 && EPI == EPI_STORE && (VAR == (UV_T3 | UV_GN0 | UV_MULTI) || VAR == (UV_T3 | UV_GN0 | UV_GN1 | UV_MULTI));
+    if (KCONV && !a.kconv_off) {   // kconv_body's own carve (separate tiles per block, reduction buffer beside them)
+        const int ks = kconv_smem_floats(a.seg[0].C, (VAR & UV_GN1) ? a.seg[1].C : 0, (VAR & UV_GN1) ? 2 : 3) * (int)sizeof(float);
+        if (ks > smem) smem = ks;
+    }
     static const int min_lds = dev_env("SAID_MIN_LDS") ? atoi(dev_env("SAID_MIN_LDS")) : 0;   // experiment: force one workgroup per CU
     if (smem < min_lds) smem = min_lds;
     if (smem > kMaxLds) { launch_fault("ugemm needs %d B of LDS", smem); return; }
@@ -1140,7 +1415,7 @@ static void ulaunch_one(const GemmArgs& a, int batch, hipStream_t s, int tt) {
     const Seg& s0 = a.seg[0];
     const bool gn0 = s0.xform == XF_GN_SILU || s0.xform == XF_GN_LN;
     const int pack = s0.C | (s0.taps << 16) | (s0.xform << 20) | (a.nseg << 24) | ((gn0 && s0.gn_eps == 1e-6f) ? (1 << 26) : 0) |
-                     ((MT ? tt : 0) << 28);
+                     ((MT ? tt : 0) << 28) | ((KCONV && a.kconv_off) ? (1 << 27) : 0);
     const unsigned ny_host = (unsigned)(a.ntiles_per_group / NB), magic = 65536u / ny_host + 1u;
     for (unsigned L = 0; L < grid.x; ++L)   // exactness of the multiply-shift over this launch's range (a few thousand at most)
         if (((L * magic) >> 16) != L / ny_host) { launch_fault("block decode magic inexact (grid %u, ny %u)", grid.x, ny_host); return; }
@@ -1263,6 +1538,18 @@ bool ugemm_supports(const GemmArgs& a, int epi, int NB, int KS, int pm, int tt) 
         if (tt > 1 || !spc) return false;
         const bool flat_shape = epi == EPI_GEGLU && NB == 4 && KS == 8 && !(var & (UV_MULTI | UV_DEEP));
         for (int s = 0; s < a.nseg; ++s) if (!a.seg[s].ws || (a.seg[s].ws_flat != 0) != flat_shape) return false;
+        if (epi == EPI_STORE && NB == 1 && KS == 8 && (var == (UV_T3 | UV_GN0 | UV_MULTI) || var == (UV_T3 | UV_GN0 | UV_GN1 | UV_MULTI)) && !a.kconv_off) {
+            // kconv_body's shapes: every segment 8 x 24 channels; [3-tap GN + SiLU] x 2, or 3-tap GN + SiLU followed by one or two plain 1-tap segments
+            const bool gn1 = (var & UV_GN1) != 0;
+            if (a.res_kind != RES_NONE || a.y2 || (gn1 ? a.nseg != 2 : (a.nseg < 2 || a.nseg > 3))) return false;
+            for (int s = 0; s < a.nseg; ++s) {
+                const Seg& sg = a.seg[s];
+                const bool gn3 = (s == 0) || gn1;
+                if (sg.C != 24 * 8 || sg.taps != (gn3 ? 3 : 1) || sg.xform != (gn3 ? XF_GN_SILU : XF_NONE) || sg.Tin != a.T) return false;
+                if (sg.x_bstride > 0x7fffffffLL || sg.gn_part_bstride > 0x7fffffffLL) return false;
+            }
+            if (a.emb && (long long)a.N * a.emb_pitch * 4 > 0x7fffffffLL) return false;
+        }
     }
     {   // what the compile-time variant assumes about the arguments
         const int xf0 = a.seg[0].xform;

@@ -133,6 +133,7 @@ struct GemmCommon {        // 8-byte members first, then 4-byte ones: no interna
     int stats_bstride;
     int geglu_gate_tiles;  // EPI_GEGLU: gate tile = value tile + geglu_gate_tiles
     int b0;                // batch offset: this launch covers samples [b0, b0 + gridDim.z)
+    int kconv_off;         // host only: 1 = the K-long ResBlock convolutions keep ugemm_body's block loop (said_debug_option "kconv" = 0; gemm_lds.hip kconv_body)
 };
 struct GemmArgs : GemmCommon {
     char pad_[256 - sizeof(GemmCommon)];

@@ -20,6 +20,7 @@ eng.unet_forward(x, ts, c)
 eng.debug_clocks(True)
 eng.unet_forward(x, ts, c)
 clk = eng.debug_clocks(False, read=True)
+DETAIL = tuple(int(v) for v in os.environ.get("CLK_DETAIL", "1,3").split(","))   # launches whose per-wave stamps are printed
 labels = ["issue", "gn-fin", "ln-stat", "band-ld", "stage", "mma", "bar1", "ldsw+bar2", "epi"]
 # stchain_kernel's stamps (stchain.hip clk_stamp_c; workgroup (tile 8, last sample, slice 0)).  Column owners (waves 0-5) stamp slots
 #   0 entry, 12 requests issued, 14 attention tile staged, 1 operands staged + barrier, 2 to_out1 done, 3 LayerNorm2 exchanged, 4 to_q done, 5 band done,
@@ -61,6 +62,6 @@ for k in range(44):
     d = np.diff(st, axis=1)
     tot = st[:, 9].max() - base
     print(f"launch {k:2d} total {tot:6d} clk | " + " ".join(f"{n}:{int(d[:, i].mean()):5d}" for i, n in enumerate(labels)))
-    if k in (1, 3):
+    if k in DETAIL:
         for w in range(8):
             print("      wave", w, " ".join(f"{int(v - base):6d}" for v in st[w]))

@@ -407,3 +407,26 @@ def test_presplit_kv_for_the_large_batch_attention_is_bit_identical(dev):
     finally:
         eng.debug_option("attn_presplit", -1)
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------- the K-long ResBlock convolutions of the up path as straight-line blocks (gemm_lds.hip kconv_body)
+@pytest.mark.parametrize("B,T", [(2, 600), (1, 37), (3, 333), (2, 1800), (5, 64)])
+def test_kconv_matches_the_block_loop_bit_for_bit(dev, B, T):
+    """The two- / three-segment convolutions of the up path (in_layers over [h ; skip]; out_layers + the 1x1 skip convolution) run on kconv_body in fp32 mode at small
+    batch: every block of a wave requested up front, staged and multiplied as straight-line code.  Same weights, same order per accumulator, same reduction order as
+    ugemm_body's block loop (said_debug_option "kconv" = 0): the UNet output is bit-identical; both sit at the oracle's distance."""
+    sd = _base_sd()
+    m = _make(sd, dev)
+    x, ts, c = _inputs(B, T, seed=33)
+    eng = m._get_engine(max(B, 2), max(T, 64))
+    y = _fwd(m, dev, x, ts, c)
+    eng.debug_option("kconv", 0)
+    try:
+        y0 = _fwd(m, dev, x, ts, c)
+    finally:
+        eng.debug_option("kconv", -1)
+    y2 = _fwd(m, dev, x, ts, c)
+    e = _rel(y, _oracle(sd, x, ts, c))
+    print(f"B={B} T={T}: kconv vs block loop max |diff| {float((y - y0).abs().max()):.3e}; vs oracle {e:.2e} of range")
+    assert torch.equal(y, y0) and torch.equal(y, y2)
+    assert e <= 1e-4
