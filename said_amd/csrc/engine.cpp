@@ -204,6 +204,7 @@ struct said_ctx {
     int out_split = -1;       // out_sched_kernel's convolution on split-fp16 operands (-1 / 1: on; 0: fp32 matrix instructions — said_debug_option "out_split")
     int kconv = -1;           // fp32 mode, small batch: the K-long ResBlock convolutions of the up path as straight-line two- / three-block waves (gemm_lds.hip kconv_body; -1 / 1: on,
                               // 0: ugemm_body's block loop — said_debug_option "kconv"; bit-identical)
+    long long kconv_max_tiles = 4096;   // launches of at most this many (sample, token tile) pairs run the K-long convolutions as NB = 1 kconv_body workgroups when the chosen NB has no split shape
     int ugemm_split = -1;     // fp32 mode: the small-batch channel-major GEMMs (ugemm_kernel) on split-fp16 operands too (gemm_lds.hip: SP; weights pre-split on the host:
                               // Seg::ws).  Default (-1) and 1: ON; 0: fp32 MFMAs (said_debug_option "ugemm_split")
     int pw_split = 0;         // make_pw: also build the split-fp16 packing (1: per-block layout, 2: flat) — set around the UNet weights only
@@ -667,6 +668,13 @@ void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS,
     a2.kconv_off = (c->kconv == 0) ? 1 : 0;
     const bool bf = c->bf16_mode;
     if (NB == 3 && epi == EPI_STORE && c->use_ugemm && !ugemm_supports(a2, epi, 3, KS, bf)) NB = 2;   // (the two-segment fp32 shapes spill at NB = 3: not built)
+    // K-long up-path convolutions (two / three K segments): the split-fp16 shapes exist for one column tile per workgroup only (kconv_body; with two the second accumulator
+    // set spills).  Where that takes at most 1.5 x the rounds of the chosen shape on the fp32 matrix instructions it wins (a round of NB = 1 split ~11 us, of NB = 2 fp32 ~21 us:
+    // configs[4] 24.3k -> 25.5k frames/s, 3 clips +6 %; 76 tiles — 2 rounds against 1 — loses 2 %: profiles/r06g_kconv_ab.txt)
+    if (!bf && epi == EPI_STORE && NB > 1 && a2.nseg >= 2 && c->kconv != 0 && sp_on(c, c->ugemm_split) && c->use_ugemm && !a2.step_inc && !c->clk_on && !c->cur_concurrent) {   // (concurrent clip groups share the CUs: fewer workgroups win there — 5 clips -1.9 %)
+        const long long tiles = (long long)batch * ((a2.T + 31) / 32), r1 = (tiles * 6 + 255) / 256, rn = (tiles * (6 / NB) + 255) / 256;
+        if (tiles <= c->kconv_max_tiles && 2 * r1 <= 3 * rn && !ugemm_supports(a2, epi, NB, KS, 2) && ugemm_supports(a2, epi, 1, 8, 2)) { NB = 1; KS = 8; }
+    }
     const int tt = pick_tt(c, a2, epi, batch, NB, KS, bf);
     // fp32 mode, single-tile workgroups: split-fp16 products wherever the shape is built for them (gemm_lds.hip SP) and the weights carry the packing
     const bool sp = !bf && tt <= 1 && sp_on(c, c->ugemm_split) && c->use_ugemm && !a2.step_inc && ugemm_supports(a2, epi, NB, KS, 2);
@@ -2794,6 +2802,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->ugemm_split = value < 0 ? -1 : (value != 0);
     } else if (k == "kconv") {
         ctx->kconv = value < 0 ? -1 : (value != 0);
+    } else if (k == "kconv_max_tiles") {
+        ctx->kconv_max_tiles = value;
     } else if (k == "st_chain") {
         ctx->st_chain = value < 0 ? -1 : (value != 0);
     } else if (k == "attn_ks") {

@@ -1089,7 +1089,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 // ugemm_body walks a wave's (segment, block) list in a run-time loop: the arguments of segments 1 / 2 are decoded per block, block i + 1 is requested only
 // when block i is about to be staged (behind both GroupNorm finalisations), the transform is a run-time switch, and in the GN1 instantiation the compiler
 // serialised the eight scalar epilogue loads (one s_waitcnt each) for lack of SGPRs: 25.4k / 21.9k clocks per launch against 12.5k for the single-segment
-// convolution (profiles/r06f_kconv_clocks.txt).  Here the wave's two or three blocks are straight-line code: every operand of every block is requested in
+// convolution (profiles/r06g_kconv_ab.txt).  Here the wave's two or three blocks are straight-line code: every operand of every block is requested in
 // the request phase (segment 0 from the preloaded header at entry, segments 1 / 2 as soon as the argument block has arrived), epilogue constants come
 // through the vector path, the tiles of the blocks are separate (a block is staged while the previous one's MFMAs drain) and the reduction buffer no longer
 // aliases them (one barrier).  Same weights (Seg::ws), same (block, step, product) order per accumulator, same reduction order: bit-identical results
@@ -1157,7 +1157,9 @@ __device__ __forceinline__ void kconv_body(const FastHdr& hd, float* smem, int b
     f32x4 x0[NRMAX], w0[5][2];
     float halo0;
     issue_x(rx0, hd.pitch * 4, hd.T, true, x0, halo0, true);
+#ifdef SAID_KCONV_W_FIRST
     issue_w5(rw0, w0, true);
+#endif
     // (the machine scheduler otherwise hoists the argument-block loads and their readlanes above these requests and sinks the requests behind that round trip)
     __builtin_amdgcn_sched_barrier(0);
     long long* const clkp = AH(clk);
@@ -1184,9 +1186,9 @@ __device__ __forceinline__ void kconv_body(const FastHdr& hd, float* smem, int b
     f32x4 x1[NRMAX], w1[NS1][2];
     float halo1;
     issue_x(rx1, pitch1 * 4, Tin1, GN1, x1, halo1, true);
-    if constexpr (GN1) issue_w5(rw1, w1, true); else issue_w2(rw1, w1, true);
     f32x4 x2[GN1 ? 1 : NRMAX], w2[GN1 ? 1 : 2][2];
     int Tin2 = 0;
+    rsrc_t rw2_ = rw1;
     const bool has2 = !GN1 && nseg > 2;
     if constexpr (!GN1) {   // (absent third segment: every request out of range — zeros against zero weights, never multiplied)
         const int C2 = AS(sv2, C), pitch2 = AS(sv2, x_pitch);
@@ -1195,7 +1197,7 @@ __device__ __forceinline__ void kconv_body(const FastHdr& hd, float* smem, int b
         const rsrc_t rw2 = make_rsrc(AS(sv2, ws), has2 ? (unsigned)ntiles * sp_tile_dwords(C2, 1) * 4u : 0u);
         float h2;
         issue_x(rx2, pitch2 * 4, Tin2, false, x2, h2, has2);
-        issue_w2(rw2, w2, has2);
+        rw2_ = rw2;
     }
     // epilogue constants of the wave's two accumulator rows (VPW = 2: r = w, w + 8) through the vector path: row by lane half
     const float* const biasp = AH(bias);
@@ -1212,6 +1214,15 @@ __device__ __forceinline__ void kconv_body(const FastHdr& hd, float* smem, int b
         e_bias[j] = bload(r_bias, n * 4, 0);
         e_emb[j] = bload(r_emb, (n * emb_pitch + erow) * 4, 0);
     }
+    // The weights go out LAST: a CU's vector-memory path takes ~16 clocks per 1 KB wave-load, so the eight waves' requests queue behind each other (the second wave of
+    // each SIMD finishes issuing 2-4k clocks after the first), and 10 KB of weights per block in front of the statistics and operands of the waves behind would hold up
+    // the head of every wave's dependent chain (partials -> coefficients -> staging) for data the MFMAs need last.
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef SAID_KCONV_W_FIRST
+    issue_w5(rw0, w0, true);
+#endif
+    if constexpr (GN1) issue_w5(rw1, w1, true); else issue_w2(rw1, w1, true);
+    if constexpr (!GN1) issue_w2(rw2_, w2, has2);
     __builtin_amdgcn_sched_barrier(0);
     clk_stamp_p(clkp, w, l, 1);
 

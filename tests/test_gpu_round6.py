@@ -410,11 +410,13 @@ def test_presplit_kv_for_the_large_batch_attention_is_bit_identical(dev):
 
 
 # ---------------------------------------------------------------- the K-long ResBlock convolutions of the up path as straight-line blocks (gemm_lds.hip kconv_body)
-@pytest.mark.parametrize("B,T", [(2, 600), (1, 37), (3, 333), (2, 1800), (5, 64)])
-def test_kconv_matches_the_block_loop_bit_for_bit(dev, B, T):
+@pytest.mark.parametrize("B,T,same_shape", [(2, 600, True), (1, 37, True), (3, 333, True), (5, 64, True), (2, 1800, False), (6, 600, False)])
+def test_kconv_matches_the_block_loop(dev, B, T, same_shape):
     """The two- / three-segment convolutions of the up path (in_layers over [h ; skip]; out_layers + the 1x1 skip convolution) run on kconv_body in fp32 mode at small
     batch: every block of a wave requested up front, staged and multiplied as straight-line code.  Same weights, same order per accumulator, same reduction order as
-    ugemm_body's block loop (said_debug_option "kconv" = 0): the UNet output is bit-identical; both sit at the oracle's distance."""
+    ugemm_body's block loop (said_debug_option "kconv" = 0): where both run one column tile per workgroup the UNet output is bit-identical.  Mid-size launches
+    (configs[4]; 3-8 clips) used to run these convolutions with two column tiles per workgroup on the fp32 matrix instructions (no split shape exists for those) and now
+    take kconv_body's shape when its rounds are no more than 1.5 x as many: there the two differ by the products' rounding.  Both sit at the oracle's distance."""
     sd = _base_sd()
     m = _make(sd, dev)
     x, ts, c = _inputs(B, T, seed=33)
@@ -426,7 +428,11 @@ def test_kconv_matches_the_block_loop_bit_for_bit(dev, B, T):
     finally:
         eng.debug_option("kconv", -1)
     y2 = _fwd(m, dev, x, ts, c)
-    e = _rel(y, _oracle(sd, x, ts, c))
-    print(f"B={B} T={T}: kconv vs block loop max |diff| {float((y - y0).abs().max()):.3e}; vs oracle {e:.2e} of range")
-    assert torch.equal(y, y0) and torch.equal(y, y2)
+    e, e0 = _rel(y, _oracle(sd, x, ts, c)), _rel(y, y0)
+    print(f"B={B} T={T}: kconv vs block loop {e0:.2e} of range (max |diff| {float((y - y0).abs().max()):.3e}); vs oracle {e:.2e} of range")
+    assert torch.equal(y, y2)
+    if same_shape:
+        assert torch.equal(y, y0)
+    else:
+        assert 0 < e0 <= 2e-6
     assert e <= 1e-4
