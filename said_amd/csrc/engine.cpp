@@ -124,6 +124,7 @@ struct said_ctx {
                                  // workgroup, two workgroups per CU; said_debug_option "st_chain_bf16").  (Round 5's two-tiles-per-workgroup variant measured slower — 96 vs 83 us,
                                  // profiles/r05p_stchain2_two_tiles_ab.txt — and was removed in round 6.)
     bool st_chain_dbg = false;   // debug: the fused kernel also writes x1 / x2 to X1 / X2
+    int attn_2q = -1;            // fp32 mode, pre-split K / V, four key slices: three query tiles per wave (attn2q_kernel) — -1: launches of >= 512 (sample, head, tile) triples, 0: never, 1: always (said_debug_option "attn_2q")
     int attn_ks_force = 0;       // development: != 0 forces the self-attention workgroup shape (8 / 4 / 1: key-split waves; -4: four query tiles per workgroup) — said_debug_option "attn_ks"
     int st_chain_slices = -1;    // fp32 mode: -1 / 3: launches of at most CHAIN3_MAX_TILES (sample, token tile) pairs run THREE workgroups per tile, of at most CHAIN2_MAX_TILES two
                                  // (stchain.hip CU<>); 2: two wherever slicing is possible; 1: never
@@ -1323,7 +1324,11 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         static const bool no_qw = dev_env("SAID_NO_ATTN_QW") != nullptr;
         const int attn_ks = (!no_qw && tt1 * HEADS >= 2048) ? -4 : ((tt1 * HEADS > 8192) ? 1 : ((g.T <= 256 && tt1 * HEADS <= 2048) ? 8 : 4));
         if (out1_tm && !attn_ks_env && attn_ks == -4) { a.o = static_cast<float*>(c->uPL); a.o_bstride = tg_rows(g); a.o_mode = 1; }
-        do_attn(c, a, n1, HD, attn_ks_env ? attn_ks_env : attn_ks, s, presplit && ((attn_ks_env ? attn_ks_env : attn_ks) == 4 || (attn_ks_env ? attn_ks_env : attn_ks) == 8 || (attn_ks_env ? attn_ks_env : attn_ks) == -4));
+        int ks_run = attn_ks_env ? attn_ks_env : attn_ks;
+        // long sequences at small batch (configs[4]): three query tiles per wave share every K / V fragment (attn.hip attn2q_kernel; bit-identical) once a
+        // third of the launch is still most of a round of workgroups
+        if (presplit && ks_run == 4 && a.o_mode == 0 && (c->attn_2q > 0 || (c->attn_2q < 0 && tt1 * HEADS >= 512))) ks_run = 34;
+        do_attn(c, a, n1, HD, ks_run, s, presplit && (ks_run == 4 || ks_run == 8 || ks_run == -4 || ks_run == 34));
         out1_done = a.o_mode == 1;
     }
     if (chain && !out1_done) {
@@ -2806,6 +2811,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->kconv_max_tiles = value;
     } else if (k == "st_chain") {
         ctx->st_chain = value < 0 ? -1 : (value != 0);
+    } else if (k == "attn_2q") {
+        ctx->attn_2q = value < 0 ? -1 : (value != 0);
     } else if (k == "attn_ks") {
         ctx->attn_ks_force = (int)value;
     } else if (k == "st_chain_slices") {

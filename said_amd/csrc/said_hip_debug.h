@@ -41,6 +41,8 @@ extern "C" {
  *   "ugemm_split"            fp32 mode, channel-major GEMMs (ugemm_kernel): 0 = fp32 MFMAs (default -1 / 1: split-fp16 products, round 5)
  *   "kconv"                  fp32 mode, small batch: 0 = the K-long ResBlock convolutions of the up path (two / three K segments) keep ugemm_body's block loop; -1 / 1 (default):
  *                            kconv_body's straight-line blocks (round 6; bit-identical)
+ *   "attn_2q"                fp32 mode, pre-split K / V, four key slices: 0 = one query tile per wave always; 1 = three always; -1 (default) = three from 512 (sample, head, query tile)
+ *                            triples per launch on (attn2q_kernel: long sequences at small batch; bit-identical)
  *   "attn_presplit"          fp32 small batch: 0 = attention splits K / V itself (default -1 / 1: the q/k/v GEMM stores them pre-split, attn_kernel<PM = 3>)
  *   "out_split"              out_sched_kernel's convolution: 0 = fp32 MFMAs (default -1 / 1: split-fp16 products, round 5)
  *   "st_chain"               fp32 mode: 0 runs everything behind a SpatialTransformer's self-attention as five launches (rounds 1-4); default -1 / 1:

@@ -436,3 +436,27 @@ def test_kconv_matches_the_block_loop(dev, B, T, same_shape):
     else:
         assert 0 < e0 <= 2e-6
     assert e <= 1e-4
+
+
+# ---------------------------------------------------------------- long sequences: two / three query tiles per wave (attn.hip attn2q_kernel)
+@pytest.mark.parametrize("B,T,opt", [(2, 1800, -1), (1, 1801, 1), (1, 1000, 1), (2, 600, 1), (3, 333, 1), (1, 37, 1)])
+def test_several_query_tiles_per_wave_are_bit_identical(dev, B, T, opt):
+    """Self-attention over pre-split K / V with a wave keeping the states of three consecutive query tiles and running them against every K / V fragment it fetches
+    (configs[4]'s shape by default: launches of >= 512 (sample, head, tile) triples).  Same key tiles per wave, same per-tile arithmetic, same merge as one tile per
+    wave ("attn_2q" = 0): the UNet output is bit-identical — also where the last workgroup's extra tiles are phantoms (57 tiles in threes is exact; 32, 19 and 11
+    tiles leave one or two over, 2 tiles are one workgroup with a phantom)."""
+    sd = _base_sd()
+    m = _make(sd, dev)
+    x, ts, c = _inputs(B, T, seed=35)
+    eng = m._get_engine(max(B, 2), max(T, 64))
+    eng.debug_option("attn_2q", 0)
+    try:
+        y0 = _fwd(m, dev, x, ts, c)
+        eng.debug_option("attn_2q", opt)
+        y = _fwd(m, dev, x, ts, c)
+    finally:
+        eng.debug_option("attn_2q", -1)
+    e = _rel(y, _oracle(sd, x, ts, c)) if T <= 600 else 0.0
+    print(f"B={B} T={T} attn_2q={opt}: max |diff| to one tile per wave {float((y - y0).abs().max()):.3e}" + (f"; vs oracle {e:.2e} of range" if T <= 600 else ""))
+    assert torch.equal(y, y0)
+    assert e <= 1e-4
