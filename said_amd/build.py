@@ -19,7 +19,7 @@ LIB = os.path.join(LIBDIR, "libsaid_hip.so")
 # gfx950 only.  SAID_OFFLOAD_ARCH may narrow the target ID for experiments (e.g. "gfx950:xnack-"; several, comma-separated,
 # give a fat binary from which the runtime picks the one matching the device).
 ARCHS = os.environ.get("SAID_OFFLOAD_ARCH", "gfx950").split(",")
-SOURCES = ["gemm.hip", "gemm_lds.hip", "attn.hip", "misc.hip", "out_sched.hip", "conv_in.hip", "tgemm.hip", "rgemm.hip", "stchain.hip", "engine.cpp"]
+SOURCES = ["gemm.hip", "gemm_lds.hip", "attn.hip", "attn2q.hip", "misc.hip", "out_sched.hip", "conv_in.hip", "tgemm.hip", "rgemm.hip", "stchain.hip", "engine.cpp"]
 FLAGS = [*[f"--offload-arch={a}" for a in ARCHS], "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 # Round 5 (profiles/r05a_pk_fma_hazard.txt): on gfx950 a packed-fp32 VALU instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) whose LOW half
 # reads the HIGH register of an operand pair (an op_sel bit set) can read that operand as 0 in lanes 48-63 while ANOTHER wave of the SIMD issues fp16 / bf16
@@ -80,6 +80,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if force or _stale(obj, [sp] + headers):
             # leading scalar kernel parameters arrive in SGPRs (14 is what the hardware has room for): see gemm_lds.hip, attn.hip
             extra = ["-mllvm", "-amdgpu-kernarg-preload-count=14"] if (src in ("gemm_lds.hip", "attn.hip", "conv_in.hip", "stchain.hip", "out_sched.hip") and not os.environ.get("SAID_NO_PRELOAD")) else []
+            if src == "attn2q.hip":   # MFMA results in the vector registers although a 256-thread workgroup could have 512 registers per wave (attn2q.hip's header)
+                extra += ["-mllvm", "-amdgpu-kernarg-preload-count=14", "-mllvm", "-amdgpu-mfma-vgpr-form"]
             extra += os.environ.get("SAID_EXTRA_DEFS", "").split()   # development: -D switches for A/B builds (scripts/gpu_ab_build.sh)
             if src in NO_SLP and not os.environ.get("SAID_KEEP_SLP"):
                 extra += ["-fno-slp-vectorize"]

@@ -193,6 +193,9 @@ bool battn_supports(const AttnArgs& a, int head_dim);
 // banded cross-attention over alignment windows of any width, q / o in place (misc.hip: band_wide_kernel)
 void launch_band_wide(float* qo, long long qo_bstride, int pitch, const float* k, const float* v, long long kv_bstride, int kv_pitch, const int* lo,
                       const int* hi, int T, int heads, int batch, float scale, hipStream_t s);
+// round 6: pre-split K / V, head_dim 32, four key slices, three query tiles per wave (attn2q.hip: long sequences at small batch); channel-major output
+void launch_attn2q(const AttnArgs& a, int batch, hipStream_t s);
+void configure_attn2q_kernel();
 void launch_battn(const AttnArgs& a, int batch, hipStream_t s, int qt = 8);   // qt: query tiles (waves) per workgroup, 4 or 8
 
 struct SchedArgs {
