@@ -1325,9 +1325,9 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         const int attn_ks = (!no_qw && tt1 * HEADS >= 2048) ? -4 : ((tt1 * HEADS > 8192) ? 1 : ((g.T <= 256 && tt1 * HEADS <= 2048) ? 8 : 4));
         if (out1_tm && !attn_ks_env && attn_ks == -4) { a.o = static_cast<float*>(c->uPL); a.o_bstride = tg_rows(g); a.o_mode = 1; }
         int ks_run = attn_ks_env ? attn_ks_env : attn_ks;
-        // long sequences at small batch (configs[4]): three query tiles per wave share every K / V fragment (attn.hip attn2q_kernel; bit-identical) once a
-        // third of the launch is still most of a round of workgroups
-        if (presplit && ks_run == 4 && a.o_mode == 0 && (c->attn_2q > 0 || (c->attn_2q < 0 && tt1 * HEADS >= 512))) ks_run = 34;
+        // long sequences at small batch (configs[4]): three query tiles per wave share every K / V fragment (attn2q.hip; bit-identical) where a third of the
+        // launch is most of ONE round of workgroups (101 KB of LDS, 264 registers: one workgroup per CU)
+        if (presplit && ks_run == 4 && a.o_mode == 0 && (c->attn_2q > 0 || (c->attn_2q < 0 && tt1 * HEADS >= 512 && (long long)n1 * HEADS * ((((g.T + 31) / 32) + 2) / 3) <= 256))) ks_run = 34;   // (one round of one workgroup per CU)
         do_attn(c, a, n1, HD, ks_run, s, presplit && (ks_run == 4 || ks_run == 8 || ks_run == -4 || ks_run == 34));
         out1_done = a.o_mode == 1;
     }
