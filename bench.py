@@ -189,7 +189,7 @@ def kernel_pipe(name, dtype, sp):
         return None, 0.0
     if dtype == "bf16":
         return "mfma_bf16", 1.0
-    split = {"stchain_kernel": sp["chain"], "ugemm_kernel": sp["ugemm"], "out_conv": sp["ugemm"], "fgemm_kernel": sp["gemm"], "attn_kernel": sp["attn"]}.get(fam, False)
+    split = {"stchain_kernel": sp["chain"], "ugemm_kernel": sp["ugemm"], "out_conv": sp["ugemm"], "fgemm_kernel": sp["gemm"], "attn_kernel": sp["attn"], "attn2q_kernel": sp["attn"]}.get(fam, False)
     return ("mfma_f16", 3.0) if split else ("mfma_f32", 1.0)
 
 
@@ -256,7 +256,8 @@ def roofline(model, Be, T, step_ms, dtype, cfg_clips=0, traffic_key="cfg1", grou
                 pass
     agg = {}
     for st in stages:
-        name = (f"attn_kernel<D{32 * st['NB']},KS{st['KS']}>" if st["kind"] == 1 else
+        name = ("attn2q_kernel<4, 3>" if st["kind"] == 1 and st["KS"] == 34 else   # (three query tiles per wave: attn2q.hip)
+                f"attn_kernel<D{32 * st['NB']},KS{st['KS']}>" if st["kind"] == 1 else
                 "battn_kernel" if st["kind"] == 9 else
                 f"{'fgemm' if st['KS'] == 32 else 'tgemm'}_kernel<{st['NB']},{EPI_NAMES[st['epi']]}>" if st["kind"] == 4 else
                 "prep_kernel" if st["kind"] == 5 else
