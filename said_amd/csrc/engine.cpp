@@ -206,6 +206,7 @@ struct said_ctx {
     int kconv = -1;           // fp32 mode, small batch: the K-long ResBlock convolutions of the up path as straight-line two- / three-block waves (gemm_lds.hip kconv_body; -1 / 1: on,
                               // 0: ugemm_body's block loop — said_debug_option "kconv"; bit-identical)
     long long kconv_max_tiles = 4096;   // launches of at most this many (sample, token tile) pairs run the K-long convolutions as NB = 1 kconv_body workgroups when the chosen NB has no split shape
+    int chain_coef = -1;      // fp32 small batch: stchain_kernel takes the block input's GroupNorm coefficients from the q/k/v GEMM (-1 / 1: on; 0: finalises them itself — said_debug_option "chain_coef")
     int ugemm_split = -1;     // fp32 mode: the small-batch channel-major GEMMs (ugemm_kernel) on split-fp16 operands too (gemm_lds.hip: SP; weights pre-split on the host:
                               // Seg::ws).  Default (-1) and 1: ON; 0: fp32 MFMAs (said_debug_option "ugemm_split")
     int pw_split = 0;         // make_pw: also build the split-fp16 packing (1: per-block layout, 2: flat) — set around the UNet weights only
@@ -640,6 +641,9 @@ inline bool dbg_go(said_ctx* c) {
     return c->dbg_stop < 0 || k < c->dbg_stop;
 }
 
+// (a helper launch that is not a node of the counted schedule: runs whenever the NEXT counted launch would)
+inline bool dbg_go_peek(const said_ctx* c) { return c->dbg_only >= 0 ? c->dbg_count == c->dbg_only : (c->dbg_stop < 0 || c->dbg_count < c->dbg_stop); }
+
 // algorithmic HBM bytes / flops of one launch: weights + operands in + residual + result out
 // Multi-tile workgroups (gemm_lds.hip, MT): once a launch would have several thousand workgroups, each workgroup walks
 // over `tt` consecutive token tiles instead, keeping its weights in registers; tt is chosen so that ~4 workgroups per
@@ -663,7 +667,9 @@ static int pick_tt(said_ctx* c, const GemmArgs& a, int epi, int batch, int& NB, 
     return tt;
 }
 
-void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s) {
+// returns true when the launch went to ugemm_kernel (gemm_lds.hip) — the only kernel that honours GemmCommon::gn_coef_out / kv_split
+bool do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS, hipStream_t s) {
+    bool on_ugemm = false;
     GemmArgs a2 = a;
     a2.b0 = c->cur_b0;
     a2.kconv_off = (c->kconv == 0) ? 1 : 0;
@@ -697,14 +703,18 @@ void do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS,
     if (dbg_go(c)) {
         if (trace_on()) { fprintf(stderr, "[said] gemm #%d epi=%d NB=%d KS=%d T=%d N=%d batch=%d tt=%d\n", c->dbg_count - 1, epi, NB, KS, a.T, a.N, batch, tt); fflush(stderr); }
         const bool ug = c->use_ugemm && !a2.step_inc;
+        on_ugemm = true;
         if (tt > 1) launch_ugemm(a2, epi, batch, NB, KS, s, bf, tt);
         else if (sp) launch_ugemm(a2, epi, batch, NB, KS, s, 2);
         else if (ug && bf && ugemm_supports(a2, epi, NB, KS, true)) launch_ugemm(a2, epi, batch, NB, KS, s, true);
         else if (ug && ugemm_supports(a2, epi, NB, KS)) launch_ugemm(a2, epi, batch, NB, KS, s);
+        else on_ugemm = false;
+        if (on_ugemm) {}
         else if (epi == EPI_QKV && a2.kv_split) c->launch_err = "q/k/v GEMM asked for pre-split k / v but does not run on ugemm_kernel";
         else launch_gemm(a2, epi, batch, NB, KS, s);
         if (trace_on()) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, "[said]   -> %s\n", hipGetErrorString(e)); fflush(stderr); }
     }
+    return on_ugemm;
 }
 void do_attn(said_ctx* c, const AttnArgs& a, int batch, int head_dim, int KS, hipStream_t s, bool presplit = false) {
     if (c->log_on) {
@@ -1257,6 +1267,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
                        ((!tg && !use_tg(c, g, g.Be)) || c->st_chain_large) && tt <= c->st_chain_max_tiles && g.S == c->band_S && g.T == c->band_T;
     const bool out1_tm = tg && !chain && !c->bf16_mode && c->f32_out1_tm && tt1 * HEADS >= 2048 && sw.tf_out1;
     bool presplit = false;   // k and v stored as packed split-fp16 pairs for attn_kernel<PM = 3> (see below)
+    bool coef_ready = false; // the q/k/v GEMM left the block input's GroupNorm coefficients in gn_coef (small-batch ugemm_kernel only)
     if (tg) {   // q, k, v on the bf16 token-major GEMM: operand = LayerNorm(GroupNorm(x)) prepared once
         const int pk = (!c->bf16_mode && sp_on(c, c->gemm_split) && c->gemm_presplit != 0 && sw.tp_qkv) ? 1 : 0;   // operands arrive split (see run_resblock)
         PrepArgs p = mkprep(g, in.p, 1, c->uPL, (long long)tg_rows(g) * MC, MC, 0);
@@ -1307,7 +1318,10 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
                        (ugemm_supports(probe, EPI_QKV, lc.NB, lc.KS, 2) || ugemm_supports(probe, EPI_QKV, lc.NB, lc.KS));
             a.kv_split = presplit ? 1 : 0;
         }
-        do_gemm(c, a, EPI_QKV, n1, lc.NB, lc.KS, s);
+        // round 6: this GEMM finalises the block input's GroupNorm coefficients anyway (its operand is LayerNorm(GroupNorm(x))): the first workgroup of every sample
+        // leaves them for stchain_kernel, whose GroupNorm'ed residual then needs 2 loads per wave instead of 23 and no finalisation in front of its first barrier
+        if (chain && c->chain_coef != 0 && c->gn_coef) { a.gn_coef_out = c->gn_coef; a.gn_coef_bs = 2 * MC; }
+        coef_ready = do_gemm(c, a, EPI_QKV, n1, lc.NB, lc.KS, s) && a.gn_coef_out != nullptr;
     }
     bool out1_done = false;
     {   // softmax(q k^T * scale) v   (attention.py:99-126)
@@ -1346,7 +1360,12 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
             if (tt <= CHAIN3_MAX_TILES && c->st_chain_slices != 2) ca.slices = 3;
             else if (tt <= CHAIN2_MAX_TILES) ca.slices = 2;
         }
-        if (ca.slices > 1) { ca.wstream = ca.slices == 3 ? sw.chain_w3 : sw.chain_w2; ca.part = c->chain_part; ca.ticket = c->chain_ticket; }
+        if (ca.slices > 1) {
+            ca.wstream = ca.slices == 3 ? sw.chain_w3 : sw.chain_w2; ca.part = c->chain_part; ca.ticket = c->chain_ticket;
+            // the sliced kernels read the block input's GroupNorm coefficients (round 6): left by the q/k/v GEMM when it ran on ugemm_kernel, else made here
+            if (!coef_ready && dbg_go_peek(c)) launch_gn_coef(in.st, g.sts, 6, g.np, g.T, 1e-6f, sw.gn_g, sw.gn_b, c->gn_coef, 2 * MC, n1, s);
+            ca.gn_coef = c->gn_coef; ca.coef_bs = 2 * MC;
+        }
         if (c->clk_on && c->dbg_count < 64) ca.clk = c->clk_dev + (long long)c->dbg_count * 128;
         if (c->st_chain_dbg) { ca.dbg_x1 = c->X1; ca.dbg_x2 = c->X2; ca.dbg_o2 = c->X3; }
         if (c->log_on) {
@@ -2805,6 +2824,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->out_split = value < 0 ? -1 : (value != 0);
     } else if (k == "ugemm_split") {
         ctx->ugemm_split = value < 0 ? -1 : (value != 0);
+    } else if (k == "chain_coef") {
+        ctx->chain_coef = value < 0 ? -1 : (value != 0);
     } else if (k == "kconv") {
         ctx->kconv = value < 0 ? -1 : (value != 0);
     } else if (k == "kconv_max_tiles") {

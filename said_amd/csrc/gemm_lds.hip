@@ -419,6 +419,10 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 
     // ================= phase 1: GroupNorm coefficients of the wave's own slice; LN affine =================
     if constexpr (GN0) gn_finish(gp0, grp_rsrc0, w * (C0 / KS), C0 / KS, l, gl0, gnS, mainS + coef_off(0));
+    if constexpr (GN0 && EPI == EPI_QKV) {   // the sample's coefficients for stchain_kernel (one workgroup per sample; every wave its own channel slice)
+        float* const co = AH(gn_coef_out);
+        if (co && bx == 0 && by == 0 && l < 2 * (C0 / KS)) gstore(co, (long long)b * AH(gn_coef_bs) + 2 * w * (C0 / KS) + l, (mainS + coef_off(0))[2 * w * (C0 / KS) + l]);
+    }
     if constexpr (GN1) gn_finish(gp1, grp_rsrc1, w * (sC1 / KS), sC1 / KS, l, gl1, gnS, mainS + coef_off(1));
     if constexpr (HAS_LN) {
         float* cL = mainS + coef_off(0) + (GN0 ? 2 * C0 : 0);

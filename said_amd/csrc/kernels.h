@@ -114,6 +114,8 @@ struct GemmCommon {        // 8-byte members first, then 4-byte ones: no interna
             long long y2_bstride;  // and guidance-shared tensors are written once per clip into both halves' slots.
         };
     };
+    float* gn_coef_out;    // EPI_QKV on ugemm_kernel, or null: the first workgroup of every sample also stores segment 0's finalised GroupNorm (a, b) [sample][C][2]
+                           // (gn_coef_bs floats between samples) — stchain_kernel's GroupNorm'ed residual then needs no partials of its own (round 6)
     long long* clk;        // optional [KS][16] shader-clock stamps of workgroup (1,0,0) (debug)
     int* step_inc;         // if set, workgroup (0,0,0) increments *step_inc before anything else (loop step counter)
     int nseg;
@@ -133,6 +135,7 @@ struct GemmCommon {        // 8-byte members first, then 4-byte ones: no interna
     int stats_bstride;
     int geglu_gate_tiles;  // EPI_GEGLU: gate tile = value tile + geglu_gate_tiles
     int b0;                // batch offset: this launch covers samples [b0, b0 + gridDim.z)
+    int gn_coef_bs;
     int kconv_off;         // host only: 1 = the K-long ResBlock convolutions keep ugemm_body's block loop (said_debug_option "kconv" = 0; gemm_lds.hip kconv_body)
 };
 struct GemmArgs : GemmCommon {

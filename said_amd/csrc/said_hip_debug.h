@@ -39,6 +39,8 @@ extern "C" {
  *   "gemm_split"             fp32 mode, large batches: 0 puts fgemm_kernel back on v_mfma_f32_32x32x2_f32 (default -1 / 1: split-fp16 products)
  *   "attn_split"             fp32 mode: 0 puts both self-attention products back on fp32 MFMAs (default -1 / 1: split-fp16 products)
  *   "ugemm_split"            fp32 mode, channel-major GEMMs (ugemm_kernel): 0 = fp32 MFMAs (default -1 / 1: split-fp16 products, round 5)
+ *   "chain_coef"             fp32 mode, small batch: 0 = stchain_kernel finalises the block input's GroupNorm coefficients from the partials itself; -1 / 1 (default): it reads the
+ *                            coefficients the q/k/v GEMM of the same block finalised and left behind (GemmCommon::gn_coef_out, round 6)
  *   "kconv"                  fp32 mode, small batch: 0 = the K-long ResBlock convolutions of the up path (two / three K segments) keep ugemm_body's block loop; -1 / 1 (default):
  *                            kconv_body's straight-line blocks (round 6; bit-identical)
  *   "attn_2q"                fp32 mode, pre-split K / V, four key slices: 0 = one query tile per wave always; 1 = three always; -1 (default) = three from 512 (sample, head, query tile)

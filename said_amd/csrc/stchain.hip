@@ -455,7 +455,14 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         GnL20 gl;
         const GnP gp = {6, a.np, hd.T, 1e-6f, a.gn_gamma, a.gn_beta, 192};
         const rsrc_t rpart = make_rsrc(a.xin_part + (long long)in_idx * a.part_bs, 192u * (unsigned)a.np * 8u);
-        if (w < 4) gn20_issue(gp, rpart, 48 * w, l, gl);   // GroupNorm partials of x_in: waves 0-3 finalise 48 channels each (eps 1e-6, six channels per group)
+        float2 cf2 = make_float2(0.f, 0.f);
+        if constexpr (S3) {   // sliced (small) launches: the coefficients were finalised by the block's q/k/v GEMM (ugemm_kernel EPI_QKV: GemmCommon::gn_coef_out; engine.cpp runs
+                              // gn_coef_kernel when that GEMM took another kernel): waves 0-3 fetch 48 channels' (a, b) each — 1 load instead of 23, nothing to finalise
+            const rsrc_t rco = make_rsrc(a.gn_coef + (long long)in_idx * a.coef_bs, 192u * 8u);
+            if (w < 4) cf2 = bload2(rco, (l < 48) ? (48 * w + l) * 8 : (int)0x80000000, 0);
+        } else {
+            if (w < 4) gn20_issue(gp, rpart, 48 * w, l, gl);   // GroupNorm partials of x_in: waves 0-3 finalise 48 channels each (eps 1e-6, six channels per group)
+        }
         int blo = 0, bhi = 0;
         if constexpr (MODE == 0) {
             const rsrc_t rlo = make_rsrc(hd.lo, (unsigned)hd.T * 4u), rhi = make_rsrc(a.hi, (unsigned)hd.T * 4u);
@@ -521,7 +528,11 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
                 }
             }
         }
-        if (w < 4) gn20_finish(gp, rpart, 48 * w, l, gl, reinterpret_cast<float*>(smem + CH_R0) + w * GN_SCRATCH, reinterpret_cast<float*>(smem + CV::GNC));
+        if constexpr (S3) {
+            if (w < 4 && l < 48) reinterpret_cast<float2*>(smem + CV::GNC)[48 * w + l] = cf2;
+        } else {
+            if (w < 4) gn20_finish(gp, rpart, 48 * w, l, gl, reinterpret_cast<float*>(smem + CH_R0) + w * GN_SCRATCH, reinterpret_cast<float*>(smem + CV::GNC));
+        }
         __syncthreads();
         clk_stamp_c(clk, w, l, 1);
         // ---- to_out1 + GroupNorm'ed residual (attention.py:127, 168, 226-227) ----
@@ -897,7 +908,7 @@ void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T,
     dim3 grid((T + 31) / 32, nsamp);
     if (bf16) hipLaunchKernelGGL((stchain_kernel<true, 1>), grid, dim3(512), Carve<true>::LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
     else if (a.slices == 3 || a.slices == 2) {
-        if (!a.part || !a.ticket) { launch_fault("stchain: a sliced launch needs the partial-sum buffer and the tickets"); return; }
+        if (!a.part || !a.ticket || !a.gn_coef) { launch_fault("stchain: a sliced launch needs the partial-sum buffer, the tickets and the block input's GroupNorm coefficients"); return; }
         if (a.slices == 3) hipLaunchKernelGGL((stchain_kernel<false, 3>), dim3(grid.x, grid.y, 3), dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
         else hipLaunchKernelGGL((stchain_kernel<false, 2>), dim3(grid.x, grid.y, 2), dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
     } else hipLaunchKernelGGL((stchain_kernel<false, 1>), grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);

@@ -460,3 +460,28 @@ def test_several_query_tiles_per_wave_are_bit_identical(dev, B, T, opt):
     print(f"B={B} T={T} attn_2q={opt}: max |diff| to one tile per wave {float((y - y0).abs().max()):.3e}" + (f"; vs oracle {e:.2e} of range" if T <= 600 else ""))
     assert torch.equal(y, y0)
     assert e <= 1e-4
+
+
+# ---------------------------------------------------------------- the sliced fused tail takes the block input's GroupNorm coefficients from the q/k/v GEMM
+@pytest.mark.parametrize("B,T", [(2, 600), (1, 37), (3, 333), (2, 1800)])
+def test_sliced_tail_reads_the_groupnorm_coefficients_the_qkv_gemm_finalised(dev, B, T):
+    """A SpatialTransformer's q/k/v GEMM normalises the block input (GroupNorm -> LayerNorm) and so finalises its GroupNorm coefficients; the fused tail needs the same
+    coefficients for the residual of attn1.to_out.  The GEMM's first workgroup per sample stores them and the sliced stchain kernels read them (1 load per wave instead
+    of 23, no finalisation in front of the first barrier).  With "chain_coef" = 0 the GEMM does not export and a gn_coef_kernel launch makes them instead (the fall-back
+    for a q/k/v GEMM that took another kernel): the two finalisations sum a channel's tiles in different groupings — 1e-6 of range apart, both at the oracle's distance."""
+    sd = _base_sd()
+    m = _make(sd, dev)
+    x, ts, c = _inputs(B, T, seed=37)
+    eng = m._get_engine(max(B, 2), max(T, 64))
+    y = _fwd(m, dev, x, ts, c)
+    eng.debug_option("chain_coef", 0)
+    try:
+        y0 = _fwd(m, dev, x, ts, c)
+    finally:
+        eng.debug_option("chain_coef", -1)
+    y2 = _fwd(m, dev, x, ts, c)
+    e0 = _rel(y, y0)
+    e = _rel(y, _oracle(sd, x, ts, c)) if T <= 600 else 0.0
+    print(f"B={B} T={T}: coefficients from the q/k/v GEMM vs a gn_coef_kernel launch: {e0:.2e} of range; vs oracle {e:.2e}")
+    assert torch.equal(y, y2)
+    assert e0 <= 1e-6 and e <= 1e-4
