@@ -238,27 +238,27 @@ __device__ __forceinline__ void gn_finish(const GnP sg, rsrc_t rp, int c_lo, int
         sm += __shfl_xor(sm, 32);
     }
     float* sc = scratch;            // [64][3]
-    float* gs = scratch + 64 * 3;   // [16][2] (mean, rstd) per group of this wave
     if (ph == 0 && chok) { sc[ch * 3] = s1; sc[ch * 3 + 1] = s2; sc[ch * 3 + 2] = sm; }
     const float rcp_cpg = __builtin_amdgcn_rcpf((float)sg.gn_cpg);
-    const int gpw = (int)(((float)cw + 0.5f) * rcp_cpg);
-    if (lane < gpw) {
+    // Round 6: EVERY lane sums its own group's channels (the lanes of a group read the same scratch words: LDS broadcasts) and derives (mean, rstd) itself — the first version
+    // let one lane per group do that and hand the pair to the others through LDS: a second write -> read round trip and a serial 3 x cpg-read loop in 4 of 64 lanes on the
+    // critical path of every GroupNorm'ed kernel.  Same summation order (q = 0 .. cpg - 1 onto 0), same formulas: bit-identical.
+    if (ph == 0 && chok) {
+        const int gi = (int)(((float)ch + 0.5f) * rcp_cpg);
+        const float* g0 = sc + gi * sg.gn_cpg * 3;
         float S1 = 0.f, S2 = 0.f, SM = 0.f;
-        for (int q = 0; q < sg.gn_cpg; ++q) {
-            const int cc = lane * sg.gn_cpg + q;
-            S1 += sc[cc * 3]; S2 += sc[cc * 3 + 1]; SM += sc[cc * 3 + 2];
+        if (sg.gn_cpg == 6) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { S1 += g0[q * 3]; S2 += g0[q * 3 + 1]; SM += g0[q * 3 + 2]; }
+        } else {
+            for (int q = 0; q < sg.gn_cpg; ++q) { S1 += g0[q * 3]; S2 += g0[q * 3 + 1]; SM += g0[q * 3 + 2]; }
         }
         const float total = (float)sg.gn_cpg * (float)sg.Tin;
         const float inv_total = __builtin_amdgcn_rcpf(total);   // 1-ulp reciprocal / rsqrt: this chain is on every
         const float md = S1 * inv_total;                        // GroupNorm'ed kernel's critical path
         const float var = fmaxf((SM + S2 - total * md * md) * inv_total, 0.f);
-        gs[lane * 2] = md;  // mean relative to the group's ref; each lane adds its own ref back
-        gs[lane * 2 + 1] = __builtin_amdgcn_rsqf(var + sg.gn_eps);
-    }
-    if (ph == 0 && chok) {
-        const int gi = (int)(((float)ch + 0.5f) * rcp_cpg);
-        const float mean = L.ref + gs[gi * 2];
-        const float av = gs[gi * 2 + 1] * L.gamma;
+        const float mean = L.ref + md;  // (md: mean relative to the group's ref)
+        const float av = __builtin_amdgcn_rsqf(var + sg.gn_eps) * L.gamma;
         cA[2 * c] = av;
         cA[2 * c + 1] = L.beta - mean * av;
     }
@@ -314,27 +314,24 @@ __device__ __forceinline__ void gn20_finish(const GnP sg, rsrc_t rp, int c_lo, i
         }
     }
     float* sc = scratch;            // [64][3]
-    float* gs = scratch + 64 * 3;   // [16][2] (mean, rstd) per group of this slice
     if (chok) { sc[lane * 3] = s1; sc[lane * 3 + 1] = s2; sc[lane * 3 + 2] = sm; }
     const float rcp_cpg = __builtin_amdgcn_rcpf((float)sg.gn_cpg);
-    const int gpw = (int)((48.0f + 0.5f) * rcp_cpg);
-    if (lane < gpw) {
+    if (chok) {   // (every lane sums its own group: gn_finish)
+        const int gi = (int)(((float)lane + 0.5f) * rcp_cpg);
+        const float* g0 = sc + gi * sg.gn_cpg * 3;
         float S1 = 0.f, S2 = 0.f, SM = 0.f;
-        for (int q = 0; q < sg.gn_cpg; ++q) {
-            const int cc = lane * sg.gn_cpg + q;
-            S1 += sc[cc * 3]; S2 += sc[cc * 3 + 1]; SM += sc[cc * 3 + 2];
+        if (sg.gn_cpg == 6) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { S1 += g0[q * 3]; S2 += g0[q * 3 + 1]; SM += g0[q * 3 + 2]; }
+        } else {
+            for (int q = 0; q < sg.gn_cpg; ++q) { S1 += g0[q * 3]; S2 += g0[q * 3 + 1]; SM += g0[q * 3 + 2]; }
         }
         const float total = (float)sg.gn_cpg * (float)sg.Tin;
         const float inv_total = __builtin_amdgcn_rcpf(total);
         const float md = S1 * inv_total;
         const float var = fmaxf((SM + S2 - total * md * md) * inv_total, 0.f);
-        gs[lane * 2] = md;
-        gs[lane * 2 + 1] = __builtin_amdgcn_rsqf(var + sg.gn_eps);
-    }
-    if (chok) {
-        const int gi = (int)(((float)lane + 0.5f) * rcp_cpg);
-        const float mean = L.ref + gs[gi * 2];
-        const float av = gs[gi * 2 + 1] * L.gamma;
+        const float mean = L.ref + md;
+        const float av = __builtin_amdgcn_rsqf(var + sg.gn_eps) * L.gamma;
         cA[2 * c] = av;
         cA[2 * c + 1] = L.beta - mean * av;
     }
