@@ -509,19 +509,26 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
         __syncthreads();
         const float invC = 1.0f / (float)C0;
         const float nw = (float)(8 * NRMAX);   // values per wave and token
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float mean = lnred[(4 * sq + e) * 2], M2 = lnred[(4 * sq + e) * 2 + 1];
+        // Round 6: a lane merges the KS partials of ONE token (lane & 31) and the wave shares the 32 (mean, rstd) pairs through its own scratch — every lane used to merge all
+        // four tokens of its quad, the same four as the seven other staging rows of the wave: 4 x 7 merges (~170 VALU instructions) per lane on the critical path of every
+        // LayerNorm'ed GEMM, 3/4 of them redundant.  Same merge order per token: bit-identical.
+        {
+            const int tk = l & 31;
+            float mean = lnred[tk * 2], M2 = lnred[tk * 2 + 1];
 #pragma unroll
             for (int w2 = 1; w2 < KS; ++w2) {   // fixed order
-                const float mk = lnred[(w2 * 32 + 4 * sq + e) * 2], qk = lnred[(w2 * 32 + 4 * sq + e) * 2 + 1];
+                const float mk = lnred[(w2 * 32 + tk) * 2], qk = lnred[(w2 * 32 + tk) * 2 + 1];
                 const float d = mk - mean;
                 const float n = nw * (float)w2, nn = n + nw;
                 mean = fmaf(d, nw / nn, mean);
                 M2 += qk + d * d * (n * nw / nn);
             }
-            mu4[e] = mean;
-            rs4[e] = __builtin_amdgcn_rsqf(M2 * invC + ln_eps);   // v_rsq_f32 (1 ulp): the IEEE 1/sqrt sequence is ~40 VALU ops
+            const float rstd = __builtin_amdgcn_rsqf(M2 * invC + ln_eps);   // v_rsq_f32 (1 ulp): the IEEE 1/sqrt sequence is ~40 VALU ops
+            float* const lst = gnS;   // (the wave's GroupNorm scratch is free by now; same-wave LDS accesses are ordered: no barrier)
+            if (l < 32) { lst[2 * tk] = mean; lst[2 * tk + 1] = rstd; }
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(lst + 8 * sq), p1 = *reinterpret_cast<const f32x4*>(lst + 8 * sq + 4);
+            mu4[0] = p0[0]; rs4[0] = p0[1]; mu4[1] = p0[2]; rs4[1] = p0[3];
+            mu4[2] = p1[0]; rs4[2] = p1[1]; mu4[3] = p1[2]; rs4[3] = p1[3];
         }
     }
     clk_stamp_p(clkp, w, l, 3);
