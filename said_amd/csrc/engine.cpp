@@ -183,6 +183,7 @@ struct said_ctx {
                               // step at 32 clips) was removed in round 6 together with xgemm_kernel's fp32 instantiations.
     bool mt_mid = true;       // multi-tile workgroups for mid-size launches too (said_debug_option "mt_mid")
     int mt_wgs = 0;           // > 0: multi-tile workgroups from this many workgroups per token tile on (said_debug_option "mt_wgs"; default 1024)
+    int tgemm_direct = -1;    // audio encoder (bf16): the projections on tgemm256d_kernel (256 x 256 tile, operand tiles loaded straight into LDS; -1 / 1: on, 0: tgemm_kernel<128> — said_debug_option "tgemm_direct")
     int tgemm_sb = 1;         // audio encoder (bf16): the single-LDS-buffer 128 x 128 GEMM variant, three workgroups per CU (said_debug_option "tgemm_sb"; 0: double buffer, two per CU)
     int unet_nb = 0;          // > 0: forces pick_unet's column tiles per workgroup (said_debug_option "unet_nb")
     bool unet_nb_model = true; // pick_unet by the busiest-CU model (0: round 2's rule; said_debug_option "unet_nb_model")
@@ -2826,6 +2827,8 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
         ctx->ugemm_split = value < 0 ? -1 : (value != 0);
     } else if (k == "chain_coef") {
         ctx->chain_coef = value < 0 ? -1 : (value != 0);
+    } else if (k == "tgemm_direct") {
+        ctx->tgemm_direct = value < 0 ? -1 : (value != 0);
     } else if (k == "kconv") {
         ctx->kconv = value < 0 ? -1 : (value != 0);
     } else if (k == "kconv_max_tiles") {
@@ -3219,7 +3222,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     a.a = ctx->bHb; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.qkv; a.bias = ly.qkv.bias;
                     a.qk = ctx->aQK; a.vt = ctx->aVT; a.v_bs = hs; a.qk_n = 2 * W2V_H; a.head_dim = W2V_HD; a.rows = Fp; a.heads2 = 2 * W2V_HEADS;
                     a.v_pitch = Fp; a.M = Fr; a.N = 3 * W2V_H; a.K = W2V_H;
-                    a.sb = ctx->tgemm_sb;
+                    a.sb = ctx->tgemm_sb; a.direct = ctx->tgemm_direct != 0;
                     if (!launch_tgemm(a, nb, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 {
@@ -3241,7 +3244,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     a.a = ctx->bO; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.out; a.bias = ly.out.bias;
                     a.res = ctx->bH; a.res_bs = hsT; a.ldr = W2V_H;
                     a.yf = ctx->bT; a.y_bs = hsT; a.ldy = W2V_H; a.M = nb * Fr; a.N = W2V_H; a.K = W2V_H;
-                    a.sb = ctx->tgemm_sb;
+                    a.sb = ctx->tgemm_sb; a.direct = ctx->tgemm_direct != 0;
                     if (!launch_tgemm(a, 1, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 launch_ln_tm(ctx->bT, nullptr, ctx->bH, ctx->bHb, ly.ln1g, ly.ln1b, (long long)nb * Fr, W2V_H, 1e-5f, s);
@@ -3250,7 +3253,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     memset(&a, 0, sizeof a);
                     a.a = ctx->bHb; a.a_bs = hsT; a.lda = W2V_H; a.w = bl.ff1; a.bias = ly.ff1.bias; a.act = 1;
                     a.yb = ctx->bF; a.y_bs = (long long)Fr * W2V_FFN; a.ldy = W2V_FFN; a.M = nb * Fr; a.N = W2V_FFN; a.K = W2V_H;
-                    a.sb = ctx->tgemm_sb;
+                    a.sb = ctx->tgemm_sb; a.direct = ctx->tgemm_direct != 0;
                     if (!launch_tgemm(a, 1, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 {   // feed_forward.output_dense + residual, then final_layer_norm
@@ -3259,7 +3262,7 @@ int said_audio_encode(said_ctx* ctx, const float* wav_dev, int B, int Ta, int nu
                     a.a = ctx->bF; a.a_bs = (long long)Fr * W2V_FFN; a.lda = W2V_FFN; a.w = bl.ff2; a.bias = ly.ff2.bias;
                     a.res = ctx->bH; a.res_bs = hsT; a.ldr = W2V_H;
                     a.yf = ctx->bT; a.y_bs = hsT; a.ldy = W2V_H; a.M = nb * Fr; a.N = W2V_H; a.K = W2V_FFN;
-                    a.sb = ctx->tgemm_sb;
+                    a.sb = ctx->tgemm_sb; a.direct = ctx->tgemm_direct != 0;
                     if (!launch_tgemm(a, 1, s)) ctx->launch_err = "audio encoder: token-major GEMM shape not served";
                 }
                 const bool last = l + 1 == ctx->w2v_layers && !apply_proj;   // the last LayerNorm writes the (B, frames, 768) result itself

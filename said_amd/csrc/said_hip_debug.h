@@ -28,6 +28,8 @@ extern "C" {
  *   "mt_wgs"                 > 0: workgroups per token tile from which a launch goes multi-tile (overrides both rules)
  *   "tgemm_sb"               0: the bf16 audio encoder's 128 x 128 GEMM tiles keep two LDS operand buffers (two workgroups per CU; round 2); default 1: one
  *                            buffer, three workgroups per CU (11.12 -> 10.90 ms per 32 clips, bit-identical)
+ *   "tgemm_direct"           0: the bf16 audio encoder's projections on tgemm_kernel<128> (rounds 2-5); -1 / 1 (default): on tgemm256d_kernel — 256 x 256 x 64 tile, operand tiles
+ *                            loaded global -> LDS directly, XOR-swizzled chunks, one barrier per k-tile (round 6; bit-identical)
  *   "f32_out1_tm"            0: fp32 mode at large batch runs attn1.to_out on the channel-major kernel (round 2); default 1: on the token-major fp32 GEMM
  *   "unet_nb_model"          0: round 2's rule for the column tiles per workgroup of the 192-wide channel-major GEMMs (default 1: busiest-CU model)
  *   "unet_nb"                > 0: forces that number of column tiles per workgroup (1, 2 or 3)

@@ -61,6 +61,7 @@ struct TGemmArgs {
     // operands addressed through a_bs (audio encoder).
     int seg_rows;
     int sb;                // tgemm_kernel<128> only: 1 = single-LDS-buffer variant (four workgroups per CU)
+    int direct;            // 1: per-sample operands with N % 256 == 0 run tgemm256d_kernel (256 x 256 tile, operand tiles loaded straight into LDS; round 6)
     int grp;               // tgemm_kernel only: > 1 = grouped launch, the batch axis is (sample, group) [batch = samples x grp]; group g reads A at
     long long a_gs, w_gs;  //   a + sample a_bs + g a_gs and W at w + g w_gs (elements) and owns the output columns [g col_gs, g col_gs + n_store)
     int col_gs;            //   of bias / res / y (the wav2vec2 positional convolution: 16 groups of 48 channels)

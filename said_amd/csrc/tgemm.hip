@@ -291,6 +291,100 @@ __global__ __launch_bounds__(512) void tgemm256_kernel(const TGemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// tgemm256d_kernel (round 6): the 256 x 256 x 64 tile with its operand tiles fetched global -> LDS DIRECTLY (buffer_load_dwordx4 ... lds): no staging registers, no
+// LDS stores, one barrier per k-tile.  Direct loads write a wave's 64 x 16 bytes contiguously (8 rows x 128 bytes: no row padding), so the 16-byte chunks are
+// XOR-swizzled instead — LDS chunk p of row r holds the row's k-chunk p ^ (r & 7), and a fragment read of chunk c takes p = c ^ (r & 7): eight consecutive rows hit
+// eight different bank groups.  Bring-up and knock-outs: scripts/ubench/bgemm.hip (profiles/r06k_bgemm_bringup.txt): the audio encoder's four projection shapes at
+// 32 clips take 77 / 28 / 85 / 83 us with a plain store epilogue where tgemm_kernel<128, SB> averages 124 and tgemm256_kernel 135; with every load, barrier and
+// LDS read of the k16 steps knocked out the loop still takes 63-65 us: prologue, epilogue and three rounds of 256 workgroups are what is left above the MFMAs.
+// Same operands, same k order per accumulator as the other bf16 tiles: bit-identical results.  Per-sample operands only (seg_rows == 0), one K segment, N % 256 == 0.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int TG256D_TILE = (256 + 256) * 128;                                   // bytes of one buffer: A 256 rows + W 256 rows x 64 bf16
+constexpr int TG256D_LDS = 2 * TG256D_TILE > 8 * 32 * (32 * 4 + 4) * 4 ? 2 * TG256D_TILE : 8 * 32 * (32 * 4 + 4) * 4;   // two buffers / the epilogue's per-wave scratch
+__global__ __launch_bounds__(512) void tgemm256d_kernel(const TGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    constexpr int BM2 = 256, BN = 256, NJ = 4;
+    char* const ldsb = reinterpret_cast<char*>(lds);
+    const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int NT = a.N / BN, MT = (a.M + BM2 - 1) / BM2;
+    const unsigned L = blockIdx.x, xcd = L & 7u, slot = L >> 3;   // XCD-aware order, as in tgemm_kernel
+    const int nt = (int)(slot % (unsigned)NT);
+    const int mg = (int)(slot / (unsigned)NT) * 8 + (int)xcd;
+    const int b = mg / MT, mt_ = mg - b * MT;
+    if (b >= a.batch) return;
+    const int m0 = mt_ * BM2, n0 = nt * BN;
+    const int nk = a.K / TBK;
+    const rsrc_t ra = make_rsrc(reinterpret_cast<const unsigned short*>(a.a) + (long long)b * a.a_bs, (unsigned)(((long long)(a.M - 1) * a.lda + a.K) * 2));
+    const rsrc_t rw = make_rsrc(a.w, (unsigned)((long long)a.N * a.K * 2));
+    // wave-load j of an operand tile = rows 8 j .. 8 j + 7 (1 KB, contiguous in LDS); lane -> (row 8 j + (l >> 3), LDS chunk l & 7) = the row's k-chunk (l & 7) ^ (l >> 3)
+    const int lrow = l >> 3, lchunk = (l & 7) ^ lrow;
+    int aoff[4], woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = w * 4 + i;
+        aoff[i] = (min(m0 + 8 * j + lrow, a.M - 1) * a.lda + lchunk * 8) * 2;   // rows past M repeat the last row (never stored)
+        woff[i] = ((n0 + 8 * j + lrow) * a.K + lchunk * 8) * 2;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* base = ldsb + buf * TG256D_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = w * 4 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(base + j * 1024), 16, aoff[i], kt * (TBK * 2), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + BM2 * 128 + j * 1024), 16, woff[i], kt * (TBK * 2), 0, 0);
+        }
+    };
+    f32x16 acc0[NJ], acc1[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
+    const int frow = l & 31, fh = l >> 5;
+    auto compute = [&](int buf) {
+        const char* pa = ldsb + buf * TG256D_TILE;
+        const char* pw = pa + BM2 * 128;
+#pragma unroll
+        for (int ks = 0; ks < TBK / 16; ++ks) {
+            const int c = ks * 2 + fh;
+            bf16x8 fa[2], fb[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + frow;
+                fa[i] = *reinterpret_cast<const bf16x8*>(pa + row * 128 + ((c ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int row = wn * (32 * NJ) + j * 32 + frow;
+                fb[j] = *reinterpret_cast<const bf16x8*>(pw + row * 128 + ((c ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[j], acc0[j], 0, 0, 0);
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[j], acc1[j], 0, 0, 0);
+            }
+        }
+    };
+    issue(0, 0);
+    __builtin_amdgcn_s_waitcnt(0);   // (vmcnt(0): the tile is in LDS)
+    __syncthreads();
+    for (int kt = 0; kt < ((a.dbg & 2) ? 0 : nk); ++kt) {
+        // tile kt + 1 goes into the buffer tile kt - 1 was read from: every wave passed the barrier that ended that step
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    }
+    // the K loop ended with a barrier: the operand buffers are free and serve as per-wave transposition scratch
+    float* sc = reinterpret_cast<float*>(lds) + w * (32 * (32 * NJ + 4));
+    tg_epilogue<NJ>(a, acc0, b, m0 + wm * 64, n0 + wn * (32 * NJ), l, sc);
+    tg_epilogue<NJ>(a, acc1, b, m0 + wm * 64 + 32, n0 + wn * (32 * NJ), l, sc);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // fp32 token-major GEMM (fp32 mode, large batches: BASELINE configs[3]'s per-GPU work) on v_mfma_f32_32x32x2_f32.
 // Same operand geometry in BYTES as the bf16 kernels — a k-tile is 128 bytes per row (32 floats), LDS rows 144 bytes, 16-byte
 // fragment reads — and the same epilogue.  A lane's 16-byte fragment holds k = 8 s + 4 (l >> 5) + {0..3}; MFMA i of step s
@@ -1316,6 +1410,7 @@ int tgemm_geglu_src_row(int n, int N) {
     return (j & 1) ? N / 2 + c : c;
 }
 void configure_tgemm_kernel() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm256d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TG256D_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (TBM + 128) * TLP * 2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TBM + 128) * TLP * 2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TBM + 64) * TLP * 2);
@@ -1403,6 +1498,13 @@ bool launch_tgemm(const TGemmArgs& a, int batch, hipStream_t s) {
         const double e_big = (double)g_big / (double)(((g_big + 255) / 256) * 256) * (double)rows_tot / (double)(mt_big * 256);
         const double e_128 = (double)g_128 / (double)(((g_128 + 511) / 512) * 512) * (double)a.M / (double)(mt_128 * TBM);
         if (e_128 > e_big + 0.01 * balance) use_big = false;
+    }
+    // round 6: per-sample operands with 256-wide outputs (the audio encoder's projections): the direct-to-LDS 256 x 256 tile (a.direct; said_debug_option "tgemm_direct")
+    if (a.direct && a.grp <= 1 && a.seg_rows == 0 && !a.geglu && !a.a2 && a.N % 256 == 0 && a.K % TBK == 0 && (long long)a.M * batch >= 4096 &&
+        ((long long)(a.M - 1) * a.lda + a.K) * 2 < 0x7fffffffLL && (long long)a.N * a.K * 2 < 0x7fffffffLL) {
+        const long long mt8 = ((long long)batch * ((a.M + 255) / 256) + 7) / 8 * 8;
+        hipLaunchKernelGGL(tgemm256d_kernel, dim3((unsigned)(mt8 * (a.N / 256))), dim3(512), TG256D_LDS, s, a2);
+        return true;
     }
     if (a.sb && a.seg_rows == 0 && !a.geglu && a.N % 128 == 0) use_big = false;   // the single-buffer 128 x 128 variant was asked for
     if (use_big) {

@@ -485,3 +485,26 @@ def test_sliced_tail_reads_the_groupnorm_coefficients_the_qkv_gemm_finalised(dev
     print(f"B={B} T={T}: coefficients from the q/k/v GEMM vs a gn_coef_kernel launch: {e0:.2e} of range; vs oracle {e:.2e}")
     assert torch.equal(y, y2)
     assert e0 <= 1e-6 and e <= 1e-4
+
+
+# ---------------------------------------------------------------- bf16 audio encoder: the projections on the direct-to-LDS 256 x 256 tile (tgemm.hip tgemm256d_kernel)
+@pytest.mark.parametrize("B,Ta", [(32, 160000), (9, 16000 * 3), (40, 16000)])
+def test_direct_to_lds_gemm_tile_is_bit_identical_to_the_staged_tiles(dev, B, Ta):
+    """bf16 mode's audio encoder runs its q/k/v, out_proj and feed-forward projections (where a pass has >= 4096 rows) on tgemm256d_kernel: 256 x 256 x 64 tiles whose
+    operand tiles go global -> LDS directly (XOR-swizzled 16-byte chunks, one barrier per k-tile).  Same operands, same k order per accumulator as tgemm_kernel<128>
+    (said_debug_option "tgemm_direct" = 0): the embedding is bit-identical — rows past the last tile boundary (499 / 149 / 49 frames per clip), a 40-clip batch in two
+    passes; and it stays at the oracle's bf16 distance (tests/test_gpu_parity.py::test_bf16_audio_encoder_vs_fp32_oracle runs on it: it is the default)."""
+    m = _make(_base_sd(), dev)   # (two encoder layers: eight projection GEMMs per pass)
+    F = int(Ta / 16000 * 60)
+    proc = op.process_audio([synth.synth_waveform(700 + i, Ta).numpy() for i in range(B)]).to(dev)
+    eng = m._get_engine(2, 64)
+    try:
+        m.set_mfma_dtype("bf16")
+        y1 = m.get_audio_embedding(proc, F).cpu()
+        eng.debug_option("tgemm_direct", 0)
+        y0 = m.get_audio_embedding(proc, F).cpu()
+    finally:
+        eng.debug_option("tgemm_direct", -1)
+        m.set_mfma_dtype("fp32")
+    print(f"B={B} Ta={Ta}: direct-to-LDS tile vs staged tiles max |diff| {float((y1 - y0).abs().max()):.3e} (|y| max {float(y0.abs().max()):.2f})")
+    assert torch.isfinite(y1).all() and torch.equal(y1, y0)
