@@ -1275,7 +1275,7 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
         p.pack = pk;
         prep_gn(c, p, g, in.st, 6, 1e-6f, sw.gn_g, sw.gn_b, n1, 0, s);
         p.ln_gamma = sw.l1g; p.ln_beta = sw.l1b;
-        if (out1_tm && p.part) { p.coef_out = c->gn_coef; p.coef_out_bs = 2 * MC; }
+        if ((out1_tm || (chain && c->chain_coef != 0)) && p.part) { p.coef_out = c->gn_coef; p.coef_out_bs = 2 * MC; coef_ready = chain; }   // (the fp32 fused tail reads them too: round 6)
         do_prep(c, p, n1, s);
         TGemmArgs t = mktg(g, c->uPL, MC, pk ? sw.tp_qkv : tw(c, sw.t_qkv, sw.tf_qkv), 3 * MC, MC);
         t.f32_packed = pk;
@@ -1361,12 +1361,10 @@ void run_transformer(said_ctx* c, const UGeo& g, const STW& sw, int blk, const A
             if (tt <= CHAIN3_MAX_TILES && c->st_chain_slices != 2) ca.slices = 3;
             else if (tt <= CHAIN2_MAX_TILES) ca.slices = 2;
         }
-        if (ca.slices > 1) {
-            ca.wstream = ca.slices == 3 ? sw.chain_w3 : sw.chain_w2; ca.part = c->chain_part; ca.ticket = c->chain_ticket;
-            // the sliced kernels read the block input's GroupNorm coefficients (round 6): left by the q/k/v GEMM when it ran on ugemm_kernel, else made here
-            if (!coef_ready && dbg_go_peek(c)) launch_gn_coef(in.st, g.sts, 6, g.np, g.T, 1e-6f, sw.gn_g, sw.gn_b, c->gn_coef, 2 * MC, n1, s);
-            ca.gn_coef = c->gn_coef; ca.coef_bs = 2 * MC;
-        }
+        if (ca.slices > 1) { ca.wstream = ca.slices == 3 ? sw.chain_w3 : sw.chain_w2; ca.part = c->chain_part; ca.ticket = c->chain_ticket; }
+        // the fp32 kernels read the block input's GroupNorm coefficients (round 6): left by the q/k/v GEMM (ugemm_kernel) or its operand preparation (prep_kernel), else made here
+        if (!coef_ready && dbg_go_peek(c)) launch_gn_coef(in.st, g.sts, 6, g.np, g.T, 1e-6f, sw.gn_g, sw.gn_b, c->gn_coef, 2 * MC, n1, s);
+        ca.gn_coef = c->gn_coef; ca.coef_bs = 2 * MC;
         if (c->clk_on && c->dbg_count < 64) ca.clk = c->clk_dev + (long long)c->dbg_count * 128;
         if (c->st_chain_dbg) { ca.dbg_x1 = c->X1; ca.dbg_x2 = c->X2; ca.dbg_o2 = c->X3; }
         if (c->log_on) {

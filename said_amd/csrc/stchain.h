@@ -23,8 +23,8 @@ constexpr int CHAIN_VEC_FLOATS_LDS = 4 * 192 + 1536;    // LDS: bo2 | c2 share a
 struct ChainArgs {
     const float* wstream;    // this block's weight stream (fp16 h / l planes in each wave's consumption order: engine.cpp pack_chain_stream)
     const float* xin_part;   // GroupNorm partials of the block input [sample][tile][192][2] (mean, M2)
-    const float* gn_coef;    // sliced launches (slices > 1; round 6): the block input's finalised GroupNorm (a, b) [sample][192][2] as the q/k/v GEMM left them (coef_bs floats
-                             // between samples) — 1 load per wave instead of 23 and no finalisation in front of the first barrier; one workgroup per tile: finalised from xin_part
+    const float* gn_coef;    // fp32 kernels (round 6): the block input's finalised GroupNorm (a, b) [sample][192][2] as the q/k/v GEMM or its operand preparation left them (coef_bs
+                             // floats between samples) — 1 load per wave instead of 23 and no finalisation in front of the first barrier; the bf16 kernel finalises from xin_part
     long long coef_bs;
     const float* gn_gamma;   // SpatialTransformer.norm (eps 1e-6)
     const float* gn_beta;

@@ -274,6 +274,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
     using U = CU<SC>;
     constexpr int NSL = U::NS;
     constexpr bool S3 = NSL > 1;   // sliced launch
+    constexpr bool COEF = !BF;     // fp32 variants read the block input's finalised GroupNorm coefficients (ChainArgs::gn_coef); the bf16 variant finalises them from the partials
     static_assert(!(BF && S3), "the sliced variants exist for the fp32 mode's small launches only");
     constexpr int U_FF = U::FF, U_HALF = U::HALF, U_END = U::END, U_W45 = U::W45, U_W67 = U::W67;
     constexpr int NR = BF ? CH_NR_BF : ((MODE == 2) ? CH_NR_HELPER : CH_NR_OWNER);
@@ -456,8 +457,8 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         const GnP gp = {6, a.np, hd.T, 1e-6f, a.gn_gamma, a.gn_beta, 192};
         const rsrc_t rpart = make_rsrc(a.xin_part + (long long)in_idx * a.part_bs, 192u * (unsigned)a.np * 8u);
         float2 cf2 = make_float2(0.f, 0.f);
-        if constexpr (S3) {   // sliced (small) launches: the coefficients were finalised by the block's q/k/v GEMM (ugemm_kernel EPI_QKV: GemmCommon::gn_coef_out; engine.cpp runs
-                              // gn_coef_kernel when that GEMM took another kernel): waves 0-3 fetch 48 channels' (a, b) each — 1 load instead of 23, nothing to finalise
+        if constexpr (COEF) { // fp32 mode: the coefficients were finalised by the block's q/k/v GEMM or its operand preparation (ugemm_kernel EPI_QKV: GemmCommon::gn_coef_out;
+                              // prep_kernel: PrepArgs::coef_out; engine.cpp runs gn_coef_kernel otherwise): waves 0-3 fetch 48 channels' (a, b) each — 1 load instead of 23, nothing to finalise
             const rsrc_t rco = make_rsrc(a.gn_coef + (long long)in_idx * a.coef_bs, 192u * 8u);
             if (w < 4) cf2 = bload2(rco, (l < 48) ? (48 * w + l) * 8 : (int)0x80000000, 0);
         } else {
@@ -528,7 +529,7 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
                 }
             }
         }
-        if constexpr (S3) {
+        if constexpr (COEF) {
             if (w < 4 && l < 48) reinterpret_cast<float2*>(smem + CV::GNC)[48 * w + l] = cf2;
         } else {
             if (w < 4) gn20_finish(gp, rpart, 48 * w, l, gl, reinterpret_cast<float*>(smem + CH_R0) + w * GN_SCRATCH, reinterpret_cast<float*>(smem + CV::GNC));
@@ -906,9 +907,10 @@ bool stchain_supports(const ChainArgs& a, int T, int pitch, long long o_bs, long
 void launch_stchain(const ChainArgs& a, const float* o, const float* xin, int T, int pitch, long long o_bs, long long x_bs, int in_mod, int n_uncond, int nsamp, hipStream_t s, bool bf16) {
     if (!stchain_supports(a, T, pitch, o_bs, x_bs)) { launch_fault("stchain: unsupported arguments (T %d, window %d)", T, a.wmax); return; }
     dim3 grid((T + 31) / 32, nsamp);
+    if (!bf16 && !a.gn_coef) { launch_fault("stchain: the fp32 kernels read the block input's GroupNorm coefficients (ChainArgs::gn_coef)"); return; }
     if (bf16) hipLaunchKernelGGL((stchain_kernel<true, 1>), grid, dim3(512), Carve<true>::LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
     else if (a.slices == 3 || a.slices == 2) {
-        if (!a.part || !a.ticket || !a.gn_coef) { launch_fault("stchain: a sliced launch needs the partial-sum buffer, the tickets and the block input's GroupNorm coefficients"); return; }
+        if (!a.part || !a.ticket) { launch_fault("stchain: a sliced launch needs the partial-sum buffer and the tickets"); return; }
         if (a.slices == 3) hipLaunchKernelGGL((stchain_kernel<false, 3>), dim3(grid.x, grid.y, 3), dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
         else hipLaunchKernelGGL((stchain_kernel<false, 2>), dim3(grid.x, grid.y, 2), dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
     } else hipLaunchKernelGGL((stchain_kernel<false, 1>), grid, dim3(512), CH_LDS, s, a.wstream, o, xin, a.lo, T, pitch, (int)o_bs, (int)x_bs, in_mod, n_uncond | (a.wmax << 24), a);
