@@ -65,9 +65,9 @@ struct AttnView {
 // (launch bounds: a workgroup of <= 256 threads may be alone on its SIMDs with 512 registers per wave, and for such kernels hipcc selects the MFMAs' ACCUMULATION-register
 //  form — every score tile then travels to the vector registers through 32 v_accvgpr_read, the output accumulators back and forth on every rescale: 96 of ~370 VALU
 //  instructions per key tile (ISA, round 6).  Asking for two waves per SIMD caps the budget at 256 registers, where the vector-register form is selected and the moves
-//  disappear; head_dim 32 shapes need 126-212 registers.)
+//  disappear; head_dim 32 shapes need 126-166 registers, head_dim 64 (the audio encoder) 136-240.)
 template <int ND, int KS, int PM, int QW = 1>
-__global__ __launch_bounds__(64 * KS * QW, (64 * KS * QW <= 256 && ND == 1) ? 2 : 1) void attn_kernel(const float* pqk, const float* pv, float* po, int v_bstride, int o_bstride, int ppitch,
+__global__ __launch_bounds__(64 * KS * QW, (64 * KS * QW <= 256) ? 2 : 1) void attn_kernel(const float* pqk, const float* pv, float* po, int v_bstride, int o_bstride, int ppitch,
                                                        int pT, int pheads, int prows, float pscale, int pb0, int po_mode) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef SAID_AB_FLOOR
