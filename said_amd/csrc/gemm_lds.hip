@@ -263,7 +263,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
 #pragma unroll
         for (int rr = 0; rr < 24; ++rr) wn[rr] = wload(u0.rw, 0, (tw * u0.C8 + rr) * WB);   // (SP: entry rr = 2 * step + plane of the same 24 KB per tile)
     } else {
-        issue_w(u0, wv, true);
+        if constexpr (!(HAS_LN && ONE_BLOCK && !MT)) issue_w(u0, wv, true);   // (LayerNorm'ed single-tile launches: behind the statistics barrier, see phase 2)
     }
     long long* const clkp = AH(clk);
     clk_stamp_p(clkp, w, l, 0);
@@ -529,6 +529,15 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             const f32x4 p0 = *reinterpret_cast<const f32x4*>(lst + 8 * sq), p1 = *reinterpret_cast<const f32x4*>(lst + 8 * sq + 4);
             mu4[0] = p0[0]; rs4[0] = p0[1]; mu4[1] = p0[2]; rs4[1] = p0[3];
             mu4[2] = p1[0]; rs4[2] = p1[1]; mu4[3] = p1[2]; rs4[3] = p1[3];
+        }
+        // Round 6: the weights of a LayerNorm'ed launch are requested HERE, behind the statistics barrier.  The request phase is a queue (a CU takes 13-23 clocks per
+        // vector-memory instruction: the second wave of every SIMD trails the first by the length of that queue), and this barrier comes early: with the 12 weight requests per
+        // wave out of its way the late waves reach it sooner; the weights still have the staging (2-3k clocks) to arrive.  Same loads: bit-identical; headline +0.5 %
+        // (the convolutions have no early barrier: there the order is neutral, profiles/r06g_kconv_ab.txt).
+        if constexpr (!NSPL && ONE_BLOCK && !MT) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_w(u0, wv, true);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     clk_stamp_p(clkp, w, l, 3);
