@@ -483,7 +483,6 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
                 vecv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rvec, (i < CHAIN_VEC_FLOATS_LDS / 4) ? gi * 16 : (int)0x80000000, 0, 0));
             }
         }
-        sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, SC, NR, decltype(qc)::value>(R, wp); });
         clk_stamp_c(clk, w, l, 12);
         if constexpr (BF) {   // both tiles as they are: bf16 rows of 384 bytes at the planes' 400-byte pitch
             *reinterpret_cast<f32x4*>(smem + CV::R1 + prow0 * (CH_AP * 2) + ppc0 * 16) = ov[0];
@@ -507,6 +506,12 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
             }
         }
         clk_stamp_c(clk, w, l, 14);
+        // the weight ring is primed HERE, behind the attention tile's staging, not at the end of the request phase: the requests of a CU are a queue (13-23 clocks each), and the
+        // ~100 ring loads of the six owners in front of the other waves' operand loads held up the first barrier; the first units still arrive by the time it falls (round 6:
+        // bit-identical, headline +0.3 %)
+        __builtin_amdgcn_sched_barrier(0);
+        sfor<0, NR>([&](auto qc) { ring_issue<MODE, BF, SC, NR, decltype(qc)::value>(R, wp); });
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (!BF) {   // x_in tile [192][32] fp32 (tokens past T: 0)
             float* xl = reinterpret_cast<float*>(smem + CH_R2);
 #pragma unroll
