@@ -679,7 +679,7 @@ bool do_gemm(said_ctx* c, const GemmArgs& a, int epi, int batch, int NB, int KS,
     // K-long up-path convolutions (two / three K segments): the split-fp16 shapes exist for one column tile per workgroup only (kconv_body; with two the second accumulator
     // set spills).  Where that takes at most 1.5 x the rounds of the chosen shape on the fp32 matrix instructions it wins (a round of NB = 1 split ~11 us, of NB = 2 fp32 ~21 us:
     // configs[4] 24.3k -> 25.5k frames/s, 3 clips +6 %; 76 tiles — 2 rounds against 1 — loses 2 %: profiles/r06g_kconv_ab.txt)
-    if (!bf && epi == EPI_STORE && NB > 1 && a2.nseg >= 2 && c->kconv != 0 && sp_on(c, c->ugemm_split) && c->use_ugemm && !a2.step_inc && !c->clk_on && !c->cur_concurrent) {   // (concurrent clip groups share the CUs: fewer workgroups win there — 5 clips -1.9 %)
+    if (!bf && epi == EPI_STORE && NB > 1 && a2.nseg >= 2 && c->kconv != 0 && sp_on(c, c->ugemm_split) && c->use_ugemm && !a2.step_inc && !c->clk_on && (!c->cur_concurrent || c->kconv == 2)) {   // (concurrent clip groups share the CUs: fewer workgroups win there — 5 clips -1.9 %; "kconv" = 2: there too)
         const long long tiles = (long long)batch * ((a2.T + 31) / 32), r1 = (tiles * 6 + 255) / 256, rn = (tiles * (6 / NB) + 255) / 256;
         if (tiles <= c->kconv_max_tiles && 2 * r1 <= 3 * rn && !ugemm_supports(a2, epi, NB, KS, 2) && ugemm_supports(a2, epi, 1, 8, 2)) { NB = 1; KS = 8; }
     }
@@ -2828,7 +2828,7 @@ int said_debug_option(said_ctx* ctx, const char* name, long long value) {
     } else if (k == "tgemm_direct") {
         ctx->tgemm_direct = value < 0 ? -1 : (value != 0);
     } else if (k == "kconv") {
-        ctx->kconv = value < 0 ? -1 : (value != 0);
+        ctx->kconv = value < 0 ? -1 : (value == 2 ? 2 : (value != 0));
     } else if (k == "kconv_max_tiles") {
         ctx->kconv_max_tiles = value;
     } else if (k == "st_chain") {

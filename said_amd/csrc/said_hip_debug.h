@@ -44,7 +44,8 @@ extern "C" {
  *   "chain_coef"             fp32 mode, small batch: 0 = stchain_kernel finalises the block input's GroupNorm coefficients from the partials itself; -1 / 1 (default): it reads the
  *                            coefficients the q/k/v GEMM of the same block finalised and left behind (GemmCommon::gn_coef_out, round 6)
  *   "kconv"                  fp32 mode, small batch: 0 = the K-long ResBlock convolutions of the up path (two / three K segments) keep ugemm_body's block loop; -1 / 1 (default):
- *                            kconv_body's straight-line blocks (round 6; bit-identical)
+ *                            kconv_body's straight-line blocks (round 6; bit-identical); 2: also under concurrent clip groups where the chosen column-tile count has no split shape
+ *                            (4 / 5 / 6 / 7 / 8 clips: -0.3 / -1.1 / +4.6 / -0.1 / +0.2 %: not the default)
  *   "attn_2q"                fp32 mode, pre-split K / V, four key slices: 0 = one query tile per wave always; 1 = three always; -1 (default) = three from 512 (sample, head, query tile)
  *                            triples per launch on (attn2q_kernel: long sequences at small batch; bit-identical)
  *   "attn_presplit"          fp32 small batch: 0 = attention splits K / V itself (default -1 / 1: the q/k/v GEMM stores them pre-split, attn_kernel<PM = 3>)
