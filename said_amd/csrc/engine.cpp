@@ -227,7 +227,8 @@ struct said_ctx {
     long long unet_tgemm_min_tokens = 3000, unet_fgemm_min_tokens = 10000;
     long long unet_fgemm_min_concurrent = 6000;   // fp32 threshold while other contexts' loops run beside this one (said_loop_params::concurrent)
     bool cur_concurrent = false;
-    int spg_limit = 10;      // denoise steps captured per graph
+    int spg_limit = 50;      // denoise steps captured per graph (round 6: 10 -> 50: at 0.245 ms per step the 100 graph boundaries of a 1000-step loop were 0.4-0.5 % of it — headline
+                             // 2424-2429 -> 2435-2438 frames/s; 100 / 250 / 500 add nothing: profiles/r06l_steps_per_graph.txt)
     int audio_chunk = 32;    // clips per audio-encoder pass
 
     // ---- audio workspace (lazily sized) ----
@@ -2639,7 +2640,7 @@ static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, boo
         // steps per graph: consecutive denoise steps captured back to back in ONE graph (the device-side step counter
         // makes the copies distinct): N / spg launches of the spg-step graph cover the loop, and a second graph holding
         // the N % spg remaining steps finishes it (prime N, e.g. 997 = 99 x 10 + 7)
-        int spg = std::min(ctx->spg_limit, N);   // measured: ~6 us per graph launch boundary; 10 steps per graph recover 1.2 % at B=1
+        int spg = std::min(ctx->spg_limit, N);   // measured: ~6 us per graph launch boundary; 10 steps per graph recovered 1.2 % at B=1 (round 1), 50 another 0.4-0.5 % (round 6)
         if (ctx->use_branches) spg = 1;
         const int rem = N % spg;
         const std::vector<long long> key = loop_graph_key(ctx, p, sa.step_noise);
