@@ -458,7 +458,7 @@ def run_secondary(model, dev, gs):
         def one(n_steps):
             return model.inference(proc, num_inference_steps=n_steps, guidance_scale=gs, eta=c["eta"], init_latents=lat0, **edit_kw).result
 
-        one(min(c["num_steps"], 50))   # warm-up: workspace growth, graph capture (50 steps per graph: a schedule of >= 50 steps with no remainder captures what the timed passes replay)
+        one(c["num_steps"] if c["num_steps"] >= 400 else min(c["num_steps"], 10))   # warm-up: workspace growth, graph capture (long loops: 50 steps per graph — the real length; short ones: 10)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(c["passes"]):

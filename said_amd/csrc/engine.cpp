@@ -227,7 +227,7 @@ struct said_ctx {
     long long unet_tgemm_min_tokens = 3000, unet_fgemm_min_tokens = 10000;
     long long unet_fgemm_min_concurrent = 6000;   // fp32 threshold while other contexts' loops run beside this one (said_loop_params::concurrent)
     bool cur_concurrent = false;
-    int spg_limit = 50;      // denoise steps captured per graph (round 6: 10 -> 50: at 0.245 ms per step the 100 graph boundaries of a 1000-step loop were 0.4-0.5 % of it — headline
+    int spg_limit = 50;      // denoise steps captured per graph in loops of >= 400 steps, at most 10 below (steps_per_graph; round 6: 10 -> 50: at 0.245 ms per step the 100 graph boundaries of a 1000-step loop were 0.4-0.5 % of it — headline
                              // 2424-2429 -> 2435-2438 frames/s; 100 / 250 / 500 add nothing: profiles/r06l_steps_per_graph.txt)
     int audio_chunk = 32;    // clips per audio-encoder pass
 
@@ -2526,13 +2526,20 @@ int said_unet_forward(said_ctx* ctx, const float* sample_dev, const int64_t* tim
 // SAID.inference loop
 // --------------------------------------------------------------------------------------------
 // What the captured step graph depends on (everything else it reads from device memory at replay time).
+// Denoise steps captured per graph.  A graph launch costs its host-side enqueue (~1 us per node) before the GPU sees its first kernel: behind a running graph that is hidden,
+// for the FIRST graph of a loop it is not — 1200-1400 nodes (50 steps) in front of a 50- or 100-step loop cost configs[2] / configs[4] 2-6 % where the long loops gain 0.4-0.5 %
+// from five times fewer graph boundaries (profiles/r06l_steps_per_graph.txt).  So: spg_limit (50) from 400 steps on, at most 10 below.
+static int steps_per_graph(const said_ctx* ctx, int N) {
+    if (ctx->use_branches) return 1;
+    const int lim = N >= 400 ? ctx->spg_limit : std::min(ctx->spg_limit, 10);
+    return std::max(1, std::min(lim, N));
+}
 static std::vector<long long> loop_graph_key(const said_ctx* ctx, const said_loop_params* p, const float* noise_cm) {
     const bool cfg = p->guidance_scale > 1.0f;
     float gs = p->guidance_scale, gr = (cfg && p->guidance_rescale > 0.f) ? p->guidance_rescale : 0.f, ls = p->latent_scale;
     int gsi, gri, lsi;
     memcpy(&gsi, &gs, 4); memcpy(&gri, &gr, 4); memcpy(&lsi, &ls, 4);
-    int spg = std::min(ctx->spg_limit, p->num_steps);
-    if (ctx->use_branches) spg = 1;
+    const int spg = p->num_steps > 0 ? steps_per_graph(ctx, p->num_steps) : 0;
     const int rem = spg > 0 ? p->num_steps % spg : 0;
     return {spg, rem, p->batch, p->frames, cfg, gsi, gri, lsi, p->prediction_type, p->use_mask, p->use_step_noise, ctx->bf16_mode ? 1 : (strict_f32(ctx) ? 2 : 0), p->noise_batch_offset, p->concurrent != 0,
             (long long)(uintptr_t)(p->save_intermediate ? p->intermediates_dev : nullptr), (long long)(uintptr_t)(p->use_step_noise == 1 ? noise_cm : nullptr)};
@@ -2640,8 +2647,7 @@ static int loop_impl(said_ctx* ctx, const said_loop_params* p, void* stream, boo
         // steps per graph: consecutive denoise steps captured back to back in ONE graph (the device-side step counter
         // makes the copies distinct): N / spg launches of the spg-step graph cover the loop, and a second graph holding
         // the N % spg remaining steps finishes it (prime N, e.g. 997 = 99 x 10 + 7)
-        int spg = std::min(ctx->spg_limit, N);   // measured: ~6 us per graph launch boundary; 10 steps per graph recovered 1.2 % at B=1 (round 1), 50 another 0.4-0.5 % (round 6)
-        if (ctx->use_branches) spg = 1;
+        const int spg = steps_per_graph(ctx, N);   // measured: ~6 us per graph launch boundary; 10 steps per graph recovered 1.2 % at B=1 (round 1), 50 another 0.4-0.5 % of a long loop (round 6)
         const int rem = N % spg;
         const std::vector<long long> key = loop_graph_key(ctx, p, sa.step_noise);
         if (!ctx->gexec || key != ctx->gkey) {

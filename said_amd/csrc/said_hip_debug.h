@@ -16,7 +16,7 @@ extern "C" {
  *   "unet_tgemm_min_tokens"  tokens per launch from which the UNet takes the token-major GEMM path, both precisions
  *                            (< 0: restore the measured defaults 3000 bf16 / 10000 fp32)
  *   "audio_chunk"            clips per audio-encoder pass (default 32)
- *   "steps_per_graph"        denoise steps captured per hipGraph (default 50; until round 6: 10)
+ *   "steps_per_graph"        denoise steps captured per hipGraph in loops of >= 400 steps (default 50; until round 6: 10); shorter loops: min(this, 10)
  *   "tm_acts"                bf16 mode, large batches: token-major bf16 activations between the UNet kernels, GroupNorm / LayerNorm applied inside the consuming
  *                            GEMMs (-1 / 1, default); 0: channel-major fp32 activations with preparation kernels (round 2).  (The fp32 twin of the schedule, measured
  *                            slower in round 3, was removed in round 6.)
