@@ -508,9 +508,9 @@ def test_loop_headline_length_10_step_segments_vs_oracle(model, sd_full, dev):
 
 
 def test_loop_997_steps_remainder_graph_teacher_forced(model, sd_full, dev):
-    """Prime step count: the 997-step schedule in 57-step segments = one 50-step graph + the 7-step remainder graph (round 6: 50 steps per graph)."""
+    """Prime step count: the 997-step schedule in 57-step segments = five 10-step graphs + the 7-step remainder graph (loops below 400 steps capture ten steps per graph)."""
     worst = _teacher_forced(model, sd_full, dev, N=997, eta=0.0, seg_lens=[57], Ta=8000, starts={57: [0, 300, 640, 940]}, chain=False)
-    print(f"N=997 teacher-forced 57-step segments (50 + 7): worst err {worst[57]:.3e}")
+    print(f"N=997 teacher-forced 57-step segments (5 x 10 + 7): worst err {worst[57]:.3e}")
     assert worst[57] <= 1e-3
 
 
@@ -537,17 +537,17 @@ def test_loop_editing_100_steps_in_betweening(model, sd_full, dev):
 
 @pytest.mark.parametrize("N", [11, 13, 23])
 def test_loop_step_counts_not_divisible_by_graph_length(model, sd_full, dev, N):
-    """With ten steps per graph (the default until round 6; now 50: said_debug_option "steps_per_graph") N = 11, 13, 23 run N // 10 ten-step graphs + one remainder graph
-    (free-running, whole loop); 23 also at the default (one remainder graph of 23 steps)."""
+    """Ten steps per graph (loops below 400 steps): N = 11, 13, 23 run N // 10 ten-step graphs + one remainder graph (free-running, whole loop); 23 also with seven steps
+    per graph (said_debug_option "steps_per_graph": 3 x 7 + 2): the segmentation must not change the result."""
     eng = model._get_engine(2, 64)
-    eng.debug_option("steps_per_graph", 10)
-    try:
-        got, ref = _loop_case(model, sd_full, dev, B=1, Ta=8000, N=N, gs=2.0, tol=1e-3)
-        print(f"N={N}: max abs err {float((got - ref).abs().max()):.3e}, nodes/step {model._eng.graph_num_nodes()}")
-    finally:
-        eng.debug_option("steps_per_graph", 50)
+    got, ref = _loop_case(model, sd_full, dev, B=1, Ta=8000, N=N, gs=2.0, tol=1e-3)
+    print(f"N={N}: max abs err {float((got - ref).abs().max()):.3e}, nodes/step {model._eng.graph_num_nodes()}")
     if N == 23:
-        got2, _ = _loop_case(model, sd_full, dev, B=1, Ta=8000, N=N, gs=2.0, tol=1e-3)
+        eng.debug_option("steps_per_graph", 7)
+        try:
+            got2, _ = _loop_case(model, sd_full, dev, B=1, Ta=8000, N=N, gs=2.0, tol=1e-3)
+        finally:
+            eng.debug_option("steps_per_graph", 50)
         assert torch.equal(got, got2), "the graph segmentation must not change the result"
 
 

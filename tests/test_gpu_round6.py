@@ -508,3 +508,24 @@ def test_direct_to_lds_gemm_tile_is_bit_identical_to_the_staged_tiles(dev, B, Ta
         m.set_mfma_dtype("fp32")
     print(f"B={B} Ta={Ta}: direct-to-LDS tile vs staged tiles max |diff| {float((y1 - y0).abs().max()):.3e} (|y| max {float(y0.abs().max()):.2f})")
     assert torch.isfinite(y1).all() and torch.equal(y1, y0)
+
+
+# ---------------------------------------------------------------- fifty steps per graph in long loops
+def test_long_loop_graph_segmentation_does_not_change_the_result(dev):
+    """Loops of >= 400 steps capture FIFTY steps per hipGraph (shorter ones ten: the first graph's host-side enqueue is exposed there): a 457-step guided loop as
+    9 x 50 + 7, as 45 x 10 + 7 (said_debug_option "steps_per_graph" = 10) and as 3 x 128 + 73 gives bit-identical results, with eta noise from the step counter."""
+    m = _make(_base_sd(), dev)
+    lat = synth.synth_latents(7, (1, 60, 32)).to(dev)
+    emb = synth.synth_latents(8, (1, 60, 768)).to(dev)
+    wav = torch.zeros(1, 16000, device=dev)
+    res = {}
+    eng = m._get_engine(2, 64)
+    for spg in (50, 10, 128):
+        eng.debug_option("steps_per_graph", spg)
+        try:
+            torch.manual_seed(5)
+            res[spg] = m.inference(wav, num_inference_steps=457, guidance_scale=2.0, eta=0.5, init_latents=lat, audio_embedding=emb).result.cpu()
+        finally:
+            eng.debug_option("steps_per_graph", 50)
+    assert torch.isfinite(res[50]).all()
+    assert torch.equal(res[50], res[10]) and torch.equal(res[50], res[128])
