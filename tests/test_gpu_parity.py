@@ -507,6 +507,16 @@ def test_loop_headline_length_10_step_segments_vs_oracle(model, sd_full, dev):
     assert worst[10] <= 1e-3
 
 
+def test_loop_headline_length_single_steps_along_the_schedule_vs_oracle(model, sd_full, dev):
+    """The headline's own shape again (at T = 600 only three ten-step segments stood in for the chain): 41 SINGLE steps spread
+    over the whole 1000-step schedule (every 25th step and the last one: timestep-embedding rows, coefficient rows and noise levels from t = 999 down
+    to t = 0), each from latents at its own noise level against the oracle's one step from the same latents — the kernels, tile counts and the
+    three-slice fused tail of the benchmarked launch at every part of the schedule (the 1 s chain above walks all 1000 steps on 60 frames)."""
+    worst = _teacher_forced(model, sd_full, dev, N=1000, eta=0.0, seg_lens=[1], Ta=160000, starts={1: list(range(0, 1000, 25)) + [999]}, chain=False)
+    print(f"N=1000, T=600 teacher-forced single steps at 41 places: worst err {worst[1]:.3e}")
+    assert worst[1] <= 2e-4
+
+
 def test_loop_997_steps_remainder_graph_teacher_forced(model, sd_full, dev):
     """Prime step count: the 997-step schedule in 57-step segments = five 10-step graphs + the 7-step remainder graph (loops below 400 steps capture ten steps per graph)."""
     worst = _teacher_forced(model, sd_full, dev, N=997, eta=0.0, seg_lens=[57], Ta=8000, starts={57: [0, 300, 640, 940]}, chain=False)
