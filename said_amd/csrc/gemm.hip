@@ -506,7 +506,7 @@ __device__ __forceinline__ void cgemm_body(const GemmArgs& a, float* smem) {
             const int ngate = nl + a.geglu_gate_tiles * 32;
             const float xv = val + (a.bias ? a.bias[nl] : 0.f);
             const float gv = gate + (a.bias ? a.bias[ngate] : 0.f);
-            if (ok) a.y[(long long)b * a.y_bstride + (long long)nl * a.y_pitch + t] = xv * gelu_f(gv);
+            if (ok) a.y[(long long)b * a.y_bstride + (long long)nl * a.y_pitch + t] = geglu_f(xv, gv);
             continue;
         }
 

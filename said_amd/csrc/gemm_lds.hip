@@ -890,7 +890,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
                 const int nl = (tile0 + w) * 32 + frow;
                 const float xv_ = acc[0][r] + epiS[w * 32 + frow];
                 const float gv = gx[(w * 16 + r) * 64 + l] + epiS[(NB + w) * 32 + frow];
-                if (nl < aN && t < aT) gstore(yo, (long long)nl * yp_ + t, xv_ * gelu_f(gv));
+                if (nl < aN && t < aT) gstore(yo, (long long)nl * yp_ + t, geglu_f(xv_, gv));
             }
         }
         clk_stamp_p(clkp, w, l, 9);
@@ -972,7 +972,7 @@ __device__ __forceinline__ void ugemm_body(const FastHdr& hd, float* smem, int b
             (void)ngate;
             const float xv_ = val + epiS[i * 32 + frow];
             const float gv = gate + epiS[(NB + i) * 32 + frow];
-            if (ok) gstore(yp, (long long)b * y_bs + (long long)nl * y_pitch + t, xv_ * gelu_f(gv));
+            if (ok) gstore(yp, (long long)b * y_bs + (long long)nl * y_pitch + t, geglu_f(xv_, gv));
             continue;
         }
         if (EPI == EPI_BAND) {

@@ -68,30 +68,7 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 __device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
-// value * gelu(gate) for two elements at a time on packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two floats per lane
-// and issue slot).  The GEGLU launch is bound by VALU ISSUE in its MFMA waves' epilogue — 16 products per lane and tile, 19 VALU instructions
-// + 2 transcendentals each in the scalar form against 24 MFMAs — so the erf (gemm_common.h: Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7)
-// is evaluated pairwise and without the copysign / 1 + erf round trip:  gelu(g) = g * (x < 0 ? q : 1 - q),  q = (p(t) / 2) t exp(-x^2),
-// x = g / sqrt(2), t = 1 / (1 + 0.3275911 |x|)  (for x < 0 the scalar form computes 1 - (1 - 2q): this one keeps q's own bits).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 geglu2(f32x2 val, f32x2 gate) {
-    const f32x2 x = gate * 0.70710678118654752440f;
-    const f32x2 ax = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
-    const f32x2 one = {1.0f, 1.0f};
-    const f32x2 d = __builtin_elementwise_fma(ax, (f32x2){0.3275911f, 0.3275911f}, one);
-    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    f32x2 p = __builtin_elementwise_fma(t, (f32x2){0.5f * 1.061405429f, 0.5f * 1.061405429f}, (f32x2){0.5f * -1.453152027f, 0.5f * -1.453152027f});
-    p = __builtin_elementwise_fma(p, t, (f32x2){0.5f * 1.421413741f, 0.5f * 1.421413741f});
-    p = __builtin_elementwise_fma(p, t, (f32x2){0.5f * -0.284496736f, 0.5f * -0.284496736f});
-    p = __builtin_elementwise_fma(p, t, (f32x2){0.5f * 0.254829592f, 0.5f * 0.254829592f});
-    const f32x2 ea = (ax * ax) * -1.4426950408889634f;
-    const f32x2 e = {__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
-    const f32x2 q = (p * t) * e;
-    const f32x2 omq = one - q;
-    const f32x2 sel = {x[0] < 0.f ? q[0] : omq[0], x[1] < 0.f ? q[1] : omq[1]};
-    return (val * gate) * sel;
-}
-
+// (geglu2 — value * gelu(gate) for two elements at a time on packed fp32 instructions — lives in gemm_common.h since round 6: stchain.hip's A/B of the same form uses it)
 // EK: 0 token-major activation out, 1 q/k/v split (direct stores), 4 banded cross-attention (transposed product)
 // MODE: operand transform (0 raw, 1 silu(GroupNorm), 2 LayerNorm, 3 LayerNorm(GroupNorm)); RES: 0 none, 1 plain, 2 GroupNorm'ed residual;
 // DUP: second copy of the result (+ per-channel constant); STATS: GroupNorm partials of the stored values

@@ -24,6 +24,9 @@
 #include "gemm_common.h"
 #include "split_f16.h"
 #include "stchain.h"
+#ifndef SAID_GEGLU_BIAS_INIT
+#define SAID_GEGLU_BIAS_INIT 1
+#endif
 
 namespace said {
 
@@ -702,10 +705,16 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         const int gp0 = (24 / NSL) * slice;   // sliced: this workgroup's pairs are the hidden tiles gp0 .. gp0 + 24 / NS - 1; its product plane holds them from column 0
         auto lpair = [&](int pi) { return w + U::LSTEP * pi + U::L0; };   // local pair (= column tile of the product plane) of this wave's pair pi
         auto epi_piece = [&](int p, int m) {   // channels 32 p + 4 lh + 8 m .. + 3 of the token: bias, gelu, product, split, 8 bytes per plane
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bff + 32 * (gp0 + p) + 4 * lh + 8 * m), bg = *reinterpret_cast<const f32x4*>(bff + 768 + 32 * (gp0 + p) + 4 * lh + 8 * m);
             float hv[4];
+#if SAID_GEGLU_BIAS_INIT   // (the pair's accumulators started from the bias: below)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hv[i] = (pv[4 * m + i] + bv[i]) * gelu_f(pg[4 * m + i] + bg[i]);
+            for (int i = 0; i < 4; ++i) hv[i] = geglu_f(pv[4 * m + i], pg[4 * m + i]);
+#else
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bff + 32 * (gp0 + p) + 4 * lh + 8 * m), bg = *reinterpret_cast<const f32x4*>(bff + 768 + 32 * (gp0 + p) + 4 * lh + 8 * m);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hv[i] = geglu_f(pv[4 * m + i] + bv[i], pg[4 * m + i] + bg[i]);
+#endif
+            (void)p;
             char* pp = hh + wrowH + (32 * p + 4 * lh + 8 * m) * 2;
             if constexpr (BF) {
                 bf16x4c h;
@@ -722,7 +731,19 @@ __device__ __forceinline__ void chain_body(const ChainHdr& hd, const ChainArgs& 
         sfor<0, U::NPAIR>([&](auto pc) {
             constexpr int pi = decltype(pc)::value;
             f32x16 av, avx, ag, agx;
-            zero16(av); zero16(avx); zero16(ag); zero16(agx);
+            zero16(avx); zero16(agx);
+#if SAID_GEGLU_BIAS_INIT
+            // the value and gate sums start from ff.net.0's bias (a lane's 16 channels of the pair's tiles: four 16-byte LDS reads each) instead of from zero: two additions per
+            // element leave the epilogue, which is what the fused tails' waves are short of (vector-instruction issue: profiles/r06m_sq_lds_l2_counters.txt)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bff + 32 * (gp0 + lpair(pi)) + 4 * lh + 8 * m), bg = *reinterpret_cast<const f32x4*>(bff + 768 + 32 * (gp0 + lpair(pi)) + 4 * lh + 8 * m);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { av[4 * m + i] = bv[i]; ag[4 * m + i] = bg[i]; }
+            }
+#else
+            zero16(av); zero16(ag);
+#endif
             geglu_run<MODE, BF, SC, NR, QG + 24 * pi>(R, wp, r1h + browA, CH_APL, av, avx, ag, agx, [&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 if constexpr (!BF && pi > 0 && s % 3 == 1) epi_piece(lpair(pi - 1), s / 3);

@@ -79,7 +79,7 @@ __device__ __forceinline__ void tg_epilogue(const TGemmArgs& a, f32x16 (&acc)[NJ
                 }
             }
             if (geglu) {
-                if constexpr (NJE % 2 == 0 && J0 % 2 == 0) v *= gelu_f(acc[J0 + (j + 1) % NJE][r] + gadd);
+                if constexpr (NJE % 2 == 0 && J0 % 2 == 0) v = geglu_f(v, acc[J0 + (j + 1) % NJE][r] + gadd);
             } else if (a.act == 1) {
                 v = gelu_f(v);
             }
