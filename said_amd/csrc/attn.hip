@@ -499,6 +499,8 @@ __global__ __launch_bounds__(64 * QT, (QT == 10 ? 5 : (QT == 8 ? 4 : 2))) void b
     // ---- the head's K and V^T -> LDS (rows past T: the last row again / the zeros the projection wrote)
     {
         const int npc = nkr >> 3;           // 16-byte pieces per V^T row
+        const float rnpc = __builtin_amdgcn_rcpf((float)npc);   // idx / npc through one float multiply (exact here: idx < 2^12, npc <= 80, the + 0.5 keeps the quotient clear of
+                                                                // rounding at multiples of npc; an integer division is ~25 dependent vector instructions, four of them per lane and pass)
         for (int i = tid; i < nkr * 4; i += NTH * 4) {
             u32x4b kv[4], vv[4];
             int ki[4], vi[4];
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(64 * QT, (QT == 10 ? 5 : (QT == 8 ? 4 : 2))) void b
                 const int row = idx >> 2, pc = idx & 3;
                 kv[u] = *reinterpret_cast<const u32x4b*>(kg + (long long)min(row, rows - 1) * 32 + 8 * pc);
                 ki[u] = row * 4 + (pc ^ ((row >> 2) & 3));
-                const int d = idx / npc, p = idx - d * npc;        // (32 npc == 4 nkr: the same index range)
+                const int d = (int)(((float)idx + 0.5f) * rnpc), p = idx - d * npc;        // (32 npc == 4 nkr: the same index range)
                 vv[u] = *reinterpret_cast<const u32x4b*>(vg + (long long)d * pitch + 8 * p);
                 vi[u] = d * 81 + p;
             }
