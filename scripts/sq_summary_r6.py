@@ -21,14 +21,19 @@ def load(f):
     return rows
 
 
-out = [f"# round 6 (final sources, bench.source_hash {bench.source_hash()}): SQ / LDS / L2 counters of the step kernels, separate rocprofv3 --pmc passes with --kernel-trace only",
+out = ["# round 6: SQ / LDS / L2 counters of the step kernels, separate rocprofv3 --pmc passes with --kernel-trace only.  Headline and configs[2] tables: sources 8a16a028011a5d12 (BEFORE the",
+       f"# GEGLU / battn / tgemm256d changes these counters led to: r06n); configs[3] and configs[4] tables: the final sources ({bench.source_hash()}).",
        "# (scripts/gpu_r6_sq.sh: python bench.py --steps 1 --warmup 0 --no_cpu_baseline --no_roofline --no_secondary + the configuration's flags).  Per-launch averages, summed over the chip.",
        "# Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles, GRBM_GUI_ACTIVE summed over the 8 XCDs;",
        "# kernels run serialised and stretched under counter collection, so shares are quoted, not times.  mfma% = MFMA_BUSY / (1024 SIMDs x GUI_ACTIVE / 8);",
        "# wait / istall / active = shares of SQ_WAVE_CYCLES (parked on s_waitcnt or a barrier / issue stall / issuing); valu/mfma = SQ_INSTS_VALU / SQ_INSTS_MFMA;",
        "# ldsconf% = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; L2hit% = TCC_HIT / (TCC_HIT + TCC_MISS); L2req MB = TCC_REQ x 128 B."]
 for cfg, title in (("cfg1", "headline: 1 clip x 600 frames, guidance (UNet batch 2), fp32 mode on split-fp16 products"),
-                   ("cfg2_bf16", "configs[2]: 32 clips x 600 frames, guidance (UNet batch 64), bf16 mode")):
+                   ("cfg2_bf16", "configs[2]: 32 clips x 600 frames, guidance (UNet batch 64), bf16 mode"),
+                   ("cfg3_f32", "configs[3] per GPU: 32 clips x 600 frames, guidance, fp32 mode (three clip groups) — scripts/gpu_r6_sq34.sh"),
+                   ("cfg4_edit", "configs[4]: 1 clip x 1800 frames, editing, fp32 mode — scripts/gpu_r6_sq34.sh")):
+    if not os.path.exists(os.path.join(base, cfg + "_A.txt")):
+        continue
     A, B, C = load(cfg + "_A.txt"), load(cfg + "_B.txt"), load(cfg + "_C.txt")
     out += ["", "== " + title,
             f"{'launches':>8} {'mfma%':>6} {'wait%':>6} {'istall%':>7} {'active%':>7} {'valu/mfma':>9} {'ldsconf%':>8} {'L2hit%':>6} {'L2req MB':>9}  kernel"]
@@ -48,5 +53,8 @@ out += ["",
         "cycles: latency chains, as the shader-clock stamps say (r06_phase_clocks_b1.txt).  The bf16 fused tail (configs[2]'s top kernel) issues 16 vector instructions per MFMA with four waves per",
         "SIMD: its vector pipe is asked for about twice the cycles of its matrix pipe (GEGLU's erf, LayerNorm, bf16 packing, the band's softmax); its 1.6 GB of L2 requests per launch hit 94 %.",
         "LDS bank conflicts are 23-54 % of the LDS-active cycles of the channel-major GEMMs (the 2-byte split-plane staging stores); round 5 measured a conflict-free 8-byte staging variant",
-        "as no faster (the staging phase waits for the X tile: profiles/r05c_*), so they are recorded here, not claimed as the bound."]
+        "as no faster (the staging phase waits for the X tile: profiles/r05c_*), so they are recorded here, not claimed as the bound.",
+        "tgemm256d_kernel's 46 % WAS a defect (a swizzle term that assumed contiguous ds_read_b128 lane groups): fixed after this pass, r06n (6): 4 %.",
+        "configs[3]: prep_kernel's LDS is active 5 % of its launch (its 53 % conflict share is of almost nothing) and it issues ~850 vector instructions per wave: it waits (57 % parked) —",
+        "a dependent chain per workgroup with 1.7 waves per SIMD under three clip groups; fgemm_kernel: MFMA busy 11 % of the fp16 pipe, 13 vector instructions per MFMA, L2 hit 83 %."]
 print("\n".join(out))
